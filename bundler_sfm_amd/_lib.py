@@ -1,0 +1,122 @@
+"""ctypes binding of libbsfm_hip.so (the C-ABI declared in include/bsfm.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C bundler_sfm_amd/csrc`.
+There is no Python or CPU fallback: if the shared object is missing, importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbsfm_hip.so")
+
+INFOSZ = 10
+JAC_FD, JAC_ANALYTIC = 0, 1
+
+
+class CameraParams(C.Structure):
+    """Layout-identical to camera_params_t (reference lib/sfm-driver/sfm.h:32-51)."""
+    _fields_ = [
+        ("R", C.c_double * 9), ("t", C.c_double * 3), ("f", C.c_double), ("k", C.c_double * 2),
+        ("k_inv", C.c_double * 6), ("constrained", C.c_char * 9), ("constraints", C.c_double * 9),
+        ("weights", C.c_double * 9), ("K_known", C.c_double * 9), ("k_known", C.c_double * 5),
+        ("fisheye", C.c_char), ("known_intrinsics", C.c_char),
+        ("f_cx", C.c_double), ("f_cy", C.c_double), ("f_rad", C.c_double), ("f_angle", C.c_double),
+        ("f_focal", C.c_double), ("f_scale", C.c_double), ("k_scale", C.c_double),
+    ]
+
+
+class Options(C.Structure):
+    _fields_ = [("jacobian", C.c_int), ("itmax", C.c_int), ("verbose", C.c_int),
+                ("opts", C.c_double * 6), ("potrf_backend", C.c_int)]
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [
+        ("n", C.c_int), ("m", C.c_int), ("mcon", C.c_int),
+        ("rowptr", C.POINTER(C.c_int)), ("colidx", C.POINTER(C.c_int)), ("projections", C.POINTER(C.c_double)),
+        ("est_focal_length", C.c_int), ("undistort", C.c_int), ("explicit_camera_centers", C.c_int),
+        ("cameras", C.POINTER(CameraParams)), ("points", C.POINTER(C.c_double)),
+        ("use_constraints", C.c_int), ("use_point_constraints", C.c_int),
+        ("point_constraints", C.POINTER(C.c_double)), ("point_constraint_weight", C.c_double),
+        ("world_size", C.c_int), ("rank", C.c_int), ("nvis_global", C.c_longlong), ("nvars_global", C.c_longlong),
+    ]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+
+# every symbol include/bsfm.h declares (tests/test_abi.py checks the header against this list)
+SYMBOLS = [
+    "bsfm_default_options", "run_sfm", "bsfm_run_sfm_ex", "bsfm_problem_create", "bsfm_problem_destroy",
+    "bsfm_problem_set_allreduce", "bsfm_problem_set_stream", "bsfm_problem_reset_params", "bsfm_lm_begin",
+    "bsfm_lm_iterate", "bsfm_lm_finish", "bsfm_lm_solve_attempts", "bsfm_lm_last_kernel_ms",
+    "bsfm_problem_download", "bsfm_problem_cnp", "bsfm_problem_nvis", "bsfm_eval_residuals",
+    "bsfm_eval_normal_equations", "bsfm_dense_chol_solve", "bsfm_match_keys_l2", "bsfm_key_match_full",
+    "bsfm_device_count", "bsfm_version", "bsfm_synth_ba", "bsfm_synth_keys",
+]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). bundler_sfm_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+    cp = C.POINTER(CameraParams)
+    lib.bsfm_default_options.argtypes = [C.POINTER(Options)]
+    lib.bsfm_default_options.restype = None
+    run_args = [C.c_int, C.c_int, C.c_int, C.c_char_p, dp, C.c_int, C.c_int, C.c_int, C.c_int, cp, dp,
+                C.c_int, C.c_int, dp, C.c_double, C.c_int, C.c_int, C.c_double, dp, dp, dp, dp]
+    lib.run_sfm.argtypes = run_args
+    lib.run_sfm.restype = None
+    lib.bsfm_run_sfm_ex.argtypes = run_args + [C.POINTER(Options), dp]
+    lib.bsfm_run_sfm_ex.restype = C.c_int
+    lib.bsfm_problem_create.argtypes = [C.POINTER(ProblemDesc), C.POINTER(Options)]
+    lib.bsfm_problem_create.restype = vp
+    lib.bsfm_problem_destroy.argtypes = [vp]
+    lib.bsfm_problem_destroy.restype = None
+    lib.bsfm_problem_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
+    lib.bsfm_problem_set_allreduce.restype = None
+    lib.bsfm_problem_set_stream.argtypes = [vp, vp]
+    lib.bsfm_problem_set_stream.restype = None
+    lib.bsfm_problem_reset_params.argtypes = [vp, cp, dp]
+    lib.bsfm_problem_reset_params.restype = C.c_int
+    lib.bsfm_lm_begin.argtypes = [vp]
+    lib.bsfm_lm_begin.restype = C.c_int
+    lib.bsfm_lm_iterate.argtypes = [vp, C.c_int]
+    lib.bsfm_lm_iterate.restype = C.c_int
+    lib.bsfm_lm_finish.argtypes = [vp, dp]
+    lib.bsfm_lm_finish.restype = C.c_int
+    lib.bsfm_lm_solve_attempts.argtypes = [vp]
+    lib.bsfm_lm_solve_attempts.restype = C.c_int
+    lib.bsfm_lm_last_kernel_ms.argtypes = [vp, C.c_char_p]
+    lib.bsfm_lm_last_kernel_ms.restype = C.c_double
+    lib.bsfm_problem_download.argtypes = [vp, dp, cp, dp]
+    lib.bsfm_problem_download.restype = C.c_int
+    lib.bsfm_problem_cnp.argtypes = [vp]
+    lib.bsfm_problem_cnp.restype = C.c_int
+    lib.bsfm_problem_nvis.argtypes = [vp]
+    lib.bsfm_problem_nvis.restype = C.c_longlong
+    lib.bsfm_eval_residuals.argtypes = [vp, dp, dp]
+    lib.bsfm_eval_residuals.restype = C.c_int
+    lib.bsfm_eval_normal_equations.argtypes = [vp, C.c_double, dp, dp, dp, dp, dp, dp, dp]
+    lib.bsfm_eval_normal_equations.restype = C.c_int
+    lib.bsfm_dense_chol_solve.argtypes = [C.c_int, dp, dp, dp, C.c_int]
+    lib.bsfm_dense_chol_solve.restype = C.c_int
+    ucp = C.POINTER(C.c_ubyte)
+    lib.bsfm_match_keys_l2.argtypes = [C.c_int, ucp, C.c_int, ucp, C.c_double, ip, C.c_int]
+    lib.bsfm_match_keys_l2.restype = C.c_int
+    lib.bsfm_key_match_full.argtypes = [C.c_int, ip, C.POINTER(ucp), C.c_double, C.c_int, C.c_char_p]
+    lib.bsfm_key_match_full.restype = C.c_int
+    lib.bsfm_device_count.argtypes = []
+    lib.bsfm_device_count.restype = C.c_int
+    lib.bsfm_version.argtypes = []
+    lib.bsfm_version.restype = C.c_char_p
+    lib.bsfm_synth_ba.argtypes = [C.c_int, C.c_int, C.c_int, C.c_ulonglong, C.c_int, ip, ip, dp, cp, dp]
+    lib.bsfm_synth_ba.restype = C.c_int
+    lib.bsfm_synth_keys.argtypes = [C.c_int, C.c_ulonglong, ucp, C.c_int, ucp]
+    lib.bsfm_synth_keys.restype = C.c_int
+    return lib
+
+
+lib = _load()

@@ -1,0 +1,614 @@
+// kernels.hip.h -- HIP kernels of the LM normal-equations path (gfx950 / CDNA4, wave64, FP64).
+//
+// Reference behaviour restated (paths relative to the reference tree):
+//   residuals / cost          sba_motstr_Qs + nrmL2xmy      lib/sba-1.5/sba_levmar_wrap.c:73-104, sba_levmar.c:159-207
+//   Jacobian                  sba_motstr_Qs_fdjac / projac  lib/sba-1.5/sba_levmar_wrap.c:163-259
+//   U_j, ea_j                 lib/sba-1.5/sba_levmar.c:919-964
+//   V_i, eb_i                 lib/sba-1.5/sba_levmar.c:987-1030
+//   (V_i + mu I)^-1           lib/sba-1.5/sba_levmar.c:1138-1162 (sba_symat_invert_BK)
+//   S_jk, e_j (Schur)         lib/sba-1.5/sba_levmar.c:1182-1339
+//   db_i (back-substitution)  lib/sba-1.5/sba_levmar.c:1393-1433
+//   step norms, dL            lib/sba-1.5/sba_levmar.c:1444-1527
+//   Snavely stop rule         lib/sba-1.5/sba_levmar.c:1552-1561
+//
+// Data layout in HBM (all FP64 / int32, observation order == the reference's CRS order, i.e. point-major,
+// camera ascending within a point -- sba_levmar.c:653-663):
+//   x[2*nvis]       measurements            obs_cam[nvis], obs_pt[nvis], rowptr[n+1]   point-major index
+//   camptr[m+1], camobs[nvis]               camera-major secondary index (replaces sba_crsm_col_elmidxs'
+//                                           per-call binary searches, sba_crsm.c:183-212)
+//   camtab[m*72]    per-camera derived row  (model.hip.h)
+//   J[nvis*(2cnp+6)] A_ij (2 x cnp) then B_ij (2 x 3), one contiguous record per observation
+//   U[m*cnp*cnp], ea[m*cnp], V[n*6] (packed upper), Vinv[n*6], eb[n*3], S[ld*ld], E[ld]
+// W_ij = A_ij^T B_ij is never materialised (1.08 GB at 5 M observations): every consumer uses the factored
+// form, e.g. Y_ij W_ik^T = A_ij^T (B_ij V*^-1 B_ik^T) A_ik with a 2x2 core, and W_ij^T da = B_ij^T (A_ij da).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include "model.hip.h"
+
+namespace bsfm {
+
+struct SchurTask { int start; int count; };
+
+struct DevProblem {
+    ModelCfg cfg;
+    int n, m, mcon, nvis;
+    int js;                       // J record stride = 2*cnp + 6
+    const double* x;
+    const int* obs_cam; const int* obs_pt; const int* rowptr;
+    const int* camptr; const int* camobs;
+    const double* Rinit; const double* finit;
+    // constraints
+    const unsigned char* ccon; const double* cval; const double* cw;   // m*cnp (may be null)
+    const unsigned char* pcon; const double* pval; double pweight;     // n, 3n (may be null)
+    double nvis_global;
+    // work arrays
+    double* J; double* U; double* ea; double* V; double* Vinv; double* eb;
+};
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_down(v, o, 64); v = (t > v) ? t : v; }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-camera derived table: one thread per camera (m <= a few thousand; trig happens only here)
+__global__ void k_cam_table(ModelCfg cfg, int m, const double* __restrict__ pa, const double* __restrict__ Rinit,
+                            const double* __restrict__ finit, int with_fd, double* __restrict__ camtab)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const double* a = pa + (size_t)j * cfg.cnp;
+    const double* R0 = Rinit + (size_t)j * 9;
+    double* ct = camtab + (size_t)j * CT_STRIDE;
+    double R[9], Q[9], Ri[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Ri[k] = R0[k];
+    rot_update(Ri, a[3], a[4], a[5], R);
+    rot_deriv_factor(Ri, R, a[3], a[4], a[5], Q);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { ct[CT_R + k] = R[k]; ct[CT_Q + k] = Q[k]; }
+    for (int k = 0; k < 9; ++k) ct[CT_A + k] = (k < cfg.cnp) ? a[k] : 0.0;
+    int col = 6;
+    double f = finit[j];
+    if (cfg.est_focal) { f = a[6] / cfg.f_scale; col = 7; }
+    ct[CT_F] = f;
+    ct[CT_K1] = cfg.undistort ? a[col] / cfg.k_scale : 0.0;
+    ct[CT_K2] = cfg.undistort ? a[col + 1] / cfg.k_scale : 0.0;
+    ct[30] = finit[j]; ct[31] = 0.0;
+    if (with_fd) {
+        for (int k = 0; k < 9; ++k) {
+            double d = 0.0;
+            if (k < cfg.cnp) { d = 1E-04 * a[k]; d = fabs(d); if (d < 1E-06) d = 1E-06; }
+            ct[CT_D + k] = d;
+        }
+        for (int k = 0; k < 3; ++k) {
+            const double d = ct[CT_D + 3 + k];
+            double Rp[9];
+            rot_update(Ri, k == 0 ? a[3] + d : a[3], k == 1 ? a[4] + d : a[4], k == 2 ? a[5] + d : a[5], Rp);
+            for (int q = 0; q < 9; ++q) ct[CT_RP + 9 * k + q] = Rp[q];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// residuals e = x - proj(p): one thread per observation, coalesced reads of x / obs_cam / obs_pt,
+// L2-resident gathers of the camera row and the point.  Block partial of sum e^2; with e_prev != null
+// also the block partial of the Snavely pct-change maximum.
+constexpr int RES_BLOCK = 256;
+__global__ __launch_bounds__(RES_BLOCK) void k_residual(ModelCfg cfg, int nvis,
+        const double* __restrict__ x, const int* __restrict__ obs_cam, const int* __restrict__ obs_pt,
+        const double* __restrict__ camtab, const double* __restrict__ pb,
+        double* __restrict__ e_out, const double* __restrict__ e_prev, double eps5,
+        double* __restrict__ part_cost, double* __restrict__ part_pct)
+{
+    __shared__ double sm[2 * (RES_BLOCK / 64)];
+    const int k = blockIdx.x * RES_BLOCK + threadIdx.x;
+    double c = 0.0, pct = 0.0;
+    if (k < nvis) {
+        const double* ct = camtab + (size_t)obs_cam[k] * CT_STRIDE;
+        const double* b = pb + (size_t)obs_pt[k] * 3;
+        double h0, h1;
+        project_row(cfg, ct, b[0], b[1], b[2], h0, h1);
+        const double2 xx = reinterpret_cast<const double2*>(x)[k];
+        const double e0 = xx.x - h0, e1 = xx.y - h1;
+        reinterpret_cast<double2*>(e_out)[k] = make_double2(e0, e1);
+        c = e0 * e0 + e1 * e1;
+        if (e_prev) {
+            const double2 eo = reinterpret_cast<const double2*>(e_prev)[k];
+            // sba_levmar.c:1552-1561: skipped when both are (signed) below eps5
+            if (!(eo.x < eps5 && e0 < eps5)) { const double q = fabs((eo.x - e0) / eo.x); if (q > pct) pct = q; }
+            if (!(eo.y < eps5 && e1 < eps5)) { const double q = fabs((eo.y - e1) / eo.y); if (q > pct) pct = q; }
+        }
+    }
+    c = wave_sum(c); pct = wave_max(pct);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sm[w] = c; sm[RES_BLOCK / 64 + w] = pct; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0, q = 0.0;
+        for (int i = 0; i < RES_BLOCK / 64; ++i) { s += sm[i]; q = sm[RES_BLOCK / 64 + i] > q ? sm[RES_BLOCK / 64 + i] : q; }
+        part_cost[blockIdx.x] = s;
+        if (part_pct) part_pct[blockIdx.x] = q;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Jacobian records: one thread per observation.
+template <int CNP, bool FD>
+__global__ __launch_bounds__(256) void k_jacobian(ModelCfg cfg, int nvis,
+        const int* __restrict__ obs_cam, const int* __restrict__ obs_pt,
+        const double* __restrict__ camtab, const double* __restrict__ pb, double* __restrict__ J)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nvis) return;
+    const double* ct = camtab + (size_t)obs_cam[k] * CT_STRIDE;
+    const double* b = pb + (size_t)obs_pt[k] * 3;
+    double A[2 * CNP], B[6], x0, x1;
+    if (FD) jac_fd<CNP>(cfg, ct, b[0], b[1], b[2], A, B, x0, x1);
+    else    jac_analytic<CNP>(cfg, ct, b[0], b[1], b[2], A, B, x0, x1);
+    constexpr int JS = 2 * CNP + 6;
+    double2* out = reinterpret_cast<double2*>(J + (size_t)k * JS);   // JS is even -> 16-byte aligned records
+#pragma unroll
+    for (int q = 0; q < CNP; ++q) out[q] = make_double2(A[2 * q], A[2 * q + 1]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) out[CNP + q] = make_double2(B[2 * q], B[2 * q + 1]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// V_i (packed upper: 00 01 02 11 12 22), eb_i: one thread per point walks its CRS row.
+template <int CNP>
+__global__ __launch_bounds__(256) void k_point_blocks(DevProblem P, const double* __restrict__ e,
+                                                      const double* __restrict__ pb)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.n) return;
+    constexpr int JS = 2 * CNP + 6;
+    double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, g0 = 0, g1 = 0, g2 = 0;
+    const int k1 = P.rowptr[i + 1];
+    for (int k = P.rowptr[i]; k < k1; ++k) {
+        const double* B = P.J + (size_t)k * JS + 2 * CNP;
+        const double b0 = B[0], b1 = B[1], b2 = B[2], b3 = B[3], b4 = B[4], b5 = B[5];
+        const double e0 = e[2 * k], e1 = e[2 * k + 1];
+        v00 += b0 * b0 + b3 * b3; v01 += b0 * b1 + b3 * b4; v02 += b0 * b2 + b3 * b5;
+        v11 += b1 * b1 + b4 * b4; v12 += b1 * b2 + b4 * b5; v22 += b2 * b2 + b5 * b5;
+        g0 += b0 * e0 + b3 * e1; g1 += b1 * e0 + b4 * e1; g2 += b2 * e0 + b5 * e1;
+    }
+    if (P.pcon && P.pcon[i]) {   // sba_levmar.c:1017-1028 (weights scale with the job-wide nvis)
+        const double w = P.nvis_global * P.pweight;
+        v00 += w; v11 += w; v22 += w;
+        g0 += w * (P.pval[3 * i] - pb[3 * i]);
+        g1 += w * (P.pval[3 * i + 1] - pb[3 * i + 1]);
+        g2 += w * (P.pval[3 * i + 2] - pb[3 * i + 2]);
+    }
+    double* V = P.V + (size_t)i * 6;
+    V[0] = v00; V[1] = v01; V[2] = v02; V[3] = v11; V[4] = v12; V[5] = v22;
+    double* g = P.eb + (size_t)i * 3;
+    g[0] = g0; g[1] = g1; g[2] = g2;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// U_j (upper triangle accumulated, mirrored on store), ea_j: one 256-thread block per camera walks the
+// camera-major index; per-thread register partials, wave shuffle reduction, LDS across the 4 waves.
+template <int CNP>
+__global__ __launch_bounds__(256) void k_cam_blocks(DevProblem P, const double* __restrict__ e)
+{
+    constexpr int JS = 2 * CNP + 6;
+    constexpr int NU = CNP * (CNP + 1) / 2;
+    constexpr int NV = NU + CNP;
+    __shared__ double sm[4][NV];
+    const int j = blockIdx.x;
+    double acc[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) acc[q] = 0.0;
+    if (j >= P.mcon) {
+        const int t1 = P.camptr[j + 1];
+        for (int t = P.camptr[j] + threadIdx.x; t < t1; t += 256) {
+            const int k = P.camobs[t];
+            const double* A = P.J + (size_t)k * JS;
+            double a[2 * CNP];
+#pragma unroll
+            for (int q = 0; q < 2 * CNP; ++q) a[q] = A[q];
+            const double e0 = e[2 * k], e1 = e[2 * k + 1];
+            int u = 0;
+#pragma unroll
+            for (int r = 0; r < CNP; ++r) {
+#pragma unroll
+                for (int c = r; c < CNP; ++c) { acc[u] += a[r] * a[c] + a[CNP + r] * a[CNP + c]; ++u; }
+            }
+#pragma unroll
+            for (int r = 0; r < CNP; ++r) acc[NU + r] += a[r] * e0 + a[CNP + r] * e1;
+        }
+    }
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) { const double s = wave_sum(acc[q]); if (lane == 0) sm[w][q] = s; }
+    __syncthreads();
+    if (threadIdx.x < CNP * CNP) {
+        const int r = threadIdx.x / CNP, c = threadIdx.x % CNP;
+        const int rr = r < c ? r : c, cc = r < c ? c : r;
+        const int u = rr * CNP - rr * (rr - 1) / 2 + (cc - rr);
+        P.U[(size_t)j * CNP * CNP + threadIdx.x] = (sm[0][u] + sm[1][u]) + (sm[2][u] + sm[3][u]);
+    }
+    if (threadIdx.x < CNP) {
+        const int u = NU + threadIdx.x;
+        P.ea[(size_t)j * CNP + threadIdx.x] = (sm[0][u] + sm[1][u]) + (sm[2][u] + sm[3][u]);
+    }
+}
+
+// camera constraints into U_j / ea_j (sba_levmar.c:953-962); replicated cameras => every rank applies it
+// AFTER the cross-rank reduction of U and ea.
+__global__ void k_cam_constraints(DevProblem P, const double* __restrict__ pa)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cnp = P.cfg.cnp;
+    if (t >= P.m * cnp) return;
+    const int j = t / cnp, jj = t % cnp;
+    if (j < P.mcon || !P.ccon[t]) return;
+    const double diff = P.cval[t] - pa[t];
+    P.U[(size_t)j * cnp * cnp + jj * cnp + jj] += P.cw[t];
+    P.ea[t] += P.cw[t] * diff;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// (V_i + mu I)^-1, closed form for the symmetric 3x3 (the reference goes through dsytrf/dsytri);
+// a non-finite or zero determinant raises the "singular" flag => more damping (sba_levmar.c:1156-1161).
+__global__ __launch_bounds__(256) void k_point_invert(int n, double mu, const double* __restrict__ V,
+                                                      double* __restrict__ Vinv, int* __restrict__ flag)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double* v = V + (size_t)i * 6;
+    const double a = v[0] + mu, b = v[1], c = v[2], d = v[3] + mu, e = v[4], f = v[5] + mu;
+    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+    const double det = a * c00 + b * c01 + c * c02;
+    const double id = 1.0 / det;
+    double* o = Vinv + (size_t)i * 6;
+    o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
+    o[3] = (a * f - c * c) * id; o[4] = (b * c - a * e) * id; o[5] = (a * d - b * b) * id;
+    if (!(fabs(det) > 0.0) || !isfinite(id)) atomicOr(flag, 1);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Schur complement partial products.  The co-visibility triples (obs_a, obs_b) of every non-zero block
+// S_jk (j <= k) were bucketed and ordered once per problem; a task is a chunk of one block's triples and is
+// owned by ONE wave: 3 lanes per triple (lane r owns output rows r, r+3, r+6), 21 triples in flight,
+// the 21 lane-groups are folded with shuffles and lanes 0..2 store the cnp x cnp partial.
+// No atomics anywhere: partials are summed in task order by k_schur_assemble => run-to-run deterministic.
+template <int CNP>
+__global__ __launch_bounds__(256) void k_schur_tasks(DevProblem P, const SchurTask* __restrict__ tasks, int ntasks,
+        const int2* __restrict__ triples, double* __restrict__ partials)
+{
+    constexpr int JS = 2 * CNP + 6;
+    constexpr int NR = (CNP + 2) / 3;
+    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (task >= ntasks) return;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / 3, r = lane - 3 * grp;
+    const SchurTask tk = tasks[task];
+    double acc[NR][CNP];
+#pragma unroll
+    for (int a = 0; a < NR; ++a)
+#pragma unroll
+        for (int c = 0; c < CNP; ++c) acc[a][c] = 0.0;
+    if (grp < 21) {
+        for (int t = grp; t < tk.count; t += 21) {
+            const int2 tr = triples[tk.start + t];
+            const double* Ja = P.J + (size_t)tr.x * JS;
+            const double* Jb = P.J + (size_t)tr.y * JS;
+            const double* vi = P.Vinv + (size_t)P.obs_pt[tr.x] * 6;
+            const double i00 = vi[0], i01 = vi[1], i02 = vi[2], i11 = vi[3], i12 = vi[4], i22 = vi[5];
+            const double* Ba = Ja + 2 * CNP;
+            const double* Bb = Jb + 2 * CNP;
+            // C = B_a V^-1 (2x3), M = C B_b^T (2x2)
+            const double c00 = Ba[0] * i00 + Ba[1] * i01 + Ba[2] * i02;
+            const double c01 = Ba[0] * i01 + Ba[1] * i11 + Ba[2] * i12;
+            const double c02 = Ba[0] * i02 + Ba[1] * i12 + Ba[2] * i22;
+            const double c10 = Ba[3] * i00 + Ba[4] * i01 + Ba[5] * i02;
+            const double c11 = Ba[3] * i01 + Ba[4] * i11 + Ba[5] * i12;
+            const double c12 = Ba[3] * i02 + Ba[4] * i12 + Ba[5] * i22;
+            const double m00 = c00 * Bb[0] + c01 * Bb[1] + c02 * Bb[2];
+            const double m01 = c00 * Bb[3] + c01 * Bb[4] + c02 * Bb[5];
+            const double m10 = c10 * Bb[0] + c11 * Bb[1] + c12 * Bb[2];
+            const double m11 = c10 * Bb[3] + c11 * Bb[4] + c12 * Bb[5];
+            double T0[CNP], T1[CNP];
+#pragma unroll
+            for (int c = 0; c < CNP; ++c) {
+                const double b0 = Jb[c], b1 = Jb[CNP + c];
+                T0[c] = m00 * b0 + m01 * b1;
+                T1[c] = m10 * b0 + m11 * b1;
+            }
+#pragma unroll
+            for (int a = 0; a < NR; ++a) {
+                const int row = r + 3 * a;
+                if (row < CNP) {
+                    const double a0 = Ja[row], a1 = Ja[CNP + row];
+#pragma unroll
+                    for (int c = 0; c < CNP; ++c) acc[a][c] += a0 * T0[c] + a1 * T1[c];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 16; s > 0; s >>= 1) {
+        const bool take = (grp < s) && (grp + s < 21);
+#pragma unroll
+        for (int a = 0; a < NR; ++a)
+#pragma unroll
+            for (int c = 0; c < CNP; ++c) {
+                const double o = __shfl_down(acc[a][c], 3 * s, 64);
+                if (take) acc[a][c] += o;
+            }
+    }
+    if (grp == 0) {
+        double* out = partials + (size_t)task * CNP * CNP;
+#pragma unroll
+        for (int a = 0; a < NR; ++a) {
+            const int row = r + 3 * a;
+            if (row < CNP) {
+#pragma unroll
+                for (int c = 0; c < CNP; ++c) out[row * CNP + c] = acc[a][c];
+            }
+        }
+    }
+}
+
+// S_jk = [j==k](U_j + mu I) - sum_tasks partial ; mirrored into S_kj (sba_levmar.c:1274-1316).
+// add_diag = 0 on ranks > 0 of a multi-GPU job (U, mu enter the cross-rank sum exactly once).
+template <int CNP>
+__global__ __launch_bounds__(128) void k_schur_assemble(int nblk, const int* __restrict__ blk_j, const int* __restrict__ blk_k,
+        const int* __restrict__ blk_task0, const double* __restrict__ partials, const double* __restrict__ U,
+        double mu, int add_diag, int mcon, double* __restrict__ S, int ld)
+{
+    const int b = blockIdx.x;
+    if (b >= nblk || threadIdx.x >= CNP * CNP) return;
+    const int j = blk_j[b], k = blk_k[b];
+    const int row = threadIdx.x / CNP, col = threadIdx.x % CNP;
+    double s = 0.0;
+    for (int t = blk_task0[b]; t < blk_task0[b + 1]; ++t) s += partials[(size_t)t * CNP * CNP + threadIdx.x];
+    double v = -s;
+    if (j == k && add_diag) { v += U[(size_t)j * CNP * CNP + threadIdx.x]; if (row == col) v += mu; }
+    const size_t rj = (size_t)(j - mcon) * CNP + row, ck = (size_t)(k - mcon) * CNP + col;
+    S[rj * ld + ck] = v;
+    if (j != k) S[ck * ld + rj] = v;
+}
+
+// diagonal blocks of cameras that share no triple list entry cannot exist (every observed camera pairs with
+// itself), but cameras WITHOUT observations on this rank still need U_j + mu I on rank 0:
+template <int CNP>
+__global__ void k_schur_diag_fill(int m, int mcon, const int* __restrict__ camptr, const double* __restrict__ U,
+                                  double mu, double* __restrict__ S, int ld)
+{
+    const int j = mcon + blockIdx.x;
+    if (j >= m || threadIdx.x >= CNP * CNP) return;
+    if (camptr[j + 1] > camptr[j]) return;    // has a (j,j) block in the triple list
+    const int row = threadIdx.x / CNP, col = threadIdx.x % CNP;
+    double v = U[(size_t)j * CNP * CNP + threadIdx.x];
+    if (row == col) v += mu;
+    S[((size_t)(j - mcon) * CNP + row) * ld + (size_t)(j - mcon) * CNP + col] = v;
+}
+
+// E_j = [add_ea] ea_j - sum_i A_ij^T (B_ij (V*_i^-1 eb_i))   (sba_levmar.c:1320-1339); block per camera.
+template <int CNP>
+__global__ __launch_bounds__(256) void k_schur_rhs(DevProblem P, int add_ea, double* __restrict__ E)
+{
+    constexpr int JS = 2 * CNP + 6;
+    __shared__ double sm[4][CNP];
+    const int j = P.mcon + blockIdx.x;
+    double acc[CNP];
+#pragma unroll
+    for (int q = 0; q < CNP; ++q) acc[q] = 0.0;
+    const int t1 = P.camptr[j + 1];
+    for (int t = P.camptr[j] + threadIdx.x; t < t1; t += 256) {
+        const int k = P.camobs[t];
+        const int i = P.obs_pt[k];
+        const double* vi = P.Vinv + (size_t)i * 6;
+        const double* g = P.eb + (size_t)i * 3;
+        const double t0 = vi[0] * g[0] + vi[1] * g[1] + vi[2] * g[2];
+        const double t1v = vi[1] * g[0] + vi[3] * g[1] + vi[4] * g[2];
+        const double t2 = vi[2] * g[0] + vi[4] * g[1] + vi[5] * g[2];
+        const double* A = P.J + (size_t)k * JS;
+        const double* B = A + 2 * CNP;
+        const double s0 = B[0] * t0 + B[1] * t1v + B[2] * t2;
+        const double s1 = B[3] * t0 + B[4] * t1v + B[5] * t2;
+#pragma unroll
+        for (int q = 0; q < CNP; ++q) acc[q] += A[q] * s0 + A[CNP + q] * s1;
+    }
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < CNP; ++q) { const double s = wave_sum(acc[q]); if (lane == 0) sm[w][q] = s; }
+    __syncthreads();
+    if (threadIdx.x < CNP) {
+        const double s = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+        const double base = add_ea ? P.ea[(size_t)j * CNP + threadIdx.x] : 0.0;
+        E[(size_t)(j - P.mcon) * CNP + threadIdx.x] = base - s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// db_i = V*_i^-1 (eb_i - sum_j W_ij^T da_j), W_ij^T da_j = B_ij^T (A_ij da_j); thread per point.
+// Also writes pdp_b = p_b + db and block partials of sum db^2, sum p_b^2 and sum db (mu db + eb).
+template <int CNP>
+__global__ __launch_bounds__(256) void k_backsub(DevProblem P, double mu, const double* __restrict__ dpa,
+        const double* __restrict__ pb, double* __restrict__ dpb, double* __restrict__ pdpb,
+        double* __restrict__ part /* [3][gridDim.x] */)
+{
+    constexpr int JS = 2 * CNP + 6;
+    __shared__ double sm[3][4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double s_dp = 0.0, s_p = 0.0, s_dl = 0.0;
+    if (i < P.n) {
+        const double* g = P.eb + (size_t)i * 3;
+        double w0 = 0, w1 = 0, w2 = 0;
+        const int k1 = P.rowptr[i + 1];
+        for (int k = P.rowptr[i]; k < k1; ++k) {
+            const int j = P.obs_cam[k];
+            if (j < P.mcon) continue;
+            const double* A = P.J + (size_t)k * JS;
+            const double* B = A + 2 * CNP;
+            const double* da = dpa + (size_t)j * CNP;
+            double q0 = 0, q1 = 0;
+#pragma unroll
+            for (int c = 0; c < CNP; ++c) { q0 += A[c] * da[c]; q1 += A[CNP + c] * da[c]; }
+            w0 += B[0] * q0 + B[3] * q1; w1 += B[1] * q0 + B[4] * q1; w2 += B[2] * q0 + B[5] * q1;
+        }
+        const double r0 = g[0] - w0, r1 = g[1] - w1, r2 = g[2] - w2;
+        const double* vi = P.Vinv + (size_t)i * 6;
+        const double d0 = vi[0] * r0 + vi[1] * r1 + vi[2] * r2;
+        const double d1 = vi[1] * r0 + vi[3] * r1 + vi[4] * r2;
+        const double d2 = vi[2] * r0 + vi[4] * r1 + vi[5] * r2;
+        dpb[3 * (size_t)i] = d0; dpb[3 * (size_t)i + 1] = d1; dpb[3 * (size_t)i + 2] = d2;
+        const double p0 = pb[3 * (size_t)i], p1 = pb[3 * (size_t)i + 1], p2 = pb[3 * (size_t)i + 2];
+        pdpb[3 * (size_t)i] = p0 + d0; pdpb[3 * (size_t)i + 1] = p1 + d1; pdpb[3 * (size_t)i + 2] = p2 + d2;
+        s_dp = d0 * d0 + d1 * d1 + d2 * d2;
+        s_p = p0 * p0 + p1 * p1 + p2 * p2;
+        s_dl = d0 * (mu * d0 + g[0]) + d1 * (mu * d1 + g[1]) + d2 * (mu * d2 + g[2]);
+    }
+    s_dp = wave_sum(s_dp); s_p = wave_sum(s_p); s_dl = wave_sum(s_dl);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sm[0][w] = s_dp; sm[1][w] = s_p; sm[2][w] = s_dl; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
+            (sm[threadIdx.x][0] + sm[threadIdx.x][1]) + (sm[threadIdx.x][2] + sm[threadIdx.x][3]);
+}
+
+// camera part of the step: pdp_a = p_a + dp_a and sum dpa^2, sum pa^2, sum dpa (mu dpa + ea) (single block).
+__global__ __launch_bounds__(256) void k_cam_step(int count, int fixed, double mu, const double* __restrict__ pa,
+        const double* __restrict__ dpa, const double* __restrict__ ea, double* __restrict__ pdpa, double* __restrict__ out3)
+{
+    __shared__ double sm[3][4];
+    double s_dp = 0, s_p = 0, s_dl = 0;
+    for (int t = threadIdx.x; t < count; t += 256) {
+        const double d = (t < fixed) ? 0.0 : dpa[t], p = pa[t];
+        pdpa[t] = p + d;
+        s_dp += d * d; s_p += p * p; s_dl += d * (mu * d + ea[t]);
+    }
+    s_dp = wave_sum(s_dp); s_p = wave_sum(s_p); s_dl = wave_sum(s_dl);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sm[0][w] = s_dp; sm[1][w] = s_p; sm[2][w] = s_dl; }
+    __syncthreads();
+    if (threadIdx.x < 3) out3[threadIdx.x] = (sm[threadIdx.x][0] + sm[threadIdx.x][1]) + (sm[threadIdx.x][2] + sm[threadIdx.x][3]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// deterministic second-stage reductions (single block, fixed order)
+__global__ __launch_bounds__(256) void k_reduce_sum(const double* __restrict__ in, int count, double* __restrict__ out)
+{
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (int t = threadIdx.x; t < count; t += 256) s += in[t];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+__global__ __launch_bounds__(256) void k_reduce_max(const double* __restrict__ in, int count, double* __restrict__ out)
+{
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (int t = threadIdx.x; t < count; t += 256) { const double v = in[t]; s = v > s ? v : s; }
+    s = wave_max(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double q = sm[0]; for (int i = 1; i < 4; ++i) q = sm[i] > q ? sm[i] : q; *out = q; }
+}
+// max |v| over a vector (eab_inf) and max over the diagonal entries of packed V / dense U blocks
+__global__ __launch_bounds__(256) void k_absmax_partial(const double* __restrict__ v, size_t count, double* __restrict__ part)
+{
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < count; t += (size_t)gridDim.x * 256) {
+        const double a = fabs(v[t]); s = a > s ? a : s;
+    }
+    s = wave_max(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double q = sm[0]; for (int i = 1; i < 4; ++i) q = sm[i] > q ? sm[i] : q; part[blockIdx.x] = q; }
+}
+__global__ __launch_bounds__(256) void k_vdiag_max_partial(const double* __restrict__ V, int n, double* __restrict__ part)
+{
+    __shared__ double sm[4];
+    double s = -DBL_MAX;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const double* v = V + (size_t)i * 6;
+        const double a = v[0] > v[3] ? v[0] : v[3];
+        const double b = a > v[5] ? a : v[5];
+        s = b > s ? b : s;
+    }
+    { double t;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { t = __shfl_down(s, o, 64); s = t > s ? t : s; } }
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double q = sm[0]; for (int i = 1; i < 4; ++i) q = sm[i] > q ? sm[i] : q; part[blockIdx.x] = q; }
+}
+__global__ __launch_bounds__(256) void k_udiag_max(const double* __restrict__ U, int m, int mcon, int cnp, double* __restrict__ out)
+{
+    __shared__ double sm[4];
+    double s = -DBL_MAX;
+    for (int t = mcon * cnp + threadIdx.x; t < m * cnp; t += 256) {
+        const int j = t / cnp, jj = t % cnp;
+        const double a = U[(size_t)j * cnp * cnp + jj * cnp + jj];
+        s = a > s ? a : s;
+    }
+    { double t;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { t = __shfl_down(s, o, 64); s = t > s ? t : s; } }
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double q = sm[0]; for (int i = 1; i < 4; ++i) q = sm[i] > q ? sm[i] : q; *out = q; }
+}
+// sum p^2 over a vector, block partials
+__global__ __launch_bounds__(256) void k_sumsq_partial(const double* __restrict__ v, size_t count, double* __restrict__ part)
+{
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < count; t += (size_t)gridDim.x * 256) s += v[t] * v[t];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+// constraint cost: sum_j w (c - p)^2 over constrained camera params (sba_levmar.c:809-826) and
+// nvis * w * (c - p)^2 over constrained points (sba_levmar.c:829-842); single block.
+__global__ __launch_bounds__(256) void k_constraint_cost(DevProblem P, const double* __restrict__ pa,
+        const double* __restrict__ pb, int with_cams, double* __restrict__ out)
+{
+    __shared__ double sm[4];
+    double s = 0.0;
+    if (P.ccon && with_cams)
+        for (int t = threadIdx.x; t < P.m * P.cfg.cnp; t += 256)
+            if (P.ccon[t]) { const double d = P.cval[t] - pa[t]; s += P.cw[t] * d * d; }
+    if (P.pcon)
+        for (int i = threadIdx.x; i < P.n; i += 256)
+            if (P.pcon[i]) {
+                for (int q = 0; q < 3; ++q) { const double d = P.pval[3 * i + q] - pb[3 * i + q]; s += P.nvis_global * P.pweight * d * d; }
+            }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+// expand packed V (+mu) to the reference's full symmetric 3x3 per point (test/export helper)
+__global__ void k_expand_v(int n, double mu, const double* __restrict__ V, double* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* v = V + (size_t)i * 6;
+    double* o = out + (size_t)i * 9;
+    o[0] = v[0] + mu; o[1] = v[1]; o[2] = v[2];
+    o[3] = v[1]; o[4] = v[3] + mu; o[5] = v[4];
+    o[6] = v[2]; o[7] = v[4]; o[8] = v[5] + mu;
+}
+
+}  // namespace bsfm

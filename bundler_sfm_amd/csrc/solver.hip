@@ -1,0 +1,844 @@
+// solver.hip -- host side of the MI355X bundle-adjustment core: resident problem object, index
+// construction, and the Levenberg-Marquardt driver.
+//
+// The LM control flow restates lib/sba-1.5/sba_levmar.c:457-2081 (sba_motstr_levmar_x) statement by
+// statement where it decides something (stop rules 1-8, damping update, the "constraint cost at the trial
+// point uses the OLD p" quirk :1488-1522, stop-8 leaving p un-updated :1569-1572, itmax overriding the stop
+// code :1617); all O(nvis) work is in the HIP kernels of kernels.hip.h and the dense solve in potrf.hip.h.
+// One stream; the host reads ONE small scalar block per decision point.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <cfloat>
+#include <vector>
+#include <algorithm>
+#include <string>
+#include <dlfcn.h>
+
+#include "../../include/bsfm.h"
+#include "kernels.hip.h"
+#include "potrf.hip.h"
+
+using namespace bsfm;
+
+#define HIP_OK(call)                                                                               \
+    do {                                                                                           \
+        hipError_t _e = (call);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            fprintf(stderr, "[bsfm] HIP error %s at %s:%d: %s\n", hipGetErrorName(_e), __FILE__,   \
+                    __LINE__, #call);                                                              \
+            return BSFM_ERROR;                                                                     \
+        }                                                                                          \
+    } while (0)
+
+namespace {
+
+constexpr double SBA_EPSILON_SQ = 1E-12 * 1E-12;   // lib/sba-1.5/sba_levmar.c:35-36
+constexpr double SBA_ONE_THIRD = 0.3333333334;     // lib/sba-1.5/sba_levmar.c:38
+constexpr int SCHUR_CHUNK = 168;                   // triples per task = 8 passes of 21
+
+enum Phase { PH_JAC = 0, PH_CAMBLK, PH_PTBLK, PH_INVERT, PH_SCHUR, PH_SOLVE, PH_BACKSUB, PH_RESID, PH_COUNT };
+const char* kPhaseNames[PH_COUNT] = { "jacobian", "cam_blocks", "point_blocks", "point_invert", "schur",
+                                      "solve", "backsub", "residual" };
+
+// scalar block layout (device doubles)
+enum Scal { SC_COST = 0, SC_COST_TRIAL, SC_PCT, SC_CAM3 /*3*/, SC_PT_DP = 6, SC_PT_P, SC_PT_DL,
+            SC_EABINF_A, SC_EABINF_B, SC_MAXDIAG_U, SC_MAXDIAG_V, SC_PL2_A, SC_PL2_B, SC_CCOST, SC_COUNT = 24 };
+
+template <typename T> hipError_t dmalloc(T** p, size_t count)
+{
+    return hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T));
+}
+
+}  // namespace
+
+struct bsfm_problem {
+    bsfm_options_t opt;
+    DevProblem P{};
+    int cnp = 0, nvars_local = 0;
+    int world = 1, rank = 0;
+    long long nvis_global = 0, nvars_global = 0;
+    int Sdim = 0, ld = 0;
+    // device
+    double *d_x = nullptr, *d_Rinit = nullptr, *d_finit = nullptr;
+    int *d_obs_cam = nullptr, *d_obs_pt = nullptr, *d_rowptr = nullptr, *d_camptr = nullptr, *d_camobs = nullptr;
+    unsigned char *d_ccon = nullptr, *d_pcon = nullptr;
+    double *d_cval = nullptr, *d_cw = nullptr, *d_pval = nullptr;
+    double *d_p = nullptr, *d_pdp = nullptr, *d_dp = nullptr;
+    double *d_camtab = nullptr, *d_camtab_trial = nullptr;
+    double *d_e = nullptr, *d_hx = nullptr;
+    double *d_J = nullptr, *d_U = nullptr, *d_ea = nullptr, *d_V = nullptr, *d_Vinv = nullptr, *d_eb = nullptr;
+    double *d_S = nullptr, *d_E = nullptr;
+    double *d_partials = nullptr;       // schur task partials
+    double *d_red = nullptr;            // block partials for reductions
+    double *d_scal = nullptr;
+    int *d_flags = nullptr;             // [0] singular V, [1] potrf info
+    // schur structure
+    int ntriples = 0, ntasks = 0, nblk = 0;
+    int2* d_triples = nullptr; SchurTask* d_tasks = nullptr;
+    int *d_blk_j = nullptr, *d_blk_k = nullptr, *d_blk_task0 = nullptr;
+    // host
+    double* h_scal = nullptr; int* h_flags = nullptr;   // pinned
+    std::vector<double> h_Rinit;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    bsfm_allreduce_fn allreduce = nullptr; void* allreduce_ctx = nullptr;
+    PotrfWorkspace potrf;
+    // LM state (names follow sba_levmar.c)
+    int itno = 0, stop = 0, nu = 2, nfev = 0, njev = 0, nlss = 0, began = 0, error = 0;
+    double mu = 0.0, p_eL2 = 0.0, init_p_eL2 = 0.0, eab_inf = 0.0, dp_L2 = DBL_MAX, p_L2 = 0.0, maxdiag = DBL_MIN;
+    // timing
+    hipEvent_t ev[PH_COUNT][2]; bool ev_ok = false;
+    double ph_ms[PH_COUNT]; int ph_cnt[PH_COUNT];
+    int red_blocks = 0;
+};
+
+namespace {
+
+void free_all(bsfm_problem* pb)
+{
+    void* ptrs[] = { pb->d_x, pb->d_Rinit, pb->d_finit, pb->d_obs_cam, pb->d_obs_pt, pb->d_rowptr, pb->d_camptr,
+                     pb->d_camobs, pb->d_ccon, pb->d_pcon, pb->d_cval, pb->d_cw, pb->d_pval, pb->d_p, pb->d_pdp,
+                     pb->d_dp, pb->d_camtab, pb->d_camtab_trial, pb->d_e, pb->d_hx, pb->d_J, pb->d_U, pb->d_ea,
+                     pb->d_V, pb->d_Vinv, pb->d_eb, pb->d_S, pb->d_E, pb->d_partials, pb->d_red, pb->d_scal,
+                     pb->d_flags, pb->d_triples, pb->d_tasks, pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0 };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (pb->h_scal) (void)hipHostFree(pb->h_scal);
+    if (pb->h_flags) (void)hipHostFree(pb->h_flags);
+    potrf_free(pb->potrf);
+    if (pb->ev_ok) for (int i = 0; i < PH_COUNT; ++i) { (void)hipEventDestroy(pb->ev[i][0]); (void)hipEventDestroy(pb->ev[i][1]); }
+    if (pb->own_stream && pb->stream) (void)hipStreamDestroy(pb->stream);
+}
+
+// Builds the co-visibility triple list bucketed by reduced-camera block (j <= k), in (j,k) order and,
+// inside a block, in point order -- the order the reference visits them (sba_levmar.c:1218-1268).
+int build_schur_structure(bsfm_problem* pb, const bsfm_problem_desc_t* d)
+{
+    const int n = d->n, m = d->m, mcon = d->mcon, mm = m - mcon;
+    std::vector<int2> triples;
+    std::vector<int> blk_j, blk_k, blk_start;
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        int cnt = 0;
+        for (int k = d->rowptr[i]; k < d->rowptr[i + 1]; ++k) cnt += (d->colidx[k] >= mcon);
+        total += (size_t)cnt * (cnt + 1) / 2;
+    }
+    if (total > 0x7fffffffULL) { fprintf(stderr, "[bsfm] too many co-visibility triples (%zu)\n", total); return BSFM_ERROR; }
+    triples.resize(total);
+    if ((size_t)mm * mm <= (size_t)1 << 27) {
+        std::vector<unsigned> cnt((size_t)mm * mm + 1, 0u);
+        for (int i = 0; i < n; ++i)
+            for (int a = d->rowptr[i]; a < d->rowptr[i + 1]; ++a) {
+                const int ja = d->colidx[a]; if (ja < mcon) continue;
+                for (int b = a; b < d->rowptr[i + 1]; ++b) ++cnt[(size_t)(ja - mcon) * mm + (d->colidx[b] - mcon) + 1];
+            }
+        for (size_t q = 0; q < (size_t)mm * mm; ++q) {   // exclusive prefix; record the non-empty blocks
+            if (cnt[q + 1]) { blk_j.push_back(mcon + (int)(q / mm)); blk_k.push_back(mcon + (int)(q % mm)); blk_start.push_back((int)cnt[q]); }
+            cnt[q + 1] += cnt[q];
+        }
+        std::vector<unsigned> cur(cnt.begin(), cnt.end() - 1);
+        for (int i = 0; i < n; ++i)
+            for (int a = d->rowptr[i]; a < d->rowptr[i + 1]; ++a) {
+                const int ja = d->colidx[a]; if (ja < mcon) continue;
+                for (int b = a; b < d->rowptr[i + 1]; ++b) {
+                    const size_t key = (size_t)(ja - mcon) * mm + (d->colidx[b] - mcon);
+                    triples[cur[key]++] = make_int2(a, b);
+                }
+            }
+    } else {
+        struct Rec { unsigned long long key; int a, b; };
+        std::vector<Rec> recs; recs.reserve(total);
+        for (int i = 0; i < n; ++i)
+            for (int a = d->rowptr[i]; a < d->rowptr[i + 1]; ++a) {
+                const int ja = d->colidx[a]; if (ja < mcon) continue;
+                for (int b = a; b < d->rowptr[i + 1]; ++b)
+                    recs.push_back({ (unsigned long long)(ja - mcon) * mm + (d->colidx[b] - mcon), a, b });
+            }
+        std::stable_sort(recs.begin(), recs.end(), [](const Rec& x, const Rec& y) { return x.key < y.key; });
+        for (size_t q = 0; q < recs.size(); ++q) {
+            if (q == 0 || recs[q].key != recs[q - 1].key) {
+                blk_j.push_back(mcon + (int)(recs[q].key / mm)); blk_k.push_back(mcon + (int)(recs[q].key % mm));
+                blk_start.push_back((int)q);
+            }
+            triples[q] = make_int2(recs[q].a, recs[q].b);
+        }
+    }
+    blk_start.push_back((int)total);
+    const int nblk = (int)blk_j.size();
+    std::vector<SchurTask> tasks;
+    std::vector<int> blk_task0(nblk + 1);
+    for (int b = 0; b < nblk; ++b) {
+        blk_task0[b] = (int)tasks.size();
+        for (int s = blk_start[b]; s < blk_start[b + 1]; s += SCHUR_CHUNK)
+            tasks.push_back({ s, std::min(SCHUR_CHUNK, blk_start[b + 1] - s) });
+    }
+    blk_task0[nblk] = (int)tasks.size();
+    pb->ntriples = (int)total; pb->ntasks = (int)tasks.size(); pb->nblk = nblk;
+    HIP_OK(dmalloc(&pb->d_triples, total)); HIP_OK(dmalloc(&pb->d_tasks, tasks.size()));
+    HIP_OK(dmalloc(&pb->d_blk_j, nblk)); HIP_OK(dmalloc(&pb->d_blk_k, nblk)); HIP_OK(dmalloc(&pb->d_blk_task0, nblk + 1));
+    HIP_OK(dmalloc(&pb->d_partials, tasks.size() * (size_t)pb->cnp * pb->cnp));
+    if (total) HIP_OK(hipMemcpy(pb->d_triples, triples.data(), total * sizeof(int2), hipMemcpyHostToDevice));
+    if (!tasks.empty()) HIP_OK(hipMemcpy(pb->d_tasks, tasks.data(), tasks.size() * sizeof(SchurTask), hipMemcpyHostToDevice));
+    if (nblk) {
+        HIP_OK(hipMemcpy(pb->d_blk_j, blk_j.data(), nblk * sizeof(int), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(pb->d_blk_k, blk_k.data(), nblk * sizeof(int), hipMemcpyHostToDevice));
+    }
+    HIP_OK(hipMemcpy(pb->d_blk_task0, blk_task0.data(), (nblk + 1) * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+
+void pack_params(const bsfm_problem* pb, const bsfm_camera_params_t* cams, const double* pts, int n,
+                 std::vector<double>& p)
+{
+    // lib/sfm-driver/sfm.c:652-703
+    const int cnp = pb->cnp, m = pb->P.m;
+    const ModelCfg& c = pb->P.cfg;
+    p.assign((size_t)m * cnp + (size_t)3 * n, 0.0);
+    for (int j = 0; j < m; ++j) {
+        double* a = &p[(size_t)j * cnp];
+        a[0] = cams[j].t[0]; a[1] = cams[j].t[1]; a[2] = cams[j].t[2];
+        int col = 6;
+        if (c.est_focal) { a[6] = cams[j].f * c.f_scale; col = 7; }
+        if (c.undistort) { a[col] = cams[j].k[0] * c.k_scale; a[col + 1] = cams[j].k[1] * c.k_scale; }
+    }
+    if (n) memcpy(&p[(size_t)m * cnp], pts, sizeof(double) * 3 * n);
+}
+
+inline void ph_begin(bsfm_problem* pb, int ph) { if (pb->ev_ok) (void)hipEventRecord(pb->ev[ph][0], pb->stream); }
+inline void ph_end(bsfm_problem* pb, int ph) { if (pb->ev_ok) (void)hipEventRecord(pb->ev[ph][1], pb->stream); }
+
+#define DISPATCH_CNP(cnp, EXPR)                   \
+    switch (cnp) {                                \
+        case 6: { constexpr int C = 6; EXPR; } break; \
+        case 7: { constexpr int C = 7; EXPR; } break; \
+        case 8: { constexpr int C = 8; EXPR; } break; \
+        default: { constexpr int C = 9; EXPR; } break; \
+    }
+
+inline int grid_for(size_t count, int block) { return (int)std::max<size_t>(1, (count + block - 1) / block); }
+
+void launch_cam_table(bsfm_problem* pb, const double* p, double* camtab)
+{
+    hipLaunchKernelGGL(k_cam_table, dim3(grid_for(pb->P.m, 64)), dim3(64), 0, pb->stream, pb->P.cfg, pb->P.m, p,
+                       pb->d_Rinit, pb->d_finit, pb->opt.jacobian == BSFM_JAC_FD ? 1 : 0, camtab);
+}
+
+// e_out = x - proj(p); SC slot gets sum e^2 ; optional pct-change vs e_prev into SC_PCT
+void launch_residual(bsfm_problem* pb, const double* camtab, const double* p, double* e_out,
+                     const double* e_prev, int cost_slot)
+{
+    const int nb = grid_for(pb->P.nvis, RES_BLOCK);
+    double* pc = pb->d_red, *pp = pb->d_red + pb->red_blocks;
+    const double* pbpts = p + (size_t)pb->P.m * pb->cnp;
+    if (pb->P.nvis > 0)
+        hipLaunchKernelGGL(k_residual, dim3(nb), dim3(RES_BLOCK), 0, pb->stream, pb->P.cfg, pb->P.nvis, pb->d_x,
+                           pb->d_obs_cam, pb->d_obs_pt, camtab, pbpts, e_out, e_prev, pb->opt.opts[5], pc,
+                           e_prev ? pp : nullptr);
+    const int cnt = pb->P.nvis > 0 ? nb : 0;
+    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, pb->stream, pc, cnt, pb->d_scal + cost_slot);
+    if (e_prev) hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, pb->stream, pp, cnt, pb->d_scal + SC_PCT);
+}
+
+int read_scalars(bsfm_problem* pb)
+{
+    HIP_OK(hipMemcpyAsync(pb->h_scal, pb->d_scal, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+    HIP_OK(hipMemcpyAsync(pb->h_flags, pb->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, pb->stream));
+    HIP_OK(hipStreamSynchronize(pb->stream));
+    return 0;
+}
+
+// cross-rank reductions of host scalars go through the same device hook (tiny device buffer)
+int allreduce_host(bsfm_problem* pb, double* vals, int count, int op)
+{
+    if (pb->world <= 1 || !pb->allreduce) return 0;
+    double* tmp = pb->d_scal + SC_COUNT;   // spare slots
+    HIP_OK(hipMemcpyAsync(tmp, vals, count * sizeof(double), hipMemcpyHostToDevice, pb->stream));
+    HIP_OK(hipStreamSynchronize(pb->stream));
+    if (pb->allreduce(tmp, (size_t)count, op, pb->allreduce_ctx) != 0) return BSFM_ERROR;
+    HIP_OK(hipMemcpy(vals, tmp, count * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+int allreduce_dev(bsfm_problem* pb, double* dbuf, size_t count, int op)
+{
+    if (pb->world <= 1 || !pb->allreduce) return 0;
+    HIP_OK(hipStreamSynchronize(pb->stream));
+    if (pb->allreduce(dbuf, count, op, pb->allreduce_ctx) != 0) { fprintf(stderr, "[bsfm] allreduce hook failed\n"); return BSFM_ERROR; }
+    return 0;
+}
+
+void collect_phase_times(bsfm_problem* pb)
+{
+    if (!pb->ev_ok) return;
+    for (int i = 0; i < PH_COUNT; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pb->ev[i][0], pb->ev[i][1]) == hipSuccess && ms >= 0.f) { pb->ph_ms[i] += ms; pb->ph_cnt[i]++; }
+    }
+    potrf_collect_time(pb->potrf);
+}
+
+// J, U/ea, V/eb at the current p
+int compute_normal_blocks(bsfm_problem* pb)
+{
+    const int cnp = pb->cnp;
+    DevProblem& P = pb->P;
+    const double* pbpts = pb->d_p + (size_t)P.m * cnp;
+    ph_begin(pb, PH_JAC);
+    if (P.nvis > 0) {
+        if (pb->opt.jacobian == BSFM_JAC_FD) {
+            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_jacobian<C, true>), dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream,
+                                                  P.cfg, P.nvis, pb->d_obs_cam, pb->d_obs_pt, pb->d_camtab, pbpts, pb->d_J));
+        } else {
+            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_jacobian<C, false>), dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream,
+                                                  P.cfg, P.nvis, pb->d_obs_cam, pb->d_obs_pt, pb->d_camtab, pbpts, pb->d_J));
+        }
+    }
+    ph_end(pb, PH_JAC);
+    ph_begin(pb, PH_CAMBLK);
+    DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_cam_blocks<C>), dim3(P.m), dim3(256), 0, pb->stream, P, pb->d_e));
+    ph_end(pb, PH_CAMBLK);
+    if (pb->world > 1) {   // U and ea are sums over ALL points: exchange step 1, 90*m doubles
+        if (allreduce_dev(pb, pb->d_U, (size_t)P.m * cnp * cnp, 0)) return BSFM_ERROR;
+        if (allreduce_dev(pb, pb->d_ea, (size_t)P.m * cnp, 0)) return BSFM_ERROR;
+    }
+    if (P.ccon)
+        hipLaunchKernelGGL(k_cam_constraints, dim3(grid_for((size_t)P.m * cnp, 256)), dim3(256), 0, pb->stream, P, pb->d_p);
+    ph_begin(pb, PH_PTBLK);
+    if (P.n > 0) DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_point_blocks<C>), dim3(grid_for(P.n, 256)), dim3(256), 0, pb->stream, P, pb->d_e, pbpts));
+    ph_end(pb, PH_PTBLK);
+    return 0;
+}
+
+// S, E for damping mu (Vinv must be current)
+int compute_schur(bsfm_problem* pb, double mu)
+{
+    const int cnp = pb->cnp;
+    DevProblem& P = pb->P;
+    const int mm = P.m - P.mcon;
+    const int lead = pb->rank == 0 ? 1 : 0;
+    (void)hipMemsetAsync(pb->d_S, 0, (size_t)pb->ld * pb->ld * sizeof(double), pb->stream);
+    if (pb->ntasks > 0) {
+        DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks<C>), dim3((pb->ntasks + 3) / 4), dim3(256), 0, pb->stream,
+                                              P, pb->d_tasks, pb->ntasks, pb->d_triples, pb->d_partials));
+        DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_assemble<C>), dim3(pb->nblk), dim3(128), 0, pb->stream, pb->nblk,
+                                              pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0, pb->d_partials, pb->d_U, mu, lead,
+                                              P.mcon, pb->d_S, pb->ld));
+    }
+    if (lead && mm > 0)
+        DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_diag_fill<C>), dim3(mm), dim3(128), 0, pb->stream, P.m, P.mcon,
+                                              pb->d_camptr, pb->d_U, mu, pb->d_S, pb->ld));
+    if (mm > 0)
+        DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_rhs<C>), dim3(mm), dim3(256), 0, pb->stream, P, lead, pb->d_E));
+    if (pb->world > 1) {   // exchange step 2: the reduced camera system
+        if (allreduce_dev(pb, pb->d_S, (size_t)pb->ld * pb->ld, 0)) return BSFM_ERROR;
+        if (allreduce_dev(pb, pb->d_E, (size_t)pb->Sdim, 0)) return BSFM_ERROR;
+    }
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================ API
+extern "C" {
+
+void bsfm_default_options(bsfm_options_t* opt)
+{
+    memset(opt, 0, sizeof(*opt));
+    opt->jacobian = BSFM_JAC_FD;
+    if (const char* e = getenv("BSFM_JACOBIAN")) {
+        if (!strcmp(e, "analytic")) opt->jacobian = BSFM_JAC_ANALYTIC;
+        else if (!strcmp(e, "fd")) opt->jacobian = BSFM_JAC_FD;
+    }
+    opt->itmax = 150;   // MAX_ITERS, sfm.c:814
+    opt->verbose = 1;
+    opt->opts[0] = 1.0e-3; opt->opts[1] = 1.0e-10; opt->opts[2] = 0.0;
+    opt->opts[3] = 1.0e-12; opt->opts[4] = 0.0; opt->opts[5] = 4.0e-2;   // sfm.c:705-714
+    opt->potrf_backend = 0;
+    if (const char* e = getenv("BSFM_POTRF")) if (!strcmp(e, "rocsolver")) opt->potrf_backend = 1;
+}
+
+int bsfm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* bsfm_version(void) { return "bundler_sfm_amd 0.1 (gfx950)"; }
+
+bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_options_t* opt_in)
+{
+    if (bsfm_device_count() <= 0) {
+        fprintf(stderr, "[bsfm] FATAL: no usable HIP device; the MI355X path has no CPU fallback\n");
+        return nullptr;
+    }
+    if (!d || d->n < 0 || d->m <= 0 || d->mcon < 0 || d->mcon > d->m) { fprintf(stderr, "[bsfm] bad problem description\n"); return nullptr; }
+    bsfm_problem* pb = new bsfm_problem();
+    if (opt_in) pb->opt = *opt_in; else bsfm_default_options(&pb->opt);
+    auto fail = [&](const char* why) -> bsfm_problem_t* {
+        fprintf(stderr, "[bsfm] problem_create failed: %s\n", why);
+        free_all(pb); delete pb; return nullptr;
+    };
+    const int n = d->n, m = d->m;
+    const int nvis = d->rowptr[n];
+    const int cnp = (d->est_focal_length ? 7 : 6) + (d->undistort ? 2 : 0);
+    pb->cnp = cnp;
+    DevProblem& P = pb->P;
+    P.cfg.cnp = cnp; P.cfg.est_focal = d->est_focal_length ? 1 : 0; P.cfg.undistort = d->undistort ? 1 : 0;
+    P.cfg.explicit_centers = d->explicit_camera_centers ? 1 : 0;
+    P.cfg.f_scale = 0.001; P.cfg.k_scale = 5.0;                    // sfm.c:634-635
+    P.n = n; P.m = m; P.mcon = d->mcon; P.nvis = nvis; P.js = 2 * cnp + 6;
+    pb->world = d->world_size > 1 ? d->world_size : 1; pb->rank = d->world_size > 1 ? d->rank : 0;
+    pb->nvis_global = d->nvis_global > 0 ? d->nvis_global : nvis;
+    pb->nvars_global = d->nvars_global > 0 ? d->nvars_global : ((long long)m * cnp + 3LL * n);
+    pb->nvars_local = m * cnp + 3 * n;
+    P.nvis_global = (double)pb->nvis_global;
+    pb->Sdim = (m - d->mcon) * cnp;
+    pb->ld = std::max(POTRF_NB, (pb->Sdim + POTRF_NB - 1) / POTRF_NB * POTRF_NB);
+
+    // ---- index bookkeeping (bit-exact integer work; validated against the CRS the reference builds)
+    for (int i = 0; i < n; ++i) {
+        if (d->rowptr[i + 1] < d->rowptr[i]) return fail("rowptr not monotone");
+        for (int k = d->rowptr[i]; k < d->rowptr[i + 1]; ++k) {
+            if (d->colidx[k] < 0 || d->colidx[k] >= m) return fail("colidx out of range");
+            if (k > d->rowptr[i] && d->colidx[k] <= d->colidx[k - 1]) return fail("colidx not strictly ascending in a row");
+        }
+    }
+    std::vector<int> obs_pt(nvis), camptr(m + 1, 0), camobs(nvis);
+    for (int i = 0; i < n; ++i) for (int k = d->rowptr[i]; k < d->rowptr[i + 1]; ++k) { obs_pt[k] = i; ++camptr[d->colidx[k] + 1]; }
+    for (int j = 0; j < m; ++j) camptr[j + 1] += camptr[j];
+    { std::vector<int> cur(camptr.begin(), camptr.end() - 1);
+      for (int k = 0; k < nvis; ++k) camobs[cur[d->colidx[k]]++] = k; }
+
+    if (hipStreamCreateWithFlags(&pb->stream, hipStreamNonBlocking) != hipSuccess) return fail("stream");
+    pb->own_stream = true;
+#define DM(ptr, cnt) if (dmalloc(&ptr, (size_t)(cnt)) != hipSuccess) return fail("hipMalloc " #ptr)
+    DM(pb->d_x, 2 * (size_t)nvis); DM(pb->d_obs_cam, nvis); DM(pb->d_obs_pt, nvis); DM(pb->d_rowptr, n + 1);
+    DM(pb->d_camptr, m + 1); DM(pb->d_camobs, nvis); DM(pb->d_Rinit, 9 * (size_t)m); DM(pb->d_finit, m);
+    DM(pb->d_p, pb->nvars_local); DM(pb->d_pdp, pb->nvars_local); DM(pb->d_dp, pb->nvars_local);
+    DM(pb->d_camtab, (size_t)m * CT_STRIDE); DM(pb->d_camtab_trial, (size_t)m * CT_STRIDE);
+    DM(pb->d_e, 2 * (size_t)nvis); DM(pb->d_hx, 2 * (size_t)nvis);
+    DM(pb->d_J, (size_t)nvis * P.js); DM(pb->d_U, (size_t)m * cnp * cnp); DM(pb->d_ea, (size_t)m * cnp);
+    DM(pb->d_V, 6 * (size_t)n); DM(pb->d_Vinv, 6 * (size_t)n); DM(pb->d_eb, 3 * (size_t)n);
+    DM(pb->d_S, (size_t)pb->ld * pb->ld); DM(pb->d_E, pb->ld);
+    pb->red_blocks = std::max(grid_for(nvis, RES_BLOCK), std::max(grid_for(n, 256), 1024));
+    DM(pb->d_red, 4 * (size_t)pb->red_blocks); DM(pb->d_scal, SC_COUNT + 16); DM(pb->d_flags, 4);
+#undef DM
+    if (hipHostMalloc((void**)&pb->h_scal, (SC_COUNT + 16) * sizeof(double)) != hipSuccess) return fail("pinned");
+    if (hipHostMalloc((void**)&pb->h_flags, 4 * sizeof(int)) != hipSuccess) return fail("pinned");
+    (void)hipMemset(pb->d_scal, 0, (SC_COUNT + 16) * sizeof(double)); (void)hipMemset(pb->d_flags, 0, 4 * sizeof(int));
+    (void)hipMemset(pb->d_S, 0, (size_t)pb->ld * pb->ld * sizeof(double)); (void)hipMemset(pb->d_E, 0, pb->ld * sizeof(double));
+    (void)hipMemset(pb->d_dp, 0, pb->nvars_local * sizeof(double));
+
+    auto up = [&](void* dst, const void* src, size_t bytes) { return bytes == 0 || hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess; };
+    bool ok = up(pb->d_x, d->projections, 2 * (size_t)nvis * sizeof(double)) && up(pb->d_obs_cam, d->colidx, nvis * sizeof(int)) &&
+              up(pb->d_obs_pt, obs_pt.data(), nvis * sizeof(int)) && up(pb->d_rowptr, d->rowptr, (n + 1) * sizeof(int)) &&
+              up(pb->d_camptr, camptr.data(), (m + 1) * sizeof(int)) && up(pb->d_camobs, camobs.data(), nvis * sizeof(int));
+    pb->h_Rinit.resize(9 * (size_t)m);
+    std::vector<double> finit(m);
+    for (int j = 0; j < m; ++j) { memcpy(&pb->h_Rinit[9 * (size_t)j], d->cameras[j].R, 9 * sizeof(double)); finit[j] = d->cameras[j].f; }
+    ok = ok && up(pb->d_Rinit, pb->h_Rinit.data(), 9 * (size_t)m * sizeof(double)) && up(pb->d_finit, finit.data(), m * sizeof(double));
+    std::vector<double> p;
+    pack_params(pb, d->cameras, d->points, n, p);
+    ok = ok && up(pb->d_p, p.data(), p.size() * sizeof(double));
+    if (d->use_constraints) {   // sfm.c:721-754 (note the hard-wired indices 6,7,8 of the rescaling)
+        std::vector<unsigned char> con((size_t)m * cnp); std::vector<double> val((size_t)m * cnp), w((size_t)m * cnp);
+        for (int j = 0; j < m; ++j) {
+            double cv[9], cw[9];
+            for (int q = 0; q < 9; ++q) { cv[q] = d->cameras[j].constraints[q]; cw[q] = d->cameras[j].weights[q]; }
+            if (d->est_focal_length) { cv[6] *= P.cfg.f_scale; cw[6] *= 1.0 / (P.cfg.f_scale * P.cfg.f_scale); }
+            if (d->undistort) { cv[7] *= P.cfg.k_scale; cw[7] *= 1.0 / (P.cfg.k_scale * P.cfg.k_scale);
+                                cv[8] *= P.cfg.k_scale; cw[8] *= 1.0 / (P.cfg.k_scale * P.cfg.k_scale); }
+            for (int q = 0; q < cnp; ++q) { con[(size_t)j * cnp + q] = d->cameras[j].constrained[q] ? 1 : 0; val[(size_t)j * cnp + q] = cv[q]; w[(size_t)j * cnp + q] = cw[q]; }
+        }
+        if (dmalloc(&pb->d_ccon, con.size()) != hipSuccess || dmalloc(&pb->d_cval, val.size()) != hipSuccess || dmalloc(&pb->d_cw, w.size()) != hipSuccess) return fail("hipMalloc constraints");
+        ok = ok && up(pb->d_ccon, con.data(), con.size()) && up(pb->d_cval, val.data(), val.size() * sizeof(double)) && up(pb->d_cw, w.data(), w.size() * sizeof(double));
+    }
+    if (d->use_point_constraints && d->point_constraints) {   // sfm.c:757-781
+        std::vector<unsigned char> con(std::max(n, 1));
+        for (int i = 0; i < n; ++i) { const double* c = d->point_constraints + 3 * (size_t)i; con[i] = !(c[0] == 0.0 && c[1] == 0.0 && c[2] == 0.0); }
+        if (dmalloc(&pb->d_pcon, (size_t)n) != hipSuccess || dmalloc(&pb->d_pval, 3 * (size_t)n) != hipSuccess) return fail("hipMalloc point constraints");
+        ok = ok && up(pb->d_pcon, con.data(), n) && up(pb->d_pval, d->point_constraints, 3 * (size_t)n * sizeof(double));
+        P.pweight = d->point_constraint_weight;
+    }
+    if (!ok) return fail("upload");
+    P.x = pb->d_x; P.obs_cam = pb->d_obs_cam; P.obs_pt = pb->d_obs_pt; P.rowptr = pb->d_rowptr;
+    P.camptr = pb->d_camptr; P.camobs = pb->d_camobs; P.Rinit = pb->d_Rinit; P.finit = pb->d_finit;
+    P.ccon = pb->d_ccon; P.cval = pb->d_cval; P.cw = pb->d_cw; P.pcon = pb->d_pcon; P.pval = pb->d_pval;
+    P.J = pb->d_J; P.U = pb->d_U; P.ea = pb->d_ea; P.V = pb->d_V; P.Vinv = pb->d_Vinv; P.eb = pb->d_eb;
+    if (build_schur_structure(pb, d) != 0) return fail("schur structure");
+    if (potrf_init(pb->potrf, pb->ld, pb->opt.potrf_backend) != 0) return fail("potrf workspace");
+    pb->ev_ok = true;
+    for (int i = 0; i < PH_COUNT; ++i) {
+        if (hipEventCreate(&pb->ev[i][0]) != hipSuccess || hipEventCreate(&pb->ev[i][1]) != hipSuccess) pb->ev_ok = false;
+        pb->ph_ms[i] = 0.0; pb->ph_cnt[i] = 0;
+    }
+    (void)hipDeviceSynchronize();
+    return pb;
+}
+
+void bsfm_problem_destroy(bsfm_problem_t* pb)
+{
+    if (!pb) return;
+    (void)hipDeviceSynchronize();
+    free_all(pb);
+    delete pb;
+}
+
+void bsfm_problem_set_allreduce(bsfm_problem_t* pb, bsfm_allreduce_fn fn, void* ctx) { pb->allreduce = fn; pb->allreduce_ctx = ctx; }
+
+void bsfm_problem_set_stream(bsfm_problem_t* pb, void* s)
+{
+    (void)hipStreamSynchronize(pb->stream);
+    if (pb->own_stream && pb->stream) (void)hipStreamDestroy(pb->stream);
+    if (s) { pb->stream = (hipStream_t)s; pb->own_stream = false; }
+    else { (void)hipStreamCreateWithFlags(&pb->stream, hipStreamNonBlocking); pb->own_stream = true; }
+}
+
+int bsfm_problem_reset_params(bsfm_problem_t* pb, const bsfm_camera_params_t* cams, const double* pts)
+{
+    std::vector<double> p;
+    pack_params(pb, cams, pts, pb->P.n, p);
+    std::vector<double> finit(pb->P.m);
+    for (int j = 0; j < pb->P.m; ++j) { memcpy(&pb->h_Rinit[9 * (size_t)j], cams[j].R, 9 * sizeof(double)); finit[j] = cams[j].f; }
+    HIP_OK(hipMemcpy(pb->d_p, p.data(), p.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(pb->d_Rinit, pb->h_Rinit.data(), pb->h_Rinit.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(pb->d_finit, finit.data(), finit.size() * sizeof(double), hipMemcpyHostToDevice));
+    pb->began = 0;
+    return 0;
+}
+
+int bsfm_problem_cnp(const bsfm_problem_t* pb) { return pb->cnp; }
+long long bsfm_problem_nvis(const bsfm_problem_t* pb) { return pb->P.nvis; }
+int bsfm_lm_solve_attempts(const bsfm_problem_t* pb) { return pb->nlss; }
+
+double bsfm_lm_last_kernel_ms(const bsfm_problem_t* pb, const char* phase)
+{
+    for (int i = 0; i < PH_COUNT; ++i)
+        if (!strcmp(phase, kPhaseNames[i])) return pb->ph_cnt[i] ? pb->ph_ms[i] / pb->ph_cnt[i] : -1.0;
+    if (!strcmp(phase, "potrf")) return pb->potrf.cnt ? pb->potrf.ms / pb->potrf.cnt : -1.0;
+    return -1.0;
+}
+
+int bsfm_lm_begin(bsfm_problem_t* pb)
+{
+    const long long nobs = 2 * pb->nvis_global;
+    pb->itno = 0; pb->stop = 0; pb->nu = 2; pb->nfev = 0; pb->njev = 0; pb->nlss = 0; pb->error = 0;
+    pb->mu = 0.0; pb->eab_inf = 0.0; pb->dp_L2 = DBL_MAX; pb->p_L2 = 0.0; pb->maxdiag = DBL_MIN;
+    for (int i = 0; i < PH_COUNT; ++i) { pb->ph_ms[i] = 0.0; pb->ph_cnt[i] = 0; }
+    pb->potrf.ms = 0.0; pb->potrf.cnt = 0;
+    if (nobs < pb->nvars_global) {   // sba_levmar.c:647-650
+        fprintf(stderr, "SBA: sba_motstr_levmar_x() cannot solve a problem with fewer measurements [%lld] than unknowns [%lld]\n",
+                nobs, pb->nvars_global);
+        pb->error = 1; pb->began = 1;
+        return BSFM_ERROR;
+    }
+    launch_cam_table(pb, pb->d_p, pb->d_camtab);
+    launch_residual(pb, pb->d_camtab, pb->d_p, pb->d_e, nullptr, SC_COST);
+    hipLaunchKernelGGL(k_constraint_cost, dim3(1), dim3(256), 0, pb->stream, pb->P, pb->d_p,
+                       pb->d_p + (size_t)pb->P.m * pb->cnp, 1, pb->d_scal + SC_CCOST);
+    if (read_scalars(pb)) return BSFM_ERROR;
+    double v[2] = { pb->h_scal[SC_COST], 0.0 };
+    // point-constraint part of SC_CCOST is per rank, camera part replicated: split them for the reduction
+    if (pb->world > 1) {
+        hipLaunchKernelGGL(k_constraint_cost, dim3(1), dim3(256), 0, pb->stream, pb->P, pb->d_p,
+                           pb->d_p + (size_t)pb->P.m * pb->cnp, 0, pb->d_scal + SC_COUNT + 8);
+        HIP_OK(hipMemcpyAsync(&pb->h_scal[SC_COUNT + 8], pb->d_scal + SC_COUNT + 8, sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+        HIP_OK(hipStreamSynchronize(pb->stream));
+        const double ptpart = pb->h_scal[SC_COUNT + 8], campart = pb->h_scal[SC_CCOST] - ptpart;
+        v[1] = ptpart;
+        if (allreduce_host(pb, v, 2, 0)) return BSFM_ERROR;
+        pb->p_eL2 = v[0] + campart + v[1];
+    } else {
+        pb->p_eL2 = v[0] + pb->h_scal[SC_CCOST];
+    }
+    pb->nfev = 1;
+    if (pb->opt.verbose >= 2) printf("initial motstr-SBA error %g [%g]\n", pb->p_eL2, pb->p_eL2 / (double)pb->nvis_global);
+    pb->init_p_eL2 = pb->p_eL2;
+    if (!std::isfinite(pb->p_eL2)) pb->stop = 7;
+    pb->began = 1;
+    return 0;
+}
+
+int bsfm_lm_iterate(bsfm_problem_t* pb, int iters)
+{
+    if (!pb->began) { if (bsfm_lm_begin(pb) != 0) return BSFM_ERROR; }
+    if (pb->error) return BSFM_ERROR;
+    const int cnp = pb->cnp;
+    DevProblem& P = pb->P;
+    const int itmax = pb->opt.itmax;
+    const double tau = fabs(pb->opt.opts[0]), eps1 = fabs(pb->opt.opts[1]), eps2 = fabs(pb->opt.opts[2]),
+                 eps2_sq = pb->opt.opts[2] * pb->opt.opts[2], eps3_sq = pb->opt.opts[3] * pb->opt.opts[3],
+                 eps4_sq = pb->opt.opts[4] * pb->opt.opts[4], eps5 = pb->opt.opts[5];
+    double* d_pa = pb->d_p; double* d_pb = pb->d_p + (size_t)P.m * cnp;
+    double* d_dpa = pb->d_dp; double* d_dpb = pb->d_dp + (size_t)P.m * cnp;
+    double* d_pdpa = pb->d_pdp; double* d_pdpb = pb->d_pdp + (size_t)P.m * cnp;
+    const int nbp = grid_for(P.n, 256);
+    int done = 0;
+
+    for (; pb->itno < itmax && !pb->stop && done < iters; ++pb->itno, ++done) {
+        if (compute_normal_blocks(pb)) return BSFM_ERROR;
+        ++pb->njev;
+        // ||J^T e||_inf, ||p||^2, max diagonal (sba_levmar.c:1085-1128)
+        hipLaunchKernelGGL(k_absmax_partial, dim3(1), dim3(256), 0, pb->stream, pb->d_ea, (size_t)P.m * cnp, pb->d_scal + SC_EABINF_A);
+        hipLaunchKernelGGL(k_absmax_partial, dim3(256), dim3(256), 0, pb->stream, pb->d_eb, (size_t)3 * P.n, pb->d_red);
+        hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, pb->stream, pb->d_red, 256, pb->d_scal + SC_EABINF_B);
+        hipLaunchKernelGGL(k_udiag_max, dim3(1), dim3(256), 0, pb->stream, pb->d_U, P.m, P.mcon, cnp, pb->d_scal + SC_MAXDIAG_U);
+        hipLaunchKernelGGL(k_vdiag_max_partial, dim3(256), dim3(256), 0, pb->stream, pb->d_V, P.n, pb->d_red + 256);
+        hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, pb->stream, pb->d_red + 256, 256, pb->d_scal + SC_MAXDIAG_V);
+        hipLaunchKernelGGL(k_sumsq_partial, dim3(1), dim3(256), 0, pb->stream, d_pa, (size_t)P.m * cnp, pb->d_scal + SC_PL2_A);
+        hipLaunchKernelGGL(k_sumsq_partial, dim3(256), dim3(256), 0, pb->stream, d_pb, (size_t)3 * P.n, pb->d_red + 512);
+        hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, pb->stream, pb->d_red + 512, 256, pb->d_scal + SC_PL2_B);
+        hipLaunchKernelGGL(k_constraint_cost, dim3(1), dim3(256), 0, pb->stream, P, d_pa, d_pb, 1, pb->d_scal + SC_CCOST);
+        if (pb->world > 1)
+            hipLaunchKernelGGL(k_constraint_cost, dim3(1), dim3(256), 0, pb->stream, P, d_pa, d_pb, 0, pb->d_scal + SC_COUNT + 8);
+        if (read_scalars(pb)) return BSFM_ERROR;
+        const double vmaxdiag = pb->h_scal[SC_MAXDIAG_V];   // diagonals are sums of squares (>= 0): a 0-based max is exact
+        double ccost = pb->h_scal[SC_CCOST];
+        {
+            double mx[2] = { pb->h_scal[SC_EABINF_B], vmaxdiag };
+            double sm[2] = { pb->h_scal[SC_PL2_B], 0.0 };
+            if (pb->world > 1) {
+                HIP_OK(hipMemcpy(&sm[1], pb->d_scal + SC_COUNT + 8, sizeof(double), hipMemcpyDeviceToHost));
+                const double campart = ccost - sm[1];
+                if (allreduce_host(pb, mx, 2, 1) || allreduce_host(pb, sm, 2, 0)) return BSFM_ERROR;
+                ccost = campart + sm[1];
+            }
+            pb->eab_inf = std::max(pb->h_scal[SC_EABINF_A], mx[0]);
+            pb->p_L2 = pb->h_scal[SC_PL2_A] + sm[0];
+            double md = DBL_MIN;
+            if (pb->h_scal[SC_MAXDIAG_U] > md) md = pb->h_scal[SC_MAXDIAG_U];
+            if (mx[1] > md) md = mx[1];
+            pb->maxdiag = md;
+        }
+        if (pb->eab_inf <= eps1) { pb->dp_L2 = 0.0; pb->stop = 1; break; }
+        if (pb->itno == 0) pb->mu = tau * pb->maxdiag;
+
+        while (1) {   // determine increment using adaptive damping (sba_levmar.c:1131)
+            const double mu = pb->mu;
+            (void)hipMemsetAsync(pb->d_flags, 0, 4 * sizeof(int), pb->stream);
+            ph_begin(pb, PH_INVERT);
+            if (P.n > 0) hipLaunchKernelGGL(k_point_invert, dim3(nbp), dim3(256), 0, pb->stream, P.n, mu, pb->d_V, pb->d_Vinv, pb->d_flags);
+            ph_end(pb, PH_INVERT);
+            ph_begin(pb, PH_SCHUR);
+            if (compute_schur(pb, mu)) return BSFM_ERROR;
+            ph_end(pb, PH_SCHUR);
+            ph_begin(pb, PH_SOLVE);
+            // S dpa = E, Cholesky (sba_Axb_Chol, lib/sba-1.5/sba_lapack.c:374-485); info -> d_flags[1]
+            if (potrf_solve(pb->potrf, pb->d_S, pb->ld, pb->Sdim, pb->d_E, d_dpa + (size_t)P.mcon * cnp, pb->d_flags + 1, pb->stream)) return BSFM_ERROR;
+            ph_end(pb, PH_SOLVE);
+            if (P.mcon > 0) (void)hipMemsetAsync(d_dpa, 0, (size_t)P.mcon * cnp * sizeof(double), pb->stream);
+            ph_begin(pb, PH_BACKSUB);
+            if (P.n > 0) DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_backsub<C>), dim3(nbp), dim3(256), 0, pb->stream, P, mu, d_dpa, d_pb, d_dpb, d_pdpb, pb->d_red));
+            for (int q = 0; q < 3; ++q)
+                hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, pb->stream, pb->d_red + (size_t)q * nbp, P.n > 0 ? nbp : 0, pb->d_scal + SC_PT_DP + q);
+            hipLaunchKernelGGL(k_cam_step, dim3(1), dim3(256), 0, pb->stream, P.m * cnp, P.mcon * cnp, mu, d_pa, d_dpa, pb->d_ea, d_pdpa, pb->d_scal + SC_CAM3);
+            ph_end(pb, PH_BACKSUB);
+            ph_begin(pb, PH_RESID);
+            launch_cam_table(pb, pb->d_pdp, pb->d_camtab_trial);
+            launch_residual(pb, pb->d_camtab_trial, pb->d_pdp, pb->d_hx, pb->d_e, SC_COST_TRIAL);
+            ph_end(pb, PH_RESID);
+            if (read_scalars(pb)) return BSFM_ERROR;
+            collect_phase_times(pb);
+
+            double flagsd[1] = { (double)pb->h_flags[0] };
+            double sums[4] = { pb->h_scal[SC_PT_DP], pb->h_scal[SC_PT_DL], pb->h_scal[SC_COST_TRIAL], 0.0 };
+            double maxs[1] = { pb->h_scal[SC_PCT] };
+            if (pb->world > 1) {
+                double mx2[2] = { flagsd[0], maxs[0] };
+                if (allreduce_host(pb, mx2, 2, 1) || allreduce_host(pb, sums, 3, 0)) return BSFM_ERROR;
+                flagsd[0] = mx2[0]; maxs[0] = mx2[1];
+            }
+            const bool singularV = flagsd[0] != 0.0;
+            const int potrf_info = pb->h_flags[1];
+            bool accepted = false;
+            if (singularV) {
+                fprintf(stderr, "SBA: singular matrix V*_i in sba_motstr_levmar_x(), increasing damping\n");
+            } else {
+                ++pb->nlss;
+                const bool issolved = potrf_info == 0;
+                if (!issolved)
+                    fprintf(stderr, "LAPACK error: the leading minor of order %d is not positive definite,\nthe factorization could not be completed for dpotf2/dpotrf in sba_Axb_Chol()\n", potrf_info);
+                if (issolved) {
+                    pb->dp_L2 = pb->h_scal[SC_CAM3 + 0] + sums[0];
+                    const double dL = pb->h_scal[SC_CAM3 + 2] + sums[1];
+                    if (pb->dp_L2 <= eps2_sq * pb->p_L2) { pb->stop = 2; break; }
+                    if (pb->dp_L2 >= (pb->p_L2 + eps2) / SBA_EPSILON_SQ) {
+                        fprintf(stderr, "SBA: the matrix of the augmented normal equations is almost singular in sba_motstr_levmar_x(),\n"
+                                        "     minimization should be restarted from the current solution with an increased damping term\n");
+                        pb->error = 1;
+                        return BSFM_ERROR;
+                    }
+                    ++pb->nfev;
+                    double pdp_eL2 = sums[2];
+                    if (!std::isfinite(pdp_eL2)) { pb->stop = 7; break; }
+                    pdp_eL2 += ccost;   // constraint terms evaluated at the OLD p (sba_levmar.c:1488-1522)
+                    const double dF = pb->p_eL2 - pdp_eL2;
+                    if (pb->opt.verbose >= 2) {
+                        printf("\ndamping term %8g, gain ratio %8g, errors %8g / %8g = %g\n", mu, dL != 0.0 ? dF / dL : dF / DBL_EPSILON,
+                               pb->p_eL2 / (double)pb->nvis_global, pdp_eL2 / (double)pb->nvis_global, pb->p_eL2 / pdp_eL2);
+                        printf("pdp_eL2: %0.3f, nvis: %lld\n", pdp_eL2, pb->nvis_global);
+                    }
+                    if (dL > 0.0 && dF > 0.0) {
+                        double tmp = (2.0 * dF / dL - 1.0);
+                        tmp = 1.0 - tmp * tmp * tmp;
+                        pb->mu = pb->mu * ((tmp >= SBA_ONE_THIRD) ? tmp : SBA_ONE_THIRD);
+                        pb->nu = 2;
+                        const double max_pct_change = maxs[0];
+                        if (pb->opt.verbose >= 2) printf("max_pct_change: %0.3e\n", max_pct_change);
+                        if (pdp_eL2 - 2.0 * sqrt(pb->p_eL2 * pdp_eL2) < (eps4_sq - 1.0) * pb->p_eL2) pb->stop = 4;
+                        if (max_pct_change < eps5 && pb->itno >= 4) { pb->stop = 8; break; }   // p NOT updated (sba_levmar.c:1569-1572)
+                        std::swap(pb->d_p, pb->d_pdp);
+                        std::swap(pb->d_e, pb->d_hx);
+                        std::swap(pb->d_camtab, pb->d_camtab_trial);
+                        d_pa = pb->d_p; d_pb = pb->d_p + (size_t)P.m * cnp;
+                        d_pdpa = pb->d_pdp; d_pdpb = pb->d_pdp + (size_t)P.m * cnp;
+                        pb->p_eL2 = pdp_eL2;
+                        accepted = true;
+                    }
+                }
+            }
+            if (accepted) break;
+            // moredamping (sba_levmar.c:1584-1611)
+            pb->mu *= pb->nu;
+            const int nu2 = (int)((unsigned)pb->nu << 1);
+            if (nu2 <= pb->nu) {
+                fprintf(stderr, "SBA: too many failed attempts to increase the damping factor in sba_motstr_levmar_x()! Singular Hessian matrix?\n");
+                pb->stop = 6;
+                break;
+            }
+            pb->nu = nu2;
+        }
+        if (pb->p_eL2 <= eps3_sq) pb->stop = 5;
+    }
+    if (pb->itno >= itmax) pb->stop = 3;
+    return pb->stop;
+}
+
+int bsfm_lm_finish(bsfm_problem_t* pb, double info[BSFM_INFOSZ])
+{
+    if (!pb->began) return BSFM_ERROR;
+    if (info) {   // sba_levmar.c:2028-2049 and the nvis scaling of sba_levmar_wrap.c:684-695
+        info[0] = pb->init_p_eL2; info[1] = pb->p_eL2; info[2] = pb->eab_inf; info[3] = pb->dp_L2;
+        info[4] = pb->mu / pb->maxdiag; info[5] = pb->itno; info[6] = pb->stop;
+        info[7] = (double)pb->nfev * (double)pb->nvis_global; info[8] = (double)pb->njev * (double)pb->nvis_global; info[9] = pb->nlss;
+    }
+    if (pb->error) return BSFM_ERROR;
+    return (pb->stop != 7) ? pb->itno : BSFM_ERROR;
+}
+
+int bsfm_problem_download(bsfm_problem_t* pb, double* p_out, bsfm_camera_params_t* cams, double* pts)
+{
+    const int cnp = pb->cnp, m = pb->P.m, n = pb->P.n;
+    std::vector<double> p(pb->nvars_local);
+    HIP_OK(hipStreamSynchronize(pb->stream));
+    HIP_OK(hipMemcpy(p.data(), pb->d_p, p.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if (p_out) memcpy(p_out, p.data(), p.size() * sizeof(double));
+    if (cams) {   // sfm.c:876-922
+        const ModelCfg& c = pb->P.cfg;
+        for (int j = 0; j < m; ++j) {
+            const double* a = &p[(size_t)j * cnp];
+            cams[j].t[0] = a[0]; cams[j].t[1] = a[1]; cams[j].t[2] = a[2];
+            // rot_update on the host (sfm.c:77-116)
+            const double* R0 = &pb->h_Rinit[9 * (size_t)j];
+            const double w0 = a[3], w1 = a[4], w2 = a[5];
+            const double th = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+            double Rn[9];
+            if (th == 0.0) memcpy(Rn, R0, sizeof(Rn));
+            else {
+                const double nn[3] = { w0 / th, w1 / th, w2 / th };
+                const double nx[9] = { 0.0, -nn[2], nn[1], nn[2], 0.0, -nn[0], -nn[1], nn[0], 0.0 };
+                double nxsq[9], dR[9];
+                for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc)
+                    nxsq[3 * r + cc] = nx[3 * r] * nx[cc] + nx[3 * r + 1] * nx[3 + cc] + nx[3 * r + 2] * nx[6 + cc];
+                const double s = sin(th), c1 = 1.0 - cos(th);
+                for (int k = 0; k < 9; ++k) dR[k] = ((k % 4 == 0) ? 1.0 : 0.0) + nx[k] * s + nxsq[k] * c1;
+                for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc)
+                    Rn[3 * r + cc] = dR[3 * r] * R0[cc] + dR[3 * r + 1] * R0[3 + cc] + dR[3 * r + 2] * R0[6 + cc];
+            }
+            memcpy(cams[j].R, Rn, sizeof(Rn));
+            int col = 6;
+            if (c.est_focal) { cams[j].f = a[6] / c.f_scale; col = 7; }
+            if (c.undistort) { cams[j].k[0] = a[col] / c.k_scale; cams[j].k[1] = a[col + 1] / c.k_scale; }
+            cams[j].f_scale = 1.0; cams[j].k_scale = 1.0;
+        }
+    }
+    if (pts && n) memcpy(pts, &p[(size_t)m * cnp], sizeof(double) * 3 * n);
+    return 0;
+}
+
+int bsfm_eval_residuals(bsfm_problem_t* pb, double* e_out, double* cost)
+{
+    launch_cam_table(pb, pb->d_p, pb->d_camtab);
+    launch_residual(pb, pb->d_camtab, pb->d_p, pb->d_e, nullptr, SC_COST);
+    hipLaunchKernelGGL(k_constraint_cost, dim3(1), dim3(256), 0, pb->stream, pb->P, pb->d_p,
+                       pb->d_p + (size_t)pb->P.m * pb->cnp, 1, pb->d_scal + SC_CCOST);
+    if (read_scalars(pb)) return BSFM_ERROR;
+    if (cost) *cost = pb->h_scal[SC_COST] + pb->h_scal[SC_CCOST];
+    if (e_out && pb->P.nvis) HIP_OK(hipMemcpy(e_out, pb->d_e, 2 * (size_t)pb->P.nvis * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int bsfm_eval_normal_equations(bsfm_problem_t* pb, double mu, double* U, double* ea, double* V, double* eb,
+                               double* J, double* S, double* E)
+{
+    const int cnp = pb->cnp, m = pb->P.m, n = pb->P.n;
+    launch_cam_table(pb, pb->d_p, pb->d_camtab);
+    launch_residual(pb, pb->d_camtab, pb->d_p, pb->d_e, nullptr, SC_COST);
+    if (compute_normal_blocks(pb)) return BSFM_ERROR;
+    (void)hipMemsetAsync(pb->d_flags, 0, 4 * sizeof(int), pb->stream);
+    if (n > 0) hipLaunchKernelGGL(k_point_invert, dim3(grid_for(n, 256)), dim3(256), 0, pb->stream, n, mu, pb->d_V, pb->d_Vinv, pb->d_flags);
+    if (compute_schur(pb, mu)) return BSFM_ERROR;
+    HIP_OK(hipStreamSynchronize(pb->stream));
+    if (U) {
+        std::vector<double> h((size_t)m * cnp * cnp);
+        HIP_OK(hipMemcpy(h.data(), pb->d_U, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int j = pb->P.mcon; j < m; ++j) for (int q = 0; q < cnp; ++q) h[(size_t)j * cnp * cnp + q * cnp + q] += mu;
+        memcpy(U, h.data(), h.size() * sizeof(double));
+    }
+    if (ea) HIP_OK(hipMemcpy(ea, pb->d_ea, (size_t)m * cnp * sizeof(double), hipMemcpyDeviceToHost));
+    if (V && n) {
+        double* tmp = nullptr;
+        HIP_OK(dmalloc(&tmp, 9 * (size_t)n));
+        hipLaunchKernelGGL(k_expand_v, dim3(grid_for(n, 256)), dim3(256), 0, pb->stream, n, mu, pb->d_V, tmp);
+        HIP_OK(hipStreamSynchronize(pb->stream));
+        HIP_OK(hipMemcpy(V, tmp, 9 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+        (void)hipFree(tmp);
+    }
+    if (eb && n) HIP_OK(hipMemcpy(eb, pb->d_eb, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    if (J && pb->P.nvis) HIP_OK(hipMemcpy(J, pb->d_J, (size_t)pb->P.nvis * pb->P.js * sizeof(double), hipMemcpyDeviceToHost));
+    if (S && pb->Sdim) HIP_OK(hipMemcpy2D(S, (size_t)pb->Sdim * sizeof(double), pb->d_S, (size_t)pb->ld * sizeof(double),
+                                          (size_t)pb->Sdim * sizeof(double), pb->Sdim, hipMemcpyDeviceToHost));
+    if (E && pb->Sdim) HIP_OK(hipMemcpy(E, pb->d_E, (size_t)pb->Sdim * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int bsfm_dense_chol_solve(int n, const double* A, const double* b, double* x, int backend)
+{
+    if (bsfm_device_count() <= 0) { fprintf(stderr, "[bsfm] FATAL: no usable HIP device\n"); return BSFM_ERROR; }
+    if (n <= 0) return BSFM_ERROR;
+    const int ld = std::max(POTRF_NB, (n + POTRF_NB - 1) / POTRF_NB * POTRF_NB);
+    PotrfWorkspace ws;
+    if (potrf_init(ws, ld, backend)) return BSFM_ERROR;
+    double *dS = nullptr, *dE = nullptr, *dx = nullptr; int* dinfo = nullptr;
+    int rc = BSFM_ERROR, info = 0;
+    hipStream_t st = nullptr;
+    do {
+        if (hipStreamCreate(&st) != hipSuccess) break;
+        if (dmalloc(&dS, (size_t)ld * ld) != hipSuccess || dmalloc(&dE, ld) != hipSuccess || dmalloc(&dx, ld) != hipSuccess || dmalloc(&dinfo, 1) != hipSuccess) break;
+        if (hipMemset(dS, 0, (size_t)ld * ld * sizeof(double)) != hipSuccess || hipMemset(dE, 0, ld * sizeof(double)) != hipSuccess || hipMemset(dinfo, 0, sizeof(int)) != hipSuccess) break;
+        if (hipMemcpy2D(dS, (size_t)ld * sizeof(double), A, (size_t)n * sizeof(double), (size_t)n * sizeof(double), n, hipMemcpyHostToDevice) != hipSuccess) break;
+        if (hipMemcpy(dE, b, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) break;
+        if (potrf_solve(ws, dS, ld, n, dE, dx, dinfo, st)) break;
+        if (hipStreamSynchronize(st) != hipSuccess) break;
+        if (hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) break;
+        if (hipMemcpy(x, dx, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) break;
+        rc = info;
+    } while (0);
+    if (dS) (void)hipFree(dS); if (dE) (void)hipFree(dE); if (dx) (void)hipFree(dx); if (dinfo) (void)hipFree(dinfo);
+    if (st) (void)hipStreamDestroy(st);
+    potrf_free(ws);
+    return rc;
+}
+
+}  // extern "C"

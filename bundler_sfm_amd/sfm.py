@@ -1,0 +1,195 @@
+"""Host-side mirror of the reference's sfm-driver interface on top of the C-ABI.
+
+`run_sfm` has the argument meaning of lib/sfm-driver/sfm.h:68-86 (numpy arrays instead of raw pointers);
+`Problem` wraps the resident-problem API (include/bsfm.h section 3) used by bench.py and the multi-GPU path.
+All compute happens in libbsfm_hip.so on the GPU.
+"""
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import CameraParams, Options, ProblemDesc, lib
+
+SYNTH_SEED = 88172645463325252
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def default_options(**kw):
+    o = Options()
+    lib.bsfm_default_options(C.byref(o))
+    for k, v in kw.items():
+        if k == "opts":
+            for i, x in enumerate(v):
+                o.opts[i] = x
+        else:
+            setattr(o, k, v)
+    return o
+
+
+def make_cameras(m):
+    return (CameraParams * m)()
+
+
+def copy_cameras(cams):
+    out = (CameraParams * len(cams))()
+    C.memmove(out, cams, C.sizeof(out))
+    return out
+
+
+def synth_ba(m, n, deg=10, seed=SYNTH_SEED, banded=False):
+    """Deterministic synthetic scene of SURVEY.md 8(d). Returns dict(rowptr, colidx, proj, cams, pts)."""
+    rowptr = np.zeros(n + 1, np.int32)
+    colidx = np.zeros(n * deg, np.int32)
+    proj = np.zeros(2 * n * deg, np.float64)
+    pts = np.zeros(3 * n, np.float64)
+    cams = make_cameras(m)
+    rc = lib.bsfm_synth_ba(m, n, deg, seed, int(banded), _ip(rowptr), _ip(colidx), _dp(proj), cams, _dp(pts))
+    if rc != 0:
+        raise ValueError("bsfm_synth_ba rejected the configuration")
+    return dict(m=m, n=n, rowptr=rowptr, colidx=colidx, proj=proj, cams=cams, pts=pts)
+
+
+def dense_vmask(n, m, rowptr, colidx):
+    vm = np.zeros((n, m), np.uint8)
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    vm[rows, colidx] = 1
+    return vm
+
+
+def run_sfm(num_pts, num_cameras, ncons, vmask, projections, est_focal_length, const_focal_length, undistort,
+            explicit_camera_centers, cameras, pts, use_constraints=0, use_point_constraints=0,
+            points_constraints=None, point_constraint_weight=0.0, fix_points=0, optimize_for_fisheye=0,
+            eps2=1e-12, Vout=None, Sout=None, Uout=None, Wout=None, options=None, want_info=True):
+    """Reference signature (sfm.h:68-86). cameras (ctypes array) and pts (float64 3n) are updated in place.
+    Returns (rc, info[10])."""
+    vm = np.ascontiguousarray(vmask, dtype=np.uint8)
+    info = np.zeros(_lib.INFOSZ)
+    rc = lib.bsfm_run_sfm_ex(num_pts, num_cameras, ncons, vm.ctypes.data_as(C.c_char_p), _dp(projections),
+                             est_focal_length, const_focal_length, undistort, explicit_camera_centers, cameras,
+                             _dp(pts), use_constraints, use_point_constraints, _dp(points_constraints),
+                             point_constraint_weight, fix_points, optimize_for_fisheye, eps2,
+                             _dp(Vout), _dp(Sout), _dp(Uout), _dp(Wout),
+                             C.byref(options) if options is not None else None, _dp(info))
+    return rc, info
+
+
+class Problem:
+    """Device-resident BA problem (sparse CRS boundary)."""
+
+    def __init__(self, n, m, rowptr, colidx, proj, cams, pts, mcon=0, est_focal_length=1, undistort=1,
+                 explicit_camera_centers=1, use_constraints=0, point_constraints=None, point_constraint_weight=0.0,
+                 options=None, world_size=1, rank=0, nvis_global=0, nvars_global=0):
+        self._keep = (np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(colidx, np.int32),
+                      np.ascontiguousarray(proj, np.float64), cams, np.ascontiguousarray(pts, np.float64),
+                      None if point_constraints is None else np.ascontiguousarray(point_constraints, np.float64))
+        d = ProblemDesc()
+        d.n, d.m, d.mcon = n, m, mcon
+        d.rowptr, d.colidx, d.projections = _ip(self._keep[0]), _ip(self._keep[1]), _dp(self._keep[2])
+        d.est_focal_length, d.undistort, d.explicit_camera_centers = est_focal_length, undistort, explicit_camera_centers
+        d.cameras = C.cast(cams, C.POINTER(CameraParams))
+        d.points = _dp(self._keep[4])
+        d.use_constraints = use_constraints
+        d.use_point_constraints = 0 if point_constraints is None else 1
+        d.point_constraints = _dp(self._keep[5])
+        d.point_constraint_weight = point_constraint_weight
+        d.world_size, d.rank, d.nvis_global, d.nvars_global = world_size, rank, nvis_global, nvars_global
+        self.options = options if options is not None else default_options()
+        self.n, self.m = n, m
+        self.h = lib.bsfm_problem_create(C.byref(d), C.byref(self.options))
+        if not self.h:
+            raise RuntimeError("bsfm_problem_create failed (no HIP device or invalid input); there is no CPU fallback")
+        self.cnp = lib.bsfm_problem_cnp(self.h)
+        self.nvis = int(lib.bsfm_problem_nvis(self.h))
+        self._hook = None
+
+    def close(self):
+        if self.h:
+            lib.bsfm_problem_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_allreduce(self, fn):
+        self._hook = _lib.ALLREDUCE_FN(fn)
+        lib.bsfm_problem_set_allreduce(self.h, self._hook, None)
+
+    def set_stream(self, stream_ptr):
+        lib.bsfm_problem_set_stream(self.h, C.c_void_p(stream_ptr))
+
+    def reset_params(self, cams, pts):
+        pts = np.ascontiguousarray(pts, np.float64)
+        return lib.bsfm_problem_reset_params(self.h, cams, _dp(pts))
+
+    def lm_begin(self):
+        return lib.bsfm_lm_begin(self.h)
+
+    def lm_iterate(self, iters):
+        return lib.bsfm_lm_iterate(self.h, iters)
+
+    def lm_finish(self):
+        info = np.zeros(_lib.INFOSZ)
+        rc = lib.bsfm_lm_finish(self.h, _dp(info))
+        return rc, info
+
+    def solve(self, itmax=None):
+        if itmax is not None:
+            self.options.itmax = itmax
+        rc = self.lm_begin()
+        if rc == 0:
+            self.lm_iterate(self.options.itmax)
+        return self.lm_finish()
+
+    def attempts(self):
+        return lib.bsfm_lm_solve_attempts(self.h)
+
+    def phase_ms(self, name):
+        return lib.bsfm_lm_last_kernel_ms(self.h, name.encode())
+
+    def download(self, want_cams=True):
+        p = np.zeros(self.m * self.cnp + 3 * self.n)
+        cams = make_cameras(self.m) if want_cams else None
+        if want_cams:
+            C.memmove(cams, self._keep[3], C.sizeof(cams))
+        pts = np.zeros(3 * self.n)
+        rc = lib.bsfm_problem_download(self.h, _dp(p), cams, _dp(pts))
+        if rc != 0:
+            raise RuntimeError("download failed")
+        return p, cams, pts
+
+    def residuals(self):
+        e = np.zeros(2 * self.nvis)
+        cost = C.c_double()
+        if lib.bsfm_eval_residuals(self.h, _dp(e), C.byref(cost)) != 0:
+            raise RuntimeError("bsfm_eval_residuals failed")
+        return e, cost.value
+
+    def normal_equations(self, mu=0.0, want_J=False):
+        cnp, m, n = self.cnp, self.m, self.n
+        mm = m  # mcon handled by the library (S is (m-mcon)*cnp wide)
+        U = np.zeros((m, cnp, cnp)); ea = np.zeros((m, cnp)); V = np.zeros((n, 3, 3)); eb = np.zeros((n, 3))
+        J = np.zeros((self.nvis, 2 * cnp + 6)) if want_J else None
+        sd = (m - self._mcon()) * cnp
+        S = np.zeros((sd, sd)); E = np.zeros(sd)
+        rc = lib.bsfm_eval_normal_equations(self.h, mu, _dp(U), _dp(ea), _dp(V), _dp(eb), _dp(J), _dp(S), _dp(E))
+        if rc != 0:
+            raise RuntimeError("bsfm_eval_normal_equations failed")
+        return dict(U=U, ea=ea, V=V, eb=eb, J=J, S=S, E=E)
+
+    def _mcon(self):
+        return getattr(self, "mcon", 0)
+
+
+def dense_chol_solve(A, b, backend=0):
+    A = np.ascontiguousarray(A, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    x = np.zeros_like(b)
+    rc = lib.bsfm_dense_chol_solve(A.shape[0], _dp(A), _dp(b), _dp(x), backend)
+    return rc, x

@@ -1,0 +1,195 @@
+/* include/bsfm.h -- C ABI of libbsfm_hip.so (MI355X / gfx950 sparse bundle-adjustment core + SIFT matcher).
+ *
+ * Everything here is `extern "C"`, plain pointers and sizes.  Paths in comments are relative to the
+ * reference tree (snavely/bundler_sfm); each entry point cites the reference interface it replaces.
+ *
+ *   1. Drop-in boundary      run_sfm                  <- lib/sfm-driver/sfm.h:68-86 (sfm.c:592-1003)
+ *   2. Extended boundary     bsfm_run_sfm_ex          <- same, but returns SBA's info[10]
+ *                                                        (lib/sba-1.5/sba_levmar.c:512-527) and takes options
+ *   3. Resident-problem API  bsfm_problem_* / bsfm_lm_*   sparse (CRS) boundary of SURVEY section 8(f).2:
+ *                                                        the visibility map is passed the way SBA builds it
+ *                                                        internally (lib/sba-1.5/sba_levmar.c:653-663)
+ *                                                        instead of the dense vmask; state stays in HBM
+ *   4. Matcher               bsfm_match_keys_l2       <- MatchKeys, src/keys2a.h:99-107 (keys2a.cpp:347-372)
+ *                            bsfm_key_match_full      <- KeyMatchFull main loop, src/KeyMatchFull.cpp:105-151
+ *
+ * Error behaviour mirrors the reference: nothing throws across the boundary, run_sfm returns void and
+ * prints the same two summary lines (sfm.c:872-873); the *_ex / bsfm_* entries return SBA's code
+ * (iterations >= 0, or BSFM_ERROR = SBA_ERROR = -1, lib/sba-1.5/sba.h:57) and fill info[].
+ * There is NO CPU fallback: when no HIP device is usable every compute entry fails loudly
+ * (message on stderr, BSFM_ERROR / NULL).
+ */
+#ifndef BSFM_H
+#define BSFM_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSFM_ERROR (-1)
+#define BSFM_INFOSZ 10
+#define BSFM_NUM_CAMERA_PARAMS 9
+#define BSFM_POLY_INVERSE_DEGREE 6
+
+/* Layout-identical to v3_t / v2_t (lib/matrix/vector.h:59-67). */
+typedef struct { double p[3]; } bsfm_v3_t;
+typedef struct { double p[2]; } bsfm_v2_t;
+
+/* Layout-identical to camera_params_t (lib/sfm-driver/sfm.h:32-51); sizeof == 504 on LP64. */
+typedef struct {
+    double R[9];
+    double t[3];
+    double f;
+    double k[2];
+    double k_inv[BSFM_POLY_INVERSE_DEGREE];
+    char constrained[BSFM_NUM_CAMERA_PARAMS];
+    double constraints[BSFM_NUM_CAMERA_PARAMS];
+    double weights[BSFM_NUM_CAMERA_PARAMS];
+    double K_known[9];
+    double k_known[5];
+    char fisheye;
+    char known_intrinsics;
+    double f_cx, f_cy;
+    double f_rad, f_angle;
+    double f_focal;
+    double f_scale, k_scale;
+} bsfm_camera_params_t;
+
+/* Jacobian used by the LM loop. */
+enum {
+    BSFM_JAC_FD = 0,       /* forward differences with the reference's steps
+                              (lib/sba-1.5/sba_levmar_wrap.c:203-256): reference-identical semantics */
+    BSFM_JAC_ANALYTIC = 1  /* closed-form derivative of the same model (no counterpart in Bundler,
+                              which passes projac=NULL, sfm.c:820-828) */
+};
+
+typedef struct {
+    int jacobian;        /* BSFM_JAC_FD (default for run_sfm) or BSFM_JAC_ANALYTIC */
+    int itmax;           /* default 150  (MAX_ITERS, sfm.c:814) */
+    int verbose;         /* 0 silent; >=1 prints the two run_sfm summary lines; >=2 per-iteration lines */
+    double opts[6];      /* tau, eps1, eps2, eps3, eps4, eps5 (sfm.c:705-714); eps2 is overwritten by the
+                            run_sfm argument */
+    int potrf_backend;   /* 0 = own MFMA-f64 tiled Cholesky (default), 1 = rocSOLVER cross-check (dlopen) */
+} bsfm_options_t;
+
+void bsfm_default_options(bsfm_options_t *opt);
+
+/* ---- 1. drop-in boundary: identical signature to lib/sfm-driver/sfm.h:68-86 ------------------------- */
+void run_sfm(int num_pts, int num_cameras, int ncons,
+             char *vmask, double *projections,
+             int est_focal_length, int const_focal_length,
+             int undistort, int explicit_camera_centers,
+             bsfm_camera_params_t *init_camera_params, bsfm_v3_t *init_pts,
+             int use_constraints, int use_point_constraints,
+             bsfm_v3_t *points_constraints, double point_constraint_weight,
+             int fix_points, int optimize_for_fisheye, double eps2,
+             double *Vout, double *Sout, double *Uout, double *Wout);
+
+/* ---- 2. same, returning SBA's code and info[10]; opt may be NULL ------------------------------------ */
+int bsfm_run_sfm_ex(int num_pts, int num_cameras, int ncons,
+                    char *vmask, double *projections,
+                    int est_focal_length, int const_focal_length,
+                    int undistort, int explicit_camera_centers,
+                    bsfm_camera_params_t *init_camera_params, bsfm_v3_t *init_pts,
+                    int use_constraints, int use_point_constraints,
+                    bsfm_v3_t *points_constraints, double point_constraint_weight,
+                    int fix_points, int optimize_for_fisheye, double eps2,
+                    double *Vout, double *Sout, double *Uout, double *Wout,
+                    const bsfm_options_t *opt, double info[BSFM_INFOSZ]);
+
+/* ---- 3. resident-problem API ------------------------------------------------------------------------ */
+typedef struct bsfm_problem bsfm_problem_t;
+
+typedef struct {
+    int n, m, mcon;              /* points, cameras, leading fixed cameras (SBA's mcon) */
+    const int *rowptr;           /* n+1: CRS row pointers, one row per point (sba_levmar.c:653-663) */
+    const int *colidx;           /* nvis: camera index of each observation, ascending within a row */
+    const double *projections;   /* 2*nvis measurements in CRS order (== vmask row-major order) */
+    int est_focal_length, undistort, explicit_camera_centers;
+    const bsfm_camera_params_t *cameras;   /* m */
+    const double *points;        /* 3*n */
+    int use_constraints;         /* camera constraints taken from cameras[j].constrained/constraints/weights */
+    int use_point_constraints;
+    const double *point_constraints;       /* 3*n or NULL; all-zero row = unconstrained (sfm.c:757-781) */
+    double point_constraint_weight;
+    /* multi-GPU: this rank owns the points listed above (all their observations); cameras
+     * are replicated.  nvis_global is the job-wide observation count (point-constraint weights scale by
+     * it, sba_levmar.c:1017-1028); 0 means "same as local". */
+    int world_size, rank;
+    long long nvis_global;
+    long long nvars_global;      /* m*cnp + 3*n_global, for the nobs<nvars check; 0 = local */
+} bsfm_problem_desc_t;
+
+/* Sum-reduce `count` doubles in place across ranks (device pointer); op 0 = sum, 1 = max.
+ * Called by the LM loop at its exchange steps when world_size > 1.  Must return 0 on success. */
+typedef int (*bsfm_allreduce_fn)(void *device_buf, size_t count, int op, void *ctx);
+
+bsfm_problem_t *bsfm_problem_create(const bsfm_problem_desc_t *desc, const bsfm_options_t *opt);
+void bsfm_problem_destroy(bsfm_problem_t *pb);
+void bsfm_problem_set_allreduce(bsfm_problem_t *pb, bsfm_allreduce_fn fn, void *ctx);
+/* Use an externally owned HIP stream (e.g. torch's current stream) for every launch; NULL = own stream. */
+void bsfm_problem_set_stream(bsfm_problem_t *pb, void *hip_stream);
+/* Re-upload parameters (cameras: centre/rotation/focal/k; points) without rebuilding the index. */
+int bsfm_problem_reset_params(bsfm_problem_t *pb, const bsfm_camera_params_t *cameras, const double *points);
+
+/* LM driver (restates lib/sba-1.5/sba_levmar.c:457-2081): begin computes the initial cost;
+ * iterate runs up to `iters` outer iterations (fewer if a stop rule fires) and returns the stop code
+ * (0 = still running); finish fills info[10] like the reference and returns iterations or BSFM_ERROR. */
+int bsfm_lm_begin(bsfm_problem_t *pb);
+int bsfm_lm_iterate(bsfm_problem_t *pb, int iters);
+int bsfm_lm_finish(bsfm_problem_t *pb, double info[BSFM_INFOSZ]);
+int bsfm_lm_solve_attempts(const bsfm_problem_t *pb);   /* linear systems solved so far (info[9]) */
+double bsfm_lm_last_kernel_ms(const bsfm_problem_t *pb, const char *phase); /* HIP-event time of a phase in the last iteration */
+
+/* Download results: packed parameter vector p (m*cnp + 3n, reference layout sfm.c:652-703), and/or
+ * updated cameras (R <- dR(w) R, t <- c, f, k as sfm.c:876-922) and points. Any pointer may be NULL. */
+int bsfm_problem_download(bsfm_problem_t *pb, double *p_out, bsfm_camera_params_t *cameras, double *points);
+int bsfm_problem_cnp(const bsfm_problem_t *pb);
+long long bsfm_problem_nvis(const bsfm_problem_t *pb);
+
+/* Component entries used by the parity tests (each one launches the production kernels):
+ *  residuals: e = x - proj(p) in CRS order, returns ||e||^2 (+ constraint terms) in *cost
+ *  normal equations at the current p with damping mu: any output may be NULL
+ *    U (m*cnp*cnp, row-major blocks incl. constraints, diagonal + mu), ea (m*cnp),
+ *    V (n*9 full symmetric, diagonal + mu), eb (n*3), J (nvis*(2*cnp+6): A_ij row-major then B_ij),
+ *    S ((m-mcon)*cnp squared, dense symmetric), E ((m-mcon)*cnp)                                  */
+int bsfm_eval_residuals(bsfm_problem_t *pb, double *e_out, double *cost);
+int bsfm_eval_normal_equations(bsfm_problem_t *pb, double mu, double *U, double *ea, double *V, double *eb,
+                               double *J, double *S, double *E);
+/* Dense SPD solve on the device with the production Cholesky: A (n x n, symmetric, row-major, host),
+ * b (n) -> x (n). Returns 0, or k>0 if the leading minor k is not positive definite (dpotrf's info). */
+int bsfm_dense_chol_solve(int n, const double *A, const double *b, double *x, int backend);
+
+/* ---- 4. matcher ------------------------------------------------------------------------------------- */
+/* Exact 2-NN ratio test between two descriptor sets (128-D uchar, squared L2 in int32):
+ * keeps (i, nn0) iff (double)d0 < ratio*ratio*(double)d1 (src/keys2a.cpp:362). out_pairs gets up to
+ * max_out (idx1, idx2) pairs in ascending idx1 order; returns the number of matches (may exceed max_out),
+ * or BSFM_ERROR.  n2 < 2 is an error (the reference's ANN aborts in that case). */
+int bsfm_match_keys_l2(int n1, const unsigned char *k1, int n2, const unsigned char *k2, double ratio,
+                       int *out_pairs, int max_out);
+/* All-pairs driver with KeyMatchFull's loop structure and output format (src/KeyMatchFull.cpp:105-151):
+ * keys[i] -> num_keys[i] x 128 uchar (host); writes the text to `out_path` ("j i\nN\nidx_j idx_i\n...")
+ * for pairs with >= 16 matches; window_radius <= 0 means all pairs.  rank/world_size shard the pairs. */
+int bsfm_key_match_full(int num_images, const int *num_keys, const unsigned char *const *keys,
+                        double ratio, int window_radius, const char *out_path);
+
+/* ---- utilities --------------------------------------------------------------------------------------- */
+int bsfm_device_count(void);                 /* 0 when no usable HIP device */
+const char *bsfm_version(void);
+/* Deterministic synthetic BA scene: ring of m cameras, n points, `deg` views per point.
+ * Fills rowptr(n+1), colidx(n*deg), projections(2*n*deg), cameras(m), points(3n) (already perturbed),
+ * banded != 0 draws each point's cameras from a window of 50 neighbours. */
+int bsfm_synth_ba(int m, int n, int deg, unsigned long long seed, int banded,
+                  int *rowptr, int *colidx, double *projections,
+                  bsfm_camera_params_t *cameras, double *points);
+/* Deterministic synthetic SIFT-like descriptors: num x 128 uchar; `dup_from` (may be NULL, n_from keys)
+ * donates ~20 % near-duplicates so that true matches exist. */
+int bsfm_synth_keys(int num, unsigned long long seed, const unsigned char *dup_from, int n_from,
+                    unsigned char *keys_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSFM_H */

@@ -1,0 +1,167 @@
+/* oracle/ref_harness.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Thin harness around the REFERENCE'S OWN sources (compiled from /root/reference by oracle/Makefile
+ * into oracle/_ref/libsfmref.so; nothing from the reference is copied into this repository).
+ * It #includes lib/sfm-driver/sfm.c so that the file-static projection callback
+ * sfm_project_point3 (sfm.c:503) and the caches global_last_ws/global_last_Rs (sfm.c:382-383) are
+ * reachable, because run_sfm hard-codes MAX_ITERS=150 (sfm.c:814) and passes projac=NULL
+ * (sfm.c:820-828).  Exports:
+ *   ref_run_sfm        verbatim reference run_sfm (oracle mode A).
+ *   ref_sba_motstr     reference sba_motstr_levmar (lib/sba-1.5/sba_levmar_wrap.c:599) with a chosen
+ *                      itmax and either the reference forward-difference Jacobian (jac_mode 0) or OUR
+ *                      analytic Jacobian supplied through SBA's projac hook (jac_mode 1, oracle mode B);
+ *                      itmax == 0 runs the reference's own Jacobian checker on it
+ *                      (lib/sba-1.5/sba_levmar.c:769-773).
+ *   ref_sizeof_camera_params   layout check for the ctypes mirror of camera_params_t (sfm.h:32-51).
+ */
+#include "sfm.c"          /* resolved through -I$(REF)/lib/sfm-driver */
+#include "snavely_model.h"
+
+#include <sys/time.h>
+
+/* f2c's exit_.c wants libf2c's I/O shutdown hook; no Fortran I/O is linked here */
+void f_exit(void) {}
+
+typedef struct {
+    sfm_global_t *globs;
+    sm_config cfg;
+} harness_adata_t;
+
+/* sfm_project_point3 receives `adata` as sfm_global_t*; SBA hands the same pointer to projac, so the
+ * config for the analytic Jacobian lives in a file-static next to it. */
+static sm_config g_cfg;
+
+static void harness_projac(int j, int i, double *aj, double *bi, double *Aij, double *Bij, void *adata)
+{
+    sfm_global_t *globs = (sfm_global_t *) adata;
+    (void) i;
+    sm_jacobian(&g_cfg, globs->init_params[j].R, globs->init_params[j].f, aj, bi, Aij, Bij);
+}
+
+int ref_sizeof_camera_params(void) { return (int) sizeof(camera_params_t); }
+
+void ref_run_sfm(int num_pts, int num_cameras, int ncons, char *vmask, double *projections,
+                 int est_focal_length, int const_focal_length, int undistort, int explicit_camera_centers,
+                 camera_params_t *init_camera_params, v3_t *init_pts, int use_constraints,
+                 int use_point_constraints, v3_t *pt_constraints, double pt_constraint_weight,
+                 int fix_points, int optimize_for_fisheye, double eps2,
+                 double *Vout, double *Sout, double *Uout, double *Wout)
+{
+    run_sfm(num_pts, num_cameras, ncons, vmask, projections, est_focal_length, const_focal_length,
+            undistort, explicit_camera_centers, init_camera_params, init_pts, use_constraints,
+            use_point_constraints, pt_constraints, pt_constraint_weight, fix_points,
+            optimize_for_fisheye, eps2, Vout, Sout, Uout, Wout);
+}
+
+/* Packs the parameter vector the way run_sfm does (sfm.c:649-703), sets up constraints
+ * (sfm.c:721-781) and the rotation cache (sfm.c:796-811), then calls the reference LM.
+ * cams are NOT modified (f_scale/k_scale are restored); the final packed parameter vector is
+ * returned in p_out (m*cnp + 3n doubles).  Returns the SBA return code; wall seconds in *secs. */
+int ref_sba_motstr(int n, int m, int mcon, char *vmask, double *projections,
+                   int est_focal, int undistort, int explicit_centers,
+                   camera_params_t *cams, double *pts,
+                   int use_constraints, int use_point_constraints, double *pt_constraints,
+                   double pt_constraint_weight, double eps2,
+                   int itmax, int jac_mode, int verbose,
+                   double *info, double *p_out,
+                   double *Vout, double *Sout, double *Uout, double *Wout, double *secs)
+{
+    const double f_scale = 0.001, k_scale = 5.0;
+    int cnp = (est_focal ? 7 : 6) + (undistort ? 2 : 0);
+    int nvars = cnp * m + 3 * n, i, j, rc;
+    double opts[6];
+    double *params = (double *) malloc(sizeof(double) * nvars);
+    camera_constraints_t *cons = NULL;
+    point_constraints_t *pcons = NULL;
+    sfm_global_t globs;
+    struct timeval t0, t1;
+
+    for (j = 0; j < m; j++) {
+        double *a = params + cnp * j;
+        int c = 6;
+        cams[j].f_scale = f_scale; cams[j].k_scale = k_scale;
+        a[0] = cams[j].t[0]; a[1] = cams[j].t[1]; a[2] = cams[j].t[2];
+        a[3] = a[4] = a[5] = 0.0;
+        if (est_focal) { a[6] = cams[j].f * f_scale; c = 7; }
+        if (undistort) { a[c] = cams[j].k[0] * k_scale; a[c + 1] = cams[j].k[1] * k_scale; }
+    }
+    memcpy(params + cnp * m, pts, sizeof(double) * 3 * n);
+
+    opts[0] = 1.0e-3; opts[1] = 1.0e-10; opts[2] = eps2; opts[3] = 1.0e-12; opts[4] = 0.0; opts[5] = 4.0e-2;
+
+    if (use_constraints) {
+        cons = (camera_constraints_t *) malloc(m * sizeof(camera_constraints_t));
+        for (j = 0; j < m; j++) {
+            cons[j].constrained = (char *) malloc(cnp);
+            cons[j].constraints = (double *) malloc(sizeof(double) * cnp);
+            cons[j].weights = (double *) malloc(sizeof(double) * cnp);
+            memcpy(cons[j].constrained, cams[j].constrained, cnp);
+            memcpy(cons[j].constraints, cams[j].constraints, cnp * sizeof(double));
+            memcpy(cons[j].weights, cams[j].weights, cnp * sizeof(double));
+            if (est_focal) { cons[j].constraints[6] *= f_scale; cons[j].weights[6] *= 1.0 / (f_scale * f_scale); }
+            if (undistort) {
+                cons[j].constraints[7] *= k_scale; cons[j].weights[7] *= 1.0 / (k_scale * k_scale);
+                cons[j].constraints[8] *= k_scale; cons[j].weights[8] *= 1.0 / (k_scale * k_scale);
+            }
+        }
+    }
+    if (use_point_constraints) {
+        pcons = (point_constraints_t *) malloc(n * sizeof(point_constraints_t));
+        for (i = 0; i < n; i++) {
+            double *pc = pt_constraints + 3 * i;
+            int on = !(pc[0] == 0.0 && pc[1] == 0.0 && pc[2] == 0.0);
+            pcons[i].constrained = (char) on;
+            pcons[i].weight = on ? pt_constraint_weight : 0.0;
+            pcons[i].constraints[0] = on ? pc[0] : 0.0;
+            pcons[i].constraints[1] = on ? pc[1] : 0.0;
+            pcons[i].constraints[2] = on ? pc[2] : 0.0;
+        }
+    }
+
+    memset(&globs, 0, sizeof(globs));
+    globs.num_cameras = m; globs.num_points = n; globs.num_params_per_camera = cnp;
+    globs.est_focal_length = est_focal; globs.const_focal_length = 0;
+    globs.estimate_distortion = undistort; globs.explicit_camera_centers = explicit_centers;
+    globs.global_params.f = 1.0; globs.init_params = cams; globs.points = (v3_t *) pts;
+
+    global_last_ws = (double *) calloc(3 * m, sizeof(double));
+    global_last_Rs = (double *) malloc(9 * m * sizeof(double));
+    for (j = 0; j < m; j++) memcpy(global_last_Rs + 9 * j, cams[j].R, 9 * sizeof(double));
+
+    g_cfg.cnp = cnp; g_cfg.est_focal = est_focal; g_cfg.undistort = undistort;
+    g_cfg.explicit_centers = explicit_centers; g_cfg.f_scale = f_scale; g_cfg.k_scale = k_scale;
+
+    gettimeofday(&t0, NULL);
+    rc = sba_motstr_levmar(n, m, mcon, vmask, params, cnp, 3, projections, NULL, 2,
+                           sfm_project_point3, jac_mode ? harness_projac : NULL, (void *) &globs,
+                           itmax, verbose, opts, info, use_constraints, cons,
+                           use_point_constraints, pcons, Vout, Sout, Uout, Wout);
+    gettimeofday(&t1, NULL);
+    if (secs) *secs = (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec);
+
+    if (p_out) memcpy(p_out, params, sizeof(double) * nvars);
+    for (j = 0; j < m; j++) { cams[j].f_scale = 1.0; cams[j].k_scale = 1.0; }
+
+    if (cons) { for (j = 0; j < m; j++) { free(cons[j].constrained); free(cons[j].constraints); free(cons[j].weights); } free(cons); }
+    free(pcons); free(params); free(global_last_ws); free(global_last_Rs);
+    global_last_ws = global_last_Rs = NULL;
+    return rc;
+}
+
+/* Reference projection of one observation with the packed parameters (for model parity tests). */
+void ref_project_point(int est_focal, int undistort, int explicit_centers, camera_params_t *cam,
+                       double *aj, double *bi, double *xij)
+{
+    sfm_global_t globs;
+    double ws[3] = { 1e300, 1e300, 1e300 }, Rs[9];
+    double fs = cam->f_scale, ks = cam->k_scale;
+    memset(&globs, 0, sizeof(globs));
+    globs.num_cameras = 1; globs.num_points = 1;
+    globs.est_focal_length = est_focal; globs.estimate_distortion = undistort;
+    globs.explicit_camera_centers = explicit_centers; globs.init_params = cam;
+    cam->f_scale = 0.001; cam->k_scale = 5.0;
+    global_last_ws = ws; global_last_Rs = Rs;
+    sfm_project_point3(0, 0, aj, bi, xij, &globs);
+    global_last_ws = global_last_Rs = NULL;
+    cam->f_scale = fs; cam->k_scale = ks;
+}
