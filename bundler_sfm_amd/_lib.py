@@ -17,9 +17,9 @@ class CameraParams(C.Structure):
     """Layout-identical to camera_params_t (reference lib/sfm-driver/sfm.h:32-51)."""
     _fields_ = [
         ("R", C.c_double * 9), ("t", C.c_double * 3), ("f", C.c_double), ("k", C.c_double * 2),
-        ("k_inv", C.c_double * 6), ("constrained", C.c_char * 9), ("constraints", C.c_double * 9),
+        ("k_inv", C.c_double * 6), ("constrained", C.c_ubyte * 9), ("constraints", C.c_double * 9),
         ("weights", C.c_double * 9), ("K_known", C.c_double * 9), ("k_known", C.c_double * 5),
-        ("fisheye", C.c_char), ("known_intrinsics", C.c_char),
+        ("fisheye", C.c_ubyte), ("known_intrinsics", C.c_ubyte),
         ("f_cx", C.c_double), ("f_cy", C.c_double), ("f_rad", C.c_double), ("f_angle", C.c_double),
         ("f_focal", C.c_double), ("f_scale", C.c_double), ("k_scale", C.c_double),
     ]
@@ -51,7 +51,7 @@ SYMBOLS = [
     "bsfm_lm_iterate", "bsfm_lm_finish", "bsfm_lm_solve_attempts", "bsfm_lm_last_kernel_ms",
     "bsfm_problem_download", "bsfm_problem_cnp", "bsfm_problem_nvis", "bsfm_eval_residuals",
     "bsfm_eval_normal_equations", "bsfm_dense_chol_solve", "bsfm_match_keys_l2", "bsfm_key_match_full",
-    "bsfm_device_count", "bsfm_version", "bsfm_synth_ba", "bsfm_synth_keys",
+    "bsfm_device_count", "bsfm_version", "bsfm_device_synchronize", "bsfm_synth_ba", "bsfm_synth_keys",
 ]
 
 
@@ -110,6 +110,8 @@ def _load():
     lib.bsfm_key_match_full.restype = C.c_int
     lib.bsfm_device_count.argtypes = []
     lib.bsfm_device_count.restype = C.c_int
+    lib.bsfm_device_synchronize.argtypes = []
+    lib.bsfm_device_synchronize.restype = C.c_int
     lib.bsfm_version.argtypes = []
     lib.bsfm_version.restype = C.c_char_p
     lib.bsfm_synth_ba.argtypes = [C.c_int, C.c_int, C.c_int, C.c_ulonglong, C.c_int, ip, ip, dp, cp, dp]

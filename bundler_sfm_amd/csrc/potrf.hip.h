@@ -13,12 +13,13 @@
 //   * panel: L_ik = S_ik * inv(L_kk)^T is a GEMM on v_mfma_f64_16x16x4_f64 (no triangular solve);
 //     it also writes a compact copy of the panel (contiguous 128 KB tiles) that the trailing update reads;
 //   * trailing update S_ij -= L_ik L_jk^T on the lower triangle: 128x128 tile per 256-thread workgroup,
-//     4 waves x (4x4 MFMA tiles of 16x16) = 64 FP64 accumulators per lane, K staged through LDS in
+//     8 waves x (32 x 64) = 32 FP64 accumulators per lane on v_mfma_f64_4x4x4_4b (the full-rate FP64
+//     matrix instruction of gfx950: 72.7 TFLOP/s measured vs 36 for v_mfma_f64_16x16x4), K staged through LDS in
 //     16-wide chunks (row stride padded to 18 doubles => conflict-free ds_read_b64 of the fragments),
 //     next chunk prefetched into registers while the MFMAs of the current one issue;
 //   * forward / backward substitution use the stored inverse diagonal tiles: one launch per tile step.
-// f64 MFMA fragment layout (cdna_hip_programming.md section 3): A[l&15][l>>4], B[l>>4][l&15],
-// C/D row = (l>>4) + 4*reg, col = l&15.
+// v_mfma_f64_4x4x4_4b lane layout (probed on MI355X, scripts/probe_mfma4.hip), lane l = 16k + 4g + r:
+// A[g][i=r][k], B[g][k][j=r], D[g][i][j] at lane 16i + 4g + j, for the 4 independent blocks g.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -48,96 +49,93 @@ struct PotrfWorkspace {
     int (*rb_destroy)(void*) = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double ms = 0.0; int cnt = 0;
+    // per-launch HIP-event timing of the trailing-update kernel (the roofline kernel bench.py reports)
+    hipEvent_t* sy0 = nullptr; hipEvent_t* sy1 = nullptr; int sy_used = 0;
+    double syrk_ms = 0.0; long long syrk_cnt = 0;
 };
 
 // ------------------------------------------------------------------------------------------------
 // C(128x128) = A(128xK, row-major lda) * B(128xK, row-major ldb)^T, per-wave 64x64 quadrant in acc[4][4].
 __device__ __forceinline__ void gemm_nt_128(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
-                                            int K, double* __restrict__ lds, v4d (&acc)[4][4])
+                                            int K, double* __restrict__ lds, double (&acc)[8][4])
 {
     double* As = lds;
     double* Bs = lds + 128 * GEMM_LDS_STRIDE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
-    // staging: 128 rows x 16 doubles = 1024 double2 per operand -> 4 per thread
-    double2 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;
-    const int srow = tid >> 3, sc2 = (tid & 7) * 2;     // rows srow + 32 q
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;   // 8 waves: 4 (rows) x 2 (cols), 32 x 64 each
+    // staging: 128 rows x 16 doubles = 1024 double2 per operand -> 2 per thread (512 threads)
+    double2 pa0, pa1, pb0, pb1;
+    const int srow = tid >> 3, sc2 = (tid & 7) * 2;     // rows srow + 64 q
     const double* Ag = A + (size_t)srow * lda + sc2;
     const double* Bg = B + (size_t)srow * ldb + sc2;
     double* Asw = As + srow * GEMM_LDS_STRIDE + sc2;
     double* Bsw = Bs + srow * GEMM_LDS_STRIDE + sc2;
 #define BSFM_GLOAD(kc)                                                                      \
     pa0 = *reinterpret_cast<const double2*>(Ag + (kc));                                     \
-    pa1 = *reinterpret_cast<const double2*>(Ag + (size_t)32 * lda + (kc));                  \
-    pa2 = *reinterpret_cast<const double2*>(Ag + (size_t)64 * lda + (kc));                  \
-    pa3 = *reinterpret_cast<const double2*>(Ag + (size_t)96 * lda + (kc));                  \
+    pa1 = *reinterpret_cast<const double2*>(Ag + (size_t)64 * lda + (kc));                  \
     pb0 = *reinterpret_cast<const double2*>(Bg + (kc));                                     \
-    pb1 = *reinterpret_cast<const double2*>(Bg + (size_t)32 * ldb + (kc));                  \
-    pb2 = *reinterpret_cast<const double2*>(Bg + (size_t)64 * ldb + (kc));                  \
-    pb3 = *reinterpret_cast<const double2*>(Bg + (size_t)96 * ldb + (kc));
+    pb1 = *reinterpret_cast<const double2*>(Bg + (size_t)64 * ldb + (kc));
     BSFM_GLOAD(0)
     for (int kc = 0; kc < K; kc += GEMM_KC) {
         __syncthreads();          // previous chunk fully consumed
         *reinterpret_cast<double2*>(Asw) = pa0;
-        *reinterpret_cast<double2*>(Asw + 32 * GEMM_LDS_STRIDE) = pa1;
-        *reinterpret_cast<double2*>(Asw + 64 * GEMM_LDS_STRIDE) = pa2;
-        *reinterpret_cast<double2*>(Asw + 96 * GEMM_LDS_STRIDE) = pa3;
+        *reinterpret_cast<double2*>(Asw + 64 * GEMM_LDS_STRIDE) = pa1;
         *reinterpret_cast<double2*>(Bsw) = pb0;
-        *reinterpret_cast<double2*>(Bsw + 32 * GEMM_LDS_STRIDE) = pb1;
-        *reinterpret_cast<double2*>(Bsw + 64 * GEMM_LDS_STRIDE) = pb2;
-        *reinterpret_cast<double2*>(Bsw + 96 * GEMM_LDS_STRIDE) = pb3;
+        *reinterpret_cast<double2*>(Bsw + 64 * GEMM_LDS_STRIDE) = pb1;
         __syncthreads();
         if (kc + GEMM_KC < K) { BSFM_GLOAD(kc + GEMM_KC) }
 #pragma unroll
         for (int kk = 0; kk < GEMM_KC; kk += 4) {
-            double a[4], b[4];
+            // v_mfma_f64_4x4x4_4b: 4 independent 4x4x4 blocks g = (lane>>2)&3 per instruction, the full-rate FP64
+            // matrix op on gfx950 (measured 72.7 TFLOP/s vs 36 for v_mfma_f64_16x16x4).  Lane l = 16k + 4g + r:
+            //   A[g][i=r][k], B[g][k][j=r]  ->  D[g][i][j] at lane 16i + 4g + j   (probed: scripts/probe_mfma4.hip).
+            // B fragment: 16 output columns (4 per block); A fragment: 4 output rows replicated over the blocks.
+            double b[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                a[t] = As[(wr + 16 * t + (lane & 15)) * GEMM_LDS_STRIDE + kk + (lane >> 4)];
-                b[t] = Bs[(wc + 16 * t + (lane & 15)) * GEMM_LDS_STRIDE + kk + (lane >> 4)];
-            }
+            for (int u = 0; u < 4; ++u)
+                b[u] = Bs[(wc + 16 * u + (lane & 15)) * GEMM_LDS_STRIDE + kk + (lane >> 4)];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 8; ++t) {
+                const double a = As[(wr + 4 * t + (lane & 3)) * GEMM_LDS_STRIDE + kk + (lane >> 4)];
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    acc[t][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[u], acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b[u], acc[t][u], 0, 0, 0);
+            }
         }
     }
 #undef BSFM_GLOAD
 }
 
 // Panel: X_i = S_ik * Linv_k^T for i = k+1 .. nblk-1; writes X back into S (it is L) and into the compact panel.
-__global__ __launch_bounds__(256, 2) void k_trsm_panel(double* __restrict__ S, int ld, int k,
+__global__ __launch_bounds__(512, 4) void k_trsm_panel(double* __restrict__ S, int ld, int k,
         const double* __restrict__ Linv, double* __restrict__ panel)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int i = k + 1 + blockIdx.x;
     double* Sik = S + ((size_t)i * POTRF_NB) * ld + (size_t)k * POTRF_NB;
-    v4d acc[4][4];
+    double acc[8][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[t][u] = (v4d){ 0.0, 0.0, 0.0, 0.0 };
+        for (int u = 0; u < 4; ++u) acc[t][u] = 0.0;
     gemm_nt_128(Sik, ld, Linv, POTRF_NB, POTRF_NB, lds, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
     double* Pt = panel + (size_t)blockIdx.x * POTRF_NB * POTRF_NB;
     __syncthreads();   // every wave has finished reading S_ik through LDS before it is overwritten
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int row = wr + 16 * t + (lane >> 4) + 4 * g, col = wc + 16 * u + (lane & 15);
-                const double v = acc[t][u][g];
-                Sik[(size_t)row * ld + col] = v;
-                Pt[row * POTRF_NB + col] = v;
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int row = wr + 4 * t + (lane >> 4), col = wc + 16 * u + (lane & 15);
+            const double v = acc[t][u];
+            Sik[(size_t)row * ld + col] = v;
+            Pt[row * POTRF_NB + col] = v;
+        }
 }
 
 // Trailing update: S_ij -= P_a P_b^T for k < j <= i (a = i-k-1, b = j-k-1), one tile per workgroup.
-__global__ __launch_bounds__(256, 2) void k_syrk_update(double* __restrict__ S, int ld, int k, const double* __restrict__ panel)
+__global__ __launch_bounds__(512, 4) void k_syrk_update(double* __restrict__ S, int ld, int k, const double* __restrict__ panel)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int t = blockIdx.x;
@@ -146,96 +144,139 @@ __global__ __launch_bounds__(256, 2) void k_syrk_update(double* __restrict__ S, 
     while (a * (a + 1) / 2 > t) --a;
     const int b = t - a * (a + 1) / 2;
     const int i = k + 1 + a, j = k + 1 + b;
-    v4d acc[4][4];
+    double acc[8][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 8; ++q)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[q][u] = (v4d){ 0.0, 0.0, 0.0, 0.0 };
+        for (int u = 0; u < 4; ++u) acc[q][u] = 0.0;
     gemm_nt_128(panel + (size_t)a * POTRF_NB * POTRF_NB, POTRF_NB, panel + (size_t)b * POTRF_NB * POTRF_NB, POTRF_NB,
                 POTRF_NB, lds, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
     double* Sij = S + ((size_t)i * POTRF_NB) * ld + (size_t)j * POTRF_NB;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 8; ++q)
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int row = wr + 16 * q + (lane >> 4) + 4 * g, col = wc + 16 * u + (lane & 15);
-                Sij[(size_t)row * ld + col] -= acc[q][u][g];
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int row = wr + 4 * q + (lane >> 4), col = wc + 16 * u + (lane & 15);
+            Sij[(size_t)row * ld + col] -= acc[q][u];
+        }
 }
 
-// Diagonal tile: fused Cholesky + inverse of the factor, 1024 threads as a 32x32 grid, thread (ti,tj) owns
-// rows ti+32a, cols tj+32b (a,b < 4) of both the tile A and X (X starts as I and ends as inv(L)).
-// Per column j: s = 1/sqrt(pivot); L[:,j] = raw*s; X[j,:] = raw*s; A -= l l^T ; X -= l xrow.
-// The raw column j+1 of A and raw row j+1 of X are published to LDS right after the update of step j,
-// so each column costs ONE barrier.  n_valid rows/cols of the tile belong to S, the rest is identity padding.
-__global__ __launch_bounds__(1024) void k_potrf_diag(double* __restrict__ S, int ld, int k, int n_total,
+// Diagonal tile: fused Cholesky + inverse of the factor in ONE 512-thread workgroup (the serial critical path of
+// the factorisation).  Threads form a 16 x 32 grid; thread (ti,tj) owns rows ti+16p (p<8), cols tj+32q (q<4) of the
+// tile A and of X (X starts as I and ends as inv(L)): 32+32 FP64 accumulators in registers, block-cyclic so that
+// the shrinking trailing matrix stays balanced.  Per column j:
+//   s = 1/sqrt(pivot) (computed ONCE by the owner of (j,j) when it publishes the column), l = raw column * s,
+//   xr = raw X row * s;  A[p>=jb][q>=jq] -= l l^T ; X[p>=jb][q<=jq] -= l xr   (finished row/column blocks are
+//   skipped with wave-uniform predicates, so the issued FMA count follows the ~1/3 triangular work).
+// Raw column j+1 / X row j+1 / next pivot scale are published right after the update => ONE barrier per column.
+__device__ __forceinline__ double rsqrt_f64(double v)
+{
+    double s = __builtin_amdgcn_rsq(v);          // v_rsq_f64 seed, two Newton steps to full precision
+    s = s * (1.5 - 0.5 * v * s * s);
+    s = s * (1.5 - 0.5 * v * s * s);
+    return s;
+}
+
+__global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int ld, int k, int n_total,
         double* __restrict__ Linv, int* __restrict__ info)
 {
     __shared__ double colbuf[2][POTRF_NB];
     __shared__ double rowbuf[2][POTRF_NB];
+    __shared__ double sbuf[2];
     const int ti = threadIdx.x >> 5, tj = threadIdx.x & 31;
     const int base = k * POTRF_NB;
     double* T = S + (size_t)base * ld + base;
-    double a[4][4], x[4][4];
+    double a[8][4], x[8][4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < 8; ++p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int r = ti + 32 * p, c = tj + 32 * q;
+            const int r = ti + 16 * p, c = tj + 32 * q;
             double v = 0.0;
             if (base + r < n_total && base + c < n_total) { if (c <= r) v = T[(size_t)r * ld + c]; }
             else if (r == c) v = 1.0;
             a[p][q] = v;
             x[p][q] = (r == c) ? 1.0 : 0.0;
         }
-    // publish raw column 0 / row 0
     if (tj == 0) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) colbuf[0][ti + 32 * p] = a[p][0];
+        for (int p = 0; p < 8; ++p) colbuf[0][ti + 16 * p] = a[p][0];
     }
     if (ti == 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) rowbuf[0][tj + 32 * q] = x[0][q];
     }
+    if (threadIdx.x == 0) {
+        const double piv = a[0][0];
+        if (!(piv > 0.0) && base < n_total) atomicCAS(info, 0, base + 1);
+        sbuf[0] = rsqrt_f64(piv);
+    }
     __syncthreads();
     for (int j = 0; j < POTRF_NB; ++j) {
         const int cur = j & 1, nxt = cur ^ 1;
-        const double piv = colbuf[cur][j];
-        if (!(piv > 0.0) && threadIdx.x == 0 && base + j < n_total) atomicCAS(info, 0, base + j + 1);
-        const double s = 1.0 / sqrt(piv);
-        double lr[4], lc[4], xr[4];
+        const int jb = j >> 4, jq = j >> 5;
+        const double s = sbuf[cur];
+        double lr[8], lc[4], xr[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) lr[p] = colbuf[cur][ti + 32 * p] * s;
+        for (int p = 0; p < 8; ++p) {
+            const int r = ti + 16 * p;
+            lr[p] = (p >= jb) ? colbuf[cur][r] * s : 0.0;
+        }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { lc[q] = colbuf[cur][tj + 32 * q] * s; xr[q] = rowbuf[cur][tj + 32 * q] * s; }
+        for (int q = 0; q < 4; ++q) {
+            const int c = tj + 32 * q;
+            lc[q] = (q >= jq && c > j) ? colbuf[cur][c] * s : 0.0;
+            xr[q] = (q <= jq) ? rowbuf[cur][c] * s : 0.0;
+        }
+        // finalize column j of L (rows >= j) and row j of X, then mask rows <= j out of the rank-1 updates
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int p = 0; p < 8; ++p) {
+            const int r = ti + 16 * p;
+            if (p >= jb) {
+                if (tj == (j & 31) && r >= j) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = ti + 32 * p, c = tj + 32 * q;
-                if (c == j) { if (r >= j) a[p][q] = lr[p]; }          // final L column j
-                else if (r > j && c > j) a[p][q] -= lr[p] * lc[q];
-                if (r == j) x[p][q] = xr[q];                           // final inverse row j
-                else if (r > j) x[p][q] -= lr[p] * xr[q];
-            }
-        if (j + 1 < POTRF_NB) {
-            const int jn = j + 1;
-            const int jq = jn >> 5;   // static selects: a runtime register-array index would go to scratch
-            if (tj == (jn & 31)) {
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const double v = jq == 0 ? a[p][0] : (jq == 1 ? a[p][1] : (jq == 2 ? a[p][2] : a[p][3]));
-                    colbuf[nxt][ti + 32 * p] = v;
+                    for (int q = 0; q < 4; ++q) if (q == jq) a[p][q] = lr[p];
                 }
+                if (r == j) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[p][q] = xr[q];
+                }
+                if (r <= j) lr[p] = 0.0;
             }
-            if (ti == (jn & 31)) {
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            if (p >= jb) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const double v = jq == 0 ? x[0][q] : (jq == 1 ? x[1][q] : (jq == 2 ? x[2][q] : x[3][q]));
+                    if (q >= jq) a[p][q] -= lr[p] * lc[q];
+                    if (q <= jq) x[p][q] -= lr[p] * xr[q];
+                }
+            }
+        }
+        if (j + 1 < POTRF_NB) {
+            const int jn = j + 1, nb = jn >> 4, nq = jn >> 5;
+            if (tj == (jn & 31)) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    double v = a[p][0];
+#pragma unroll
+                    for (int q = 1; q < 4; ++q) if (q == nq) v = a[p][q];
+                    colbuf[nxt][ti + 16 * p] = v;
+                    if (p == nb && ti == (jn & 15)) {      // owner of the next pivot
+                        if (!(v > 0.0) && base + jn < n_total) atomicCAS(info, 0, base + jn + 1);
+                        sbuf[nxt] = rsqrt_f64(v);
+                    }
+                }
+            }
+            if (ti == (jn & 15)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double v = x[0][q];
+#pragma unroll
+                    for (int p = 1; p < 8; ++p) if (p == nb) v = x[p][q];
                     rowbuf[nxt][tj + 32 * q] = v;
                 }
             }
@@ -244,10 +285,10 @@ __global__ __launch_bounds__(1024) void k_potrf_diag(double* __restrict__ S, int
     }
     double* Li = Linv + (size_t)k * POTRF_NB * POTRF_NB;
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < 8; ++p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int r = ti + 32 * p, c = tj + 32 * q;
+            const int r = ti + 16 * p, c = tj + 32 * q;
             if (c <= r) T[(size_t)r * ld + c] = a[p][q];
             Li[r * POTRF_NB + c] = (c <= r) ? x[p][q] : 0.0;
         }
@@ -330,6 +371,8 @@ inline void potrf_free(PotrfWorkspace& w)
     if (w.rb_handle && w.rb_destroy) w.rb_destroy(w.rb_handle);
     if (w.ev0) (void)hipEventDestroy(w.ev0);
     if (w.ev1) (void)hipEventDestroy(w.ev1);
+    for (int i = 0; w.sy0 && i < w.nblk; ++i) { (void)hipEventDestroy(w.sy0[i]); (void)hipEventDestroy(w.sy1[i]); }
+    delete[] w.sy0; delete[] w.sy1;
     w = PotrfWorkspace();
 }
 
@@ -343,6 +386,8 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
     if (hipMalloc((void**)&w.xs, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
     if (hipMalloc((void**)&w.etmp, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
     (void)hipEventCreate(&w.ev0); (void)hipEventCreate(&w.ev1);
+    w.sy0 = new hipEvent_t[w.nblk]; w.sy1 = new hipEvent_t[w.nblk];
+    for (int i = 0; i < w.nblk; ++i) { (void)hipEventCreate(&w.sy0[i]); (void)hipEventCreate(&w.sy1[i]); }
     if (backend == 1) {
         // cross-check backend only: rocSOLVER through dlopen, never linked
         w.rb_lib = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
@@ -375,16 +420,20 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         return 0;
     }
     const int nblk = (n + POTRF_NB - 1) / POTRF_NB;
+    w.sy_used = 0;
     const size_t lds_bytes = 2 * 128 * GEMM_LDS_STRIDE * sizeof(double);
     (void)hipMemsetAsync(w.etmp, 0, (size_t)ld * sizeof(double), st);
     (void)hipMemcpyAsync(w.etmp, E, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
     for (int k = 0; k < nblk; ++k) {
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(1024), 0, st, S, ld, k, n, w.linv, d_info);
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), 0, st, S, ld, k, n, w.linv, d_info);
         const int T = nblk - k - 1;
         if (T > 0) {
-            hipLaunchKernelGGL(k_trsm_panel, dim3(T), dim3(256), lds_bytes, st, S, ld, k,
+            hipLaunchKernelGGL(k_trsm_panel, dim3(T), dim3(512), lds_bytes, st, S, ld, k,
                                w.linv + (size_t)k * POTRF_NB * POTRF_NB, w.panel);
-            hipLaunchKernelGGL(k_syrk_update, dim3(T * (T + 1) / 2), dim3(256), lds_bytes, st, S, ld, k, w.panel);
+            (void)hipEventRecord(w.sy0[k], st);
+            hipLaunchKernelGGL(k_syrk_update, dim3(T * (T + 1) / 2), dim3(512), lds_bytes, st, S, ld, k, w.panel);
+            (void)hipEventRecord(w.sy1[k], st);
+            w.sy_used = k + 1;
         }
     }
     for (int k = -1; k < nblk - 1; ++k)
@@ -400,6 +449,9 @@ inline void potrf_collect_time(PotrfWorkspace& w)
 {
     float ms = 0.f;
     if (w.ev0 && w.ev1 && hipEventElapsedTime(&ms, w.ev0, w.ev1) == hipSuccess && ms >= 0.f) { w.ms += ms; w.cnt++; }
+    for (int i = 0; i < w.sy_used; ++i)
+        if (hipEventElapsedTime(&ms, w.sy0[i], w.sy1[i]) == hipSuccess && ms >= 0.f) { w.syrk_ms += ms; w.syrk_cnt++; }
+    w.sy_used = 0;
 }
 
 }  // namespace bsfm

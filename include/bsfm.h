@@ -178,6 +178,7 @@ int bsfm_key_match_full(int num_images, const int *num_keys, const unsigned char
 /* ---- utilities --------------------------------------------------------------------------------------- */
 int bsfm_device_count(void);                 /* 0 when no usable HIP device */
 const char *bsfm_version(void);
+int bsfm_device_synchronize(void);           /* hipDeviceSynchronize on the current device */
 /* Deterministic synthetic BA scene: ring of m cameras, n points, `deg` views per point.
  * Fills rowptr(n+1), colidx(n*deg), projections(2*n*deg), cameras(m), points(3n) (already perturbed),
  * banded != 0 draws each point's cameras from a window of 50 neighbours. */

@@ -1,0 +1,179 @@
+"""Generates the committed golden fixtures from the REFERENCE ITSELF (oracle/_ref, built from /root/reference
+by oracle/Makefile).  Run in the build container only:  python tests/golden/make_golden.py
+The GPU box has no /root/reference; tests read the .npz files written here.
+
+  ba_golden.npz      small synthetic scenes run through the reference run_sfm / sba_motstr_levmar
+                     (FD Jacobian = verbatim reference; analytic Jacobian supplied through projac)
+  kermit_golden.npz  replay of the reference's only golden artefact, examples/kermit/results.example/bundle.out
+                     (9 registered cameras / 634 points / 2 039 observations): parsed inputs + reference outputs
+  match_golden.npz   synthetic SIFT-like keys + the reference MatchKeys output (exact search and the shipped
+                     200-visit approximate search)
+  model_golden.npz   sfm_project_point3 values for random parameters
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_util as O  # noqa: E402
+import bundler_sfm_amd as B  # noqa: E402  (synthetic generator + dense_vmask are host-only helpers)
+
+REF_ROOT = "/root/reference"
+
+
+def ba_cases():
+    out = {}
+    cases = [
+        ("s9", dict(m=8, n=60, deg=4, est=1, und=1, ncons=0, cons=0)),
+        ("s9c", dict(m=8, n=60, deg=4, est=1, und=1, ncons=0, cons=1)),
+        ("s9m", dict(m=8, n=60, deg=4, est=1, und=1, ncons=2, cons=0)),
+        ("s7", dict(m=6, n=50, deg=3, est=1, und=0, ncons=0, cons=0)),
+        ("s6", dict(m=6, n=50, deg=3, est=0, und=0, ncons=0, cons=1)),
+        ("band", dict(m=60, n=300, deg=5, est=1, und=1, ncons=0, cons=1, banded=1)),
+    ]
+    for name, c in cases:
+        s = B.synth_ba(c["m"], c["n"], c["deg"], banded=bool(c.get("banded", 0)))
+        cams = s["cams"]
+        if c["cons"]:
+            O.set_bundler_constraints(cams)
+        vm = B.dense_vmask(c["n"], c["m"], s["rowptr"], s["colidx"])
+        ca = O.cams_to_arrays(cams)
+        out[f"{name}_cfg"] = np.array([c["m"], c["n"], c["deg"], c["est"], c["und"], c["ncons"], c["cons"]])
+        out[f"{name}_rowptr"] = s["rowptr"]; out[f"{name}_colidx"] = s["colidx"]; out[f"{name}_proj"] = s["proj"]
+        out[f"{name}_pts"] = s["pts"]
+        for k, v in ca.items():
+            out[f"{name}_cam_{k}"] = v
+        for jm, tag in ((0, "fd"), (1, "an")):
+            for it in (1, 3, 150):
+                r = O.ref_sba(c["n"], c["m"], vm, s["proj"], cams, s["pts"], itmax=it, jac_mode=jm, ncons=c["ncons"],
+                              est_focal=c["est"], undistort=c["und"], use_constraints=c["cons"])
+                out[f"{name}_{tag}_it{it}_p"] = r["p"]; out[f"{name}_{tag}_it{it}_info"] = r["info"]
+        rc, rp = O.ref_run_sfm(c["n"], c["m"], vm, s["proj"], cams, s["pts"], ncons=c["ncons"], est_focal=c["est"],
+                               undistort=c["und"], use_constraints=c["cons"])
+        ra = O.cams_to_arrays(rc)
+        for k in ("R", "t", "f", "k"):
+            out[f"{name}_run_cam_{k}"] = ra[k]
+        out[f"{name}_run_pts"] = rp
+    np.savez_compressed(os.path.join(HERE, "ba_golden.npz"), **out)
+    print("ba_golden:", len(out), "arrays")
+
+
+def parse_bundle(path):
+    toks = open(path).read().split("\n")
+    assert toks[0].startswith("# Bundle file v0.3")
+    it = iter(" ".join(toks[1:]).split())
+    ncam, npts = int(next(it)), int(next(it))
+    cams = []
+    for _ in range(ncam):
+        f, k1, k2 = float(next(it)), float(next(it)), float(next(it))
+        R = np.array([float(next(it)) for _ in range(9)]).reshape(3, 3)
+        t = np.array([float(next(it)) for _ in range(3)])
+        cams.append((f, k1, k2, R, t))
+    pts, views = [], []
+    for _ in range(npts):
+        X = [float(next(it)) for _ in range(3)]
+        _ = [next(it) for _ in range(3)]
+        nv = int(next(it))
+        v = []
+        for _ in range(nv):
+            c, key, x, y = int(next(it)), int(next(it)), float(next(it)), float(next(it))
+            v.append((c, x, y))
+        pts.append(X); views.append(v)
+    return cams, np.array(pts), views
+
+
+def kermit():
+    cams, pts, views = parse_bundle(os.path.join(REF_ROOT, "examples/kermit/results.example/bundle.out"))
+    active = [j for j, c in enumerate(cams) if c[0] != 0.0]
+    remap = {j: q for q, j in enumerate(active)}
+    m = len(active)
+    R = np.array([cams[j][3].ravel() for j in active]); f = np.array([cams[j][0] for j in active])
+    k = np.array([[cams[j][1], cams[j][2]] for j in active])
+    ctr = np.array([-cams[j][3].T @ cams[j][4] for j in active])      # c = -R^T t (README.md:233-264)
+    rowptr, colidx, proj, keep = [0], [], [], []
+    for i, v in enumerate(views):
+        vv = sorted((remap[c], x, y) for c, x, y in v if c in remap)
+        if len(vv) < 2:
+            continue
+        keep.append(i)
+        for c, x, y in vv:
+            colidx.append(c); proj += [x, y]
+        rowptr.append(len(colidx))
+    P = pts[keep]
+    n = len(keep)
+    rowptr = np.array(rowptr, np.int32); colidx = np.array(colidx, np.int32); proj = np.array(proj)
+    print("kermit: cams", m, "pts", n, "obs", len(colidx))
+    rng = np.random.default_rng(20260923)
+    P1 = P + 0.01 * rng.standard_normal(P.shape)
+    C1 = ctr + 0.01 * rng.standard_normal(ctr.shape)
+    f1 = f * (1 + 0.01 * rng.standard_normal(m))
+    cam0 = O.arrays_to_cams(R, C1, f1, k)
+    O.set_bundler_constraints(cam0)
+    ca = O.cams_to_arrays(cam0)
+    vm = B.dense_vmask(n, m, rowptr, colidx)
+    out = dict(rowptr=rowptr, colidx=colidx, proj=proj, pts=P1.ravel(), gold_R=R, gold_c=ctr, gold_f=f, gold_k=k, gold_pts=P.ravel())
+    for kk, v in ca.items():
+        out[f"cam_{kk}"] = v
+    for jm, tag in ((0, "fd"), (1, "an")):
+        for it in (1, 3, 150):
+            r = O.ref_sba(n, m, vm, proj, cam0, P1.ravel(), itmax=it, jac_mode=jm, use_constraints=1, eps2=1e-12)
+            out[f"{tag}_it{it}_p"] = r["p"]; out[f"{tag}_it{it}_info"] = r["info"]
+            print("  kermit", tag, it, r["info"][[0, 1, 5, 6]])
+    rc, rp = O.ref_run_sfm(n, m, vm, proj, cam0, P1.ravel(), use_constraints=1)
+    ra = O.cams_to_arrays(rc)
+    for kk in ("R", "t", "f", "k"):
+        out[f"run_cam_{kk}"] = ra[kk]
+    out["run_pts"] = rp
+    np.savez_compressed(os.path.join(HERE, "kermit_golden.npz"), **out)
+
+
+def matcher():
+    import ctypes as C
+    u = C.POINTER(C.c_ubyte)
+    out = {}
+    for name, (n1, n2) in (("a", (300, 400)), ("b", (1000, 1000)), ("tiny", (5, 2))):
+        k2 = np.zeros((n2, 128), np.uint8); k1 = np.zeros((n1, 128), np.uint8)
+        B.lib.bsfm_synth_keys(n2, 11, None, 0, k2.ctypes.data_as(u))
+        B.lib.bsfm_synth_keys(n1, 12, k2.ctypes.data_as(u), n2, k1.ctypes.data_as(u))
+        exact, _ = O.ref_match(k1, k2, 0.6, 0)
+        approx, _ = O.ref_match(k1, k2, 0.6, 200)
+        out[f"{name}_k1"] = k1; out[f"{name}_k2"] = k2; out[f"{name}_exact"] = exact; out[f"{name}_ann200"] = approx
+        print("match", name, len(exact), len(approx))
+    np.savez_compressed(os.path.join(HERE, "match_golden.npz"), **out)
+
+
+def model():
+    import ctypes as C
+    rng = np.random.default_rng(7)
+    N = 200
+    rows = []
+    for est, und in ((1, 1), (1, 0), (0, 0), (0, 1)):
+        cnp = (7 if est else 6) + (2 if und else 0)
+        for _ in range(N // 4):
+            A = rng.standard_normal((3, 3)); Q, _ = np.linalg.qr(A)
+            if np.linalg.det(Q) < 0:
+                Q[:, 0] *= -1
+            cam = O.arrays_to_cams([Q.ravel()], [rng.standard_normal(3)], [900 + 200 * rng.random()], [[0, 0]])
+            a = np.zeros(9)
+            a[0:3] = rng.standard_normal(3)
+            a[3:6] = 0.05 * rng.standard_normal(3) * (rng.random() > 0.3)
+            c = 6
+            if est:
+                a[6] = (900 + 200 * rng.random()) * 0.001; c = 7
+            if und:
+                a[c] = -0.05 * rng.random() * 5; a[c + 1] = 0.01 * rng.random() * 5
+            b = a[0:3] + Q.T @ np.array([rng.standard_normal(), rng.standard_normal(), -4 - rng.random()])
+            x = np.zeros(2)
+            dp = C.POINTER(C.c_double)
+            O.ref().ref_project_point(est, und, 1, cam, a.ctypes.data_as(dp), b.ctypes.data_as(dp), x.ctypes.data_as(dp))
+            rows.append(np.concatenate([[est, und, cam[0].f], Q.ravel(), a, b, x]))
+    np.savez_compressed(os.path.join(HERE, "model_golden.npz"), rows=np.array(rows))
+    print("model rows", len(rows))
+
+
+if __name__ == "__main__":
+    assert O.have_ref(), "build oracle/_ref first (make -C oracle ref)"
+    ba_cases(); kermit(); matcher(); model()

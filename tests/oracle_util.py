@@ -143,3 +143,139 @@ def cams_from_packed(cams0, p, m, cnp, est_focal=1, undistort=1):
             out[j].k[0] = a[c] / 5.0
             out[j].k[1] = a[c + 1] / 5.0
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# port = oracle/liboracle_port.so
+class OracleDumps(C.Structure):
+    _fields_ = [(k, _dp) for k in ("J", "U", "ea", "V", "eb", "S", "E", "dp", "mu")]
+
+
+_port = None
+
+
+def port():
+    global _port
+    if _port is None:
+        lib = C.CDLL(PORT_PATH)
+        lib.oracle_sizeof_camera.restype = C.c_int
+        assert lib.oracle_sizeof_camera() == C.sizeof(CameraParams)
+        lib.oracle_run_sfm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, _dp, C.c_int, C.c_int, C.c_int, _cp, _dp,
+                                       C.c_int, C.c_int, _dp, C.c_double, C.c_double, C.c_int, C.c_int, _dp, _dp,
+                                       C.POINTER(OracleDumps)]
+        lib.oracle_run_sfm.restype = C.c_int
+        lib.oracle_crs_from_vmask.argtypes = [C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.oracle_crs_from_vmask.restype = C.c_int
+        lib.oracle_project.argtypes = [C.c_int, C.c_int, C.c_int, _dp, C.c_double, _dp, _dp, _dp]
+        lib.oracle_project.restype = None
+        lib.oracle_jacobian.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _dp, C.c_double, _dp, _dp, _dp, _dp]
+        lib.oracle_jacobian.restype = None
+        lib.oracle_chol_solve.argtypes = [C.c_int, _dp, _dp, _dp]
+        lib.oracle_chol_solve.restype = C.c_int
+        lib.oracle_match_keys.argtypes = [C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.POINTER(C.c_ubyte), C.c_double,
+                                          C.POINTER(C.c_int), C.c_int]
+        lib.oracle_match_keys.restype = C.c_int
+        _port = lib
+    return _port
+
+
+def port_run_sfm(n, m, vmask, proj, cams, pts, itmax=150, jac_mode=0, ncons=0, est_focal=1, undistort=1, explicit=1,
+                 use_constraints=0, point_constraints=None, point_w=0.0, eps2=1e-12, want_dumps=False):
+    """Restated run_sfm. Returns dict(rc, info, p, cams, pts[, dumps...])."""
+    cnp = (7 if est_focal else 6) + (2 if undistort else 0)
+    cams = copy_cams(cams)
+    pts = np.array(pts, np.float64, copy=True)
+    vm = np.ascontiguousarray(vmask, np.uint8)
+    proj = np.ascontiguousarray(proj, np.float64)
+    nvis = int(vm.sum())
+    info = np.zeros(10)
+    p = np.zeros(m * cnp + 3 * n)
+    out = {}
+    dumps = None
+    if want_dumps:
+        sd = (m - ncons) * cnp
+        out = dict(J=np.zeros((nvis, 2 * cnp + 6)), U=np.zeros((m, cnp, cnp)), ea=np.zeros((m, cnp)),
+                   V=np.zeros((n, 3, 3)), eb=np.zeros((n, 3)), S=np.zeros((sd, sd)), E=np.zeros(sd),
+                   dp=np.zeros(m * cnp + 3 * n), mu=np.zeros(1))
+        dumps = OracleDumps(*[_d(out[k]) for k in ("J", "U", "ea", "V", "eb", "S", "E", "dp", "mu")])
+    rc = port().oracle_run_sfm(n, m, ncons, vm.ctypes.data_as(C.c_char_p), _d(proj), est_focal, undistort, explicit,
+                               cams, _d(pts), use_constraints, 0 if point_constraints is None else 1,
+                               _d(point_constraints), point_w, eps2, itmax, jac_mode, _d(info), _d(p),
+                               C.byref(dumps) if dumps is not None else None)
+    out.update(rc=rc, info=info, p=p, cams=cams, pts=pts, cnp=cnp)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+def cams_to_arrays(cams):
+    m = len(cams)
+    out = dict(R=np.zeros((m, 9)), t=np.zeros((m, 3)), f=np.zeros(m), k=np.zeros((m, 2)),
+               constrained=np.zeros((m, 9), np.uint8), constraints=np.zeros((m, 9)), weights=np.zeros((m, 9)))
+    for j in range(m):
+        out["R"][j] = list(cams[j].R); out["t"][j] = list(cams[j].t); out["f"][j] = cams[j].f
+        out["k"][j] = list(cams[j].k)
+        out["constrained"][j] = [1 if cams[j].constrained[q] else 0 for q in range(9)]
+        out["constraints"][j] = list(cams[j].constraints); out["weights"][j] = list(cams[j].weights)
+    return out
+
+
+def arrays_to_cams(R, t, f, k, constrained=None, constraints=None, weights=None):
+    m = len(f)
+    cams = (CameraParams * m)()
+    for j in range(m):
+        for q in range(9):
+            cams[j].R[q] = R[j][q]
+        for q in range(3):
+            cams[j].t[q] = t[j][q]
+        cams[j].f = f[j]; cams[j].k[0] = k[j][0]; cams[j].k[1] = k[j][1]
+        cams[j].f_scale = 1.0; cams[j].k_scale = 1.0
+        if constrained is not None:
+            for q in range(9):
+                cams[j].constrained[q] = int(constrained[j][q])
+                cams[j].constraints[q] = constraints[j][q]; cams[j].weights[q] = weights[j][q]
+    return cams
+
+
+def set_bundler_constraints(cams, focal_weight=1e-4, distortion_weight=100.0):
+    """RunBundler's settings: --constrain_focal with weight 0.0001 (RunBundler.sh:55,122; SetFocalConstraint,
+    src/Bundle.cpp:977-984) and distortion parameters constrained to 0 with weight 100 (src/Bundle.cpp:942-974)."""
+    for c in cams:
+        for q in range(9):
+            c.constrained[q] = 1 if q >= 6 else 0
+        c.constraints[6] = c.f; c.weights[6] = focal_weight
+        c.constraints[7] = 0.0; c.weights[7] = distortion_weight
+        c.constraints[8] = 0.0; c.weights[8] = distortion_weight
+    return cams
+
+
+_km = None
+
+
+def ref_km():
+    global _km
+    if _km is None:
+        lib = C.CDLL(REF_KM_PATH)
+        lib.ref_match_keys.argtypes = [C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.POINTER(C.c_ubyte), C.c_double, C.c_int,
+                                       C.POINTER(C.c_int), C.c_int, _dp]
+        lib.ref_match_keys.restype = C.c_int
+        _km = lib
+    return _km
+
+
+def ref_match(k1, k2, ratio=0.6, max_pts_visit=0):
+    k1 = np.ascontiguousarray(k1, np.uint8); k2 = np.ascontiguousarray(k2, np.uint8)
+    out = np.zeros((len(k1), 2), np.int32)
+    secs = C.c_double()
+    u = C.POINTER(C.c_ubyte)
+    cnt = ref_km().ref_match_keys(len(k1), k1.ctypes.data_as(u), len(k2), k2.ctypes.data_as(u), ratio, max_pts_visit,
+                                  out.ctypes.data_as(C.POINTER(C.c_int)), len(k1), C.byref(secs))
+    return out[:cnt].copy(), secs.value
+
+
+def port_match(k1, k2, ratio=0.6):
+    k1 = np.ascontiguousarray(k1, np.uint8); k2 = np.ascontiguousarray(k2, np.uint8)
+    out = np.zeros((len(k1), 2), np.int32)
+    u = C.POINTER(C.c_ubyte)
+    cnt = port().oracle_match_keys(len(k1), k1.ctypes.data_as(u), len(k2), k2.ctypes.data_as(u), ratio,
+                                   out.ctypes.data_as(C.POINTER(C.c_int)), len(k1))
+    return out[:cnt].copy()

@@ -1,0 +1,65 @@
+"""C-ABI surface: the library loads without a GPU and exports every symbol include/bsfm.h declares."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "bsfm.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b((?:bsfm_[a-z0-9_]+|run_sfm))\s*\(", src)
+    return sorted({n for n in names if n not in ("bsfm_allreduce_fn",)})
+
+
+def test_library_loads_and_exports_header(bsfm):
+    syms = header_symbols()
+    assert "run_sfm" in syms and "bsfm_match_keys_l2" in syms and len(syms) >= 24
+    for s in syms:
+        assert hasattr(bsfm.lib, s), f"{s} declared in include/bsfm.h but not exported"
+    assert sorted(bsfm._lib.SYMBOLS) == syms
+
+
+def test_camera_struct_layout_matches_reference(bsfm):
+    # sizeof(camera_params_t) measured on the reference build: oracle/_ref ref_sizeof_camera_params() == 504
+    assert C.sizeof(bsfm.CameraParams) == 504
+    assert bsfm.CameraParams.f.offset == 96 and bsfm.CameraParams.constrained.offset == 168
+    assert bsfm.CameraParams.f_scale.offset == 488
+
+
+def test_default_options_follow_run_sfm(bsfm):
+    o = bsfm.default_options()
+    assert o.itmax == 150                                    # MAX_ITERS, sfm.c:814
+    assert list(o.opts) == [1e-3, 1e-10, 0.0, 1e-12, 0.0, 4e-2]   # sfm.c:705-714
+    assert o.jacobian == bsfm.JAC_FD                         # projac=NULL, sfm.c:820-828
+
+
+def test_no_gpu_fails_loudly(bsfm, capfd):
+    if bsfm.lib.bsfm_device_count() > 0:
+        return
+    s = bsfm.synth_ba(6, 40, 3)
+    try:
+        bsfm.Problem(40, 6, s["rowptr"], s["colidx"], s["proj"], s["cams"], s["pts"])
+        raised = False
+    except RuntimeError:
+        raised = True
+    assert raised, "problem creation must fail without a HIP device (no CPU fallback)"
+    assert "no usable HIP device" in capfd.readouterr().err
+    rc, _ = bsfm.dense_chol_solve(np.eye(4), np.ones(4))
+    assert rc == -1
+
+
+def test_synth_scene_is_deterministic_and_sorted(bsfm):
+    a = bsfm.synth_ba(50, 500, 10)
+    b = bsfm.synth_ba(50, 500, 10)
+    assert np.array_equal(a["colidx"], b["colidx"]) and np.array_equal(a["proj"], b["proj"])
+    ci = a["colidx"].reshape(500, 10)
+    assert (np.diff(ci, axis=1) > 0).all()          # camera ascending inside every point row (vmask order)
+    assert a["rowptr"][-1] == 5000
+    band = bsfm.synth_ba(200, 300, 6, banded=True)
+    ci = band["colidx"].reshape(300, 6)
+    span = (ci.max(1) - ci.min(1))
+    assert ((span < 50) | (span > 150)).all()       # window of 50 neighbours (possibly wrapping)

