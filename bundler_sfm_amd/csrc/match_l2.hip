@@ -1,7 +1,274 @@
-// match_l2.hip -- placeholder, filled in below (brute-force 128-D uchar L2 matcher).
-#include "../../include/bsfm.h"
+// match_l2.hip -- brute-force SIFT descriptor matcher for gfx950 (replaces the ANN kd-tree of KeyMatchFull).
+//
+// Reference behaviour restated (paths relative to the reference tree):
+//   MatchKeys            src/keys2a.cpp:347-372      2-NN of every key of image j among the keys of image i,
+//                                                    keep (q, nn0) iff (double)d0 < ratio*ratio*(double)d1
+//   ANN distance         lib/ann_1.1_char/include/ANN/ANN.h:161-162   squared L2 over 128 uchar in int32
+//   KeyMatchFull main    src/KeyMatchFull.cpp:105-151                  pair loop + "j i / N / idx idx" text format
+// The reference searches approximately (priority search capped at 200 visited points); this kernel is the exact
+// search that approximation converges to (annMaxPtsVisit(0), eps = 0): distances are exact integers, so the match
+// list is bit-identical to the exact reference search (ties between the two nearest can never pass the strict test).
+//
+// MI355X design: a dense int8 contraction on v_mfma_i32_16x16x64_i8 with exact int32 accumulation.
+//   * uchar -> int8 by XOR 0x80 (x - 128) in registers; d = qa + qb - 2 * dot(a', b') with the per-key terms
+//     qa = |a|^2 - 256 sum(a') - 2*128^3, qb = |b|^2 - 256 sum(b') precomputed once per key (k_key_stats);
+//   * a workgroup owns 64 queries (4 row-groups x 2 k-steps of A fragments live in registers for the whole scan);
+//     each of its 4 waves streams a different 16-key slice of every 64-key database tile straight from global
+//     memory into B fragments (a 640 KB image stays L2-resident; no LDS staging needed: a B fragment is consumed
+//     by exactly one wave, 8 MFMAs per fragment pair);
+//   * every lane keeps a branch-free running top-2 (d0, d1, idx0) for its 16 (row, column-class) slots; the 64
+//     partial lists per query are merged through LDS at the end, then the ratio test runs in FP64 exactly as the
+//     reference writes it.
+//   * KeyMatchFull: all pairs (j < i) of one database image i go into ONE launch (grid = sum of query blocks).
+#include <hip/hip_runtime.h>
 #include <cstdio>
-extern "C" int bsfm_match_keys_l2(int, const unsigned char*, int, const unsigned char*, double, int*, int)
-{ fprintf(stderr, "[bsfm] matcher not built yet\n"); return BSFM_ERROR; }
-extern "C" int bsfm_key_match_full(int, const int*, const unsigned char* const*, double, int, const char*)
-{ fprintf(stderr, "[bsfm] matcher not built yet\n"); return BSFM_ERROR; }
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include "../../include/bsfm.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int QB = 64;             // queries per workgroup
+constexpr int BIG = 0x3fffffff;
+
+#define HIPM(call)                                                                                   \
+    do { hipError_t _e = (call); if (_e != hipSuccess) {                                             \
+        fprintf(stderr, "[bsfm] HIP error %s at %s:%d\n", hipGetErrorName(_e), __FILE__, __LINE__); \
+        return BSFM_ERROR; } } while (0)
+
+// per key: q = |x|^2 - 256 * sum(x - 128)   (the query side subtracts the constant 2*128^3 later)
+__global__ void k_key_stats(const unsigned char* __restrict__ keys, int n, int* __restrict__ q)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4* p = reinterpret_cast<const uint4*>(keys + (size_t)i * 128);
+    int sq = 0, s = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const uint4 v = p[w];
+        const unsigned u[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { const int x = (u[c] >> (8 * b)) & 255; sq += x * x; s += x - 128; }
+    }
+    q[i] = sq - 256 * s;
+}
+
+struct PairDesc { int q_off, q_n, out_off, blk0; };   // query image: key offset / count; output offset; first block
+
+__device__ __forceinline__ v4i load_frag(const unsigned char* __restrict__ keys, int key, int lane, int kstep)
+{
+    const uint4 v = *reinterpret_cast<const uint4*>(keys + (size_t)key * 128 + 64 * kstep + 16 * (lane >> 4));
+    v4i r;
+    r.x = (int)(v.x ^ 0x80808080u); r.y = (int)(v.y ^ 0x80808080u);
+    r.z = (int)(v.z ^ 0x80808080u); r.w = (int)(v.w ^ 0x80808080u);
+    return r;
+}
+
+// nn_out[out_off + query] = index of the accepted nearest neighbour in the database image, or -1.
+__global__ __launch_bounds__(256) void k_match_l2(const unsigned char* __restrict__ keys, const int* __restrict__ qstat,
+        const PairDesc* __restrict__ pairs, int npairs, int db_off, int db_n, double ratio_sq, int* __restrict__ nn_out)
+{
+    __shared__ int sm_d0[QB][64], sm_d1[QB][64], sm_i0[QB][64];
+    // locate the pair this block belongs to (pairs are few hundred at most: linear scan by one lane is fine)
+    __shared__ int s_pair;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = npairs - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pairs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+        s_pair = lo;
+    }
+    __syncthreads();
+    const PairDesc pd = pairs[s_pair];
+    const int qbase = (blockIdx.x - pd.blk0) * QB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned char* qkeys = keys + (size_t)pd.q_off * 128;
+    const unsigned char* dkeys = keys + (size_t)db_off * 128;
+
+    // A fragments: 4 row-groups x 2 k-steps, and the per-row query terms
+    v4i afrag[4][2];
+    int qa[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int row = min(qbase + 16 * g + (lane & 15), pd.q_n - 1);
+        afrag[g][0] = load_frag(qkeys, row, lane, 0);
+        afrag[g][1] = load_frag(qkeys, row, lane, 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = min(qbase + 16 * g + 4 * (lane >> 4) + r, pd.q_n - 1);
+            qa[g][r] = qstat[pd.q_off + rr] - 2 * 128 * 128 * 128;
+        }
+    }
+    int b0[4][4], b1[4][4], i0[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { b0[g][r] = BIG; b1[g][r] = BIG; i0[g][r] = -1; }
+
+    for (int tile = 0; tile < db_n; tile += 64) {
+        const int col = tile + 16 * wave + (lane & 15);
+        const int colc = min(col, db_n - 1);
+        const v4i bf0 = load_frag(dkeys, colc, lane, 0);
+        const v4i bf1 = load_frag(dkeys, colc, lane, 1);
+        const int qb = (col < db_n) ? qstat[db_off + colc] : BIG;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            v4i acc = { 0, 0, 0, 0 };
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[g][0], bf0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[g][1], bf1, acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = qa[g][r] + (qb - 2 * acc[r]);
+                const bool lt0 = d < b0[g][r], lt1 = d < b1[g][r];
+                b1[g][r] = lt0 ? b0[g][r] : (lt1 ? d : b1[g][r]);
+                i0[g][r] = lt0 ? col : i0[g][r];
+                b0[g][r] = lt0 ? d : b0[g][r];
+            }
+        }
+    }
+    // merge: slot = wave*16 + (lane&15); row = 16g + 4*(lane>>4) + r
+    const int slot = wave * 16 + (lane & 15);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * g + 4 * (lane >> 4) + r;
+            sm_d0[row][slot] = b0[g][r]; sm_d1[row][slot] = b1[g][r]; sm_i0[row][slot] = i0[g][r];
+        }
+    __syncthreads();
+    if (threadIdx.x < QB) {
+        const int row = threadIdx.x, q = qbase + row;
+        if (q < pd.q_n) {
+            int d0 = BIG, d1 = BIG, idx = -1;
+            for (int s = 0; s < 64; ++s) {
+                const int ss = (s + row) & 63;    // skewed walk: conflict-free LDS columns
+                const int c0 = sm_d0[row][ss], c1 = sm_d1[row][ss], ci = sm_i0[row][ss];
+                // insert the partial list (c0 <= c1) into the running (d0 <= d1)
+                if (c0 < d0) { d1 = d0; d0 = c0; idx = ci; }
+                else if (c0 < d1) d1 = c0;
+                if (c1 < d1) d1 = c1;
+            }
+            bool ok;
+            {
+#pragma clang fp contract(off)
+                ok = ((double)d0) < ratio_sq * ((double)d1);      // src/keys2a.cpp:362
+            }
+            nn_out[pd.out_off + q] = ok ? idx : -1;
+        }
+    }
+}
+
+struct DevKeys {
+    unsigned char* keys = nullptr; int* qstat = nullptr; PairDesc* pairs = nullptr; int* nn = nullptr;
+    ~DevKeys() { if (keys) (void)hipFree(keys); if (qstat) (void)hipFree(qstat); if (pairs) (void)hipFree(pairs); if (nn) (void)hipFree(nn); }
+};
+
+int have_device()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        fprintf(stderr, "[bsfm] FATAL: no usable HIP device; the matcher has no CPU fallback\n");
+        return 0;
+    }
+    return 1;
+}
+
+}  // namespace
+
+extern "C" int bsfm_match_keys_l2(int n1, const unsigned char* k1, int n2, const unsigned char* k2, double ratio,
+                                  int* out_pairs, int max_out)
+{
+    if (!have_device()) return BSFM_ERROR;
+    if (n1 < 0 || n2 < 2) {   // ANN aborts when asked for 2 neighbours among fewer points (ANN.h, annkPriSearch)
+        fprintf(stderr, "[bsfm] bsfm_match_keys_l2: need at least 2 database keys (n2 = %d)\n", n2);
+        return BSFM_ERROR;
+    }
+    if (n1 == 0) return 0;
+    DevKeys d;
+    const size_t tot = (size_t)n1 + n2;
+    HIPM(hipMalloc((void**)&d.keys, tot * 128)); HIPM(hipMalloc((void**)&d.qstat, tot * sizeof(int)));
+    HIPM(hipMalloc((void**)&d.pairs, sizeof(PairDesc))); HIPM(hipMalloc((void**)&d.nn, (size_t)n1 * sizeof(int)));
+    HIPM(hipMemcpy(d.keys, k1, (size_t)n1 * 128, hipMemcpyHostToDevice));
+    HIPM(hipMemcpy(d.keys + (size_t)n1 * 128, k2, (size_t)n2 * 128, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_key_stats, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, d.keys, (int)tot, d.qstat);
+    const PairDesc pd = { 0, n1, 0, 0 };
+    HIPM(hipMemcpy(d.pairs, &pd, sizeof(pd), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_match_l2, dim3((n1 + QB - 1) / QB), dim3(256), 0, 0, d.keys, d.qstat, d.pairs, 1, n1, n2,
+                       ratio * ratio, d.nn);
+    std::vector<int> nn(n1);
+    HIPM(hipDeviceSynchronize());
+    HIPM(hipMemcpy(nn.data(), d.nn, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost));
+    int cnt = 0;
+    for (int i = 0; i < n1; ++i)
+        if (nn[i] >= 0) {
+            if (cnt < max_out && out_pairs) { out_pairs[2 * cnt] = i; out_pairs[2 * cnt + 1] = nn[i]; }
+            ++cnt;
+        }
+    return cnt;
+}
+
+extern "C" int bsfm_key_match_full(int num_images, const int* num_keys, const unsigned char* const* keys,
+                                   double ratio, int window_radius, const char* out_path)
+{
+    if (!have_device()) return BSFM_ERROR;
+    FILE* f = fopen(out_path, "w");
+    if (!f) { printf("Could not open %s for writing.\n", out_path); return BSFM_ERROR; }   // KeyMatchFull.cpp:86-89
+    std::vector<size_t> off(num_images + 1, 0);
+    int maxk = 0;
+    for (int i = 0; i < num_images; ++i) { off[i + 1] = off[i] + (size_t)std::max(num_keys[i], 0); maxk = std::max(maxk, num_keys[i]); }
+    const size_t tot = off[num_images];
+    if (tot == 0) { fclose(f); return 0; }
+    if (tot > 0x7fffffffULL) { fprintf(stderr, "[bsfm] too many keys\n"); fclose(f); return BSFM_ERROR; }
+    DevKeys d;
+    HIPM(hipMalloc((void**)&d.keys, tot * 128)); HIPM(hipMalloc((void**)&d.qstat, tot * sizeof(int)));
+    HIPM(hipMalloc((void**)&d.pairs, (size_t)num_images * sizeof(PairDesc)));
+    HIPM(hipMalloc((void**)&d.nn, (size_t)num_images * (size_t)maxk * sizeof(int)));
+    for (int i = 0; i < num_images; ++i)
+        if (num_keys[i] > 0) HIPM(hipMemcpy(d.keys + off[i] * 128, keys[i], (size_t)num_keys[i] * 128, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_key_stats, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, d.keys, (int)tot, d.qstat);
+    std::vector<PairDesc> pairs;
+    std::vector<int> nn;
+    int total_pairs_written = 0;
+    for (int i = 0; i < num_images; ++i) {
+        if (num_keys[i] == 0) continue;
+        int start = 0;
+        if (window_radius > 0) start = std::max(i - window_radius, 0);   // KeyMatchFull.cpp:117-119
+        pairs.clear();
+        int blk = 0; size_t out = 0;
+        std::vector<int> js;
+        for (int j = start; j < i; ++j) {
+            if (num_keys[j] == 0) continue;
+            pairs.push_back({ (int)off[j], num_keys[j], (int)out, blk });
+            js.push_back(j);
+            blk += (num_keys[j] + QB - 1) / QB; out += (size_t)num_keys[j];
+        }
+        if (pairs.empty()) continue;
+        if (num_keys[i] < 2) {
+            fprintf(stderr, "[bsfm] image %d has fewer than 2 keys: the reference's ANN search aborts here; skipped\n", i);
+            continue;
+        }
+        HIPM(hipMemcpy(d.pairs, pairs.data(), pairs.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_match_l2, dim3(blk), dim3(256), 0, 0, d.keys, d.qstat, d.pairs, (int)pairs.size(),
+                           (int)off[i], num_keys[i], ratio * ratio, d.nn);
+        nn.resize(out);
+        HIPM(hipDeviceSynchronize());
+        HIPM(hipMemcpy(nn.data(), d.nn, out * sizeof(int), hipMemcpyDeviceToHost));
+        for (size_t p = 0; p < pairs.size(); ++p) {
+            const int* row = nn.data() + pairs[p].out_off;
+            int cnt = 0;
+            for (int q = 0; q < pairs[p].q_n; ++q) cnt += row[q] >= 0;
+            if (cnt >= 16) {   // KeyMatchFull.cpp:131-142
+                fprintf(f, "%d %d\n", js[p], i);
+                fprintf(f, "%d\n", cnt);
+                for (int q = 0; q < pairs[p].q_n; ++q) if (row[q] >= 0) fprintf(f, "%d %d\n", q, row[q]);
+                ++total_pairs_written;
+            }
+        }
+    }
+    fclose(f);
+    return total_pairs_written;
+}

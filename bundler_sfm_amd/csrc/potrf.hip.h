@@ -184,7 +184,8 @@ __global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int 
 {
     __shared__ double colbuf[2][POTRF_NB];
     __shared__ double rowbuf[2][POTRF_NB];
-    __shared__ double sbuf[2];
+    __shared__ double svec[POTRF_NB];      // 1/sqrt(pivot_j): finished columns of A / rows of X stay RAW in
+                                           // registers and are scaled once, at the store
     const int ti = threadIdx.x >> 5, tj = threadIdx.x & 31;
     const int base = k * POTRF_NB;
     double* T = S + (size_t)base * ld + base;
@@ -211,86 +212,70 @@ __global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int 
     if (threadIdx.x == 0) {
         const double piv = a[0][0];
         if (!(piv > 0.0) && base < n_total) atomicCAS(info, 0, base + 1);
-        sbuf[0] = rsqrt_f64(piv);
+        svec[0] = rsqrt_f64(piv);
     }
     __syncthreads();
-    for (int j = 0; j < POTRF_NB; ++j) {
-        const int cur = j & 1, nxt = cur ^ 1;
-        const int jb = j >> 4, jq = j >> 5;
-        const double s = sbuf[cur];
-        double lr[8], lc[4], xr[4];
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int r = ti + 16 * p;
-            lr[p] = (p >= jb) ? colbuf[cur][r] * s : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = tj + 32 * q;
-            lc[q] = (q >= jq && c > j) ? colbuf[cur][c] * s : 0.0;
-            xr[q] = (q <= jq) ? rowbuf[cur][c] * s : 0.0;
-        }
-        // finalize column j of L (rows >= j) and row j of X, then mask rows <= j out of the rank-1 updates
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int r = ti + 16 * p;
-            if (p >= jb) {
-                if (tj == (j & 31) && r >= j) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) if (q == jq) a[p][q] = lr[p];
-                }
-                if (r == j) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) x[p][q] = xr[q];
-                }
-                if (r <= j) lr[p] = 0.0;
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            if (p >= jb) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (q >= jq) a[p][q] -= lr[p] * lc[q];
-                    if (q <= jq) x[p][q] -= lr[p] * xr[q];
-                }
-            }
-        }
-        if (j + 1 < POTRF_NB) {
-            const int jn = j + 1, nb = jn >> 4, nq = jn >> 5;
-            if (tj == (jn & 31)) {
-#pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    double v = a[p][0];
-#pragma unroll
-                    for (int q = 1; q < 4; ++q) if (q == nq) v = a[p][q];
-                    colbuf[nxt][ti + 16 * p] = v;
-                    if (p == nb && ti == (jn & 15)) {      // owner of the next pivot
-                        if (!(v > 0.0) && base + jn < n_total) atomicCAS(info, 0, base + jn + 1);
-                        sbuf[nxt] = rsqrt_f64(v);
-                    }
-                }
-            }
-            if (ti == (jn & 15)) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    double v = x[0][q];
-#pragma unroll
-                    for (int p = 1; p < 8; ++p) if (p == nb) v = x[p][q];
-                    rowbuf[nxt][tj + 32 * q] = v;
-                }
-            }
-        }
-        __syncthreads();
+
+    // one column step for a fixed (compile-time) column-block index JQ = j >> 5
+#define BSFM_DIAG_STEP(JQ)                                                                                   \
+    {                                                                                                        \
+        const double s = svec[j];                                                                            \
+        const int jb = j >> 4;                                                                               \
+        double lc[4], xr[4];                                                                                 \
+        _Pragma("unroll") for (int q = JQ; q < 4; ++q) lc[q] = colbuf[cur][tj + 32 * q] * s;                 \
+        if (tj <= (j & 31)) lc[JQ] = 0.0;                                                                    \
+        _Pragma("unroll") for (int q = 0; q <= JQ; ++q) xr[q] = rowbuf[cur][tj + 32 * q] * s;                \
+        _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                      \
+            if (p >= jb) {                                                                                   \
+                double l = colbuf[cur][ti + 16 * p] * s;                                                     \
+                if (p == jb && ti <= (j & 15)) l = 0.0;                                                      \
+                _Pragma("unroll") for (int q = JQ; q < 4; ++q) a[p][q] -= l * lc[q];                         \
+                _Pragma("unroll") for (int q = 0; q <= JQ; ++q) x[p][q] -= l * xr[q];                        \
+            }                                                                                                \
+        }                                                                                                    \
+        if (j + 1 < POTRF_NB) {                                                                              \
+            const int jn = j + 1, nb = jn >> 4;                                                              \
+            constexpr int NQ0 = JQ, NQ1 = (JQ < 3) ? JQ + 1 : 3;                                             \
+            const bool nextq = (jn >> 5) != JQ;                                                              \
+            if (tj == (jn & 31)) {                                                                           \
+                _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                              \
+                    const double v = nextq ? a[p][NQ1] : a[p][NQ0];                                          \
+                    colbuf[nxt][ti + 16 * p] = v;                                                            \
+                    if (p == nb && ti == (jn & 15)) {                                                        \
+                        if (!(v > 0.0) && base + jn < n_total) atomicCAS(info, 0, base + jn + 1);            \
+                        svec[jn] = rsqrt_f64(v);                                                             \
+                    }                                                                                        \
+                }                                                                                            \
+            }                                                                                                \
+            if (ti == (jn & 15)) {                                                                           \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                              \
+                    double v = x[0][q];                                                                      \
+                    _Pragma("unroll") for (int p = 1; p < 8; ++p) if (p == nb) v = x[p][q];                  \
+                    rowbuf[nxt][tj + 32 * q] = v;                                                            \
+                }                                                                                            \
+            }                                                                                                \
+        }                                                                                                    \
+        __syncthreads();                                                                                     \
     }
+
+#pragma unroll 1
+    for (int j = 0; j < 32; ++j) { const int cur = j & 1, nxt = cur ^ 1; BSFM_DIAG_STEP(0) }
+#pragma unroll 1
+    for (int j = 32; j < 64; ++j) { const int cur = j & 1, nxt = cur ^ 1; BSFM_DIAG_STEP(1) }
+#pragma unroll 1
+    for (int j = 64; j < 96; ++j) { const int cur = j & 1, nxt = cur ^ 1; BSFM_DIAG_STEP(2) }
+#pragma unroll 1
+    for (int j = 96; j < 128; ++j) { const int cur = j & 1, nxt = cur ^ 1; BSFM_DIAG_STEP(3) }
+#undef BSFM_DIAG_STEP
+
     double* Li = Linv + (size_t)k * POTRF_NB * POTRF_NB;
 #pragma unroll
     for (int p = 0; p < 8; ++p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = ti + 16 * p, c = tj + 32 * q;
-            if (c <= r) T[(size_t)r * ld + c] = a[p][q];
-            Li[r * POTRF_NB + c] = (c <= r) ? x[p][q] : 0.0;
+            if (c <= r) T[(size_t)r * ld + c] = a[p][q] * svec[c];       // L = raw column * 1/sqrt(pivot)
+            Li[r * POTRF_NB + c] = (c <= r) ? x[p][q] * svec[r] : 0.0;   // inv(L) row r = raw row * 1/sqrt(pivot_r)
         }
 }
 

@@ -1,0 +1,114 @@
+"""Matcher parity.  CPU part: the oracle's exhaustive 2-NN (oracle/match_oracle.c) against the reference's own
+MatchKeys output (fixture generated from oracle/_ref with the ANN visit cap disabled = exact search, and with the
+shipped 200-visit cap).  GPU part: the HIP brute-force kernel must equal the exact reference search bit for bit."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_util as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MG = np.load(os.path.join(HERE, "golden", "match_golden.npz"))
+U = C.POINTER(C.c_ubyte)
+
+
+def synth_keys(B, n, seed, dup=None):
+    k = np.zeros((n, 128), np.uint8)
+    B.lib.bsfm_synth_keys(n, seed, None if dup is None else dup.ctypes.data_as(U), 0 if dup is None else len(dup),
+                          k.ctypes.data_as(U))
+    return k
+
+
+def gpu_match(B, k1, k2, ratio=0.6):
+    out = np.zeros((len(k1), 2), np.int32)
+    cnt = B.lib.bsfm_match_keys_l2(len(k1), k1.ctypes.data_as(U), len(k2), k2.ctypes.data_as(U), ratio,
+                                   out.ctypes.data_as(C.POINTER(C.c_int)), len(k1))
+    return cnt, out[:max(cnt, 0)]
+
+
+@pytest.mark.parametrize("name", ["a", "b", "tiny"])
+def test_oracle_equals_reference_exact_search(name):
+    got = O.port_match(MG[f"{name}_k1"], MG[f"{name}_k2"])
+    assert np.array_equal(got, MG[f"{name}_exact"])
+    # the shipped approximate search may only MISS matches relative to the exact one, never invent different ones
+    approx = {tuple(r) for r in MG[f"{name}_ann200"]}
+    assert approx <= {tuple(r) for r in got} or len(approx - {tuple(r) for r in got}) <= len(approx) // 20
+
+
+def test_integer_ratio_test_is_equivalent_to_the_double_compare():
+    # (double)d0 < 0.6*0.6*(double)d1  <=>  25*d0 < 9*d1 on the whole int32 range used
+    rng = np.random.default_rng(0)
+    d1 = rng.integers(0, 128 * 255 * 255 + 1, 200000)
+    thr = np.floor(0.36 * d1).astype(np.int64)
+    for delta in (-1, 0, 1):
+        d0 = np.clip(thr + delta, 0, None)
+        lhs = d0.astype(np.float64) < (0.6 * 0.6) * d1.astype(np.float64)
+        assert np.array_equal(lhs, 25 * d0 < 9 * d1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["a", "b", "tiny"])
+def test_gpu_matches_reference_fixture(gpu_bsfm, name):
+    cnt, got = gpu_match(gpu_bsfm, MG[f"{name}_k1"], MG[f"{name}_k2"])
+    assert cnt == len(MG[f"{name}_exact"])
+    assert np.array_equal(got, MG[f"{name}_exact"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n1,n2", [(1, 2), (63, 17), (64, 64), (65, 129), (500, 333), (2049, 1000)])
+def test_gpu_matches_oracle_ragged_sizes(gpu_bsfm, n1, n2):
+    B = gpu_bsfm
+    k2 = synth_keys(B, n2, 100 + n2)
+    k1 = synth_keys(B, n1, 200 + n1, dup=k2)
+    cnt, got = gpu_match(B, k1, k2)
+    ref = O.port_match(k1, k2)
+    assert cnt == len(ref) and np.array_equal(got, ref)
+    # extreme descriptors: all-zero / all-255 rows and exact duplicates (d0 == 0)
+    k1[0] = 0; k1[-1] = 255; k2[0] = 255
+    if n2 > 2:
+        k2[1] = k1[n1 // 2]
+    cnt, got = gpu_match(B, k1, k2)
+    ref = O.port_match(k1, k2)
+    assert cnt == len(ref) and np.array_equal(got, ref)
+
+
+@pytest.mark.gpu
+def test_gpu_rejects_what_the_reference_cannot_search(gpu_bsfm):
+    k = synth_keys(gpu_bsfm, 4, 1)
+    cnt, _ = gpu_match(gpu_bsfm, k, k[:1])
+    assert cnt == -1        # ANN aborts when asked for 2 neighbours among < 2 points
+
+
+@pytest.mark.gpu
+def test_key_match_full_text_is_byte_identical(gpu_bsfm, tmp_path):
+    """KeyMatchFull driver: 6 images, all pairs, output text vs the same loop driven by the CPU oracle
+    (src/KeyMatchFull.cpp:105-151: pair header 'j i', count, 'idx_j idx_i' lines, only pairs with >= 16 matches)."""
+    B = gpu_bsfm
+    sizes = [300, 0, 257, 400, 64, 350]
+    keys = []
+    prev = None
+    for i, nk in enumerate(sizes):
+        k = synth_keys(B, nk, 1000 + i, dup=prev) if nk else np.zeros((0, 128), np.uint8)
+        keys.append(k)
+        if nk:
+            prev = k
+    arr = (U * len(sizes))(*[k.ctypes.data_as(U) for k in keys])
+    nks = np.array(sizes, np.int32)
+    out = tmp_path / "matches.init.txt"
+    rc = B.lib.bsfm_key_match_full(len(sizes), nks.ctypes.data_as(C.POINTER(C.c_int)), arr, 0.6, -1, str(out).encode())
+    expect = []
+    npairs = 0
+    for i in range(len(sizes)):
+        if sizes[i] == 0:
+            continue
+        for j in range(i):
+            if sizes[j] == 0:
+                continue
+            mt = O.port_match(keys[j], keys[i])
+            if len(mt) >= 16:
+                npairs += 1
+                expect.append(f"{j} {i}\n{len(mt)}\n" + "".join(f"{a} {b}\n" for a, b in mt))
+    assert rc == npairs and npairs > 0
+    assert out.read_text() == "".join(expect)
