@@ -59,10 +59,11 @@ def shard_points(rowptr, world, rank):
 
 
 def syrk_flops_per_launch(sdim):
-    """Algorithmic FP64 flop of the trailing-update launches of one factorisation: step k updates the
-    T(T+1)/2 lower tiles (T = nblk-k-1) with a 128-deep product: 2*128^3 flop per tile."""
+    """Algorithmic FP64 flop of the timed trailing-update launches of one factorisation: step k updates the
+    T(T+1)/2 lower tiles (T = nblk-k-1) with a 128-deep product, 2*128^3 flop per tile; the first trailing column
+    (T tiles) runs on the lookahead stream, the timed bulk launch (k_syrk_update part 2) does the other T(T-1)/2."""
     nblk = (sdim + NB - 1) // NB
-    tiles = [t * (t + 1) // 2 for t in range(nblk - 1, 0, -1)]
+    tiles = [t * (t - 1) // 2 for t in range(nblk - 1, 1, -1)]
     return 2.0 * NB ** 3 * sum(tiles) / max(len(tiles), 1), len(tiles)
 
 

@@ -24,7 +24,10 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cmath>
+#include <cstdint>
+#include <vector>
 
 namespace bsfm {
 
@@ -36,7 +39,9 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 struct PotrfWorkspace {
     int ld = 0, nblk = 0, backend = 0;
-    double* panel = nullptr;   // (nblk-1) tiles of NB x NB, compact copy of the current panel
+    double* panel = nullptr;   // 2 x (nblk-1) tiles of NB x NB: compact copy of the current panel, double-buffered
+    hipStream_t s2 = nullptr;  // update stream of the lookahead schedule
+    hipEvent_t* evP = nullptr; hipEvent_t* evU = nullptr;   // panel k ready / trailing update k done
     double* linv = nullptr;    // nblk tiles: inverse of each diagonal factor tile
     double* y = nullptr;       // ld
     double* xs = nullptr;      // ld
@@ -52,6 +57,7 @@ struct PotrfWorkspace {
     // per-launch HIP-event timing of the trailing-update kernel (the roofline kernel bench.py reports)
     hipEvent_t* sy0 = nullptr; hipEvent_t* sy1 = nullptr; int sy_used = 0;
     double syrk_ms = 0.0; long long syrk_cnt = 0;
+    long long* dbg = nullptr;   // optional device buffer: cycle stamps of k_potrf_diag phases (BSFM_DEBUG_DIAG=1)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -135,14 +141,21 @@ __global__ __launch_bounds__(512, 4) void k_trsm_panel(double* __restrict__ S, i
 }
 
 // Trailing update: S_ij -= P_a P_b^T for k < j <= i (a = i-k-1, b = j-k-1), one tile per workgroup.
-__global__ __launch_bounds__(512, 4) void k_syrk_update(double* __restrict__ S, int ld, int k, const double* __restrict__ panel)
+// part 1 = only the first trailing column (b == 0, grid T): the tiles the NEXT panel needs (lookahead stream);
+// part 2 = every other tile (b >= 1, grid T(T-1)/2): the bulk, on the update stream.
+__global__ __launch_bounds__(512, 4) void k_syrk_update(double* __restrict__ S, int ld, int k, const double* __restrict__ panel, int part)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int t = blockIdx.x;
-    int a = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-    while ((a + 1) * (a + 2) / 2 <= t) ++a;
-    while (a * (a + 1) / 2 > t) --a;
-    const int b = t - a * (a + 1) / 2;
+    int a, b;
+    if (part == 1) { a = blockIdx.x; b = 0; }
+    else {
+        const int t = blockIdx.x;
+        a = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while ((a + 1) * (a + 2) / 2 <= t) ++a;
+        while (a * (a + 1) / 2 > t) --a;
+        b = t - a * (a + 1) / 2;
+        ++a; ++b;      // triangle of size T-1 shifted past the first column
+    }
     const int i = k + 1 + a, j = k + 1 + b;
     double acc[8][4];
 #pragma unroll
@@ -163,14 +176,19 @@ __global__ __launch_bounds__(512, 4) void k_syrk_update(double* __restrict__ S, 
         }
 }
 
-// Diagonal tile: fused Cholesky + inverse of the factor in ONE 512-thread workgroup (the serial critical path of
-// the factorisation).  Threads form a 16 x 32 grid; thread (ti,tj) owns rows ti+16p (p<8), cols tj+32q (q<4) of the
-// tile A and of X (X starts as I and ends as inv(L)): 32+32 FP64 accumulators in registers, block-cyclic so that
-// the shrinking trailing matrix stays balanced.  Per column j:
-//   s = 1/sqrt(pivot) (computed ONCE by the owner of (j,j) when it publishes the column), l = raw column * s,
-//   xr = raw X row * s;  A[p>=jb][q>=jq] -= l l^T ; X[p>=jb][q<=jq] -= l xr   (finished row/column blocks are
-//   skipped with wave-uniform predicates, so the issued FMA count follows the ~1/3 triangular work).
-// Raw column j+1 / X row j+1 / next pivot scale are published right after the update => ONE barrier per column.
+// Diagonal tile: Cholesky factor AND its inverse in ONE 512-thread workgroup -- the serial critical path of the
+// factorisation, so it is blocked to keep the truly serial work tiny:
+//   * the 128x128 tile lives in LDS (row stride 132 doubles) as 8x8 blocks of 16x16;
+//   * phase A, per block column s: wave 0 factors the 16x16 diagonal block (and inverts it) column by column with
+//     no workgroup barrier (single wave: LDS ops are in order); then the waves form the panel blocks
+//     T[I][s] <- T[I][s] * inv(L_ss)^T and the trailing updates T[I][J] -= T[I][s] T[J][s]^T as 16x16x16 products on
+//     v_mfma_f64_4x4x4_4b (16 instructions each);
+//   * phase B, inverse: X = inv(L) by block forward substitution, ONE WAVE PER BLOCK COLUMN J and no barriers:
+//     X[I][J] = -inv(L_II) * sum_{K=J}^{I-1} L[I][K] X[K][J]; X[K][J]^T is parked in the unused upper block T[J][K]
+//     so that every product is of the A * Bt^T ("NT") form the MFMA fragments read directly from LDS.
+constexpr int DG_TS = 132;                                   // LDS row stride of the tile (doubles)
+constexpr int DG_LDS_DOUBLES = POTRF_NB * DG_TS + 8 * 256;
+
 __device__ __forceinline__ double rsqrt_f64(double v)
 {
     double s = __builtin_amdgcn_rsq(v);          // v_rsq_f64 seed, two Newton steps to full precision
@@ -179,104 +197,198 @@ __device__ __forceinline__ double rsqrt_f64(double v)
     return s;
 }
 
-__global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int ld, int k, int n_total,
-        double* __restrict__ Linv, int* __restrict__ info)
+// acc[a] += A(16x16, row stride sa) * Bt(16x16, row stride sb)^T ; acc[a] holds rows 4a + (lane>>4), col lane&15.
+__device__ __forceinline__ void mma16_nt(double (&acc)[4], const double* A, int sa, const double* Bt, int sb, int lane)
 {
-    __shared__ double colbuf[2][POTRF_NB];
-    __shared__ double rowbuf[2][POTRF_NB];
-    __shared__ double svec[POTRF_NB];      // 1/sqrt(pivot_j): finished columns of A / rows of X stay RAW in
-                                           // registers and are scaled once, at the store
-    const int ti = threadIdx.x >> 5, tj = threadIdx.x & 31;
-    const int base = k * POTRF_NB;
-    double* T = S + (size_t)base * ld + base;
-    double a[8][4], x[8][4];
 #pragma unroll
-    for (int p = 0; p < 8; ++p)
+    for (int kk = 0; kk < 16; kk += 4) {
+        const double b = Bt[(lane & 15) * sb + kk + (lane >> 4)];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = ti + 16 * p, c = tj + 32 * q;
-            double v = 0.0;
-            if (base + r < n_total && base + c < n_total) { if (c <= r) v = T[(size_t)r * ld + c]; }
-            else if (r == c) v = 1.0;
-            a[p][q] = v;
-            x[p][q] = (r == c) ? 1.0 : 0.0;
+        for (int a = 0; a < 4; ++a) {
+            const double av = A[(4 * a + (lane & 3)) * sa + kk + (lane >> 4)];
+            acc[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b, acc[a], 0, 0, 0);
         }
-    if (tj == 0) {
-#pragma unroll
-        for (int p = 0; p < 8; ++p) colbuf[0][ti + 16 * p] = a[p][0];
     }
-    if (ti == 0) {
+}
+
+__global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int ld, int k, int n_total,
+        double* __restrict__ Linv, int* __restrict__ info, long long* __restrict__ dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) double dlds[];
+    long long t0 = 0; if (dbg && threadIdx.x == 0) t0 = wall_clock64();
+    double* T = dlds;                                  // [128][DG_TS]
+    double* Di = dlds + POTRF_NB * DG_TS;              // 8 blocks of 16x16: inverse diagonal blocks
+    // statically declared => guaranteed LDS address space (a volatile generic pointer compiled to FLAT ops + waits)
+    __shared__ double svec[POTRF_NB];      // raw pivots (statically declared => LDS address space)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int base = k * POTRF_NB;
+    double* G = S + (size_t)base * ld + base;
+
+    // load the tile (lower triangle; identity in the padding beyond n_total)
+    {
+        double v[32];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rowbuf[0][tj + 32 * q] = x[0][q];
-    }
-    if (threadIdx.x == 0) {
-        const double piv = a[0][0];
-        if (!(piv > 0.0) && base < n_total) atomicCAS(info, 0, base + 1);
-        svec[0] = rsqrt_f64(piv);
+        for (int it = 0; it < 32; ++it) {          // all 32 loads in flight before the first LDS store
+            const int idx = tid + 512 * it, r = idx >> 7, c = idx & 127;
+            v[it] = 0.0;
+            if (base + r < n_total && base + c < n_total) { if (c <= r) v[it] = G[(size_t)r * ld + c]; }
+            else if (r == c) v[it] = 1.0;
+        }
+#pragma unroll
+        for (int it = 0; it < 32; ++it) {
+            const int idx = tid + 512 * it, r = idx >> 7, c = idx & 127;
+            T[r * DG_TS + c] = v[it];
+        }
     }
     __syncthreads();
 
-    // one column step for a fixed (compile-time) column-block index JQ = j >> 5
-#define BSFM_DIAG_STEP(JQ)                                                                                   \
-    {                                                                                                        \
-        const double s = svec[j];                                                                            \
-        const int jb = j >> 4;                                                                               \
-        double lc[4], xr[4];                                                                                 \
-        _Pragma("unroll") for (int q = JQ; q < 4; ++q) lc[q] = colbuf[cur][tj + 32 * q] * s;                 \
-        if (tj <= (j & 31)) lc[JQ] = 0.0;                                                                    \
-        _Pragma("unroll") for (int q = 0; q <= JQ; ++q) xr[q] = rowbuf[cur][tj + 32 * q] * s;                \
-        _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                      \
-            if (p >= jb) {                                                                                   \
-                double l = colbuf[cur][ti + 16 * p] * s;                                                     \
-                if (p == jb && ti <= (j & 15)) l = 0.0;                                                      \
-                _Pragma("unroll") for (int q = JQ; q < 4; ++q) a[p][q] -= l * lc[q];                         \
-                _Pragma("unroll") for (int q = 0; q <= JQ; ++q) x[p][q] -= l * xr[q];                        \
-            }                                                                                                \
-        }                                                                                                    \
-        if (j + 1 < POTRF_NB) {                                                                              \
-            const int jn = j + 1, nb = jn >> 4;                                                              \
-            constexpr int NQ0 = JQ, NQ1 = (JQ < 3) ? JQ + 1 : 3;                                             \
-            const bool nextq = (jn >> 5) != JQ;                                                              \
-            if (tj == (jn & 31)) {                                                                           \
-                _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                              \
-                    const double v = nextq ? a[p][NQ1] : a[p][NQ0];                                          \
-                    colbuf[nxt][ti + 16 * p] = v;                                                            \
-                    if (p == nb && ti == (jn & 15)) {                                                        \
-                        if (!(v > 0.0) && base + jn < n_total) atomicCAS(info, 0, base + jn + 1);            \
-                        svec[jn] = rsqrt_f64(v);                                                             \
-                    }                                                                                        \
-                }                                                                                            \
-            }                                                                                                \
-            if (ti == (jn & 15)) {                                                                           \
-                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                              \
-                    double v = x[0][q];                                                                      \
-                    _Pragma("unroll") for (int p = 1; p < 8; ++p) if (p == nb) v = x[p][q];                  \
-                    rowbuf[nxt][tj + 32 * q] = v;                                                            \
-                }                                                                                            \
-            }                                                                                                \
-        }                                                                                                    \
-        __syncthreads();                                                                                     \
-    }
-
-#pragma unroll 1
-    for (int j = 0; j < 32; ++j) { const int cur = j & 1, nxt = cur ^ 1; BSFM_DIAG_STEP(0) }
-#pragma unroll 1
-    for (int j = 32; j < 64; ++j) { const int cur = j & 1, nxt = cur ^ 1; BSFM_DIAG_STEP(1) }
-#pragma unroll 1
-    for (int j = 64; j < 96; ++j) { const int cur = j & 1, nxt = cur ^ 1; BSFM_DIAG_STEP(2) }
-#pragma unroll 1
-    for (int j = 96; j < 128; ++j) { const int cur = j & 1, nxt = cur ^ 1; BSFM_DIAG_STEP(3) }
-#undef BSFM_DIAG_STEP
-
-    double* Li = Linv + (size_t)k * POTRF_NB * POTRF_NB;
+    if (dbg && threadIdx.x == 0) dbg[0] = wall_clock64() - t0;
+    long long tA1 = 0, tA2 = 0, tA3 = 0, tq = 0;
+    for (int s = 0; s < 8; ++s) {
+        if (dbg && threadIdx.x == 0) tq = wall_clock64();
+        // ---- A1: wave 0 factors the diagonal block (s,s) and its inverse, entirely in registers:
+        // lane (r = l&15, cg = l>>4) owns D[r][4cg..4cg+3] and X[r][4cg..4cg+3]; per column the pivot comes by
+        // v_readlane, the column / X-row by ds_bpermute (no LDS round trip, no barrier); the rank-1 updates use
+        // 1/pivot (v_rcp_f64 + 2 Newton steps) and all square roots are deferred to the end of the block.
+        if (wave == 0) {
+            double* B = T + (16 * s) * DG_TS + 16 * s;
+            const int r = lane & 15, cg = lane >> 4;
+            double d[4], x[4], pv[16];
 #pragma unroll
-    for (int p = 0; p < 8; ++p)
+            for (int t = 0; t < 4; ++t) {
+                const int c = 4 * cg + t;
+                d[t] = (c <= r) ? B[r * DG_TS + c] : 0.0;
+                x[t] = (c == r) ? 1.0 : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int jq = j >> 2, jo = j & 3;
+                const double mine = d[jo];                                  // static register select (j is unrolled)
+                const double col_r = __shfl(mine, r + 16 * jq, 64);
+                double col_c[4], xrow[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    col_c[t] = __shfl(mine, 4 * cg + t + 16 * jq, 64);
+                    xrow[t] = __shfl(x[t], j + 16 * cg, 64);
+                }
+                const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), j + 16 * jq),
+                                                    __builtin_amdgcn_readlane(__double2loint(mine), j + 16 * jq));
+                pv[j] = piv;
+                double inv = __builtin_amdgcn_rcp(piv);
+                inv = fma(fma(-piv, inv, 1.0), inv, inv);
+                inv = fma(fma(-piv, inv, 1.0), inv, inv);
+                const double lr = (r > j) ? col_r * inv : 0.0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int c = 4 * cg + t;
+                    d[t] -= lr * ((c > j) ? col_c[t] : 0.0);
+                    x[t] -= lr * xrow[t];
+                }
+            }
+            // first non-positive pivot = dpotrf's info
+            if (lane == 0) {
+                int bad = -1;
+#pragma unroll
+                for (int j = 15; j >= 0; --j) if (!(pv[j] > 0.0)) bad = j;
+                if (bad >= 0 && base + 16 * s + bad < n_total) atomicCAS(info, 0, base + 16 * s + bad + 1);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) svec[16 * s + j] = pv[j];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const double s_r = rsqrt_f64(svec[16 * s + r]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int c = 4 * cg + t;
+                const double s_c = rsqrt_f64(svec[16 * s + c]);
+                B[r * DG_TS + c] = (c <= r) ? d[t] * s_c : 0.0;             // L = raw column * 1/sqrt(pivot)
+                Di[s * 256 + r * 16 + c] = (c <= r) ? x[t] * s_r : 0.0;     // inv(L_ss) row r = raw row * 1/sqrt(pivot_r)
+            }
+        }
+        __syncthreads();
+        if (dbg && threadIdx.x == 0) { const long long t = wall_clock64(); tA1 += t - tq; tq = t; }
+        // ---- A2: panel blocks I = s+1 .. 7 : T[I][s] <- T[I][s] * inv(L_ss)^T
+        {
+            const int I = s + 1 + wave;
+            if (I < 8) {
+                double* X = T + (16 * I) * DG_TS + 16 * s;
+                double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+                mma16_nt(acc, X, DG_TS, Di + s * 256, 16, lane);
+#pragma unroll
+                for (int a = 0; a < 4; ++a) X[(4 * a + (lane >> 4)) * DG_TS + (lane & 15)] = acc[a];
+            }
+        }
+        __syncthreads();
+        if (dbg && threadIdx.x == 0) { const long long t = wall_clock64(); tA2 += t - tq; tq = t; }
+        // ---- A3: trailing blocks (I,J), s < J <= I < 8
+        {
+            const int rem = 7 - s;
+            const int cnt = rem * (rem + 1) / 2;
+            for (int idx = wave; idx < cnt; idx += 8) {
+                int a = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
+                while ((a + 1) * (a + 2) / 2 <= idx) ++a;
+                while (a * (a + 1) / 2 > idx) --a;
+                const int b = idx - a * (a + 1) / 2;
+                const int I = s + 1 + a, J = s + 1 + b;
+                double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+                mma16_nt(acc, T + (16 * I) * DG_TS + 16 * s, DG_TS, T + (16 * J) * DG_TS + 16 * s, DG_TS, lane);
+                double* C = T + (16 * I) * DG_TS + 16 * J;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) C[(4 * q + (lane >> 4)) * DG_TS + (lane & 15)] -= acc[q];
+            }
+        }
+        __syncthreads();
+        if (dbg && threadIdx.x == 0) { const long long t = wall_clock64(); tA3 += t - tq; tq = t; }
+    }
+    if (dbg && threadIdx.x == 0) { dbg[4] = tA1; dbg[5] = tA2; dbg[6] = tA3; }
+    if (dbg && threadIdx.x == 0) dbg[1] = wall_clock64() - t0;
+    // ---- write L back to S (lower triangle incl. diagonal)
+#pragma unroll 8
+    for (int it = 0; it < 32; ++it) {
+        const int idx = tid + 512 * it, r = idx >> 7, c = idx & 127;
+        if (c <= r) G[(size_t)r * ld + c] = T[r * DG_TS + c];
+    }
+    __syncthreads();
+    if (dbg && threadIdx.x == 0) dbg[2] = wall_clock64() - t0;
+    // ---- phase B: inverse, wave J owns block column J
+    double* Li = Linv + (size_t)k * POTRF_NB * POTRF_NB;
+    {
+        const int J = wave;
+        // X[J][J]^T = inv(L_JJ)^T parked in T[J][J] (L_JJ itself is no longer needed), and written out
+        double* DJ = T + (16 * J) * DG_TS + 16 * J;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int r = ti + 16 * p, c = tj + 32 * q;
-            if (c <= r) T[(size_t)r * ld + c] = a[p][q] * svec[c];       // L = raw column * 1/sqrt(pivot)
-            Li[r * POTRF_NB + c] = (c <= r) ? x[p][q] * svec[r] : 0.0;   // inv(L) row r = raw row * 1/sqrt(pivot_r)
+            const int r = 4 * q + (lane >> 4), c = lane & 15;
+            const double v = Di[J * 256 + r * 16 + c];
+            Li[(16 * J + r) * POTRF_NB + 16 * J + c] = v;
+            DJ[c * DG_TS + r] = v;
         }
+        // zero blocks above the diagonal in the output
+        for (int Iu = 0; Iu < J; ++Iu)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                Li[(16 * Iu + 4 * q + (lane >> 4)) * POTRF_NB + 16 * J + (lane & 15)] = 0.0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int I = J + 1; I < 8; ++I) {
+            double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+            for (int K = J; K < I; ++K)
+                mma16_nt(acc, T + (16 * I) * DG_TS + 16 * K, DG_TS, T + (16 * J) * DG_TS + 16 * K, DG_TS, lane);
+            double* U = T + (16 * J) * DG_TS + 16 * I;       // upper block (J,I): receives acc^T, then X[I][J]^T
+#pragma unroll
+            for (int q = 0; q < 4; ++q) U[(lane & 15) * DG_TS + 4 * q + (lane >> 4)] = acc[q];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            double res[4] = { 0.0, 0.0, 0.0, 0.0 };
+            mma16_nt(res, Di + I * 256, 16, U, DG_TS, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * q + (lane >> 4), c = lane & 15;
+                U[c * DG_TS + r] = -res[q];
+                Li[(16 * I + r) * POTRF_NB + 16 * J + c] = -res[q];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    if (dbg && threadIdx.x == 0) dbg[3] = wall_clock64() - t0;
 }
 
 // forward substitution step: tiles i > k do E_i -= L_ik y_k ; tile k+1 then computes y_{k+1} = Linv_{k+1} E_{k+1}.
@@ -358,6 +470,9 @@ inline void potrf_free(PotrfWorkspace& w)
     if (w.ev1) (void)hipEventDestroy(w.ev1);
     for (int i = 0; w.sy0 && i < w.nblk; ++i) { (void)hipEventDestroy(w.sy0[i]); (void)hipEventDestroy(w.sy1[i]); }
     delete[] w.sy0; delete[] w.sy1;
+    for (int i = 0; w.evP && i <= w.nblk; ++i) { (void)hipEventDestroy(w.evP[i]); (void)hipEventDestroy(w.evU[i]); }
+    delete[] w.evP; delete[] w.evU;
+    if (w.s2) (void)hipStreamDestroy(w.s2);
     w = PotrfWorkspace();
 }
 
@@ -365,14 +480,37 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
 {
     w.ld = ld; w.nblk = ld / POTRF_NB; w.backend = backend;
     const size_t tile = (size_t)POTRF_NB * POTRF_NB;
-    if (hipMalloc((void**)&w.panel, std::max<size_t>(1, (size_t)(w.nblk - 1)) * tile * sizeof(double)) != hipSuccess) return -1;
+    if (hipMalloc((void**)&w.panel, 2 * std::max<size_t>(1, (size_t)(w.nblk - 1)) * tile * sizeof(double)) != hipSuccess) return -1;
+    {   // The bulk trailing update must not occupy every CU, otherwise the 150 KB-LDS diagonal-tile workgroup of the
+        // lookahead stream can never be placed: reserve BSFM_PANEL_CUS compute units (default 32) by masking them
+        // out of the update stream (hipExtStreamCreateWithCUMask); 0 disables the reservation.
+        int reserve = 32;
+        if (const char* e = getenv("BSFM_PANEL_CUS")) reserve = atoi(e);
+        hipDeviceProp_t prop; int dev = 0; (void)hipGetDevice(&dev);
+        hipError_t rc = hipErrorUnknown;
+        if (reserve > 0 && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 2 * reserve) {
+            const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+            std::vector<uint32_t> mask(words, 0u);
+            for (int c = reserve; c < ncu; ++c) mask[c >> 5] |= 1u << (c & 31);
+            rc = hipExtStreamCreateWithCUMask(&w.s2, (uint32_t)words, mask.data());
+        }
+        if (rc != hipSuccess && hipStreamCreateWithFlags(&w.s2, hipStreamNonBlocking) != hipSuccess) return -1;
+    }
+    w.evP = new hipEvent_t[w.nblk + 1]; w.evU = new hipEvent_t[w.nblk + 1];
+    for (int i = 0; i <= w.nblk; ++i) {
+        if (hipEventCreateWithFlags(&w.evP[i], hipEventDisableTiming) != hipSuccess) return -1;
+        if (hipEventCreateWithFlags(&w.evU[i], hipEventDisableTiming) != hipSuccess) return -1;
+    }
     if (hipMalloc((void**)&w.linv, (size_t)w.nblk * tile * sizeof(double)) != hipSuccess) return -1;
     if (hipMalloc((void**)&w.y, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
     if (hipMalloc((void**)&w.xs, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
     if (hipMalloc((void**)&w.etmp, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
     (void)hipEventCreate(&w.ev0); (void)hipEventCreate(&w.ev1);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(DG_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
     w.sy0 = new hipEvent_t[w.nblk]; w.sy1 = new hipEvent_t[w.nblk];
     for (int i = 0; i < w.nblk; ++i) { (void)hipEventCreate(&w.sy0[i]); (void)hipEventCreate(&w.sy1[i]); }
+    if (getenv("BSFM_DEBUG_DIAG")) { (void)hipMalloc((void**)&w.dbg, 8 * sizeof(long long)); }
     if (backend == 1) {
         // cross-check backend only: rocSOLVER through dlopen, never linked
         w.rb_lib = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
@@ -409,24 +547,50 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
     const size_t lds_bytes = 2 * 128 * GEMM_LDS_STRIDE * sizeof(double);
     (void)hipMemsetAsync(w.etmp, 0, (size_t)ld * sizeof(double), st);
     (void)hipMemcpyAsync(w.etmp, E, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
-    for (int k = 0; k < nblk; ++k) {
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), 0, st, S, ld, k, n, w.linv, d_info);
+    // Lookahead schedule on two streams (st = panel stream, s2 = update stream):
+    //   st : [first trailing column of step k] -> diag(k+1) -> trsm(k+1)            (serial critical path)
+    //   s2 : [rest of the trailing update of step k], needs panel k only            (the MFMA bulk)
+    // The compact panel is double-buffered (k & 1): trsm(k+1) may run while the bulk of step k still reads panel k.
+    const size_t pstride = std::max<size_t>(1, (size_t)(w.nblk - 1)) * POTRF_NB * POTRF_NB;
+    const size_t diag_lds = DG_LDS_DOUBLES * sizeof(double);
+    (void)hipEventRecord(w.evU[w.nblk], st);                 // everything queued before the solve (S, E ready)
+    (void)hipStreamWaitEvent(w.s2, w.evU[w.nblk], 0);
+    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, 0, n, w.linv, d_info, w.dbg);
+    if (nblk > 1)
+        hipLaunchKernelGGL(k_trsm_panel, dim3(nblk - 1), dim3(512), lds_bytes, st, S, ld, 0, w.linv, w.panel);
+    (void)hipEventRecord(w.evP[0], st);
+    for (int k = 0; k + 1 < nblk; ++k) {
         const int T = nblk - k - 1;
-        if (T > 0) {
-            hipLaunchKernelGGL(k_trsm_panel, dim3(T), dim3(512), lds_bytes, st, S, ld, k,
-                               w.linv + (size_t)k * POTRF_NB * POTRF_NB, w.panel);
-            (void)hipEventRecord(w.sy0[k], st);
-            hipLaunchKernelGGL(k_syrk_update, dim3(T * (T + 1) / 2), dim3(512), lds_bytes, st, S, ld, k, w.panel);
-            (void)hipEventRecord(w.sy1[k], st);
+        double* pk = w.panel + (size_t)(k & 1) * pstride;
+        // update stream: bulk of step k
+        (void)hipStreamWaitEvent(w.s2, w.evP[k], 0);
+        if (T > 1) {
+            (void)hipEventRecord(w.sy0[k], w.s2);
+            hipLaunchKernelGGL(k_syrk_update, dim3(T * (T - 1) / 2), dim3(512), lds_bytes, w.s2, S, ld, k, pk, 2);
+            (void)hipEventRecord(w.sy1[k], w.s2);
             w.sy_used = k + 1;
         }
+        (void)hipEventRecord(w.evU[k], w.s2);
+        // panel stream: first trailing column of step k, then panel k+1
+        if (k > 0) (void)hipStreamWaitEvent(st, w.evU[k - 1], 0);   // column k+1 was last written by the bulk of step k-1
+        hipLaunchKernelGGL(k_syrk_update, dim3(T), dim3(512), lds_bytes, st, S, ld, k, pk, 1);
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, k + 1, n, w.linv, d_info, w.dbg);
+        if (T > 1)
+            hipLaunchKernelGGL(k_trsm_panel, dim3(T - 1), dim3(512), lds_bytes, st, S, ld, k + 1,
+                               w.linv + (size_t)(k + 1) * POTRF_NB * POTRF_NB, w.panel + (size_t)((k + 1) & 1) * pstride);
+        (void)hipEventRecord(w.evP[k + 1], st);
     }
+    if (nblk > 1) (void)hipStreamWaitEvent(st, w.evU[nblk - 2], 0);
     for (int k = -1; k < nblk - 1; ++k)
         hipLaunchKernelGGL(k_fwd_step, dim3(k < 0 ? 1 : nblk - k - 1), dim3(256), 0, st, S, ld, k, w.linv, w.etmp, w.y);
     for (int i = nblk; i >= 1; --i)
         hipLaunchKernelGGL(k_bwd_step, dim3(i == nblk ? 1 : i), dim3(256), 0, st, S, ld, i, nblk, w.linv, w.y, w.xs);
     (void)hipMemcpyAsync(x_out, w.xs, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
     if (w.ev1) (void)hipEventRecord(w.ev1, st);
+    if (w.dbg) {
+        long long h[8]; (void)hipStreamSynchronize(st); (void)hipMemcpy(h, w.dbg, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[bsfm] diag tile stamps (100 MHz ticks): load %lld, phaseA %lld (A1 %lld A2 %lld A3 %lld), store %lld, phaseB %lld\n", h[0], h[1], h[4], h[5], h[6], h[2], h[3]);
+    }
     return 0;
 }
 

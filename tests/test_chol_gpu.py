@@ -46,6 +46,8 @@ def test_not_positive_definite_reports_leading_minor(gpu_bsfm, n, bad):
     assert rc == bad + 1
 
 
+@pytest.mark.skipif(__import__("os").environ.get("BSFM_TEST_ROCSOLVER") != "1",
+                    reason="rocSOLVER cross-check costs ~2 min of library initialisation; set BSFM_TEST_ROCSOLVER=1")
 def test_cross_check_backend_agrees(gpu_bsfm):
     A, b = spd(700, 3)
     rc0, x0 = gpu_bsfm.dense_chol_solve(A, b, 0)
