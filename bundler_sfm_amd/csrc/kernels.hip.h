@@ -17,7 +17,9 @@
 //   camptr[m+1], camobs[nvis]               camera-major secondary index (replaces sba_crsm_col_elmidxs'
 //                                           per-call binary searches, sba_crsm.c:183-212)
 //   camtab[m*72]    per-camera derived row  (model.hip.h)
-//   J[nvis*(2cnp+6)] A_ij (2 x cnp) then B_ij (2 x 3), one contiguous record per observation
+//   J[nvis*(2cnp+6)] A_ij (2 x cnp) then B_ij (2 x 3), one contiguous record per observation (point-major);
+//   Jc               the same records in CAMERA-major order (position campos[k]): the camera-side consumers
+//                    (U_j/ea_j, Schur tasks, e_j) then read contiguous / monotone streams instead of random 192-byte gathers
 //   U[m*cnp*cnp], ea[m*cnp], V[n*6] (packed upper), Vinv[n*6], eb[n*3], S[ld*ld], E[ld]
 // W_ij = A_ij^T B_ij is never materialised (1.08 GB at 5 M observations): every consumer uses the factored
 // form, e.g. Y_ij W_ik^T = A_ij^T (B_ij V*^-1 B_ik^T) A_ik with a 2x2 core, and W_ij^T da = B_ij^T (A_ij da).
@@ -37,13 +39,15 @@ struct DevProblem {
     const double* x;
     const int* obs_cam; const int* obs_pt; const int* rowptr;
     const int* camptr; const int* camobs;
+    const int* campos;            // obs k -> its position in camera-major order (inverse of camobs)
+    const int* cam_pt;            // camera-major position -> point index
     const double* Rinit; const double* finit;
     // constraints
     const unsigned char* ccon; const double* cval; const double* cw;   // m*cnp (may be null)
     const unsigned char* pcon; const double* pval; double pweight;     // n, 3n (may be null)
     double nvis_global;
     // work arrays
-    double* J; double* U; double* ea; double* V; double* Vinv; double* eb;
+    double* J; double* Jc; double* U; double* ea; double* V; double* Vinv; double* eb;
 };
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -146,7 +150,8 @@ __global__ __launch_bounds__(RES_BLOCK) void k_residual(ModelCfg cfg, int nvis,
 template <int CNP, bool FD>
 __global__ __launch_bounds__(256) void k_jacobian(ModelCfg cfg, int nvis,
         const int* __restrict__ obs_cam, const int* __restrict__ obs_pt,
-        const double* __restrict__ camtab, const double* __restrict__ pb, double* __restrict__ J)
+        const double* __restrict__ camtab, const double* __restrict__ pb, double* __restrict__ J,
+        const int* __restrict__ campos, double* __restrict__ Jc)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= nvis) return;
@@ -157,10 +162,11 @@ __global__ __launch_bounds__(256) void k_jacobian(ModelCfg cfg, int nvis,
     else    jac_analytic<CNP>(cfg, ct, b[0], b[1], b[2], A, B, x0, x1);
     constexpr int JS = 2 * CNP + 6;
     double2* out = reinterpret_cast<double2*>(J + (size_t)k * JS);   // JS is even -> 16-byte aligned records
+    double2* outc = reinterpret_cast<double2*>(Jc + (size_t)campos[k] * JS);
 #pragma unroll
-    for (int q = 0; q < CNP; ++q) out[q] = make_double2(A[2 * q], A[2 * q + 1]);
+    for (int q = 0; q < CNP; ++q) { const double2 v = make_double2(A[2 * q], A[2 * q + 1]); out[q] = v; outc[q] = v; }
 #pragma unroll
-    for (int q = 0; q < 3; ++q) out[CNP + q] = make_double2(B[2 * q], B[2 * q + 1]);
+    for (int q = 0; q < 3; ++q) { const double2 v = make_double2(B[2 * q], B[2 * q + 1]); out[CNP + q] = v; outc[CNP + q] = v; }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(256) void k_cam_blocks(DevProblem P, const double* 
         const int t1 = P.camptr[j + 1];
         for (int t = P.camptr[j] + threadIdx.x; t < t1; t += 256) {
             const int k = P.camobs[t];
-            const double* A = P.J + (size_t)k * JS;
+            const double* A = P.Jc + (size_t)t * JS;
             double a[2 * CNP];
 #pragma unroll
             for (int q = 0; q < 2 * CNP; ++q) a[q] = A[q];
@@ -302,12 +308,23 @@ __global__ __launch_bounds__(256) void k_schur_tasks(DevProblem P, const SchurTa
     if (grp < 21) {
         for (int t = grp; t < tk.count; t += 21) {
             const int2 tr = triples[tk.start + t];
-            const double* Ja = P.J + (size_t)tr.x * JS;
-            const double* Jb = P.J + (size_t)tr.y * JS;
-            const double* vi = P.Vinv + (size_t)P.obs_pt[tr.x] * 6;
-            const double i00 = vi[0], i01 = vi[1], i02 = vi[2], i11 = vi[3], i12 = vi[4], i22 = vi[5];
-            const double* Ba = Ja + 2 * CNP;
-            const double* Bb = Jb + 2 * CNP;
+            const double* Ja = P.Jc + (size_t)tr.x * JS;        // triples hold CAMERA-major positions
+            const double* Jb = P.Jc + (size_t)tr.y * JS;
+            const double* vi = P.Vinv + (size_t)P.cam_pt[tr.x] * 6;
+            // 16-byte loads of the contiguous pieces (records are 16-byte aligned: JS is even): the kernel is bound by
+            // line requests on the texture path, so halving the load-instruction count is what matters
+            double vv[6], Ba[6], Jbv[2 * CNP + 6];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const double2 t2 = reinterpret_cast<const double2*>(vi)[q]; vv[2 * q] = t2.x; vv[2 * q + 1] = t2.y;
+                const double2 u2 = reinterpret_cast<const double2*>(Ja + 2 * CNP)[q]; Ba[2 * q] = u2.x; Ba[2 * q + 1] = u2.y;
+            }
+#pragma unroll
+            for (int q = 0; q < CNP + 3; ++q) {
+                const double2 t2 = reinterpret_cast<const double2*>(Jb)[q]; Jbv[2 * q] = t2.x; Jbv[2 * q + 1] = t2.y;
+            }
+            const double i00 = vv[0], i01 = vv[1], i02 = vv[2], i11 = vv[3], i12 = vv[4], i22 = vv[5];
+            const double* Bb = Jbv + 2 * CNP;
             // C = B_a V^-1 (2x3), M = C B_b^T (2x2)
             const double c00 = Ba[0] * i00 + Ba[1] * i01 + Ba[2] * i02;
             const double c01 = Ba[0] * i01 + Ba[1] * i11 + Ba[2] * i12;
@@ -322,7 +339,7 @@ __global__ __launch_bounds__(256) void k_schur_tasks(DevProblem P, const SchurTa
             double T0[CNP], T1[CNP];
 #pragma unroll
             for (int c = 0; c < CNP; ++c) {
-                const double b0 = Jb[c], b1 = Jb[CNP + c];
+                const double b0 = Jbv[c], b1 = Jbv[CNP + c];
                 T0[c] = m00 * b0 + m01 * b1;
                 T1[c] = m10 * b0 + m11 * b1;
             }
@@ -408,14 +425,13 @@ __global__ __launch_bounds__(256) void k_schur_rhs(DevProblem P, int add_ea, dou
     for (int q = 0; q < CNP; ++q) acc[q] = 0.0;
     const int t1 = P.camptr[j + 1];
     for (int t = P.camptr[j] + threadIdx.x; t < t1; t += 256) {
-        const int k = P.camobs[t];
-        const int i = P.obs_pt[k];
+        const int i = P.cam_pt[t];
         const double* vi = P.Vinv + (size_t)i * 6;
         const double* g = P.eb + (size_t)i * 3;
         const double t0 = vi[0] * g[0] + vi[1] * g[1] + vi[2] * g[2];
         const double t1v = vi[1] * g[0] + vi[3] * g[1] + vi[4] * g[2];
         const double t2 = vi[2] * g[0] + vi[4] * g[1] + vi[5] * g[2];
-        const double* A = P.J + (size_t)k * JS;
+        const double* A = P.Jc + (size_t)t * JS;
         const double* B = A + 2 * CNP;
         const double s0 = B[0] * t0 + B[1] * t1v + B[2] * t2;
         const double s1 = B[3] * t0 + B[4] * t1v + B[5] * t2;

@@ -112,6 +112,150 @@ __device__ __forceinline__ void gemm_nt_128(const double* __restrict__ A, int ld
 #undef BSFM_GLOAD
 }
 
+// Latency-critical variant for the panel chain: C(64 x 128) = A(64 x K) * B(128 x K)^T by a 256-thread workgroup
+// (4 waves, 32 x 64 each).  The tiles of the serial chain (panel solve, first trailing column) are split into two
+// such halves so that twice as many CUs share the chain's MFMA work.
+__device__ __forceinline__ void gemm_nt_64(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
+                                           int K, double* __restrict__ lds, double (&acc)[8][4])
+{
+    double* As = lds;
+    double* Bs = lds + 64 * GEMM_LDS_STRIDE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
+    double2 pa0, pa1, pb0, pb1, pb2, pb3;
+    const int srow = tid >> 3, sc2 = (tid & 7) * 2;     // 32 rows per pass
+    const double* Ag = A + (size_t)srow * lda + sc2;
+    const double* Bg = B + (size_t)srow * ldb + sc2;
+    double* Asw = As + srow * GEMM_LDS_STRIDE + sc2;
+    double* Bsw = Bs + srow * GEMM_LDS_STRIDE + sc2;
+#define BSFM_GLOAD64(kc)                                                                    \
+    pa0 = *reinterpret_cast<const double2*>(Ag + (kc));                                     \
+    pa1 = *reinterpret_cast<const double2*>(Ag + (size_t)32 * lda + (kc));                  \
+    pb0 = *reinterpret_cast<const double2*>(Bg + (kc));                                     \
+    pb1 = *reinterpret_cast<const double2*>(Bg + (size_t)32 * ldb + (kc));                  \
+    pb2 = *reinterpret_cast<const double2*>(Bg + (size_t)64 * ldb + (kc));                  \
+    pb3 = *reinterpret_cast<const double2*>(Bg + (size_t)96 * ldb + (kc));
+    BSFM_GLOAD64(0)
+    for (int kc = 0; kc < K; kc += GEMM_KC) {
+        __syncthreads();
+        *reinterpret_cast<double2*>(Asw) = pa0;
+        *reinterpret_cast<double2*>(Asw + 32 * GEMM_LDS_STRIDE) = pa1;
+        *reinterpret_cast<double2*>(Bsw) = pb0;
+        *reinterpret_cast<double2*>(Bsw + 32 * GEMM_LDS_STRIDE) = pb1;
+        *reinterpret_cast<double2*>(Bsw + 64 * GEMM_LDS_STRIDE) = pb2;
+        *reinterpret_cast<double2*>(Bsw + 96 * GEMM_LDS_STRIDE) = pb3;
+        __syncthreads();
+        if (kc + GEMM_KC < K) { BSFM_GLOAD64(kc + GEMM_KC) }
+#pragma unroll
+        for (int kk = 0; kk < GEMM_KC; kk += 4) {
+            double b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                b[u] = Bs[(wc + 16 * u + (lane & 15)) * GEMM_LDS_STRIDE + kk + (lane >> 4)];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const double a = As[(wr + 4 * t + (lane & 3)) * GEMM_LDS_STRIDE + kk + (lane >> 4)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b[u], acc[t][u], 0, 0, 0);
+            }
+        }
+    }
+#undef BSFM_GLOAD64
+}
+
+// Panel, two halves per tile: workgroup (tile, half) computes rows 64*half .. +63 of X_i = S_ik * Linv_k^T.
+// y_k = inv(L_kk) * E_k for one tile (forward substitution rides on the factorisation chain: E_k is final once the
+// first-trailing-column launch of step k-1 has run).
+__device__ __forceinline__ void fwd_tile_solve(const double* __restrict__ Linv, const double* __restrict__ Ek,
+                                               double* __restrict__ yk, double* __restrict__ lds)
+{
+    double* vec = lds; double* red = lds + POTRF_NB;
+    const int r = threadIdx.x & 127, h = threadIdx.x >> 7;
+    if (threadIdx.x < POTRF_NB) vec[threadIdx.x] = Ek[threadIdx.x];
+    __syncthreads();
+    const double* Li = Linv + (size_t)r * POTRF_NB + 64 * h;
+    double s = 0.0;
+#pragma unroll 8
+    for (int c = 0; c < 64; ++c) s += Li[c] * vec[64 * h + c];
+    red[h * POTRF_NB + r] = s;
+    __syncthreads();
+    if (threadIdx.x < POTRF_NB) yk[r] = red[r] + red[POTRF_NB + r];
+}
+
+__global__ __launch_bounds__(256) void k_fwd_last(const double* __restrict__ Linv, const double* __restrict__ Ek, double* __restrict__ yk)
+{
+    __shared__ double sm[3 * POTRF_NB];
+    fwd_tile_solve(Linv, Ek, yk, sm);
+}
+
+__global__ __launch_bounds__(256) void k_trsm_panel64(double* __restrict__ S, int ld, int k,
+        const double* __restrict__ Linv, double* __restrict__ panel, int nwork, const double* __restrict__ E, double* __restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if ((int)blockIdx.x == nwork) {          // the extra workgroup: y_k = inv(L_kk) E_k
+        fwd_tile_solve(Linv, E + (size_t)k * POTRF_NB, y + (size_t)k * POTRF_NB, lds);
+        return;
+    }
+    const int tile = blockIdx.x >> 1, half = blockIdx.x & 1;
+    double* Sik = S + ((size_t)(k + 1 + tile) * POTRF_NB + 64 * half) * ld + (size_t)k * POTRF_NB;
+    double acc[8][4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[t][u] = 0.0;
+    gemm_nt_64(Sik, ld, Linv, POTRF_NB, POTRF_NB, lds, acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
+    double* Pt = panel + (size_t)tile * POTRF_NB * POTRF_NB + (size_t)(64 * half) * POTRF_NB;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = wr + 4 * t + (lane >> 4), col = wc + 16 * u + (lane & 15);
+            const double v = acc[t][u];
+            Sik[(size_t)row * ld + col] = v;
+            Pt[row * POTRF_NB + col] = v;
+        }
+}
+
+// First trailing column, two halves per tile: S_{k+1+a, k+1} -= P_a P_0^T.
+__global__ __launch_bounds__(256) void k_syrk_col64(double* __restrict__ S, int ld, int k, const double* __restrict__ panel,
+        double* __restrict__ E, const double* __restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int a = blockIdx.x >> 1, half = blockIdx.x & 1;
+    {   // forward substitution: E_{k+1+a}[rows of this half] -= L_{k+1+a,k}[rows] * y_k   (4 lanes per row)
+        const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+        const double* Pr = panel + (size_t)a * POTRF_NB * POTRF_NB + (size_t)(64 * half + row) * POTRF_NB + 32 * part;
+        const double* yk = y + (size_t)k * POTRF_NB + 32 * part;
+        double sacc = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < 32; ++c) sacc += Pr[c] * yk[c];
+        sacc += __shfl_xor(sacc, 1, 64);
+        sacc += __shfl_xor(sacc, 2, 64);
+        if (part == 0) E[(size_t)(k + 1 + a) * POTRF_NB + 64 * half + row] -= sacc;
+    }
+    double acc[8][4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[t][u] = 0.0;
+    gemm_nt_64(panel + (size_t)a * POTRF_NB * POTRF_NB + (size_t)(64 * half) * POTRF_NB, POTRF_NB, panel, POTRF_NB,
+               POTRF_NB, lds, acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
+    double* Sij = S + ((size_t)(k + 1 + a) * POTRF_NB + 64 * half) * ld + (size_t)(k + 1) * POTRF_NB;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = wr + 4 * t + (lane >> 4), col = wc + 16 * u + (lane & 15);
+            Sij[(size_t)row * ld + col] -= acc[t][u];
+        }
+}
+
 // Panel: X_i = S_ik * Linv_k^T for i = k+1 .. nblk-1; writes X back into S (it is L) and into the compact panel.
 __global__ __launch_bounds__(512, 4) void k_trsm_panel(double* __restrict__ S, int ld, int k,
         const double* __restrict__ Linv, double* __restrict__ panel)
@@ -553,11 +697,15 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
     // The compact panel is double-buffered (k & 1): trsm(k+1) may run while the bulk of step k still reads panel k.
     const size_t pstride = std::max<size_t>(1, (size_t)(w.nblk - 1)) * POTRF_NB * POTRF_NB;
     const size_t diag_lds = DG_LDS_DOUBLES * sizeof(double);
+    const size_t lds64 = (64 + 128) * GEMM_LDS_STRIDE * sizeof(double);
     (void)hipEventRecord(w.evU[w.nblk], st);                 // everything queued before the solve (S, E ready)
     (void)hipStreamWaitEvent(w.s2, w.evU[w.nblk], 0);
     hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, 0, n, w.linv, d_info, w.dbg);
     if (nblk > 1)
-        hipLaunchKernelGGL(k_trsm_panel, dim3(nblk - 1), dim3(512), lds_bytes, st, S, ld, 0, w.linv, w.panel);
+        hipLaunchKernelGGL(k_trsm_panel64, dim3(2 * (nblk - 1) + 1), dim3(256), lds64, st, S, ld, 0, w.linv, w.panel,
+                           2 * (nblk - 1), w.etmp, w.y);
+    else
+        hipLaunchKernelGGL(k_fwd_last, dim3(1), dim3(256), 0, st, w.linv, w.etmp, w.y);
     (void)hipEventRecord(w.evP[0], st);
     for (int k = 0; k + 1 < nblk; ++k) {
         const int T = nblk - k - 1;
@@ -573,16 +721,18 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         (void)hipEventRecord(w.evU[k], w.s2);
         // panel stream: first trailing column of step k, then panel k+1
         if (k > 0) (void)hipStreamWaitEvent(st, w.evU[k - 1], 0);   // column k+1 was last written by the bulk of step k-1
-        hipLaunchKernelGGL(k_syrk_update, dim3(T), dim3(512), lds_bytes, st, S, ld, k, pk, 1);
+        hipLaunchKernelGGL(k_syrk_col64, dim3(2 * T), dim3(256), lds64, st, S, ld, k, pk, w.etmp, w.y);
         hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, k + 1, n, w.linv, d_info, w.dbg);
         if (T > 1)
-            hipLaunchKernelGGL(k_trsm_panel, dim3(T - 1), dim3(512), lds_bytes, st, S, ld, k + 1,
-                               w.linv + (size_t)(k + 1) * POTRF_NB * POTRF_NB, w.panel + (size_t)((k + 1) & 1) * pstride);
+            hipLaunchKernelGGL(k_trsm_panel64, dim3(2 * (T - 1) + 1), dim3(256), lds64, st, S, ld, k + 1,
+                               w.linv + (size_t)(k + 1) * POTRF_NB * POTRF_NB, w.panel + (size_t)((k + 1) & 1) * pstride,
+                               2 * (T - 1), w.etmp, w.y);
+        else   // last tile: no panel below it, only its forward-substitution solve
+            hipLaunchKernelGGL(k_fwd_last, dim3(1), dim3(256), 0, st, w.linv + (size_t)(k + 1) * POTRF_NB * POTRF_NB,
+                               w.etmp + (size_t)(k + 1) * POTRF_NB, w.y + (size_t)(k + 1) * POTRF_NB);
         (void)hipEventRecord(w.evP[k + 1], st);
     }
     if (nblk > 1) (void)hipStreamWaitEvent(st, w.evU[nblk - 2], 0);
-    for (int k = -1; k < nblk - 1; ++k)
-        hipLaunchKernelGGL(k_fwd_step, dim3(k < 0 ? 1 : nblk - k - 1), dim3(256), 0, st, S, ld, k, w.linv, w.etmp, w.y);
     for (int i = nblk; i >= 1; --i)
         hipLaunchKernelGGL(k_bwd_step, dim3(i == nblk ? 1 : i), dim3(256), 0, st, S, ld, i, nblk, w.linv, w.y, w.xs);
     (void)hipMemcpyAsync(x_out, w.xs, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);

@@ -64,12 +64,13 @@ struct bsfm_problem {
     // device
     double *d_x = nullptr, *d_Rinit = nullptr, *d_finit = nullptr;
     int *d_obs_cam = nullptr, *d_obs_pt = nullptr, *d_rowptr = nullptr, *d_camptr = nullptr, *d_camobs = nullptr;
+    int *d_campos = nullptr, *d_cam_pt = nullptr;
     unsigned char *d_ccon = nullptr, *d_pcon = nullptr;
     double *d_cval = nullptr, *d_cw = nullptr, *d_pval = nullptr;
     double *d_p = nullptr, *d_pdp = nullptr, *d_dp = nullptr;
     double *d_camtab = nullptr, *d_camtab_trial = nullptr;
     double *d_e = nullptr, *d_hx = nullptr;
-    double *d_J = nullptr, *d_U = nullptr, *d_ea = nullptr, *d_V = nullptr, *d_Vinv = nullptr, *d_eb = nullptr;
+    double *d_J = nullptr, *d_Jc = nullptr, *d_U = nullptr, *d_ea = nullptr, *d_V = nullptr, *d_Vinv = nullptr, *d_eb = nullptr;
     double *d_S = nullptr, *d_E = nullptr;
     double *d_partials = nullptr;       // schur task partials
     double *d_red = nullptr;            // block partials for reductions
@@ -99,7 +100,7 @@ namespace {
 void free_all(bsfm_problem* pb)
 {
     void* ptrs[] = { pb->d_x, pb->d_Rinit, pb->d_finit, pb->d_obs_cam, pb->d_obs_pt, pb->d_rowptr, pb->d_camptr,
-                     pb->d_camobs, pb->d_ccon, pb->d_pcon, pb->d_cval, pb->d_cw, pb->d_pval, pb->d_p, pb->d_pdp,
+                     pb->d_camobs, pb->d_campos, pb->d_cam_pt, pb->d_Jc, pb->d_ccon, pb->d_pcon, pb->d_cval, pb->d_cw, pb->d_pval, pb->d_p, pb->d_pdp,
                      pb->d_dp, pb->d_camtab, pb->d_camtab_trial, pb->d_e, pb->d_hx, pb->d_J, pb->d_U, pb->d_ea,
                      pb->d_V, pb->d_Vinv, pb->d_eb, pb->d_S, pb->d_E, pb->d_partials, pb->d_red, pb->d_scal,
                      pb->d_flags, pb->d_triples, pb->d_tasks, pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0 };
@@ -113,7 +114,8 @@ void free_all(bsfm_problem* pb)
 
 // Builds the co-visibility triple list bucketed by reduced-camera block (j <= k), in (j,k) order and,
 // inside a block, in point order -- the order the reference visits them (sba_levmar.c:1218-1268).
-int build_schur_structure(bsfm_problem* pb, const bsfm_problem_desc_t* d)
+int build_schur_structure(bsfm_problem* pb, const bsfm_problem_desc_t* d, const std::vector<int>& campos,
+                          const std::vector<int>& cam_pt)
 {
     const int n = d->n, m = d->m, mcon = d->mcon, mm = m - mcon;
     std::vector<int2> triples;
@@ -143,7 +145,7 @@ int build_schur_structure(bsfm_problem* pb, const bsfm_problem_desc_t* d)
                 const int ja = d->colidx[a]; if (ja < mcon) continue;
                 for (int b = a; b < d->rowptr[i + 1]; ++b) {
                     const size_t key = (size_t)(ja - mcon) * mm + (d->colidx[b] - mcon);
-                    triples[cur[key]++] = make_int2(a, b);
+                    triples[cur[key]++] = make_int2(campos[a], campos[b]);
                 }
             }
     } else {
@@ -161,7 +163,7 @@ int build_schur_structure(bsfm_problem* pb, const bsfm_problem_desc_t* d)
                 blk_j.push_back(mcon + (int)(recs[q].key / mm)); blk_k.push_back(mcon + (int)(recs[q].key % mm));
                 blk_start.push_back((int)q);
             }
-            triples[q] = make_int2(recs[q].a, recs[q].b);
+            triples[q] = make_int2(campos[recs[q].a], campos[recs[q].b]);
         }
     }
     blk_start.push_back((int)total);
@@ -287,10 +289,10 @@ int compute_normal_blocks(bsfm_problem* pb)
     if (P.nvis > 0) {
         if (pb->opt.jacobian == BSFM_JAC_FD) {
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_jacobian<C, true>), dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream,
-                                                  P.cfg, P.nvis, pb->d_obs_cam, pb->d_obs_pt, pb->d_camtab, pbpts, pb->d_J));
+                                                  P.cfg, P.nvis, pb->d_obs_cam, pb->d_obs_pt, pb->d_camtab, pbpts, pb->d_J, pb->d_campos, pb->d_Jc));
         } else {
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_jacobian<C, false>), dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream,
-                                                  P.cfg, P.nvis, pb->d_obs_cam, pb->d_obs_pt, pb->d_camtab, pbpts, pb->d_J));
+                                                  P.cfg, P.nvis, pb->d_obs_cam, pb->d_obs_pt, pb->d_camtab, pbpts, pb->d_J, pb->d_campos, pb->d_Jc));
         }
     }
     ph_end(pb, PH_JAC);
@@ -409,8 +411,9 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     std::vector<int> obs_pt(nvis), camptr(m + 1, 0), camobs(nvis);
     for (int i = 0; i < n; ++i) for (int k = d->rowptr[i]; k < d->rowptr[i + 1]; ++k) { obs_pt[k] = i; ++camptr[d->colidx[k] + 1]; }
     for (int j = 0; j < m; ++j) camptr[j + 1] += camptr[j];
+    std::vector<int> campos(nvis), cam_pt(nvis);
     { std::vector<int> cur(camptr.begin(), camptr.end() - 1);
-      for (int k = 0; k < nvis; ++k) camobs[cur[d->colidx[k]]++] = k; }
+      for (int k = 0; k < nvis; ++k) { const int t = cur[d->colidx[k]]++; camobs[t] = k; campos[k] = t; cam_pt[t] = obs_pt[k]; } }
 
     if (hipStreamCreateWithFlags(&pb->stream, hipStreamNonBlocking) != hipSuccess) return fail("stream");
     pb->own_stream = true;
@@ -420,7 +423,7 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     DM(pb->d_p, pb->nvars_local); DM(pb->d_pdp, pb->nvars_local); DM(pb->d_dp, pb->nvars_local);
     DM(pb->d_camtab, (size_t)m * CT_STRIDE); DM(pb->d_camtab_trial, (size_t)m * CT_STRIDE);
     DM(pb->d_e, 2 * (size_t)nvis); DM(pb->d_hx, 2 * (size_t)nvis);
-    DM(pb->d_J, (size_t)nvis * P.js); DM(pb->d_U, (size_t)m * cnp * cnp); DM(pb->d_ea, (size_t)m * cnp);
+    DM(pb->d_J, (size_t)nvis * P.js); DM(pb->d_Jc, (size_t)nvis * P.js); DM(pb->d_campos, nvis); DM(pb->d_cam_pt, nvis); DM(pb->d_U, (size_t)m * cnp * cnp); DM(pb->d_ea, (size_t)m * cnp);
     DM(pb->d_V, 6 * (size_t)n); DM(pb->d_Vinv, 6 * (size_t)n); DM(pb->d_eb, 3 * (size_t)n);
     DM(pb->d_S, (size_t)pb->ld * pb->ld); DM(pb->d_E, pb->ld);
     pb->red_blocks = std::max(grid_for(nvis, RES_BLOCK), std::max(grid_for(n, 256), 1024));
@@ -435,7 +438,8 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     auto up = [&](void* dst, const void* src, size_t bytes) { return bytes == 0 || hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess; };
     bool ok = up(pb->d_x, d->projections, 2 * (size_t)nvis * sizeof(double)) && up(pb->d_obs_cam, d->colidx, nvis * sizeof(int)) &&
               up(pb->d_obs_pt, obs_pt.data(), nvis * sizeof(int)) && up(pb->d_rowptr, d->rowptr, (n + 1) * sizeof(int)) &&
-              up(pb->d_camptr, camptr.data(), (m + 1) * sizeof(int)) && up(pb->d_camobs, camobs.data(), nvis * sizeof(int));
+              up(pb->d_camptr, camptr.data(), (m + 1) * sizeof(int)) && up(pb->d_camobs, camobs.data(), nvis * sizeof(int)) &&
+              up(pb->d_campos, campos.data(), nvis * sizeof(int)) && up(pb->d_cam_pt, cam_pt.data(), nvis * sizeof(int));
     pb->h_Rinit.resize(9 * (size_t)m);
     std::vector<double> finit(m);
     for (int j = 0; j < m; ++j) { memcpy(&pb->h_Rinit[9 * (size_t)j], d->cameras[j].R, 9 * sizeof(double)); finit[j] = d->cameras[j].f; }
@@ -465,10 +469,10 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     }
     if (!ok) return fail("upload");
     P.x = pb->d_x; P.obs_cam = pb->d_obs_cam; P.obs_pt = pb->d_obs_pt; P.rowptr = pb->d_rowptr;
-    P.camptr = pb->d_camptr; P.camobs = pb->d_camobs; P.Rinit = pb->d_Rinit; P.finit = pb->d_finit;
+    P.camptr = pb->d_camptr; P.camobs = pb->d_camobs; P.campos = pb->d_campos; P.cam_pt = pb->d_cam_pt; P.Rinit = pb->d_Rinit; P.finit = pb->d_finit;
     P.ccon = pb->d_ccon; P.cval = pb->d_cval; P.cw = pb->d_cw; P.pcon = pb->d_pcon; P.pval = pb->d_pval;
-    P.J = pb->d_J; P.U = pb->d_U; P.ea = pb->d_ea; P.V = pb->d_V; P.Vinv = pb->d_Vinv; P.eb = pb->d_eb;
-    if (build_schur_structure(pb, d) != 0) return fail("schur structure");
+    P.J = pb->d_J; P.Jc = pb->d_Jc; P.U = pb->d_U; P.ea = pb->d_ea; P.V = pb->d_V; P.Vinv = pb->d_Vinv; P.eb = pb->d_eb;
+    if (build_schur_structure(pb, d, campos, cam_pt) != 0) return fail("schur structure");
     if (potrf_init(pb->potrf, pb->ld, pb->opt.potrf_backend) != 0) return fail("potrf workspace");
     pb->ev_ok = true;
     for (int i = 0; i < PH_COUNT; ++i) {
