@@ -46,6 +46,7 @@ struct PotrfWorkspace {
     double* y = nullptr;       // ld
     double* xs = nullptr;      // ld
     double* etmp = nullptr;    // ld (rhs working copy)
+    int* bflags = nullptr;     // nblk + 1: hand-off flags of the persistent backward substitution (+ timeout word)
     // rocSOLVER cross-check backend
     void* rs_lib = nullptr; void* rb_lib = nullptr; void* rb_handle = nullptr;
     int (*rs_potrf)(void*, int, int, double*, int, int*) = nullptr;
@@ -222,21 +223,24 @@ __global__ __launch_bounds__(256) void k_trsm_panel64(double* __restrict__ S, in
 
 // First trailing column, two halves per tile: S_{k+1+a, k+1} -= P_a P_0^T.
 __global__ __launch_bounds__(256) void k_syrk_col64(double* __restrict__ S, int ld, int k, const double* __restrict__ panel,
-        double* __restrict__ E, const double* __restrict__ y)
+        int ngemm, double* __restrict__ E, const double* __restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int a = blockIdx.x >> 1, half = blockIdx.x & 1;
-    {   // forward substitution: E_{k+1+a}[rows of this half] -= L_{k+1+a,k}[rows] * y_k   (4 lanes per row)
-        const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
-        const double* Pr = panel + (size_t)a * POTRF_NB * POTRF_NB + (size_t)(64 * half + row) * POTRF_NB + 32 * part;
-        const double* yk = y + (size_t)k * POTRF_NB + 32 * part;
+    if ((int)blockIdx.x >= ngemm) {
+        // extra workgroups (one per tile row, off the GEMM workgroups' critical path): forward substitution
+        // E_{k+1+a} -= L_{k+1+a,k} * y_k, 2 lanes per row
+        const int a = blockIdx.x - ngemm;
+        const int row = threadIdx.x >> 1, part = threadIdx.x & 1;
+        const double* Pr = panel + (size_t)a * POTRF_NB * POTRF_NB + (size_t)row * POTRF_NB + 64 * part;
+        const double* yk = y + (size_t)k * POTRF_NB + 64 * part;
         double sacc = 0.0;
-#pragma unroll 8
-        for (int c = 0; c < 32; ++c) sacc += Pr[c] * yk[c];
+#pragma unroll 16
+        for (int c = 0; c < 64; ++c) sacc += Pr[c] * yk[c];
         sacc += __shfl_xor(sacc, 1, 64);
-        sacc += __shfl_xor(sacc, 2, 64);
-        if (part == 0) E[(size_t)(k + 1 + a) * POTRF_NB + 64 * half + row] -= sacc;
+        if (part == 0) E[(size_t)(k + 1 + a) * POTRF_NB + row] -= sacc;
+        return;
     }
+    const int a = blockIdx.x >> 1, half = blockIdx.x & 1;
     double acc[8][4];
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -568,6 +572,65 @@ __global__ __launch_bounds__(256) void k_fwd_step(const double* __restrict__ S, 
     if (threadIdx.x < POTRF_NB) y[(size_t)i * POTRF_NB + r] = red[0][r] + red[1][r];
 }
 
+// Backward substitution x = L^-T y as ONE persistent launch (replaces nblk dependent launches).
+// Workgroup kk owns tile column kk, all nblk workgroups are resident at once (nblk <= #CUs, 256 threads, no big LDS):
+//   for i = nblk-1 .. kk+1 :  wait for x_i  ->  y_kk -= L_{i,kk}^T x_i        (tile (i,kk) prefetched into registers
+//   x_kk = inv(L_kk)^T y_kk  ->  publish                                       while waiting; inv(L_kk) lives in registers)
+// Hand-off follows the guide's write-through recipe (cdna_hip_programming.md, Guideline 16, R1): the producer stores
+// x_kk with agent-scope relaxed atomic stores (sc1, write-through), every storing wave drains vmcnt, one lane stores
+// the flag; consumers poll the flag relaxed from one lane and then read x_i with agent-scope (sc1) loads, which bypass
+// the possibly stale L1.  Flags are zeroed by a memset node before every launch; epoch = 1.
+__global__ __launch_bounds__(256) void k_bwd_persistent(const double* __restrict__ S, int ld, int nblk,
+        const double* __restrict__ Linv, const double* __restrict__ y, double* x, int* flags, int* timeout)
+{
+    __shared__ double yk[POTRF_NB];
+    __shared__ double xi[POTRF_NB];
+    __shared__ double red[POTRF_NB];
+    const int kk = nblk - 1 - (int)blockIdx.x;
+    const int c = threadIdx.x & 127, h = threadIdx.x >> 7;
+    double lreg[64], tcur[64];
+    {
+        const double* Li = Linv + (size_t)kk * POTRF_NB * POTRF_NB + (size_t)(64 * h) * POTRF_NB + c;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) lreg[r] = Li[(size_t)r * POTRF_NB];
+    }
+    if (threadIdx.x < POTRF_NB) yk[threadIdx.x] = y[(size_t)kk * POTRF_NB + threadIdx.x];
+    for (int i = nblk - 1; i > kk; --i) {
+        {   // tile (i, kk), rows of this half, column c
+            const double* Lc = S + ((size_t)i * POTRF_NB + 64 * h) * ld + (size_t)kk * POTRF_NB + c;
+#pragma unroll
+            for (int r = 0; r < 64; ++r) tcur[r] = Lc[(size_t)r * ld];
+        }
+        if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(&flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 26)) { atomicExch(timeout, 1); break; }     // bounded spin
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < POTRF_NB)
+            xi[threadIdx.x] = __hip_atomic_load(&x[(size_t)i * POTRF_NB + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        double sacc = 0.0;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) sacc += tcur[r] * xi[64 * h + r];
+        if (h == 1) red[c] = sacc;
+        __syncthreads();
+        if (h == 0) yk[c] -= sacc + red[c];
+        __syncthreads();
+    }
+    double sacc = 0.0;
+#pragma unroll
+    for (int r = 0; r < 64; ++r) sacc += lreg[r] * yk[64 * h + r];
+    if (h == 1) red[c] = sacc;
+    __syncthreads();
+    if (h == 0) __hip_atomic_store(&x[(size_t)kk * POTRF_NB + c], sacc + red[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave drains its write-through stores
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&flags[kk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // backward substitution step: tiles kk < i do y_kk -= L_{i,kk}^T x_i ; tile i-1 then computes
 // x_{i-1} = Linv_{i-1}^T y_{i-1}.  i == nblk bootstraps x_{nblk-1}.
 __global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ S, int ld, int i, int nblk,
@@ -609,6 +672,7 @@ inline void potrf_free(PotrfWorkspace& w)
     if (w.y) (void)hipFree(w.y);
     if (w.xs) (void)hipFree(w.xs);
     if (w.etmp) (void)hipFree(w.etmp);
+    if (w.bflags) (void)hipFree(w.bflags);
     if (w.rb_handle && w.rb_destroy) w.rb_destroy(w.rb_handle);
     if (w.ev0) (void)hipEventDestroy(w.ev0);
     if (w.ev1) (void)hipEventDestroy(w.ev1);
@@ -649,6 +713,7 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
     if (hipMalloc((void**)&w.y, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
     if (hipMalloc((void**)&w.xs, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
     if (hipMalloc((void**)&w.etmp, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
+    if (hipMalloc((void**)&w.bflags, (size_t)(w.nblk + 1) * sizeof(int)) != hipSuccess) return -1;
     (void)hipEventCreate(&w.ev0); (void)hipEventCreate(&w.ev1);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(DG_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
@@ -721,7 +786,7 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         (void)hipEventRecord(w.evU[k], w.s2);
         // panel stream: first trailing column of step k, then panel k+1
         if (k > 0) (void)hipStreamWaitEvent(st, w.evU[k - 1], 0);   // column k+1 was last written by the bulk of step k-1
-        hipLaunchKernelGGL(k_syrk_col64, dim3(2 * T), dim3(256), lds64, st, S, ld, k, pk, w.etmp, w.y);
+        hipLaunchKernelGGL(k_syrk_col64, dim3(3 * T), dim3(256), lds64, st, S, ld, k, pk, 2 * T, w.etmp, w.y);
         hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, k + 1, n, w.linv, d_info, w.dbg);
         if (T > 1)
             hipLaunchKernelGGL(k_trsm_panel64, dim3(2 * (T - 1) + 1), dim3(256), lds64, st, S, ld, k + 1,
@@ -733,8 +798,14 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         (void)hipEventRecord(w.evP[k + 1], st);
     }
     if (nblk > 1) (void)hipStreamWaitEvent(st, w.evU[nblk - 2], 0);
-    for (int i = nblk; i >= 1; --i)
-        hipLaunchKernelGGL(k_bwd_step, dim3(i == nblk ? 1 : i), dim3(256), 0, st, S, ld, i, nblk, w.linv, w.y, w.xs);
+    if (nblk <= 200 && !getenv("BSFM_BWD_STEPS")) {
+        // persistent backward substitution: all nblk workgroups resident (one per tile column)
+        (void)hipMemsetAsync(w.bflags, 0, (size_t)(w.nblk + 1) * sizeof(int), st);
+        hipLaunchKernelGGL(k_bwd_persistent, dim3(nblk), dim3(256), 0, st, S, ld, nblk, w.linv, w.y, w.xs, w.bflags, w.bflags + w.nblk);
+    } else {
+        for (int i = nblk; i >= 1; --i)
+            hipLaunchKernelGGL(k_bwd_step, dim3(i == nblk ? 1 : i), dim3(256), 0, st, S, ld, i, nblk, w.linv, w.y, w.xs);
+    }
     (void)hipMemcpyAsync(x_out, w.xs, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
     if (w.ev1) (void)hipEventRecord(w.ev1, st);
     if (w.dbg) {
