@@ -595,6 +595,7 @@ __global__ __launch_bounds__(256) void k_bwd_persistent(const double* __restrict
         for (int r = 0; r < 64; ++r) lreg[r] = Li[(size_t)r * POTRF_NB];
     }
     if (threadIdx.x < POTRF_NB) yk[threadIdx.x] = y[(size_t)kk * POTRF_NB + threadIdx.x];
+    __syncthreads();
     for (int i = nblk - 1; i > kk; --i) {
         {   // tile (i, kk), rows of this half, column c
             const double* Lc = S + ((size_t)i * POTRF_NB + 64 * h) * ld + (size_t)kk * POTRF_NB + c;
