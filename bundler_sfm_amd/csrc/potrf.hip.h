@@ -32,8 +32,16 @@
 namespace bsfm {
 
 constexpr int POTRF_NB = 128;
-constexpr int GEMM_KC = 16;
-constexpr int GEMM_LDS_STRIDE = GEMM_KC + 2;
+#ifndef BSFM_SYRK_WPS
+#define BSFM_SYRK_WPS 4      // waves per SIMD the bulk tile kernel is compiled for (4 = two workgroups per CU)
+#endif
+#ifndef BSFM_GEMM_KC
+#define BSFM_GEMM_KC 16
+#endif
+constexpr int GEMM_KC = BSFM_GEMM_KC;             // K chunk of the bulk 128x128 tile kernel
+constexpr int GEMM_LDS_STRIDE = GEMM_KC + (GEMM_KC == 16 ? 2 : 4);   // 18: conflict-free; 36: 16-byte aligned rows, <= 2-way conflicts
+constexpr int G64_KC = 16;                        // the latency-critical 64-row chain kernels keep 16-wide chunks
+constexpr int G64_STRIDE = G64_KC + 2;
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -70,25 +78,30 @@ __device__ __forceinline__ void gemm_nt_128(const double* __restrict__ A, int ld
     double* Bs = lds + 128 * GEMM_LDS_STRIDE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;   // 8 waves: 4 (rows) x 2 (cols), 32 x 64 each
-    // staging: 128 rows x 16 doubles = 1024 double2 per operand -> 2 per thread (512 threads)
-    double2 pa0, pa1, pb0, pb1;
-    const int srow = tid >> 3, sc2 = (tid & 7) * 2;     // rows srow + 64 q
+    // staging: 128 rows x GEMM_KC doubles per operand and chunk, 512 threads
+    constexpr int DPR = GEMM_KC / 2;                    // double2 per row
+    constexpr int RPP = 512 / DPR;                      // rows per pass
+    constexpr int NPASS = 128 / RPP;
+    double pa[NPASS][2], pb[NPASS][2];                  // plain doubles (double2 arrays would land in scratch)
+    const int srow = tid / DPR, sc2 = (tid % DPR) * 2;
     const double* Ag = A + (size_t)srow * lda + sc2;
     const double* Bg = B + (size_t)srow * ldb + sc2;
     double* Asw = As + srow * GEMM_LDS_STRIDE + sc2;
     double* Bsw = Bs + srow * GEMM_LDS_STRIDE + sc2;
-#define BSFM_GLOAD(kc)                                                                      \
-    pa0 = *reinterpret_cast<const double2*>(Ag + (kc));                                     \
-    pa1 = *reinterpret_cast<const double2*>(Ag + (size_t)64 * lda + (kc));                  \
-    pb0 = *reinterpret_cast<const double2*>(Bg + (kc));                                     \
-    pb1 = *reinterpret_cast<const double2*>(Bg + (size_t)64 * ldb + (kc));
+#define BSFM_GLOAD(kc)                                                                                    \
+    _Pragma("unroll") for (int q = 0; q < NPASS; ++q) {                                                   \
+        const double2 ta = *reinterpret_cast<const double2*>(Ag + (size_t)(RPP * q) * lda + (kc));         \
+        const double2 tb = *reinterpret_cast<const double2*>(Bg + (size_t)(RPP * q) * ldb + (kc));         \
+        pa[q][0] = ta.x; pa[q][1] = ta.y; pb[q][0] = tb.x; pb[q][1] = tb.y;                               \
+    }
     BSFM_GLOAD(0)
     for (int kc = 0; kc < K; kc += GEMM_KC) {
         __syncthreads();          // previous chunk fully consumed
-        *reinterpret_cast<double2*>(Asw) = pa0;
-        *reinterpret_cast<double2*>(Asw + 64 * GEMM_LDS_STRIDE) = pa1;
-        *reinterpret_cast<double2*>(Bsw) = pb0;
-        *reinterpret_cast<double2*>(Bsw + 64 * GEMM_LDS_STRIDE) = pb1;
+#pragma unroll
+        for (int q = 0; q < NPASS; ++q) {
+            *reinterpret_cast<double2*>(Asw + RPP * q * GEMM_LDS_STRIDE) = make_double2(pa[q][0], pa[q][1]);
+            *reinterpret_cast<double2*>(Bsw + RPP * q * GEMM_LDS_STRIDE) = make_double2(pb[q][0], pb[q][1]);
+        }
         __syncthreads();
         if (kc + GEMM_KC < K) { BSFM_GLOAD(kc + GEMM_KC) }
 #pragma unroll
@@ -117,52 +130,51 @@ __device__ __forceinline__ void gemm_nt_128(const double* __restrict__ A, int ld
 // (4 waves, 32 x 64 each).  The tiles of the serial chain (panel solve, first trailing column) are split into two
 // such halves so that twice as many CUs share the chain's MFMA work.
 __device__ __forceinline__ void gemm_nt_64(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
-                                           int K, double* __restrict__ lds, double (&acc)[8][4])
+                                           double* __restrict__ lds, double (&acc)[8][4])
 {
+    // K = 128 fixed.  The whole K range of both operands is fetched into registers up front (48 double2 per lane:
+    // these workgroups run one wave per SIMD, so the 512-VGPR budget is available) -- the chain kernels are latency-,
+    // not throughput-bound, and this removes the per-chunk global-load wait.
     double* As = lds;
-    double* Bs = lds + 64 * GEMM_LDS_STRIDE;
+    double* Bs = lds + 64 * G64_STRIDE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
-    double2 pa0, pa1, pb0, pb1, pb2, pb3;
     const int srow = tid >> 3, sc2 = (tid & 7) * 2;     // 32 rows per pass
     const double* Ag = A + (size_t)srow * lda + sc2;
     const double* Bg = B + (size_t)srow * ldb + sc2;
-    double* Asw = As + srow * GEMM_LDS_STRIDE + sc2;
-    double* Bsw = Bs + srow * GEMM_LDS_STRIDE + sc2;
-#define BSFM_GLOAD64(kc)                                                                    \
-    pa0 = *reinterpret_cast<const double2*>(Ag + (kc));                                     \
-    pa1 = *reinterpret_cast<const double2*>(Ag + (size_t)32 * lda + (kc));                  \
-    pb0 = *reinterpret_cast<const double2*>(Bg + (kc));                                     \
-    pb1 = *reinterpret_cast<const double2*>(Bg + (size_t)32 * ldb + (kc));                  \
-    pb2 = *reinterpret_cast<const double2*>(Bg + (size_t)64 * ldb + (kc));                  \
-    pb3 = *reinterpret_cast<const double2*>(Bg + (size_t)96 * ldb + (kc));
-    BSFM_GLOAD64(0)
-    for (int kc = 0; kc < K; kc += GEMM_KC) {
-        __syncthreads();
-        *reinterpret_cast<double2*>(Asw) = pa0;
-        *reinterpret_cast<double2*>(Asw + 32 * GEMM_LDS_STRIDE) = pa1;
-        *reinterpret_cast<double2*>(Bsw) = pb0;
-        *reinterpret_cast<double2*>(Bsw + 32 * GEMM_LDS_STRIDE) = pb1;
-        *reinterpret_cast<double2*>(Bsw + 64 * GEMM_LDS_STRIDE) = pb2;
-        *reinterpret_cast<double2*>(Bsw + 96 * GEMM_LDS_STRIDE) = pb3;
-        __syncthreads();
-        if (kc + GEMM_KC < K) { BSFM_GLOAD64(kc + GEMM_KC) }
+    double* Asw = As + srow * G64_STRIDE + sc2;
+    double* Bsw = Bs + srow * G64_STRIDE + sc2;
+    double pa[8][2][2], pb[8][4][2];      // plain doubles: arrays of the double2 vector struct are not promoted to registers
+#pragma clang loop unroll(full)
+    for (int ch = 0; ch < 8; ++ch) {
 #pragma unroll
-        for (int kk = 0; kk < GEMM_KC; kk += 4) {
+        for (int q = 0; q < 2; ++q) { const double2 t2 = *reinterpret_cast<const double2*>(Ag + (size_t)(32 * q) * lda + G64_KC * ch); pa[ch][q][0] = t2.x; pa[ch][q][1] = t2.y; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const double2 t2 = *reinterpret_cast<const double2*>(Bg + (size_t)(32 * q) * ldb + G64_KC * ch); pb[ch][q][0] = t2.x; pb[ch][q][1] = t2.y; }
+    }
+#pragma clang loop unroll(full)
+    for (int ch = 0; ch < 8; ++ch) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<double2*>(Asw + 32 * q * G64_STRIDE) = make_double2(pa[ch][q][0], pa[ch][q][1]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<double2*>(Bsw + 32 * q * G64_STRIDE) = make_double2(pb[ch][q][0], pb[ch][q][1]);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < G64_KC; kk += 4) {
             double b[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                b[u] = Bs[(wc + 16 * u + (lane & 15)) * GEMM_LDS_STRIDE + kk + (lane >> 4)];
+                b[u] = Bs[(wc + 16 * u + (lane & 15)) * G64_STRIDE + kk + (lane >> 4)];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const double a = As[(wr + 4 * t + (lane & 3)) * GEMM_LDS_STRIDE + kk + (lane >> 4)];
+                const double a = As[(wr + 4 * t + (lane & 3)) * G64_STRIDE + kk + (lane >> 4)];
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     acc[t][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b[u], acc[t][u], 0, 0, 0);
             }
         }
     }
-#undef BSFM_GLOAD64
 }
 
 // Panel, two halves per tile: workgroup (tile, half) computes rows 64*half .. +63 of X_i = S_ik * Linv_k^T.
@@ -190,7 +202,7 @@ __global__ __launch_bounds__(256) void k_fwd_last(const double* __restrict__ Lin
     fwd_tile_solve(Linv, Ek, yk, sm);
 }
 
-__global__ __launch_bounds__(256) void k_trsm_panel64(double* __restrict__ S, int ld, int k,
+__global__ __launch_bounds__(256, 1) void k_trsm_panel64(double* __restrict__ S, int ld, int k,
         const double* __restrict__ Linv, double* __restrict__ panel, int nwork, const double* __restrict__ E, double* __restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(256) void k_trsm_panel64(double* __restrict__ S, in
     for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[t][u] = 0.0;
-    gemm_nt_64(Sik, ld, Linv, POTRF_NB, POTRF_NB, lds, acc);
+    gemm_nt_64(Sik, ld, Linv, POTRF_NB, lds, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
     double* Pt = panel + (size_t)tile * POTRF_NB * POTRF_NB + (size_t)(64 * half) * POTRF_NB;
@@ -222,7 +234,7 @@ __global__ __launch_bounds__(256) void k_trsm_panel64(double* __restrict__ S, in
 }
 
 // First trailing column, two halves per tile: S_{k+1+a, k+1} -= P_a P_0^T.
-__global__ __launch_bounds__(256) void k_syrk_col64(double* __restrict__ S, int ld, int k, const double* __restrict__ panel,
+__global__ __launch_bounds__(256, 1) void k_syrk_col64(double* __restrict__ S, int ld, int k, const double* __restrict__ panel,
         int ngemm, double* __restrict__ E, const double* __restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -246,17 +258,22 @@ __global__ __launch_bounds__(256) void k_syrk_col64(double* __restrict__ S, int 
     for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[t][u] = 0.0;
-    gemm_nt_64(panel + (size_t)a * POTRF_NB * POTRF_NB + (size_t)(64 * half) * POTRF_NB, POTRF_NB, panel, POTRF_NB,
-               POTRF_NB, lds, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
     double* Sij = S + ((size_t)(k + 1 + a) * POTRF_NB + 64 * half) * ld + (size_t)(k + 1) * POTRF_NB;
+    double cin[8][4];                     // the C tile is fetched up front as well
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            cin[t][u] = Sij[(size_t)(wr + 4 * t + (lane >> 4)) * ld + wc + 16 * u + (lane & 15)];
+    gemm_nt_64(panel + (size_t)a * POTRF_NB * POTRF_NB + (size_t)(64 * half) * POTRF_NB, POTRF_NB, panel, POTRF_NB, lds, acc);
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = wr + 4 * t + (lane >> 4), col = wc + 16 * u + (lane & 15);
-            Sij[(size_t)row * ld + col] -= acc[t][u];
+            Sij[(size_t)row * ld + col] = cin[t][u] - acc[t][u];
         }
 }
 
@@ -291,7 +308,7 @@ __global__ __launch_bounds__(512, 4) void k_trsm_panel(double* __restrict__ S, i
 // Trailing update: S_ij -= P_a P_b^T for k < j <= i (a = i-k-1, b = j-k-1), one tile per workgroup.
 // part 1 = only the first trailing column (b == 0, grid T): the tiles the NEXT panel needs (lookahead stream);
 // part 2 = every other tile (b >= 1, grid T(T-1)/2): the bulk, on the update stream.
-__global__ __launch_bounds__(512, 4) void k_syrk_update(double* __restrict__ S, int ld, int k, const double* __restrict__ panel, int part)
+__global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __restrict__ S, int ld, int k, const double* __restrict__ panel, int part)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int a, b;
@@ -763,7 +780,7 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
     // The compact panel is double-buffered (k & 1): trsm(k+1) may run while the bulk of step k still reads panel k.
     const size_t pstride = std::max<size_t>(1, (size_t)(w.nblk - 1)) * POTRF_NB * POTRF_NB;
     const size_t diag_lds = DG_LDS_DOUBLES * sizeof(double);
-    const size_t lds64 = (64 + 128) * GEMM_LDS_STRIDE * sizeof(double);
+    const size_t lds64 = (64 + 128) * G64_STRIDE * sizeof(double);
     (void)hipEventRecord(w.evU[w.nblk], st);                 // everything queued before the solve (S, E ready)
     (void)hipStreamWaitEvent(w.s2, w.evU[w.nblk], 0);
     hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, 0, n, w.linv, d_info, w.dbg);

@@ -1,0 +1,152 @@
+// schur.hip.h -- Schur-complement task kernel, version 2: coalesced record staging through LDS.
+//
+// Same mathematics and the same task structure as k_schur_tasks in kernels.hip.h (one wave per task = <= 168
+// co-visibility triples of ONE block S_jk, 3 lanes per triple, 21 triples per pass, no atomics; reference:
+// lib/sba-1.5/sba_levmar.c:1182-1302).  What changes is the data path:
+//   * v1 lets every lane gather its 42 doubles itself: each wave-level load touches ~20-30 different 128-byte lines;
+//   * v2 reads the two 192-byte Jacobian records of each triple (camera-major copy Jc: consecutive triples of a block
+//     are monotone, mostly consecutive records) and the 48-byte V*^-1 with 16-byte-per-lane coalesced loads
+//     (12 lanes per record), parks them in a wave-private LDS slab (record stride 26 doubles: 16-byte aligned, at
+//     most 2-way bank conflicts), prefetches the next pass into registers while the current pass computes, and the
+//     3 lanes of a triple read their operands from LDS (broadcast where they coincide).
+// NOTE (gfx950 / hipcc 7.2): the prefetch registers are arrays of plain double -- arrays of the double2 vector
+// struct are not promoted to registers and end up in scratch, which serialises the whole pipeline.
+#pragma once
+#include "kernels.hip.h"
+
+namespace bsfm {
+
+constexpr int SCH_PASS = 21;          // triples in flight per wave (3 lanes each)
+constexpr int SCH_MAXT = 168;         // triples per task (SCHUR_CHUNK in solver.hip)
+
+template <int CNP>
+__global__ __launch_bounds__(256) void k_schur_tasks_v2(DevProblem P, const SchurTask* __restrict__ tasks, int ntasks,
+        const int2* __restrict__ triples, const int* __restrict__ tri_pt, double* __restrict__ partials)
+{
+    constexpr int JS = 2 * CNP + 6;            // doubles per Jacobian record
+    constexpr int RS = JS + 2;                 // LDS record stride (doubles), 16-byte aligned
+    constexpr int CH = JS / 2;                 // 16-byte chunks per record
+    constexpr int NR = (CNP + 2) / 3;
+    constexpr int NA = (SCH_PASS * CH + 63) / 64;      // staging rounds for one record stream
+    constexpr int SLAB = 2 * SCH_PASS * RS + SCH_PASS * 6;
+    __shared__ __attribute__((aligned(16))) double sm[4][SLAB];
+    __shared__ int sm_tri[4][3 * SCH_MAXT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int task = blockIdx.x * 4 + wave;
+    if (task >= ntasks) return;
+    const SchurTask tk = tasks[task];
+    double* recA = sm[wave];
+    double* recB = recA + SCH_PASS * RS;
+    double* vin = recB + SCH_PASS * RS;
+    int* tq = sm_tri[wave];
+    for (int t = lane; t < tk.count; t += 64) {         // all triples of the task -> LDS (qa, qb, pt)
+        const int2 tr = triples[tk.start + t];
+        tq[3 * t] = tr.x; tq[3 * t + 1] = tr.y; tq[3 * t + 2] = tri_pt[tk.start + t];
+    }
+    const int grp = lane / 3, r = lane - 3 * grp;
+    double acc[NR][CNP];
+#pragma unroll
+    for (int a = 0; a < NR; ++a)
+#pragma unroll
+        for (int c = 0; c < CNP; ++c) acc[a][c] = 0.0;
+
+    // staging slots of this lane: chunk c = lane + 64 q  ->  record c / CH, 16-byte part c % CH
+    int srec[NA], spart[NA];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) { const int c = lane + 64 * q; srec[q] = c / CH; spart[q] = c - srec[q] * CH; }
+    const int vrec = lane / 3, vpart = lane - 3 * vrec;
+    double pa[NA][2], pb[NA][2], pv[2];
+
+#define BSFM_SCH_ISSUE(p0_)                                                                                         \
+    {                                                                                                               \
+        const int np_ = min(SCH_PASS, tk.count - (p0_));                                                            \
+        _Pragma("unroll") for (int q = 0; q < NA; ++q) {                                                            \
+            if (srec[q] < np_) {                                                                                    \
+                const double2 ta = *reinterpret_cast<const double2*>(P.Jc + (size_t)tq[3 * ((p0_) + srec[q])] * JS + 2 * spart[q]);     \
+                const double2 tb = *reinterpret_cast<const double2*>(P.Jc + (size_t)tq[3 * ((p0_) + srec[q]) + 1] * JS + 2 * spart[q]); \
+                pa[q][0] = ta.x; pa[q][1] = ta.y; pb[q][0] = tb.x; pb[q][1] = tb.y;                                 \
+            }                                                                                                       \
+        }                                                                                                           \
+        if (vrec < np_) {                                                                                           \
+            const double2 tv = *reinterpret_cast<const double2*>(P.Vinv + (size_t)tq[3 * ((p0_) + vrec) + 2] * 6 + 2 * vpart); \
+            pv[0] = tv.x; pv[1] = tv.y;                                                                             \
+        }                                                                                                           \
+    }
+#define BSFM_SCH_PARK(p0_)                                                                                          \
+    {                                                                                                               \
+        const int np_ = min(SCH_PASS, tk.count - (p0_));                                                            \
+        _Pragma("unroll") for (int q = 0; q < NA; ++q) {                                                            \
+            if (srec[q] < np_) {                                                                                    \
+                *reinterpret_cast<double2*>(recA + srec[q] * RS + 2 * spart[q]) = make_double2(pa[q][0], pa[q][1]); \
+                *reinterpret_cast<double2*>(recB + srec[q] * RS + 2 * spart[q]) = make_double2(pb[q][0], pb[q][1]); \
+            }                                                                                                       \
+        }                                                                                                           \
+        if (vrec < np_) *reinterpret_cast<double2*>(vin + vrec * 6 + 2 * vpart) = make_double2(pv[0], pv[1]);       \
+    }
+
+    BSFM_SCH_ISSUE(0)
+    for (int p0 = 0; p0 < tk.count; p0 += SCH_PASS) {
+        BSFM_SCH_PARK(p0)
+        if (p0 + SCH_PASS < tk.count) BSFM_SCH_ISSUE(p0 + SCH_PASS)
+        if (grp < SCH_PASS && p0 + grp < tk.count) {
+            const double* Ja = recA + grp * RS;
+            const double* Jb = recB + grp * RS;
+            const double* vi = vin + grp * 6;
+            const double i00 = vi[0], i01 = vi[1], i02 = vi[2], i11 = vi[3], i12 = vi[4], i22 = vi[5];
+            const double* Ba = Ja + 2 * CNP;
+            const double* Bb = Jb + 2 * CNP;
+            const double c00 = Ba[0] * i00 + Ba[1] * i01 + Ba[2] * i02;
+            const double c01 = Ba[0] * i01 + Ba[1] * i11 + Ba[2] * i12;
+            const double c02 = Ba[0] * i02 + Ba[1] * i12 + Ba[2] * i22;
+            const double c10 = Ba[3] * i00 + Ba[4] * i01 + Ba[5] * i02;
+            const double c11 = Ba[3] * i01 + Ba[4] * i11 + Ba[5] * i12;
+            const double c12 = Ba[3] * i02 + Ba[4] * i12 + Ba[5] * i22;
+            const double m00 = c00 * Bb[0] + c01 * Bb[1] + c02 * Bb[2];
+            const double m01 = c00 * Bb[3] + c01 * Bb[4] + c02 * Bb[5];
+            const double m10 = c10 * Bb[0] + c11 * Bb[1] + c12 * Bb[2];
+            const double m11 = c10 * Bb[3] + c11 * Bb[4] + c12 * Bb[5];
+            double T0[CNP], T1[CNP];
+#pragma unroll
+            for (int c = 0; c < CNP; ++c) {
+                const double b0 = Jb[c], b1 = Jb[CNP + c];
+                T0[c] = m00 * b0 + m01 * b1;
+                T1[c] = m10 * b0 + m11 * b1;
+            }
+#pragma unroll
+            for (int a = 0; a < NR; ++a) {
+                const int row = r + 3 * a;
+                if (row < CNP) {
+                    const double a0 = Ja[row], a1 = Ja[CNP + row];
+#pragma unroll
+                    for (int c = 0; c < CNP; ++c) acc[a][c] += a0 * T0[c] + a1 * T1[c];
+                }
+            }
+        }
+    }
+#undef BSFM_SCH_ISSUE
+#undef BSFM_SCH_PARK
+#pragma unroll
+    for (int s = 16; s > 0; s >>= 1) {
+        const bool take = (grp < s) && (grp + s < SCH_PASS);
+#pragma unroll
+        for (int a = 0; a < NR; ++a)
+#pragma unroll
+            for (int c = 0; c < CNP; ++c) {
+                const double o = __shfl_down(acc[a][c], 3 * s, 64);
+                if (take) acc[a][c] += o;
+            }
+    }
+    if (grp == 0) {
+        double* out = partials + (size_t)task * CNP * CNP;
+#pragma unroll
+        for (int a = 0; a < NR; ++a) {
+            const int row = r + 3 * a;
+            if (row < CNP) {
+#pragma unroll
+                for (int c = 0; c < CNP; ++c) out[row * CNP + c] = acc[a][c];
+            }
+        }
+    }
+}
+
+}  // namespace bsfm

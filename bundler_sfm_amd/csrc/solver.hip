@@ -19,6 +19,7 @@
 
 #include "../../include/bsfm.h"
 #include "kernels.hip.h"
+#include "schur.hip.h"
 #include "potrf.hip.h"
 
 using namespace bsfm;
@@ -78,7 +79,7 @@ struct bsfm_problem {
     int *d_flags = nullptr;             // [0] singular V, [1] potrf info
     // schur structure
     int ntriples = 0, ntasks = 0, nblk = 0;
-    int2* d_triples = nullptr; SchurTask* d_tasks = nullptr;
+    int2* d_triples = nullptr; SchurTask* d_tasks = nullptr; int* d_tri_pt = nullptr; int schur_v1 = 0;
     int *d_blk_j = nullptr, *d_blk_k = nullptr, *d_blk_task0 = nullptr;
     // host
     double* h_scal = nullptr; int* h_flags = nullptr;   // pinned
@@ -103,7 +104,7 @@ void free_all(bsfm_problem* pb)
                      pb->d_camobs, pb->d_campos, pb->d_cam_pt, pb->d_Jc, pb->d_ccon, pb->d_pcon, pb->d_cval, pb->d_cw, pb->d_pval, pb->d_p, pb->d_pdp,
                      pb->d_dp, pb->d_camtab, pb->d_camtab_trial, pb->d_e, pb->d_hx, pb->d_J, pb->d_U, pb->d_ea,
                      pb->d_V, pb->d_Vinv, pb->d_eb, pb->d_S, pb->d_E, pb->d_partials, pb->d_red, pb->d_scal,
-                     pb->d_flags, pb->d_triples, pb->d_tasks, pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0 };
+                     pb->d_flags, pb->d_triples, pb->d_tri_pt, pb->d_tasks, pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0 };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (pb->h_scal) (void)hipHostFree(pb->h_scal);
     if (pb->h_flags) (void)hipHostFree(pb->h_flags);
@@ -181,6 +182,13 @@ int build_schur_structure(bsfm_problem* pb, const bsfm_problem_desc_t* d, const 
     HIP_OK(dmalloc(&pb->d_blk_j, nblk)); HIP_OK(dmalloc(&pb->d_blk_k, nblk)); HIP_OK(dmalloc(&pb->d_blk_task0, nblk + 1));
     HIP_OK(dmalloc(&pb->d_partials, tasks.size() * (size_t)pb->cnp * pb->cnp));
     if (total) HIP_OK(hipMemcpy(pb->d_triples, triples.data(), total * sizeof(int2), hipMemcpyHostToDevice));
+    {   // point index of every triple (V*^-1 lookup without a dependent gather through cam_pt)
+        std::vector<int> tri_pt(total);
+        for (size_t q = 0; q < total; ++q) tri_pt[q] = cam_pt[triples[q].x];
+        HIP_OK(dmalloc(&pb->d_tri_pt, total));
+        if (total) HIP_OK(hipMemcpy(pb->d_tri_pt, tri_pt.data(), total * sizeof(int), hipMemcpyHostToDevice));
+        pb->schur_v1 = getenv("BSFM_SCHUR_V1") ? 1 : 0;
+    }
     if (!tasks.empty()) HIP_OK(hipMemcpy(pb->d_tasks, tasks.data(), tasks.size() * sizeof(SchurTask), hipMemcpyHostToDevice));
     if (nblk) {
         HIP_OK(hipMemcpy(pb->d_blk_j, blk_j.data(), nblk * sizeof(int), hipMemcpyHostToDevice));
@@ -320,8 +328,13 @@ int compute_schur(bsfm_problem* pb, double mu)
     const int lead = pb->rank == 0 ? 1 : 0;
     (void)hipMemsetAsync(pb->d_S, 0, (size_t)pb->ld * pb->ld * sizeof(double), pb->stream);
     if (pb->ntasks > 0) {
-        DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks<C>), dim3((pb->ntasks + 3) / 4), dim3(256), 0, pb->stream,
-                                              P, pb->d_tasks, pb->ntasks, pb->d_triples, pb->d_partials));
+        if (pb->schur_v1) {
+            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks<C>), dim3((pb->ntasks + 3) / 4), dim3(256), 0, pb->stream,
+                                                  P, pb->d_tasks, pb->ntasks, pb->d_triples, pb->d_partials));
+        } else {
+            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks_v2<C>), dim3((pb->ntasks + 3) / 4), dim3(256), 0, pb->stream,
+                                                  P, pb->d_tasks, pb->ntasks, pb->d_triples, pb->d_tri_pt, pb->d_partials));
+        }
         DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_assemble<C>), dim3(pb->nblk), dim3(128), 0, pb->stream, pb->nblk,
                                               pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0, pb->d_partials, pb->d_U, mu, lead,
                                               P.mcon, pb->d_S, pb->ld));

@@ -6,7 +6,7 @@ diag = [i for i, r in enumerate(rows) if 'k_potrf_diag' in r['Kernel_Name']]
 last = diag[-71:] if len(diag) >= 71 else diag
 i0 = last[0]; t0 = int(rows[i0]['Start_Timestamp'])
 sel = [r for r in rows[i0:] ]
-end = max(int(r['End_Timestamp']) for r in sel if any(k in r['Kernel_Name'] for k in ('k_bwd_step',)))
+end = max(int(r['End_Timestamp']) for r in sel if any(k in r['Kernel_Name'] for k in ('k_bwd_step', 'k_bwd_persistent')))
 print("factor+solve span (us):", (end - t0) / 1e3)
 byname = collections.defaultdict(list)
 for r in sel:
