@@ -7,17 +7,22 @@
 // MI355X design (the one MFMA-bound contraction of the LM iteration, ~N^3/3 FP64 flop):
 //   * right-looking tiled factorisation, tile NB = 128; S is padded to a multiple of NB (identity in
 //     the padding) so every kernel works on full tiles;
-//   * diagonal tile: ONE 1024-thread workgroup, register-tiled (4x4 cyclic per thread) fused
-//     potrf + triangular inverse with a single barrier per column (pivot column / inverse row are
-//     double-buffered through LDS);
-//   * panel: L_ik = S_ik * inv(L_kk)^T is a GEMM on v_mfma_f64_16x16x4_f64 (no triangular solve);
-//     it also writes a compact copy of the panel (contiguous 128 KB tiles) that the trailing update reads;
+//   * diagonal tile: ONE 512-thread workgroup, tile in LDS as 8x8 blocks of 16x16; only the 16x16 diagonal blocks
+//     are factored serially (one wave, registers + ds_bpermute/readlane, no barrier), everything else -- panel
+//     blocks, trailing blocks and the block-wise inverse of the factor -- is 16x16x16 products on the 4x4x4 MFMA;
+//   * panel: L_ik = S_ik * inv(L_kk)^T is a GEMM (no triangular solve) split into two 64-row halves per tile with
+//     the whole K range prefetched into registers (latency-critical); it also writes a compact, double-buffered
+//     copy of the panel (contiguous 128 KB tiles) that the trailing update reads;
+//   * lookahead: the first trailing column + the next panel run on the caller's stream, the bulk of the trailing
+//     update on a second stream whose CU mask leaves 32 CUs free so that the 150 KB-LDS diagonal-tile workgroup can
+//     always be placed;
 //   * trailing update S_ij -= L_ik L_jk^T on the lower triangle: 128x128 tile per 256-thread workgroup,
 //     8 waves x (32 x 64) = 32 FP64 accumulators per lane on v_mfma_f64_4x4x4_4b (the full-rate FP64
 //     matrix instruction of gfx950: 72.7 TFLOP/s measured vs 36 for v_mfma_f64_16x16x4), K staged through LDS in
 //     16-wide chunks (row stride padded to 18 doubles => conflict-free ds_read_b64 of the fragments),
 //     next chunk prefetched into registers while the MFMAs of the current one issue;
-//   * forward / backward substitution use the stored inverse diagonal tiles: one launch per tile step.
+//   * forward substitution rides on the factorisation chain (y_k in the panel launch, E updates in the
+//     first-trailing-column launch); backward substitution is ONE persistent launch with flag hand-offs.
 // v_mfma_f64_4x4x4_4b lane layout (probed on MI355X, scripts/probe_mfma4.hip), lane l = 16k + 4g + r:
 // A[g][i=r][k], B[g][k][j=r], D[g][i][j] at lane 16i + 4g + j, for the 4 independent blocks g.
 #pragma once
@@ -32,6 +37,7 @@
 namespace bsfm {
 
 constexpr int POTRF_NB = 128;
+constexpr int POTRF_MAX_TILES = 240;   // k_bwd_persistent needs one resident workgroup per tile column (256 CUs)
 #ifndef BSFM_SYRK_WPS
 #define BSFM_SYRK_WPS 4      // waves per SIMD the bulk tile kernel is compiled for (4 = two workgroups per CU)
 #endif
@@ -274,34 +280,6 @@ __global__ __launch_bounds__(256, 1) void k_syrk_col64(double* __restrict__ S, i
         for (int u = 0; u < 4; ++u) {
             const int row = wr + 4 * t + (lane >> 4), col = wc + 16 * u + (lane & 15);
             Sij[(size_t)row * ld + col] = cin[t][u] - acc[t][u];
-        }
-}
-
-// Panel: X_i = S_ik * Linv_k^T for i = k+1 .. nblk-1; writes X back into S (it is L) and into the compact panel.
-__global__ __launch_bounds__(512, 4) void k_trsm_panel(double* __restrict__ S, int ld, int k,
-        const double* __restrict__ Linv, double* __restrict__ panel)
-{
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int i = k + 1 + blockIdx.x;
-    double* Sik = S + ((size_t)i * POTRF_NB) * ld + (size_t)k * POTRF_NB;
-    double acc[8][4];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[t][u] = 0.0;
-    gemm_nt_128(Sik, ld, Linv, POTRF_NB, POTRF_NB, lds, acc);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
-    double* Pt = panel + (size_t)blockIdx.x * POTRF_NB * POTRF_NB;
-    __syncthreads();   // every wave has finished reading S_ik through LDS before it is overwritten
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = wr + 4 * t + (lane >> 4), col = wc + 16 * u + (lane & 15);
-            const double v = acc[t][u];
-            Sik[(size_t)row * ld + col] = v;
-            Pt[row * POTRF_NB + col] = v;
         }
 }
 
@@ -556,39 +534,6 @@ __global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int 
     if (dbg && threadIdx.x == 0) dbg[3] = wall_clock64() - t0;
 }
 
-// forward substitution step: tiles i > k do E_i -= L_ik y_k ; tile k+1 then computes y_{k+1} = Linv_{k+1} E_{k+1}.
-// k == -1 bootstraps y_0 = Linv_0 E_0.
-__global__ __launch_bounds__(256) void k_fwd_step(const double* __restrict__ S, int ld, int k, const double* __restrict__ Linv,
-                                                  double* __restrict__ E, double* __restrict__ y)
-{
-    __shared__ double vec[POTRF_NB];
-    __shared__ double red[2][POTRF_NB];
-    const int i = k + 1 + blockIdx.x;
-    const int r = threadIdx.x & 127, h = threadIdx.x >> 7;
-    if (k >= 0) {
-        if (threadIdx.x < POTRF_NB) vec[threadIdx.x] = y[(size_t)k * POTRF_NB + threadIdx.x];
-        __syncthreads();
-        const double* Lr = S + ((size_t)i * POTRF_NB + r) * ld + (size_t)k * POTRF_NB + 64 * h;
-        double s = 0.0;
-#pragma unroll 8
-        for (int c = 0; c < 64; ++c) s += Lr[c] * vec[64 * h + c];
-        red[h][r] = s;
-        __syncthreads();
-        if (threadIdx.x < POTRF_NB) E[(size_t)i * POTRF_NB + r] -= red[0][r] + red[1][r];
-        if (blockIdx.x != 0) return;
-        __syncthreads();
-    }
-    if (threadIdx.x < POTRF_NB) vec[threadIdx.x] = E[(size_t)i * POTRF_NB + threadIdx.x];
-    __syncthreads();
-    const double* Li = Linv + (size_t)i * POTRF_NB * POTRF_NB + (size_t)r * POTRF_NB + 64 * h;
-    double s = 0.0;
-#pragma unroll 8
-    for (int c = 0; c < 64; ++c) s += Li[c] * vec[64 * h + c];
-    red[h][r] = s;
-    __syncthreads();
-    if (threadIdx.x < POTRF_NB) y[(size_t)i * POTRF_NB + r] = red[0][r] + red[1][r];
-}
-
 // Backward substitution x = L^-T y as ONE persistent launch (replaces nblk dependent launches).
 // Workgroup kk owns tile column kk, all nblk workgroups are resident at once (nblk <= #CUs, 256 threads, no big LDS):
 //   for i = nblk-1 .. kk+1 :  wait for x_i  ->  y_kk -= L_{i,kk}^T x_i        (tile (i,kk) prefetched into registers
@@ -649,39 +594,6 @@ __global__ __launch_bounds__(256) void k_bwd_persistent(const double* __restrict
     if (threadIdx.x == 0) __hip_atomic_store(&flags[kk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// backward substitution step: tiles kk < i do y_kk -= L_{i,kk}^T x_i ; tile i-1 then computes
-// x_{i-1} = Linv_{i-1}^T y_{i-1}.  i == nblk bootstraps x_{nblk-1}.
-__global__ __launch_bounds__(256) void k_bwd_step(const double* __restrict__ S, int ld, int i, int nblk,
-        const double* __restrict__ Linv, double* __restrict__ y, double* __restrict__ x)
-{
-    __shared__ double vec[POTRF_NB];
-    __shared__ double red[2][POTRF_NB];
-    const int kk = i - 1 - blockIdx.x;
-    const int c = threadIdx.x & 127, h = threadIdx.x >> 7;
-    if (i < nblk) {
-        if (threadIdx.x < POTRF_NB) vec[threadIdx.x] = x[(size_t)i * POTRF_NB + threadIdx.x];
-        __syncthreads();
-        const double* Lc = S + ((size_t)i * POTRF_NB + 64 * h) * ld + (size_t)kk * POTRF_NB + c;
-        double s = 0.0;
-#pragma unroll 8
-        for (int r = 0; r < 64; ++r) s += Lc[(size_t)r * ld] * vec[64 * h + r];
-        red[h][c] = s;
-        __syncthreads();
-        if (threadIdx.x < POTRF_NB) y[(size_t)kk * POTRF_NB + c] -= red[0][c] + red[1][c];
-        if (blockIdx.x != 0) return;
-        __syncthreads();
-    }
-    if (threadIdx.x < POTRF_NB) vec[threadIdx.x] = y[(size_t)kk * POTRF_NB + threadIdx.x];
-    __syncthreads();
-    const double* Li = Linv + (size_t)kk * POTRF_NB * POTRF_NB + (size_t)(64 * h) * POTRF_NB + c;
-    double s = 0.0;
-#pragma unroll 8
-    for (int r = 0; r < 64; ++r) s += Li[(size_t)r * POTRF_NB] * vec[64 * h + r];
-    red[h][c] = s;
-    __syncthreads();
-    if (threadIdx.x < POTRF_NB) x[(size_t)kk * POTRF_NB + c] = red[0][c] + red[1][c];
-}
-
 // ------------------------------------------------------------------------------------------------
 inline void potrf_free(PotrfWorkspace& w)
 {
@@ -714,7 +626,8 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
         if (const char* e = getenv("BSFM_PANEL_CUS")) reserve = atoi(e);
         hipDeviceProp_t prop; int dev = 0; (void)hipGetDevice(&dev);
         hipError_t rc = hipErrorUnknown;
-        if (reserve > 0 && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 2 * reserve) {
+        // only systems with enough tiles to be bulk-bound profit from the reservation; small ones use a plain stream
+        if (reserve > 0 && w.nblk >= 16 && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 2 * reserve) {
             const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
             std::vector<uint32_t> mask(words, 0u);
             for (int c = reserve; c < ncu; ++c) mask[c >> 5] |= 1u << (c & 31);
@@ -770,6 +683,11 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         return 0;
     }
     const int nblk = (n + POTRF_NB - 1) / POTRF_NB;
+    if (nblk > POTRF_MAX_TILES) {
+        fprintf(stderr, "[bsfm] reduced camera system of order %d exceeds the %d-tile residency limit of the persistent "
+                        "backward substitution\n", n, POTRF_MAX_TILES);
+        return -1;
+    }
     w.sy_used = 0;
     const size_t lds_bytes = 2 * 128 * GEMM_LDS_STRIDE * sizeof(double);
     (void)hipMemsetAsync(w.etmp, 0, (size_t)ld * sizeof(double), st);
@@ -816,14 +734,9 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         (void)hipEventRecord(w.evP[k + 1], st);
     }
     if (nblk > 1) (void)hipStreamWaitEvent(st, w.evU[nblk - 2], 0);
-    if (nblk <= 200 && !getenv("BSFM_BWD_STEPS")) {
-        // persistent backward substitution: all nblk workgroups resident (one per tile column)
-        (void)hipMemsetAsync(w.bflags, 0, (size_t)(w.nblk + 1) * sizeof(int), st);
-        hipLaunchKernelGGL(k_bwd_persistent, dim3(nblk), dim3(256), 0, st, S, ld, nblk, w.linv, w.y, w.xs, w.bflags, w.bflags + w.nblk);
-    } else {
-        for (int i = nblk; i >= 1; --i)
-            hipLaunchKernelGGL(k_bwd_step, dim3(i == nblk ? 1 : i), dim3(256), 0, st, S, ld, i, nblk, w.linv, w.y, w.xs);
-    }
+    // persistent backward substitution: all nblk workgroups must be resident (one per tile column)
+    (void)hipMemsetAsync(w.bflags, 0, (size_t)(w.nblk + 1) * sizeof(int), st);
+    hipLaunchKernelGGL(k_bwd_persistent, dim3(nblk), dim3(256), 0, st, S, ld, nblk, w.linv, w.y, w.xs, w.bflags, w.bflags + w.nblk);
     (void)hipMemcpyAsync(x_out, w.xs, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
     if (w.ev1) (void)hipEventRecord(w.ev1, st);
     if (w.dbg) {

@@ -13,6 +13,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    # a wedged GPU must fail the test quickly instead of hanging the whole run (pytest-timeout is installed)
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(180))
+
+
 @pytest.fixture(scope="session")
 def bsfm():
     import bundler_sfm_amd
