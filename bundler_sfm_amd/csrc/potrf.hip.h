@@ -53,7 +53,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 struct PotrfWorkspace {
     int ld = 0, nblk = 0, backend = 0;
-    double* panel = nullptr;   // 2 x (nblk-1) tiles of NB x NB: compact copy of the current panel, double-buffered
+    double* panel = nullptr;   // 4 x (nblk-1) tiles of NB x NB: compact copies of the last panels (ring, k & 3)
     hipStream_t s2 = nullptr;  // update stream of the lookahead schedule
     hipEvent_t* evP = nullptr; hipEvent_t* evU = nullptr;   // panel k ready / trailing update k done
     double* linv = nullptr;    // nblk tiles: inverse of each diagonal factor tile
@@ -72,14 +72,19 @@ struct PotrfWorkspace {
     // per-launch HIP-event timing of the trailing-update kernel (the roofline kernel bench.py reports)
     hipEvent_t* sy0 = nullptr; hipEvent_t* sy1 = nullptr; int sy_used = 0;
     double syrk_ms = 0.0; long long syrk_cnt = 0;
+    double* sy_flops = nullptr; double syrk_flops = 0.0;     // flops of each timed launch / running sum
+    int pair_min_t = 1 << 30;  // BSFM_PAIR_MIN_T: steps with more trailing tile rows than this apply TWO panels per bulk launch (measured slower end-to-end: off)
     long long* dbg = nullptr;   // optional device buffer: cycle stamps of k_potrf_diag phases (BSFM_DEBUG_DIAG=1)
 };
 
 // ------------------------------------------------------------------------------------------------
 // C(128x128) = A(128xK, row-major lda) * B(128xK, row-major ldb)^T, per-wave 64x64 quadrant in acc[4][4].
+template <bool NEG_A = false>
 __device__ __forceinline__ void gemm_nt_128(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
-                                            int K, double* __restrict__ lds, double (&acc)[8][4])
+                                            int K, double* __restrict__ lds, double (&acc)[8][4], long seg2 = 0)
 {
+    // K > 128: columns 128.. of BOTH operands continue at element offset seg2 from their first column (second panel
+    // buffer of a two-panel update; the offset is wave-uniform and identical for A and B, so it costs no VGPRs)
     double* As = lds;
     double* Bs = lds + 128 * GEMM_LDS_STRIDE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -96,8 +101,9 @@ __device__ __forceinline__ void gemm_nt_128(const double* __restrict__ A, int ld
     double* Bsw = Bs + srow * GEMM_LDS_STRIDE + sc2;
 #define BSFM_GLOAD(kc)                                                                                    \
     _Pragma("unroll") for (int q = 0; q < NPASS; ++q) {                                                   \
-        const double2 ta = *reinterpret_cast<const double2*>(Ag + (size_t)(RPP * q) * lda + (kc));         \
-        const double2 tb = *reinterpret_cast<const double2*>(Bg + (size_t)(RPP * q) * ldb + (kc));         \
+        const long ko_ = (kc) >= POTRF_NB ? (long)(kc) - POTRF_NB + seg2 : (long)(kc);                    \
+        const double2 ta = *reinterpret_cast<const double2*>(Ag + (size_t)(RPP * q) * lda + ko_);          \
+        const double2 tb = *reinterpret_cast<const double2*>(Bg + (size_t)(RPP * q) * ldb + ko_);          \
         pa[q][0] = ta.x; pa[q][1] = ta.y; pb[q][0] = tb.x; pb[q][1] = tb.y;                               \
     }
     BSFM_GLOAD(0)
@@ -105,7 +111,7 @@ __device__ __forceinline__ void gemm_nt_128(const double* __restrict__ A, int ld
         __syncthreads();          // previous chunk fully consumed
 #pragma unroll
         for (int q = 0; q < NPASS; ++q) {
-            *reinterpret_cast<double2*>(Asw + RPP * q * GEMM_LDS_STRIDE) = make_double2(pa[q][0], pa[q][1]);
+            *reinterpret_cast<double2*>(Asw + RPP * q * GEMM_LDS_STRIDE) = NEG_A ? make_double2(-pa[q][0], -pa[q][1]) : make_double2(pa[q][0], pa[q][1]);
             *reinterpret_cast<double2*>(Bsw + RPP * q * GEMM_LDS_STRIDE) = make_double2(pb[q][0], pb[q][1]);
         }
         __syncthreads();
@@ -283,6 +289,8 @@ __global__ __launch_bounds__(256, 1) void k_syrk_col64(double* __restrict__ S, i
         }
 }
 
+// (Tried and dropped: no-return global_atomic_add_f64 of -acc instead of a load/subtract/store epilogue -- bit-identical,
+// but slower, 31.1 vs 34.8 TFLOP/s on config 3: L2 atomic throughput becomes the limit.)
 // Trailing update: S_ij -= P_a P_b^T for k < j <= i (a = i-k-1, b = j-k-1), one tile per workgroup.
 // part 1 = only the first trailing column (b == 0, grid T): the tiles the NEXT panel needs (lookahead stream);
 // part 2 = every other tile (b >= 1, grid T(T-1)/2): the bulk, on the update stream.
@@ -300,23 +308,125 @@ __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __re
         ++a; ++b;      // triangle of size T-1 shifted past the first column
     }
     const int i = k + 1 + a, j = k + 1 + b;
-    double acc[8][4];
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[q][u] = 0.0;
-    gemm_nt_128(panel + (size_t)a * POTRF_NB * POTRF_NB, POTRF_NB, panel + (size_t)b * POTRF_NB * POTRF_NB, POTRF_NB,
-                POTRF_NB, lds, acc);
+    // The accumulators START as the C tile and the A operand is negated while it is staged into LDS, so the matrix
+    // cores produce S_ij - P_a P_b^T directly: the C loads overlap the first panel-chunk loads (no extra registers)
+    // and the epilogue is stores only -- a workgroup no longer waits for its 128 KB C tile at the end
+    // (measured on the tile kernel alone: 42 -> 51 TFLOP/s is the cost of a load/subtract/store epilogue).
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
     double* Sij = S + ((size_t)i * POTRF_NB) * ld + (size_t)j * POTRF_NB;
+    double acc[8][4];
+    {
+        const double* cp = Sij + (size_t)(wr + (lane >> 4)) * ld + wc + (lane & 15);   // rows 4 ld apart
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[q][u] = cp[16 * u];
+            cp += 4 * (size_t)ld;
+        }
+    }
+    gemm_nt_128<true>(panel + (size_t)a * POTRF_NB * POTRF_NB, POTRF_NB, panel + (size_t)b * POTRF_NB * POTRF_NB, POTRF_NB,
+                      POTRF_NB, lds, acc);
+    // the store address is recomputed from an opaque copy of the thread id: keeping the load addresses alive across
+    // the K loop would push the kernel over its 128-VGPR budget (and the staging registers into scratch)
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    double* Sl = Sij + (size_t)(((tid2 >> 7) << 5) + ((tid2 & 63) >> 4)) * ld + (((tid2 >> 6) & 1) << 6) + (tid2 & 15);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Sl[16 * u] = acc[q][u];
+        Sl += 4 * (size_t)ld;
+    }
+}
+
+// Two-panel variants (steps far from the end, where the factorisation is bound by the bulk update and not by the panel
+// chain): a rank-128 update of a 128x128 tile moves 256 KB of C for 4.2 MFLOP = 16 flop/byte, exactly the machine
+// balance of the part (78.6 TFLOP/s over ~5 TB/s), so HBM and the matrix cores are both saturated and neither
+// overlaps perfectly.  Applying panels k and k+1 in ONE pass over C (rank 256) halves the C traffic per flop.
+//   first trailing column of the pair: S_{k+2+a, k+2} -= P0_{a+1} P0_1^T + P1_a P1_0^T     (P0 = panel k, P1 = panel k+1)
+__global__ __launch_bounds__(256, 1) void k_syrk_col64x2(double* __restrict__ S, int ld, int k, const double* __restrict__ p0,
+        const double* __restrict__ p1, int ngemm, double* __restrict__ E, const double* __restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr size_t TL = (size_t)POTRF_NB * POTRF_NB;
+    if ((int)blockIdx.x >= ngemm) {      // forward substitution with y_{k+1} only (y_k went in with the first step of the pair)
+        const int a = blockIdx.x - ngemm;
+        const int row = threadIdx.x >> 1, part = threadIdx.x & 1;
+        const double* Pr = p1 + (size_t)a * TL + (size_t)row * POTRF_NB + 64 * part;
+        const double* yk = y + (size_t)(k + 1) * POTRF_NB + 64 * part;
+        double sacc = 0.0;
+#pragma unroll 16
+        for (int c = 0; c < 64; ++c) sacc += Pr[c] * yk[c];
+        sacc += __shfl_xor(sacc, 1, 64);
+        if (part == 0) E[(size_t)(k + 2 + a) * POTRF_NB + row] -= sacc;
+        return;
+    }
+    const int a = blockIdx.x >> 1, half = blockIdx.x & 1;
+    double acc[8][4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[t][u] = 0.0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
+    double* Sij = S + ((size_t)(k + 2 + a) * POTRF_NB + 64 * half) * ld + (size_t)(k + 2) * POTRF_NB;
+    double cin[8][4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            cin[t][u] = Sij[(size_t)(wr + 4 * t + (lane >> 4)) * ld + wc + 16 * u + (lane & 15)];
+    gemm_nt_64(p0 + (size_t)(a + 1) * TL + (size_t)(64 * half) * POTRF_NB, POTRF_NB, p0 + TL, POTRF_NB, lds, acc);
+    gemm_nt_64(p1 + (size_t)a * TL + (size_t)(64 * half) * POTRF_NB, POTRF_NB, p1, POTRF_NB, lds, acc);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int row = wr + 4 * q + (lane >> 4), col = wc + 16 * u + (lane & 15);
-            Sij[(size_t)row * ld + col] -= acc[q][u];
+            const int row = wr + 4 * t + (lane >> 4), col = wc + 16 * u + (lane & 15);
+            Sij[(size_t)row * ld + col] = cin[t][u] - acc[t][u];
         }
+}
+
+//   bulk of the pair: S_ij -= P0_{i-k-1} P0_{j-k-1}^T + P1_{i-k-2} P1_{j-k-2}^T for i >= j >= k+3, grid T2 (T2+1)/2
+__global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update2(double* __restrict__ S, int ld, int k,
+        const double* __restrict__ p0, const double* __restrict__ p1)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr size_t TL = (size_t)POTRF_NB * POTRF_NB;
+    const int t = blockIdx.x;
+    int a = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= t) ++a;
+    while (a * (a + 1) / 2 > t) --a;
+    const int b = t - a * (a + 1) / 2;
+    const int i = k + 3 + a, j = k + 3 + b;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
+    double* Sij = S + ((size_t)i * POTRF_NB) * ld + (size_t)j * POTRF_NB;
+    double acc[8][4];                   // starts as the C tile, see k_syrk_update
+    {
+        const double* cp = Sij + (size_t)(wr + (lane >> 4)) * ld + wc + (lane & 15);   // rows 4 ld apart
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[q][u] = cp[16 * u];
+            cp += 4 * (size_t)ld;
+        }
+    }
+    // second segment: p1 + (a+1) TL = (p0 + (a+2) TL) + ((p1 - p0) - TL), the same shift for the B operand
+    gemm_nt_128<true>(p0 + (size_t)(a + 2) * TL, POTRF_NB, p0 + (size_t)(b + 2) * TL, POTRF_NB, 2 * POTRF_NB, lds, acc,
+                      (long)(p1 - p0) - (long)TL);
+    // the store address is recomputed from an opaque copy of the thread id: keeping the load addresses alive across
+    // the K loop would push the kernel over its 128-VGPR budget (and the staging registers into scratch)
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    double* Sl = Sij + (size_t)(((tid2 >> 7) << 5) + ((tid2 & 63) >> 4)) * ld + (((tid2 >> 6) & 1) << 6) + (tid2 & 15);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Sl[16 * u] = acc[q][u];
+        Sl += 4 * (size_t)ld;
+    }
 }
 
 // Diagonal tile: Cholesky factor AND its inverse in ONE 512-thread workgroup -- the serial critical path of the
@@ -607,7 +717,7 @@ inline void potrf_free(PotrfWorkspace& w)
     if (w.ev0) (void)hipEventDestroy(w.ev0);
     if (w.ev1) (void)hipEventDestroy(w.ev1);
     for (int i = 0; w.sy0 && i < w.nblk; ++i) { (void)hipEventDestroy(w.sy0[i]); (void)hipEventDestroy(w.sy1[i]); }
-    delete[] w.sy0; delete[] w.sy1;
+    delete[] w.sy0; delete[] w.sy1; delete[] w.sy_flops;
     for (int i = 0; w.evP && i <= w.nblk; ++i) { (void)hipEventDestroy(w.evP[i]); (void)hipEventDestroy(w.evU[i]); }
     delete[] w.evP; delete[] w.evU;
     if (w.s2) (void)hipStreamDestroy(w.s2);
@@ -618,7 +728,7 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
 {
     w.ld = ld; w.nblk = ld / POTRF_NB; w.backend = backend;
     const size_t tile = (size_t)POTRF_NB * POTRF_NB;
-    if (hipMalloc((void**)&w.panel, 2 * std::max<size_t>(1, (size_t)(w.nblk - 1)) * tile * sizeof(double)) != hipSuccess) return -1;
+    if (hipMalloc((void**)&w.panel, 4 * std::max<size_t>(1, (size_t)(w.nblk - 1)) * tile * sizeof(double)) != hipSuccess) return -1;
     {   // The bulk trailing update must not occupy every CU, otherwise the 150 KB-LDS diagonal-tile workgroup of the
         // lookahead stream can never be placed: reserve BSFM_PANEL_CUS compute units (default 32) by masking them
         // out of the update stream (hipExtStreamCreateWithCUMask); 0 disables the reservation.
@@ -648,7 +758,8 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
     (void)hipEventCreate(&w.ev0); (void)hipEventCreate(&w.ev1);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(DG_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
-    w.sy0 = new hipEvent_t[w.nblk]; w.sy1 = new hipEvent_t[w.nblk];
+    w.sy0 = new hipEvent_t[w.nblk]; w.sy1 = new hipEvent_t[w.nblk]; w.sy_flops = new double[w.nblk];
+    if (const char* e = getenv("BSFM_PAIR_MIN_T")) w.pair_min_t = std::max(4, atoi(e));
     for (int i = 0; i < w.nblk; ++i) { (void)hipEventCreate(&w.sy0[i]); (void)hipEventCreate(&w.sy1[i]); }
     if (getenv("BSFM_DEBUG_DIAG")) { (void)hipMalloc((void**)&w.dbg, 8 * sizeof(long long)); }
     if (backend == 1) {
@@ -708,32 +819,58 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
     else
         hipLaunchKernelGGL(k_fwd_last, dim3(1), dim3(256), 0, st, w.linv, w.etmp, w.y);
     (void)hipEventRecord(w.evP[0], st);
-    for (int k = 0; k + 1 < nblk; ++k) {
+    const double tile_flops = 2.0 * POTRF_NB * POTRF_NB * POTRF_NB;
+    int last_bulk = -1;                  // index of the evU event of the most recent bulk launch
+    auto panel_of = [&](int k) { return w.panel + (size_t)(k & 3) * pstride; };
+    auto chain_panel = [&](int k1, int Tbelow) {   // diag(k1) and the panel below it (Tbelow tile rows), records evP[k1]
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, k1, n, w.linv, d_info, w.dbg);
+        if (Tbelow > 0)
+            hipLaunchKernelGGL(k_trsm_panel64, dim3(2 * Tbelow + 1), dim3(256), lds64, st, S, ld, k1,
+                               w.linv + (size_t)k1 * POTRF_NB * POTRF_NB, panel_of(k1), 2 * Tbelow, w.etmp, w.y);
+        else   // last tile: no panel below it, only its forward-substitution solve
+            hipLaunchKernelGGL(k_fwd_last, dim3(1), dim3(256), 0, st, w.linv + (size_t)k1 * POTRF_NB * POTRF_NB,
+                               w.etmp + (size_t)k1 * POTRF_NB, w.y + (size_t)k1 * POTRF_NB);
+        (void)hipEventRecord(w.evP[k1], st);
+    };
+    for (int k = 0; k + 1 < nblk;) {
         const int T = nblk - k - 1;
-        double* pk = w.panel + (size_t)(k & 1) * pstride;
+        if (T > w.pair_min_t) {
+            // bulk-bound regime: panels k and k+1 go into the trailing matrix in ONE rank-256 pass
+            if (last_bulk >= 0) (void)hipStreamWaitEvent(st, w.evU[last_bulk], 0);
+            hipLaunchKernelGGL(k_syrk_col64, dim3(3 * T), dim3(256), lds64, st, S, ld, k, panel_of(k), 2 * T, w.etmp, w.y);
+            chain_panel(k + 1, T - 1);
+            (void)hipStreamWaitEvent(w.s2, w.evP[k + 1], 0);
+            const int T2 = T - 2;
+            (void)hipEventRecord(w.sy0[w.sy_used], w.s2);
+            hipLaunchKernelGGL(k_syrk_update2, dim3(T2 * (T2 + 1) / 2), dim3(512), lds_bytes, w.s2, S, ld, k, panel_of(k), panel_of(k + 1));
+            (void)hipEventRecord(w.sy1[w.sy_used], w.s2);
+            w.sy_flops[w.sy_used++] = 2.0 * tile_flops * (T2 * (T2 + 1) / 2);
+            (void)hipEventRecord(w.evU[k + 1], w.s2);
+            last_bulk = k + 1;
+            hipLaunchKernelGGL(k_syrk_col64x2, dim3(3 * (T - 1)), dim3(256), lds64, st, S, ld, k, panel_of(k), panel_of(k + 1),
+                               2 * (T - 1), w.etmp, w.y);
+            chain_panel(k + 2, T - 2);
+            k += 2;
+            continue;
+        }
+        double* pk = panel_of(k);
         // update stream: bulk of step k
         (void)hipStreamWaitEvent(w.s2, w.evP[k], 0);
         if (T > 1) {
-            (void)hipEventRecord(w.sy0[k], w.s2);
+            (void)hipEventRecord(w.sy0[w.sy_used], w.s2);
             hipLaunchKernelGGL(k_syrk_update, dim3(T * (T - 1) / 2), dim3(512), lds_bytes, w.s2, S, ld, k, pk, 2);
-            (void)hipEventRecord(w.sy1[k], w.s2);
-            w.sy_used = k + 1;
+            (void)hipEventRecord(w.sy1[w.sy_used], w.s2);
+            w.sy_flops[w.sy_used++] = tile_flops * (T * (T - 1) / 2);
         }
-        (void)hipEventRecord(w.evU[k], w.s2);
         // panel stream: first trailing column of step k, then panel k+1
-        if (k > 0) (void)hipStreamWaitEvent(st, w.evU[k - 1], 0);   // column k+1 was last written by the bulk of step k-1
+        if (last_bulk >= 0) (void)hipStreamWaitEvent(st, w.evU[last_bulk], 0);   // column k+1 was last written by that launch
+        (void)hipEventRecord(w.evU[k], w.s2);
+        last_bulk = k;
         hipLaunchKernelGGL(k_syrk_col64, dim3(3 * T), dim3(256), lds64, st, S, ld, k, pk, 2 * T, w.etmp, w.y);
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, k + 1, n, w.linv, d_info, w.dbg);
-        if (T > 1)
-            hipLaunchKernelGGL(k_trsm_panel64, dim3(2 * (T - 1) + 1), dim3(256), lds64, st, S, ld, k + 1,
-                               w.linv + (size_t)(k + 1) * POTRF_NB * POTRF_NB, w.panel + (size_t)((k + 1) & 1) * pstride,
-                               2 * (T - 1), w.etmp, w.y);
-        else   // last tile: no panel below it, only its forward-substitution solve
-            hipLaunchKernelGGL(k_fwd_last, dim3(1), dim3(256), 0, st, w.linv + (size_t)(k + 1) * POTRF_NB * POTRF_NB,
-                               w.etmp + (size_t)(k + 1) * POTRF_NB, w.y + (size_t)(k + 1) * POTRF_NB);
-        (void)hipEventRecord(w.evP[k + 1], st);
+        chain_panel(k + 1, T - 1);
+        ++k;
     }
-    if (nblk > 1) (void)hipStreamWaitEvent(st, w.evU[nblk - 2], 0);
+    if (last_bulk >= 0) (void)hipStreamWaitEvent(st, w.evU[last_bulk], 0);
     // persistent backward substitution: all nblk workgroups must be resident (one per tile column)
     (void)hipMemsetAsync(w.bflags, 0, (size_t)(w.nblk + 1) * sizeof(int), st);
     hipLaunchKernelGGL(k_bwd_persistent, dim3(nblk), dim3(256), 0, st, S, ld, nblk, w.linv, w.y, w.xs, w.bflags, w.bflags + w.nblk);
@@ -751,7 +888,7 @@ inline void potrf_collect_time(PotrfWorkspace& w)
     float ms = 0.f;
     if (w.ev0 && w.ev1 && hipEventElapsedTime(&ms, w.ev0, w.ev1) == hipSuccess && ms >= 0.f) { w.ms += ms; w.cnt++; }
     for (int i = 0; i < w.sy_used; ++i)
-        if (hipEventElapsedTime(&ms, w.sy0[i], w.sy1[i]) == hipSuccess && ms >= 0.f) { w.syrk_ms += ms; w.syrk_cnt++; }
+        if (hipEventElapsedTime(&ms, w.sy0[i], w.sy1[i]) == hipSuccess && ms >= 0.f) { w.syrk_ms += ms; w.syrk_cnt++; w.syrk_flops += w.sy_flops[i]; }
     w.sy_used = 0;
 }
 

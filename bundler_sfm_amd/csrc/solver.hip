@@ -537,6 +537,8 @@ double bsfm_lm_last_kernel_ms(const bsfm_problem_t* pb, const char* phase)
         if (!strcmp(phase, kPhaseNames[i])) return pb->ph_cnt[i] ? pb->ph_ms[i] / pb->ph_cnt[i] : -1.0;
     if (!strcmp(phase, "potrf")) return pb->potrf.cnt ? pb->potrf.ms / pb->potrf.cnt : -1.0;
     if (!strcmp(phase, "syrk")) return pb->potrf.syrk_cnt ? pb->potrf.syrk_ms / (double)pb->potrf.syrk_cnt : -1.0;
+    if (!strcmp(phase, "syrk_gflop")) return pb->potrf.syrk_cnt ? pb->potrf.syrk_flops * 1e-9 / (double)pb->potrf.syrk_cnt : -1.0;
+    if (!strcmp(phase, "syrk_launches")) return pb->potrf.cnt ? (double)pb->potrf.syrk_cnt / (double)pb->potrf.cnt : -1.0;
     return -1.0;
 }
 
@@ -546,7 +548,7 @@ int bsfm_lm_begin(bsfm_problem_t* pb)
     pb->itno = 0; pb->stop = 0; pb->nu = 2; pb->nfev = 0; pb->njev = 0; pb->nlss = 0; pb->error = 0;
     pb->mu = 0.0; pb->eab_inf = 0.0; pb->dp_L2 = DBL_MAX; pb->p_L2 = 0.0; pb->maxdiag = DBL_MIN;
     for (int i = 0; i < PH_COUNT; ++i) { pb->ph_ms[i] = 0.0; pb->ph_cnt[i] = 0; }
-    pb->potrf.ms = 0.0; pb->potrf.cnt = 0; pb->potrf.syrk_ms = 0.0; pb->potrf.syrk_cnt = 0;
+    pb->potrf.ms = 0.0; pb->potrf.cnt = 0; pb->potrf.syrk_ms = 0.0; pb->potrf.syrk_cnt = 0; pb->potrf.syrk_flops = 0.0;
     if (nobs < pb->nvars_global) {   // sba_levmar.c:647-650
         fprintf(stderr, "SBA: sba_motstr_levmar_x() cannot solve a problem with fewer measurements [%lld] than unknowns [%lld]\n",
                 nobs, pb->nvars_global);
