@@ -60,24 +60,12 @@ def shard_points(rowptr, world, rank):
 
 def syrk_flops_per_launch(sdim):
     """Algorithmic FP64 flop of the timed trailing-update launches of one factorisation (mirrors the schedule in
-    csrc/potrf.hip.h:potrf_solve).  One 128x128 tile x one 128-deep panel = 2*128^3 flop.  While more than
-    BSFM_PAIR_MIN_T (40) tile rows remain, panels k and k+1 are applied together by k_syrk_update2 to the
-    T2(T2+1)/2 lower tiles of columns >= k+3 (T2 = nblk-k-3), two panels each; afterwards every step k launches
-    k_syrk_update on the T(T-1)/2 tiles of columns >= k+2 (T = nblk-k-1).  The first trailing column(s) of a step run
-    on the panel stream (k_syrk_col64*) and are not part of the timed launches."""
+    csrc/potrf.hip.h:potrf_solve).  One 128x128 tile x one 128-deep panel = 2*128^3 flop; step k launches k_syrk_update
+    on the T(T-1)/2 lower tiles of the columns past k+1 (T = nblk-k-1).  The first trailing column of a step is
+    updated by k_syrk_col64 on the chain/side streams and is not part of the timed launches."""
     nblk = (sdim + NB - 1) // NB
-    pair_min_t = max(4, int(os.environ.get("BSFM_PAIR_MIN_T", str(1 << 30))))
-    flops, k = [], 0
-    while k + 1 < nblk:
-        t = nblk - k - 1
-        if t > pair_min_t:
-            t2 = t - 2
-            flops.append(2 * 2.0 * NB ** 3 * (t2 * (t2 + 1) // 2)); k += 2
-        else:
-            if t > 1:
-                flops.append(2.0 * NB ** 3 * (t * (t - 1) // 2))
-            k += 1
-    return sum(flops) / max(len(flops), 1), len(flops)
+    tiles = [t * (t - 1) // 2 for t in range(nblk - 1, 1, -1)]
+    return 2.0 * NB ** 3 * sum(tiles) / max(len(tiles), 1), len(tiles)
 
 
 def cpu_baseline(sample):
@@ -188,7 +176,7 @@ def main():
             lib_gflop = pb.phase_ms("syrk_gflop")       # the library's own count of what it launched
             assert abs(lib_gflop * 1e9 - flops_launch) <= 1e-9 * flops_launch, (lib_gflop, flops_launch)
             ach = flops_launch / (syrk_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "k_syrk_update2+k_syrk_update (trailing update of the reduced-camera Cholesky)", "achieved": round(ach, 3), "peak": FP64_MFMA_PEAK_TFLOPS,
+            roof = {"bound": "mfma", "kernel": "k_syrk_update", "achieved": round(ach, 3), "peak": FP64_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                     "launches_per_solve": nlaunch, "avg_launch_ms": round(syrk_ms, 4),
                     "alg_flop_per_launch": flops_launch}

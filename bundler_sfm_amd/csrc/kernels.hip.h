@@ -379,11 +379,10 @@ __global__ __launch_bounds__(256) void k_schur_tasks(DevProblem P, const SchurTa
 }
 
 // S_jk = [j==k](U_j + mu I) - sum_tasks partial ; mirrored into S_kj (sba_levmar.c:1274-1316).
-// add_diag = 0 on ranks > 0 of a multi-GPU job (U, mu enter the cross-rank sum exactly once).
 template <int CNP>
 __global__ __launch_bounds__(128) void k_schur_assemble(int nblk, const int* __restrict__ blk_j, const int* __restrict__ blk_k,
         const int* __restrict__ blk_task0, const double* __restrict__ partials, const double* __restrict__ U,
-        double mu, int add_diag, int mcon, double* __restrict__ S, int ld)
+        double mu, int mcon, double* __restrict__ S, int ld)
 {
     const int b = blockIdx.x;
     if (b >= nblk || threadIdx.x >= CNP * CNP) return;
@@ -392,21 +391,49 @@ __global__ __launch_bounds__(128) void k_schur_assemble(int nblk, const int* __r
     double s = 0.0;
     for (int t = blk_task0[b]; t < blk_task0[b + 1]; ++t) s += partials[(size_t)t * CNP * CNP + threadIdx.x];
     double v = -s;
-    if (j == k && add_diag) { v += U[(size_t)j * CNP * CNP + threadIdx.x]; if (row == col) v += mu; }
+    if (j == k) { v += U[(size_t)j * CNP * CNP + threadIdx.x]; if (row == col) v += mu; }
     const size_t rj = (size_t)(j - mcon) * CNP + row, ck = (size_t)(k - mcon) * CNP + col;
     S[rj * ld + ck] = v;
     if (j != k) S[ck * ld + rj] = v;
 }
 
-// diagonal blocks of cameras that share no triple list entry cannot exist (every observed camera pairs with
-// itself), but cameras WITHOUT observations on this rank still need U_j + mu I on rank 0:
+// Multi-GPU job: this rank's block sums go to their slot of the union structure (the buffer that is all-reduced) ...
+template <int CNP>
+__global__ __launch_bounds__(128) void k_schur_pack(int nblk, const int* __restrict__ blk_task0, const double* __restrict__ partials,
+        const int* __restrict__ gidx, double* __restrict__ G)
+{
+    const int b = blockIdx.x;
+    if (b >= nblk || threadIdx.x >= CNP * CNP) return;
+    double s = 0.0;
+    for (int t = blk_task0[b]; t < blk_task0[b + 1]; ++t) s += partials[(size_t)t * CNP * CNP + threadIdx.x];
+    G[(size_t)gidx[b] * CNP * CNP + threadIdx.x] = s;
+}
+
+// ... and after the exchange every rank assembles the same S from the summed blocks.
+template <int CNP>
+__global__ __launch_bounds__(128) void k_schur_unpack(int ngblk, const int* __restrict__ gj, const int* __restrict__ gk,
+        const double* __restrict__ G, const double* __restrict__ U, double mu, int mcon, double* __restrict__ S, int ld)
+{
+    const int g = blockIdx.x;
+    if (g >= ngblk || threadIdx.x >= CNP * CNP) return;
+    const int j = gj[g], k = gk[g];
+    const int row = threadIdx.x / CNP, col = threadIdx.x % CNP;
+    double v = -G[(size_t)g * CNP * CNP + threadIdx.x];
+    if (j == k) { v += U[(size_t)j * CNP * CNP + threadIdx.x]; if (row == col) v += mu; }
+    const size_t rj = (size_t)(j - mcon) * CNP + row, ck = (size_t)(k - mcon) * CNP + col;
+    S[rj * ld + ck] = v;
+    if (j != k) S[ck * ld + rj] = v;
+}
+
+// Cameras that own no (j,j) block in the triple list (no observation) still need U_j + mu I.
+// camptr == nullptr: fill EVERY diagonal block (multi-GPU path: k_schur_unpack then overwrites those with a block).
 template <int CNP>
 __global__ void k_schur_diag_fill(int m, int mcon, const int* __restrict__ camptr, const double* __restrict__ U,
                                   double mu, double* __restrict__ S, int ld)
 {
     const int j = mcon + blockIdx.x;
     if (j >= m || threadIdx.x >= CNP * CNP) return;
-    if (camptr[j + 1] > camptr[j]) return;    // has a (j,j) block in the triple list
+    if (camptr && camptr[j + 1] > camptr[j]) return;    // has a (j,j) block in the triple list
     const int row = threadIdx.x / CNP, col = threadIdx.x % CNP;
     double v = U[(size_t)j * CNP * CNP + threadIdx.x];
     if (row == col) v += mu;

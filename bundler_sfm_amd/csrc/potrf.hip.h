@@ -54,8 +54,10 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 struct PotrfWorkspace {
     int ld = 0, nblk = 0, backend = 0;
     double* panel = nullptr;   // 4 x (nblk-1) tiles of NB x NB: compact copies of the last panels (ring, k & 3)
-    hipStream_t s2 = nullptr;  // update stream of the lookahead schedule
-    hipEvent_t* evP = nullptr; hipEvent_t* evU = nullptr;   // panel k ready / trailing update k done
+    hipStream_t s2 = nullptr;  // bulk-update stream of the lookahead schedule (CU-masked)
+    hipStream_t sd = nullptr;  // side stream: the part of panel k / first trailing column the NEXT diagonal tile does not need
+    hipEvent_t* evP = nullptr; hipEvent_t* evU = nullptr;   // panel k complete (side stream) / trailing update k done
+    hipEvent_t* evT = nullptr; hipEvent_t* evC = nullptr;   // first panel tile of step k ready (chain) / first trailing column done (side)
     double* linv = nullptr;    // nblk tiles: inverse of each diagonal factor tile
     double* y = nullptr;       // ld
     double* xs = nullptr;      // ld
@@ -73,7 +75,6 @@ struct PotrfWorkspace {
     hipEvent_t* sy0 = nullptr; hipEvent_t* sy1 = nullptr; int sy_used = 0;
     double syrk_ms = 0.0; long long syrk_cnt = 0;
     double* sy_flops = nullptr; double syrk_flops = 0.0;     // flops of each timed launch / running sum
-    int pair_min_t = 1 << 30;  // BSFM_PAIR_MIN_T: steps with more trailing tile rows than this apply TWO panels per bulk launch (measured slower end-to-end: off)
     long long* dbg = nullptr;   // optional device buffer: cycle stamps of k_potrf_diag phases (BSFM_DEBUG_DIAG=1)
 };
 
@@ -215,14 +216,14 @@ __global__ __launch_bounds__(256) void k_fwd_last(const double* __restrict__ Lin
 }
 
 __global__ __launch_bounds__(256, 1) void k_trsm_panel64(double* __restrict__ S, int ld, int k,
-        const double* __restrict__ Linv, double* __restrict__ panel, int nwork, const double* __restrict__ E, double* __restrict__ y)
+        const double* __restrict__ Linv, double* __restrict__ panel, int tile0, int nwork, const double* __restrict__ E, double* __restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if ((int)blockIdx.x == nwork) {          // the extra workgroup: y_k = inv(L_kk) E_k
         fwd_tile_solve(Linv, E + (size_t)k * POTRF_NB, y + (size_t)k * POTRF_NB, lds);
         return;
     }
-    const int tile = blockIdx.x >> 1, half = blockIdx.x & 1;
+    const int tile = tile0 + (blockIdx.x >> 1), half = blockIdx.x & 1;
     double* Sik = S + ((size_t)(k + 1 + tile) * POTRF_NB + 64 * half) * ld + (size_t)k * POTRF_NB;
     double acc[8][4];
 #pragma unroll
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256, 1) void k_trsm_panel64(double* __restrict__ S,
 
 // First trailing column, two halves per tile: S_{k+1+a, k+1} -= P_a P_0^T.
 __global__ __launch_bounds__(256, 1) void k_syrk_col64(double* __restrict__ S, int ld, int k, const double* __restrict__ panel,
-        int ngemm, double* __restrict__ E, const double* __restrict__ y)
+        int a0, int ngemm, double* __restrict__ E, const double* __restrict__ y)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if ((int)blockIdx.x >= ngemm) {
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void k_syrk_col64(double* __restrict__ S, i
         if (part == 0) E[(size_t)(k + 1 + a) * POTRF_NB + row] -= sacc;
         return;
     }
-    const int a = blockIdx.x >> 1, half = blockIdx.x & 1;
+    const int a = a0 + (blockIdx.x >> 1), half = blockIdx.x & 1;
     double acc[8][4];
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -340,94 +341,9 @@ __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __re
     }
 }
 
-// Two-panel variants (steps far from the end, where the factorisation is bound by the bulk update and not by the panel
-// chain): a rank-128 update of a 128x128 tile moves 256 KB of C for 4.2 MFLOP = 16 flop/byte, exactly the machine
-// balance of the part (78.6 TFLOP/s over ~5 TB/s), so HBM and the matrix cores are both saturated and neither
-// overlaps perfectly.  Applying panels k and k+1 in ONE pass over C (rank 256) halves the C traffic per flop.
-//   first trailing column of the pair: S_{k+2+a, k+2} -= P0_{a+1} P0_1^T + P1_a P1_0^T     (P0 = panel k, P1 = panel k+1)
-__global__ __launch_bounds__(256, 1) void k_syrk_col64x2(double* __restrict__ S, int ld, int k, const double* __restrict__ p0,
-        const double* __restrict__ p1, int ngemm, double* __restrict__ E, const double* __restrict__ y)
-{
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr size_t TL = (size_t)POTRF_NB * POTRF_NB;
-    if ((int)blockIdx.x >= ngemm) {      // forward substitution with y_{k+1} only (y_k went in with the first step of the pair)
-        const int a = blockIdx.x - ngemm;
-        const int row = threadIdx.x >> 1, part = threadIdx.x & 1;
-        const double* Pr = p1 + (size_t)a * TL + (size_t)row * POTRF_NB + 64 * part;
-        const double* yk = y + (size_t)(k + 1) * POTRF_NB + 64 * part;
-        double sacc = 0.0;
-#pragma unroll 16
-        for (int c = 0; c < 64; ++c) sacc += Pr[c] * yk[c];
-        sacc += __shfl_xor(sacc, 1, 64);
-        if (part == 0) E[(size_t)(k + 2 + a) * POTRF_NB + row] -= sacc;
-        return;
-    }
-    const int a = blockIdx.x >> 1, half = blockIdx.x & 1;
-    double acc[8][4];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[t][u] = 0.0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
-    double* Sij = S + ((size_t)(k + 2 + a) * POTRF_NB + 64 * half) * ld + (size_t)(k + 2) * POTRF_NB;
-    double cin[8][4];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            cin[t][u] = Sij[(size_t)(wr + 4 * t + (lane >> 4)) * ld + wc + 16 * u + (lane & 15)];
-    gemm_nt_64(p0 + (size_t)(a + 1) * TL + (size_t)(64 * half) * POTRF_NB, POTRF_NB, p0 + TL, POTRF_NB, lds, acc);
-    gemm_nt_64(p1 + (size_t)a * TL + (size_t)(64 * half) * POTRF_NB, POTRF_NB, p1, POTRF_NB, lds, acc);
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = wr + 4 * t + (lane >> 4), col = wc + 16 * u + (lane & 15);
-            Sij[(size_t)row * ld + col] = cin[t][u] - acc[t][u];
-        }
-}
-
-//   bulk of the pair: S_ij -= P0_{i-k-1} P0_{j-k-1}^T + P1_{i-k-2} P1_{j-k-2}^T for i >= j >= k+3, grid T2 (T2+1)/2
-__global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update2(double* __restrict__ S, int ld, int k,
-        const double* __restrict__ p0, const double* __restrict__ p1)
-{
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr size_t TL = (size_t)POTRF_NB * POTRF_NB;
-    const int t = blockIdx.x;
-    int a = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-    while ((a + 1) * (a + 2) / 2 <= t) ++a;
-    while (a * (a + 1) / 2 > t) --a;
-    const int b = t - a * (a + 1) / 2;
-    const int i = k + 3 + a, j = k + 3 + b;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
-    double* Sij = S + ((size_t)i * POTRF_NB) * ld + (size_t)j * POTRF_NB;
-    double acc[8][4];                   // starts as the C tile, see k_syrk_update
-    {
-        const double* cp = Sij + (size_t)(wr + (lane >> 4)) * ld + wc + (lane & 15);   // rows 4 ld apart
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[q][u] = cp[16 * u];
-            cp += 4 * (size_t)ld;
-        }
-    }
-    // second segment: p1 + (a+1) TL = (p0 + (a+2) TL) + ((p1 - p0) - TL), the same shift for the B operand
-    gemm_nt_128<true>(p0 + (size_t)(a + 2) * TL, POTRF_NB, p0 + (size_t)(b + 2) * TL, POTRF_NB, 2 * POTRF_NB, lds, acc,
-                      (long)(p1 - p0) - (long)TL);
-    // the store address is recomputed from an opaque copy of the thread id: keeping the load addresses alive across
-    // the K loop would push the kernel over its 128-VGPR budget (and the staging registers into scratch)
-    int tid2 = threadIdx.x;
-    asm volatile("" : "+v"(tid2));
-    double* Sl = Sij + (size_t)(((tid2 >> 7) << 5) + ((tid2 & 63) >> 4)) * ld + (((tid2 >> 6) & 1) << 6) + (tid2 & 15);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) Sl[16 * u] = acc[q][u];
-        Sl += 4 * (size_t)ld;
-    }
-}
+// (Tried and dropped, see git history: a rank-256 variant applying panels k and k+1 in one pass over C.  Alone it runs at
+// 46.6 instead of 42.9 TFLOP/s (C traffic per flop halves), but the chain then has to serve two columns per pair and the
+// factorisation as a whole got slower: 10.9 vs 10.1 ms at config 3.)
 
 // Diagonal tile: Cholesky factor AND its inverse in ONE 512-thread workgroup -- the serial critical path of the
 // factorisation, so it is blocked to keep the truly serial work tiny:
@@ -718,9 +634,12 @@ inline void potrf_free(PotrfWorkspace& w)
     if (w.ev1) (void)hipEventDestroy(w.ev1);
     for (int i = 0; w.sy0 && i < w.nblk; ++i) { (void)hipEventDestroy(w.sy0[i]); (void)hipEventDestroy(w.sy1[i]); }
     delete[] w.sy0; delete[] w.sy1; delete[] w.sy_flops;
-    for (int i = 0; w.evP && i <= w.nblk; ++i) { (void)hipEventDestroy(w.evP[i]); (void)hipEventDestroy(w.evU[i]); }
-    delete[] w.evP; delete[] w.evU;
+    for (int i = 0; w.evP && i <= w.nblk; ++i) {
+        (void)hipEventDestroy(w.evP[i]); (void)hipEventDestroy(w.evU[i]); (void)hipEventDestroy(w.evT[i]); (void)hipEventDestroy(w.evC[i]);
+    }
+    delete[] w.evP; delete[] w.evU; delete[] w.evT; delete[] w.evC;
     if (w.s2) (void)hipStreamDestroy(w.s2);
+    if (w.sd) (void)hipStreamDestroy(w.sd);
     w = PotrfWorkspace();
 }
 
@@ -745,10 +664,14 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
         }
         if (rc != hipSuccess && hipStreamCreateWithFlags(&w.s2, hipStreamNonBlocking) != hipSuccess) return -1;
     }
+    if (hipStreamCreateWithFlags(&w.sd, hipStreamNonBlocking) != hipSuccess) return -1;
     w.evP = new hipEvent_t[w.nblk + 1]; w.evU = new hipEvent_t[w.nblk + 1];
+    w.evT = new hipEvent_t[w.nblk + 1]; w.evC = new hipEvent_t[w.nblk + 1];
     for (int i = 0; i <= w.nblk; ++i) {
         if (hipEventCreateWithFlags(&w.evP[i], hipEventDisableTiming) != hipSuccess) return -1;
         if (hipEventCreateWithFlags(&w.evU[i], hipEventDisableTiming) != hipSuccess) return -1;
+        if (hipEventCreateWithFlags(&w.evT[i], hipEventDisableTiming) != hipSuccess) return -1;
+        if (hipEventCreateWithFlags(&w.evC[i], hipEventDisableTiming) != hipSuccess) return -1;
     }
     if (hipMalloc((void**)&w.linv, (size_t)w.nblk * tile * sizeof(double)) != hipSuccess) return -1;
     if (hipMalloc((void**)&w.y, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
@@ -759,7 +682,6 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(DG_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
     w.sy0 = new hipEvent_t[w.nblk]; w.sy1 = new hipEvent_t[w.nblk]; w.sy_flops = new double[w.nblk];
-    if (const char* e = getenv("BSFM_PAIR_MIN_T")) w.pair_min_t = std::max(4, atoi(e));
     for (int i = 0; i < w.nblk; ++i) { (void)hipEventCreate(&w.sy0[i]); (void)hipEventCreate(&w.sy1[i]); }
     if (getenv("BSFM_DEBUG_DIAG")) { (void)hipMalloc((void**)&w.dbg, 8 * sizeof(long long)); }
     if (backend == 1) {
@@ -803,58 +725,39 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
     const size_t lds_bytes = 2 * 128 * GEMM_LDS_STRIDE * sizeof(double);
     (void)hipMemsetAsync(w.etmp, 0, (size_t)ld * sizeof(double), st);
     (void)hipMemcpyAsync(w.etmp, E, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
-    // Lookahead schedule on two streams (st = panel stream, s2 = update stream):
-    //   st : [first trailing column of step k] -> diag(k+1) -> trsm(k+1)            (serial critical path)
-    //   s2 : [rest of the trailing update of step k], needs panel k only            (the MFMA bulk)
-    // The compact panel is double-buffered (k & 1): trsm(k+1) may run while the bulk of step k still reads panel k.
+    // Lookahead schedule on three streams.  With L = the factor, P_a = tile (k+1+a, k) of panel k:
+    //   st (chain) : diag(k) -> P_0 = S_{k+1,k} inv(L_kk)^T -> S_{k+1,k+1} -= P_0 P_0^T -> diag(k+1) ...
+    //                the serial critical path touches only ONE tile of the panel and ONE tile of the next column;
+    //   sd (side)  : the other panel tiles P_1.. (+ y_k of the fused forward substitution), then the rest of the first
+    //                trailing column S_{k+1+a,k+1} -= P_a P_0^T (+ E -= P y_k): runs while diag(k+1) is busy;
+    //   s2 (bulk)  : S_ij -= P_a P_b^T for the columns past k+1, needs the whole panel k      (the MFMA bulk).
+    // The compact panel copies live in a ring of 4 buffers (k & 3): panel k+1 is written while the bulk still reads k.
     const size_t pstride = std::max<size_t>(1, (size_t)(w.nblk - 1)) * POTRF_NB * POTRF_NB;
     const size_t diag_lds = DG_LDS_DOUBLES * sizeof(double);
     const size_t lds64 = (64 + 128) * G64_STRIDE * sizeof(double);
+    const size_t tl = (size_t)POTRF_NB * POTRF_NB;
+    const double tile_flops = 2.0 * POTRF_NB * POTRF_NB * POTRF_NB;
+    auto panel_of = [&](int k) { return w.panel + (size_t)(k & 3) * pstride; };
     (void)hipEventRecord(w.evU[w.nblk], st);                 // everything queued before the solve (S, E ready)
     (void)hipStreamWaitEvent(w.s2, w.evU[w.nblk], 0);
+    (void)hipStreamWaitEvent(w.sd, w.evU[w.nblk], 0);
     hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, 0, n, w.linv, d_info, w.dbg);
-    if (nblk > 1)
-        hipLaunchKernelGGL(k_trsm_panel64, dim3(2 * (nblk - 1) + 1), dim3(256), lds64, st, S, ld, 0, w.linv, w.panel,
-                           2 * (nblk - 1), w.etmp, w.y);
-    else
-        hipLaunchKernelGGL(k_fwd_last, dim3(1), dim3(256), 0, st, w.linv, w.etmp, w.y);
-    (void)hipEventRecord(w.evP[0], st);
-    const double tile_flops = 2.0 * POTRF_NB * POTRF_NB * POTRF_NB;
-    int last_bulk = -1;                  // index of the evU event of the most recent bulk launch
-    auto panel_of = [&](int k) { return w.panel + (size_t)(k & 3) * pstride; };
-    auto chain_panel = [&](int k1, int Tbelow) {   // diag(k1) and the panel below it (Tbelow tile rows), records evP[k1]
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, k1, n, w.linv, d_info, w.dbg);
-        if (Tbelow > 0)
-            hipLaunchKernelGGL(k_trsm_panel64, dim3(2 * Tbelow + 1), dim3(256), lds64, st, S, ld, k1,
-                               w.linv + (size_t)k1 * POTRF_NB * POTRF_NB, panel_of(k1), 2 * Tbelow, w.etmp, w.y);
-        else   // last tile: no panel below it, only its forward-substitution solve
-            hipLaunchKernelGGL(k_fwd_last, dim3(1), dim3(256), 0, st, w.linv + (size_t)k1 * POTRF_NB * POTRF_NB,
-                               w.etmp + (size_t)k1 * POTRF_NB, w.y + (size_t)k1 * POTRF_NB);
-        (void)hipEventRecord(w.evP[k1], st);
-    };
-    for (int k = 0; k + 1 < nblk;) {
-        const int T = nblk - k - 1;
-        if (T > w.pair_min_t) {
-            // bulk-bound regime: panels k and k+1 go into the trailing matrix in ONE rank-256 pass
-            if (last_bulk >= 0) (void)hipStreamWaitEvent(st, w.evU[last_bulk], 0);
-            hipLaunchKernelGGL(k_syrk_col64, dim3(3 * T), dim3(256), lds64, st, S, ld, k, panel_of(k), 2 * T, w.etmp, w.y);
-            chain_panel(k + 1, T - 1);
-            (void)hipStreamWaitEvent(w.s2, w.evP[k + 1], 0);
-            const int T2 = T - 2;
-            (void)hipEventRecord(w.sy0[w.sy_used], w.s2);
-            hipLaunchKernelGGL(k_syrk_update2, dim3(T2 * (T2 + 1) / 2), dim3(512), lds_bytes, w.s2, S, ld, k, panel_of(k), panel_of(k + 1));
-            (void)hipEventRecord(w.sy1[w.sy_used], w.s2);
-            w.sy_flops[w.sy_used++] = 2.0 * tile_flops * (T2 * (T2 + 1) / 2);
-            (void)hipEventRecord(w.evU[k + 1], w.s2);
-            last_bulk = k + 1;
-            hipLaunchKernelGGL(k_syrk_col64x2, dim3(3 * (T - 1)), dim3(256), lds64, st, S, ld, k, panel_of(k), panel_of(k + 1),
-                               2 * (T - 1), w.etmp, w.y);
-            chain_panel(k + 2, T - 2);
-            k += 2;
-            continue;
-        }
+    for (int k = 0; k + 1 < nblk; ++k) {
+        const int T = nblk - k - 1;                          // tile rows below the diagonal tile k
         double* pk = panel_of(k);
-        // update stream: bulk of step k
+        const double* Lk = w.linv + (size_t)k * tl;
+        // chain: first panel tile (its column k was completed by the side stream of step k-1)
+        if (k > 0) (void)hipStreamWaitEvent(st, w.evC[k - 1], 0);
+        hipLaunchKernelGGL(k_trsm_panel64, dim3(2), dim3(256), lds64, st, S, ld, k, Lk, pk, 0, 2, w.etmp, w.y);
+        (void)hipEventRecord(w.evT[k], st);
+        // side: rest of the panel and y_k (the extra workgroup), then the rest of the first trailing column
+        (void)hipStreamWaitEvent(w.sd, w.evT[k], 0);
+        hipLaunchKernelGGL(k_trsm_panel64, dim3(2 * (T - 1) + 1), dim3(256), lds64, w.sd, S, ld, k, Lk, pk, 1, 2 * (T - 1), w.etmp, w.y);
+        (void)hipEventRecord(w.evP[k], w.sd);
+        if (k > 0) (void)hipStreamWaitEvent(w.sd, w.evU[k - 1], 0);   // column k+1 was last written by the bulk of step k-1
+        hipLaunchKernelGGL(k_syrk_col64, dim3(2 * (T - 1) + T), dim3(256), lds64, w.sd, S, ld, k, pk, 1, 2 * (T - 1), w.etmp, w.y);
+        (void)hipEventRecord(w.evC[k], w.sd);
+        // bulk
         (void)hipStreamWaitEvent(w.s2, w.evP[k], 0);
         if (T > 1) {
             (void)hipEventRecord(w.sy0[w.sy_used], w.s2);
@@ -862,15 +765,16 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
             (void)hipEventRecord(w.sy1[w.sy_used], w.s2);
             w.sy_flops[w.sy_used++] = tile_flops * (T * (T - 1) / 2);
         }
-        // panel stream: first trailing column of step k, then panel k+1
-        if (last_bulk >= 0) (void)hipStreamWaitEvent(st, w.evU[last_bulk], 0);   // column k+1 was last written by that launch
         (void)hipEventRecord(w.evU[k], w.s2);
-        last_bulk = k;
-        hipLaunchKernelGGL(k_syrk_col64, dim3(3 * T), dim3(256), lds64, st, S, ld, k, pk, 2 * T, w.etmp, w.y);
-        chain_panel(k + 1, T - 1);
-        ++k;
+        // chain: next diagonal tile
+        if (k > 0) (void)hipStreamWaitEvent(st, w.evU[k - 1], 0);
+        hipLaunchKernelGGL(k_syrk_col64, dim3(2), dim3(256), lds64, st, S, ld, k, pk, 0, 2, w.etmp, w.y);
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, k + 1, n, w.linv, d_info, w.dbg);
     }
-    if (last_bulk >= 0) (void)hipStreamWaitEvent(st, w.evU[last_bulk], 0);
+    // y of the last tile: E_last is final once the side stream has drained
+    if (nblk > 1) { (void)hipStreamWaitEvent(st, w.evC[nblk - 2], 0); (void)hipStreamWaitEvent(st, w.evU[nblk - 2], 0); }
+    hipLaunchKernelGGL(k_fwd_last, dim3(1), dim3(256), 0, st, w.linv + (size_t)(nblk - 1) * tl,
+                       w.etmp + (size_t)(nblk - 1) * POTRF_NB, w.y + (size_t)(nblk - 1) * POTRF_NB);
     // persistent backward substitution: all nblk workgroups must be resident (one per tile column)
     (void)hipMemsetAsync(w.bflags, 0, (size_t)(w.nblk + 1) * sizeof(int), st);
     hipLaunchKernelGGL(k_bwd_persistent, dim3(nblk), dim3(256), 0, st, S, ld, nblk, w.linv, w.y, w.xs, w.bflags, w.bflags + w.nblk);

@@ -81,6 +81,12 @@ struct bsfm_problem {
     int ntriples = 0, ntasks = 0, nblk = 0;
     int2* d_triples = nullptr; SchurTask* d_tasks = nullptr; int* d_tri_pt = nullptr; int schur_v1 = 0;
     int *d_blk_j = nullptr, *d_blk_k = nullptr, *d_blk_task0 = nullptr;
+    // multi-GPU exchange of the reduced camera system: the UNION over ranks of the non-empty blocks S_jk (j <= k),
+    // one cnp x cnp sum per block, is what crosses xGMI -- not the dense (9m)^2 matrix
+    std::vector<int> h_blk_j, h_blk_k;
+    int ngblk = -1;                       // -1: union not exchanged yet
+    int *d_gidx = nullptr, *d_gblk_j = nullptr, *d_gblk_k = nullptr;
+    double* d_G = nullptr;
     // host
     double* h_scal = nullptr; int* h_flags = nullptr;   // pinned
     std::vector<double> h_Rinit;
@@ -102,9 +108,10 @@ void free_all(bsfm_problem* pb)
 {
     void* ptrs[] = { pb->d_x, pb->d_Rinit, pb->d_finit, pb->d_obs_cam, pb->d_obs_pt, pb->d_rowptr, pb->d_camptr,
                      pb->d_camobs, pb->d_campos, pb->d_cam_pt, pb->d_Jc, pb->d_ccon, pb->d_pcon, pb->d_cval, pb->d_cw, pb->d_pval, pb->d_p, pb->d_pdp,
-                     pb->d_dp, pb->d_camtab, pb->d_camtab_trial, pb->d_e, pb->d_hx, pb->d_J, pb->d_U, pb->d_ea,
+                     pb->d_dp, pb->d_camtab, pb->d_camtab_trial, pb->d_e, pb->d_hx, pb->d_J, pb->d_U,
                      pb->d_V, pb->d_Vinv, pb->d_eb, pb->d_S, pb->d_E, pb->d_partials, pb->d_red, pb->d_scal,
-                     pb->d_flags, pb->d_triples, pb->d_tri_pt, pb->d_tasks, pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0 };
+                     pb->d_flags, pb->d_triples, pb->d_tri_pt, pb->d_tasks, pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0,
+                     pb->d_gidx, pb->d_gblk_j, pb->d_gblk_k, pb->d_G };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (pb->h_scal) (void)hipHostFree(pb->h_scal);
     if (pb->h_flags) (void)hipHostFree(pb->h_flags);
@@ -178,6 +185,7 @@ int build_schur_structure(bsfm_problem* pb, const bsfm_problem_desc_t* d, const 
     }
     blk_task0[nblk] = (int)tasks.size();
     pb->ntriples = (int)total; pb->ntasks = (int)tasks.size(); pb->nblk = nblk;
+    pb->h_blk_j = blk_j; pb->h_blk_k = blk_k;
     HIP_OK(dmalloc(&pb->d_triples, total)); HIP_OK(dmalloc(&pb->d_tasks, tasks.size()));
     HIP_OK(dmalloc(&pb->d_blk_j, nblk)); HIP_OK(dmalloc(&pb->d_blk_k, nblk)); HIP_OK(dmalloc(&pb->d_blk_task0, nblk + 1));
     HIP_OK(dmalloc(&pb->d_partials, tasks.size() * (size_t)pb->cnp * pb->cnp));
@@ -308,14 +316,56 @@ int compute_normal_blocks(bsfm_problem* pb)
     DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_cam_blocks<C>), dim3(P.m), dim3(256), 0, pb->stream, P, pb->d_e));
     ph_end(pb, PH_CAMBLK);
     if (pb->world > 1) {   // U and ea are sums over ALL points: exchange step 1, 90*m doubles
-        if (allreduce_dev(pb, pb->d_U, (size_t)P.m * cnp * cnp, 0)) return BSFM_ERROR;
-        if (allreduce_dev(pb, pb->d_ea, (size_t)P.m * cnp, 0)) return BSFM_ERROR;
+        if (allreduce_dev(pb, pb->d_U, (size_t)P.m * cnp * cnp + (size_t)P.m * cnp, 0)) return BSFM_ERROR;   // ea follows U
     }
     if (P.ccon)
         hipLaunchKernelGGL(k_cam_constraints, dim3(grid_for((size_t)P.m * cnp, 256)), dim3(256), 0, pb->stream, P, pb->d_p);
     ph_begin(pb, PH_PTBLK);
     if (P.n > 0) DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_point_blocks<C>), dim3(grid_for(P.n, 256)), dim3(256), 0, pb->stream, P, pb->d_e, pbpts));
     ph_end(pb, PH_PTBLK);
+    return 0;
+}
+
+// Union over ranks of the non-empty reduced-camera blocks.  The hook only sums, so the all-gather is a sum of
+// disjoint segments: rank r writes key+1 of its blocks into segment r of a world x maxcount buffer (0 = empty slot).
+int exchange_block_union(bsfm_problem* pb)
+{
+    const int m = pb->P.m;
+    double cnt = (double)pb->nblk;
+    if (allreduce_host(pb, &cnt, 1, 1)) return BSFM_ERROR;
+    const size_t maxcnt = (size_t)cnt, total = maxcnt * (size_t)pb->world;
+    std::vector<double> seg(std::max<size_t>(total, 1), 0.0);
+    for (int b = 0; b < pb->nblk; ++b)
+        seg[(size_t)pb->rank * maxcnt + b] = (double)((long long)pb->h_blk_j[b] * m + pb->h_blk_k[b] + 1);
+    double* dseg = nullptr;
+    HIP_OK(dmalloc(&dseg, total));
+    HIP_OK(hipMemcpy(dseg, seg.data(), total * sizeof(double), hipMemcpyHostToDevice));
+    if (total && allreduce_dev(pb, dseg, total, 0)) { (void)hipFree(dseg); return BSFM_ERROR; }
+    HIP_OK(hipMemcpy(seg.data(), dseg, total * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(dseg);
+    std::vector<long long> keys;
+    keys.reserve(total);
+    for (size_t q = 0; q < total; ++q) if (seg[q] > 0.5) keys.push_back((long long)(seg[q] + 0.5) - 1);
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    const int ng = (int)keys.size();
+    std::vector<int> gj(ng), gk(ng), gidx(pb->nblk);
+    for (int g = 0; g < ng; ++g) { gj[g] = (int)(keys[g] / m); gk[g] = (int)(keys[g] % m); }
+    for (int b = 0; b < pb->nblk; ++b) {
+        const long long key = (long long)pb->h_blk_j[b] * m + pb->h_blk_k[b];
+        gidx[b] = (int)(std::lower_bound(keys.begin(), keys.end(), key) - keys.begin());
+    }
+    HIP_OK(dmalloc(&pb->d_gidx, (size_t)pb->nblk)); HIP_OK(dmalloc(&pb->d_gblk_j, (size_t)ng)); HIP_OK(dmalloc(&pb->d_gblk_k, (size_t)ng));
+    HIP_OK(dmalloc(&pb->d_G, (size_t)ng * pb->cnp * pb->cnp + (size_t)pb->ld));     // + tail: this rank's part of E
+    if (pb->nblk) HIP_OK(hipMemcpy(pb->d_gidx, gidx.data(), (size_t)pb->nblk * sizeof(int), hipMemcpyHostToDevice));
+    if (ng) {
+        HIP_OK(hipMemcpy(pb->d_gblk_j, gj.data(), (size_t)ng * sizeof(int), hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(pb->d_gblk_k, gk.data(), (size_t)ng * sizeof(int), hipMemcpyHostToDevice));
+    }
+    pb->ngblk = ng;
+    if (pb->opt.verbose >= 2)
+        printf("[bsfm] rank %d: %d local / %d global reduced-camera blocks, %.1f MB per exchange (dense S: %.1f MB)\n", pb->rank,
+               pb->nblk, ng, ng * pb->cnp * pb->cnp * 8e-6, (double)pb->ld * pb->ld * 8e-6);
     return 0;
 }
 
@@ -326,7 +376,10 @@ int compute_schur(bsfm_problem* pb, double mu)
     DevProblem& P = pb->P;
     const int mm = P.m - P.mcon;
     const int lead = pb->rank == 0 ? 1 : 0;
+    const bool packed = pb->world > 1 && pb->allreduce;
+    if (packed && pb->ngblk < 0 && exchange_block_union(pb)) return BSFM_ERROR;
     (void)hipMemsetAsync(pb->d_S, 0, (size_t)pb->ld * pb->ld * sizeof(double), pb->stream);
+    if (packed) (void)hipMemsetAsync(pb->d_G, 0, ((size_t)pb->ngblk * cnp * cnp + (size_t)pb->ld) * sizeof(double), pb->stream);
     if (pb->ntasks > 0) {
         if (pb->schur_v1) {
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks<C>), dim3((pb->ntasks + 3) / 4), dim3(256), 0, pb->stream,
@@ -335,19 +388,35 @@ int compute_schur(bsfm_problem* pb, double mu)
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks_v2<C>), dim3((pb->ntasks + 3) / 4), dim3(256), 0, pb->stream,
                                                   P, pb->d_tasks, pb->ntasks, pb->d_triples, pb->d_tri_pt, pb->d_partials));
         }
-        DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_assemble<C>), dim3(pb->nblk), dim3(128), 0, pb->stream, pb->nblk,
-                                              pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0, pb->d_partials, pb->d_U, mu, lead,
-                                              P.mcon, pb->d_S, pb->ld));
+        if (packed) {
+            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_pack<C>), dim3(pb->nblk), dim3(128), 0, pb->stream, pb->nblk,
+                                                  pb->d_blk_task0, pb->d_partials, pb->d_gidx, pb->d_G));
+        } else {
+            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_assemble<C>), dim3(pb->nblk), dim3(128), 0, pb->stream, pb->nblk,
+                                                  pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0, pb->d_partials, pb->d_U, mu,
+                                                  P.mcon, pb->d_S, pb->ld));
+        }
     }
-    if (lead && mm > 0)
+    if (packed) {
+        // exchange step 2: the block sums of the union structure; U was already summed over ranks, so every
+        // rank then assembles the SAME S = [j==k](U_j + mu I) - G_jk and solves it redundantly (no broadcast of the step)
+        double* Etail = pb->d_G + (size_t)pb->ngblk * cnp * cnp;
+        if (mm > 0)
+            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_rhs<C>), dim3(mm), dim3(256), 0, pb->stream, P, lead, Etail));
+        if (allreduce_dev(pb, pb->d_G, (size_t)pb->ngblk * cnp * cnp + (size_t)pb->Sdim, 0)) return BSFM_ERROR;
+        (void)hipMemcpyAsync(pb->d_E, Etail, (size_t)pb->Sdim * sizeof(double), hipMemcpyDeviceToDevice, pb->stream);
+        if (mm > 0)
+            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_diag_fill<C>), dim3(mm), dim3(128), 0, pb->stream, P.m, P.mcon,
+                                                  (const int*)nullptr, pb->d_U, mu, pb->d_S, pb->ld));
+        if (pb->ngblk > 0)
+            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_unpack<C>), dim3(pb->ngblk), dim3(128), 0, pb->stream, pb->ngblk,
+                                                  pb->d_gblk_j, pb->d_gblk_k, pb->d_G, pb->d_U, mu, P.mcon, pb->d_S, pb->ld));
+    } else if (mm > 0) {
         DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_diag_fill<C>), dim3(mm), dim3(128), 0, pb->stream, P.m, P.mcon,
                                               pb->d_camptr, pb->d_U, mu, pb->d_S, pb->ld));
-    if (mm > 0)
-        DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_rhs<C>), dim3(mm), dim3(256), 0, pb->stream, P, lead, pb->d_E));
-    if (pb->world > 1) {   // exchange step 2: the reduced camera system
-        if (allreduce_dev(pb, pb->d_S, (size_t)pb->ld * pb->ld, 0)) return BSFM_ERROR;
-        if (allreduce_dev(pb, pb->d_E, (size_t)pb->Sdim, 0)) return BSFM_ERROR;
     }
+    if (!packed && mm > 0)
+        DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_rhs<C>), dim3(mm), dim3(256), 0, pb->stream, P, lead, pb->d_E));
     return 0;
 }
 
@@ -436,7 +505,7 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     DM(pb->d_p, pb->nvars_local); DM(pb->d_pdp, pb->nvars_local); DM(pb->d_dp, pb->nvars_local);
     DM(pb->d_camtab, (size_t)m * CT_STRIDE); DM(pb->d_camtab_trial, (size_t)m * CT_STRIDE);
     DM(pb->d_e, 2 * (size_t)nvis); DM(pb->d_hx, 2 * (size_t)nvis);
-    DM(pb->d_J, (size_t)nvis * P.js); DM(pb->d_Jc, (size_t)nvis * P.js); DM(pb->d_campos, nvis); DM(pb->d_cam_pt, nvis); DM(pb->d_U, (size_t)m * cnp * cnp); DM(pb->d_ea, (size_t)m * cnp);
+    DM(pb->d_J, (size_t)nvis * P.js); DM(pb->d_Jc, (size_t)nvis * P.js); DM(pb->d_campos, nvis); DM(pb->d_cam_pt, nvis); DM(pb->d_U, (size_t)m * cnp * cnp + (size_t)m * cnp); pb->d_ea = pb->d_U + (size_t)m * cnp * cnp;   /* one buffer: one exchange */
     DM(pb->d_V, 6 * (size_t)n); DM(pb->d_Vinv, 6 * (size_t)n); DM(pb->d_eb, 3 * (size_t)n);
     DM(pb->d_S, (size_t)pb->ld * pb->ld); DM(pb->d_E, pb->ld);
     pb->red_blocks = std::max(grid_for(nvis, RES_BLOCK), std::max(grid_for(n, 256), 1024));

@@ -1,0 +1,106 @@
+"""Multi-GPU exchange step through the real library on ONE GPU: two processes share cuda:0, each owns a
+point shard, and the all-reduce hook sums device buffers across the two processes (gloo on a host copy -- RCCL refuses
+two ranks on the same device; bench.py uses RCCL with one rank per GPU, the hook contract is identical).
+The packed block-union exchange (solver.hip:exchange_block_union / k_schur_pack / k_schur_unpack) must reproduce the
+single-process LM trajectory up to summation order."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+
+from bench import shard_points  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+ITERS = 6
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _scene(B):
+    m, n = 14, 700
+    s = B.synth_ba(m, n, 5)
+    keep = np.ones(len(s["colidx"]), bool)
+    keep[np.arange(0, len(keep), 9)] = False          # ragged shards
+    rows = np.repeat(np.arange(n), 5)
+    cnt = np.bincount(rows[keep], minlength=n)
+    rowptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    return dict(m=m, n=n, rowptr=rowptr, colidx=s["colidx"][keep].copy(),
+                proj=s["proj"].reshape(-1, 2)[keep].ravel().copy(), cams=s["cams"], pts=s["pts"])
+
+
+def _solve(B, sc, lo, hi, world, rank, hook=None, jac=None):
+    rp = (sc["rowptr"][lo:hi + 1] - sc["rowptr"][lo]).astype(np.int32)
+    k0, k1 = int(sc["rowptr"][lo]), int(sc["rowptr"][hi])
+    opt = B.default_options(jacobian=B.JAC_ANALYTIC if jac is None else jac, verbose=0, itmax=ITERS,
+                            opts=[1e-3, 0.0, 0.0, 0.0, 0.0, -1.0])
+    pb = B.Problem(hi - lo, sc["m"], rp, sc["colidx"][k0:k1], sc["proj"][2 * k0:2 * k1], sc["cams"], sc["pts"][3 * lo:3 * hi],
+                   options=opt, world_size=world, rank=rank, nvis_global=int(sc["rowptr"][-1]),
+                   nvars_global=sc["m"] * 9 + 3 * sc["n"])
+    if hook is not None:
+        pb.set_allreduce(hook)
+    assert pb.lm_begin() == 0
+    pb.lm_iterate(ITERS)
+    rc, info = pb.lm_finish()
+    p = pb.download(want_cams=False)[0]
+    pb.close()
+    return p, info
+
+
+def _worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    import bundler_sfm_amd as B
+    sc = _scene(B)
+    lo, hi = shard_points(sc["rowptr"], world, rank)
+    calls = []
+
+    def hook(dev_ptr, count, op, _ctx):
+        class _Buf:
+            __cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (dev_ptr, False), "version": 2}
+        t = torch.as_tensor(_Buf(), device="cuda:0")
+        c = t.cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
+        t.copy_(c)
+        torch.cuda.synchronize()
+        calls.append(count)
+        return 0
+
+    p, info = _solve(B, sc, lo, hi, world, rank, hook)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), p=p, info=info, lo=lo, hi=hi, max_count=max(calls), ncalls=len(calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_match_single_rank(tmp_path):
+    import torch
+    import torch.multiprocessing as mp
+    import bundler_sfm_amd as B
+    sc = _scene(B)
+    p1, info1 = _solve(B, sc, 0, sc["n"], 1, 0)
+    assert info1[1] < 0.05 * info1[0]                      # the LM run actually converged somewhere
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r = [np.load(tmp_path / f"rank{k}.npz") for k in (0, 1)]
+    m = sc["m"]
+    for k in (0, 1):
+        # every rank ends with the same cameras (replicated) and the global cost
+        assert abs(r[k]["info"][1] - info1[1]) <= 1e-9 * info1[1]
+        assert r[k]["info"][5] == info1[5]
+        cam = r[k]["p"][:9 * m]
+        assert np.abs(cam - p1[:9 * m]).max() <= 1e-8 * np.abs(p1[:9 * m]).max()
+        lo, hi = int(r[k]["lo"]), int(r[k]["hi"])
+        pts = r[k]["p"][9 * m:]
+        assert np.abs(pts - p1[9 * m + 3 * lo:9 * m + 3 * hi]).max() <= 1e-8
+        # the exchange is the packed block union (<= lower triangle: m(m+1)/2 blocks of 81), never the dense (9m)^2 matrix
+        assert int(r[k]["max_count"]) <= max(81 * m * (m + 1) // 2, 81 * m)
+    assert np.array_equal(r[0]["p"][:9 * m], r[1]["p"][:9 * m])      # bitwise identical replicas
