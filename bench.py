@@ -61,10 +61,10 @@ def shard_points(rowptr, world, rank):
 def syrk_flops_per_launch(sdim):
     """Algorithmic FP64 flop of the timed trailing-update launches of one factorisation (mirrors the schedule in
     csrc/potrf.hip.h:potrf_solve).  One 128x128 tile x one 128-deep panel = 2*128^3 flop; step k launches k_syrk_update
-    on the T(T-1)/2 lower tiles of the columns past k+1 (T = nblk-k-1).  The first trailing column of a step is
-    updated by k_syrk_col64 on the chain/side streams and is not part of the timed launches."""
+    on the T(T-1)/2 - 1 lower tiles of the columns past k+1 (T = nblk-k-1; the tile S_{k+2,k+2} and the first trailing
+    column belong to the chain/side streams and are not part of the timed launches)."""
     nblk = (sdim + NB - 1) // NB
-    tiles = [t * (t - 1) // 2 for t in range(nblk - 1, 1, -1)]
+    tiles = [t * (t - 1) // 2 - 1 for t in range(nblk - 1, 2, -1)]
     return 2.0 * NB ** 3 * sum(tiles) / max(len(tiles), 1), len(tiles)
 
 

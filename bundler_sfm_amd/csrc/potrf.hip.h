@@ -223,6 +223,14 @@ __global__ __launch_bounds__(256, 1) void k_trsm_panel64(double* __restrict__ S,
         fwd_tile_solve(Linv, E + (size_t)k * POTRF_NB, y + (size_t)k * POTRF_NB, lds);
         return;
     }
+    if ((int)blockIdx.x == nwork + 1) {      // second extra workgroup: L_{k+1,k} = slot 0 of the compact panel (k_chain_tile32<0>) -> S
+        double* dst = S + ((size_t)(k + 1) * POTRF_NB) * ld + (size_t)k * POTRF_NB;
+        for (int idx = threadIdx.x; idx < POTRF_NB * POTRF_NB / 2; idx += 256) {
+            const int r = idx >> 6, c2 = (idx & 63) * 2;
+            *reinterpret_cast<double2*>(dst + (size_t)r * ld + c2) = *reinterpret_cast<const double2*>(panel + (size_t)r * POTRF_NB + c2);
+        }
+        return;
+    }
     const int tile = tile0 + (blockIdx.x >> 1), half = blockIdx.x & 1;
     double* Sik = S + ((size_t)(k + 1 + tile) * POTRF_NB + 64 * half) * ld + (size_t)k * POTRF_NB;
     double acc[8][4];
@@ -292,16 +300,119 @@ __global__ __launch_bounds__(256, 1) void k_syrk_col64(double* __restrict__ S, i
 
 // (Tried and dropped: no-return global_atomic_add_f64 of -acc instead of a load/subtract/store epilogue -- bit-identical,
 // but slower, 31.1 vs 34.8 TFLOP/s on config 3: L2 atomic throughput becomes the limit.)
+// The two single-tile products ON the serial chain, cut into 32x32 blocks so that 16 (10) compute units share one
+// 128x128x128 product and no wave issues more than 128 matrix instructions (a 64-row half per workgroup keeps one wave
+// busy for ~7 us of pure MFMA issue; here it is < 1 us and the kernel is bounded by one global-load round trip):
+//   MODE 0 (grid 16): P_0 = S_{k+1,k} inv(L_kk)^T, written to S and to slot 0 of the compact panel.  inv(L_kk) is lower
+//                     triangular: output column block bc only needs k < 32 (bc + 1);
+//   MODE 1 (grid 10): S_{k+1,k+1} -= P_0 P_0^T, lower-triangle blocks only (all the diagonal-tile kernel reads); with
+//                     prev != nullptr ALSO -= Q_1 Q_1^T, Q = panel k-1: the bulk launch of step k-1 leaves this one tile
+//                     to the chain, so the next diagonal tile never waits for the bulk launch that has just started.
+// The whole K range of both operands goes to LDS in one step (row stride 132 doubles: conflict-free A fragments).
+constexpr int T32_STRIDE = 132;
+constexpr int T32_LDS_DOUBLES = 2 * 32 * T32_STRIDE;
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void k_chain_tile32(double* __restrict__ S, int ld, int k, const double* __restrict__ Linv,
+                                                         double* __restrict__ panel, const double* __restrict__ prev)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    int br, bc;
+    if (MODE == 0) { br = blockIdx.x >> 2; bc = blockIdx.x & 3; }
+    else { const int t = blockIdx.x; br = t < 1 ? 0 : t < 3 ? 1 : t < 6 ? 2 : 3; bc = t - br * (br + 1) / 2; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = (wave >> 1) * 16, wc = (wave & 1) * 16;
+    const double* A; const double* B; int lda, K;
+    if (MODE == 0) {
+        A = S + ((size_t)(k + 1) * POTRF_NB + 32 * br) * ld + (size_t)k * POTRF_NB; lda = ld;
+        B = Linv + (size_t)(32 * bc) * POTRF_NB; K = 32 * (bc + 1);
+    } else {
+        A = panel + (size_t)(32 * br) * POTRF_NB; lda = POTRF_NB;
+        B = panel + (size_t)(32 * bc) * POTRF_NB; K = POTRF_NB;
+    }
+    double* As = lds; double* Bs = lds + 32 * T32_STRIDE;
+    double* Ct = S + ((size_t)(k + 1) * POTRF_NB + 32 * br) * ld + (size_t)(k + (MODE == 0 ? 0 : 1)) * POTRF_NB + 32 * bc;
+    double cin[4];
+    if (MODE == 1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) cin[t] = Ct[(size_t)(wr + 4 * t + (lane >> 4)) * ld + wc + (lane & 15)];
+    }
+    {   // 32 rows x K doubles per operand: thread -> (row = tid >> 3, 16-byte columns (tid & 7) + 8 q)
+        const int row = tid >> 3, c2 = (tid & 7) * 2;
+        double pa[8][2], pb[8][2];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (16 * q < K) {
+                const double2 ta = *reinterpret_cast<const double2*>(A + (size_t)row * lda + 16 * q + c2);
+                const double2 tb = *reinterpret_cast<const double2*>(B + (size_t)row * POTRF_NB + 16 * q + c2);
+                pa[q][0] = ta.x; pa[q][1] = ta.y; pb[q][0] = tb.x; pb[q][1] = tb.y;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (16 * q < K) {
+                *reinterpret_cast<double2*>(As + row * T32_STRIDE + 16 * q + c2) = make_double2(pa[q][0], pa[q][1]);
+                *reinterpret_cast<double2*>(Bs + row * T32_STRIDE + 16 * q + c2) = make_double2(pb[q][0], pb[q][1]);
+            }
+        }
+    }
+    double qa[8][2], qb[8][2];                  // second segment (MODE 1 with prev): fetched before the first product starts
+    const int row_s = tid >> 3, c2_s = (tid & 7) * 2;
+    if (MODE == 1 && prev) {
+        const double* A2 = prev + (size_t)POTRF_NB * POTRF_NB + (size_t)(32 * br) * POTRF_NB;
+        const double* B2 = prev + (size_t)POTRF_NB * POTRF_NB + (size_t)(32 * bc) * POTRF_NB;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double2 ta = *reinterpret_cast<const double2*>(A2 + (size_t)row_s * POTRF_NB + 16 * q + c2_s);
+            const double2 tb = *reinterpret_cast<const double2*>(B2 + (size_t)row_s * POTRF_NB + 16 * q + c2_s);
+            qa[q][0] = ta.x; qa[q][1] = ta.y; qb[q][0] = tb.x; qb[q][1] = tb.y;
+        }
+    }
+    __syncthreads();
+    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+    const double* ap = As + (wr + (lane & 3)) * T32_STRIDE + (lane >> 4);
+    const double* bp = Bs + (wc + (lane & 15)) * T32_STRIDE + (lane >> 4);
+    for (int kk = 0; kk < K; kk += 4) {
+        const double b = bp[kk];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(ap[4 * t * T32_STRIDE + kk], b, acc[t], 0, 0, 0);
+    }
+    if (MODE == 1 && prev) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            *reinterpret_cast<double2*>(As + row_s * T32_STRIDE + 16 * q + c2_s) = make_double2(qa[q][0], qa[q][1]);
+            *reinterpret_cast<double2*>(Bs + row_s * T32_STRIDE + 16 * q + c2_s) = make_double2(qb[q][0], qb[q][1]);
+        }
+        __syncthreads();
+        for (int kk = 0; kk < POTRF_NB; kk += 4) {
+            const double b = bp[kk];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(ap[4 * t * T32_STRIDE + kk], b, acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = wr + 4 * t + (lane >> 4), col = wc + (lane & 15);
+        if (MODE == 0) {
+            // NOT written back to S here: the other column blocks of this row block still read the tile (in-place hazard
+            // across workgroups); the side stream's panel kernel copies slot 0 of the compact panel to S afterwards
+            panel[(size_t)(32 * br + row) * POTRF_NB + 32 * bc + col] = acc[t];
+        } else {
+            Ct[(size_t)row * ld + col] = cin[t] - acc[t];
+        }
+    }
+}
+
 // Trailing update: S_ij -= P_a P_b^T for k < j <= i (a = i-k-1, b = j-k-1), one tile per workgroup.
 // part 1 = only the first trailing column (b == 0, grid T): the tiles the NEXT panel needs (lookahead stream);
-// part 2 = every other tile (b >= 1, grid T(T-1)/2): the bulk, on the update stream.
+// part 2 = every other tile (b >= 1) except S_{k+2,k+2}, grid T(T-1)/2 - 1: the bulk, on the update stream.
 __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __restrict__ S, int ld, int k, const double* __restrict__ panel, int part)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int a, b;
     if (part == 1) { a = blockIdx.x; b = 0; }
     else {
-        const int t = blockIdx.x;
+        const int t = blockIdx.x + 1;      // tile 0 of the triangle = S_{k+2,k+2} is left to the chain (k_chain_tile32<1>)
         a = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
         while ((a + 1) * (a + 2) / 2 <= t) ++a;
         while (a * (a + 1) / 2 > t) --a;
@@ -681,6 +792,8 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
     (void)hipEventCreate(&w.ev0); (void)hipEventCreate(&w.ev1);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(DG_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_tile32<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(T32_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_tile32<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(T32_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
     w.sy0 = new hipEvent_t[w.nblk]; w.sy1 = new hipEvent_t[w.nblk]; w.sy_flops = new double[w.nblk];
     for (int i = 0; i < w.nblk; ++i) { (void)hipEventCreate(&w.sy0[i]); (void)hipEventCreate(&w.sy1[i]); }
     if (getenv("BSFM_DEBUG_DIAG")) { (void)hipMalloc((void**)&w.dbg, 8 * sizeof(long long)); }
@@ -735,6 +848,7 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
     const size_t pstride = std::max<size_t>(1, (size_t)(w.nblk - 1)) * POTRF_NB * POTRF_NB;
     const size_t diag_lds = DG_LDS_DOUBLES * sizeof(double);
     const size_t lds64 = (64 + 128) * G64_STRIDE * sizeof(double);
+    const size_t lds32 = T32_LDS_DOUBLES * sizeof(double);
     const size_t tl = (size_t)POTRF_NB * POTRF_NB;
     const double tile_flops = 2.0 * POTRF_NB * POTRF_NB * POTRF_NB;
     auto panel_of = [&](int k) { return w.panel + (size_t)(k & 3) * pstride; };
@@ -748,27 +862,29 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         const double* Lk = w.linv + (size_t)k * tl;
         // chain: first panel tile (its column k was completed by the side stream of step k-1)
         if (k > 0) (void)hipStreamWaitEvent(st, w.evC[k - 1], 0);
-        hipLaunchKernelGGL(k_trsm_panel64, dim3(2), dim3(256), lds64, st, S, ld, k, Lk, pk, 0, 2, w.etmp, w.y);
+        hipLaunchKernelGGL(k_chain_tile32<0>, dim3(16), dim3(256), lds32, st, S, ld, k, Lk, pk, (const double*)nullptr);
         (void)hipEventRecord(w.evT[k], st);
         // side: rest of the panel and y_k (the extra workgroup), then the rest of the first trailing column
         (void)hipStreamWaitEvent(w.sd, w.evT[k], 0);
-        hipLaunchKernelGGL(k_trsm_panel64, dim3(2 * (T - 1) + 1), dim3(256), lds64, w.sd, S, ld, k, Lk, pk, 1, 2 * (T - 1), w.etmp, w.y);
+        hipLaunchKernelGGL(k_trsm_panel64, dim3(2 * (T - 1) + 2), dim3(256), lds64, w.sd, S, ld, k, Lk, pk, 1, 2 * (T - 1), w.etmp, w.y);
         (void)hipEventRecord(w.evP[k], w.sd);
         if (k > 0) (void)hipStreamWaitEvent(w.sd, w.evU[k - 1], 0);   // column k+1 was last written by the bulk of step k-1
         hipLaunchKernelGGL(k_syrk_col64, dim3(2 * (T - 1) + T), dim3(256), lds64, w.sd, S, ld, k, pk, 1, 2 * (T - 1), w.etmp, w.y);
         (void)hipEventRecord(w.evC[k], w.sd);
         // bulk
         (void)hipStreamWaitEvent(w.s2, w.evP[k], 0);
-        if (T > 1) {
+        if (T > 2) {
             (void)hipEventRecord(w.sy0[w.sy_used], w.s2);
-            hipLaunchKernelGGL(k_syrk_update, dim3(T * (T - 1) / 2), dim3(512), lds_bytes, w.s2, S, ld, k, pk, 2);
+            hipLaunchKernelGGL(k_syrk_update, dim3(T * (T - 1) / 2 - 1), dim3(512), lds_bytes, w.s2, S, ld, k, pk, 2);
             (void)hipEventRecord(w.sy1[w.sy_used], w.s2);
-            w.sy_flops[w.sy_used++] = tile_flops * (T * (T - 1) / 2);
+            w.sy_flops[w.sy_used++] = tile_flops * (T * (T - 1) / 2 - 1);
         }
         (void)hipEventRecord(w.evU[k], w.s2);
         // chain: next diagonal tile
-        if (k > 0) (void)hipStreamWaitEvent(st, w.evU[k - 1], 0);
-        hipLaunchKernelGGL(k_syrk_col64, dim3(2), dim3(256), lds64, st, S, ld, k, pk, 0, 2, w.etmp, w.y);
+        // S_{k+1,k+1} takes panels k-1 and k here; the last bulk launch that touched it is the one of step k-2
+        if (k > 1) (void)hipStreamWaitEvent(st, w.evU[k - 2], 0);
+        hipLaunchKernelGGL(k_chain_tile32<1>, dim3(10), dim3(256), lds32, st, S, ld, k, Lk, pk,
+                           k > 0 ? (const double*)panel_of(k - 1) : (const double*)nullptr);
         hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, k + 1, n, w.linv, d_info, w.dbg);
     }
     // y of the last tile: E_last is final once the side stream has drained

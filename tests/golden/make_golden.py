@@ -61,6 +61,26 @@ def ba_cases():
     print("ba_golden:", len(out), "arrays")
 
 
+def exports():
+    """Covariance-export blocks (Vout/Sout/Uout/Wout, sba_levmar.c:1633-2026) of the reference after 3 analytic-Jacobian
+    iterations: the fixture of tests/test_ba_gpu.py::test_covariance_export_matches_reference."""
+    out = {}
+    for name, c in (("s9", dict(m=8, n=60, deg=4, est=1, und=1, ncons=0, cons=0)),
+                    ("s9c", dict(m=8, n=60, deg=4, est=1, und=1, ncons=0, cons=1)),
+                    ("s7", dict(m=6, n=50, deg=3, est=1, und=0, ncons=0, cons=0))):
+        s = B.synth_ba(c["m"], c["n"], c["deg"])
+        cams = s["cams"]
+        if c["cons"]:
+            O.set_bundler_constraints(cams)
+        vm = B.dense_vmask(c["n"], c["m"], s["rowptr"], s["colidx"])
+        r = O.ref_sba(c["n"], c["m"], vm, s["proj"], cams, s["pts"], itmax=3, jac_mode=1, ncons=c["ncons"],
+                      est_focal=c["est"], undistort=c["und"], use_constraints=c["cons"], want_blocks=True)
+        for k in ("U", "V", "S", "W", "p", "info"):
+            out[f"{name}_{k}"] = r[k]
+    np.savez_compressed(os.path.join(HERE, "export_golden.npz"), **out)
+    print("export_golden:", len(out), "arrays")
+
+
 def parse_bundle(path):
     toks = open(path).read().split("\n")
     assert toks[0].startswith("# Bundle file v0.3")
@@ -176,4 +196,7 @@ def model():
 
 if __name__ == "__main__":
     assert O.have_ref(), "build oracle/_ref first (make -C oracle ref)"
-    ba_cases(); kermit(); matcher(); model()
+    only = sys.argv[1:]
+    for fn in (ba_cases, kermit, matcher, model, exports):
+        if not only or fn.__name__ in only:
+            fn()

@@ -249,3 +249,26 @@ def test_point_constraints(gpu_bsfm):
     assert abs(info[1] - q["info"][1]) <= 1e-9 * q["info"][1]
     assert np.abs(p - q["p"]).max() <= 1e-7 * np.abs(q["p"]).max()
     pb.close()
+
+
+@pytest.mark.parametrize("name", ["s9", "s9c", "s7"])
+def test_covariance_export_matches_reference(gpu_bsfm, name):
+    """run_sfm's optional Vout/Sout/Uout/Wout (sfm.h:68-86; filled by sba_levmar.c:1633-2026 at the solution,
+    undamped) against the reference's own export after the same 3 analytic-Jacobian iterations
+    (tests/golden/export_golden.npz, generated by tests/golden/make_golden.py:exports from oracle/_ref)."""
+    B = gpu_bsfm
+    X = np.load(os.path.join(os.path.dirname(__file__), "golden", "export_golden.npz"))
+    c = load_case(name)
+    m, n = c["m"], c["n"]
+    cnp = 6 + c["est"] + 2 * c["und"]
+    cams = B.copy_cameras(c["cams"]); pts = c["pts"].copy()
+    V = np.zeros((n, 3, 3)); S = np.zeros((m * cnp, m * cnp)); U = np.zeros((m, cnp, cnp)); W = np.zeros((m * cnp, 3 * n))
+    rc, info = B.run_sfm(n, m, c["ncons"], c["vm"], c["proj"], c["est"], 0, c["und"], 1, cams, pts,
+                         use_constraints=c["cons"], eps2=1e-12, Vout=V, Sout=S, Uout=U, Wout=W,
+                         options=B.default_options(jacobian=B.JAC_ANALYTIC, verbose=0, itmax=3))
+    assert rc >= 0
+    assert abs(info[1] - X[f"{name}_info"][1]) <= 1e-9 * X[f"{name}_info"][1]
+    for got, key in ((U, "U"), (V, "V"), (S, "S"), (W, "W")):
+        ref = X[f"{name}_{key}"]
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 1e-8 * np.abs(ref).max(), key
