@@ -17,7 +17,127 @@
 #include <vector>
 #include "../../include/bsfm.h"
 
+namespace {
+
+// dense vmask -> CRS: the k-th set bit in row-major order is the k-th measurement (sba_levmar.c:653-663)
+void vmask_to_crs(int n, int m, const char* vmask, std::vector<int>& rowptr, std::vector<int>& colidx)
+{
+    rowptr.assign((size_t)n + 1, 0);
+    size_t nvis = 0;
+    const size_t tot = (size_t)n * m;
+    for (size_t q = 0; q < tot; ++q) nvis += (vmask[q] != 0);
+    colidx.resize(nvis);
+    size_t k = 0;
+    for (int i = 0; i < n; ++i) {
+        rowptr[i] = (int)k;
+        const char* row = vmask + (size_t)i * m;
+        for (int j = 0; j < m; ++j) if (row[j]) colidx[k++] = j;
+    }
+    rowptr[n] = (int)k;
+}
+
+// optional covariance export at the current parameters, undamped (sba_levmar.c:1633-2026)
+void export_blocks(bsfm_problem_t* pb, int n, int mcon, int cnp, const std::vector<int>& rowptr, const std::vector<int>& colidx,
+                   double* Vout, double* Sout, double* Uout, double* Wout)
+{
+    if (!(Sout || Uout || Vout || Wout)) return;
+    const size_t nvis = colidx.size();
+    std::vector<double> J;
+    if (Wout) J.resize(nvis * (size_t)(2 * cnp + 6));
+    bsfm_eval_normal_equations(pb, 0.0, Uout, nullptr, Vout, nullptr, Wout ? J.data() : nullptr, Sout, nullptr);
+    if (Wout) {   // Wout[(j*cnp+ii)*3*n + 3*i + jj] = (A_ij^T B_ij)[ii][jj]  (sba_levmar.c:1836-1846)
+        const int js = 2 * cnp + 6;
+        for (int i = 0; i < n; ++i)
+            for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+                const int j = colidx[k];
+                const double* A = &J[(size_t)k * js]; const double* B = A + 2 * cnp;
+                for (int ii = 0; ii < cnp; ++ii)
+                    for (int jj = 0; jj < 3; ++jj)
+                        Wout[((size_t)j * cnp + ii) * 3 * n + (size_t)3 * i + jj] =
+                            (j < mcon) ? 0.0 : A[ii] * B[jj] + A[cnp + ii] * B[3 + jj];
+            }
+    }
+}
+
+}  // namespace
+
 extern "C" {
+
+int bsfm_sba_motstr_levmar(int n, int m, int mcon, char* vmask, double* p, int cnp, int pnp,
+                           double* x, double* covx, int mnp, int camera_model, const void* model_data,
+                           int itmax, int verbose, double opts[6], double info[BSFM_INFOSZ],
+                           int use_constraints, bsfm_camera_constraints_t* constraints,
+                           int use_point_constraints, bsfm_point_constraints_t* point_constraints,
+                           double* Vout, double* Sout, double* Uout, double* Wout)
+{
+    double linfo[BSFM_INFOSZ];
+    for (int i = 0; i < BSFM_INFOSZ; ++i) linfo[i] = 0.0;
+    if (!info) info = linfo;
+    auto refuse = [](const char* why) { fprintf(stderr, "[bsfm] bsfm_sba_motstr_levmar: %s; nothing was changed\n", why); return BSFM_ERROR; };
+    if (camera_model != BSFM_MODEL_SNAVELY || !model_data) return refuse("only BSFM_MODEL_SNAVELY with its data block is implemented");
+    const bsfm_snavely_model_t* md = static_cast<const bsfm_snavely_model_t*>(model_data);
+    if (pnp != 3 || mnp != 2) return refuse("pnp must be 3 and mnp 2");
+    if (covx) return refuse("measurement covariances (covx) are not implemented");
+    if (cnp != 6 + (md->est_focal_length ? 1 : 0) + (md->undistort ? 2 : 0)) return refuse("cnp does not match the model flags");
+    if (!md->R_init || (!md->est_focal_length && !md->f_init)) return refuse("model data incomplete (R_init / f_init)");
+    for (int j = 0; j < m; ++j)
+        if (p[(size_t)j * cnp + 3] != 0.0 || p[(size_t)j * cnp + 4] != 0.0 || p[(size_t)j * cnp + 5] != 0.0)
+            return refuse("the rotation increments p[j*cnp+3..5] must be zero on entry (fold them into R_init)");
+
+    std::vector<bsfm_camera_params_t> cams((size_t)m);
+    memset(cams.data(), 0, cams.size() * sizeof(bsfm_camera_params_t));
+    for (int j = 0; j < m; ++j) {
+        memcpy(cams[j].R, md->R_init + 9 * (size_t)j, 9 * sizeof(double));
+        cams[j].f = md->est_focal_length ? 1.0 : md->f_init[j];
+        if (use_constraints && constraints)
+            for (int q = 0; q < cnp; ++q) {
+                cams[j].constrained[q] = constraints[j].constrained[q];
+                cams[j].constraints[q] = constraints[j].constraints[q];
+                cams[j].weights[q] = constraints[j].weights[q];
+            }
+    }
+    std::vector<double> pcon;
+    double pweight = 0.0;
+    if (use_point_constraints && point_constraints) {
+        pcon.assign((size_t)3 * n, 0.0);
+        bool have = false;
+        for (int i = 0; i < n; ++i) {
+            if (!point_constraints[i].constrained) continue;
+            const double* c = point_constraints[i].constraints;
+            if (c[0] == 0.0 && c[1] == 0.0 && c[2] == 0.0) return refuse("a point constrained exactly to the origin cannot be expressed (zero vector = unconstrained, sfm.c:757-781)");
+            if (have && point_constraints[i].weight != pweight) return refuse("point-constraint weights must be uniform");
+            pweight = point_constraints[i].weight; have = true;
+            pcon[3 * (size_t)i] = c[0]; pcon[3 * (size_t)i + 1] = c[1]; pcon[3 * (size_t)i + 2] = c[2];
+        }
+    }
+
+    std::vector<int> rowptr, colidx;
+    vmask_to_crs(n, m, vmask, rowptr, colidx);
+    bsfm_options_t opt;
+    bsfm_default_options(&opt);
+    opt.itmax = itmax; opt.verbose = verbose;
+    if (opts) for (int q = 0; q < 6; ++q) opt.opts[q] = opts[q];
+    bsfm_problem_desc_t d;
+    memset(&d, 0, sizeof(d));
+    d.n = n; d.m = m; d.mcon = mcon;
+    d.rowptr = rowptr.data(); d.colidx = colidx.data(); d.projections = x;
+    d.est_focal_length = md->est_focal_length; d.undistort = md->undistort; d.explicit_camera_centers = md->explicit_camera_centers;
+    d.cameras = cams.data(); d.points = p + (size_t)m * cnp;
+    d.use_constraints = use_constraints && constraints; d.constraints_prescaled = 1;
+    d.use_point_constraints = !pcon.empty(); d.point_constraints = pcon.empty() ? nullptr : pcon.data();
+    d.point_constraint_weight = pweight;
+    d.p_packed = p;
+    d.world_size = 1;
+    bsfm_problem_t* pb = bsfm_problem_create(&d, &opt);
+    if (!pb) return BSFM_ERROR;
+    int rc = bsfm_lm_begin(pb);
+    if (rc == 0) bsfm_lm_iterate(pb, opt.itmax);
+    rc = bsfm_lm_finish(pb, info);
+    if (rc != BSFM_ERROR || info[5] > 0) bsfm_problem_download(pb, p, nullptr, nullptr);
+    export_blocks(pb, n, mcon, cnp, rowptr, colidx, Vout, Sout, Uout, Wout);
+    bsfm_problem_destroy(pb);
+    return rc == BSFM_ERROR ? BSFM_ERROR : (int)info[5];
+}
 
 int bsfm_run_sfm_ex(int num_pts, int num_cameras, int ncons, char* vmask, double* projections,
                     int est_focal_length, int const_focal_length, int undistort, int explicit_camera_centers,
@@ -49,20 +169,8 @@ int bsfm_run_sfm_ex(int num_pts, int num_cameras, int ncons, char* vmask, double
         }
 
     // 1. vmask -> CRS
-    std::vector<int> rowptr((size_t)num_pts + 1), colidx;
-    {
-        size_t nvis = 0;
-        const size_t tot = (size_t)num_pts * num_cameras;
-        for (size_t q = 0; q < tot; ++q) nvis += (vmask[q] != 0);
-        colidx.resize(nvis);
-        size_t k = 0;
-        for (int i = 0; i < num_pts; ++i) {
-            rowptr[i] = (int)k;
-            const char* row = vmask + (size_t)i * num_cameras;
-            for (int j = 0; j < num_cameras; ++j) if (row[j]) colidx[k++] = j;
-        }
-        rowptr[num_pts] = (int)k;
-    }
+    std::vector<int> rowptr, colidx;
+    vmask_to_crs(num_pts, num_cameras, vmask, rowptr, colidx);
 
     bsfm_problem_desc_t d;
     memset(&d, 0, sizeof(d));
@@ -89,24 +197,7 @@ int bsfm_run_sfm_ex(int num_pts, int num_cameras, int ncons, char* vmask, double
         // the reference copies the parameter vector back unconditionally (sfm.c:876-929)
         bsfm_problem_download(pb, nullptr, init_camera_params, reinterpret_cast<double*>(init_pts));
     }
-    if (Sout || Uout || Vout || Wout) {
-        const size_t nvis = colidx.size();
-        std::vector<double> J;
-        if (Wout) J.resize(nvis * (size_t)(2 * cnp + 6));
-        bsfm_eval_normal_equations(pb, 0.0, Uout, nullptr, Vout, nullptr, Wout ? J.data() : nullptr, Sout, nullptr);
-        if (Wout) {   // Wout[(j*cnp+ii)*3*n + 3*i + jj] = (A_ij^T B_ij)[ii][jj]  (sba_levmar.c:1836-1846)
-            const int js = 2 * cnp + 6;
-            for (int i = 0; i < num_pts; ++i)
-                for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-                    const int j = colidx[k];
-                    const double* A = &J[(size_t)k * js]; const double* B = A + 2 * cnp;
-                    for (int ii = 0; ii < cnp; ++ii)
-                        for (int jj = 0; jj < 3; ++jj)
-                            Wout[((size_t)j * cnp + ii) * 3 * num_pts + (size_t)3 * i + jj] =
-                                (j < ncons) ? 0.0 : A[ii] * B[jj] + A[cnp + ii] * B[3 + jj];
-                }
-        }
-    }
+    export_blocks(pb, num_pts, ncons, cnp, rowptr, colidx, Vout, Sout, Uout, Wout);
     bsfm_problem_destroy(pb);
     return rc;
 }

@@ -527,15 +527,16 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     for (int j = 0; j < m; ++j) { memcpy(&pb->h_Rinit[9 * (size_t)j], d->cameras[j].R, 9 * sizeof(double)); finit[j] = d->cameras[j].f; }
     ok = ok && up(pb->d_Rinit, pb->h_Rinit.data(), 9 * (size_t)m * sizeof(double)) && up(pb->d_finit, finit.data(), m * sizeof(double));
     std::vector<double> p;
-    pack_params(pb, d->cameras, d->points, n, p);
+    if (d->p_packed) p.assign(d->p_packed, d->p_packed + (size_t)m * cnp + (size_t)3 * n);
+    else pack_params(pb, d->cameras, d->points, n, p);
     ok = ok && up(pb->d_p, p.data(), p.size() * sizeof(double));
     if (d->use_constraints) {   // sfm.c:721-754 (note the hard-wired indices 6,7,8 of the rescaling)
         std::vector<unsigned char> con((size_t)m * cnp); std::vector<double> val((size_t)m * cnp), w((size_t)m * cnp);
         for (int j = 0; j < m; ++j) {
             double cv[9], cw[9];
             for (int q = 0; q < 9; ++q) { cv[q] = d->cameras[j].constraints[q]; cw[q] = d->cameras[j].weights[q]; }
-            if (d->est_focal_length) { cv[6] *= P.cfg.f_scale; cw[6] *= 1.0 / (P.cfg.f_scale * P.cfg.f_scale); }
-            if (d->undistort) { cv[7] *= P.cfg.k_scale; cw[7] *= 1.0 / (P.cfg.k_scale * P.cfg.k_scale);
+            if (d->est_focal_length && !d->constraints_prescaled) { cv[6] *= P.cfg.f_scale; cw[6] *= 1.0 / (P.cfg.f_scale * P.cfg.f_scale); }
+            if (d->undistort && !d->constraints_prescaled) { cv[7] *= P.cfg.k_scale; cw[7] *= 1.0 / (P.cfg.k_scale * P.cfg.k_scale);
                                 cv[8] *= P.cfg.k_scale; cw[8] *= 1.0 / (P.cfg.k_scale * P.cfg.k_scale); }
             for (int q = 0; q < cnp; ++q) { con[(size_t)j * cnp + q] = d->cameras[j].constrained[q] ? 1 : 0; val[(size_t)j * cnp + q] = cv[q]; w[(size_t)j * cnp + q] = cw[q]; }
         }

@@ -99,6 +99,29 @@ int bsfm_run_sfm_ex(int num_pts, int num_cameras, int ncons,
                     double *Vout, double *Sout, double *Uout, double *Wout,
                     const bsfm_options_t *opt, double info[BSFM_INFOSZ]);
 
+/* ---- 2b. SBA-level sibling ---------------------------------------------------------------------------
+ * Same argument list as the reference's sba_motstr_levmar (lib/sba-1.5/sba.h:95-108 as extended by Bundler:
+ * constraints and the V/S/U/W outputs, sba_levmar_wrap.c:599-698), except that the two host callbacks + adata
+ * (proj, projac, adata) -- which a GPU core cannot honour per observation -- are replaced by a camera-model id and its
+ * data block.  p (m*cnp camera + n*pnp point parameters) is refined in place; returns the number of iterations or
+ * BSFM_ERROR (SBA_ERROR = -1), info[10] as SBA.  Restrictions, all failing loudly: pnp = 3, mnp = 2, covx = NULL,
+ * omega (p[j*cnp+3..5]) zero on entry as in run_sfm (sfm.c:652-696), point-constraint weights uniform. */
+#define BSFM_MODEL_SNAVELY 1     /* lib/sfm-driver/sfm.c:503-552: centre, incremental rotation, f*0.001, k*5.0 */
+typedef struct {
+    int est_focal_length, undistort, explicit_camera_centers;   /* cnp = 6 + est + 2*undistort */
+    const double *R_init;        /* 9*m row-major: rotation of camera j at omega = 0 (init_params[j].R) */
+    const double *f_init;        /* m: focal lengths used when est_focal_length == 0 (may be NULL otherwise) */
+} bsfm_snavely_model_t;
+typedef struct { char *constrained; double *constraints; double *weights; } bsfm_camera_constraints_t;   /* sba.h:80-84 */
+typedef struct { char constrained; double constraints[3]; double weight; } bsfm_point_constraints_t;     /* sba.h:86-90 */
+int bsfm_sba_motstr_levmar(int n, int m, int mcon, char *vmask, double *p, int cnp, int pnp,
+                           double *x, double *covx, int mnp,
+                           int camera_model, const void *model_data,
+                           int itmax, int verbose, double opts[6], double info[BSFM_INFOSZ],
+                           int use_constraints, bsfm_camera_constraints_t *constraints,
+                           int use_point_constraints, bsfm_point_constraints_t *point_constraints,
+                           double *Vout, double *Sout, double *Uout, double *Wout);
+
 /* ---- 3. resident-problem API ------------------------------------------------------------------------ */
 typedef struct bsfm_problem bsfm_problem_t;
 
@@ -120,6 +143,11 @@ typedef struct {
     int world_size, rank;
     long long nvis_global;
     long long nvars_global;      /* m*cnp + 3*n_global, for the nobs<nvars check; 0 = local */
+    /* SBA-level callers (bsfm_sba_motstr_levmar) hand over the LM vector itself: m*cnp + 3*n doubles already in the
+     * scaled parametrisation of sfm.c:652-703 (then cameras[j] only supplies R, and f when the focal is not estimated),
+     * and constraint values/weights already in that parametrisation (the rescaling of sfm.c:721-754 is skipped). */
+    const double *p_packed;      /* NULL = pack from cameras/points */
+    int constraints_prescaled;
 } bsfm_problem_desc_t;
 
 /* Sum-reduce `count` doubles in place across ranks (device pointer); op 0 = sum, 1 = max.

@@ -63,3 +63,13 @@ def test_synth_scene_is_deterministic_and_sorted(bsfm):
     ci = band["colidx"].reshape(300, 6)
     span = (ci.max(1) - ci.min(1))
     assert ((span < 50) | (span > 150)).all()       # window of 50 neighbours (possibly wrapping)
+
+
+def test_keymatchfull_cli_is_built_and_prints_the_reference_usage():
+    """tools/KeyMatchFull.cpp -> bundler_sfm_amd/bin/KeyMatchFull (same usage line as src/KeyMatchFull.cpp:64-67)."""
+    import subprocess
+    exe = os.path.join(ROOT, "bundler_sfm_amd", "bin", "KeyMatchFull")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0
+    assert "<list.txt> <outfile> [window_radius]" in r.stdout

@@ -272,3 +272,65 @@ def test_covariance_export_matches_reference(gpu_bsfm, name):
         ref = X[f"{name}_{key}"]
         assert got.shape == ref.shape
         assert np.abs(got - ref).max() <= 1e-8 * np.abs(ref).max(), key
+
+
+@pytest.mark.parametrize("name", ["s9", "s9c", "s9m", "s7", "s6"])
+def test_sba_level_sibling_entry_matches_reference_sba(gpu_bsfm, name):
+    """SURVEY 8(b) secondary boundary: bsfm_sba_motstr_levmar takes sba_motstr_levmar's argument list (sba.h:95-108 +
+    Bundler's constraint / V,S,U,W arguments) with a camera-model id in place of the host callbacks.  Called exactly
+    like oracle/ref_harness.c:ref_sba_motstr calls the reference (scaled parameter vector, scaled constraints) it must
+    reproduce the reference's parameter vector after 3 analytic-Jacobian iterations (fixture <case>_an_it3_p)."""
+    import ctypes as C
+    from bundler_sfm_amd import _lib as L
+    B = gpu_bsfm
+    c = load_case(name)
+    m, n, est, und = c["m"], c["n"], c["est"], c["und"]
+    cnp = 6 + est + 2 * und
+    ca = O.cams_to_arrays(c["cams"])
+    p = np.zeros(m * cnp + 3 * n)
+    for j in range(m):
+        a = p[j * cnp:(j + 1) * cnp]
+        a[0:3] = ca["t"][j]
+        col = 6
+        if est:
+            a[6] = ca["f"][j] * 0.001; col = 7
+        if und:
+            a[col:col + 2] = ca["k"][j] * 5.0
+    p[m * cnp:] = c["pts"]
+    Rinit = np.ascontiguousarray(ca["R"].reshape(m, 9)); finit = np.ascontiguousarray(ca["f"], np.float64)
+    md = L.SnavelyModel(est, und, 1, Rinit.ctypes.data_as(C.POINTER(C.c_double)), finit.ctypes.data_as(C.POINTER(C.c_double)))
+    cons = None; keep = []
+    if c["cons"]:
+        cons = (L.CameraConstraints * m)()
+        for j in range(m):
+            con = np.ascontiguousarray(ca["constrained"][j][:cnp], np.uint8)
+            val = np.array(ca["constraints"][j][:cnp], np.float64); w = np.array(ca["weights"][j][:cnp], np.float64)
+            if est:
+                val[6] *= 0.001; w[6] *= 1.0 / (0.001 * 0.001)          # sfm.c:721-754, as ref_harness.c does
+            if und:
+                val[7:9] *= 5.0; w[7:9] *= 1.0 / 25.0
+            keep += [con, val, w]
+            cons[j].constrained = C.cast(con.ctypes.data, C.POINTER(C.c_char))
+            cons[j].constraints = val.ctypes.data_as(C.POINTER(C.c_double)); cons[j].weights = w.ctypes.data_as(C.POINTER(C.c_double))
+    opts = (C.c_double * 6)(1e-3, 1e-10, 1e-12, 1e-12, 0.0, 4e-2)
+    info = np.zeros(10)
+    os.environ["BSFM_JACOBIAN"] = "analytic"
+    try:
+        fn = B.lib.bsfm_sba_motstr_levmar
+        fn.restype = C.c_int
+        vm = np.ascontiguousarray(c["vm"], np.uint8); proj = np.ascontiguousarray(c["proj"], np.float64)
+        rc = fn(n, m, c["ncons"], vm.ctypes.data_as(C.c_char_p), p.ctypes.data_as(C.POINTER(C.c_double)), cnp, 3,
+                proj.ctypes.data_as(C.POINTER(C.c_double)), None, 2, 1, C.byref(md), 3, 0, opts,
+                info.ctypes.data_as(C.POINTER(C.c_double)), 1 if cons is not None else 0, cons, 0, None, None, None, None, None)
+    finally:
+        del os.environ["BSFM_JACOBIAN"]
+    gi, gp = G[f"{name}_an_it3_info"], G[f"{name}_an_it3_p"]
+    assert rc == int(gi[5]) == 3
+    assert abs(info[1] - gi[1]) <= 1e-9 * gi[1]
+    assert np.abs(p - gp).max() <= 1e-8 * np.abs(gp).max()
+    # refusals leave p untouched
+    p2 = p.copy()
+    assert fn(n, m, 0, vm.ctypes.data_as(C.c_char_p), p2.ctypes.data_as(C.POINTER(C.c_double)), cnp, 3,
+              proj.ctypes.data_as(C.POINTER(C.c_double)), None, 2, 7, C.byref(md), 3, 0, opts, None, 0, None, 0, None,
+              None, None, None, None) == -1
+    assert np.array_equal(p2, p)

@@ -112,3 +112,70 @@ def test_key_match_full_text_is_byte_identical(gpu_bsfm, tmp_path):
                 expect.append(f"{j} {i}\n{len(mt)}\n" + "".join(f"{a} {b}\n" for a, b in mt))
     assert rc == npairs and npairs > 0
     assert out.read_text() == "".join(expect)
+
+
+def _write_key_file(path, keys, gz=False):
+    """Lowe's ASCII .key format (keys2a.cpp:183-190): 'num 128', then per key 'row col scale ori' and the 128 bytes
+    on 7 lines (6 x 20 + 8)."""
+    import gzip
+    lines = [f"{len(keys)} 128\n"]
+    for q, d in enumerate(keys):
+        lines.append(f"{10.5 + q:.2f} {20.25 + q:.2f} {1.5:.2f} {-0.733:.3f}\n")
+        for s in range(0, 120, 20):
+            lines.append(" " + " ".join(str(int(v)) for v in d[s:s + 20]) + "\n")
+        lines.append(" " + " ".join(str(int(v)) for v in d[120:128]) + "\n")
+    data = "".join(lines).encode()
+    if gz:
+        with gzip.open(str(path) + ".gz", "wb") as f:
+            f.write(data)
+    else:
+        with open(path, "wb") as f:
+            f.write(data)
+
+
+@pytest.mark.gpu
+def test_keymatchfull_cli_same_process_boundary_as_reference(gpu_bsfm, tmp_path):
+    """The command-line tool (tools/KeyMatchFull.cpp; reference usage KeyMatchFull.cpp:64-76): list file -> key files
+    (plain, gzip fallback, a missing one) -> matches file, byte-identical to the in-process driver and to the oracle loop;
+    also the window_radius argument."""
+    import subprocess
+    B = gpu_bsfm
+    exe = os.path.join(os.path.dirname(HERE), "bundler_sfm_amd", "bin", "KeyMatchFull")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    sizes = [280, 300, 0, 190, 320]
+    keys, prev = [], None
+    for i, nk in enumerate(sizes):
+        k = synth_keys(B, nk, 4000 + i, dup=prev) if nk else np.zeros((0, 128), np.uint8)
+        keys.append(k)
+        if nk:
+            prev = k
+    names = []
+    for i, k in enumerate(keys):
+        p = tmp_path / f"img{i}.key"
+        names.append(str(p))
+        if sizes[i] == 0:
+            continue                          # image 2: no file at all -> "Could not open file", 0 keys, skipped
+        _write_key_file(p, k, gz=(i == 3))    # image 3 only exists as .key.gz
+    (tmp_path / "list.txt").write_text("\n".join(names) + "\n")
+
+    def expect(window):
+        out = []
+        for i in range(len(sizes)):
+            for j in range(max(i - window, 0) if window > 0 else 0, i):
+                if sizes[i] == 0 or sizes[j] == 0:
+                    continue
+                mt = O.port_match(keys[j], keys[i])
+                if len(mt) >= 16:
+                    out.append(f"{j} {i}\n{len(mt)}\n" + "".join(f"{a} {b}\n" for a, b in mt))
+        return "".join(out)
+
+    for window, extra in ((-1, []), (1, ["1"])):
+        outp = tmp_path / f"matches{window}.txt"
+        r = subprocess.run([exe, str(tmp_path / "list.txt"), str(outp)] + extra, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "Could not open file" in r.stdout and "[KeyMatchFull] Matching took" in r.stdout
+        text = outp.read_text()
+        assert text == expect(window)
+        assert text.count("\n") > 50          # something was actually matched
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode != 0 and "Usage:" in r.stdout
