@@ -68,6 +68,20 @@ def syrk_flops_per_launch(sdim):
     return 2.0 * NB ** 3 * sum(tiles) / max(len(tiles), 1), len(tiles)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (counters need their own profiler passes,
+    so they cannot be collected inside this run); None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(kernel)
+        return None if not k else round(k["traffic_bytes"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(sample):
     """Reference SBA (oracle/_ref = the reference's own C sources) on a bounded sample, 1 thread."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -177,7 +191,10 @@ def main():
             assert abs(lib_gflop * 1e9 - flops_launch) <= 1e-9 * flops_launch, (lib_gflop, flops_launch)
             ach = flops_launch / (syrk_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "k_syrk_update", "achieved": round(ach, 3), "peak": FP64_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic("k_syrk_update"),
+                    "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                    "this command (scripts/profile_round.sh -> profiles/*_pmc_traffic.json; 2 x FETCH_SIZE "
+                                    "per the gfx950 correction); algorithmic C traffic is 2 x 128 KB per tile",
                     "launches_per_solve": nlaunch, "avg_launch_ms": round(syrk_ms, 4),
                     "alg_flop_per_launch": flops_launch}
         out = {

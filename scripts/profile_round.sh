@@ -1,0 +1,20 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): the round's rocprofv3 evidence for bench.py's default command.
+#   1. kernel trace + stats        -> gpurun_out/prof/<tag>_kernel_stats.csv
+#   2. PMC pass FETCH_SIZE         (separate runs: --pmc never together with trace flags other than kernel-trace,
+#   3. PMC pass WRITE_SIZE          and the two TCC counters do not fit one pass)
+#   4. scripts/pmc_summary.py      -> gpurun_out/prof/<tag>_pmc_traffic.json
+# usage: scripts/profile_round.sh <tag>      e.g. r01_cfg3_fd_v3
+set -u
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/prof
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout 250 rocprofv3 --kernel-trace --stats -d /tmp/p_stats -o st --output-format csv -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_bench_under_profiler.json 2> /tmp/st.err
+cp $(find /tmp/p_stats -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
+python $ROOT/scripts/trace_chain.py $(find /tmp/p_stats -name "*kernel_trace.csv" | head -1) 40 41 > $OUT/${TAG}_chain_timeline.txt 2>&1
+timeout 250 rocprofv3 --pmc FETCH_SIZE -d /tmp/p_f -o f --output-format csv -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> /tmp/f.err
+timeout 250 rocprofv3 --pmc WRITE_SIZE -d /tmp/p_w -o w --output-format csv -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> /tmp/w.err
+python $ROOT/scripts/pmc_summary.py $(find /tmp/p_f -name "*counter_collection.csv" | head -1) $(find /tmp/p_w -name "*counter_collection.csv" | head -1) $OUT/${TAG}_pmc_traffic.json
+head -12 $OUT/${TAG}_kernel_stats.csv | cut -c1-150

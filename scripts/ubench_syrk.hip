@@ -1,6 +1,7 @@
 // ubench_syrk.hip -- where does the bulk trailing-update kernel lose time?  Runs k_syrk_update (part 2, T = 69 tile
 // rows = the first step of config 3) alone on the whole device and compares with variants that drop the epilogue,
-// drop the prologue latency (K repeated 8x) or drop the global loads.
+// drop the prologue latency (K repeated 8x) or drop the global loads, and an XCD-aware tile order (no gain in the
+// real factorisation: 35.0 TFLOP/s with and without, so it is not in the library).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I bundler_sfm_amd/csrc -I include scripts/ubench_syrk.hip -o /tmp/ubench_syrk
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -147,8 +148,7 @@ int main()
         printf("%-34s grid %5d  %8.3f ms  %7.2f TFLOP/s\n", name, grid, best, flop / (best * 1e-3) / 1e12);
     };
     run("shipped k_syrk_update part 2", [&] { hipLaunchKernelGGL(k_syrk_update, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2); }, flop1);
-    run("shipped k_syrk_update2 (K=256)", [&] { const int T2 = T - 2; hipLaunchKernelGGL(k_syrk_update2, dim3(T2 * (T2 + 1) / 2), dim3(512), lds_bytes, 0, S, ld, 0, panel, panel + (size_t)T * POTRF_NB * POTRF_NB); },
-        2.0 * 2.0 * 128 * 128 * 128 * ((T - 2) * (T - 1) / 2));
+    // (a rank-256 two-panel variant measured 46.6 vs 42.9 TFLOP/s here; dropped, see potrf.hip.h)
     run("same, mode 0 copy", [&] { hipLaunchKernelGGL(k_var<0>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, flop1);
     run("no C epilogue", [&] { hipLaunchKernelGGL(k_var<1>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, flop1);
     run("K x8 (1024) with epilogue", [&] { hipLaunchKernelGGL(k_var<2>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, 8 * flop1);
