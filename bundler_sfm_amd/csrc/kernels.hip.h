@@ -17,7 +17,7 @@
 //   camptr[m+1], camobs[nvis]               camera-major secondary index (replaces sba_crsm_col_elmidxs'
 //                                           per-call binary searches, sba_crsm.c:183-212)
 //   camtab[m*72]    per-camera derived row  (model.hip.h)
-//   J[nvis*(2cnp+6)] A_ij (2 x cnp) then B_ij (2 x 3), one contiguous record per observation (point-major);
+//   Jc[nvis*(2cnp+6)] A_ij (2 x cnp) then B_ij (2 x 3), one contiguous record per observation, CAMERA-major order;
 //   Jc               the same records in CAMERA-major order (position campos[k]): the camera-side consumers
 //                    (U_j/ea_j, Schur tasks, e_j) then read contiguous / monotone streams instead of random 192-byte gathers
 //   U[m*cnp*cnp], ea[m*cnp], V[n*6] (packed upper), Vinv[n*6], eb[n*3], S[ld*ld], E[ld]
@@ -47,7 +47,7 @@ struct DevProblem {
     const unsigned char* pcon; const double* pval; double pweight;     // n, 3n (may be null)
     double nvis_global;
     // work arrays
-    double* J; double* Jc; double* U; double* ea; double* V; double* Vinv; double* eb;
+    double* Jc; double* U; double* ea; double* V; double* Vinv; double* eb;
 };
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(RES_BLOCK) void k_residual(ModelCfg cfg, int nvis,
 template <int CNP, bool FD>
 __global__ __launch_bounds__(256) void k_jacobian(ModelCfg cfg, int nvis,
         const int* __restrict__ obs_cam, const int* __restrict__ obs_pt,
-        const double* __restrict__ camtab, const double* __restrict__ pb, double* __restrict__ J,
+        const double* __restrict__ camtab, const double* __restrict__ pb,
         const int* __restrict__ campos, double* __restrict__ Jc)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -161,12 +161,26 @@ __global__ __launch_bounds__(256) void k_jacobian(ModelCfg cfg, int nvis,
     if (FD) jac_fd<CNP>(cfg, ct, b[0], b[1], b[2], A, B, x0, x1);
     else    jac_analytic<CNP>(cfg, ct, b[0], b[1], b[2], A, B, x0, x1);
     constexpr int JS = 2 * CNP + 6;
-    double2* out = reinterpret_cast<double2*>(J + (size_t)k * JS);   // JS is even -> 16-byte aligned records
+    // ONE copy, camera-major (record of observation k at position campos[k]; JS is even -> 16-byte aligned records):
+    // the camera-side consumers (U/ea, Schur tasks, Schur rhs) stream it, the point-side ones gather whole records.
     double2* outc = reinterpret_cast<double2*>(Jc + (size_t)campos[k] * JS);
 #pragma unroll
-    for (int q = 0; q < CNP; ++q) { const double2 v = make_double2(A[2 * q], A[2 * q + 1]); out[q] = v; outc[q] = v; }
+    for (int q = 0; q < CNP; ++q) outc[q] = make_double2(A[2 * q], A[2 * q + 1]);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) { const double2 v = make_double2(B[2 * q], B[2 * q + 1]); out[CNP + q] = v; outc[CNP + q] = v; }
+    for (int q = 0; q < 3; ++q) outc[CNP + q] = make_double2(B[2 * q], B[2 * q + 1]);
+}
+
+// N 16-byte loads of 2N consecutive doubles.  Jacobian records are 16-byte aligned (even length, 2*cnp even), which
+// the compiler cannot know from a double*: spelled out, a 192-byte record costs 12 load instructions instead of 24 --
+// the per-observation kernels are bound by the number of line requests on the vector-memory path, not by bytes.
+template <int N>
+__device__ __forceinline__ void load_pairs(const double* __restrict__ p, double* __restrict__ out)
+{
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        const double2 t = reinterpret_cast<const double2*>(p)[q];
+        out[2 * q] = t.x; out[2 * q + 1] = t.y;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -181,9 +195,11 @@ __global__ __launch_bounds__(256) void k_point_blocks(DevProblem P, const double
     double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, g0 = 0, g1 = 0, g2 = 0;
     const int k1 = P.rowptr[i + 1];
     for (int k = P.rowptr[i]; k < k1; ++k) {
-        const double* B = P.J + (size_t)k * JS + 2 * CNP;
+        double B[6], ee[2];
+        load_pairs<3>(P.Jc + (size_t)P.campos[k] * JS + 2 * CNP, B);
+        load_pairs<1>(e + 2 * (size_t)k, ee);
         const double b0 = B[0], b1 = B[1], b2 = B[2], b3 = B[3], b4 = B[4], b5 = B[5];
-        const double e0 = e[2 * k], e1 = e[2 * k + 1];
+        const double e0 = ee[0], e1 = ee[1];
         v00 += b0 * b0 + b3 * b3; v01 += b0 * b1 + b3 * b4; v02 += b0 * b2 + b3 * b5;
         v11 += b1 * b1 + b4 * b4; v12 += b1 * b2 + b4 * b5; v22 += b2 * b2 + b5 * b5;
         g0 += b0 * e0 + b3 * e1; g1 += b1 * e0 + b4 * e1; g2 += b2 * e0 + b5 * e1;
@@ -219,11 +235,10 @@ __global__ __launch_bounds__(256) void k_cam_blocks(DevProblem P, const double* 
         const int t1 = P.camptr[j + 1];
         for (int t = P.camptr[j] + threadIdx.x; t < t1; t += 256) {
             const int k = P.camobs[t];
-            const double* A = P.Jc + (size_t)t * JS;
-            double a[2 * CNP];
-#pragma unroll
-            for (int q = 0; q < 2 * CNP; ++q) a[q] = A[q];
-            const double e0 = e[2 * k], e1 = e[2 * k + 1];
+            double a[2 * CNP], ee[2];
+            load_pairs<CNP>(P.Jc + (size_t)t * JS, a);
+            load_pairs<1>(e + 2 * (size_t)k, ee);
+            const double e0 = ee[0], e1 = ee[1];
             int u = 0;
 #pragma unroll
             for (int r = 0; r < CNP; ++r) {
@@ -458,7 +473,8 @@ __global__ __launch_bounds__(256) void k_schur_rhs(DevProblem P, int add_ea, dou
         const double t0 = vi[0] * g[0] + vi[1] * g[1] + vi[2] * g[2];
         const double t1v = vi[1] * g[0] + vi[3] * g[1] + vi[4] * g[2];
         const double t2 = vi[2] * g[0] + vi[4] * g[1] + vi[5] * g[2];
-        const double* A = P.Jc + (size_t)t * JS;
+        double A[JS];
+        load_pairs<CNP + 3>(P.Jc + (size_t)t * JS, A);
         const double* B = A + 2 * CNP;
         const double s0 = B[0] * t0 + B[1] * t1v + B[2] * t2;
         const double s1 = B[3] * t0 + B[4] * t1v + B[5] * t2;
@@ -495,7 +511,8 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem P, double mu, const 
         for (int k = P.rowptr[i]; k < k1; ++k) {
             const int j = P.obs_cam[k];
             if (j < P.mcon) continue;
-            const double* A = P.J + (size_t)k * JS;
+            double A[JS];
+            load_pairs<CNP + 3>(P.Jc + (size_t)P.campos[k] * JS, A);
             const double* B = A + 2 * CNP;
             const double* da = dpa + (size_t)j * CNP;
             double q0 = 0, q1 = 0;

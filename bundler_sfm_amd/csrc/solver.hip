@@ -71,7 +71,7 @@ struct bsfm_problem {
     double *d_p = nullptr, *d_pdp = nullptr, *d_dp = nullptr;
     double *d_camtab = nullptr, *d_camtab_trial = nullptr;
     double *d_e = nullptr, *d_hx = nullptr;
-    double *d_J = nullptr, *d_Jc = nullptr, *d_U = nullptr, *d_ea = nullptr, *d_V = nullptr, *d_Vinv = nullptr, *d_eb = nullptr;
+    double *d_Jc = nullptr, *d_U = nullptr, *d_ea = nullptr, *d_V = nullptr, *d_Vinv = nullptr, *d_eb = nullptr;
     double *d_S = nullptr, *d_E = nullptr;
     double *d_partials = nullptr;       // schur task partials
     double *d_red = nullptr;            // block partials for reductions
@@ -108,7 +108,7 @@ void free_all(bsfm_problem* pb)
 {
     void* ptrs[] = { pb->d_x, pb->d_Rinit, pb->d_finit, pb->d_obs_cam, pb->d_obs_pt, pb->d_rowptr, pb->d_camptr,
                      pb->d_camobs, pb->d_campos, pb->d_cam_pt, pb->d_Jc, pb->d_ccon, pb->d_pcon, pb->d_cval, pb->d_cw, pb->d_pval, pb->d_p, pb->d_pdp,
-                     pb->d_dp, pb->d_camtab, pb->d_camtab_trial, pb->d_e, pb->d_hx, pb->d_J, pb->d_U,
+                     pb->d_dp, pb->d_camtab, pb->d_camtab_trial, pb->d_e, pb->d_hx, pb->d_U,
                      pb->d_V, pb->d_Vinv, pb->d_eb, pb->d_S, pb->d_E, pb->d_partials, pb->d_red, pb->d_scal,
                      pb->d_flags, pb->d_triples, pb->d_tri_pt, pb->d_tasks, pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0,
                      pb->d_gidx, pb->d_gblk_j, pb->d_gblk_k, pb->d_G };
@@ -305,10 +305,10 @@ int compute_normal_blocks(bsfm_problem* pb)
     if (P.nvis > 0) {
         if (pb->opt.jacobian == BSFM_JAC_FD) {
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_jacobian<C, true>), dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream,
-                                                  P.cfg, P.nvis, pb->d_obs_cam, pb->d_obs_pt, pb->d_camtab, pbpts, pb->d_J, pb->d_campos, pb->d_Jc));
+                                                  P.cfg, P.nvis, pb->d_obs_cam, pb->d_obs_pt, pb->d_camtab, pbpts, pb->d_campos, pb->d_Jc));
         } else {
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_jacobian<C, false>), dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream,
-                                                  P.cfg, P.nvis, pb->d_obs_cam, pb->d_obs_pt, pb->d_camtab, pbpts, pb->d_J, pb->d_campos, pb->d_Jc));
+                                                  P.cfg, P.nvis, pb->d_obs_cam, pb->d_obs_pt, pb->d_camtab, pbpts, pb->d_campos, pb->d_Jc));
         }
     }
     ph_end(pb, PH_JAC);
@@ -505,7 +505,7 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     DM(pb->d_p, pb->nvars_local); DM(pb->d_pdp, pb->nvars_local); DM(pb->d_dp, pb->nvars_local);
     DM(pb->d_camtab, (size_t)m * CT_STRIDE); DM(pb->d_camtab_trial, (size_t)m * CT_STRIDE);
     DM(pb->d_e, 2 * (size_t)nvis); DM(pb->d_hx, 2 * (size_t)nvis);
-    DM(pb->d_J, (size_t)nvis * P.js); DM(pb->d_Jc, (size_t)nvis * P.js); DM(pb->d_campos, nvis); DM(pb->d_cam_pt, nvis); DM(pb->d_U, (size_t)m * cnp * cnp + (size_t)m * cnp); pb->d_ea = pb->d_U + (size_t)m * cnp * cnp;   /* one buffer: one exchange */
+    DM(pb->d_Jc, (size_t)nvis * P.js); DM(pb->d_campos, nvis); DM(pb->d_cam_pt, nvis); DM(pb->d_U, (size_t)m * cnp * cnp + (size_t)m * cnp); pb->d_ea = pb->d_U + (size_t)m * cnp * cnp;   /* one buffer: one exchange */
     DM(pb->d_V, 6 * (size_t)n); DM(pb->d_Vinv, 6 * (size_t)n); DM(pb->d_eb, 3 * (size_t)n);
     DM(pb->d_S, (size_t)pb->ld * pb->ld); DM(pb->d_E, pb->ld);
     pb->red_blocks = std::max(grid_for(nvis, RES_BLOCK), std::max(grid_for(n, 256), 1024));
@@ -554,7 +554,7 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     P.x = pb->d_x; P.obs_cam = pb->d_obs_cam; P.obs_pt = pb->d_obs_pt; P.rowptr = pb->d_rowptr;
     P.camptr = pb->d_camptr; P.camobs = pb->d_camobs; P.campos = pb->d_campos; P.cam_pt = pb->d_cam_pt; P.Rinit = pb->d_Rinit; P.finit = pb->d_finit;
     P.ccon = pb->d_ccon; P.cval = pb->d_cval; P.cw = pb->d_cw; P.pcon = pb->d_pcon; P.pval = pb->d_pval;
-    P.J = pb->d_J; P.Jc = pb->d_Jc; P.U = pb->d_U; P.ea = pb->d_ea; P.V = pb->d_V; P.Vinv = pb->d_Vinv; P.eb = pb->d_eb;
+    P.Jc = pb->d_Jc; P.U = pb->d_U; P.ea = pb->d_ea; P.V = pb->d_V; P.Vinv = pb->d_Vinv; P.eb = pb->d_eb;
     if (build_schur_structure(pb, d, campos, cam_pt) != 0) return fail("schur structure");
     if (potrf_init(pb->potrf, pb->ld, pb->opt.potrf_backend) != 0) return fail("potrf workspace");
     pb->ev_ok = true;
@@ -898,7 +898,13 @@ int bsfm_eval_normal_equations(bsfm_problem_t* pb, double mu, double* U, double*
         (void)hipFree(tmp);
     }
     if (eb && n) HIP_OK(hipMemcpy(eb, pb->d_eb, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    if (J && pb->P.nvis) HIP_OK(hipMemcpy(J, pb->d_J, (size_t)pb->P.nvis * pb->P.js * sizeof(double), hipMemcpyDeviceToHost));
+    if (J && pb->P.nvis) {   // the device copy is camera-major: back to observation order on the host (export path only)
+        const size_t nv = (size_t)pb->P.nvis, js = (size_t)pb->P.js;
+        std::vector<double> jc(nv * js); std::vector<int> pos(nv);
+        HIP_OK(hipMemcpy(jc.data(), pb->d_Jc, nv * js * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(pos.data(), pb->d_campos, nv * sizeof(int), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < nv; ++k) memcpy(J + k * js, jc.data() + (size_t)pos[k] * js, js * sizeof(double));
+    }
     if (S && pb->Sdim) HIP_OK(hipMemcpy2D(S, (size_t)pb->Sdim * sizeof(double), pb->d_S, (size_t)pb->ld * sizeof(double),
                                           (size_t)pb->Sdim * sizeof(double), pb->Sdim, hipMemcpyDeviceToHost));
     if (E && pb->Sdim) HIP_OK(hipMemcpy(E, pb->d_E, (size_t)pb->Sdim * sizeof(double), hipMemcpyDeviceToHost));
