@@ -30,7 +30,7 @@
 
 namespace bsfm {
 
-struct SchurTask { int start; int count; };
+struct SchurTask { int start; int count; int diag; };   // diag: the task's block is S_jj (it also produces its part of e_j)
 
 struct DevProblem {
     ModelCfg cfg;
@@ -218,22 +218,33 @@ __global__ __launch_bounds__(256) void k_point_blocks(DevProblem P, const double
 }
 
 // ---------------------------------------------------------------------------------------------------
-// U_j (upper triangle accumulated, mirrored on store), ea_j: one 256-thread block per camera walks the
-// camera-major index; per-thread register partials, wave shuffle reduction, LDS across the 4 waves.
+// U_j (upper triangle accumulated, mirrored on store), ea_j.  CAM_SPLIT 256-thread blocks per camera each walk one slice
+// of the camera's (contiguous, camera-major) records: per-thread register partials, wave shuffle reduction, LDS across
+// the 4 waves, one partial row per block; k_cam_blocks_fin adds the CAM_SPLIT rows in slice order (deterministic).
+// One block per camera left a third of the device idle: 1000 blocks of ~166 VGPRs fill 768 slots, then 232.
+constexpr int CAM_SPLIT = 4;
+__device__ __forceinline__ void cam_slice(const int* __restrict__ camptr, int j, int s, int& t0, int& t1)
+{
+    const int a = camptr[j], b = camptr[j + 1];
+    const int chunk = (b - a + CAM_SPLIT - 1) / CAM_SPLIT;
+    t0 = min(b, a + s * chunk); t1 = min(b, t0 + chunk);
+}
+
 template <int CNP>
-__global__ __launch_bounds__(256) void k_cam_blocks(DevProblem P, const double* __restrict__ e)
+__global__ __launch_bounds__(256) void k_cam_blocks(DevProblem P, const double* __restrict__ e, double* __restrict__ part)
 {
     constexpr int JS = 2 * CNP + 6;
     constexpr int NU = CNP * (CNP + 1) / 2;
     constexpr int NV = NU + CNP;
     __shared__ double sm[4][NV];
-    const int j = blockIdx.x;
+    const int j = blockIdx.x / CAM_SPLIT, s = blockIdx.x % CAM_SPLIT;
     double acc[NV];
 #pragma unroll
     for (int q = 0; q < NV; ++q) acc[q] = 0.0;
     if (j >= P.mcon) {
-        const int t1 = P.camptr[j + 1];
-        for (int t = P.camptr[j] + threadIdx.x; t < t1; t += 256) {
+        int t0, t1;
+        cam_slice(P.camptr, j, s, t0, t1);
+        for (int t = t0 + threadIdx.x; t < t1; t += 256) {
             const int k = P.camobs[t];
             double a[2 * CNP], ee[2];
             load_pairs<CNP>(P.Jc + (size_t)t * JS, a);
@@ -251,17 +262,33 @@ __global__ __launch_bounds__(256) void k_cam_blocks(DevProblem P, const double* 
     }
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int q = 0; q < NV; ++q) { const double s = wave_sum(acc[q]); if (lane == 0) sm[w][q] = s; }
+    for (int q = 0; q < NV; ++q) { const double v = wave_sum(acc[q]); if (lane == 0) sm[w][q] = v; }
     __syncthreads();
+    if (threadIdx.x < NV)
+        part[(size_t)blockIdx.x * NV + threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+template <int CNP>
+__global__ __launch_bounds__(128) void k_cam_blocks_fin(DevProblem P, const double* __restrict__ part)
+{
+    constexpr int NU = CNP * (CNP + 1) / 2;
+    constexpr int NV = NU + CNP;
+    const int j = blockIdx.x;
+    const double* pj = part + (size_t)j * CAM_SPLIT * NV;
     if (threadIdx.x < CNP * CNP) {
         const int r = threadIdx.x / CNP, c = threadIdx.x % CNP;
         const int rr = r < c ? r : c, cc = r < c ? c : r;
         const int u = rr * CNP - rr * (rr - 1) / 2 + (cc - rr);
-        P.U[(size_t)j * CNP * CNP + threadIdx.x] = (sm[0][u] + sm[1][u]) + (sm[2][u] + sm[3][u]);
-    }
-    if (threadIdx.x < CNP) {
-        const int u = NU + threadIdx.x;
-        P.ea[(size_t)j * CNP + threadIdx.x] = (sm[0][u] + sm[1][u]) + (sm[2][u] + sm[3][u]);
+        double v = 0.0;
+#pragma unroll
+        for (int s = 0; s < CAM_SPLIT; ++s) v += pj[s * NV + u];
+        P.U[(size_t)j * CNP * CNP + threadIdx.x] = v;
+    } else if (threadIdx.x < CNP * CNP + CNP) {
+        const int u = NU + (threadIdx.x - CNP * CNP);
+        double v = 0.0;
+#pragma unroll
+        for (int s = 0; s < CAM_SPLIT; ++s) v += pj[s * NV + u];
+        P.ea[(size_t)j * CNP + (threadIdx.x - CNP * CNP)] = v;
     }
 }
 
@@ -299,109 +326,23 @@ __global__ __launch_bounds__(256) void k_point_invert(int n, double mu, const do
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Schur complement partial products.  The co-visibility triples (obs_a, obs_b) of every non-zero block
-// S_jk (j <= k) were bucketed and ordered once per problem; a task is a chunk of one block's triples and is
-// owned by ONE wave: 3 lanes per triple (lane r owns output rows r, r+3, r+6), 21 triples in flight,
-// the 21 lane-groups are folded with shuffles and lanes 0..2 store the cnp x cnp partial.
-// No atomics anywhere: partials are summed in task order by k_schur_assemble => run-to-run deterministic.
-template <int CNP>
-__global__ __launch_bounds__(256) void k_schur_tasks(DevProblem P, const SchurTask* __restrict__ tasks, int ntasks,
-        const int2* __restrict__ triples, double* __restrict__ partials)
-{
-    constexpr int JS = 2 * CNP + 6;
-    constexpr int NR = (CNP + 2) / 3;
-    const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (task >= ntasks) return;
-    const int lane = threadIdx.x & 63;
-    const int grp = lane / 3, r = lane - 3 * grp;
-    const SchurTask tk = tasks[task];
-    double acc[NR][CNP];
-#pragma unroll
-    for (int a = 0; a < NR; ++a)
-#pragma unroll
-        for (int c = 0; c < CNP; ++c) acc[a][c] = 0.0;
-    if (grp < 21) {
-        for (int t = grp; t < tk.count; t += 21) {
-            const int2 tr = triples[tk.start + t];
-            const double* Ja = P.Jc + (size_t)tr.x * JS;        // triples hold CAMERA-major positions
-            const double* Jb = P.Jc + (size_t)tr.y * JS;
-            const double* vi = P.Vinv + (size_t)P.cam_pt[tr.x] * 6;
-            // 16-byte loads of the contiguous pieces (records are 16-byte aligned: JS is even): the kernel is bound by
-            // line requests on the texture path, so halving the load-instruction count is what matters
-            double vv[6], Ba[6], Jbv[2 * CNP + 6];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const double2 t2 = reinterpret_cast<const double2*>(vi)[q]; vv[2 * q] = t2.x; vv[2 * q + 1] = t2.y;
-                const double2 u2 = reinterpret_cast<const double2*>(Ja + 2 * CNP)[q]; Ba[2 * q] = u2.x; Ba[2 * q + 1] = u2.y;
-            }
-#pragma unroll
-            for (int q = 0; q < CNP + 3; ++q) {
-                const double2 t2 = reinterpret_cast<const double2*>(Jb)[q]; Jbv[2 * q] = t2.x; Jbv[2 * q + 1] = t2.y;
-            }
-            const double i00 = vv[0], i01 = vv[1], i02 = vv[2], i11 = vv[3], i12 = vv[4], i22 = vv[5];
-            const double* Bb = Jbv + 2 * CNP;
-            // C = B_a V^-1 (2x3), M = C B_b^T (2x2)
-            const double c00 = Ba[0] * i00 + Ba[1] * i01 + Ba[2] * i02;
-            const double c01 = Ba[0] * i01 + Ba[1] * i11 + Ba[2] * i12;
-            const double c02 = Ba[0] * i02 + Ba[1] * i12 + Ba[2] * i22;
-            const double c10 = Ba[3] * i00 + Ba[4] * i01 + Ba[5] * i02;
-            const double c11 = Ba[3] * i01 + Ba[4] * i11 + Ba[5] * i12;
-            const double c12 = Ba[3] * i02 + Ba[4] * i12 + Ba[5] * i22;
-            const double m00 = c00 * Bb[0] + c01 * Bb[1] + c02 * Bb[2];
-            const double m01 = c00 * Bb[3] + c01 * Bb[4] + c02 * Bb[5];
-            const double m10 = c10 * Bb[0] + c11 * Bb[1] + c12 * Bb[2];
-            const double m11 = c10 * Bb[3] + c11 * Bb[4] + c12 * Bb[5];
-            double T0[CNP], T1[CNP];
-#pragma unroll
-            for (int c = 0; c < CNP; ++c) {
-                const double b0 = Jbv[c], b1 = Jbv[CNP + c];
-                T0[c] = m00 * b0 + m01 * b1;
-                T1[c] = m10 * b0 + m11 * b1;
-            }
-#pragma unroll
-            for (int a = 0; a < NR; ++a) {
-                const int row = r + 3 * a;
-                if (row < CNP) {
-                    const double a0 = Ja[row], a1 = Ja[CNP + row];
-#pragma unroll
-                    for (int c = 0; c < CNP; ++c) acc[a][c] += a0 * T0[c] + a1 * T1[c];
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int s = 16; s > 0; s >>= 1) {
-        const bool take = (grp < s) && (grp + s < 21);
-#pragma unroll
-        for (int a = 0; a < NR; ++a)
-#pragma unroll
-            for (int c = 0; c < CNP; ++c) {
-                const double o = __shfl_down(acc[a][c], 3 * s, 64);
-                if (take) acc[a][c] += o;
-            }
-    }
-    if (grp == 0) {
-        double* out = partials + (size_t)task * CNP * CNP;
-#pragma unroll
-        for (int a = 0; a < NR; ++a) {
-            const int row = r + 3 * a;
-            if (row < CNP) {
-#pragma unroll
-                for (int c = 0; c < CNP; ++c) out[row * CNP + c] = acc[a][c];
-            }
-        }
-    }
-}
-
+// Schur complement: the task kernel lives in schur.hip.h; here are the assembly kernels.
 // S_jk = [j==k](U_j + mu I) - sum_tasks partial ; mirrored into S_kj (sba_levmar.c:1274-1316).
 template <int CNP>
 __global__ __launch_bounds__(128) void k_schur_assemble(int nblk, const int* __restrict__ blk_j, const int* __restrict__ blk_k,
-        const int* __restrict__ blk_task0, const double* __restrict__ partials, const double* __restrict__ U,
-        double mu, int mcon, double* __restrict__ S, int ld)
+        const int* __restrict__ blk_task0, const double* __restrict__ partials, const double* __restrict__ epart,
+        const double* __restrict__ U, double mu, int mcon, double* __restrict__ S, int ld, double* __restrict__ E)
 {
     const int b = blockIdx.x;
-    if (b >= nblk || threadIdx.x >= CNP * CNP) return;
+    if (b >= nblk) return;
     const int j = blk_j[b], k = blk_k[b];
+    if (j == k && threadIdx.x >= CNP * CNP && threadIdx.x < CNP * CNP + CNP) {   // e_j -= this block's tasks (E was set to ea by k_rhs_init)
+        const int q = threadIdx.x - CNP * CNP;
+        double se = 0.0;
+        for (int t = blk_task0[b]; t < blk_task0[b + 1]; ++t) se += epart[(size_t)t * CNP + q];
+        E[(size_t)(j - mcon) * CNP + q] -= se;
+    }
+    if (threadIdx.x >= CNP * CNP) return;
     const int row = threadIdx.x / CNP, col = threadIdx.x % CNP;
     double s = 0.0;
     for (int t = blk_task0[b]; t < blk_task0[b + 1]; ++t) s += partials[(size_t)t * CNP * CNP + threadIdx.x];
@@ -414,11 +355,19 @@ __global__ __launch_bounds__(128) void k_schur_assemble(int nblk, const int* __r
 
 // Multi-GPU job: this rank's block sums go to their slot of the union structure (the buffer that is all-reduced) ...
 template <int CNP>
-__global__ __launch_bounds__(128) void k_schur_pack(int nblk, const int* __restrict__ blk_task0, const double* __restrict__ partials,
-        const int* __restrict__ gidx, double* __restrict__ G)
+__global__ __launch_bounds__(128) void k_schur_pack(int nblk, const int* __restrict__ blk_j, const int* __restrict__ blk_k,
+        const int* __restrict__ blk_task0, const double* __restrict__ partials, const double* __restrict__ epart,
+        const int* __restrict__ gidx, double* __restrict__ G, int mcon, double* __restrict__ E)
 {
     const int b = blockIdx.x;
-    if (b >= nblk || threadIdx.x >= CNP * CNP) return;
+    if (b >= nblk) return;
+    if (blk_j[b] == blk_k[b] && threadIdx.x >= CNP * CNP && threadIdx.x < CNP * CNP + CNP) {
+        const int q = threadIdx.x - CNP * CNP;
+        double se = 0.0;
+        for (int t = blk_task0[b]; t < blk_task0[b + 1]; ++t) se += epart[(size_t)t * CNP + q];
+        E[(size_t)(blk_j[b] - mcon) * CNP + q] -= se;
+    }
+    if (threadIdx.x >= CNP * CNP) return;
     double s = 0.0;
     for (int t = blk_task0[b]; t < blk_task0[b + 1]; ++t) s += partials[(size_t)t * CNP * CNP + threadIdx.x];
     G[(size_t)gidx[b] * CNP * CNP + threadIdx.x] = s;
@@ -455,41 +404,12 @@ __global__ void k_schur_diag_fill(int m, int mcon, const int* __restrict__ campt
     S[((size_t)(j - mcon) * CNP + row) * ld + (size_t)(j - mcon) * CNP + col] = v;
 }
 
-// E_j = [add_ea] ea_j - sum_i A_ij^T (B_ij (V*_i^-1 eb_i))   (sba_levmar.c:1320-1339); block per camera.
-template <int CNP>
-__global__ __launch_bounds__(256) void k_schur_rhs(DevProblem P, int add_ea, double* __restrict__ E)
+// Reduced right-hand side: E_j starts as ea_j (on the rank that contributes U/ea to a multi-GPU sum, else 0); the tasks of
+// the diagonal blocks subtract sum_i A_ij^T (B_ij V*_i^-1 eb_i) in k_schur_assemble / k_schur_pack (sba_levmar.c:1320-1339).
+__global__ __launch_bounds__(256) void k_rhs_init(int count, int off, int add_ea, const double* __restrict__ ea, double* __restrict__ E)
 {
-    constexpr int JS = 2 * CNP + 6;
-    __shared__ double sm[4][CNP];
-    const int j = P.mcon + blockIdx.x;
-    double acc[CNP];
-#pragma unroll
-    for (int q = 0; q < CNP; ++q) acc[q] = 0.0;
-    const int t1 = P.camptr[j + 1];
-    for (int t = P.camptr[j] + threadIdx.x; t < t1; t += 256) {
-        const int i = P.cam_pt[t];
-        const double* vi = P.Vinv + (size_t)i * 6;
-        const double* g = P.eb + (size_t)i * 3;
-        const double t0 = vi[0] * g[0] + vi[1] * g[1] + vi[2] * g[2];
-        const double t1v = vi[1] * g[0] + vi[3] * g[1] + vi[4] * g[2];
-        const double t2 = vi[2] * g[0] + vi[4] * g[1] + vi[5] * g[2];
-        double A[JS];
-        load_pairs<CNP + 3>(P.Jc + (size_t)t * JS, A);
-        const double* B = A + 2 * CNP;
-        const double s0 = B[0] * t0 + B[1] * t1v + B[2] * t2;
-        const double s1 = B[3] * t0 + B[4] * t1v + B[5] * t2;
-#pragma unroll
-        for (int q = 0; q < CNP; ++q) acc[q] += A[q] * s0 + A[CNP + q] * s1;
-    }
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-    for (int q = 0; q < CNP; ++q) { const double s = wave_sum(acc[q]); if (lane == 0) sm[w][q] = s; }
-    __syncthreads();
-    if (threadIdx.x < CNP) {
-        const double s = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
-        const double base = add_ea ? P.ea[(size_t)j * CNP + threadIdx.x] : 0.0;
-        E[(size_t)(j - P.mcon) * CNP + threadIdx.x] = base - s;
-    }
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < count) E[t] = add_ea ? ea[off + t] : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------

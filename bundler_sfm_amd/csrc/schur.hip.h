@@ -1,10 +1,16 @@
-// schur.hip.h -- Schur-complement task kernel, version 2: coalesced record staging through LDS.
+// schur.hip.h -- Schur-complement task kernel (coalesced record staging through LDS).
 //
-// Same mathematics and the same task structure as k_schur_tasks in kernels.hip.h (one wave per task = <= 168
-// co-visibility triples of ONE block S_jk, 3 lanes per triple, 21 triples per pass, no atomics; reference:
-// lib/sba-1.5/sba_levmar.c:1182-1302).  What changes is the data path:
-//   * v1 lets every lane gather its 42 doubles itself: each wave-level load touches ~20-30 different 128-byte lines;
-//   * v2 reads the two 192-byte Jacobian records of each triple (camera-major copy Jc: consecutive triples of a block
+// S_jk (j <= k) receives sum_i Y_ij W_ik^T = sum_i A_ij^T (B_ij V*_i^-1 B_ik^T) A_ik over the points seen by both cameras
+// (lib/sba-1.5/sba_levmar.c:1182-1302; W is never materialised).  The co-visibility triples (record of (i,j), record of
+// (i,k), point i) were bucketed and ordered once per problem by block; a task = <= 168 triples of ONE block = one wave,
+// 3 lanes per triple (lane r owns output rows r, r+3, r+6), 21 triples per pass, the 21 lane groups are folded with
+// shuffles.  No atomics anywhere: partials are summed in task order by k_schur_assemble => run-to-run deterministic.
+// Tasks of DIAGONAL blocks (j == k) also accumulate this task's part of the reduced right-hand side
+// e_j = ea_j - sum_i A_ij^T (B_ij V*_i^-1 eb_i) (sba_levmar.c:1320-1339): B_ij V*_i^-1 is already there, so E costs one
+// 24-byte gather of eb_i and 8 FMAs per triple instead of a second pass over all Jacobian records (that pass took 0.55 ms).
+// Data path:
+//   * (a first version let every lane gather its 42 doubles itself: each wave-level load touched ~20-30 different lines;)
+//   * this one reads the two 192-byte Jacobian records of each triple (camera-major copy Jc: consecutive triples of a block
 //     are monotone, mostly consecutive records) and the 48-byte V*^-1 with 16-byte-per-lane coalesced loads
 //     (12 lanes per record), parks them in a wave-private LDS slab (record stride 26 doubles: 16-byte aligned, at
 //     most 2-way bank conflicts), prefetches the next pass into registers while the current pass computes, and the
@@ -21,14 +27,15 @@ constexpr int SCH_MAXT = 168;         // triples per task (SCHUR_CHUNK in solver
 
 template <int CNP>
 __global__ __launch_bounds__(256) void k_schur_tasks_v2(DevProblem P, const SchurTask* __restrict__ tasks, int ntasks,
-        const int2* __restrict__ triples, const int* __restrict__ tri_pt, double* __restrict__ partials)
+        const int2* __restrict__ triples, const int* __restrict__ tri_pt, double* __restrict__ partials,
+        double* __restrict__ epart)
 {
     constexpr int JS = 2 * CNP + 6;            // doubles per Jacobian record
     constexpr int RS = JS + 2;                 // LDS record stride (doubles), 16-byte aligned
     constexpr int CH = JS / 2;                 // 16-byte chunks per record
     constexpr int NR = (CNP + 2) / 3;
     constexpr int NA = (SCH_PASS * CH + 63) / 64;      // staging rounds for one record stream
-    constexpr int SLAB = 2 * SCH_PASS * RS + SCH_PASS * 6;
+    constexpr int SLAB = 2 * SCH_PASS * RS + SCH_PASS * 6 + SCH_PASS * 4;
     __shared__ __attribute__((aligned(16))) double sm[4][SLAB];
     __shared__ int sm_tri[4][3 * SCH_MAXT];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -38,24 +45,28 @@ __global__ __launch_bounds__(256) void k_schur_tasks_v2(DevProblem P, const Schu
     double* recA = sm[wave];
     double* recB = recA + SCH_PASS * RS;
     double* vin = recB + SCH_PASS * RS;
+    double* ebin = vin + SCH_PASS * 6;          // eb_i of the pass's points (diagonal-block tasks only), stride 4
     int* tq = sm_tri[wave];
+    const bool diag = tk.diag != 0;
     for (int t = lane; t < tk.count; t += 64) {         // all triples of the task -> LDS (qa, qb, pt)
         const int2 tr = triples[tk.start + t];
         tq[3 * t] = tr.x; tq[3 * t + 1] = tr.y; tq[3 * t + 2] = tri_pt[tk.start + t];
     }
     const int grp = lane / 3, r = lane - 3 * grp;
-    double acc[NR][CNP];
+    double acc[NR][CNP], acce[NR];
 #pragma unroll
-    for (int a = 0; a < NR; ++a)
+    for (int a = 0; a < NR; ++a) {
+        acce[a] = 0.0;
 #pragma unroll
         for (int c = 0; c < CNP; ++c) acc[a][c] = 0.0;
+    }
 
     // staging slots of this lane: chunk c = lane + 64 q  ->  record c / CH, 16-byte part c % CH
     int srec[NA], spart[NA];
 #pragma unroll
     for (int q = 0; q < NA; ++q) { const int c = lane + 64 * q; srec[q] = c / CH; spart[q] = c - srec[q] * CH; }
     const int vrec = lane / 3, vpart = lane - 3 * vrec;
-    double pa[NA][2], pb[NA][2], pv[2];
+    double pa[NA][2], pb[NA][2], pv[2], pe = 0.0;
 
 #define BSFM_SCH_ISSUE(p0_)                                                                                         \
     {                                                                                                               \
@@ -70,6 +81,7 @@ __global__ __launch_bounds__(256) void k_schur_tasks_v2(DevProblem P, const Schu
         if (vrec < np_) {                                                                                           \
             const double2 tv = *reinterpret_cast<const double2*>(P.Vinv + (size_t)tq[3 * ((p0_) + vrec) + 2] * 6 + 2 * vpart); \
             pv[0] = tv.x; pv[1] = tv.y;                                                                             \
+            if (diag) pe = P.eb[(size_t)tq[3 * ((p0_) + vrec) + 2] * 3 + vpart];                                    \
         }                                                                                                           \
     }
 #define BSFM_SCH_PARK(p0_)                                                                                          \
@@ -81,7 +93,10 @@ __global__ __launch_bounds__(256) void k_schur_tasks_v2(DevProblem P, const Schu
                 *reinterpret_cast<double2*>(recB + srec[q] * RS + 2 * spart[q]) = make_double2(pb[q][0], pb[q][1]); \
             }                                                                                                       \
         }                                                                                                           \
-        if (vrec < np_) *reinterpret_cast<double2*>(vin + vrec * 6 + 2 * vpart) = make_double2(pv[0], pv[1]);       \
+        if (vrec < np_) {                                                                                           \
+            *reinterpret_cast<double2*>(vin + vrec * 6 + 2 * vpart) = make_double2(pv[0], pv[1]);                   \
+            if (diag) ebin[vrec * 4 + vpart] = pe;                                                                  \
+        }                                                                                                           \
     }
 
     BSFM_SCH_ISSUE(0)
@@ -112,6 +127,12 @@ __global__ __launch_bounds__(256) void k_schur_tasks_v2(DevProblem P, const Schu
                 T0[c] = m00 * b0 + m01 * b1;
                 T1[c] = m10 * b0 + m11 * b1;
             }
+            double g0 = 0.0, g1 = 0.0;
+            if (diag) {
+                const double e0 = ebin[grp * 4], e1 = ebin[grp * 4 + 1], e2 = ebin[grp * 4 + 2];
+                g0 = c00 * e0 + c01 * e1 + c02 * e2;
+                g1 = c10 * e0 + c11 * e1 + c12 * e2;
+            }
 #pragma unroll
             for (int a = 0; a < NR; ++a) {
                 const int row = r + 3 * a;
@@ -119,6 +140,7 @@ __global__ __launch_bounds__(256) void k_schur_tasks_v2(DevProblem P, const Schu
                     const double a0 = Ja[row], a1 = Ja[CNP + row];
 #pragma unroll
                     for (int c = 0; c < CNP; ++c) acc[a][c] += a0 * T0[c] + a1 * T1[c];
+                    acce[a] += a0 * g0 + a1 * g1;
                 }
             }
         }
@@ -129,12 +151,15 @@ __global__ __launch_bounds__(256) void k_schur_tasks_v2(DevProblem P, const Schu
     for (int s = 16; s > 0; s >>= 1) {
         const bool take = (grp < s) && (grp + s < SCH_PASS);
 #pragma unroll
-        for (int a = 0; a < NR; ++a)
+        for (int a = 0; a < NR; ++a) {
 #pragma unroll
             for (int c = 0; c < CNP; ++c) {
                 const double o = __shfl_down(acc[a][c], 3 * s, 64);
                 if (take) acc[a][c] += o;
             }
+            const double oe = __shfl_down(acce[a], 3 * s, 64);
+            if (take) acce[a] += oe;
+        }
     }
     if (grp == 0) {
         double* out = partials + (size_t)task * CNP * CNP;
@@ -144,6 +169,7 @@ __global__ __launch_bounds__(256) void k_schur_tasks_v2(DevProblem P, const Schu
             if (row < CNP) {
 #pragma unroll
                 for (int c = 0; c < CNP; ++c) out[row * CNP + c] = acc[a][c];
+                if (diag) epart[(size_t)task * CNP + row] = acce[a];
             }
         }
     }

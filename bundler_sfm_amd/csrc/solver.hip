@@ -74,12 +74,14 @@ struct bsfm_problem {
     double *d_Jc = nullptr, *d_U = nullptr, *d_ea = nullptr, *d_V = nullptr, *d_Vinv = nullptr, *d_eb = nullptr;
     double *d_S = nullptr, *d_E = nullptr;
     double *d_partials = nullptr;       // schur task partials
+    double *d_epart = nullptr;          // ... and their parts of the reduced right-hand side (diagonal-block tasks)
+    double *d_campart = nullptr;        // per-camera slice partials of k_cam_blocks / k_schur_rhs (m x CAM_SPLIT x 54)
     double *d_red = nullptr;            // block partials for reductions
     double *d_scal = nullptr;
     int *d_flags = nullptr;             // [0] singular V, [1] potrf info
     // schur structure
     int ntriples = 0, ntasks = 0, nblk = 0;
-    int2* d_triples = nullptr; SchurTask* d_tasks = nullptr; int* d_tri_pt = nullptr; int schur_v1 = 0;
+    int2* d_triples = nullptr; SchurTask* d_tasks = nullptr; int* d_tri_pt = nullptr;
     int *d_blk_j = nullptr, *d_blk_k = nullptr, *d_blk_task0 = nullptr;
     // multi-GPU exchange of the reduced camera system: the UNION over ranks of the non-empty blocks S_jk (j <= k),
     // one cnp x cnp sum per block, is what crosses xGMI -- not the dense (9m)^2 matrix
@@ -109,7 +111,7 @@ void free_all(bsfm_problem* pb)
     void* ptrs[] = { pb->d_x, pb->d_Rinit, pb->d_finit, pb->d_obs_cam, pb->d_obs_pt, pb->d_rowptr, pb->d_camptr,
                      pb->d_camobs, pb->d_campos, pb->d_cam_pt, pb->d_Jc, pb->d_ccon, pb->d_pcon, pb->d_cval, pb->d_cw, pb->d_pval, pb->d_p, pb->d_pdp,
                      pb->d_dp, pb->d_camtab, pb->d_camtab_trial, pb->d_e, pb->d_hx, pb->d_U,
-                     pb->d_V, pb->d_Vinv, pb->d_eb, pb->d_S, pb->d_E, pb->d_partials, pb->d_red, pb->d_scal,
+                     pb->d_V, pb->d_Vinv, pb->d_eb, pb->d_S, pb->d_E, pb->d_partials, pb->d_epart, pb->d_campart, pb->d_red, pb->d_scal,
                      pb->d_flags, pb->d_triples, pb->d_tri_pt, pb->d_tasks, pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0,
                      pb->d_gidx, pb->d_gblk_j, pb->d_gblk_k, pb->d_G };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -181,7 +183,7 @@ int build_schur_structure(bsfm_problem* pb, const bsfm_problem_desc_t* d, const 
     for (int b = 0; b < nblk; ++b) {
         blk_task0[b] = (int)tasks.size();
         for (int s = blk_start[b]; s < blk_start[b + 1]; s += SCHUR_CHUNK)
-            tasks.push_back({ s, std::min(SCHUR_CHUNK, blk_start[b + 1] - s) });
+            tasks.push_back({ s, std::min(SCHUR_CHUNK, blk_start[b + 1] - s), blk_j[b] == blk_k[b] ? 1 : 0 });
     }
     blk_task0[nblk] = (int)tasks.size();
     pb->ntriples = (int)total; pb->ntasks = (int)tasks.size(); pb->nblk = nblk;
@@ -189,13 +191,13 @@ int build_schur_structure(bsfm_problem* pb, const bsfm_problem_desc_t* d, const 
     HIP_OK(dmalloc(&pb->d_triples, total)); HIP_OK(dmalloc(&pb->d_tasks, tasks.size()));
     HIP_OK(dmalloc(&pb->d_blk_j, nblk)); HIP_OK(dmalloc(&pb->d_blk_k, nblk)); HIP_OK(dmalloc(&pb->d_blk_task0, nblk + 1));
     HIP_OK(dmalloc(&pb->d_partials, tasks.size() * (size_t)pb->cnp * pb->cnp));
+    HIP_OK(dmalloc(&pb->d_epart, tasks.size() * (size_t)pb->cnp));
     if (total) HIP_OK(hipMemcpy(pb->d_triples, triples.data(), total * sizeof(int2), hipMemcpyHostToDevice));
     {   // point index of every triple (V*^-1 lookup without a dependent gather through cam_pt)
         std::vector<int> tri_pt(total);
         for (size_t q = 0; q < total; ++q) tri_pt[q] = cam_pt[triples[q].x];
         HIP_OK(dmalloc(&pb->d_tri_pt, total));
         if (total) HIP_OK(hipMemcpy(pb->d_tri_pt, tri_pt.data(), total * sizeof(int), hipMemcpyHostToDevice));
-        pb->schur_v1 = getenv("BSFM_SCHUR_V1") ? 1 : 0;
     }
     if (!tasks.empty()) HIP_OK(hipMemcpy(pb->d_tasks, tasks.data(), tasks.size() * sizeof(SchurTask), hipMemcpyHostToDevice));
     if (nblk) {
@@ -313,7 +315,8 @@ int compute_normal_blocks(bsfm_problem* pb)
     }
     ph_end(pb, PH_JAC);
     ph_begin(pb, PH_CAMBLK);
-    DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_cam_blocks<C>), dim3(P.m), dim3(256), 0, pb->stream, P, pb->d_e));
+    DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_cam_blocks<C>), dim3(P.m * CAM_SPLIT), dim3(256), 0, pb->stream, P, pb->d_e, pb->d_campart));
+    DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_cam_blocks_fin<C>), dim3(P.m), dim3(128), 0, pb->stream, P, pb->d_campart));
     ph_end(pb, PH_CAMBLK);
     if (pb->world > 1) {   // U and ea are sums over ALL points: exchange step 1, 90*m doubles
         if (allreduce_dev(pb, pb->d_U, (size_t)P.m * cnp * cnp + (size_t)P.m * cnp, 0)) return BSFM_ERROR;   // ea follows U
@@ -380,31 +383,28 @@ int compute_schur(bsfm_problem* pb, double mu)
     if (packed && pb->ngblk < 0 && exchange_block_union(pb)) return BSFM_ERROR;
     (void)hipMemsetAsync(pb->d_S, 0, (size_t)pb->ld * pb->ld * sizeof(double), pb->stream);
     if (packed) (void)hipMemsetAsync(pb->d_G, 0, ((size_t)pb->ngblk * cnp * cnp + (size_t)pb->ld) * sizeof(double), pb->stream);
+    double* Edst = packed ? pb->d_G + (size_t)pb->ngblk * cnp * cnp : pb->d_E;     // packed: E rides behind the blocks
+    if (mm > 0)
+        hipLaunchKernelGGL(k_rhs_init, dim3(grid_for((size_t)mm * cnp, 256)), dim3(256), 0, pb->stream, mm * cnp, P.mcon * cnp,
+                           lead, pb->d_ea, Edst);
     if (pb->ntasks > 0) {
-        if (pb->schur_v1) {
-            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks<C>), dim3((pb->ntasks + 3) / 4), dim3(256), 0, pb->stream,
-                                                  P, pb->d_tasks, pb->ntasks, pb->d_triples, pb->d_partials));
-        } else {
-            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks_v2<C>), dim3((pb->ntasks + 3) / 4), dim3(256), 0, pb->stream,
-                                                  P, pb->d_tasks, pb->ntasks, pb->d_triples, pb->d_tri_pt, pb->d_partials));
-        }
+        DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks_v2<C>), dim3((pb->ntasks + 3) / 4), dim3(256), 0, pb->stream,
+                                              P, pb->d_tasks, pb->ntasks, pb->d_triples, pb->d_tri_pt, pb->d_partials, pb->d_epart));
         if (packed) {
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_pack<C>), dim3(pb->nblk), dim3(128), 0, pb->stream, pb->nblk,
-                                                  pb->d_blk_task0, pb->d_partials, pb->d_gidx, pb->d_G));
+                                                  pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0, pb->d_partials, pb->d_epart,
+                                                  pb->d_gidx, pb->d_G, P.mcon, Edst));
         } else {
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_assemble<C>), dim3(pb->nblk), dim3(128), 0, pb->stream, pb->nblk,
-                                                  pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0, pb->d_partials, pb->d_U, mu,
-                                                  P.mcon, pb->d_S, pb->ld));
+                                                  pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0, pb->d_partials, pb->d_epart,
+                                                  pb->d_U, mu, P.mcon, pb->d_S, pb->ld, Edst));
         }
     }
     if (packed) {
-        // exchange step 2: the block sums of the union structure; U was already summed over ranks, so every
-        // rank then assembles the SAME S = [j==k](U_j + mu I) - G_jk and solves it redundantly (no broadcast of the step)
-        double* Etail = pb->d_G + (size_t)pb->ngblk * cnp * cnp;
-        if (mm > 0)
-            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_rhs<C>), dim3(mm), dim3(256), 0, pb->stream, P, lead, Etail));
+        // exchange step 2: the block sums of the union structure and E in ONE buffer; U was already summed over
+        // ranks, so every rank then assembles the SAME S = [j==k](U_j + mu I) - G_jk and solves it redundantly
         if (allreduce_dev(pb, pb->d_G, (size_t)pb->ngblk * cnp * cnp + (size_t)pb->Sdim, 0)) return BSFM_ERROR;
-        (void)hipMemcpyAsync(pb->d_E, Etail, (size_t)pb->Sdim * sizeof(double), hipMemcpyDeviceToDevice, pb->stream);
+        (void)hipMemcpyAsync(pb->d_E, Edst, (size_t)pb->Sdim * sizeof(double), hipMemcpyDeviceToDevice, pb->stream);
         if (mm > 0)
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_diag_fill<C>), dim3(mm), dim3(128), 0, pb->stream, P.m, P.mcon,
                                                   (const int*)nullptr, pb->d_U, mu, pb->d_S, pb->ld));
@@ -415,8 +415,6 @@ int compute_schur(bsfm_problem* pb, double mu)
         DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_diag_fill<C>), dim3(mm), dim3(128), 0, pb->stream, P.m, P.mcon,
                                               pb->d_camptr, pb->d_U, mu, pb->d_S, pb->ld));
     }
-    if (!packed && mm > 0)
-        DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_rhs<C>), dim3(mm), dim3(256), 0, pb->stream, P, lead, pb->d_E));
     return 0;
 }
 
@@ -505,7 +503,7 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     DM(pb->d_p, pb->nvars_local); DM(pb->d_pdp, pb->nvars_local); DM(pb->d_dp, pb->nvars_local);
     DM(pb->d_camtab, (size_t)m * CT_STRIDE); DM(pb->d_camtab_trial, (size_t)m * CT_STRIDE);
     DM(pb->d_e, 2 * (size_t)nvis); DM(pb->d_hx, 2 * (size_t)nvis);
-    DM(pb->d_Jc, (size_t)nvis * P.js); DM(pb->d_campos, nvis); DM(pb->d_cam_pt, nvis); DM(pb->d_U, (size_t)m * cnp * cnp + (size_t)m * cnp); pb->d_ea = pb->d_U + (size_t)m * cnp * cnp;   /* one buffer: one exchange */
+    DM(pb->d_Jc, (size_t)nvis * P.js); DM(pb->d_campart, (size_t)m * CAM_SPLIT * (cnp * (cnp + 1) / 2 + cnp)); DM(pb->d_campos, nvis); DM(pb->d_cam_pt, nvis); DM(pb->d_U, (size_t)m * cnp * cnp + (size_t)m * cnp); pb->d_ea = pb->d_U + (size_t)m * cnp * cnp;   /* one buffer: one exchange */
     DM(pb->d_V, 6 * (size_t)n); DM(pb->d_Vinv, 6 * (size_t)n); DM(pb->d_eb, 3 * (size_t)n);
     DM(pb->d_S, (size_t)pb->ld * pb->ld); DM(pb->d_E, pb->ld);
     pb->red_blocks = std::max(grid_for(nvis, RES_BLOCK), std::max(grid_for(n, 256), 1024));
