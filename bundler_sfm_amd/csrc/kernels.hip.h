@@ -404,6 +404,22 @@ __global__ void k_schur_diag_fill(int m, int mcon, const int* __restrict__ campt
     S[((size_t)(j - mcon) * CNP + row) * ld + (size_t)(j - mcon) * CNP + col] = v;
 }
 
+// S is rebuilt for every solve attempt (the factorisation overwrites it and fills in its zero blocks).  Only the lower
+// triangle of 128x128 tiles is read by the factorisation, so only that half is cleared: one workgroup per tile,
+// 16-byte stores.  (The strictly upper tiles keep whatever the mirror writes of the assembly put there.)
+__global__ __launch_bounds__(256) void k_zero_lower_tiles(double* __restrict__ S, int ld)
+{
+    int a = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= (int)blockIdx.x) ++a;
+    while (a * (a + 1) / 2 > (int)blockIdx.x) --a;
+    const int b = blockIdx.x - a * (a + 1) / 2;          // tile (a, b), b <= a
+    double* T = S + ((size_t)a * 128) * ld + (size_t)b * 128;
+    for (int idx = threadIdx.x; idx < 128 * 64; idx += 256) {
+        const int r = idx >> 6, c2 = (idx & 63) * 2;
+        *reinterpret_cast<double2*>(T + (size_t)r * ld + c2) = make_double2(0.0, 0.0);
+    }
+}
+
 // Reduced right-hand side: E_j starts as ea_j (on the rank that contributes U/ea to a multi-GPU sum, else 0); the tasks of
 // the diagonal blocks subtract sum_i A_ij^T (B_ij V*_i^-1 eb_i) in k_schur_assemble / k_schur_pack (sba_levmar.c:1320-1339).
 __global__ __launch_bounds__(256) void k_rhs_init(int count, int off, int add_ea, const double* __restrict__ ea, double* __restrict__ E)

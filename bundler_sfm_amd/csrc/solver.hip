@@ -73,6 +73,7 @@ struct bsfm_problem {
     double *d_e = nullptr, *d_hx = nullptr;
     double *d_Jc = nullptr, *d_U = nullptr, *d_ea = nullptr, *d_V = nullptr, *d_Vinv = nullptr, *d_eb = nullptr;
     double *d_S = nullptr, *d_E = nullptr;
+    int export_full_s = 0;              // bsfm_eval_normal_equations hands S out as a full symmetric matrix: clear all of it
     double *d_partials = nullptr;       // schur task partials
     double *d_epart = nullptr;          // ... and their parts of the reduced right-hand side (diagonal-block tasks)
     double *d_campart = nullptr;        // per-camera slice partials of k_cam_blocks / k_schur_rhs (m x CAM_SPLIT x 54)
@@ -381,7 +382,8 @@ int compute_schur(bsfm_problem* pb, double mu)
     const int lead = pb->rank == 0 ? 1 : 0;
     const bool packed = pb->world > 1 && pb->allreduce;
     if (packed && pb->ngblk < 0 && exchange_block_union(pb)) return BSFM_ERROR;
-    (void)hipMemsetAsync(pb->d_S, 0, (size_t)pb->ld * pb->ld * sizeof(double), pb->stream);
+    if (pb->export_full_s) (void)hipMemsetAsync(pb->d_S, 0, (size_t)pb->ld * pb->ld * sizeof(double), pb->stream);
+    else { const int nt = pb->ld / POTRF_NB; hipLaunchKernelGGL(k_zero_lower_tiles, dim3(nt * (nt + 1) / 2), dim3(256), 0, pb->stream, pb->d_S, pb->ld); }
     if (packed) (void)hipMemsetAsync(pb->d_G, 0, ((size_t)pb->ngblk * cnp * cnp + (size_t)pb->ld) * sizeof(double), pb->stream);
     double* Edst = packed ? pb->d_G + (size_t)pb->ngblk * cnp * cnp : pb->d_E;     // packed: E rides behind the blocks
     if (mm > 0)
@@ -878,7 +880,10 @@ int bsfm_eval_normal_equations(bsfm_problem_t* pb, double mu, double* U, double*
     if (compute_normal_blocks(pb)) return BSFM_ERROR;
     (void)hipMemsetAsync(pb->d_flags, 0, 4 * sizeof(int), pb->stream);
     if (n > 0) hipLaunchKernelGGL(k_point_invert, dim3(grid_for(n, 256)), dim3(256), 0, pb->stream, n, mu, pb->d_V, pb->d_Vinv, pb->d_flags);
-    if (compute_schur(pb, mu)) return BSFM_ERROR;
+    pb->export_full_s = 1;            // S is copied out below as a full symmetric matrix
+    const int rc_schur = compute_schur(pb, mu);
+    pb->export_full_s = 0;
+    if (rc_schur) return BSFM_ERROR;
     HIP_OK(hipStreamSynchronize(pb->stream));
     if (U) {
         std::vector<double> h((size_t)m * cnp * cnp);
