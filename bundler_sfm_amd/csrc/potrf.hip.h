@@ -461,10 +461,10 @@ __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __re
 // Diagonal tile: Cholesky factor AND its inverse in ONE 512-thread workgroup -- the serial critical path of the
 // factorisation, so it is blocked to keep the truly serial work tiny:
 //   * the 128x128 tile lives in LDS (row stride 132 doubles) as 8x8 blocks of 16x16;
-//   * phase A, per block column s: wave 0 factors the 16x16 diagonal block (and inverts it) column by column with
-//     no workgroup barrier (single wave: LDS ops are in order); then the waves form the panel blocks
-//     T[I][s] <- T[I][s] * inv(L_ss)^T and the trailing updates T[I][J] -= T[I][s] T[J][s]^T as 16x16x16 products on
-//     v_mfma_f64_4x4x4_4b (16 instructions each);
+//   * phase A, per block column s: wave 0 factors the 16x16 diagonal block with one lane per row (v_readlane
+//     broadcasts, no LDS traffic); the rows of the panel blocks below are solved against it by one thread each (forward
+//     substitution in registers) while an idle wave derives inv(L_ss) the same way; the trailing updates
+//     T[I][J] -= T[I][s] T[J][s]^T are 16x16x16 products on v_mfma_f64_4x4x4_4b (16 instructions each);
 //   * phase B, inverse: X = inv(L) by block forward substitution, ONE WAVE PER BLOCK COLUMN J and no barriers:
 //     X[I][J] = -inv(L_II) * sum_{K=J}^{I-1} L[I][K] X[K][J]; X[K][J]^T is parked in the unused upper block T[J][K]
 //     so that every product is of the A * Bt^T ("NT") form the MFMA fragments read directly from LDS.
@@ -528,44 +528,28 @@ __global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int 
     long long tA1 = 0, tA2 = 0, tA3 = 0, tq = 0;
     for (int s = 0; s < 8; ++s) {
         if (dbg && threadIdx.x == 0) tq = wall_clock64();
-        // ---- A1: wave 0 factors the diagonal block (s,s) and its inverse, entirely in registers:
-        // lane (r = l&15, cg = l>>4) owns D[r][4cg..4cg+3] and X[r][4cg..4cg+3]; per column the pivot comes by
-        // v_readlane, the column / X-row by ds_bpermute (no LDS round trip, no barrier); the rank-1 updates use
-        // 1/pivot (v_rcp_f64 + 2 Newton steps) and all square roots are deferred to the end of the block.
+        // ---- A1: wave 0 factors the diagonal block (s,s) in registers, ONE LANE PER ROW (lanes 16.. mirror lane & 15):
+        // lane r holds D[r][0..15]; per column the pivot and the column entries D[c][j] come by v_readlane (static lane
+        // ids -> SGPR operands, no LDS round trip), the multiplier uses 1/pivot (v_rcp_f64 + 2 Newton steps), and all
+        // square roots are deferred to the end of the block (L = raw column * 1/sqrt(pivot)).  Entries above the
+        // diagonal take part in the updates unmasked: they are never read.
         if (wave == 0) {
             double* B = T + (16 * s) * DG_TS + 16 * s;
-            const int r = lane & 15, cg = lane >> 4;
-            double d[4], x[4], pv[16];
+            const int r = lane & 15;
+            double d[16], pv[16];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int c = 4 * cg + t;
-                d[t] = (c <= r) ? B[r * DG_TS + c] : 0.0;
-                x[t] = (c == r) ? 1.0 : 0.0;
-            }
+            for (int c = 0; c < 16; ++c) d[c] = B[r * DG_TS + c];
+#define BSFM_RDLANE(v, l) __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), (l)), __builtin_amdgcn_readlane(__double2loint(v), (l)))
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const int jq = j >> 2, jo = j & 3;
-                const double mine = d[jo];                                  // static register select (j is unrolled)
-                const double col_r = __shfl(mine, r + 16 * jq, 64);
-                double col_c[4], xrow[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    col_c[t] = __shfl(mine, 4 * cg + t + 16 * jq, 64);
-                    xrow[t] = __shfl(x[t], j + 16 * cg, 64);
-                }
-                const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), j + 16 * jq),
-                                                    __builtin_amdgcn_readlane(__double2loint(mine), j + 16 * jq));
+                const double piv = BSFM_RDLANE(d[j], j);
                 pv[j] = piv;
                 double inv = __builtin_amdgcn_rcp(piv);
                 inv = fma(fma(-piv, inv, 1.0), inv, inv);
                 inv = fma(fma(-piv, inv, 1.0), inv, inv);
-                const double lr = (r > j) ? col_r * inv : 0.0;
+                const double lr = d[j] * inv;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int c = 4 * cg + t;
-                    d[t] -= lr * ((c > j) ? col_c[t] : 0.0);
-                    x[t] -= lr * xrow[t];
-                }
+                for (int c = j + 1; c < 16; ++c) { const double sc = BSFM_RDLANE(d[j], c); d[c] -= lr * sc; }
             }
             // first non-positive pivot = dpotrf's info
             if (lane == 0) {
@@ -573,30 +557,50 @@ __global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int 
 #pragma unroll
                 for (int j = 15; j >= 0; --j) if (!(pv[j] > 0.0)) bad = j;
                 if (bad >= 0 && base + 16 * s + bad < n_total) atomicCAS(info, 0, base + 16 * s + bad + 1);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) svec[16 * s + j] = pv[j];
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const double s_r = rsqrt_f64(svec[16 * s + r]);
+            double myp = pv[0];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int c = 4 * cg + t;
-                const double s_c = rsqrt_f64(svec[16 * s + c]);
-                B[r * DG_TS + c] = (c <= r) ? d[t] * s_c : 0.0;             // L = raw column * 1/sqrt(pivot)
-                Di[s * 256 + r * 16 + c] = (c <= r) ? x[t] * s_r : 0.0;     // inv(L_ss) row r = raw row * 1/sqrt(pivot_r)
+            for (int c = 1; c < 16; ++c) myp = (r == c) ? pv[c] : myp;
+            const double myrs = rsqrt_f64(myp);                       // 1 / L[r][r]
+            if (lane < 16) {
+                svec[16 * s + r] = myrs;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const double rs_c = BSFM_RDLANE(myrs, c);
+                    B[r * DG_TS + c] = (c <= r) ? d[c] * rs_c : 0.0;
+                }
             }
+#undef BSFM_RDLANE
         }
         __syncthreads();
         if (dbg && threadIdx.x == 0) { const long long t = wall_clock64(); tA1 += t - tq; tq = t; }
-        // ---- A2: panel blocks I = s+1 .. 7 : T[I][s] <- T[I][s] * inv(L_ss)^T
+        // ---- A2: rows of the panel blocks below, x <- x * inv(L_ss)^T by forward substitution, ONE THREAD PER ROW with
+        // the 16 entries in registers (L_ss and 1/diag are wave-uniform LDS broadcasts): no cross-lane traffic at all.
+        // Wave 7 meanwhile runs the SAME substitution on the rows of the identity: row c of inv(L_ss)^T = column c of
+        // inv(L_ss), the diagonal block of the inverse that phase B needs -- off the critical path.
         {
-            const int I = s + 1 + wave;
-            if (I < 8) {
-                double* X = T + (16 * I) * DG_TS + 16 * s;
-                double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
-                mma16_nt(acc, X, DG_TS, Di + s * 256, 16, lane);
+            const double* Lb = T + (16 * s) * DG_TS + 16 * s;
+            const int nrows = (7 - s) * 16;
+            const bool inv_job = (wave == 7 && lane < 16);
+            if (inv_job || tid < nrows) {
+                double* X = T + (size_t)(16 * (s + 1) + tid) * DG_TS + 16 * s;
+                double t[16];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) X[(4 * a + (lane >> 4)) * DG_TS + (lane & 15)] = acc[a];
+                for (int c = 0; c < 16; ++c) t[c] = inv_job ? ((c == lane) ? 1.0 : 0.0) : X[c];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const double xc = t[c] * svec[16 * s + c];
+                    t[c] = xc;
+#pragma unroll
+                    for (int kq = c + 1; kq < 16; ++kq) t[kq] -= xc * Lb[kq * DG_TS + c];
+                }
+                if (inv_job) {
+#pragma unroll
+                    for (int rr = 0; rr < 16; ++rr) Di[s * 256 + rr * 16 + lane] = t[rr];     // inv(L_ss)[rr][lane]
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) X[c] = t[c];
+                }
             }
         }
         __syncthreads();
