@@ -68,18 +68,38 @@ def syrk_flops_per_launch(sdim):
     return 2.0 * NB ** 3 * sum(tiles) / max(len(tiles), 1), len(tiles)
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed PMC summary (counters need their own profiler passes,
-    so they cannot be collected inside this run); None when no summary is committed."""
+def pmc_summary():
+    """Newest committed PMC summary (counters need their own profiler passes, so they cannot be collected inside this run)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    if not files:
-        return None
     try:
-        k = json.load(open(files[-1]))["kernels"].get(kernel)
-        return None if not k else round(k["traffic_bytes"])
+        return (json.load(open(files[-1])), os.path.basename(files[-1])) if files else (None, None)
     except Exception:
+        return None, None
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from that summary; None when no summary is committed."""
+    d, _ = pmc_summary()
+    k = d["kernels"].get(kernel) if d else None
+    return None if not k else round(k["traffic_bytes"])
+
+
+def pmc_mfma(kernel):
+    """MFMA-busy evidence of `kernel` from the same summary: SQ_VALU_MFMA_BUSY_CYCLES per launch (summed over SIMDs),
+    its share of all SIMD cycles of the device (GRBM_GUI_ACTIVE is summed over the 8 XCDs) and of the busy CU cycles."""
+    d, name = pmc_summary()
+    c = (d["kernels"].get(kernel) or {}).get("counters") if d else None
+    if not c or "SQ_VALU_MFMA_BUSY_CYCLES" not in c:
         return None
+    out = {"source": "profiles/" + name, "SQ_VALU_MFMA_BUSY_CYCLES": round(c["SQ_VALU_MFMA_BUSY_CYCLES"])}
+    if c.get("GRBM_GUI_ACTIVE"):
+        out["mfma_busy_of_all_simd_cycles"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 256 * 4), 4)
+    if c.get("SQ_BUSY_CU_CYCLES"):
+        out["mfma_busy_of_busy_cu_cycles"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_BUSY_CU_CYCLES"]), 4)
+        if c.get("GRBM_GUI_ACTIVE"):
+            out["cu_busy_fraction"] = round(c["SQ_BUSY_CU_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 256), 4)
+    return out
 
 
 def cpu_baseline(sample):
@@ -195,8 +215,22 @@ def main():
                     "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                     "this command (scripts/profile_round.sh -> profiles/*_pmc_traffic.json; 2 x FETCH_SIZE "
                                     "per the gfx950 correction); algorithmic C traffic is 2 x 128 KB per tile",
-                    "launches_per_solve": nlaunch, "avg_launch_ms": round(syrk_ms, 4),
+                    "mfma_counters": pmc_mfma("k_syrk_update"), "launches_per_solve": nlaunch, "avg_launch_ms": round(syrk_ms, 4),
                     "alg_flop_per_launch": flops_launch}
+        # HBM-bound streaming kernels against the 8 TB/s roof: algorithmic bytes / HIP-event time
+        nv_loc, np_loc, js = float(k1 - k0), float(hi - lo), 2 * cnp + 6
+        deg2 = float(np.sum(np.diff(rp).astype(np.float64) * (np.diff(rp) + 1) / 2))        # co-visibility triples
+        alg = {"jacobian": nv_loc * (8 * js + 12 + 24), "cam_blocks": nv_loc * (16 * cnp + 16 + 4),
+               "point_blocks": nv_loc * (48 + 16 + 4) + np_loc * 72, "backsub": nv_loc * (8 * js + 8) + np_loc * 120,
+               "residual": nv_loc * 56, "schur": deg2 * (2 * 8 * js + 48) + nv_loc * 24}
+        hbm = {}
+        for ph, nbytes in alg.items():
+            ms = phases.get(ph, 0.0)
+            if ms and ms > 0:
+                gbs = nbytes / (ms * 1e-3) / 1e9
+                hbm[ph] = {"alg_GB": round(nbytes / 1e9, 3), "ms": ms, "GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / 8000.0, 3)}
+        hbm["note"] = ("algorithmic bytes per phase over its HIP-event time; schur counts the record gathers of all co-visibility "
+                       "triples (served by L2/Infinity Cache: its unique footprint is the 8*js bytes per observation)")
         out = {
             "metric": "BA LM iterations/sec", "value": round(done / elapsed, 4), "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -206,7 +240,7 @@ def main():
                                    f"cnp=9, {args.jacobian} Jacobian, point-sharded x{world}",
                        "cameras": m, "points": n, "observations": nvis_global, "jacobian": args.jacobian,
                        "solve_attempts_per_step": round(att / max(done, 1), 3), "problem_create_s": round(t_create, 2)},
-            "phases_ms": phases, "final_cost": info[1], "initial_cost": info[0],
+            "phases_ms": phases, "hbm_kernels": hbm, "final_cost": info[1], "initial_cost": info[0],
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
