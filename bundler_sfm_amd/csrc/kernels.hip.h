@@ -595,6 +595,93 @@ __global__ __launch_bounds__(256) void k_constraint_cost(DevProblem P, const dou
     if (threadIdx.x == 0) *out = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Post-solve statistics of RunSFM_SBA (src/Bundle.cpp:659-913) on the resident problem.
+// dist = |x - proj(p)| per observation, stored in observation order and at its camera-major position
+__global__ __launch_bounds__(256) void k_obs_dist(int nvis, const double* __restrict__ e, const int* __restrict__ campos,
+                                                  double* __restrict__ dist, double* __restrict__ dist_cm)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nvis) return;
+    const double2 ee = reinterpret_cast<const double2*>(e)[k];
+    const double d = sqrt(ee.x * ee.x + ee.y * ee.y);
+    dist[k] = d; dist_cm[campos[k]] = d;
+}
+
+// Per camera: the k-th smallest distance for k = iround(0.8 n) and iround(0.5 n) (kth_element_copy, lib/imagelib/
+// qsort.c:152-203 -- returns 0.0 when k >= n, which happens for n <= 2), the mean, and the outlier threshold
+// clamp(1.2 * 2.0 * kth80, min_thr, max_thr) (Bundle.cpp:761-771).  Exact selection without sorting: distances are >= 0,
+// so their bit patterns order like unsigned integers; 8 passes of an 8-bit histogram narrow the prefix of the k-th key.
+__global__ __launch_bounds__(256) void k_cam_dist_stats(int m, const int* __restrict__ camptr, const double* __restrict__ dist_cm,
+        double min_thr, double max_thr, int* __restrict__ nobs, double* __restrict__ mean, double* __restrict__ kth80,
+        double* __restrict__ kth50, double* __restrict__ thresh)
+{
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ int s_k;
+    __shared__ double sm[4];
+    const int j = blockIdx.x;
+    const int t0 = camptr[j], n = camptr[j + 1] - t0;
+    const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(dist_cm) + t0;
+    double res[2] = { 0.0, 0.0 };
+    for (int which = 0; which < 2; ++which) {
+        const double frac = which == 0 ? 0.8 : 0.5;
+        const int kk = (int)(frac * n + 0.5);                  // iround, lib/imagelib/util.c:75-81 (n >= 0)
+        if (kk >= n) continue;                                  // "[kth_element] Error: k should be < n" -> 0.0
+        if (threadIdx.x == 0) { s_prefix = 0ull; s_k = kk; }
+        __syncthreads();
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            hist[threadIdx.x] = 0u;
+            __syncthreads();
+            const unsigned long long prefix = s_prefix;
+            const unsigned long long himask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+            for (int t = threadIdx.x; t < n; t += 256) {
+                const unsigned long long key = keys[t];
+                if ((key & himask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int k = s_k; unsigned b = 0;
+                while (k >= (int)hist[b]) { k -= (int)hist[b]; ++b; }
+                s_k = k; s_prefix = prefix | ((unsigned long long)b << shift);
+            }
+            __syncthreads();
+        }
+        res[which] = __longlong_as_double((long long)s_prefix);
+        __syncthreads();
+    }
+    double sacc = 0.0;
+    for (int t = threadIdx.x; t < n; t += 256) sacc += dist_cm[t0 + t];
+    sacc = wave_sum(sacc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = sacc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double tot = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+        nobs[j] = n; mean[j] = n > 0 ? tot / n : 0.0;
+        kth80[j] = res[0]; kth50[j] = res[1];
+        double th = 1.2 * 2.0 * res[0];
+        th = th < min_thr ? min_thr : (th > max_thr ? max_thr : th);
+        thresh[j] = th;
+    }
+}
+
+// A point is an outlier when one of its observations lies above its camera's threshold; the reference records the error
+// of the first such observation in camera order (Bundle.cpp:806-821) = ascending camera index = CRS row order.
+// Constrained points are exempt -- the reference only tests the x component of the constraint (Bundle.cpp:800-804).
+__global__ __launch_bounds__(256) void k_point_outliers(int n, const int* __restrict__ rowptr, const int* __restrict__ obs_cam,
+        const double* __restrict__ dist, const double* __restrict__ thresh, const double* __restrict__ pval,
+        unsigned char* __restrict__ flag, double* __restrict__ err)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned char f = 0; double ev = 0.0;
+    if (!(pval && pval[3 * (size_t)i] != 0.0)) {
+        for (int k = rowptr[i]; k < rowptr[i + 1]; ++k)
+            if (dist[k] > thresh[obs_cam[k]]) { f = 1; ev = dist[k]; break; }
+    }
+    flag[i] = f; err[i] = ev;
+}
+
 // expand packed V (+mu) to the reference's full symmetric 3x3 per point (test/export helper)
 __global__ void k_expand_v(int n, double mu, const double* __restrict__ V, double* __restrict__ out)
 {

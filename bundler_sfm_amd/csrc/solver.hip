@@ -859,6 +859,50 @@ int bsfm_problem_download(bsfm_problem_t* pb, double* p_out, bsfm_camera_params_
     return 0;
 }
 
+int bsfm_problem_outlier_stats(bsfm_problem_t* pb, double min_thr, double max_thr, int* cam_nobs, double* cam_mean,
+                               double* cam_kth80, double* cam_kth50, double* cam_thresh,
+                               unsigned char* point_outlier, double* point_err, double* global_mean)
+{
+    const int m = pb->P.m, n = pb->P.n, nvis = pb->P.nvis;
+    // residuals at the current parameters (idempotent for the LM state: d_e always holds e(p))
+    launch_cam_table(pb, pb->d_p, pb->d_camtab);
+    launch_residual(pb, pb->d_camtab, pb->d_p, pb->d_e, nullptr, SC_COST);
+    double *dist = nullptr, *dist_cm = nullptr, *stats = nullptr, *perr = nullptr; int* cnt = nullptr; unsigned char* pflag = nullptr;
+    auto cleanup = [&] { for (void* q : { (void*)dist, (void*)dist_cm, (void*)stats, (void*)perr, (void*)cnt, (void*)pflag }) if (q) (void)hipFree(q); };
+    if (dmalloc(&dist, (size_t)nvis) != hipSuccess || dmalloc(&dist_cm, (size_t)nvis) != hipSuccess ||
+        dmalloc(&stats, (size_t)4 * m) != hipSuccess || dmalloc(&perr, (size_t)n) != hipSuccess ||
+        dmalloc(&cnt, (size_t)m) != hipSuccess || dmalloc(&pflag, (size_t)n) != hipSuccess) { cleanup(); return BSFM_ERROR; }
+    if (nvis > 0)
+        hipLaunchKernelGGL(k_obs_dist, dim3(grid_for(nvis, 256)), dim3(256), 0, pb->stream, nvis, pb->d_e, pb->d_campos, dist, dist_cm);
+    if (m > 0)
+        hipLaunchKernelGGL(k_cam_dist_stats, dim3(m), dim3(256), 0, pb->stream, m, pb->d_camptr, dist_cm, min_thr, max_thr,
+                           cnt, stats, stats + m, stats + 2 * (size_t)m, stats + 3 * (size_t)m);
+    if (n > 0)
+        hipLaunchKernelGGL(k_point_outliers, dim3(grid_for(n, 256)), dim3(256), 0, pb->stream, n, pb->d_rowptr, pb->d_obs_cam, dist,
+                           stats + 3 * (size_t)m, pb->d_pcon ? pb->d_pval : (const double*)nullptr, pflag, perr);
+    if (hipStreamSynchronize(pb->stream) != hipSuccess) { cleanup(); return BSFM_ERROR; }
+    std::vector<double> h((size_t)4 * m); std::vector<int> hc((size_t)m);
+    bool ok = true;
+    if (m > 0) {
+        ok = ok && hipMemcpy(h.data(), stats, h.size() * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+        ok = ok && hipMemcpy(hc.data(), cnt, hc.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (cam_nobs) memcpy(cam_nobs, hc.data(), hc.size() * sizeof(int));
+    if (cam_mean) memcpy(cam_mean, h.data(), (size_t)m * sizeof(double));
+    if (cam_kth80) memcpy(cam_kth80, h.data() + m, (size_t)m * sizeof(double));
+    if (cam_kth50) memcpy(cam_kth50, h.data() + 2 * (size_t)m, (size_t)m * sizeof(double));
+    if (cam_thresh) memcpy(cam_thresh, h.data() + 3 * (size_t)m, (size_t)m * sizeof(double));
+    if (global_mean) {            // Bundle.cpp:846-849: sum of the per-camera sums over all observations
+        double tot = 0.0; long long cntall = 0;
+        for (int j = 0; j < m; ++j) { tot += h[j] * hc[j]; cntall += hc[j]; }
+        *global_mean = cntall ? tot / (double)cntall : 0.0;
+    }
+    if (point_outlier && n > 0) ok = ok && hipMemcpy(point_outlier, pflag, (size_t)n, hipMemcpyDeviceToHost) == hipSuccess;
+    if (point_err && n > 0) ok = ok && hipMemcpy(point_err, perr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+    cleanup();
+    return ok ? 0 : BSFM_ERROR;
+}
+
 int bsfm_eval_residuals(bsfm_problem_t* pb, double* e_out, double* cost)
 {
     launch_cam_table(pb, pb->d_p, pb->d_camtab);

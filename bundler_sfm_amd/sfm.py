@@ -164,6 +164,20 @@ class Problem:
             raise RuntimeError("download failed")
         return p, cams, pts
 
+    def outlier_stats(self, min_thr=8.0, max_thr=16.0):
+        """RunSFM_SBA's post-solve statistics (src/Bundle.cpp:659-913) at the current parameters."""
+        m, n = self.m, self.n
+        out = dict(nobs=np.zeros(m, np.int32), mean=np.zeros(m), kth80=np.zeros(m), kth50=np.zeros(m), thresh=np.zeros(m),
+                   outlier=np.zeros(n, np.uint8), err=np.zeros(n))
+        gm = C.c_double()
+        rc = lib.bsfm_problem_outlier_stats(self.h, float(min_thr), float(max_thr), _ip(out["nobs"]), _dp(out["mean"]),
+                                            _dp(out["kth80"]), _dp(out["kth50"]), _dp(out["thresh"]),
+                                            out["outlier"].ctypes.data_as(C.POINTER(C.c_ubyte)), _dp(out["err"]), C.byref(gm))
+        if rc != 0:
+            raise RuntimeError("bsfm_problem_outlier_stats failed")
+        out["global_mean"] = gm.value
+        return out
+
     def residuals(self):
         e = np.zeros(2 * self.nvis)
         cost = C.c_double()

@@ -184,6 +184,16 @@ long long bsfm_problem_nvis(const bsfm_problem_t *pb);
  *    V (n*9 full symmetric, diagonal + mu), eb (n*3), J (nvis*(2*cnp+6): A_ij row-major then B_ij),
  *    S ((m-mcon)*cnp squared, dense symmetric), E ((m-mcon)*cnp)                                  */
 int bsfm_eval_residuals(bsfm_problem_t *pb, double *e_out, double *cost);
+/* Post-solve statistics of RunSFM_SBA (src/Bundle.cpp:659-913) at the problem's current parameters, without a round
+ * trip of cameras/points: reprojection distance d = |x - proj| per observation; per camera the observation count, mean
+ * distance, kth_element_copy(n, iround(0.8 n)) and (n, iround(0.5 n)) (lib/imagelib/qsort.c:152-203; 0.0 when k >= n) and
+ * the outlier threshold clamp(1.2 * 2.0 * kth80, min_thr, max_thr) (Bundle.cpp:761-771; Bundler passes
+ * m_min_proj_error_threshold = 8, m_max_proj_error_threshold = 16); per point the outlier flag (an observation above its
+ * camera's threshold; points whose constraint has a non-zero x component are exempt, Bundle.cpp:800-804) and the error
+ * of the first flagged observation in camera order (what "[RunSFM] Removing outlier" prints).  Any output may be NULL. */
+int bsfm_problem_outlier_stats(bsfm_problem_t *pb, double min_thr, double max_thr,
+                               int *cam_nobs, double *cam_mean, double *cam_kth80, double *cam_kth50, double *cam_thresh,
+                               unsigned char *point_outlier, double *point_err, double *global_mean);
 int bsfm_eval_normal_equations(bsfm_problem_t *pb, double mu, double *U, double *ea, double *V, double *eb,
                                double *J, double *S, double *E);
 /* Dense SPD solve on the device with the production Cholesky: A (n x n, symmetric, row-major, host),

@@ -334,3 +334,73 @@ def test_sba_level_sibling_entry_matches_reference_sba(gpu_bsfm, name):
               proj.ctypes.data_as(C.POINTER(C.c_double)), None, 2, 7, C.byref(md), 3, 0, opts, None, 0, None, 0, None,
               None, None, None, None) == -1
     assert np.array_equal(p2, p)
+
+
+def _iround(x):
+    return int(x + 0.5)
+
+
+@pytest.mark.parametrize("with_pcons", [False, True])
+def test_post_solve_outlier_statistics(gpu_bsfm, with_pcons):
+    """the statistics RunSFM_SBA computes after every run_sfm (src/Bundle.cpp:659-913) from the resident
+    problem.  CPU side: every observation projected with the oracle's camera model, then the reference's formulas
+    restated in numpy (kth_element_copy = k-th smallest, 0.0 when k >= n; thresh = clamp(2.4 * kth80, 8, 16); a point is
+    an outlier if one observation exceeds its camera's threshold; constrained points (x != 0) are exempt)."""
+    import ctypes as C
+    B = gpu_bsfm
+    c = load_case("band")
+    m, n = c["m"], c["n"]
+    rng = np.random.default_rng(5)
+    proj = c["proj"].copy().reshape(-1, 2)
+    bad = rng.choice(len(proj), 40, replace=False)
+    proj[bad] += rng.normal(0, 30.0, (40, 2))                     # a few gross outliers
+    pcons = None
+    if with_pcons:
+        pcons = np.zeros((n, 3)); ids = np.repeat(np.arange(n), np.diff(c["rowptr"]))[bad[:10]]
+        pcons[ids] = c["pts"].reshape(-1, 3)[ids] + 0.01           # exempt some of the outliers' points
+    opt = B.default_options(jacobian=B.JAC_ANALYTIC, verbose=0, itmax=5)
+    pb = B.Problem(n, m, c["rowptr"], c["colidx"], proj.ravel(), c["cams"], c["pts"], est_focal_length=c["est"],
+                   undistort=c["und"], use_constraints=c["cons"], point_constraints=pcons, point_constraint_weight=1.0,
+                   options=opt)
+    pb.solve()
+    st = pb.outlier_stats(8.0, 16.0)
+    p, cams, pts = pb.download()
+    pb.close()
+    # CPU restatement
+    cnp = 9
+    ca = O.cams_to_arrays(c["cams"])
+    dp = C.POINTER(C.c_double)
+    dist = np.zeros(len(proj))
+    cam_of = c["colidx"]; pt_of = np.repeat(np.arange(n), np.diff(c["rowptr"]))
+    x = np.zeros(2)
+    for k in range(len(proj)):
+        j, i = cam_of[k], pt_of[k]
+        a = np.ascontiguousarray(p[j * cnp:(j + 1) * cnp]); b = np.ascontiguousarray(p[m * cnp + 3 * i:m * cnp + 3 * i + 3])
+        Rj = np.ascontiguousarray(ca["R"][j])
+        O.port().oracle_project(c["est"], c["und"], 1, Rj.ctypes.data_as(dp), float(ca["f"][j]), a.ctypes.data_as(dp),
+                                b.ctypes.data_as(dp), x.ctypes.data_as(dp))
+        dist[k] = np.hypot(proj[k, 0] - x[0], proj[k, 1] - x[1])
+    thresh = np.zeros(m)
+    for j in range(m):
+        d = np.sort(dist[cam_of == j]); nj = len(d)
+        k80, k50 = _iround(0.8 * nj), _iround(0.5 * nj)
+        v80 = d[k80] if k80 < nj else 0.0
+        v50 = d[k50] if k50 < nj else 0.0
+        thresh[j] = min(max(2.4 * v80, 8.0), 16.0)
+        assert st["nobs"][j] == nj
+        assert abs(st["kth80"][j] - v80) <= 1e-9 * max(1.0, v80) and abs(st["kth50"][j] - v50) <= 1e-9 * max(1.0, v50)
+        assert abs(st["thresh"][j] - thresh[j]) <= 1e-9 * thresh[j]
+        assert abs(st["mean"][j] - d.mean()) <= 1e-9 * max(1.0, d.mean())
+    assert abs(st["global_mean"] - dist.mean()) <= 1e-9 * dist.mean()
+    flag = np.zeros(n, np.uint8); err = np.zeros(n)
+    for i in range(n):
+        if pcons is not None and pcons[i, 0] != 0.0:
+            continue
+        for k in range(c["rowptr"][i], c["rowptr"][i + 1]):
+            if dist[k] > thresh[cam_of[k]]:
+                flag[i] = 1; err[i] = dist[k]; break
+    margin = np.abs(dist - thresh[cam_of]).min()
+    assert margin > 1e-6                                          # no observation sits on a threshold: flags must agree exactly
+    assert np.array_equal(st["outlier"], flag)
+    assert flag.sum() >= 10 and (pcons is None or flag.sum() < 40)
+    assert np.abs(st["err"] - err).max() <= 1e-9 * max(1.0, err.max())
