@@ -887,8 +887,10 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         }
         (void)hipEventRecord(w.evU[k], w.s2);
         // chain: next diagonal tile
-        // S_{k+1,k+1} takes panels k-1 and k here; the last bulk launch that touched it is the one of step k-2
-        if (k > 1) (void)hipStreamWaitEvent(st, w.evU[k - 2], 0);
+        // S_{k+1,k+1} takes panels k-1 and k here; the last bulk launch that touched it is the one of step k-2, and that one
+        // is already ordered before this point: the chain waited for evC[k-1] above, and the side stream recorded it after
+        // having waited for evU[k-2] itself.  (Tried: hipStreamWriteValue32 / hipStreamWaitValue32 on signal memory instead
+        // of the chain <-> side events: no faster.)
         hipLaunchKernelGGL(k_chain_tile32<1>, dim3(10), dim3(256), lds32, st, S, ld, k, Lk, pk,
                            k > 0 ? (const double*)panel_of(k - 1) : (const double*)nullptr);
         hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, k + 1, n, w.linv, d_info, w.dbg);
