@@ -404,7 +404,8 @@ __global__ __launch_bounds__(256, 1) void k_chain_tile32(double* __restrict__ S,
 }
 
 // (Also tried and dropped: an XCD-aware blockIdx -> tile order (super-tiles of 8x8 tiles per XCD chunk).  +8-11 % for the
-// kernel alone on the whole device (scripts/ubench_syrk.hip), exactly 0 in the factorisation: 35.0 TFLOP/s either way.)
+// kernel alone on the whole device (scripts/ubench_syrk.hip), exactly 0 in the factorisation -- with the CU-masked bulk
+// stream (35.0 TFLOP/s either way) and again without the mask (38.4 vs 38.5).)
 // Trailing update: S_ij -= P_a P_b^T for k < j <= i (a = i-k-1, b = j-k-1), one tile per workgroup.
 // part 1 = only the first trailing column (b == 0, grid T): the tiles the NEXT panel needs (lookahead stream);
 // part 2 = every other tile (b >= 1) except S_{k+2,k+2}, grid T(T-1)/2 - 1: the bulk, on the update stream.
@@ -765,10 +766,12 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
     w.ld = ld; w.nblk = ld / POTRF_NB; w.backend = backend;
     const size_t tile = (size_t)POTRF_NB * POTRF_NB;
     if (hipMalloc((void**)&w.panel, 4 * std::max<size_t>(1, (size_t)(w.nblk - 1)) * tile * sizeof(double)) != hipSuccess) return -1;
-    {   // The bulk trailing update must not occupy every CU, otherwise the 150 KB-LDS diagonal-tile workgroup of the
-        // lookahead stream can never be placed: reserve BSFM_PANEL_CUS compute units (default 32) by masking them
-        // out of the update stream (hipExtStreamCreateWithCUMask); 0 disables the reservation.
-        int reserve = 32;
+    {   // Optional CU reservation (BSFM_PANEL_CUS=n masks n CUs out of the bulk stream, hipExtStreamCreateWithCUMask).
+        // It was essential for the two-stream schedule (the 150 KB-LDS diagonal-tile workgroup could never be placed
+        // while 2 400 bulk workgroups were queued: 12.4 vs 13.9 ms).  With the three-stream schedule the chain only
+        // needs small kernels while a bulk launch is in flight, and no reservation is faster at every size measured
+        // (config 3: 8.9 vs 9.2 ms; 2 000 cameras: 44.5 vs 48.3 ms; 3 000: 136 vs 148 ms) -- default 0.
+        int reserve = 0;
         if (const char* e = getenv("BSFM_PANEL_CUS")) reserve = atoi(e);
         hipDeviceProp_t prop; int dev = 0; (void)hipGetDevice(&dev);
         hipError_t rc = hipErrorUnknown;
