@@ -41,6 +41,7 @@ struct DevProblem {
     const int* camptr; const int* camobs;
     const int* campos;            // obs k -> its position in camera-major order (inverse of camobs)
     const int* cam_pt;            // camera-major position -> point index
+    const int* cam_cam;           // camera-major position -> camera index
     const double* Rinit; const double* finit;
     // constraints
     const unsigned char* ccon; const double* cval; const double* cw;   // m*cnp (may be null)
@@ -149,21 +150,22 @@ __global__ __launch_bounds__(RES_BLOCK) void k_residual(ModelCfg cfg, int nvis,
 // Jacobian records: one thread per observation.
 template <int CNP, bool FD>
 __global__ __launch_bounds__(256) void k_jacobian(ModelCfg cfg, int nvis,
-        const int* __restrict__ obs_cam, const int* __restrict__ obs_pt,
-        const double* __restrict__ camtab, const double* __restrict__ pb,
-        const int* __restrict__ campos, double* __restrict__ Jc)
+        const int* __restrict__ cam_cam, const int* __restrict__ cam_pt,
+        const double* __restrict__ camtab, const double* __restrict__ pb, double* __restrict__ Jc)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= nvis) return;
-    const double* ct = camtab + (size_t)obs_cam[k] * CT_STRIDE;
-    const double* b = pb + (size_t)obs_pt[k] * 3;
+    // One thread per CAMERA-major position t: neighbouring threads share the camera (its 72-double table row is one
+    // broadcast), gather their point (24 bytes, the point array is L2-resident) and write consecutive 192-byte records.
+    // ONE copy of the Jacobian: the camera-side consumers (U/ea, Schur tasks) stream it, the point-side ones gather
+    // whole records through campos[].
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nvis) return;
+    const double* ct = camtab + (size_t)cam_cam[t] * CT_STRIDE;
+    const double* b = pb + (size_t)cam_pt[t] * 3;
     double A[2 * CNP], B[6], x0, x1;
     if (FD) jac_fd<CNP>(cfg, ct, b[0], b[1], b[2], A, B, x0, x1);
     else    jac_analytic<CNP>(cfg, ct, b[0], b[1], b[2], A, B, x0, x1);
     constexpr int JS = 2 * CNP + 6;
-    // ONE copy, camera-major (record of observation k at position campos[k]; JS is even -> 16-byte aligned records):
-    // the camera-side consumers (U/ea, Schur tasks, Schur rhs) stream it, the point-side ones gather whole records.
-    double2* outc = reinterpret_cast<double2*>(Jc + (size_t)campos[k] * JS);
+    double2* outc = reinterpret_cast<double2*>(Jc + (size_t)t * JS);     // JS is even -> 16-byte aligned records
 #pragma unroll
     for (int q = 0; q < CNP; ++q) outc[q] = make_double2(A[2 * q], A[2 * q + 1]);
 #pragma unroll

@@ -65,7 +65,7 @@ struct bsfm_problem {
     // device
     double *d_x = nullptr, *d_Rinit = nullptr, *d_finit = nullptr;
     int *d_obs_cam = nullptr, *d_obs_pt = nullptr, *d_rowptr = nullptr, *d_camptr = nullptr, *d_camobs = nullptr;
-    int *d_campos = nullptr, *d_cam_pt = nullptr;
+    int *d_campos = nullptr, *d_cam_pt = nullptr, *d_cam_cam = nullptr;
     unsigned char *d_ccon = nullptr, *d_pcon = nullptr;
     double *d_cval = nullptr, *d_cw = nullptr, *d_pval = nullptr;
     double *d_p = nullptr, *d_pdp = nullptr, *d_dp = nullptr;
@@ -110,7 +110,7 @@ namespace {
 void free_all(bsfm_problem* pb)
 {
     void* ptrs[] = { pb->d_x, pb->d_Rinit, pb->d_finit, pb->d_obs_cam, pb->d_obs_pt, pb->d_rowptr, pb->d_camptr,
-                     pb->d_camobs, pb->d_campos, pb->d_cam_pt, pb->d_Jc, pb->d_ccon, pb->d_pcon, pb->d_cval, pb->d_cw, pb->d_pval, pb->d_p, pb->d_pdp,
+                     pb->d_camobs, pb->d_campos, pb->d_cam_pt, pb->d_cam_cam, pb->d_Jc, pb->d_ccon, pb->d_pcon, pb->d_cval, pb->d_cw, pb->d_pval, pb->d_p, pb->d_pdp,
                      pb->d_dp, pb->d_camtab, pb->d_camtab_trial, pb->d_e, pb->d_hx, pb->d_U,
                      pb->d_V, pb->d_Vinv, pb->d_eb, pb->d_S, pb->d_E, pb->d_partials, pb->d_epart, pb->d_campart, pb->d_red, pb->d_scal,
                      pb->d_flags, pb->d_triples, pb->d_tri_pt, pb->d_tasks, pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0,
@@ -308,10 +308,10 @@ int compute_normal_blocks(bsfm_problem* pb)
     if (P.nvis > 0) {
         if (pb->opt.jacobian == BSFM_JAC_FD) {
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_jacobian<C, true>), dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream,
-                                                  P.cfg, P.nvis, pb->d_obs_cam, pb->d_obs_pt, pb->d_camtab, pbpts, pb->d_campos, pb->d_Jc));
+                                                  P.cfg, P.nvis, pb->d_cam_cam, pb->d_cam_pt, pb->d_camtab, pbpts, pb->d_Jc));
         } else {
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_jacobian<C, false>), dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream,
-                                                  P.cfg, P.nvis, pb->d_obs_cam, pb->d_obs_pt, pb->d_camtab, pbpts, pb->d_campos, pb->d_Jc));
+                                                  P.cfg, P.nvis, pb->d_cam_cam, pb->d_cam_pt, pb->d_camtab, pbpts, pb->d_Jc));
         }
     }
     ph_end(pb, PH_JAC);
@@ -493,9 +493,9 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     std::vector<int> obs_pt(nvis), camptr(m + 1, 0), camobs(nvis);
     for (int i = 0; i < n; ++i) for (int k = d->rowptr[i]; k < d->rowptr[i + 1]; ++k) { obs_pt[k] = i; ++camptr[d->colidx[k] + 1]; }
     for (int j = 0; j < m; ++j) camptr[j + 1] += camptr[j];
-    std::vector<int> campos(nvis), cam_pt(nvis);
+    std::vector<int> campos(nvis), cam_pt(nvis), cam_cam(nvis);
     { std::vector<int> cur(camptr.begin(), camptr.end() - 1);
-      for (int k = 0; k < nvis; ++k) { const int t = cur[d->colidx[k]]++; camobs[t] = k; campos[k] = t; cam_pt[t] = obs_pt[k]; } }
+      for (int k = 0; k < nvis; ++k) { const int t = cur[d->colidx[k]]++; camobs[t] = k; campos[k] = t; cam_pt[t] = obs_pt[k]; cam_cam[t] = d->colidx[k]; } }
 
     if (hipStreamCreateWithFlags(&pb->stream, hipStreamNonBlocking) != hipSuccess) return fail("stream");
     pb->own_stream = true;
@@ -505,7 +505,7 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     DM(pb->d_p, pb->nvars_local); DM(pb->d_pdp, pb->nvars_local); DM(pb->d_dp, pb->nvars_local);
     DM(pb->d_camtab, (size_t)m * CT_STRIDE); DM(pb->d_camtab_trial, (size_t)m * CT_STRIDE);
     DM(pb->d_e, 2 * (size_t)nvis); DM(pb->d_hx, 2 * (size_t)nvis);
-    DM(pb->d_Jc, (size_t)nvis * P.js); DM(pb->d_campart, (size_t)m * CAM_SPLIT * (cnp * (cnp + 1) / 2 + cnp)); DM(pb->d_campos, nvis); DM(pb->d_cam_pt, nvis); DM(pb->d_U, (size_t)m * cnp * cnp + (size_t)m * cnp); pb->d_ea = pb->d_U + (size_t)m * cnp * cnp;   /* one buffer: one exchange */
+    DM(pb->d_Jc, (size_t)nvis * P.js); DM(pb->d_campart, (size_t)m * CAM_SPLIT * (cnp * (cnp + 1) / 2 + cnp)); DM(pb->d_campos, nvis); DM(pb->d_cam_pt, nvis); DM(pb->d_cam_cam, nvis); DM(pb->d_U, (size_t)m * cnp * cnp + (size_t)m * cnp); pb->d_ea = pb->d_U + (size_t)m * cnp * cnp;   /* one buffer: one exchange */
     DM(pb->d_V, 6 * (size_t)n); DM(pb->d_Vinv, 6 * (size_t)n); DM(pb->d_eb, 3 * (size_t)n);
     DM(pb->d_S, (size_t)pb->ld * pb->ld); DM(pb->d_E, pb->ld);
     pb->red_blocks = std::max(grid_for(nvis, RES_BLOCK), std::max(grid_for(n, 256), 1024));
@@ -521,7 +521,8 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     bool ok = up(pb->d_x, d->projections, 2 * (size_t)nvis * sizeof(double)) && up(pb->d_obs_cam, d->colidx, nvis * sizeof(int)) &&
               up(pb->d_obs_pt, obs_pt.data(), nvis * sizeof(int)) && up(pb->d_rowptr, d->rowptr, (n + 1) * sizeof(int)) &&
               up(pb->d_camptr, camptr.data(), (m + 1) * sizeof(int)) && up(pb->d_camobs, camobs.data(), nvis * sizeof(int)) &&
-              up(pb->d_campos, campos.data(), nvis * sizeof(int)) && up(pb->d_cam_pt, cam_pt.data(), nvis * sizeof(int));
+              up(pb->d_campos, campos.data(), nvis * sizeof(int)) && up(pb->d_cam_pt, cam_pt.data(), nvis * sizeof(int)) &&
+              up(pb->d_cam_cam, cam_cam.data(), nvis * sizeof(int));
     pb->h_Rinit.resize(9 * (size_t)m);
     std::vector<double> finit(m);
     for (int j = 0; j < m; ++j) { memcpy(&pb->h_Rinit[9 * (size_t)j], d->cameras[j].R, 9 * sizeof(double)); finit[j] = d->cameras[j].f; }
@@ -552,7 +553,7 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     }
     if (!ok) return fail("upload");
     P.x = pb->d_x; P.obs_cam = pb->d_obs_cam; P.obs_pt = pb->d_obs_pt; P.rowptr = pb->d_rowptr;
-    P.camptr = pb->d_camptr; P.camobs = pb->d_camobs; P.campos = pb->d_campos; P.cam_pt = pb->d_cam_pt; P.Rinit = pb->d_Rinit; P.finit = pb->d_finit;
+    P.camptr = pb->d_camptr; P.camobs = pb->d_camobs; P.campos = pb->d_campos; P.cam_pt = pb->d_cam_pt; P.cam_cam = pb->d_cam_cam; P.Rinit = pb->d_Rinit; P.finit = pb->d_finit;
     P.ccon = pb->d_ccon; P.cval = pb->d_cval; P.cw = pb->d_cw; P.pcon = pb->d_pcon; P.pval = pb->d_pval;
     P.Jc = pb->d_Jc; P.U = pb->d_U; P.ea = pb->d_ea; P.V = pb->d_V; P.Vinv = pb->d_Vinv; P.eb = pb->d_eb;
     if (build_schur_structure(pb, d, campos, cam_pt) != 0) return fail("schur structure");
