@@ -220,7 +220,7 @@ def main():
         # HBM-bound streaming kernels against the 8 TB/s roof: algorithmic bytes / HIP-event time
         nv_loc, np_loc, js = float(k1 - k0), float(hi - lo), 2 * cnp + 6
         deg2 = float(np.sum(np.diff(rp).astype(np.float64) * (np.diff(rp) + 1) / 2))        # co-visibility triples
-        alg = {"jacobian": nv_loc * (8 * js + 12 + 24), "cam_blocks": nv_loc * (16 * cnp + 16 + 4),
+        alg = {"jacobian": nv_loc * (8 * js + 8 + 24), "cam_blocks": nv_loc * (16 * cnp + 16 + 4),
                "point_blocks": nv_loc * (48 + 16 + 4) + np_loc * 72, "backsub": nv_loc * (8 * js + 8) + np_loc * 120,
                "residual": nv_loc * 56, "schur": deg2 * (2 * 8 * js + 48) + nv_loc * 24}
         hbm = {}
