@@ -65,6 +65,7 @@ SYMBOLS = [
     "bsfm_lm_iterate", "bsfm_lm_finish", "bsfm_lm_solve_attempts", "bsfm_lm_last_kernel_ms",
     "bsfm_problem_download", "bsfm_problem_cnp", "bsfm_problem_nvis", "bsfm_eval_residuals", "bsfm_problem_outlier_stats",
     "bsfm_eval_normal_equations", "bsfm_dense_chol_solve", "bsfm_match_keys_l2", "bsfm_key_match_full",
+    "bsfm_key_match_full_sharded", "bsfm_merge_match_files",
     "bsfm_device_count", "bsfm_version", "bsfm_device_synchronize", "bsfm_synth_ba", "bsfm_synth_keys",
 ]
 

@@ -214,6 +214,47 @@ extern "C" int bsfm_match_keys_l2(int n1, const unsigned char* k1, int n2, const
 extern "C" int bsfm_key_match_full(int num_images, const int* num_keys, const unsigned char* const* keys,
                                    double ratio, int window_radius, const char* out_path)
 {
+    return bsfm_key_match_full_sharded(num_images, num_keys, keys, ratio, window_radius, out_path, 0, 1);
+}
+
+// Concatenates the per-rank files of bsfm_key_match_full_sharded into the file one rank would have written: blocks are
+// "j i\nN\n" + N lines, ascending in i inside every rank file; a k-way merge on i restores the reference's (i, j) order.
+extern "C" int bsfm_merge_match_files(int count, const char* const* paths, const char* out_path)
+{
+    struct Src { FILE* f; int j, i, n; bool have; };
+    std::vector<Src> src((size_t)count);
+    auto advance = [](Src& s) { s.have = s.f && fscanf(s.f, "%d %d %d", &s.j, &s.i, &s.n) == 3; };
+    for (int r = 0; r < count; ++r) {
+        src[r].f = fopen(paths[r], "r");
+        if (!src[r].f) { printf("Could not open %s for reading.\n", paths[r]); for (int q = 0; q < r; ++q) fclose(src[q].f); return BSFM_ERROR; }
+        advance(src[r]);
+    }
+    FILE* out = fopen(out_path, "w");
+    if (!out) { printf("Could not open %s for writing.\n", out_path); for (auto& s : src) fclose(s.f); return BSFM_ERROR; }
+    int blocks = 0;
+    for (;;) {
+        int best = -1;
+        for (int r = 0; r < count; ++r)
+            if (src[r].have && (best < 0 || src[r].i < src[best].i || (src[r].i == src[best].i && src[r].j < src[best].j))) best = r;
+        if (best < 0) break;
+        Src& s = src[best];
+        fprintf(out, "%d %d\n%d\n", s.j, s.i, s.n);
+        for (int q = 0; q < s.n; ++q) { int a, b; if (fscanf(s.f, "%d %d", &a, &b) != 2) { s.n = -1; break; } fprintf(out, "%d %d\n", a, b); }
+        if (s.n < 0) { fclose(out); for (auto& t : src) fclose(t.f); return BSFM_ERROR; }
+        ++blocks;
+        advance(s);
+    }
+    fclose(out);
+    for (auto& s : src) fclose(s.f);
+    return blocks;
+}
+
+// rank / world_size: this call handles the database images i with i % world_size == rank (each with all its j < i), so
+// the pair list is split without any exchange (matcher = embarrassingly parallel, descriptors replicated).
+extern "C" int bsfm_key_match_full_sharded(int num_images, const int* num_keys, const unsigned char* const* keys,
+                                           double ratio, int window_radius, const char* out_path, int rank, int world_size)
+{
+    if (world_size < 1 || rank < 0 || rank >= world_size) return BSFM_ERROR;
     if (!have_device()) return BSFM_ERROR;
     FILE* f = fopen(out_path, "w");
     if (!f) { printf("Could not open %s for writing.\n", out_path); return BSFM_ERROR; }   // KeyMatchFull.cpp:86-89
@@ -234,7 +275,7 @@ extern "C" int bsfm_key_match_full(int num_images, const int* num_keys, const un
     std::vector<int> nn;
     int total_pairs_written = 0;
     for (int i = 0; i < num_images; ++i) {
-        if (num_keys[i] == 0) continue;
+        if (num_keys[i] == 0 || i % world_size != rank) continue;
         int start = 0;
         if (window_radius > 0) start = std::max(i - window_radius, 0);   // KeyMatchFull.cpp:117-119
         pairs.clear();

@@ -209,9 +209,15 @@ int bsfm_match_keys_l2(int n1, const unsigned char *k1, int n2, const unsigned c
                        int *out_pairs, int max_out);
 /* All-pairs driver with KeyMatchFull's loop structure and output format (src/KeyMatchFull.cpp:105-151):
  * keys[i] -> num_keys[i] x 128 uchar (host); writes the text to `out_path` ("j i\nN\nidx_j idx_i\n...")
- * for pairs with >= 16 matches; window_radius <= 0 means all pairs.  rank/world_size shard the pairs. */
+ * for pairs with >= 16 matches; window_radius <= 0 means all pairs.  Returns the number of pair blocks written. */
 int bsfm_key_match_full(int num_images, const int *num_keys, const unsigned char *const *keys,
                         double ratio, int window_radius, const char *out_path);
+/* Multi-GPU form (pair-parallel, no collective): rank r of world_size handles the database images i with
+ * i % world_size == r (each against all j < i) and writes its own file; bsfm_merge_match_files then restores the single-run
+ * file byte for byte (k-way merge of the "j i" blocks on i). */
+int bsfm_key_match_full_sharded(int num_images, const int *num_keys, const unsigned char *const *keys,
+                                double ratio, int window_radius, const char *out_path, int rank, int world_size);
+int bsfm_merge_match_files(int count, const char *const *paths, const char *out_path);
 
 /* ---- utilities --------------------------------------------------------------------------------------- */
 int bsfm_device_count(void);                 /* 0 when no usable HIP device */

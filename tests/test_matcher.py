@@ -179,3 +179,37 @@ def test_keymatchfull_cli_same_process_boundary_as_reference(gpu_bsfm, tmp_path)
         assert text.count("\n") > 50          # something was actually matched
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode != 0 and "Usage:" in r.stdout
+
+
+@pytest.mark.gpu
+def test_sharded_matcher_merges_to_the_single_run_file(gpu_bsfm, tmp_path):
+    """SURVEY 8(e), matcher: pairs are split over ranks by database image (no collective); the merged per-rank files
+    equal the single-run file byte for byte."""
+    B = gpu_bsfm
+    sizes = [260, 300, 0, 190, 320, 280, 310]
+    keys, prev = [], None
+    for i, nk in enumerate(sizes):
+        k = synth_keys(B, nk, 7000 + i, dup=prev) if nk else np.zeros((0, 128), np.uint8)
+        keys.append(k)
+        if nk:
+            prev = k
+    arr = (U * len(sizes))(*[k.ctypes.data_as(U) for k in keys])
+    nks = np.array(sizes, np.int32)
+    ip = nks.ctypes.data_as(C.POINTER(C.c_int))
+    single = tmp_path / "single.txt"
+    n_single = B.lib.bsfm_key_match_full(len(sizes), ip, arr, C.c_double(0.6), -1, str(single).encode())
+    assert n_single > 3
+    world = 3
+    paths, total = [], 0
+    for r in range(world):
+        p = tmp_path / f"rank{r}.txt"
+        paths.append(str(p).encode())
+        got = B.lib.bsfm_key_match_full_sharded(len(sizes), ip, arr, C.c_double(0.6), -1, paths[-1], r, world)
+        assert got >= 0
+        total += got
+    assert total == n_single
+    merged = tmp_path / "merged.txt"
+    cp = (C.c_char_p * world)(*paths)
+    assert B.lib.bsfm_merge_match_files(world, cp, str(merged).encode()) == n_single
+    assert merged.read_bytes() == single.read_bytes()
+    assert B.lib.bsfm_key_match_full_sharded(len(sizes), ip, arr, C.c_double(0.6), -1, paths[0], 3, 3) < 0     # bad rank
