@@ -103,41 +103,77 @@ __global__ __launch_bounds__(256) void k_match_l2(const unsigned char* __restric
             qa[g][r] = qstat[pd.q_off + rr] - 2 * 128 * 128 * 128;
         }
     }
-    int b0[4][4], b1[4][4], i0[4][4];
+    // Running top-2 per slot on PACKED keys: key = (d << TB) | tile, d < 2^23 (max 128 * 255^2) and the tile number
+    // (column = 64 * tile + 16 * wave + (lane & 15): the only part of the column that varies inside a lane) in TB = 9 bits,
+    // i.e. segments of 32 768 database keys (larger images are scanned segment by segment).  One v_min_u32 and one median (v_med3_u32) then maintain (best, second) -- for
+    // b0 <= b1 the new second is the median of (b0, b1, key) -- instead of two compares and four selects; equal
+    // distances order by tile = by column, like the reference's first-found rule, and two equal nearest distances can
+    // never pass the strict ratio test anyway.
+    constexpr int TB = 9;
+    constexpr int SEG = 64 << TB;                      // database keys per packed segment
+    int D0[4][4], D1[4][4], I0[4][4];                  // running result over the segments (one segment for <= 32 768 keys)
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { b0[g][r] = BIG; b1[g][r] = BIG; i0[g][r] = -1; }
-
-    for (int tile = 0; tile < db_n; tile += 64) {
-        const int col = tile + 16 * wave + (lane & 15);
-        const int colc = min(col, db_n - 1);
-        const v4i bf0 = load_frag(dkeys, colc, lane, 0);
-        const v4i bf1 = load_frag(dkeys, colc, lane, 1);
-        const int qb = (col < db_n) ? qstat[db_off + colc] : BIG;
+        for (int r = 0; r < 4; ++r) { D0[g][r] = BIG; D1[g][r] = BIG; I0[g][r] = -1; }
+    const int slot = wave * 16 + (lane & 15);
+    for (int seg = 0; seg < db_n; seg += SEG) {
+        unsigned b0[4][4], b1[4][4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            v4i acc = { 0, 0, 0, 0 };
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[g][0], bf0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[g][1], bf1, acc, 0, 0, 0);
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int d = qa[g][r] + (qb - 2 * acc[r]);
-                const bool lt0 = d < b0[g][r], lt1 = d < b1[g][r];
-                b1[g][r] = lt0 ? b0[g][r] : (lt1 ? d : b1[g][r]);
-                i0[g][r] = lt0 ? col : i0[g][r];
-                b0[g][r] = lt0 ? d : b0[g][r];
+            for (int r = 0; r < 4; ++r) { b0[g][r] = 0xffffffffu; b1[g][r] = 0xffffffffu; }
+        const int seg_end = min(db_n, seg + SEG);
+        // software pipeline: the B fragments of tile t+1 are in flight while tile t is multiplied and ranked (the scan is
+        // otherwise bound by the L2 round trip of these loads: 3 waves per SIMD cannot hide it)
+        const int col0 = min(seg + 16 * wave + (lane & 15), db_n - 1);
+        v4i nf0 = load_frag(dkeys, col0, lane, 0), nf1 = load_frag(dkeys, col0, lane, 1);
+        int nqb = qstat[db_off + col0];
+        for (int tile = seg; tile < seg_end; tile += 64) {
+            const int col = tile + 16 * wave + (lane & 15);
+            const v4i bf0 = nf0, bf1 = nf1;
+            const int qb = nqb;
+            if (tile + 64 < seg_end) {
+                const int coln = min(col + 64, db_n - 1);
+                nf0 = load_frag(dkeys, coln, lane, 0); nf1 = load_frag(dkeys, coln, lane, 1);
+                nqb = qstat[db_off + coln];
+            }
+            const bool live = col < db_n;
+            const unsigned tnum = (unsigned)((tile - seg) >> 6);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                v4i acc = { 0, 0, 0, 0 };
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[g][0], bf0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[g][1], bf1, acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned d = (unsigned)(qa[g][r] + (qb - 2 * acc[r]));      // exact squared distance, 0 .. 8 323 200
+                    const unsigned key = live ? ((d << TB) | tnum) : 0xffffffffu;
+                    b1[g][r] = max(b0[g][r], min(b1[g][r], key));      // median of (b0 <= b1, key)
+                    b0[g][r] = min(b0[g][r], key);
+                }
             }
         }
+        // fold the segment's packed pair into the running (D0 <= D1, I0)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned k0 = b0[g][r], k1 = b1[g][r];
+                const int c0 = k0 == 0xffffffffu ? BIG : (int)(k0 >> TB);
+                const int c1 = k1 == 0xffffffffu ? BIG : (int)(k1 >> TB);
+                const int ci = seg + (int)((k0 & ((1u << TB) - 1)) << 6) + slot;
+                if (c0 < D0[g][r]) { D1[g][r] = min(D0[g][r], c1); D0[g][r] = c0; I0[g][r] = ci; }
+                else D1[g][r] = min(D1[g][r], c0);
+            }
     }
     // merge: slot = wave*16 + (lane&15); row = 16g + 4*(lane>>4) + r
-    const int slot = wave * 16 + (lane & 15);
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * g + 4 * (lane >> 4) + r;
-            sm_d0[row][slot] = b0[g][r]; sm_d1[row][slot] = b1[g][r]; sm_i0[row][slot] = i0[g][r];
+            sm_d0[row][slot] = D0[g][r]; sm_d1[row][slot] = D1[g][r]; sm_i0[row][slot] = I0[g][r];
         }
     __syncthreads();
     if (threadIdx.x < QB) {
@@ -266,50 +302,96 @@ extern "C" int bsfm_key_match_full_sharded(int num_images, const int* num_keys, 
     if (tot > 0x7fffffffULL) { fprintf(stderr, "[bsfm] too many keys\n"); fclose(f); return BSFM_ERROR; }
     DevKeys d;
     HIPM(hipMalloc((void**)&d.keys, tot * 128)); HIPM(hipMalloc((void**)&d.qstat, tot * sizeof(int)));
-    HIPM(hipMalloc((void**)&d.pairs, (size_t)num_images * sizeof(PairDesc)));
-    HIPM(hipMalloc((void**)&d.nn, (size_t)num_images * (size_t)maxk * sizeof(int)));
     for (int i = 0; i < num_images; ++i)
         if (num_keys[i] > 0) HIPM(hipMemcpy(d.keys + off[i] * 128, keys[i], (size_t)num_keys[i] * 128, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_key_stats, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, d.keys, (int)tot, d.qstat);
-    std::vector<PairDesc> pairs;
-    std::vector<int> nn;
+    // Two-slot pipeline on one stream: while the GPU scans database image k, the host turns the nearest-neighbour table of
+    // image k-1 into text (own integer formatter: the text, not the search, was the larger part of the wall time).
+    struct Slot {
+        PairDesc* h_pairs = nullptr; PairDesc* d_pairs = nullptr; int* h_nn = nullptr; int* d_nn = nullptr;
+        hipEvent_t done = nullptr; int image = -1; size_t npairs = 0; std::vector<int> js; bool busy = false;
+    } slots[2];
+    hipStream_t st = nullptr;
+    auto release = [&] {
+        for (Slot& s : slots) {
+            if (s.h_pairs) (void)hipHostFree(s.h_pairs);
+            if (s.h_nn) (void)hipHostFree(s.h_nn);
+            if (s.d_pairs) (void)hipFree(s.d_pairs);
+            if (s.d_nn) (void)hipFree(s.d_nn);
+            if (s.done) (void)hipEventDestroy(s.done);
+        }
+        if (st) (void)hipStreamDestroy(st);
+    };
+    bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    for (Slot& s : slots) {
+        ok = ok && hipHostMalloc((void**)&s.h_pairs, (size_t)num_images * sizeof(PairDesc)) == hipSuccess;
+        ok = ok && hipHostMalloc((void**)&s.h_nn, tot * sizeof(int)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&s.d_pairs, (size_t)num_images * sizeof(PairDesc)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&s.d_nn, tot * sizeof(int)) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) { fprintf(stderr, "[bsfm] matcher: allocation failed\n"); release(); fclose(f); return BSFM_ERROR; }
+    (void)hipDeviceSynchronize();          // key upload + statistics (null stream) before the pipeline stream starts
     int total_pairs_written = 0;
-    for (int i = 0; i < num_images; ++i) {
+    std::vector<char> text;
+    auto put_int = [&](int v, char sep) {
+        char tmp[12]; int n = 0;
+        unsigned u = (unsigned)v;
+        do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+        while (n) text.push_back(tmp[--n]);
+        text.push_back(sep);
+    };
+    auto drain = [&](Slot& s) -> bool {
+        if (!s.busy) return true;
+        if (hipEventSynchronize(s.done) != hipSuccess) return false;
+        text.clear();
+        for (size_t p = 0; p < s.npairs; ++p) {
+            const int* row = s.h_nn + s.h_pairs[p].out_off;
+            const int qn = s.h_pairs[p].q_n;
+            int cnt = 0;
+            for (int q = 0; q < qn; ++q) cnt += row[q] >= 0;
+            if (cnt >= 16) {   // KeyMatchFull.cpp:131-142: "j i\n", count, "idx_j idx_i" lines
+                put_int(s.js[p], ' '); put_int(s.image, '\n'); put_int(cnt, '\n');
+                for (int q = 0; q < qn; ++q) if (row[q] >= 0) { put_int(q, ' '); put_int(row[q], '\n'); }
+                ++total_pairs_written;
+            }
+        }
+        if (!text.empty()) fwrite(text.data(), 1, text.size(), f);
+        s.busy = false;
+        return true;
+    };
+    int turn = 0;
+    for (int i = 0; i < num_images && ok; ++i) {
         if (num_keys[i] == 0 || i % world_size != rank) continue;
         int start = 0;
         if (window_radius > 0) start = std::max(i - window_radius, 0);   // KeyMatchFull.cpp:117-119
-        pairs.clear();
+        Slot& s = slots[turn & 1];
+        ok = drain(s);
+        if (!ok) break;
+        s.js.clear(); s.npairs = 0; s.image = i;
         int blk = 0; size_t out = 0;
-        std::vector<int> js;
         for (int j = start; j < i; ++j) {
             if (num_keys[j] == 0) continue;
-            pairs.push_back({ (int)off[j], num_keys[j], (int)out, blk });
-            js.push_back(j);
+            s.h_pairs[s.npairs++] = { (int)off[j], num_keys[j], (int)out, blk };
+            s.js.push_back(j);
             blk += (num_keys[j] + QB - 1) / QB; out += (size_t)num_keys[j];
         }
-        if (pairs.empty()) continue;
+        if (s.npairs == 0) continue;
         if (num_keys[i] < 2) {
             fprintf(stderr, "[bsfm] image %d has fewer than 2 keys: the reference's ANN search aborts here; skipped\n", i);
             continue;
         }
-        HIPM(hipMemcpy(d.pairs, pairs.data(), pairs.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_match_l2, dim3(blk), dim3(256), 0, 0, d.keys, d.qstat, d.pairs, (int)pairs.size(),
-                           (int)off[i], num_keys[i], ratio * ratio, d.nn);
-        nn.resize(out);
-        HIPM(hipDeviceSynchronize());
-        HIPM(hipMemcpy(nn.data(), d.nn, out * sizeof(int), hipMemcpyDeviceToHost));
-        for (size_t p = 0; p < pairs.size(); ++p) {
-            const int* row = nn.data() + pairs[p].out_off;
-            int cnt = 0;
-            for (int q = 0; q < pairs[p].q_n; ++q) cnt += row[q] >= 0;
-            if (cnt >= 16) {   // KeyMatchFull.cpp:131-142
-                fprintf(f, "%d %d\n", js[p], i);
-                fprintf(f, "%d\n", cnt);
-                for (int q = 0; q < pairs[p].q_n; ++q) if (row[q] >= 0) fprintf(f, "%d %d\n", q, row[q]);
-                ++total_pairs_written;
-            }
-        }
+        ok = ok && hipMemcpyAsync(s.d_pairs, s.h_pairs, s.npairs * sizeof(PairDesc), hipMemcpyHostToDevice, st) == hipSuccess;
+        hipLaunchKernelGGL(k_match_l2, dim3(blk), dim3(256), 0, st, d.keys, d.qstat, s.d_pairs, (int)s.npairs,
+                           (int)off[i], num_keys[i], ratio * ratio, s.d_nn);
+        ok = ok && hipMemcpyAsync(s.h_nn, s.d_nn, out * sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess;
+        ok = ok && hipEventRecord(s.done, st) == hipSuccess;
+        s.busy = true;
+        ++turn;
     }
+    ok = ok && drain(slots[turn & 1]) && drain(slots[(turn + 1) & 1]);
+    release();
+    if (!ok) { fprintf(stderr, "[bsfm] matcher: HIP error in the pair pipeline\n"); fclose(f); return BSFM_ERROR; }
     fclose(f);
     return total_pairs_written;
 }
