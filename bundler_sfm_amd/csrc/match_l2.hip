@@ -72,7 +72,7 @@ __device__ __forceinline__ v4i load_frag(const unsigned char* __restrict__ keys,
 
 // nn_out[out_off + query] = index of the accepted nearest neighbour in the database image, or -1.
 __global__ __launch_bounds__(256) void k_match_l2(const unsigned char* __restrict__ keys, const int* __restrict__ qstat,
-        const PairDesc* __restrict__ pairs, int npairs, int db_off, int db_n, double ratio_sq, int* __restrict__ nn_out)
+        const PairDesc* __restrict__ pairs, int npairs, int db_off, int db_n, double ratio_sq, int* __restrict__ nn_out, int one)
 {
     __shared__ int sm_d0[QB][64], sm_d1[QB][64], sm_i0[QB][64];
     // locate the pair this block belongs to (pairs are few hundred at most: linear scan by one lane is fine)
@@ -103,15 +103,26 @@ __global__ __launch_bounds__(256) void k_match_l2(const unsigned char* __restric
             qa[g][r] = qstat[pd.q_off + rr] - 2 * 128 * 128 * 128;
         }
     }
-    // Running top-2 per slot on PACKED keys: key = (d << TB) | tile, d < 2^23 (max 128 * 255^2) and the tile number
-    // (column = 64 * tile + 16 * wave + (lane & 15): the only part of the column that varies inside a lane) in TB = 9 bits,
-    // i.e. segments of 32 768 database keys (larger images are scanned segment by segment).  One v_min_u32 and one median (v_med3_u32) then maintain (best, second) -- for
-    // b0 <= b1 the new second is the median of (b0, b1, key) -- instead of two compares and four selects; equal
-    // distances order by tile = by column, like the reference's first-found rule, and two equal nearest distances can
-    // never pass the strict ratio test anyway.
-    constexpr int TB = 9;
-    constexpr int SEG = 64 << TB;                      // database keys per packed segment
-    int D0[4][4], D1[4][4], I0[4][4];                  // running result over the segments (one segment for <= 32 768 keys)
+    // Running top-2 per slot on PACKED keys.  Ranking needs only e = qb - 2 dot (the query term qa is the same for every
+    // candidate of a row), so the per-distance work is: read the accumulator, e + BIAS by one 24-bit multiply-add
+    // (|dot| <= 2^21), (e << TB) | tile by one shift-or, one v_min_u32 for the best and one v_med3_u32 for the second
+    // (for b0 <= b1 the new second is the median of b0, b1, key).  BIAS makes e non-negative for every possible key pair:
+    // qa = |a|^2 - 256 sum(a - 128) - 2*128^3 lies in [-8 355 840, 8 323 200], d = qa + e in [0, 8 323 200], so
+    // e + BIAS < 2^25 with BIAS = 8 388 608, which leaves TB = 7 bits for the tile number inside a segment of 128 tiles
+    // (8 192 database keys; larger images are scanned segment by segment and folded into an unpacked running pair).
+    // Equal distances order by tile = by column like the reference's first-found rule, and two equal nearest
+    // distances can never pass the strict ratio test anyway.
+    constexpr int TB = 7;
+    constexpr int SEG = 64 << TB;
+    // -(2 << TB) reaches the kernel as data (`one` == 1) so that the compiler keeps the 24-bit multiply-add: with a literal
+    // power of two it strength-reduces it to shift + subtract, one VALU instruction more per distance
+    const int mscale = -(2 << TB) * one;
+    constexpr int EBIAS = 1 << 23;
+    // padding columns (past the end of the database) carry qb + BIAS = DEADQ: with |2 dot| <= 4 194 304 their e + BIAS stays
+    // above the largest real value (8 323 200 + 8 355 840 + 8 388 608 = 25 067 648) and below 2^25 -- no select per distance
+    constexpr int DEADQ = 29300000;
+    constexpr unsigned DEADTHR = 25100000u;
+    int D0[4][4], D1[4][4], I0[4][4];                  // running result over the segments
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -124,22 +135,23 @@ __global__ __launch_bounds__(256) void k_match_l2(const unsigned char* __restric
 #pragma unroll
             for (int r = 0; r < 4; ++r) { b0[g][r] = 0xffffffffu; b1[g][r] = 0xffffffffu; }
         const int seg_end = min(db_n, seg + SEG);
-        // software pipeline: the B fragments of tile t+1 are in flight while tile t is multiplied and ranked (the scan is
-        // otherwise bound by the L2 round trip of these loads: 3 waves per SIMD cannot hide it)
-        const int col0 = min(seg + 16 * wave + (lane & 15), db_n - 1);
+        // software pipeline: the B fragments of tile t+1 are in flight while tile t is multiplied and ranked
+        const int colf = seg + 16 * wave + (lane & 15);
+        const int col0 = min(colf, db_n - 1);
         v4i nf0 = load_frag(dkeys, col0, lane, 0), nf1 = load_frag(dkeys, col0, lane, 1);
-        int nqb = qstat[db_off + col0];
+        int nqb = colf < db_n ? qstat[db_off + col0] + EBIAS : DEADQ;
         for (int tile = seg; tile < seg_end; tile += 64) {
-            const int col = tile + 16 * wave + (lane & 15);
             const v4i bf0 = nf0, bf1 = nf1;
-            const int qb = nqb;
+            const int qbb = nqb;
             if (tile + 64 < seg_end) {
-                const int coln = min(col + 64, db_n - 1);
-                nf0 = load_frag(dkeys, coln, lane, 0); nf1 = load_frag(dkeys, coln, lane, 1);
-                nqb = qstat[db_off + coln];
+                const int coln = tile + 64 + 16 * wave + (lane & 15);
+                const int colc = min(coln, db_n - 1);
+                nf0 = load_frag(dkeys, colc, lane, 0); nf1 = load_frag(dkeys, colc, lane, 1);
+                nqb = coln < db_n ? qstat[db_off + colc] + EBIAS : DEADQ;
             }
-            const bool live = col < db_n;
-            const unsigned tnum = (unsigned)((tile - seg) >> 6);
+            // key = ((qb + BIAS - 2 dot) << TB) | tile = K - (dot << (TB + 1)) with K = ((qb + BIAS) << TB) | tile: the low TB
+            // bits are untouched by the subtraction, so ONE 24-bit multiply-add per distance builds the packed key
+            const int K = (int)(((unsigned)qbb << TB) | (unsigned)((tile - seg) >> 6));
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 v4i acc = { 0, 0, 0, 0 };
@@ -147,21 +159,25 @@ __global__ __launch_bounds__(256) void k_match_l2(const unsigned char* __restric
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[g][1], bf1, acc, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const unsigned d = (unsigned)(qa[g][r] + (qb - 2 * acc[r]));      // exact squared distance, 0 .. 8 323 200
-                    const unsigned key = live ? ((d << TB) | tnum) : 0xffffffffu;
-                    b1[g][r] = max(b0[g][r], min(b1[g][r], key));      // median of (b0 <= b1, key)
+                    // (no inline asm on the accumulator itself: the compiler must see the MFMA -> VALU dependency to place
+                    //  the hazard wait states)
+                    const unsigned key = (unsigned)(__mul24(acc[r], mscale) + K);        // v_mad_i32_i24
+                    unsigned m;
+                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(b0[g][r]), "v"(b1[g][r]), "v"(key));
+                    b1[g][r] = m;
                     b0[g][r] = min(b0[g][r], key);
                 }
             }
         }
-        // fold the segment's packed pair into the running (D0 <= D1, I0)
+        // fold the segment's packed pair into the running (D0 <= D1, I0): d = e + qa
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const unsigned k0 = b0[g][r], k1 = b1[g][r];
-                const int c0 = k0 == 0xffffffffu ? BIG : (int)(k0 >> TB);
-                const int c1 = k1 == 0xffffffffu ? BIG : (int)(k1 >> TB);
+                const unsigned e0 = k0 >> TB, e1 = k1 >> TB;
+                const int c0 = e0 >= DEADTHR ? BIG : (int)e0 - EBIAS + qa[g][r];
+                const int c1 = e1 >= DEADTHR ? BIG : (int)e1 - EBIAS + qa[g][r];
                 const int ci = seg + (int)((k0 & ((1u << TB) - 1)) << 6) + slot;
                 if (c0 < D0[g][r]) { D1[g][r] = min(D0[g][r], c1); D0[g][r] = c0; I0[g][r] = ci; }
                 else D1[g][r] = min(D1[g][r], c0);
@@ -234,7 +250,7 @@ extern "C" int bsfm_match_keys_l2(int n1, const unsigned char* k1, int n2, const
     const PairDesc pd = { 0, n1, 0, 0 };
     HIPM(hipMemcpy(d.pairs, &pd, sizeof(pd), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_match_l2, dim3((n1 + QB - 1) / QB), dim3(256), 0, 0, d.keys, d.qstat, d.pairs, 1, n1, n2,
-                       ratio * ratio, d.nn);
+                       ratio * ratio, d.nn, 1);
     std::vector<int> nn(n1);
     HIPM(hipDeviceSynchronize());
     HIPM(hipMemcpy(nn.data(), d.nn, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost));
@@ -383,7 +399,7 @@ extern "C" int bsfm_key_match_full_sharded(int num_images, const int* num_keys, 
         }
         ok = ok && hipMemcpyAsync(s.d_pairs, s.h_pairs, s.npairs * sizeof(PairDesc), hipMemcpyHostToDevice, st) == hipSuccess;
         hipLaunchKernelGGL(k_match_l2, dim3(blk), dim3(256), 0, st, d.keys, d.qstat, s.d_pairs, (int)s.npairs,
-                           (int)off[i], num_keys[i], ratio * ratio, s.d_nn);
+                           (int)off[i], num_keys[i], ratio * ratio, s.d_nn, 1);
         ok = ok && hipMemcpyAsync(s.h_nn, s.d_nn, out * sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess;
         ok = ok && hipEventRecord(s.done, st) == hipSuccess;
         s.busy = true;
