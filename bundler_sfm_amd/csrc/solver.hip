@@ -79,6 +79,7 @@ struct bsfm_problem {
     double *d_campart = nullptr;        // per-camera slice partials of k_cam_blocks / k_schur_rhs (m x CAM_SPLIT x 54)
     double *d_red = nullptr;            // block partials for reductions
     double *d_scal = nullptr;
+    double *d_mixed = nullptr;          // staging of allreduce_mixed: a few sums + world slots per maximum
     int *d_flags = nullptr;             // [0] singular V, [1] potrf info
     // schur structure
     int ntriples = 0, ntasks = 0, nblk = 0;
@@ -112,7 +113,7 @@ void free_all(bsfm_problem* pb)
     void* ptrs[] = { pb->d_x, pb->d_Rinit, pb->d_finit, pb->d_obs_cam, pb->d_obs_pt, pb->d_rowptr, pb->d_camptr,
                      pb->d_camobs, pb->d_campos, pb->d_cam_pt, pb->d_cam_cam, pb->d_Jc, pb->d_ccon, pb->d_pcon, pb->d_cval, pb->d_cw, pb->d_pval, pb->d_p, pb->d_pdp,
                      pb->d_dp, pb->d_camtab, pb->d_camtab_trial, pb->d_e, pb->d_hx, pb->d_U,
-                     pb->d_V, pb->d_Vinv, pb->d_eb, pb->d_S, pb->d_E, pb->d_partials, pb->d_epart, pb->d_campart, pb->d_red, pb->d_scal,
+                     pb->d_V, pb->d_Vinv, pb->d_eb, pb->d_S, pb->d_E, pb->d_partials, pb->d_epart, pb->d_campart, pb->d_red, pb->d_scal, pb->d_mixed,
                      pb->d_flags, pb->d_triples, pb->d_tri_pt, pb->d_tasks, pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0,
                      pb->d_gidx, pb->d_gblk_j, pb->d_gblk_k, pb->d_G };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -278,6 +279,28 @@ int allreduce_host(bsfm_problem* pb, double* vals, int count, int op)
     HIP_OK(hipStreamSynchronize(pb->stream));
     if (pb->allreduce(tmp, (size_t)count, op, pb->allreduce_ctx) != 0) return BSFM_ERROR;
     HIP_OK(hipMemcpy(vals, tmp, count * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+// One exchange for a handful of host scalars of both kinds: `ns` values to be summed and `nm` values to be maximised.
+// The maxima ride the same SUM as an all-gather: value q of rank r sits in slot q*world + r, zeros elsewhere.
+int allreduce_mixed(bsfm_problem* pb, double* sums, int ns, double* maxs, int nm)
+{
+    if (pb->world <= 1 || !pb->allreduce) return 0;
+    const int count = ns + nm * pb->world;
+    std::vector<double> h((size_t)count, 0.0);
+    for (int q = 0; q < ns; ++q) h[q] = sums[q];
+    for (int q = 0; q < nm; ++q) h[ns + q * pb->world + pb->rank] = maxs[q];
+    double* tmp = pb->d_mixed;
+    HIP_OK(hipMemcpyAsync(tmp, h.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice, pb->stream));
+    HIP_OK(hipStreamSynchronize(pb->stream));
+    if (pb->allreduce(tmp, (size_t)count, 0, pb->allreduce_ctx) != 0) return BSFM_ERROR;
+    HIP_OK(hipMemcpy(h.data(), tmp, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    for (int q = 0; q < ns; ++q) sums[q] = h[q];
+    for (int q = 0; q < nm; ++q) {
+        double m = h[ns + q * pb->world];
+        for (int r = 1; r < pb->world; ++r) m = std::max(m, h[ns + q * pb->world + r]);
+        maxs[q] = m;
+    }
     return 0;
 }
 int allreduce_dev(bsfm_problem* pb, double* dbuf, size_t count, int op)
@@ -509,7 +532,7 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     DM(pb->d_V, 6 * (size_t)n); DM(pb->d_Vinv, 6 * (size_t)n); DM(pb->d_eb, 3 * (size_t)n);
     DM(pb->d_S, (size_t)pb->ld * pb->ld); DM(pb->d_E, pb->ld);
     pb->red_blocks = std::max(grid_for(nvis, RES_BLOCK), std::max(grid_for(n, 256), 1024));
-    DM(pb->d_red, 4 * (size_t)pb->red_blocks); DM(pb->d_scal, SC_COUNT + 16); DM(pb->d_flags, 4);
+    DM(pb->d_red, 4 * (size_t)pb->red_blocks); DM(pb->d_scal, SC_COUNT + 16); DM(pb->d_mixed, 8 + 4 * (size_t)std::max(1, d->world_size)); DM(pb->d_flags, 4);
 #undef DM
     if (hipHostMalloc((void**)&pb->h_scal, (SC_COUNT + 16) * sizeof(double)) != hipSuccess) return fail("pinned");
     if (hipHostMalloc((void**)&pb->h_flags, 4 * sizeof(int)) != hipSuccess) return fail("pinned");
@@ -694,7 +717,7 @@ int bsfm_lm_iterate(bsfm_problem_t* pb, int iters)
             if (pb->world > 1) {
                 HIP_OK(hipMemcpy(&sm[1], pb->d_scal + SC_COUNT + 8, sizeof(double), hipMemcpyDeviceToHost));
                 const double campart = ccost - sm[1];
-                if (allreduce_host(pb, mx, 2, 1) || allreduce_host(pb, sm, 2, 0)) return BSFM_ERROR;
+                if (allreduce_mixed(pb, sm, 2, mx, 2)) return BSFM_ERROR;
                 ccost = campart + sm[1];
             }
             pb->eab_inf = std::max(pb->h_scal[SC_EABINF_A], mx[0]);
@@ -739,7 +762,7 @@ int bsfm_lm_iterate(bsfm_problem_t* pb, int iters)
             double maxs[1] = { pb->h_scal[SC_PCT] };
             if (pb->world > 1) {
                 double mx2[2] = { flagsd[0], maxs[0] };
-                if (allreduce_host(pb, mx2, 2, 1) || allreduce_host(pb, sums, 3, 0)) return BSFM_ERROR;
+                if (allreduce_mixed(pb, sums, 3, mx2, 2)) return BSFM_ERROR;
                 flagsd[0] = mx2[0]; maxs[0] = mx2[1];
             }
             const bool singularV = flagsd[0] != 0.0;
