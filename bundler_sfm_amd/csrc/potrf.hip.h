@@ -405,7 +405,8 @@ __global__ __launch_bounds__(256, 1) void k_chain_tile32(double* __restrict__ S,
 
 // (Also tried and dropped: an XCD-aware blockIdx -> tile order (super-tiles of 8x8 tiles per XCD chunk).  +8-11 % for the
 // kernel alone on the whole device (scripts/ubench_syrk.hip), exactly 0 in the factorisation -- with the CU-masked bulk
-// stream (35.0 TFLOP/s either way) and again without the mask (38.4 vs 38.5).)
+// stream (35.0 TFLOP/s either way) and again without the mask (38.4 vs 38.5).  Nor do 64-row half-tile workgroups for the
+// late, device-underfilling launches: 37.7-38.5 TFLOP/s with a threshold of 24-32 tile rows vs 38.0 without.)
 // Trailing update: S_ij -= P_a P_b^T for k < j <= i (a = i-k-1, b = j-k-1), one tile per workgroup.
 // part 1 = only the first trailing column (b == 0, grid T): the tiles the NEXT panel needs (lookahead stream);
 // part 2 = every other tile (b >= 1) except S_{k+2,k+2}, grid T(T-1)/2 - 1: the bulk, on the update stream.
