@@ -306,14 +306,16 @@ __global__ __launch_bounds__(256, 1) void k_syrk_col64(double* __restrict__ S, i
 //   MODE 0 (grid 16): P_0 = S_{k+1,k} inv(L_kk)^T, written to S and to slot 0 of the compact panel.  inv(L_kk) is lower
 //                     triangular: output column block bc only needs k < 32 (bc + 1);
 //   MODE 1 (grid 10): S_{k+1,k+1} -= P_0 P_0^T, lower-triangle blocks only (all the diagonal-tile kernel reads); with
-//                     prev != nullptr ALSO -= Q_1 Q_1^T, Q = panel k-1: the bulk launch of step k-1 leaves this one tile
-//                     to the chain, so the next diagonal tile never waits for the bulk launch that has just started.
+//                     prev != nullptr ALSO -= Q_1 Q_1^T, Q = panel k-1 (and with prev2 the tile of panel k-2): the bulk
+//                     launches leave this one tile to the chain, so the next diagonal tile never waits for a bulk launch
+//                     that has just started.
 // The whole K range of both operands goes to LDS in one step (row stride 132 doubles: conflict-free A fragments).
 constexpr int T32_STRIDE = 132;
 constexpr int T32_LDS_DOUBLES = 2 * 32 * T32_STRIDE;
 template <int MODE>
 __global__ __launch_bounds__(256, 1) void k_chain_tile32(double* __restrict__ S, int ld, int k, const double* __restrict__ Linv,
-                                                         double* __restrict__ panel, const double* __restrict__ prev)
+                                                         double* __restrict__ panel, const double* __restrict__ prev,
+                                                         const double* __restrict__ prev2)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int br, bc;
@@ -321,14 +323,11 @@ __global__ __launch_bounds__(256, 1) void k_chain_tile32(double* __restrict__ S,
     else { const int t = blockIdx.x; br = t < 1 ? 0 : t < 3 ? 1 : t < 6 ? 2 : 3; bc = t - br * (br + 1) / 2; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = (wave >> 1) * 16, wc = (wave & 1) * 16;
-    const double* A; const double* B; int lda, K;
-    if (MODE == 0) {
-        A = S + ((size_t)(k + 1) * POTRF_NB + 32 * br) * ld + (size_t)k * POTRF_NB; lda = ld;
-        B = Linv + (size_t)(32 * bc) * POTRF_NB; K = 32 * (bc + 1);
-    } else {
-        A = panel + (size_t)(32 * br) * POTRF_NB; lda = POTRF_NB;
-        B = panel + (size_t)(32 * bc) * POTRF_NB; K = POTRF_NB;
-    }
+    constexpr size_t TL = (size_t)POTRF_NB * POTRF_NB;
+    // product segments: MODE 0 one (tile x inverse factor, K = 32 (bc + 1)); MODE 1 up to three panels, K = 128 each:
+    // P0 of panel k, tile 1 of panel k-1, tile 2 of panel k-2 (= the rows of S_{k+1,*} in those panels)
+    const int nseg = MODE == 0 ? 1 : (prev ? (prev2 ? 3 : 2) : 1);
+    const int K0 = MODE == 0 ? 32 * (bc + 1) : POTRF_NB;
     double* As = lds; double* Bs = lds + 32 * T32_STRIDE;
     double* Ct = S + ((size_t)(k + 1) * POTRF_NB + 32 * br) * ld + (size_t)(k + (MODE == 0 ? 0 : 1)) * POTRF_NB + 32 * bc;
     double cin[4];
@@ -336,69 +335,59 @@ __global__ __launch_bounds__(256, 1) void k_chain_tile32(double* __restrict__ S,
 #pragma unroll
         for (int t = 0; t < 4; ++t) cin[t] = Ct[(size_t)(wr + 4 * t + (lane >> 4)) * ld + wc + (lane & 15)];
     }
-    {   // 32 rows x K doubles per operand: thread -> (row = tid >> 3, 16-byte columns (tid & 7) + 8 q)
-        const int row = tid >> 3, c2 = (tid & 7) * 2;
-        double pa[8][2], pb[8][2];
+    // 32 rows x K doubles per operand: thread -> (row = tid >> 3, 16-byte columns (tid & 7) + 8 q)
+    const int row = tid >> 3, c2 = (tid & 7) * 2;
+    double pa[8][2], pb[8][2];
+#define BSFM_T32_FETCH(sg)                                                                                           \
+    {                                                                                                                \
+        const double* A_; const double* B_; int lda_;                                                                \
+        if (MODE == 0) {                                                                                             \
+            A_ = S + ((size_t)(k + 1) * POTRF_NB + 32 * br) * ld + (size_t)k * POTRF_NB; lda_ = ld;                  \
+            B_ = Linv + (size_t)(32 * bc) * POTRF_NB;                                                                \
+        } else {                                                                                                     \
+            const double* base_ = (sg) == 0 ? (const double*)panel : ((sg) == 1 ? prev + TL : prev2 + 2 * TL);       \
+            A_ = base_ + (size_t)(32 * br) * POTRF_NB; B_ = base_ + (size_t)(32 * bc) * POTRF_NB; lda_ = POTRF_NB;   \
+        }                                                                                                            \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                              \
+            if (16 * q < K0) {                                                                                       \
+                const double2 ta = *reinterpret_cast<const double2*>(A_ + (size_t)row * lda_ + 16 * q + c2);         \
+                const double2 tb = *reinterpret_cast<const double2*>(B_ + (size_t)row * POTRF_NB + 16 * q + c2);     \
+                pa[q][0] = ta.x; pa[q][1] = ta.y; pb[q][0] = tb.x; pb[q][1] = tb.y;                                  \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+    BSFM_T32_FETCH(0)
+    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+    const double* ap = As + (wr + (lane & 3)) * T32_STRIDE + (lane >> 4);
+    const double* bp = Bs + (wc + (lane & 15)) * T32_STRIDE + (lane >> 4);
+#pragma unroll 1
+    for (int sg = 0; sg < nseg; ++sg) {
+        if (sg > 0) __syncthreads();             // the previous segment has been consumed
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            if (16 * q < K) {
-                const double2 ta = *reinterpret_cast<const double2*>(A + (size_t)row * lda + 16 * q + c2);
-                const double2 tb = *reinterpret_cast<const double2*>(B + (size_t)row * POTRF_NB + 16 * q + c2);
-                pa[q][0] = ta.x; pa[q][1] = ta.y; pb[q][0] = tb.x; pb[q][1] = tb.y;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (16 * q < K) {
+            if (16 * q < K0) {
                 *reinterpret_cast<double2*>(As + row * T32_STRIDE + 16 * q + c2) = make_double2(pa[q][0], pa[q][1]);
                 *reinterpret_cast<double2*>(Bs + row * T32_STRIDE + 16 * q + c2) = make_double2(pb[q][0], pb[q][1]);
             }
         }
-    }
-    double qa[8][2], qb[8][2];                  // second segment (MODE 1 with prev): fetched before the first product starts
-    const int row_s = tid >> 3, c2_s = (tid & 7) * 2;
-    if (MODE == 1 && prev) {
-        const double* A2 = prev + (size_t)POTRF_NB * POTRF_NB + (size_t)(32 * br) * POTRF_NB;
-        const double* B2 = prev + (size_t)POTRF_NB * POTRF_NB + (size_t)(32 * bc) * POTRF_NB;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const double2 ta = *reinterpret_cast<const double2*>(A2 + (size_t)row_s * POTRF_NB + 16 * q + c2_s);
-            const double2 tb = *reinterpret_cast<const double2*>(B2 + (size_t)row_s * POTRF_NB + 16 * q + c2_s);
-            qa[q][0] = ta.x; qa[q][1] = ta.y; qb[q][0] = tb.x; qb[q][1] = tb.y;
-        }
-    }
-    __syncthreads();
-    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
-    const double* ap = As + (wr + (lane & 3)) * T32_STRIDE + (lane >> 4);
-    const double* bp = Bs + (wc + (lane & 15)) * T32_STRIDE + (lane >> 4);
-    for (int kk = 0; kk < K; kk += 4) {
-        const double b = bp[kk];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(ap[4 * t * T32_STRIDE + kk], b, acc[t], 0, 0, 0);
-    }
-    if (MODE == 1 && prev) {
         __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            *reinterpret_cast<double2*>(As + row_s * T32_STRIDE + 16 * q + c2_s) = make_double2(qa[q][0], qa[q][1]);
-            *reinterpret_cast<double2*>(Bs + row_s * T32_STRIDE + 16 * q + c2_s) = make_double2(qb[q][0], qb[q][1]);
-        }
-        __syncthreads();
-        for (int kk = 0; kk < POTRF_NB; kk += 4) {
+        if (sg + 1 < nseg) BSFM_T32_FETCH(sg + 1)      // in flight during this segment's products
+        for (int kk = 0; kk < K0; kk += 4) {
             const double b = bp[kk];
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(ap[4 * t * T32_STRIDE + kk], b, acc[t], 0, 0, 0);
         }
     }
+#undef BSFM_T32_FETCH
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const int row = wr + 4 * t + (lane >> 4), col = wc + (lane & 15);
+        const int rw = wr + 4 * t + (lane >> 4), col = wc + (lane & 15);
         if (MODE == 0) {
             // NOT written back to S here: the other column blocks of this row block still read the tile (in-place hazard
             // across workgroups); the side stream's panel kernel copies slot 0 of the compact panel to S afterwards
-            panel[(size_t)(32 * br + row) * POTRF_NB + 32 * bc + col] = acc[t];
+            panel[(size_t)(32 * br + rw) * POTRF_NB + 32 * bc + col] = acc[t];
         } else {
-            Ct[(size_t)row * ld + col] = cin[t] - acc[t];
+            Ct[(size_t)rw * ld + col] = cin[t] - acc[t];
         }
     }
 }
@@ -872,7 +861,7 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         const double* Lk = w.linv + (size_t)k * tl;
         // chain: first panel tile (its column k was completed by the side stream of step k-1)
         if (k > 0) (void)hipStreamWaitEvent(st, w.evC[k - 1], 0);
-        hipLaunchKernelGGL(k_chain_tile32<0>, dim3(16), dim3(256), lds32, st, S, ld, k, Lk, pk, (const double*)nullptr);
+        hipLaunchKernelGGL(k_chain_tile32<0>, dim3(16), dim3(256), lds32, st, S, ld, k, Lk, pk, (const double*)nullptr, (const double*)nullptr);
         (void)hipEventRecord(w.evT[k], st);
         // side: rest of the panel and y_k (the extra workgroup), then the rest of the first trailing column
         (void)hipStreamWaitEvent(w.sd, w.evT[k], 0);
@@ -896,7 +885,7 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         // having waited for evU[k-2] itself.  (Tried: hipStreamWriteValue32 / hipStreamWaitValue32 on signal memory instead
         // of the chain <-> side events: no faster.)
         hipLaunchKernelGGL(k_chain_tile32<1>, dim3(10), dim3(256), lds32, st, S, ld, k, Lk, pk,
-                           k > 0 ? (const double*)panel_of(k - 1) : (const double*)nullptr);
+                           k > 0 ? (const double*)panel_of(k - 1) : (const double*)nullptr, (const double*)nullptr);
         hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, k + 1, n, w.linv, d_info, w.dbg);
     }
     // y of the last tile: E_last is final once the side stream has drained
