@@ -445,9 +445,12 @@ __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __re
     }
 }
 
-// (Tried and dropped, see git history: a rank-256 variant applying panels k and k+1 in one pass over C.  Alone it runs at
-// 46.6 instead of 42.9 TFLOP/s (C traffic per flop halves), but the chain then has to serve two columns per pair and the
-// factorisation as a whole got slower: 10.9 vs 10.1 ms at config 3.)
+// (Tried twice and dropped: rank-256 bulk launches that apply panels k and k+1 in one pass over C.  The kernel alone runs at
+// 46.6 instead of 42.9 TFLOP/s (C traffic per flop halves), but the factorisation got slower both times -- with the
+// two-stream schedule (10.9 vs 10.1 ms) and again on the three-stream schedule with the skipped launch's work moved to
+// the side kernel (K = 256) and the chain tile kernel (three panels) and the launch split so that the side stream only
+// waits for its first two columns (9.5 vs 9.0 ms): the bulk stream idles while the chain and side streams prepare the
+// second panel of a pair, and their own kernels get heavier.)
 
 // Diagonal tile: Cholesky factor AND its inverse in ONE 512-thread workgroup -- the serial critical path of the
 // factorisation, so it is blocked to keep the truly serial work tiny:
