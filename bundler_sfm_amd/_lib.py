@@ -39,7 +39,7 @@ class ProblemDesc(C.Structure):
         ("use_constraints", C.c_int), ("use_point_constraints", C.c_int),
         ("point_constraints", C.POINTER(C.c_double)), ("point_constraint_weight", C.c_double),
         ("world_size", C.c_int), ("rank", C.c_int), ("nvis_global", C.c_longlong), ("nvars_global", C.c_longlong),
-        ("p_packed", C.POINTER(C.c_double)), ("constraints_prescaled", C.c_int),
+        ("p_packed", C.POINTER(C.c_double)), ("constraints_prescaled", C.c_int), ("fix_points", C.c_int),
     ]
 
 

@@ -9,8 +9,8 @@
 //   3. LM on the GPU (bsfm_lm_*), itmax = 150, verbose summary lines as sfm.c:872-873;
 //   4. unpack cameras / points in place (sfm.c:876-929);
 //   5. optional Vout/Sout/Uout/Wout export at the solution (lib/sba-1.5/sba_levmar.c:1633-2026).
-// Modes the GPU core does not cover (fix_points -> sba_mot_levmar, fisheye, known intrinsics) fail
-// loudly and leave every input untouched: there is deliberately no CPU fallback in this library.
+// fix_points != 0 selects the camera-only refinement (sba_mot_levmar, sfm.c:839-846).  Modes the GPU core does not cover
+// (fisheye, known intrinsics) fail loudly and leave every input untouched: there is deliberately no CPU fallback here.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -155,9 +155,9 @@ int bsfm_run_sfm_ex(int num_pts, int num_cameras, int ncons, char* vmask, double
     for (int i = 0; i < BSFM_INFOSZ; ++i) linfo[i] = 0.0;
     if (!info) info = linfo;
 
-    if (fix_points || optimize_for_fisheye) {
-        fprintf(stderr, "[bsfm] run_sfm: fix_points / fisheye modes are not implemented on the GPU core "
-                        "(reference: sba_mot_levmar, sfm.c:839-855); inputs left untouched\n");
+    if (optimize_for_fisheye) {
+        fprintf(stderr, "[bsfm] run_sfm: the fisheye projection (sfm.c:448-492) is not implemented on the GPU core; "
+                        "inputs left untouched\n");
         return BSFM_ERROR;
     }
     if (est_focal_length && const_focal_length)
@@ -181,6 +181,7 @@ int bsfm_run_sfm_ex(int num_pts, int num_cameras, int ncons, char* vmask, double
     d.use_constraints = use_constraints; d.use_point_constraints = use_point_constraints;
     d.point_constraints = reinterpret_cast<const double*>(points_constraints);
     d.point_constraint_weight = point_constraint_weight;
+    d.fix_points = fix_points ? 1 : 0;              // sba_mot_levmar: cameras only, no point constraints, no V/S/W
     d.world_size = 1; d.rank = 0;
 
     bsfm_problem_t* pb = bsfm_problem_create(&d, &opt);
@@ -195,9 +196,9 @@ int bsfm_run_sfm_ex(int num_pts, int num_cameras, int ncons, char* vmask, double
     const int cnp = bsfm_problem_cnp(pb);
     if (rc != BSFM_ERROR || info[5] > 0) {
         // the reference copies the parameter vector back unconditionally (sfm.c:876-929)
-        bsfm_problem_download(pb, nullptr, init_camera_params, reinterpret_cast<double*>(init_pts));
+        bsfm_problem_download(pb, nullptr, init_camera_params, fix_points ? nullptr : reinterpret_cast<double*>(init_pts));
     }
-    export_blocks(pb, num_pts, ncons, cnp, rowptr, colidx, Vout, Sout, Uout, Wout);
+    if (!fix_points) export_blocks(pb, num_pts, ncons, cnp, rowptr, colidx, Vout, Sout, Uout, Wout);
     bsfm_problem_destroy(pb);
     return rc;
 }

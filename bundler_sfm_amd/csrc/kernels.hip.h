@@ -684,6 +684,58 @@ __global__ __launch_bounds__(256) void k_point_outliers(int n, const int* __rest
     flag[i] = f; err[i] = ev;
 }
 
+// Camera-only refinement (points fixed): (U_j + mu I) da_j = ea_j, one thread per camera, Cholesky in registers
+// (the reference calls sba_Axb_Chol on every U_j, sba_levmar.c:2499-2513); a non-positive pivot raises flag[1].
+template <int CNP>
+__global__ __launch_bounds__(64) void k_cam_solve(DevProblem P, double mu, double* __restrict__ dpa, int* __restrict__ flag)
+{
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= P.m) return;
+    double* out = dpa + (size_t)j * CNP;
+    if (j < P.mcon) {
+#pragma unroll
+        for (int q = 0; q < CNP; ++q) out[q] = 0.0;
+        return;
+    }
+    const double* U = P.U + (size_t)j * CNP * CNP;
+    double l[CNP][CNP], x[CNP];
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < CNP; ++c) {
+        double d = U[c * CNP + c] + mu;
+#pragma unroll
+        for (int q = 0; q < c; ++q) d -= l[c][q] * l[c][q];
+        if (!(d > 0.0)) bad = true;
+        const double s = sqrt(d);
+        l[c][c] = s;
+        const double inv = 1.0 / s;
+#pragma unroll
+        for (int r = c + 1; r < CNP; ++r) {
+            double v = U[r * CNP + c];
+#pragma unroll
+            for (int q = 0; q < c; ++q) v -= l[r][q] * l[c][q];
+            l[r][c] = v * inv;
+        }
+    }
+    if (bad) { atomicOr(flag + 1, 1); return; }
+#pragma unroll
+    for (int r = 0; r < CNP; ++r) {          // L y = ea
+        double v = P.ea[(size_t)j * CNP + r];
+#pragma unroll
+        for (int q = 0; q < r; ++q) v -= l[r][q] * x[q];
+        x[r] = v / l[r][r];
+    }
+#pragma unroll
+    for (int r = CNP - 1; r >= 0; --r) {     // L^T da = y
+        double v = x[r];
+#pragma unroll
+        for (int q = r + 1; q < CNP; ++q) v -= l[q][r] * x[q];
+        x[r] = v / l[r][r];
+    }
+#pragma unroll
+    for (int q = 0; q < CNP; ++q) out[q] = x[q];
+}
+
 // expand packed V (+mu) to the reference's full symmetric 3x3 per point (test/export helper)
 __global__ void k_expand_v(int n, double mu, const double* __restrict__ V, double* __restrict__ out)
 {

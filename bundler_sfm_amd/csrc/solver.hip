@@ -60,6 +60,7 @@ struct bsfm_problem {
     DevProblem P{};
     int cnp = 0, nvars_local = 0;
     int world = 1, rank = 0;
+    int mot = 0;                        // camera-only refinement (desc.fix_points)
     long long nvis_global = 0, nvars_global = 0;
     int Sdim = 0, ld = 0;
     // device
@@ -348,7 +349,7 @@ int compute_normal_blocks(bsfm_problem* pb)
     if (P.ccon)
         hipLaunchKernelGGL(k_cam_constraints, dim3(grid_for((size_t)P.m * cnp, 256)), dim3(256), 0, pb->stream, P, pb->d_p);
     ph_begin(pb, PH_PTBLK);
-    if (P.n > 0) DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_point_blocks<C>), dim3(grid_for(P.n, 256)), dim3(256), 0, pb->stream, P, pb->d_e, pbpts));
+    if (P.n > 0 && !pb->mot) DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_point_blocks<C>), dim3(grid_for(P.n, 256)), dim3(256), 0, pb->stream, P, pb->d_e, pbpts));
     ph_end(pb, PH_PTBLK);
     return 0;
 }
@@ -499,7 +500,8 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     P.n = n; P.m = m; P.mcon = d->mcon; P.nvis = nvis; P.js = 2 * cnp + 6;
     pb->world = d->world_size > 1 ? d->world_size : 1; pb->rank = d->world_size > 1 ? d->rank : 0;
     pb->nvis_global = d->nvis_global > 0 ? d->nvis_global : nvis;
-    pb->nvars_global = d->nvars_global > 0 ? d->nvars_global : ((long long)m * cnp + 3LL * n);
+    pb->mot = d->fix_points ? 1 : 0;
+    pb->nvars_global = d->nvars_global > 0 ? d->nvars_global : (pb->mot ? (long long)m * cnp : (long long)m * cnp + 3LL * n);
     pb->nvars_local = m * cnp + 3 * n;
     P.nvis_global = (double)pb->nvis_global;
     pb->Sdim = (m - d->mcon) * cnp;
@@ -567,7 +569,7 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
         if (dmalloc(&pb->d_ccon, con.size()) != hipSuccess || dmalloc(&pb->d_cval, val.size()) != hipSuccess || dmalloc(&pb->d_cw, w.size()) != hipSuccess) return fail("hipMalloc constraints");
         ok = ok && up(pb->d_ccon, con.data(), con.size()) && up(pb->d_cval, val.data(), val.size() * sizeof(double)) && up(pb->d_cw, w.data(), w.size() * sizeof(double));
     }
-    if (d->use_point_constraints && d->point_constraints) {   // sfm.c:757-781
+    if (d->use_point_constraints && d->point_constraints && !d->fix_points) {   // sfm.c:757-781 (sba_mot_levmar takes none)
         std::vector<unsigned char> con(std::max(n, 1));
         for (int i = 0; i < n; ++i) { const double* c = d->point_constraints + 3 * (size_t)i; con[i] = !(c[0] == 0.0 && c[1] == 0.0 && c[2] == 0.0); }
         if (dmalloc(&pb->d_pcon, (size_t)n) != hipSuccess || dmalloc(&pb->d_pval, 3 * (size_t)n) != hipSuccess) return fail("hipMalloc point constraints");
@@ -676,10 +678,104 @@ int bsfm_lm_begin(bsfm_problem_t* pb)
     return 0;
 }
 
+// Camera-only LM (sba_mot_levmar_x, lib/sba-1.5/sba_levmar.c:2090-2690): same damping control as the full problem, but
+// the step is one cnp x cnp solve per camera, there is no Snavely stop rule (stop 8) and nlss counts cameras.
+static int lm_iterate_mot(bsfm_problem_t* pb, int iters)
+{
+    const int cnp = pb->cnp;
+    DevProblem& P = pb->P;
+    const int itmax = pb->opt.itmax;
+    const double tau = fabs(pb->opt.opts[0]), eps1 = fabs(pb->opt.opts[1]), eps2 = fabs(pb->opt.opts[2]),
+                 eps2_sq = pb->opt.opts[2] * pb->opt.opts[2], eps3_sq = pb->opt.opts[3] * pb->opt.opts[3],
+                 eps4_sq = pb->opt.opts[4] * pb->opt.opts[4];
+    const size_t npts3 = (size_t)3 * P.n;
+    int done = 0;
+    for (; pb->itno < itmax && !pb->stop && done < iters; ++pb->itno, ++done) {
+        if (compute_normal_blocks(pb)) return BSFM_ERROR;      // J (A part is what matters), U, ea (+ constraints)
+        ++pb->njev;
+        double* d_pa = pb->d_p;
+        hipLaunchKernelGGL(k_absmax_partial, dim3(1), dim3(256), 0, pb->stream, pb->d_ea, (size_t)P.m * cnp, pb->d_scal + SC_EABINF_A);
+        hipLaunchKernelGGL(k_udiag_max, dim3(1), dim3(256), 0, pb->stream, pb->d_U, P.m, P.mcon, cnp, pb->d_scal + SC_MAXDIAG_U);
+        hipLaunchKernelGGL(k_sumsq_partial, dim3(1), dim3(256), 0, pb->stream, d_pa, (size_t)P.m * cnp, pb->d_scal + SC_PL2_A);
+        hipLaunchKernelGGL(k_constraint_cost, dim3(1), dim3(256), 0, pb->stream, P, d_pa, d_pa + (size_t)P.m * cnp, 1, pb->d_scal + SC_CCOST);
+        if (read_scalars(pb)) return BSFM_ERROR;
+        const double ccost = pb->h_scal[SC_CCOST];
+        pb->eab_inf = pb->h_scal[SC_EABINF_A];
+        pb->p_L2 = pb->h_scal[SC_PL2_A];
+        pb->maxdiag = std::max(DBL_MIN, pb->h_scal[SC_MAXDIAG_U]);
+        if (pb->eab_inf <= eps1) { pb->dp_L2 = 0.0; pb->stop = 1; break; }
+        if (pb->itno == 0) pb->mu = tau * pb->maxdiag;
+        while (1) {
+            const double mu = pb->mu;
+            (void)hipMemsetAsync(pb->d_flags, 0, 4 * sizeof(int), pb->stream);
+            ph_begin(pb, PH_SOLVE);
+            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_cam_solve<C>), dim3(grid_for(P.m, 64)), dim3(64), 0, pb->stream, P, mu, pb->d_dp, pb->d_flags));
+            ph_end(pb, PH_SOLVE);
+            pb->nlss += P.m - P.mcon;                       // one linear system per free camera (sba_levmar.c:2505-2513)
+            hipLaunchKernelGGL(k_cam_step, dim3(1), dim3(256), 0, pb->stream, P.m * cnp, P.mcon * cnp, mu, d_pa, pb->d_dp, pb->d_ea,
+                               pb->d_pdp, pb->d_scal + SC_CAM3);
+            if (npts3) (void)hipMemcpyAsync(pb->d_pdp + (size_t)P.m * cnp, pb->d_p + (size_t)P.m * cnp, npts3 * sizeof(double), hipMemcpyDeviceToDevice, pb->stream);
+            ph_begin(pb, PH_RESID);
+            launch_cam_table(pb, pb->d_pdp, pb->d_camtab_trial);
+            launch_residual(pb, pb->d_camtab_trial, pb->d_pdp, pb->d_hx, pb->d_e, SC_COST_TRIAL);
+            ph_end(pb, PH_RESID);
+            if (read_scalars(pb)) return BSFM_ERROR;
+            collect_phase_times(pb);
+            double sums[1] = { pb->h_scal[SC_COST_TRIAL] };
+            if (pb->world > 1 && allreduce_host(pb, sums, 1, 0)) return BSFM_ERROR;
+            bool accepted = false;
+            if (pb->h_flags[1] == 0) {                      // every U_j + mu I was positive definite (nsolved == m)
+                pb->dp_L2 = pb->h_scal[SC_CAM3 + 0];
+                const double dL = pb->h_scal[SC_CAM3 + 2];
+                if (pb->dp_L2 <= eps2_sq * pb->p_L2) { pb->stop = 2; break; }
+                if (pb->dp_L2 >= (pb->p_L2 + eps2) / SBA_EPSILON_SQ) {
+                    fprintf(stderr, "SBA: the matrix of the augmented normal equations is almost singular in sba_mot_levmar_x(),\n"
+                                    "     minimization should be restarted from the current solution with an increased damping term\n");
+                    pb->error = 1;
+                    return BSFM_ERROR;
+                }
+                ++pb->nfev;
+                double pdp_eL2 = sums[0];
+                if (!std::isfinite(pdp_eL2)) { pb->stop = 7; break; }
+                pdp_eL2 += ccost;                            // constraint terms at the OLD p, as in the reference (sba_levmar.c:2592-2611)
+                const double dF = pb->p_eL2 - pdp_eL2;
+                if (pb->opt.verbose >= 2)
+                    printf("\ndamping term %8g, gain ratio %8g, errors %8g / %8g = %g\n", mu, dL != 0.0 ? dF / dL : dF / DBL_EPSILON,
+                           pb->p_eL2 / (double)pb->nvis_global, pdp_eL2 / (double)pb->nvis_global, pb->p_eL2 / pdp_eL2);
+                if (dL > 0.0 && dF > 0.0) {
+                    double tmp = (2.0 * dF / dL - 1.0);
+                    tmp = 1.0 - tmp * tmp * tmp;
+                    pb->mu = pb->mu * ((tmp >= SBA_ONE_THIRD) ? tmp : SBA_ONE_THIRD);
+                    pb->nu = 2;
+                    if (pdp_eL2 - 2.0 * sqrt(pb->p_eL2 * pdp_eL2) < (eps4_sq - 1.0) * pb->p_eL2) pb->stop = 4;
+                    std::swap(pb->d_p, pb->d_pdp);
+                    std::swap(pb->d_e, pb->d_hx);
+                    std::swap(pb->d_camtab, pb->d_camtab_trial);
+                    pb->p_eL2 = pdp_eL2;
+                    accepted = true;
+                }
+            }
+            if (accepted) break;
+            pb->mu *= pb->nu;
+            const int nu2 = (int)((unsigned)pb->nu << 1);
+            if (nu2 <= pb->nu) {
+                fprintf(stderr, "SBA: too many failed attempts to increase the damping factor in sba_mot_levmar_x()! Singular Hessian matrix?\n");
+                pb->stop = 6;
+                break;
+            }
+            pb->nu = nu2;
+        }
+        if (pb->p_eL2 <= eps3_sq) pb->stop = 5;
+    }
+    if (pb->itno >= itmax) pb->stop = 3;
+    return pb->stop;
+}
+
 int bsfm_lm_iterate(bsfm_problem_t* pb, int iters)
 {
     if (!pb->began) { if (bsfm_lm_begin(pb) != 0) return BSFM_ERROR; }
     if (pb->error) return BSFM_ERROR;
+    if (pb->mot) return lm_iterate_mot(pb, iters);
     const int cnp = pb->cnp;
     DevProblem& P = pb->P;
     const int itmax = pb->opt.itmax;

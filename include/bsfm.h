@@ -148,6 +148,9 @@ typedef struct {
      * and constraint values/weights already in that parametrisation (the rescaling of sfm.c:721-754 is skipped). */
     const double *p_packed;      /* NULL = pack from cameras/points */
     int constraints_prescaled;
+    /* Camera-only refinement (run_sfm's fix_points != 0 -> sba_mot_levmar, lib/sfm-driver/sfm.c:839-846): the points are
+     * constants, the normal equations decouple into one cnp x cnp system per camera (sba_levmar.c:2090-2690). */
+    int fix_points;
 } bsfm_problem_desc_t;
 
 /* Sum-reduce `count` doubles in place across ranks (device pointer); op 0 = sum, 1 = max.

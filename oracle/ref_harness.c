@@ -148,6 +148,82 @@ int ref_sba_motstr(int n, int m, int mcon, char *vmask, double *projections,
     return rc;
 }
 
+/* Camera-only refinement (run_sfm with fix_points != 0: lib/sfm-driver/sfm.c:839-846 -> sba_mot_levmar,
+ * lib/sba-1.5/sba_levmar_wrap.c:707-800, expert driver sba_levmar.c:2090-2690): same set-up as ref_sba_motstr but the
+ * parameter vector holds the m*cnp camera parameters only; points stay what `pts` says.  jac_mode 1 hands OUR analytic
+ * d x / d a to SBA through its projac hook.  p_out gets m*cnp doubles. */
+static void harness_projac_mot(int j, int i, double *aj, double *Aij, void *adata)
+{
+    sfm_global_t *globs = (sfm_global_t *) adata;
+    double Bij[6];
+    sm_jacobian(&g_cfg, globs->init_params[j].R, globs->init_params[j].f, aj, globs->points[i].p, Aij, Bij);
+}
+
+int ref_sba_mot(int n, int m, int mcon, char *vmask, double *projections,
+                int est_focal, int undistort, int explicit_centers,
+                camera_params_t *cams, double *pts, int use_constraints, double eps2,
+                int itmax, int jac_mode, int verbose, double *info, double *p_out, double *secs)
+{
+    const double f_scale = 0.001, k_scale = 5.0;
+    int cnp = (est_focal ? 7 : 6) + (undistort ? 2 : 0);
+    int nvars = cnp * m, j, rc;
+    double opts[6];
+    double *params = (double *) malloc(sizeof(double) * nvars);
+    camera_constraints_t *cons = NULL;
+    sfm_global_t globs;
+    struct timeval t0, t1;
+
+    for (j = 0; j < m; j++) {
+        double *a = params + cnp * j;
+        int c = 6;
+        cams[j].f_scale = f_scale; cams[j].k_scale = k_scale;
+        a[0] = cams[j].t[0]; a[1] = cams[j].t[1]; a[2] = cams[j].t[2];
+        a[3] = a[4] = a[5] = 0.0;
+        if (est_focal) { a[6] = cams[j].f * f_scale; c = 7; }
+        if (undistort) { a[c] = cams[j].k[0] * k_scale; a[c + 1] = cams[j].k[1] * k_scale; }
+    }
+    opts[0] = 1.0e-3; opts[1] = 1.0e-10; opts[2] = eps2; opts[3] = 1.0e-12; opts[4] = 0.0; opts[5] = 4.0e-2;
+    if (use_constraints) {
+        cons = (camera_constraints_t *) malloc(m * sizeof(camera_constraints_t));
+        for (j = 0; j < m; j++) {
+            cons[j].constrained = (char *) malloc(cnp);
+            cons[j].constraints = (double *) malloc(sizeof(double) * cnp);
+            cons[j].weights = (double *) malloc(sizeof(double) * cnp);
+            memcpy(cons[j].constrained, cams[j].constrained, cnp);
+            memcpy(cons[j].constraints, cams[j].constraints, cnp * sizeof(double));
+            memcpy(cons[j].weights, cams[j].weights, cnp * sizeof(double));
+            if (est_focal) { cons[j].constraints[6] *= f_scale; cons[j].weights[6] *= 1.0 / (f_scale * f_scale); }
+            if (undistort) {
+                cons[j].constraints[7] *= k_scale; cons[j].weights[7] *= 1.0 / (k_scale * k_scale);
+                cons[j].constraints[8] *= k_scale; cons[j].weights[8] *= 1.0 / (k_scale * k_scale);
+            }
+        }
+    }
+    memset(&globs, 0, sizeof(globs));
+    globs.num_cameras = m; globs.num_points = n; globs.num_params_per_camera = cnp;
+    globs.est_focal_length = est_focal; globs.const_focal_length = 0;
+    globs.estimate_distortion = undistort; globs.explicit_camera_centers = explicit_centers;
+    globs.global_params.f = 1.0; globs.init_params = cams; globs.points = (v3_t *) pts;
+    global_last_ws = (double *) calloc(3 * m, sizeof(double));
+    global_last_Rs = (double *) malloc(9 * m * sizeof(double));
+    for (j = 0; j < m; j++) memcpy(global_last_Rs + 9 * j, cams[j].R, 9 * sizeof(double));
+    g_cfg.cnp = cnp; g_cfg.est_focal = est_focal; g_cfg.undistort = undistort;
+    g_cfg.explicit_centers = explicit_centers; g_cfg.f_scale = f_scale; g_cfg.k_scale = k_scale;
+
+    gettimeofday(&t0, NULL);
+    rc = sba_mot_levmar(n, m, mcon, vmask, params, cnp, projections, NULL, 2,
+                        sfm_project_point3_mot, jac_mode ? harness_projac_mot : NULL, (void *) &globs,
+                        itmax, verbose, opts, info, use_constraints, cons);
+    gettimeofday(&t1, NULL);
+    if (secs) *secs = (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec);
+    if (p_out) memcpy(p_out, params, sizeof(double) * nvars);
+    for (j = 0; j < m; j++) { cams[j].f_scale = 1.0; cams[j].k_scale = 1.0; }
+    if (cons) { for (j = 0; j < m; j++) { free(cons[j].constrained); free(cons[j].constraints); free(cons[j].weights); } free(cons); }
+    free(params); free(global_last_ws); free(global_last_Rs);
+    global_last_ws = global_last_Rs = NULL;
+    return rc;
+}
+
 /* Reference projection of one observation with the packed parameters (for model parity tests). */
 void ref_project_point(int est_focal, int undistort, int explicit_centers, camera_params_t *cam,
                        double *aj, double *bi, double *xij)

@@ -81,6 +81,33 @@ def exports():
     print("export_golden:", len(out), "arrays")
 
 
+def mot():
+    """Camera-only refinement (run_sfm with fix_points = 1 -> sba_mot_levmar): fixtures of tests/test_ba_gpu.py::test_mot_*."""
+    out = {}
+    for name, c in (("s9", dict(m=8, n=60, deg=4, est=1, und=1, ncons=0, cons=0)),
+                    ("s9c", dict(m=8, n=60, deg=4, est=1, und=1, ncons=0, cons=1)),
+                    ("s9m", dict(m=8, n=60, deg=4, est=1, und=1, ncons=2, cons=0)),
+                    ("s7", dict(m=6, n=50, deg=3, est=1, und=0, ncons=0, cons=0))):
+        s = B.synth_ba(c["m"], c["n"], c["deg"])
+        cams = s["cams"]
+        if c["cons"]:
+            O.set_bundler_constraints(cams)
+        vm = B.dense_vmask(c["n"], c["m"], s["rowptr"], s["colidx"])
+        for jm, tag in ((0, "fd"), (1, "an")):
+            for it in (1, 3, 150):
+                r = O.ref_sba_mot(c["n"], c["m"], vm, s["proj"], cams, s["pts"], itmax=it, jac_mode=jm, ncons=c["ncons"],
+                                  est_focal=c["est"], undistort=c["und"], use_constraints=c["cons"])
+                out[f"{name}_{tag}_it{it}_p"] = r["p"]; out[f"{name}_{tag}_it{it}_info"] = r["info"]
+        rc, rp = O.ref_run_sfm(c["n"], c["m"], vm, s["proj"], cams, s["pts"], ncons=c["ncons"], est_focal=c["est"],
+                               undistort=c["und"], use_constraints=c["cons"], fix_points=1)
+        ra = O.cams_to_arrays(rc)
+        for k in ("R", "t", "f", "k"):
+            out[f"{name}_run_cam_{k}"] = ra[k]
+        assert np.array_equal(rp, s["pts"])               # points untouched
+    np.savez_compressed(os.path.join(HERE, "mot_golden.npz"), **out)
+    print("mot_golden:", len(out), "arrays")
+
+
 def parse_bundle(path):
     toks = open(path).read().split("\n")
     assert toks[0].startswith("# Bundle file v0.3")
@@ -197,6 +224,6 @@ def model():
 if __name__ == "__main__":
     assert O.have_ref(), "build oracle/_ref first (make -C oracle ref)"
     only = sys.argv[1:]
-    for fn in (ba_cases, kermit, matcher, model, exports):
+    for fn in (ba_cases, kermit, matcher, model, exports, mot):
         if not only or fn.__name__ in only:
             fn()

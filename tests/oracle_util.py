@@ -78,7 +78,7 @@ def copy_cams(cams):
 
 
 def ref_run_sfm(n, m, vmask, proj, cams, pts, ncons=0, est_focal=1, undistort=1, explicit=1, use_constraints=0,
-                point_constraints=None, point_w=0.0, eps2=1e-12, quiet=True):
+                point_constraints=None, point_w=0.0, eps2=1e-12, quiet=True, fix_points=0):
     """Verbatim reference run_sfm (oracle mode A). Returns (cams_out, pts_out)."""
     cams = copy_cams(cams)
     pts = np.array(pts, np.float64, copy=True)
@@ -88,8 +88,29 @@ def ref_run_sfm(n, m, vmask, proj, cams, pts, ncons=0, est_focal=1, undistort=1,
     with ctx:
         ref().ref_run_sfm(n, m, ncons, vm.ctypes.data_as(C.c_char_p), _d(proj), est_focal, 0, undistort, explicit,
                           cams, _d(pts), use_constraints, 0 if point_constraints is None else 1,
-                          _d(point_constraints), point_w, 0, 0, eps2, None, None, None, None)
+                          _d(point_constraints), point_w, fix_points, 0, eps2, None, None, None, None)
     return cams, pts
+
+
+def ref_sba_mot(n, m, vmask, proj, cams, pts, itmax, jac_mode, ncons=0, est_focal=1, undistort=1, explicit=1,
+                use_constraints=0, eps2=1e-12, quiet=True):
+    """Reference sba_mot_levmar (camera-only refinement, what run_sfm calls with fix_points != 0) with chosen itmax /
+    Jacobian.  Returns dict(rc, info, p (m*cnp), secs)."""
+    cnp = (7 if est_focal else 6) + (2 if undistort else 0)
+    cams = copy_cams(cams)
+    pts = np.array(pts, np.float64, copy=True)
+    vm = np.ascontiguousarray(vmask, np.uint8)
+    proj = np.ascontiguousarray(proj, np.float64)
+    info = np.zeros(10)
+    p = np.zeros(m * cnp)
+    secs = C.c_double()
+    fn = ref().ref_sba_mot
+    fn.restype = C.c_int
+    ctx = quiet_stdout() if quiet else contextlib.nullcontext()
+    with ctx:
+        rc = fn(n, m, ncons, vm.ctypes.data_as(C.c_char_p), _d(proj), est_focal, undistort, explicit, cams, _d(pts),
+                use_constraints, C.c_double(eps2), itmax, jac_mode, 0 if quiet else 3, _d(info), _d(p), C.byref(secs))
+    return dict(rc=rc, info=info, p=p, secs=secs.value, cnp=cnp)
 
 
 def ref_sba(n, m, vmask, proj, cams, pts, itmax, jac_mode, ncons=0, est_focal=1, undistort=1, explicit=1,

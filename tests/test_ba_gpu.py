@@ -404,3 +404,58 @@ def test_post_solve_outlier_statistics(gpu_bsfm, with_pcons):
     assert np.array_equal(st["outlier"], flag)
     assert flag.sum() >= 10 and (pcons is None or flag.sum() < 40)
     assert np.abs(st["err"] - err).max() <= 1e-9 * max(1.0, err.max())
+
+
+MOT = np.load(os.path.join(os.path.dirname(__file__), "golden", "mot_golden.npz"))
+REF_OPTS = [1e-3, 1e-10, 1e-12, 1e-12, 0.0, 4e-2]     # what run_sfm passes (sfm.c:705-714, eps2 = 1e-12 as in the fixtures)
+
+
+@pytest.mark.parametrize("name", ["s9", "s9c", "s9m", "s7"])
+def test_mot_camera_only_refinement_matches_reference(gpu_bsfm, name):
+    """SURVEY 8(f).3 / run_sfm's fix_points: camera-only LM (sba_mot_levmar_x, sba_levmar.c:2090-2690) against the
+    reference's own runs (tests/golden/mot_golden.npz from oracle/_ref): parameter vector after 1 and 3 iterations,
+    counters (iterations, function / Jacobian evaluations, linear systems = attempts x free cameras), final cost."""
+    B = gpu_bsfm
+    c = load_case(name)
+    m, n = c["m"], c["n"]
+    cnp = 6 + c["est"] + 2 * c["und"]
+    for tag, jac, tol in (("an", B.JAC_ANALYTIC, 1e-8), ("fd", B.JAC_FD, 1e-6)):
+        for it in (1, 3):
+            opt = B.default_options(jacobian=jac, verbose=0, itmax=it, opts=REF_OPTS)
+            pb = B.Problem(n, m, c["rowptr"], c["colidx"], c["proj"], c["cams"], c["pts"], mcon=c["ncons"],
+                           est_focal_length=c["est"], undistort=c["und"], use_constraints=c["cons"], options=opt, fix_points=1)
+            rc, info = pb.solve()
+            p = pb.download(want_cams=False)[0]
+            pb.close()
+            gi, gp = MOT[f"{name}_{tag}_it{it}_info"], MOT[f"{name}_{tag}_it{it}_p"]
+            assert rc == it and list(info[5:10]) == list(gi[5:10]), (info, gi)
+            assert abs(info[0] - gi[0]) <= 1e-12 * gi[0] and abs(info[1] - gi[1]) <= 1e-9 * gi[1]
+            assert np.abs(p[:m * cnp] - gp).max() <= tol * np.abs(gp).max()
+            assert np.array_equal(p[m * cnp:], c["pts"])                      # points are constants
+        pb = B.Problem(n, m, c["rowptr"], c["colidx"], c["proj"], c["cams"], c["pts"], mcon=c["ncons"],
+                       est_focal_length=c["est"], undistort=c["und"], use_constraints=c["cons"],
+                       options=B.default_options(jacobian=jac, verbose=0, itmax=150, opts=REF_OPTS), fix_points=1)
+        rc, info = pb.solve()
+        pb.close()
+        gi = MOT[f"{name}_{tag}_it150_info"]
+        assert abs(info[1] - gi[1]) <= 1e-7 * gi[1]
+        # the tail is rounding noise: with eps4 = 0 stop rule 4 (sba_levmar.c:2625) fires as soon as the relative cost
+        # change drops below ~1e-8 -- the reference itself ends after 24 (FD) or 28 (analytic) iterations on s9
+        assert info[6] in (2.0, 4.0) and abs(info[5] - gi[5]) <= 6
+
+
+def test_run_sfm_fix_points_matches_reference_run_sfm(gpu_bsfm):
+    """The boundary itself with fix_points = 1 (EstimateIgnoredCameras, src/Bundle.cpp:1917,1969)."""
+    B = gpu_bsfm
+    for name in ("s9", "s9c", "s7"):
+        c = load_case(name)
+        cams = B.copy_cameras(c["cams"]); pts = c["pts"].copy()
+        rc, info = B.run_sfm(c["n"], c["m"], c["ncons"], c["vm"], c["proj"], c["est"], 0, c["und"], 1, cams, pts,
+                             use_constraints=c["cons"], fix_points=1, eps2=1e-12, options=B.default_options(verbose=0))
+        assert rc >= 0
+        assert np.array_equal(pts, c["pts"])
+        f = np.array([cm.f for cm in cams]); t = np.array([list(cm.t) for cm in cams])
+        R = np.array([list(cm.R) for cm in cams])
+        assert np.abs(f - MOT[f"{name}_run_cam_f"]).max() <= 1e-5 * np.abs(f).max()
+        assert np.abs(t - MOT[f"{name}_run_cam_t"]).max() <= 1e-5 * max(1.0, np.abs(t).max())
+        assert np.abs(R - MOT[f"{name}_run_cam_R"]).max() <= 1e-5
