@@ -231,8 +231,9 @@ def test_edge_cases(gpu_bsfm):
     pb.close()
     # unsupported modes fail loudly and leave inputs untouched
     cams = B.copy_cameras(base["cams"]); pts = base["pts"].copy()
-    rc, _ = B.run_sfm(n, m, 0, vm, proj, 1, 0, 1, 1, cams, pts, fix_points=1, options=B.default_options(verbose=0))
+    rc, _ = B.run_sfm(n, m, 0, vm, proj, 1, 0, 1, 1, cams, pts, optimize_for_fisheye=1, options=B.default_options(verbose=0))
     assert rc == -1 and np.array_equal(pts, base["pts"])
+    assert all(list(a.t) == list(b.t) and a.f == b.f for a, b in zip(cams, base["cams"]))
 
 
 def test_point_constraints(gpu_bsfm):
