@@ -45,7 +45,7 @@ class ProblemDesc(C.Structure):
 
 class SnavelyModel(C.Structure):
     _fields_ = [("est_focal_length", C.c_int), ("undistort", C.c_int), ("explicit_camera_centers", C.c_int),
-                ("R_init", C.POINTER(C.c_double)), ("f_init", C.POINTER(C.c_double))]
+                ("R_init", C.POINTER(C.c_double)), ("f_init", C.POINTER(C.c_double)), ("points", C.POINTER(C.c_double))]
 
 
 class CameraConstraints(C.Structure):     # lib/sba-1.5/sba.h:80-84
@@ -60,7 +60,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 
 # every symbol include/bsfm.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
-    "bsfm_default_options", "run_sfm", "bsfm_run_sfm_ex", "bsfm_sba_motstr_levmar", "bsfm_problem_create", "bsfm_problem_destroy",
+    "bsfm_default_options", "run_sfm", "bsfm_run_sfm_ex", "bsfm_sba_motstr_levmar", "bsfm_sba_mot_levmar", "bsfm_problem_create", "bsfm_problem_destroy",
     "bsfm_problem_set_allreduce", "bsfm_problem_set_stream", "bsfm_problem_reset_params", "bsfm_lm_begin",
     "bsfm_lm_iterate", "bsfm_lm_finish", "bsfm_lm_solve_attempts", "bsfm_lm_last_kernel_ms",
     "bsfm_problem_download", "bsfm_problem_cnp", "bsfm_problem_nvis", "bsfm_eval_residuals", "bsfm_problem_outlier_stats",

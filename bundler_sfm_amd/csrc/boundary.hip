@@ -139,6 +139,65 @@ int bsfm_sba_motstr_levmar(int n, int m, int mcon, char* vmask, double* p, int c
     return rc == BSFM_ERROR ? BSFM_ERROR : (int)info[5];
 }
 
+int bsfm_sba_mot_levmar(int n, int m, int mcon, char* vmask, double* p, int cnp, double* x, double* covx, int mnp,
+                        int camera_model, const void* model_data, int itmax, int verbose, double opts[6],
+                        double info[BSFM_INFOSZ], int use_constraints, bsfm_camera_constraints_t* constraints)
+{
+    double linfo[BSFM_INFOSZ];
+    for (int i = 0; i < BSFM_INFOSZ; ++i) linfo[i] = 0.0;
+    if (!info) info = linfo;
+    auto refuse = [](const char* why) { fprintf(stderr, "[bsfm] bsfm_sba_mot_levmar: %s; nothing was changed\n", why); return BSFM_ERROR; };
+    if (camera_model != BSFM_MODEL_SNAVELY || !model_data) return refuse("only BSFM_MODEL_SNAVELY with its data block is implemented");
+    const bsfm_snavely_model_t* md = static_cast<const bsfm_snavely_model_t*>(model_data);
+    if (mnp != 2) return refuse("mnp must be 2");
+    if (covx) return refuse("measurement covariances (covx) are not implemented");
+    if (cnp != 6 + (md->est_focal_length ? 1 : 0) + (md->undistort ? 2 : 0)) return refuse("cnp does not match the model flags");
+    if (!md->R_init || !md->points || (!md->est_focal_length && !md->f_init)) return refuse("model data incomplete (R_init / points / f_init)");
+    for (int j = 0; j < m; ++j)
+        if (p[(size_t)j * cnp + 3] != 0.0 || p[(size_t)j * cnp + 4] != 0.0 || p[(size_t)j * cnp + 5] != 0.0)
+            return refuse("the rotation increments p[j*cnp+3..5] must be zero on entry (fold them into R_init)");
+    std::vector<bsfm_camera_params_t> cams((size_t)m);
+    memset(cams.data(), 0, cams.size() * sizeof(bsfm_camera_params_t));
+    for (int j = 0; j < m; ++j) {
+        memcpy(cams[j].R, md->R_init + 9 * (size_t)j, 9 * sizeof(double));
+        cams[j].f = md->est_focal_length ? 1.0 : md->f_init[j];
+        if (use_constraints && constraints)
+            for (int q = 0; q < cnp; ++q) {
+                cams[j].constrained[q] = constraints[j].constrained[q];
+                cams[j].constraints[q] = constraints[j].constraints[q];
+                cams[j].weights[q] = constraints[j].weights[q];
+            }
+    }
+    std::vector<double> packed((size_t)m * cnp + (size_t)3 * n);
+    memcpy(packed.data(), p, (size_t)m * cnp * sizeof(double));
+    memcpy(packed.data() + (size_t)m * cnp, md->points, (size_t)3 * n * sizeof(double));
+    std::vector<int> rowptr, colidx;
+    vmask_to_crs(n, m, vmask, rowptr, colidx);
+    bsfm_options_t opt;
+    bsfm_default_options(&opt);
+    opt.itmax = itmax; opt.verbose = verbose;
+    if (opts) for (int q = 0; q < 6; ++q) opt.opts[q] = opts[q];
+    bsfm_problem_desc_t d;
+    memset(&d, 0, sizeof(d));
+    d.n = n; d.m = m; d.mcon = mcon;
+    d.rowptr = rowptr.data(); d.colidx = colidx.data(); d.projections = x;
+    d.est_focal_length = md->est_focal_length; d.undistort = md->undistort; d.explicit_camera_centers = md->explicit_camera_centers;
+    d.cameras = cams.data(); d.points = md->points;
+    d.use_constraints = use_constraints && constraints; d.constraints_prescaled = 1;
+    d.p_packed = packed.data(); d.fix_points = 1; d.world_size = 1;
+    bsfm_problem_t* pb = bsfm_problem_create(&d, &opt);
+    if (!pb) return BSFM_ERROR;
+    int rc = bsfm_lm_begin(pb);
+    if (rc == 0) bsfm_lm_iterate(pb, opt.itmax);
+    rc = bsfm_lm_finish(pb, info);
+    if (rc != BSFM_ERROR || info[5] > 0) {
+        bsfm_problem_download(pb, packed.data(), nullptr, nullptr);
+        memcpy(p, packed.data(), (size_t)m * cnp * sizeof(double));
+    }
+    bsfm_problem_destroy(pb);
+    return rc == BSFM_ERROR ? BSFM_ERROR : (int)info[5];
+}
+
 int bsfm_run_sfm_ex(int num_pts, int num_cameras, int ncons, char* vmask, double* projections,
                     int est_focal_length, int const_focal_length, int undistort, int explicit_camera_centers,
                     bsfm_camera_params_t* init_camera_params, bsfm_v3_t* init_pts,

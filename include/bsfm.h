@@ -111,6 +111,7 @@ typedef struct {
     int est_focal_length, undistort, explicit_camera_centers;   /* cnp = 6 + est + 2*undistort */
     const double *R_init;        /* 9*m row-major: rotation of camera j at omega = 0 (init_params[j].R) */
     const double *f_init;        /* m: focal lengths used when est_focal_length == 0 (may be NULL otherwise) */
+    const double *points;        /* 3*n: the fixed points of bsfm_sba_mot_levmar (globs->points of sfm.c:554-561); else NULL */
 } bsfm_snavely_model_t;
 typedef struct { char *constrained; double *constraints; double *weights; } bsfm_camera_constraints_t;   /* sba.h:80-84 */
 typedef struct { char constrained; double constraints[3]; double weight; } bsfm_point_constraints_t;     /* sba.h:86-90 */
@@ -121,6 +122,14 @@ int bsfm_sba_motstr_levmar(int n, int m, int mcon, char *vmask, double *p, int c
                            int use_constraints, bsfm_camera_constraints_t *constraints,
                            int use_point_constraints, bsfm_point_constraints_t *point_constraints,
                            double *Vout, double *Sout, double *Uout, double *Wout);
+
+/* Camera-only sibling: sba_mot_levmar's argument list (lib/sba-1.5/sba_levmar_wrap.c:707-768) with the model id + data
+ * block in place of proj/projac/adata; p holds the m*cnp camera parameters, the points come from model->points. */
+int bsfm_sba_mot_levmar(int n, int m, int mcon, char *vmask, double *p, int cnp,
+                        double *x, double *covx, int mnp,
+                        int camera_model, const void *model_data,
+                        int itmax, int verbose, double opts[6], double info[BSFM_INFOSZ],
+                        int use_constraints, bsfm_camera_constraints_t *constraints);
 
 /* ---- 3. resident-problem API ------------------------------------------------------------------------ */
 typedef struct bsfm_problem bsfm_problem_t;

@@ -298,8 +298,11 @@ def test_sba_level_sibling_entry_matches_reference_sba(gpu_bsfm, name):
         if und:
             a[col:col + 2] = ca["k"][j] * 5.0
     p[m * cnp:] = c["pts"]
+    p0_packed = p.copy()
     Rinit = np.ascontiguousarray(ca["R"].reshape(m, 9)); finit = np.ascontiguousarray(ca["f"], np.float64)
-    md = L.SnavelyModel(est, und, 1, Rinit.ctypes.data_as(C.POINTER(C.c_double)), finit.ctypes.data_as(C.POINTER(C.c_double)))
+    ptsc = np.ascontiguousarray(c["pts"], np.float64)
+    md = L.SnavelyModel(est, und, 1, Rinit.ctypes.data_as(C.POINTER(C.c_double)), finit.ctypes.data_as(C.POINTER(C.c_double)),
+                        ptsc.ctypes.data_as(C.POINTER(C.c_double)))
     cons = None; keep = []
     if c["cons"]:
         cons = (L.CameraConstraints * m)()
@@ -329,6 +332,20 @@ def test_sba_level_sibling_entry_matches_reference_sba(gpu_bsfm, name):
     assert rc == int(gi[5]) == 3
     assert abs(info[1] - gi[1]) <= 1e-9 * gi[1]
     assert np.abs(p - gp).max() <= 1e-8 * np.abs(gp).max()
+    # camera-only sibling (sba_mot_levmar's argument list) against the reference's mot fixture
+    if name in ("s9", "s9c", "s9m", "s7"):
+        pm = p0_packed[:m * cnp].copy()
+        os.environ["BSFM_JACOBIAN"] = "analytic"
+        try:
+            fm = B.lib.bsfm_sba_mot_levmar
+            fm.restype = C.c_int
+            rcm = fm(n, m, c["ncons"], vm.ctypes.data_as(C.c_char_p), pm.ctypes.data_as(C.POINTER(C.c_double)), cnp,
+                     proj.ctypes.data_as(C.POINTER(C.c_double)), None, 2, 1, C.byref(md), 3, 0, opts,
+                     info.ctypes.data_as(C.POINTER(C.c_double)), 1 if cons is not None else 0, cons)
+        finally:
+            del os.environ["BSFM_JACOBIAN"]
+        assert rcm == 3 and list(info[5:10]) == list(MOT[f"{name}_an_it3_info"][5:10])
+        assert np.abs(pm - MOT[f"{name}_an_it3_p"]).max() <= 1e-8 * np.abs(MOT[f"{name}_an_it3_p"]).max()
     # refusals leave p untouched
     p2 = p.copy()
     assert fn(n, m, 0, vm.ctypes.data_as(C.c_char_p), p2.ctypes.data_as(C.POINTER(C.c_double)), cnp, 3,
