@@ -36,6 +36,35 @@
 
 namespace bsfm {
 
+// Process-wide pool of plain non-blocking streams.  An incremental reconstruction calls run_sfm hundreds of times on small
+// problems; creating and destroying the three streams of a problem cost ~7 ms + ~7 ms per call (hipStreamCreateWithFlags /
+// hipStreamDestroy, measured with rocprofv3 --hip-trace) -- more than the LM iterations themselves at 10 cameras.
+// Streams go back to the pool drained (the owner synchronises before releasing); per device.
+struct StreamPool {
+    std::mutex mu;
+    std::vector<std::pair<int, hipStream_t>> idle;
+    hipStream_t acquire()
+    {
+        int dev = 0; (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < idle.size(); ++i)
+                if (idle[i].first == dev) { hipStream_t s = idle[i].second; idle.erase(idle.begin() + (long)i); return s; }
+        }
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        return s;
+    }
+    void release(hipStream_t s)
+    {
+        if (!s) return;
+        int dev = 0; (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(mu);
+        if (idle.size() < 16) idle.emplace_back(dev, s); else (void)hipStreamDestroy(s);
+    }
+};
+inline StreamPool& stream_pool() { static StreamPool* p = new StreamPool(); return *p; }   // leaked on purpose: no teardown order issues at exit
+
 constexpr int POTRF_NB = 128;
 constexpr int POTRF_MAX_TILES = 240;   // k_bwd_persistent needs one resident workgroup per tile column (256 CUs)
 #ifndef BSFM_SYRK_WPS
@@ -54,7 +83,8 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 struct PotrfWorkspace {
     int ld = 0, nblk = 0, backend = 0;
     double* panel = nullptr;   // 4 x (nblk-1) tiles of NB x NB: compact copies of the last panels (ring, k & 3)
-    hipStream_t s2 = nullptr;  // bulk-update stream of the lookahead schedule (CU-masked)
+    hipStream_t s2 = nullptr;  // bulk-update stream of the lookahead schedule
+    bool s2_masked = false;    // created with a CU mask (BSFM_PANEL_CUS): not a pool stream
     hipStream_t sd = nullptr;  // side stream: the part of panel k / first trailing column the NEXT diagonal tile does not need
     hipEvent_t* evP = nullptr; hipEvent_t* evU = nullptr;   // panel k complete (side stream) / trailing update k done
     hipEvent_t* evT = nullptr; hipEvent_t* evC = nullptr;   // first panel tile of step k ready (chain) / first trailing column done (side)
@@ -749,8 +779,8 @@ inline void potrf_free(PotrfWorkspace& w)
         (void)hipEventDestroy(w.evP[i]); (void)hipEventDestroy(w.evU[i]); (void)hipEventDestroy(w.evT[i]); (void)hipEventDestroy(w.evC[i]);
     }
     delete[] w.evP; delete[] w.evU; delete[] w.evT; delete[] w.evC;
-    if (w.s2) (void)hipStreamDestroy(w.s2);
-    if (w.sd) (void)hipStreamDestroy(w.sd);
+    if (w.s2) { if (w.s2_masked) (void)hipStreamDestroy(w.s2); else stream_pool().release(w.s2); }
+    stream_pool().release(w.sd);
     w = PotrfWorkspace();
 }
 
@@ -775,9 +805,10 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
             for (int c = reserve; c < ncu; ++c) mask[c >> 5] |= 1u << (c & 31);
             rc = hipExtStreamCreateWithCUMask(&w.s2, (uint32_t)words, mask.data());
         }
-        if (rc != hipSuccess && hipStreamCreateWithFlags(&w.s2, hipStreamNonBlocking) != hipSuccess) return -1;
+        w.s2_masked = (rc == hipSuccess);
+        if (rc != hipSuccess && !(w.s2 = stream_pool().acquire())) return -1;
     }
-    if (hipStreamCreateWithFlags(&w.sd, hipStreamNonBlocking) != hipSuccess) return -1;
+    if (!(w.sd = stream_pool().acquire())) return -1;
     w.evP = new hipEvent_t[w.nblk + 1]; w.evU = new hipEvent_t[w.nblk + 1];
     w.evT = new hipEvent_t[w.nblk + 1]; w.evC = new hipEvent_t[w.nblk + 1];
     for (int i = 0; i <= w.nblk; ++i) {

@@ -15,6 +15,8 @@
 #include <vector>
 #include <algorithm>
 #include <string>
+#include <mutex>
+#include <utility>
 #include <dlfcn.h>
 
 #include "../../include/bsfm.h"
@@ -122,7 +124,7 @@ void free_all(bsfm_problem* pb)
     if (pb->h_flags) (void)hipHostFree(pb->h_flags);
     potrf_free(pb->potrf);
     if (pb->ev_ok) for (int i = 0; i < PH_COUNT; ++i) { (void)hipEventDestroy(pb->ev[i][0]); (void)hipEventDestroy(pb->ev[i][1]); }
-    if (pb->own_stream && pb->stream) (void)hipStreamDestroy(pb->stream);
+    if (pb->own_stream && pb->stream) stream_pool().release(pb->stream);
 }
 
 // Builds the co-visibility triple list bucketed by reduced-camera block (j <= k), in (j,k) order and,
@@ -522,7 +524,7 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     { std::vector<int> cur(camptr.begin(), camptr.end() - 1);
       for (int k = 0; k < nvis; ++k) { const int t = cur[d->colidx[k]]++; camobs[t] = k; campos[k] = t; cam_pt[t] = obs_pt[k]; cam_cam[t] = d->colidx[k]; } }
 
-    if (hipStreamCreateWithFlags(&pb->stream, hipStreamNonBlocking) != hipSuccess) return fail("stream");
+    if (!(pb->stream = stream_pool().acquire())) return fail("stream");
     pb->own_stream = true;
 #define DM(ptr, cnt) if (dmalloc(&ptr, (size_t)(cnt)) != hipSuccess) return fail("hipMalloc " #ptr)
     DM(pb->d_x, 2 * (size_t)nvis); DM(pb->d_obs_cam, nvis); DM(pb->d_obs_pt, nvis); DM(pb->d_rowptr, n + 1);
@@ -605,9 +607,9 @@ void bsfm_problem_set_allreduce(bsfm_problem_t* pb, bsfm_allreduce_fn fn, void* 
 void bsfm_problem_set_stream(bsfm_problem_t* pb, void* s)
 {
     (void)hipStreamSynchronize(pb->stream);
-    if (pb->own_stream && pb->stream) (void)hipStreamDestroy(pb->stream);
+    if (pb->own_stream && pb->stream) stream_pool().release(pb->stream);
     if (s) { pb->stream = (hipStream_t)s; pb->own_stream = false; }
-    else { (void)hipStreamCreateWithFlags(&pb->stream, hipStreamNonBlocking); pb->own_stream = true; }
+    else { pb->stream = stream_pool().acquire(); pb->own_stream = true; }
 }
 
 int bsfm_problem_reset_params(bsfm_problem_t* pb, const bsfm_camera_params_t* cams, const double* pts)
