@@ -477,3 +477,45 @@ def test_run_sfm_fix_points_matches_reference_run_sfm(gpu_bsfm):
         assert np.abs(f - MOT[f"{name}_run_cam_f"]).max() <= 1e-5 * np.abs(f).max()
         assert np.abs(t - MOT[f"{name}_run_cam_t"]).max() <= 1e-5 * max(1.0, np.abs(t).max())
         assert np.abs(R - MOT[f"{name}_run_cam_R"]).max() <= 1e-5
+
+
+def test_resident_problem_reuse_and_caller_stream(gpu_bsfm):
+    """Resident API across outer rounds: bsfm_problem_reset_params restarts the same device problem from
+    new parameters and must reproduce a fresh problem bit for bit (all reductions are fixed-order); a caller-provided
+    HIP stream (bsfm_problem_set_stream) gives the same result as the library's own."""
+    import ctypes as C
+    B = gpu_bsfm
+    c = load_case("band")
+    opt = B.default_options(jacobian=B.JAC_ANALYTIC, verbose=0, itmax=4, opts=REF_OPTS)
+
+    def fresh(cams, pts):
+        pb = B.Problem(c["n"], c["m"], c["rowptr"], c["colidx"], c["proj"], cams, pts, est_focal_length=c["est"],
+                       undistort=c["und"], use_constraints=c["cons"], options=opt)
+        rc, info = pb.solve()
+        p = pb.download(want_cams=False)[0]
+        return pb, p, info
+
+    pb, p1, info1 = fresh(c["cams"], c["pts"])
+    # second round: perturbed start, same structure, same problem object
+    rng = np.random.default_rng(3)
+    pts2 = c["pts"] + 1e-3 * rng.standard_normal(c["pts"].shape)
+    assert pb.reset_params(c["cams"], pts2) == 0
+    rc, info2 = pb.solve()
+    p2 = pb.download(want_cams=False)[0]
+    pb.close()
+    pbf, p2f, info2f = fresh(c["cams"], pts2)
+    pbf.close()
+    assert np.array_equal(p2, p2f) and np.array_equal(info2, info2f)
+    assert not np.array_equal(p1, p2)
+    # caller-owned stream
+    st = C.c_void_p()
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipStreamCreate(C.byref(st)) == 0
+    pbs = B.Problem(c["n"], c["m"], c["rowptr"], c["colidx"], c["proj"], c["cams"], c["pts"], est_focal_length=c["est"],
+                    undistort=c["und"], use_constraints=c["cons"], options=opt)
+    pbs.set_stream(st.value)
+    rc, info3 = pbs.solve()
+    p3 = pbs.download(want_cams=False)[0]
+    pbs.close()
+    hip.hipStreamDestroy(st)
+    assert np.array_equal(p3, p1) and np.array_equal(info3, info1)
