@@ -488,7 +488,8 @@ __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __re
 //   * phase A, per block column s: wave 0 factors the 16x16 diagonal block with one lane per row (v_readlane
 //     broadcasts, no LDS traffic); the rows of the panel blocks below are solved against it by one thread each (forward
 //     substitution in registers) while an idle wave derives inv(L_ss) the same way; the trailing updates
-//     T[I][J] -= T[I][s] T[J][s]^T are 16x16x16 products on v_mfma_f64_4x4x4_4b (16 instructions each);
+//     T[I][J] -= T[I][s] T[J][s]^T are 16x16x16 products on v_mfma_f64_4x4x4_4b (16 instructions each), done by waves
+//     1..7 WHILE wave 0 already updates and factors the next diagonal block (51 -> 47 us per tile);
 //   * phase B, inverse: X = inv(L) by block forward substitution, ONE WAVE PER BLOCK COLUMN J and no barriers:
 //     X[I][J] = -inv(L_II) * sum_{K=J}^{I-1} L[I][K] X[K][J]; X[K][J]^T is parked in the unused upper block T[J][K]
 //     so that every product is of the A * Bt^T ("NT") form the MFMA fragments read directly from LDS.
@@ -515,6 +516,53 @@ __device__ __forceinline__ void mma16_nt(double (&acc)[4], const double* A, int 
             acc[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b, acc[a], 0, 0, 0);
         }
     }
+}
+
+// ---- A1: wave 0 factors the diagonal block (s,s) in registers, ONE LANE PER ROW (lanes 16.. mirror lane & 15):
+// lane r holds D[r][0..15]; per column the pivot and the column entries D[c][j] come by v_readlane (static lane
+// ids -> SGPR operands, no LDS round trip), the multiplier uses 1/pivot (v_rcp_f64 + 2 Newton steps), and all
+// square roots are deferred to the end of the block (L = raw column * 1/sqrt(pivot)).  Entries above the
+// diagonal take part in the updates unmasked: they are never read.
+__device__ __forceinline__ void diag_factor_block(double* __restrict__ T, double* __restrict__ svec, int* __restrict__ info,
+                                                  int base, int n_total, int s, int lane)
+{
+    double* B = T + (16 * s) * DG_TS + 16 * s;
+    const int r = lane & 15;
+    double d[16], pv[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) d[c] = B[r * DG_TS + c];
+#define BSFM_RDLANE(v, l) __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), (l)), __builtin_amdgcn_readlane(__double2loint(v), (l)))
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double piv = BSFM_RDLANE(d[j], j);
+        pv[j] = piv;
+        double inv = __builtin_amdgcn_rcp(piv);
+        inv = fma(fma(-piv, inv, 1.0), inv, inv);
+        inv = fma(fma(-piv, inv, 1.0), inv, inv);
+        const double lr = d[j] * inv;
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) { const double sc = BSFM_RDLANE(d[j], c); d[c] -= lr * sc; }
+    }
+    // first non-positive pivot = dpotrf's info
+    if (lane == 0) {
+        int bad = -1;
+#pragma unroll
+        for (int j = 15; j >= 0; --j) if (!(pv[j] > 0.0)) bad = j;
+        if (bad >= 0 && base + 16 * s + bad < n_total) atomicCAS(info, 0, base + 16 * s + bad + 1);
+    }
+    double myp = pv[0];
+#pragma unroll
+    for (int c = 1; c < 16; ++c) myp = (r == c) ? pv[c] : myp;
+    const double myrs = rsqrt_f64(myp);                       // 1 / L[r][r]
+    if (lane < 16) {
+        svec[16 * s + r] = myrs;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const double rs_c = BSFM_RDLANE(myrs, c);
+            B[r * DG_TS + c] = (c <= r) ? d[c] * rs_c : 0.0;
+        }
+    }
+#undef BSFM_RDLANE
 }
 
 __global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int ld, int k, int n_total,
@@ -550,54 +598,15 @@ __global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int 
 
     if (dbg && threadIdx.x == 0) dbg[0] = wall_clock64() - t0;
     long long tA1 = 0, tA2 = 0, tA3 = 0, tq = 0;
+    // Block-column schedule (two barriers per block column):
+    //   phase P: all waves solve the rows below block (s,s) against L_ss (A2) while wave 7 derives inv(L_ss);
+    //   phase Q: wave 0 alone applies column s to block (s+1,s+1) and immediately factors it (A1 of the next column) --
+    //            meanwhile waves 1..7 apply column s to all the other trailing blocks (A3).  The serial 16x16
+    //            factorisation thus overlaps the MFMA updates instead of following them.
+    if (wave == 0) diag_factor_block(T, svec, info, base, n_total, 0, lane);
+    __syncthreads();
     for (int s = 0; s < 8; ++s) {
         if (dbg && threadIdx.x == 0) tq = wall_clock64();
-        // ---- A1: wave 0 factors the diagonal block (s,s) in registers, ONE LANE PER ROW (lanes 16.. mirror lane & 15):
-        // lane r holds D[r][0..15]; per column the pivot and the column entries D[c][j] come by v_readlane (static lane
-        // ids -> SGPR operands, no LDS round trip), the multiplier uses 1/pivot (v_rcp_f64 + 2 Newton steps), and all
-        // square roots are deferred to the end of the block (L = raw column * 1/sqrt(pivot)).  Entries above the
-        // diagonal take part in the updates unmasked: they are never read.
-        if (wave == 0) {
-            double* B = T + (16 * s) * DG_TS + 16 * s;
-            const int r = lane & 15;
-            double d[16], pv[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) d[c] = B[r * DG_TS + c];
-#define BSFM_RDLANE(v, l) __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), (l)), __builtin_amdgcn_readlane(__double2loint(v), (l)))
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const double piv = BSFM_RDLANE(d[j], j);
-                pv[j] = piv;
-                double inv = __builtin_amdgcn_rcp(piv);
-                inv = fma(fma(-piv, inv, 1.0), inv, inv);
-                inv = fma(fma(-piv, inv, 1.0), inv, inv);
-                const double lr = d[j] * inv;
-#pragma unroll
-                for (int c = j + 1; c < 16; ++c) { const double sc = BSFM_RDLANE(d[j], c); d[c] -= lr * sc; }
-            }
-            // first non-positive pivot = dpotrf's info
-            if (lane == 0) {
-                int bad = -1;
-#pragma unroll
-                for (int j = 15; j >= 0; --j) if (!(pv[j] > 0.0)) bad = j;
-                if (bad >= 0 && base + 16 * s + bad < n_total) atomicCAS(info, 0, base + 16 * s + bad + 1);
-            }
-            double myp = pv[0];
-#pragma unroll
-            for (int c = 1; c < 16; ++c) myp = (r == c) ? pv[c] : myp;
-            const double myrs = rsqrt_f64(myp);                       // 1 / L[r][r]
-            if (lane < 16) {
-                svec[16 * s + r] = myrs;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const double rs_c = BSFM_RDLANE(myrs, c);
-                    B[r * DG_TS + c] = (c <= r) ? d[c] * rs_c : 0.0;
-                }
-            }
-#undef BSFM_RDLANE
-        }
-        __syncthreads();
-        if (dbg && threadIdx.x == 0) { const long long t = wall_clock64(); tA1 += t - tq; tq = t; }
         // ---- A2: rows of the panel blocks below, x <- x * inv(L_ss)^T by forward substitution, ONE THREAD PER ROW with
         // the 16 entries in registers (L_ss and 1/diag are wave-uniform LDS broadcasts): no cross-lane traffic at all.
         // Wave 7 meanwhile runs the SAME substitution on the rows of the identity: row c of inv(L_ss)^T = column c of
@@ -629,11 +638,23 @@ __global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int 
         }
         __syncthreads();
         if (dbg && threadIdx.x == 0) { const long long t = wall_clock64(); tA2 += t - tq; tq = t; }
-        // ---- A3: trailing blocks (I,J), s < J <= I < 8
-        {
+        // ---- phase Q
+        if (wave == 0) {
+            if (s < 7) {
+                double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+                const double* Ps = T + (16 * (s + 1)) * DG_TS + 16 * s;
+                mma16_nt(acc, Ps, DG_TS, Ps, DG_TS, lane);
+                double* C = T + (16 * (s + 1)) * DG_TS + 16 * (s + 1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) C[(4 * q + (lane >> 4)) * DG_TS + (lane & 15)] -= acc[q];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                diag_factor_block(T, svec, info, base, n_total, s + 1, lane);
+            }
+        } else {
+            // A3: trailing blocks (I,J), s < J <= I < 8, except (s+1,s+1) which wave 0 has taken
             const int rem = 7 - s;
             const int cnt = rem * (rem + 1) / 2;
-            for (int idx = wave; idx < cnt; idx += 8) {
+            for (int idx = wave; idx < cnt; idx += 7) {          // idx 0 = block (s+1,s+1); waves 1..7 start at 1..7
                 int a = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
                 while ((a + 1) * (a + 2) / 2 <= idx) ++a;
                 while (a * (a + 1) / 2 > idx) --a;
@@ -647,7 +668,7 @@ __global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int 
             }
         }
         __syncthreads();
-        if (dbg && threadIdx.x == 0) { const long long t = wall_clock64(); tA3 += t - tq; tq = t; }
+        if (dbg && threadIdx.x == 0) { const long long t = wall_clock64(); tA1 += t - tq; tq = t; }
     }
     if (dbg && threadIdx.x == 0) { dbg[4] = tA1; dbg[5] = tA2; dbg[6] = tA3; }
     if (dbg && threadIdx.x == 0) dbg[1] = wall_clock64() - t0;
