@@ -12,13 +12,13 @@
 // MI355X design: a dense int8 contraction on v_mfma_i32_16x16x64_i8 with exact int32 accumulation.
 //   * uchar -> int8 by XOR 0x80 (x - 128) in registers; d = qa + qb - 2 * dot(a', b') with the per-key terms
 //     qa = |a|^2 - 256 sum(a') - 2*128^3, qb = |b|^2 - 256 sum(b') precomputed once per key (k_key_stats);
-//   * a workgroup owns 64 queries (4 row-groups x 2 k-steps of A fragments live in registers for the whole scan);
+//   * a workgroup owns 128 queries (8 row-groups x 2 k-steps of A fragments live in registers for the whole scan);
 //     each of its 4 waves streams a different 16-key slice of every 64-key database tile straight from global
 //     memory into B fragments (a 640 KB image stays L2-resident; no LDS staging needed: a B fragment is consumed
-//     by exactly one wave, 8 MFMAs per fragment pair);
-//   * every lane keeps a branch-free running top-2 (d0, d1, idx0) for its 16 (row, column-class) slots; the 64
-//     partial lists per query are merged through LDS at the end, then the ratio test runs in FP64 exactly as the
-//     reference writes it.
+//     by exactly one wave, 16 MFMAs per fragment pair);
+//   * every lane keeps a branch-free running top-2 on packed (distance, tile) keys for its 32 (row, column-class)
+//     slots; the 16 column classes of a row are merged with wave shuffles, the four waves through LDS, then the ratio
+//     test runs in FP64 exactly as the reference writes it.
 //   * KeyMatchFull: all pairs (j < i) of one database image i go into ONE launch (grid = sum of query blocks).
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -32,7 +32,7 @@ namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-constexpr int QB = 64;             // queries per workgroup
+constexpr int QB = 128;            // queries per workgroup
 constexpr int BIG = 0x3fffffff;
 
 #define HIPM(call)                                                                                   \
@@ -74,14 +74,15 @@ __device__ __forceinline__ v4i load_frag(const unsigned char* __restrict__ keys,
 __global__ __launch_bounds__(256) void k_match_l2(const unsigned char* __restrict__ keys, const int* __restrict__ qstat,
         const PairDesc* __restrict__ pairs, int npairs, int db_off, int db_n, double ratio_sq, int* __restrict__ nn_out, int one)
 {
-    __shared__ int sm_d0[QB][64], sm_d1[QB][64], sm_i0[QB][64];
-    // locate the pair this block belongs to (pairs are few hundred at most: linear scan by one lane is fine)
+    constexpr int NG = QB / 16;                       // row groups of 16 queries held by every wave
+    __shared__ int st_d0[QB][4], st_d1[QB][4], st_i0[QB][4];     // running (best, second, index) per query and wave
     __shared__ int s_pair;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {          // locate the pair this block belongs to
         int lo = 0, hi = npairs - 1;
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pairs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
         s_pair = lo;
     }
+    for (int t = threadIdx.x; t < QB * 4; t += 256) { (&st_d0[0][0])[t] = BIG; (&st_d1[0][0])[t] = BIG; (&st_i0[0][0])[t] = -1; }
     __syncthreads();
     const PairDesc pd = pairs[s_pair];
     const int qbase = (blockIdx.x - pd.blk0) * QB;
@@ -89,29 +90,24 @@ __global__ __launch_bounds__(256) void k_match_l2(const unsigned char* __restric
     const unsigned char* qkeys = keys + (size_t)pd.q_off * 128;
     const unsigned char* dkeys = keys + (size_t)db_off * 128;
 
-    // A fragments: 4 row-groups x 2 k-steps, and the per-row query terms
-    v4i afrag[4][2];
-    int qa[4][4];
+    // A fragments: NG row groups x 2 k-steps stay in registers for the whole scan.  QB = 128 queries per workgroup: every
+    // database fragment a wave fetches from L2 is used for 8 MFMA pairs -- the scan is bound by that L2 -> CU traffic
+    // (128 MAC per byte at QB = 128), it was 8.0 us per 5000 x 5000 pair with 64 queries per workgroup.
+    v4i afrag[NG][2];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < NG; ++g) {
         const int row = min(qbase + 16 * g + (lane & 15), pd.q_n - 1);
         afrag[g][0] = load_frag(qkeys, row, lane, 0);
         afrag[g][1] = load_frag(qkeys, row, lane, 1);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rr = min(qbase + 16 * g + 4 * (lane >> 4) + r, pd.q_n - 1);
-            qa[g][r] = qstat[pd.q_off + rr] - 2 * 128 * 128 * 128;
-        }
     }
     // Running top-2 per slot on PACKED keys.  Ranking needs only e = qb - 2 dot (the query term qa is the same for every
-    // candidate of a row), so the per-distance work is: read the accumulator, e + BIAS by one 24-bit multiply-add
-    // (|dot| <= 2^21), (e << TB) | tile by one shift-or, one v_min_u32 for the best and one v_med3_u32 for the second
-    // (for b0 <= b1 the new second is the median of b0, b1, key).  BIAS makes e non-negative for every possible key pair:
-    // qa = |a|^2 - 256 sum(a - 128) - 2*128^3 lies in [-8 355 840, 8 323 200], d = qa + e in [0, 8 323 200], so
-    // e + BIAS < 2^25 with BIAS = 8 388 608, which leaves TB = 7 bits for the tile number inside a segment of 128 tiles
-    // (8 192 database keys; larger images are scanned segment by segment and folded into an unpacked running pair).
-    // Equal distances order by tile = by column like the reference's first-found rule, and two equal nearest
-    // distances can never pass the strict ratio test anyway.
+    // candidate of a row), so the per-distance work is ONE 24-bit multiply-add that builds the key (below), one v_min_u32
+    // for the best and one v_med3_u32 for the second (for b0 <= b1 the new second is the median of b0, b1, key).
+    // BIAS makes e non-negative for every possible key pair: qa = |a|^2 - 256 sum(a - 128) - 2*128^3 lies in
+    // [-8 355 840, 8 323 200], d = qa + e in [0, 8 323 200], so e + BIAS < 2^25 with BIAS = 8 388 608, which leaves
+    // TB = 7 bits for the tile number inside a segment of 128 tiles (8 192 database keys; larger images are scanned
+    // segment by segment).  Equal distances order by tile = by column like the reference's first-found rule, and two equal
+    // nearest distances can never pass the strict ratio test anyway.
     constexpr int TB = 7;
     constexpr int SEG = 64 << TB;
     // -(2 << TB) reaches the kernel as data (`one` == 1) so that the compiler keeps the 24-bit multiply-add: with a literal
@@ -122,16 +118,10 @@ __global__ __launch_bounds__(256) void k_match_l2(const unsigned char* __restric
     // above the largest real value (8 323 200 + 8 355 840 + 8 388 608 = 25 067 648) and below 2^25 -- no select per distance
     constexpr int DEADQ = 29300000;
     constexpr unsigned DEADTHR = 25100000u;
-    int D0[4][4], D1[4][4], I0[4][4];                  // running result over the segments
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { D0[g][r] = BIG; D1[g][r] = BIG; I0[g][r] = -1; }
-    const int slot = wave * 16 + (lane & 15);
     for (int seg = 0; seg < db_n; seg += SEG) {
-        unsigned b0[4][4], b1[4][4];
+        unsigned b0[NG][4], b1[NG][4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { b0[g][r] = 0xffffffffu; b1[g][r] = 0xffffffffu; }
         const int seg_end = min(db_n, seg + SEG);
@@ -153,7 +143,7 @@ __global__ __launch_bounds__(256) void k_match_l2(const unsigned char* __restric
             // bits are untouched by the subtraction, so ONE 24-bit multiply-add per distance builds the packed key
             const int K = (int)(((unsigned)qbb << TB) | (unsigned)((tile - seg) >> 6));
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < NG; ++g) {
                 v4i acc = { 0, 0, 0, 0 };
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[g][0], bf0, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[g][1], bf1, acc, 0, 0, 0);
@@ -169,36 +159,46 @@ __global__ __launch_bounds__(256) void k_match_l2(const unsigned char* __restric
                 }
             }
         }
-        // fold the segment's packed pair into the running (D0 <= D1, I0): d = e + qa
+        // The 16 column classes of a row sit in the 16 lanes (lane & 15) of a quarter wave: butterfly-merge their packed
+        // pairs (the lane id of the best travels along), then lane 0 of each quarter folds the segment's result into the
+        // wave's slot of the per-query state in LDS (d = e + qa; nobody else touches that slot: no barrier).
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const unsigned k0 = b0[g][r], k1 = b1[g][r];
-                const unsigned e0 = k0 >> TB, e1 = k1 >> TB;
-                const int c0 = e0 >= DEADTHR ? BIG : (int)e0 - EBIAS + qa[g][r];
-                const int c1 = e1 >= DEADTHR ? BIG : (int)e1 - EBIAS + qa[g][r];
-                const int ci = seg + (int)((k0 & ((1u << TB) - 1)) << 6) + slot;
-                if (c0 < D0[g][r]) { D1[g][r] = min(D0[g][r], c1); D0[g][r] = c0; I0[g][r] = ci; }
-                else D1[g][r] = min(D1[g][r], c0);
+                unsigned k0 = b0[g][r], k1 = b1[g][r];
+                int l0 = lane & 15;
+#pragma unroll
+                for (int m = 1; m < 16; m <<= 1) {
+                    const unsigned o0 = (unsigned)__shfl_xor((int)k0, m, 64), o1 = (unsigned)__shfl_xor((int)k1, m, 64);
+                    const int ol = __shfl_xor(l0, m, 64);
+                    k1 = min(max(k0, o0), min(k1, o1));
+                    const bool take = o0 < k0 || (o0 == k0 && ol < l0);
+                    l0 = take ? ol : l0;
+                    k0 = min(k0, o0);
+                }
+                if ((lane & 15) == 0) {
+                    const int row = 16 * g + 4 * (lane >> 4) + r;
+                    const int qrow = min(qbase + row, pd.q_n - 1);
+                    const int qa = qstat[pd.q_off + qrow] - 2 * 128 * 128 * 128;
+                    const unsigned e0 = k0 >> TB, e1 = k1 >> TB;
+                    const int c0 = e0 >= DEADTHR ? BIG : (int)e0 - EBIAS + qa;
+                    const int c1 = e1 >= DEADTHR ? BIG : (int)e1 - EBIAS + qa;
+                    const int ci = seg + (int)((k0 & ((1u << TB) - 1)) << 6) + 16 * wave + l0;
+                    const int d0 = st_d0[row][wave], d1 = st_d1[row][wave];
+                    if (c0 < d0) { st_d1[row][wave] = min(d0, c1); st_d0[row][wave] = c0; st_i0[row][wave] = ci; }
+                    else st_d1[row][wave] = min(d1, c0);
+                }
             }
     }
-    // merge: slot = wave*16 + (lane&15); row = 16g + 4*(lane>>4) + r
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * g + 4 * (lane >> 4) + r;
-            sm_d0[row][slot] = D0[g][r]; sm_d1[row][slot] = D1[g][r]; sm_i0[row][slot] = I0[g][r];
-        }
     __syncthreads();
     if (threadIdx.x < QB) {
         const int row = threadIdx.x, q = qbase + row;
         if (q < pd.q_n) {
             int d0 = BIG, d1 = BIG, idx = -1;
-            for (int s = 0; s < 64; ++s) {
-                const int ss = (s + row) & 63;    // skewed walk: conflict-free LDS columns
-                const int c0 = sm_d0[row][ss], c1 = sm_d1[row][ss], ci = sm_i0[row][ss];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int c0 = st_d0[row][w], c1 = st_d1[row][w], ci = st_i0[row][w];
                 // insert the partial list (c0 <= c1) into the running (d0 <= d1)
                 if (c0 < d0) { d1 = d0; d0 = c0; idx = ci; }
                 else if (c0 < d1) d1 = c0;
