@@ -7,21 +7,23 @@
 // MI355X design (the one MFMA-bound contraction of the LM iteration, ~N^3/3 FP64 flop):
 //   * right-looking tiled factorisation, tile NB = 128; S is padded to a multiple of NB (identity in
 //     the padding) so every kernel works on full tiles;
-//   * diagonal tile: ONE 512-thread workgroup, tile in LDS as 8x8 blocks of 16x16; only the 16x16 diagonal blocks
-//     are factored serially (one wave, registers + ds_bpermute/readlane, no barrier), everything else -- panel
-//     blocks, trailing blocks and the block-wise inverse of the factor -- is 16x16x16 products on the 4x4x4 MFMA;
-//   * panel: L_ik = S_ik * inv(L_kk)^T is a GEMM (no triangular solve) split into two 64-row halves per tile with
-//     the whole K range prefetched into registers (latency-critical); it also writes a compact, double-buffered
-//     copy of the panel (contiguous 128 KB tiles) that the trailing update reads;
-//   * lookahead: the first trailing column + the next panel run on the caller's stream, the bulk of the trailing
-//     update on a second stream whose CU mask leaves 32 CUs free so that the 150 KB-LDS diagonal-tile workgroup can
-//     always be placed;
-//   * trailing update S_ij -= L_ik L_jk^T on the lower triangle: 128x128 tile per 256-thread workgroup,
+//   * what bounds it at N = 9000 is the serial chain diag(k) -> panel(k) -> update of tile (k+1,k+1) -> diag(k+1), so the
+//     schedule (potrf_solve) runs on three streams and keeps everything else off that chain:
+//       chain  : k_potrf_diag (ONE 512-thread workgroup, tile in LDS as 8x8 blocks of 16x16: 16x16 diagonal blocks
+//                factored by one wave with v_readlane broadcasts, rows below solved by in-register substitution, trailing
+//                blocks and the block-wise inverse of the factor as 16x16x16 products on the 4x4x4 MFMA), then
+//                k_chain_tile32<0> (ONLY the first panel tile) and k_chain_tile32<1> (next diagonal tile -= two panels);
+//       side   : the rest of the panel (L_ik = S_ik * inv(L_kk)^T is a GEMM, no triangular solve; 64-row halves with the
+//                whole K range prefetched into registers; also writes the compact panel copy, ring of 4 buffers) and the
+//                rest of the first trailing column -- while the next diagonal tile is being factored;
+//       bulk   : the trailing update of all other tiles (k_syrk_update), the MFMA bulk;
+//   * trailing update S_ij -= L_ik L_jk^T on the lower triangle: 128x128 tile per 512-thread workgroup,
 //     8 waves x (32 x 64) = 32 FP64 accumulators per lane on v_mfma_f64_4x4x4_4b (the full-rate FP64
 //     matrix instruction of gfx950: 72.7 TFLOP/s measured vs 36 for v_mfma_f64_16x16x4), K staged through LDS in
 //     16-wide chunks (row stride padded to 18 doubles => conflict-free ds_read_b64 of the fragments),
-//     next chunk prefetched into registers while the MFMAs of the current one issue;
-//   * forward substitution rides on the factorisation chain (y_k in the panel launch, E updates in the
+//     next chunk prefetched into registers while the MFMAs of the current one issue; the accumulators start as the C
+//     tile (store-only epilogue);
+//   * forward substitution rides on the side stream (y_k in the panel launch, E updates in the
 //     first-trailing-column launch); backward substitution is ONE persistent launch with flag hand-offs.
 // v_mfma_f64_4x4x4_4b lane layout (probed on MI355X, scripts/probe_mfma4.hip), lane l = 16k + 4g + r:
 // A[g][i=r][k], B[g][k][j=r], D[g][i][j] at lane 16i + 4g + j, for the 4 independent blocks g.
