@@ -6,7 +6,8 @@
 //   U_j, ea_j                 lib/sba-1.5/sba_levmar.c:919-964
 //   V_i, eb_i                 lib/sba-1.5/sba_levmar.c:987-1030
 //   (V_i + mu I)^-1           lib/sba-1.5/sba_levmar.c:1138-1162 (sba_symat_invert_BK)
-//   S_jk, e_j (Schur)         lib/sba-1.5/sba_levmar.c:1182-1339
+//   S_jk, e_j (Schur)         lib/sba-1.5/sba_levmar.c:1182-1339          (task kernel: schur.hip.h)
+//   camera-only step          lib/sba-1.5/sba_levmar.c:2499-2513          (k_cam_solve, fix_points mode)
 //   db_i (back-substitution)  lib/sba-1.5/sba_levmar.c:1393-1433
 //   step norms, dL            lib/sba-1.5/sba_levmar.c:1444-1527
 //   Snavely stop rule         lib/sba-1.5/sba_levmar.c:1552-1561
@@ -17,9 +18,11 @@
 //   camptr[m+1], camobs[nvis]               camera-major secondary index (replaces sba_crsm_col_elmidxs'
 //                                           per-call binary searches, sba_crsm.c:183-212)
 //   camtab[m*72]    per-camera derived row  (model.hip.h)
-//   Jc[nvis*(2cnp+6)] A_ij (2 x cnp) then B_ij (2 x 3), one contiguous record per observation, CAMERA-major order;
-//   Jc               the same records in CAMERA-major order (position campos[k]): the camera-side consumers
-//                    (U_j/ea_j, Schur tasks, e_j) then read contiguous / monotone streams instead of random 192-byte gathers
+//   campos[nvis], cam_pt[nvis], cam_cam[nvis]   observation -> camera-major position; position -> point / camera
+//   Jc[nvis*(2cnp+6)] A_ij (2 x cnp) then B_ij (2 x 3), one contiguous record per observation, stored ONCE, in
+//                    CAMERA-major order (record of observation k at position campos[k]): the Jacobian kernel and the
+//                    camera-side consumers (U_j/ea_j, Schur tasks incl. e_j) stream it, the point-side ones (V_i/eb_i,
+//                    back-substitution) gather whole records
 //   U[m*cnp*cnp], ea[m*cnp], V[n*6] (packed upper), Vinv[n*6], eb[n*3], S[ld*ld], E[ld]
 // W_ij = A_ij^T B_ij is never materialised (1.08 GB at 5 M observations): every consumer uses the factored
 // form, e.g. Y_ij W_ik^T = A_ij^T (B_ij V*^-1 B_ik^T) A_ik with a 2x2 core, and W_ij^T da = B_ij^T (A_ij da).

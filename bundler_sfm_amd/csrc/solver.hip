@@ -4,8 +4,10 @@
 // The LM control flow restates lib/sba-1.5/sba_levmar.c:457-2081 (sba_motstr_levmar_x) statement by
 // statement where it decides something (stop rules 1-8, damping update, the "constraint cost at the trial
 // point uses the OLD p" quirk :1488-1522, stop-8 leaving p un-updated :1569-1572, itmax overriding the stop
-// code :1617); all O(nvis) work is in the HIP kernels of kernels.hip.h and the dense solve in potrf.hip.h.
-// One stream; the host reads ONE small scalar block per decision point.
+// code :1617), and sba_mot_levmar_x (:2090-2690) for the camera-only mode; all O(nvis) work is in the HIP kernels of
+// kernels.hip.h / schur.hip.h and the dense solve in potrf.hip.h (which adds two internal streams of its own).
+// The host reads ONE small scalar block per decision point.  Multi-GPU: point-sharded ranks exchange U||ea, the packed
+// union of the reduced-camera blocks ||E, and small scalar blocks through the caller's all-reduce hook.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
