@@ -502,83 +502,6 @@ __global__ __launch_bounds__(256) void k_cam_step(int count, int fixed, double m
 
 // ---------------------------------------------------------------------------------------------------
 // deterministic second-stage reductions (single block, fixed order)
-__global__ __launch_bounds__(256) void k_reduce_sum(const double* __restrict__ in, int count, double* __restrict__ out)
-{
-    __shared__ double sm[4];
-    double s = 0.0;
-    for (int t = threadIdx.x; t < count; t += 256) s += in[t];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) *out = (sm[0] + sm[1]) + (sm[2] + sm[3]);
-}
-__global__ __launch_bounds__(256) void k_reduce_max(const double* __restrict__ in, int count, double* __restrict__ out)
-{
-    __shared__ double sm[4];
-    double s = 0.0;
-    for (int t = threadIdx.x; t < count; t += 256) { const double v = in[t]; s = v > s ? v : s; }
-    s = wave_max(s);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) { double q = sm[0]; for (int i = 1; i < 4; ++i) q = sm[i] > q ? sm[i] : q; *out = q; }
-}
-// max |v| over a vector (eab_inf) and max over the diagonal entries of packed V / dense U blocks
-__global__ __launch_bounds__(256) void k_absmax_partial(const double* __restrict__ v, size_t count, double* __restrict__ part)
-{
-    __shared__ double sm[4];
-    double s = 0.0;
-    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < count; t += (size_t)gridDim.x * 256) {
-        const double a = fabs(v[t]); s = a > s ? a : s;
-    }
-    s = wave_max(s);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) { double q = sm[0]; for (int i = 1; i < 4; ++i) q = sm[i] > q ? sm[i] : q; part[blockIdx.x] = q; }
-}
-__global__ __launch_bounds__(256) void k_vdiag_max_partial(const double* __restrict__ V, int n, double* __restrict__ part)
-{
-    __shared__ double sm[4];
-    double s = -DBL_MAX;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const double* v = V + (size_t)i * 6;
-        const double a = v[0] > v[3] ? v[0] : v[3];
-        const double b = a > v[5] ? a : v[5];
-        s = b > s ? b : s;
-    }
-    { double t;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { t = __shfl_down(s, o, 64); s = t > s ? t : s; } }
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) { double q = sm[0]; for (int i = 1; i < 4; ++i) q = sm[i] > q ? sm[i] : q; part[blockIdx.x] = q; }
-}
-__global__ __launch_bounds__(256) void k_udiag_max(const double* __restrict__ U, int m, int mcon, int cnp, double* __restrict__ out)
-{
-    __shared__ double sm[4];
-    double s = -DBL_MAX;
-    for (int t = mcon * cnp + threadIdx.x; t < m * cnp; t += 256) {
-        const int j = t / cnp, jj = t % cnp;
-        const double a = U[(size_t)j * cnp * cnp + jj * cnp + jj];
-        s = a > s ? a : s;
-    }
-    { double t;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { t = __shfl_down(s, o, 64); s = t > s ? t : s; } }
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) { double q = sm[0]; for (int i = 1; i < 4; ++i) q = sm[i] > q ? sm[i] : q; *out = q; }
-}
-// sum p^2 over a vector, block partials
-__global__ __launch_bounds__(256) void k_sumsq_partial(const double* __restrict__ v, size_t count, double* __restrict__ part)
-{
-    __shared__ double sm[4];
-    double s = 0.0;
-    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < count; t += (size_t)gridDim.x * 256) s += v[t] * v[t];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
-}
 // constraint cost: sum_j w (c - p)^2 over constrained camera params (sba_levmar.c:809-826) and
 // nvis * w * (c - p)^2 over constrained points (sba_levmar.c:829-842); single block.
 __global__ __launch_bounds__(256) void k_constraint_cost(DevProblem P, const double* __restrict__ pa,
@@ -737,6 +660,130 @@ __global__ __launch_bounds__(64) void k_cam_solve(DevProblem P, double mu, doubl
     }
 #pragma unroll
     for (int q = 0; q < CNP; ++q) out[q] = x[q];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Per-iteration scalars in TWO launches instead of eleven (every launch is ~5 us of an iteration that, for the small
+// problems an incremental reconstruction mostly solves, is nothing but launch latency).  Same partitions and the same
+// reduction order as the individual kernels above, so the values are bit-identical.
+//   k_iter_partials (256 blocks): max |eb|, max diag V, sum p_b^2 over the block's slice -> part[0..255], [256..511], [512..767]
+//   k_iter_final    (1 block)  : reduces those, and computes max |ea|, max diag U, sum p_a^2, the constraint cost and
+//                                (multi-GPU) its point part.
+__device__ __forceinline__ double block_max4(double s, double* sm)      // result valid in thread 0
+{
+    { double t;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { t = __shfl_down(s, o, 64); s = t > s ? t : s; } }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    double q = sm[0];
+    for (int i = 1; i < 4; ++i) q = sm[i] > q ? sm[i] : q;
+    return q;
+}
+__device__ __forceinline__ double block_sum4(double s, double* sm)
+{
+    s = wave_sum(s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+__global__ __launch_bounds__(256) void k_iter_partials(const double* __restrict__ eb, const double* __restrict__ V,
+        const double* __restrict__ pb, int n, double* __restrict__ part)
+{
+    __shared__ double sm[4];
+    const size_t cnt3 = (size_t)3 * n;
+    double a = 0.0, ss = 0.0, vd = -DBL_MAX;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < cnt3; t += (size_t)gridDim.x * 256) {
+        const double x = fabs(eb[t]); a = x > a ? x : a;
+        const double y = pb[t]; ss += y * y;
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const double* v = V + (size_t)i * 6;
+        const double q = v[0] > v[3] ? v[0] : v[3];
+        const double b = q > v[5] ? q : v[5];
+        vd = b > vd ? b : vd;
+    }
+    const double ra = block_max4(a, sm), rv = block_max4(vd, sm), rs = block_sum4(ss, sm);
+    if (threadIdx.x == 0) { part[blockIdx.x] = ra; part[256 + blockIdx.x] = rv; part[512 + blockIdx.x] = rs; }
+}
+
+__global__ __launch_bounds__(256) void k_iter_final(DevProblem P, const double* __restrict__ pa, const double* __restrict__ pb,
+        const double* __restrict__ part, int have_points, int point_part_slot,
+        int s_eabinf_a, int s_eabinf_b, int s_maxdiag_u, int s_maxdiag_v, int s_pl2_a, int s_pl2_b, int s_ccost,
+        double* __restrict__ scal)
+{
+    __shared__ double sm[4];
+    const int cnp = P.cfg.cnp, t = threadIdx.x;
+    if (have_points) {
+        double a = part[t];        a = a > 0.0 ? a : 0.0;                   // k_reduce_max starts from 0
+        double v = part[256 + t];  v = v > 0.0 ? v : 0.0;
+        const double ra = block_max4(a, sm), rv = block_max4(v, sm), rs = block_sum4(part[512 + t], sm);
+        if (t == 0) { scal[s_eabinf_b] = ra; scal[s_maxdiag_v] = rv; scal[s_pl2_b] = rs; }
+    }
+    double ea = 0.0, ud = -DBL_MAX, ps = 0.0;
+    for (int q = t; q < P.m * cnp; q += 256) {
+        const double x = fabs(P.ea[q]); ea = x > ea ? x : ea;
+        ps += pa[q] * pa[q];
+    }
+    for (int q = P.mcon * cnp + t; q < P.m * cnp; q += 256) {
+        const int j = q / cnp, jj = q % cnp;
+        const double x = P.U[(size_t)j * cnp * cnp + jj * cnp + jj];
+        ud = x > ud ? x : ud;
+    }
+    const double rea = block_max4(ea, sm), rud = block_max4(ud, sm), rps = block_sum4(ps, sm);
+    // constraint cost: cameras (sba_levmar.c:809-826) + points (sba_levmar.c:829-842); the point part separately for the
+    // multi-GPU sum (cameras are replicated, points sharded)
+    double cc = 0.0, cp = 0.0;
+    if (P.ccon)
+        for (int q = t; q < P.m * cnp; q += 256)
+            if (P.ccon[q]) { const double d = P.cval[q] - pa[q]; cc += P.cw[q] * d * d; }
+    if (P.pcon)
+        for (int i = t; i < P.n; i += 256)
+            if (P.pcon[i])
+                for (int q = 0; q < 3; ++q) { const double d = P.pval[3 * i + q] - pb[3 * i + q]; const double w = P.nvis_global * P.pweight * d * d; cc += w; cp += w; }
+    const double rcc = block_sum4(cc, sm), rcp = block_sum4(cp, sm);
+    if (t == 0) {
+        scal[s_eabinf_a] = rea; scal[s_maxdiag_u] = rud; scal[s_pl2_a] = rps; scal[s_ccost] = rcc;
+        if (point_part_slot >= 0) scal[point_part_slot] = rcp;
+    }
+}
+
+// sum of the three block-partial rows of k_backsub + the camera part of the step in ONE launch (was four):
+// out3 = sum dpa^2, sum pa^2, sum dpa (mu dpa + ea); pt3 = sums of the point partials.
+__global__ __launch_bounds__(256) void k_step_sums(int count, int fixed, double mu, const double* __restrict__ pa,
+        const double* __restrict__ dpa, const double* __restrict__ ea, double* __restrict__ pdpa, double* __restrict__ out3,
+        const double* __restrict__ part, int nbp, double* __restrict__ pt3)
+{
+    __shared__ double sm[4];
+    double s_dp = 0, s_p = 0, s_dl = 0;
+    for (int t = threadIdx.x; t < count; t += 256) {
+        const double d = (t < fixed) ? 0.0 : dpa[t], p = pa[t];
+        pdpa[t] = p + d;
+        s_dp += d * d; s_p += p * p; s_dl += d * (mu * d + ea[t]);
+    }
+    const double r0 = block_sum4(s_dp, sm), r1 = block_sum4(s_p, sm), r2 = block_sum4(s_dl, sm);
+    double q[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double s = 0.0;
+        for (int t = threadIdx.x; t < nbp; t += 256) s += part[(size_t)c * nbp + t];
+        q[c] = block_sum4(s, sm);
+    }
+    if (threadIdx.x == 0) { out3[0] = r0; out3[1] = r1; out3[2] = r2; pt3[0] = q[0]; pt3[1] = q[1]; pt3[2] = q[2]; }
+}
+
+// cost sum and Snavely pct-change max of the residual pass in one launch
+__global__ __launch_bounds__(256) void k_reduce_sum_max(const double* __restrict__ in_sum, const double* __restrict__ in_max,
+        int count, double* __restrict__ out_sum, double* __restrict__ out_max)
+{
+    __shared__ double sm[4];
+    double s = 0.0, m = 0.0;
+    for (int t = threadIdx.x; t < count; t += 256) { s += in_sum[t]; if (in_max) { const double v = in_max[t]; m = v > m ? v : m; } }
+    const double rs = block_sum4(s, sm), rm = block_max4(m, sm);
+    if (threadIdx.x == 0) { *out_sum = rs; if (in_max) *out_max = rm; }
 }
 
 // expand packed V (+mu) to the reference's full symmetric 3x3 per point (test/export helper)

@@ -263,8 +263,8 @@ void launch_residual(bsfm_problem* pb, const double* camtab, const double* p, do
                            pb->d_obs_cam, pb->d_obs_pt, camtab, pbpts, e_out, e_prev, pb->opt.opts[5], pc,
                            e_prev ? pp : nullptr);
     const int cnt = pb->P.nvis > 0 ? nb : 0;
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, pb->stream, pc, cnt, pb->d_scal + cost_slot);
-    if (e_prev) hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, pb->stream, pp, cnt, pb->d_scal + SC_PCT);
+    hipLaunchKernelGGL(k_reduce_sum_max, dim3(1), dim3(256), 0, pb->stream, pc, e_prev ? pp : (const double*)nullptr, cnt,
+                       pb->d_scal + cost_slot, pb->d_scal + SC_PCT);
 }
 
 int read_scalars(bsfm_problem* pb)
@@ -698,10 +698,9 @@ static int lm_iterate_mot(bsfm_problem_t* pb, int iters)
         if (compute_normal_blocks(pb)) return BSFM_ERROR;      // J (A part is what matters), U, ea (+ constraints)
         ++pb->njev;
         double* d_pa = pb->d_p;
-        hipLaunchKernelGGL(k_absmax_partial, dim3(1), dim3(256), 0, pb->stream, pb->d_ea, (size_t)P.m * cnp, pb->d_scal + SC_EABINF_A);
-        hipLaunchKernelGGL(k_udiag_max, dim3(1), dim3(256), 0, pb->stream, pb->d_U, P.m, P.mcon, cnp, pb->d_scal + SC_MAXDIAG_U);
-        hipLaunchKernelGGL(k_sumsq_partial, dim3(1), dim3(256), 0, pb->stream, d_pa, (size_t)P.m * cnp, pb->d_scal + SC_PL2_A);
-        hipLaunchKernelGGL(k_constraint_cost, dim3(1), dim3(256), 0, pb->stream, P, d_pa, d_pa + (size_t)P.m * cnp, 1, pb->d_scal + SC_CCOST);
+        hipLaunchKernelGGL(k_iter_final, dim3(1), dim3(256), 0, pb->stream, P, d_pa, d_pa + (size_t)P.m * cnp, pb->d_red, 0, -1,
+                           (int)SC_EABINF_A, (int)SC_EABINF_B, (int)SC_MAXDIAG_U, (int)SC_MAXDIAG_V, (int)SC_PL2_A, (int)SC_PL2_B,
+                           (int)SC_CCOST, pb->d_scal);
         if (read_scalars(pb)) return BSFM_ERROR;
         const double ccost = pb->h_scal[SC_CCOST];
         pb->eab_inf = pb->h_scal[SC_EABINF_A];
@@ -796,18 +795,10 @@ int bsfm_lm_iterate(bsfm_problem_t* pb, int iters)
         if (compute_normal_blocks(pb)) return BSFM_ERROR;
         ++pb->njev;
         // ||J^T e||_inf, ||p||^2, max diagonal (sba_levmar.c:1085-1128)
-        hipLaunchKernelGGL(k_absmax_partial, dim3(1), dim3(256), 0, pb->stream, pb->d_ea, (size_t)P.m * cnp, pb->d_scal + SC_EABINF_A);
-        hipLaunchKernelGGL(k_absmax_partial, dim3(256), dim3(256), 0, pb->stream, pb->d_eb, (size_t)3 * P.n, pb->d_red);
-        hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, pb->stream, pb->d_red, 256, pb->d_scal + SC_EABINF_B);
-        hipLaunchKernelGGL(k_udiag_max, dim3(1), dim3(256), 0, pb->stream, pb->d_U, P.m, P.mcon, cnp, pb->d_scal + SC_MAXDIAG_U);
-        hipLaunchKernelGGL(k_vdiag_max_partial, dim3(256), dim3(256), 0, pb->stream, pb->d_V, P.n, pb->d_red + 256);
-        hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(256), 0, pb->stream, pb->d_red + 256, 256, pb->d_scal + SC_MAXDIAG_V);
-        hipLaunchKernelGGL(k_sumsq_partial, dim3(1), dim3(256), 0, pb->stream, d_pa, (size_t)P.m * cnp, pb->d_scal + SC_PL2_A);
-        hipLaunchKernelGGL(k_sumsq_partial, dim3(256), dim3(256), 0, pb->stream, d_pb, (size_t)3 * P.n, pb->d_red + 512);
-        hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, pb->stream, pb->d_red + 512, 256, pb->d_scal + SC_PL2_B);
-        hipLaunchKernelGGL(k_constraint_cost, dim3(1), dim3(256), 0, pb->stream, P, d_pa, d_pb, 1, pb->d_scal + SC_CCOST);
-        if (pb->world > 1)
-            hipLaunchKernelGGL(k_constraint_cost, dim3(1), dim3(256), 0, pb->stream, P, d_pa, d_pb, 0, pb->d_scal + SC_COUNT + 8);
+        hipLaunchKernelGGL(k_iter_partials, dim3(256), dim3(256), 0, pb->stream, pb->d_eb, pb->d_V, d_pb, P.n, pb->d_red);
+        hipLaunchKernelGGL(k_iter_final, dim3(1), dim3(256), 0, pb->stream, P, d_pa, d_pb, pb->d_red, 1,
+                           pb->world > 1 ? SC_COUNT + 8 : -1, (int)SC_EABINF_A, (int)SC_EABINF_B, (int)SC_MAXDIAG_U, (int)SC_MAXDIAG_V,
+                           (int)SC_PL2_A, (int)SC_PL2_B, (int)SC_CCOST, pb->d_scal);
         if (read_scalars(pb)) return BSFM_ERROR;
         const double vmaxdiag = pb->h_scal[SC_MAXDIAG_V];   // diagonals are sums of squares (>= 0): a 0-based max is exact
         double ccost = pb->h_scal[SC_CCOST];
@@ -846,9 +837,8 @@ int bsfm_lm_iterate(bsfm_problem_t* pb, int iters)
             if (P.mcon > 0) (void)hipMemsetAsync(d_dpa, 0, (size_t)P.mcon * cnp * sizeof(double), pb->stream);
             ph_begin(pb, PH_BACKSUB);
             if (P.n > 0) DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_backsub<C>), dim3(nbp), dim3(256), 0, pb->stream, P, mu, d_dpa, d_pb, d_dpb, d_pdpb, pb->d_red));
-            for (int q = 0; q < 3; ++q)
-                hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(256), 0, pb->stream, pb->d_red + (size_t)q * nbp, P.n > 0 ? nbp : 0, pb->d_scal + SC_PT_DP + q);
-            hipLaunchKernelGGL(k_cam_step, dim3(1), dim3(256), 0, pb->stream, P.m * cnp, P.mcon * cnp, mu, d_pa, d_dpa, pb->d_ea, d_pdpa, pb->d_scal + SC_CAM3);
+            hipLaunchKernelGGL(k_step_sums, dim3(1), dim3(256), 0, pb->stream, P.m * cnp, P.mcon * cnp, mu, d_pa, d_dpa, pb->d_ea, d_pdpa,
+                               pb->d_scal + SC_CAM3, pb->d_red, P.n > 0 ? nbp : 0, pb->d_scal + SC_PT_DP);
             ph_end(pb, PH_BACKSUB);
             ph_begin(pb, PH_RESID);
             launch_cam_table(pb, pb->d_pdp, pb->d_camtab_trial);
