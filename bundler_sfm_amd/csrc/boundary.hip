@@ -9,8 +9,9 @@
 //   3. LM on the GPU (bsfm_lm_*), itmax = 150, verbose summary lines as sfm.c:872-873;
 //   4. unpack cameras / points in place (sfm.c:876-929);
 //   5. optional Vout/Sout/Uout/Wout export at the solution (lib/sba-1.5/sba_levmar.c:1633-2026).
-// fix_points != 0 selects the camera-only refinement (sba_mot_levmar, sfm.c:839-846).  Modes the GPU core does not cover
-// (fisheye, known intrinsics) fail loudly and leave every input untouched: there is deliberately no CPU fallback here.
+// fix_points != 0 selects the camera-only refinement (sba_mot_levmar, sfm.c:839-846); cameras with known intrinsics
+// (sfm.c:339-358) are projected through their own K and Brown distortion.  The one mode the GPU core does not cover, the
+// fisheye projection, fails loudly and leaves every input untouched: there is deliberately no CPU fallback here.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -221,12 +222,6 @@ int bsfm_run_sfm_ex(int num_pts, int num_cameras, int ncons, char* vmask, double
     }
     if (est_focal_length && const_focal_length)
         printf("Error: case of constant focal length has not been implemented.\n");   // sfm.c:521-523
-    for (int j = 0; j < num_cameras; ++j)
-        if (init_camera_params[j].known_intrinsics) {
-            fprintf(stderr, "[bsfm] run_sfm: known-intrinsics cameras (sfm.c:339-358) are not implemented on the GPU core\n");
-            return BSFM_ERROR;
-        }
-
     // 1. vmask -> CRS
     std::vector<int> rowptr, colidx;
     vmask_to_crs(num_pts, num_cameras, vmask, rowptr, colidx);

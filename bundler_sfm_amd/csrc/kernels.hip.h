@@ -70,7 +70,7 @@ __device__ __forceinline__ double wave_max(double v)
 // ---------------------------------------------------------------------------------------------------
 // per-camera derived table: one thread per camera (m <= a few thousand; trig happens only here)
 __global__ void k_cam_table(ModelCfg cfg, int m, const double* __restrict__ pa, const double* __restrict__ Rinit,
-                            const double* __restrict__ finit, int with_fd, double* __restrict__ camtab)
+                            const double* __restrict__ finit, const double* __restrict__ known, int with_fd, double* __restrict__ camtab)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
@@ -92,6 +92,8 @@ __global__ void k_cam_table(ModelCfg cfg, int m, const double* __restrict__ pa, 
     ct[CT_K1] = cfg.undistort ? a[col] / cfg.k_scale : 0.0;
     ct[CT_K2] = cfg.undistort ? a[col + 1] / cfg.k_scale : 0.0;
     ct[30] = finit[j]; ct[31] = 0.0;
+    for (int k = 0; k < 11; ++k) ct[CT_KN + k] = known ? known[(size_t)j * 11 + k] : 0.0;     // known-intrinsics block (model.hip.h)
+    ct[CT_KN + 11] = 0.0;
     if (with_fd) {
         for (int k = 0; k < 9; ++k) {
             double d = 0.0;
@@ -112,6 +114,7 @@ __global__ void k_cam_table(ModelCfg cfg, int m, const double* __restrict__ pa, 
 // L2-resident gathers of the camera row and the point.  Block partial of sum e^2; with e_prev != null
 // also the block partial of the Snavely pct-change maximum.
 constexpr int RES_BLOCK = 256;
+template <bool KNOWN>
 __global__ __launch_bounds__(RES_BLOCK) void k_residual(ModelCfg cfg, int nvis,
         const double* __restrict__ x, const int* __restrict__ obs_cam, const int* __restrict__ obs_pt,
         const double* __restrict__ camtab, const double* __restrict__ pb,
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(RES_BLOCK) void k_residual(ModelCfg cfg, int nvis,
         const double* ct = camtab + (size_t)obs_cam[k] * CT_STRIDE;
         const double* b = pb + (size_t)obs_pt[k] * 3;
         double h0, h1;
-        project_row(cfg, ct, b[0], b[1], b[2], h0, h1);
+        project_row<KNOWN>(cfg, ct, b[0], b[1], b[2], h0, h1);
         const double2 xx = reinterpret_cast<const double2*>(x)[k];
         const double e0 = xx.x - h0, e1 = xx.y - h1;
         reinterpret_cast<double2*>(e_out)[k] = make_double2(e0, e1);
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(RES_BLOCK) void k_residual(ModelCfg cfg, int nvis,
 
 // ---------------------------------------------------------------------------------------------------
 // Jacobian records: one thread per observation.
-template <int CNP, bool FD>
+template <int CNP, bool FD, bool KNOWN>
 __global__ __launch_bounds__(256) void k_jacobian(ModelCfg cfg, int nvis,
         const int* __restrict__ cam_cam, const int* __restrict__ cam_pt,
         const double* __restrict__ camtab, const double* __restrict__ pb, double* __restrict__ Jc)
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void k_jacobian(ModelCfg cfg, int nvis,
     const double* ct = camtab + (size_t)cam_cam[t] * CT_STRIDE;
     const double* b = pb + (size_t)cam_pt[t] * 3;
     double A[2 * CNP], B[6], x0, x1;
-    if (FD) jac_fd<CNP>(cfg, ct, b[0], b[1], b[2], A, B, x0, x1);
+    if (FD) jac_fd<CNP, KNOWN>(cfg, ct, b[0], b[1], b[2], A, B, x0, x1);
     else    jac_analytic<CNP>(cfg, ct, b[0], b[1], b[2], A, B, x0, x1);
     constexpr int JS = 2 * CNP + 6;
     double2* outc = reinterpret_cast<double2*>(Jc + (size_t)t * JS);     // JS is even -> 16-byte aligned records

@@ -34,7 +34,8 @@ constexpr int CT_K1 = 28;
 constexpr int CT_K2 = 29;
 constexpr int CT_D = 32;     // 9  FD steps d = max(|1e-4 a|, 1e-6)
 constexpr int CT_RP = 41;    // 27 rotations for w + d e_k, k = 0..2
-constexpr int CT_STRIDE = 72;
+constexpr int CT_KN = 72;    // known-intrinsics flag (0/1), then k_known[5] (CT_KN+1..5) and K_known[0,1,2,4,5] (CT_KN+6..10)
+constexpr int CT_STRIDE = 84;
 
 __device__ __forceinline__ void rot_update(const double* __restrict__ Rinit, double w0, double w1, double w2,
                                            double* __restrict__ R)
@@ -93,9 +94,12 @@ __device__ __forceinline__ void rot_deriv_factor(const double* __restrict__ Rini
 }
 
 // Projection with an explicit rotation / centre / focal / distortion (operation order of sfm.c:316-377).
+// kn = camera-table slot CT_KN: cameras with known intrinsics go through the reference's 5-parameter Brown model and
+// their own K before the (optional) radial term (sfm_project_rd, lib/sfm-driver/sfm.c:339-358).
 __device__ __forceinline__ void project_core(int explicit_centers, int undistort, const double* __restrict__ R,
                                              double c0, double c1, double c2, double f, double k1, double k2,
-                                             double b0, double b1, double b2, double& x0, double& x1)
+                                             double b0, double b1, double b2, double& x0, double& x1,
+                                             const double* __restrict__ kn = nullptr)
 {
 #pragma clang fp contract(off)
     double P0, P1, P2;
@@ -109,8 +113,20 @@ __device__ __forceinline__ void project_core(int explicit_centers, int undistort
         P1 = R[3] * b0 + R[4] * b1 + R[5] * b2; P1 += c1;
         P2 = R[6] * b0 + R[7] * b1 + R[8] * b2; P2 += c2;
     }
-    double p0 = -P0 * f / P2;
-    double p1 = -P1 * f / P2;
+    double p0, p1;
+    if (kn && kn[0] != 0.0) {
+        const double xn = -P0 / P2, yn = -P1 / P2;
+        const double r2 = xn * xn + yn * yn;
+        const double fac = 1.0 + kn[1] * r2 + kn[2] * r2 * r2 + kn[5] * r2 * r2 * r2;
+        const double dxx = 2 * kn[3] * xn * yn + kn[4] * (r2 + 2 * xn * xn);
+        const double dxy = kn[3] * (r2 + 2 * yn * yn) + 2 * kn[4] * xn * yn;
+        const double xd = xn * fac + dxx, yd = yn * fac + dxy;
+        p0 = kn[6] * xd + kn[7] * yd + kn[8];
+        p1 = kn[9] * yd + kn[10];
+    } else {
+        p0 = -P0 * f / P2;
+        p1 = -P1 * f / P2;
+    }
     if (undistort) {
         const double rsq = (p0 * p0 + p1 * p1) / (f * f);
         const double factor = 1.0 + k1 * rsq + k2 * rsq * rsq;
@@ -120,11 +136,12 @@ __device__ __forceinline__ void project_core(int explicit_centers, int undistort
 }
 
 // Projection from a camera-table row.
+template <bool KNOWN = false>
 __device__ __forceinline__ void project_row(const ModelCfg& cfg, const double* __restrict__ ct,
                                             double b0, double b1, double b2, double& x0, double& x1)
 {
     project_core(cfg.explicit_centers, cfg.undistort, ct + CT_R, ct[CT_A], ct[CT_A + 1], ct[CT_A + 2],
-                 ct[CT_F], ct[CT_K1], ct[CT_K2], b0, b1, b2, x0, x1);
+                 ct[CT_F], ct[CT_K1], ct[CT_K2], b0, b1, b2, x0, x1, KNOWN ? ct + CT_KN : nullptr);
 }
 
 // Analytic A (2 x cnp row-major, A[r*cnp+c]) and B (2 x 3) plus the projection itself.
@@ -197,7 +214,9 @@ __device__ __forceinline__ void jac_analytic(const ModelCfg& cfg, const double* 
 }
 
 // Forward-difference A, B with the reference's steps; hx = base projection.
-template <int CNP>
+// KNOWN: the scene has cameras with known intrinsics (their table block is consulted); false removes that branch at
+// compile time from the hot kernels of ordinary scenes.
+template <int CNP, bool KNOWN = false>
 __device__ __forceinline__ void jac_fd(const ModelCfg& cfg, const double* __restrict__ ct,
                                        double b0, double b1, double b2,
                                        double* __restrict__ A, double* __restrict__ B, double& x0, double& x1)
@@ -208,7 +227,7 @@ __device__ __forceinline__ void jac_fd(const ModelCfg& cfg, const double* __rest
     const double f = ct[CT_F], k1 = ct[CT_K1], k2 = ct[CT_K2];
     const double* d = ct + CT_D;
     double h0, h1, q0, q1;
-    project_core(cfg.explicit_centers, cfg.undistort, R, c0, c1, c2, f, k1, k2, b0, b1, b2, h0, h1);
+    project_core(cfg.explicit_centers, cfg.undistort, R, c0, c1, c2, f, k1, k2, b0, b1, b2, h0, h1, KNOWN ? ct + CT_KN : nullptr);
     x0 = h0; x1 = h1;
     // centre / translation
 #pragma unroll
@@ -216,14 +235,14 @@ __device__ __forceinline__ void jac_fd(const ModelCfg& cfg, const double* __rest
         const double dj = d[jj], d1 = 1.0 / dj;
         project_core(cfg.explicit_centers, cfg.undistort, R,
                      jj == 0 ? c0 + dj : c0, jj == 1 ? c1 + dj : c1, jj == 2 ? c2 + dj : c2,
-                     f, k1, k2, b0, b1, b2, q0, q1);
+                     f, k1, k2, b0, b1, b2, q0, q1, KNOWN ? ct + CT_KN : nullptr);
         A[jj] = (q0 - h0) * d1; A[CNP + jj] = (q1 - h1) * d1;
     }
     // rotation increments: perturbed rotations come from the camera table
 #pragma unroll
     for (int jj = 0; jj < 3; ++jj) {
         const double d1 = 1.0 / d[3 + jj];
-        project_core(cfg.explicit_centers, cfg.undistort, ct + CT_RP + 9 * jj, c0, c1, c2, f, k1, k2, b0, b1, b2, q0, q1);
+        project_core(cfg.explicit_centers, cfg.undistort, ct + CT_RP + 9 * jj, c0, c1, c2, f, k1, k2, b0, b1, b2, q0, q1, KNOWN ? ct + CT_KN : nullptr);
         A[3 + jj] = (q0 - h0) * d1; A[CNP + 3 + jj] = (q1 - h1) * d1;
     }
     constexpr bool EST = (CNP == 7 || CNP == 9), UND = (CNP >= 8);
@@ -231,7 +250,7 @@ __device__ __forceinline__ void jac_fd(const ModelCfg& cfg, const double* __rest
     if constexpr (EST) {
         const double dj = d[6], d1 = 1.0 / dj;
         const double fp = (ct[CT_A + 6] + dj) / cfg.f_scale;
-        project_core(cfg.explicit_centers, cfg.undistort, R, c0, c1, c2, fp, k1, k2, b0, b1, b2, q0, q1);
+        project_core(cfg.explicit_centers, cfg.undistort, R, c0, c1, c2, fp, k1, k2, b0, b1, b2, q0, q1, KNOWN ? ct + CT_KN : nullptr);
         A[6] = (q0 - h0) * d1; A[CNP + 6] = (q1 - h1) * d1;
     }
     if constexpr (UND) {
@@ -240,7 +259,7 @@ __device__ __forceinline__ void jac_fd(const ModelCfg& cfg, const double* __rest
             const double dj = d[KC + t], d1 = 1.0 / dj;
             const double kp = (ct[CT_A + KC + t] + dj) / cfg.k_scale;
             project_core(cfg.explicit_centers, 1, R, c0, c1, c2, f, t == 0 ? kp : k1, t == 1 ? kp : k2,
-                         b0, b1, b2, q0, q1);
+                         b0, b1, b2, q0, q1, KNOWN ? ct + CT_KN : nullptr);
             A[KC + t] = (q0 - h0) * d1; A[CNP + KC + t] = (q1 - h1) * d1;
         }
     }
@@ -251,7 +270,7 @@ __device__ __forceinline__ void jac_fd(const ModelCfg& cfg, const double* __rest
         double dj = 1E-04 * bj; dj = fabs(dj); if (dj < 1E-06) dj = 1E-06;
         const double d1 = 1.0 / dj;
         project_core(cfg.explicit_centers, cfg.undistort, R, c0, c1, c2, f, k1, k2,
-                     jj == 0 ? b0 + dj : b0, jj == 1 ? b1 + dj : b1, jj == 2 ? b2 + dj : b2, q0, q1);
+                     jj == 0 ? b0 + dj : b0, jj == 1 ? b1 + dj : b1, jj == 2 ? b2 + dj : b2, q0, q1, KNOWN ? ct + CT_KN : nullptr);
         B[jj] = (q0 - h0) * d1; B[3 + jj] = (q1 - h1) * d1;
     }
 }

@@ -69,6 +69,7 @@ struct bsfm_problem {
     int Sdim = 0, ld = 0;
     // device
     double *d_x = nullptr, *d_Rinit = nullptr, *d_finit = nullptr;
+    double *d_known = nullptr;          // m x 11: known-intrinsics flag, k_known[5], K_known[0,1,2,4,5]; null when no camera has them
     int *d_obs_cam = nullptr, *d_obs_pt = nullptr, *d_rowptr = nullptr, *d_camptr = nullptr, *d_camobs = nullptr;
     int *d_campos = nullptr, *d_cam_pt = nullptr, *d_cam_cam = nullptr;
     unsigned char *d_ccon = nullptr, *d_pcon = nullptr;
@@ -115,7 +116,7 @@ namespace {
 
 void free_all(bsfm_problem* pb)
 {
-    void* ptrs[] = { pb->d_x, pb->d_Rinit, pb->d_finit, pb->d_obs_cam, pb->d_obs_pt, pb->d_rowptr, pb->d_camptr,
+    void* ptrs[] = { pb->d_x, pb->d_Rinit, pb->d_finit, pb->d_known, pb->d_obs_cam, pb->d_obs_pt, pb->d_rowptr, pb->d_camptr,
                      pb->d_camobs, pb->d_campos, pb->d_cam_pt, pb->d_cam_cam, pb->d_Jc, pb->d_ccon, pb->d_pcon, pb->d_cval, pb->d_cw, pb->d_pval, pb->d_p, pb->d_pdp,
                      pb->d_dp, pb->d_camtab, pb->d_camtab_trial, pb->d_e, pb->d_hx, pb->d_U,
                      pb->d_V, pb->d_Vinv, pb->d_eb, pb->d_S, pb->d_E, pb->d_partials, pb->d_epart, pb->d_campart, pb->d_red, pb->d_scal, pb->d_mixed,
@@ -248,7 +249,7 @@ inline int grid_for(size_t count, int block) { return (int)std::max<size_t>(1, (
 void launch_cam_table(bsfm_problem* pb, const double* p, double* camtab)
 {
     hipLaunchKernelGGL(k_cam_table, dim3(grid_for(pb->P.m, 64)), dim3(64), 0, pb->stream, pb->P.cfg, pb->P.m, p,
-                       pb->d_Rinit, pb->d_finit, pb->opt.jacobian == BSFM_JAC_FD ? 1 : 0, camtab);
+                       pb->d_Rinit, pb->d_finit, pb->d_known, pb->opt.jacobian == BSFM_JAC_FD ? 1 : 0, camtab);
 }
 
 // e_out = x - proj(p); SC slot gets sum e^2 ; optional pct-change vs e_prev into SC_PCT
@@ -258,8 +259,12 @@ void launch_residual(bsfm_problem* pb, const double* camtab, const double* p, do
     const int nb = grid_for(pb->P.nvis, RES_BLOCK);
     double* pc = pb->d_red, *pp = pb->d_red + pb->red_blocks;
     const double* pbpts = p + (size_t)pb->P.m * pb->cnp;
-    if (pb->P.nvis > 0)
-        hipLaunchKernelGGL(k_residual, dim3(nb), dim3(RES_BLOCK), 0, pb->stream, pb->P.cfg, pb->P.nvis, pb->d_x,
+    if (pb->P.nvis > 0 && pb->d_known)
+        hipLaunchKernelGGL(k_residual<true>, dim3(nb), dim3(RES_BLOCK), 0, pb->stream, pb->P.cfg, pb->P.nvis, pb->d_x,
+                           pb->d_obs_cam, pb->d_obs_pt, camtab, pbpts, e_out, e_prev, pb->opt.opts[5], pc,
+                           e_prev ? pp : nullptr);
+    if (pb->P.nvis > 0 && !pb->d_known)
+        hipLaunchKernelGGL(k_residual<false>, dim3(nb), dim3(RES_BLOCK), 0, pb->stream, pb->P.cfg, pb->P.nvis, pb->d_x,
                            pb->d_obs_cam, pb->d_obs_pt, camtab, pbpts, e_out, e_prev, pb->opt.opts[5], pc,
                            e_prev ? pp : nullptr);
     const int cnt = pb->P.nvis > 0 ? nb : 0;
@@ -335,10 +340,14 @@ int compute_normal_blocks(bsfm_problem* pb)
     ph_begin(pb, PH_JAC);
     if (P.nvis > 0) {
         if (pb->opt.jacobian == BSFM_JAC_FD) {
-            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_jacobian<C, true>), dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream,
+            if (pb->d_known) {
+                DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_jacobian<C, true, true>), dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream,
+                                                      P.cfg, P.nvis, pb->d_cam_cam, pb->d_cam_pt, pb->d_camtab, pbpts, pb->d_Jc));
+            } else
+            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_jacobian<C, true, false>), dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream,
                                                   P.cfg, P.nvis, pb->d_cam_cam, pb->d_cam_pt, pb->d_camtab, pbpts, pb->d_Jc));
         } else {
-            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_jacobian<C, false>), dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream,
+            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_jacobian<C, false, false>), dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream,
                                                   P.cfg, P.nvis, pb->d_cam_cam, pb->d_cam_pt, pb->d_camtab, pbpts, pb->d_Jc));
         }
     }
@@ -556,6 +565,28 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     std::vector<double> finit(m);
     for (int j = 0; j < m; ++j) { memcpy(&pb->h_Rinit[9 * (size_t)j], d->cameras[j].R, 9 * sizeof(double)); finit[j] = d->cameras[j].f; }
     ok = ok && up(pb->d_Rinit, pb->h_Rinit.data(), 9 * (size_t)m * sizeof(double)) && up(pb->d_finit, finit.data(), m * sizeof(double));
+    {   // cameras with known intrinsics (sfm.c:339-358): their block of the camera table; the closed-form Jacobian does not
+        // cover that branch, so such problems use the reference's own forward differences
+        bool any = false;
+        for (int j = 0; j < m; ++j) any = any || d->cameras[j].known_intrinsics;
+        if (any) {
+            std::vector<double> kn((size_t)m * 11, 0.0);
+            for (int j = 0; j < m; ++j)
+                if (d->cameras[j].known_intrinsics) {
+                    double* q = &kn[(size_t)j * 11];
+                    q[0] = 1.0;
+                    for (int t = 0; t < 5; ++t) q[1 + t] = d->cameras[j].k_known[t];
+                    q[6] = d->cameras[j].K_known[0]; q[7] = d->cameras[j].K_known[1]; q[8] = d->cameras[j].K_known[2];
+                    q[9] = d->cameras[j].K_known[4]; q[10] = d->cameras[j].K_known[5];
+                }
+            if (dmalloc(&pb->d_known, kn.size()) != hipSuccess) return fail("hipMalloc known intrinsics");
+            ok = ok && up(pb->d_known, kn.data(), kn.size() * sizeof(double));
+            if (pb->opt.jacobian != BSFM_JAC_FD) {
+                if (pb->opt.verbose >= 1) printf("[bsfm] cameras with known intrinsics: using the forward-difference Jacobian\n");
+                pb->opt.jacobian = BSFM_JAC_FD;
+            }
+        }
+    }
     std::vector<double> p;
     if (d->p_packed) p.assign(d->p_packed, d->p_packed + (size_t)m * cnp + (size_t)3 * n);
     else pack_params(pb, d->cameras, d->points, n, p);
@@ -623,6 +654,24 @@ int bsfm_problem_reset_params(bsfm_problem_t* pb, const bsfm_camera_params_t* ca
     HIP_OK(hipMemcpy(pb->d_p, p.data(), p.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(pb->d_Rinit, pb->h_Rinit.data(), pb->h_Rinit.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(pb->d_finit, finit.data(), finit.size() * sizeof(double), hipMemcpyHostToDevice));
+    {   // known-intrinsics block of the new cameras
+        bool any = false;
+        for (int j = 0; j < pb->P.m; ++j) any = any || cams[j].known_intrinsics;
+        if (any || pb->d_known) {
+            std::vector<double> kn((size_t)pb->P.m * 11, 0.0);
+            for (int j = 0; j < pb->P.m; ++j)
+                if (cams[j].known_intrinsics) {
+                    double* q = &kn[(size_t)j * 11];
+                    q[0] = 1.0;
+                    for (int t = 0; t < 5; ++t) q[1 + t] = cams[j].k_known[t];
+                    q[6] = cams[j].K_known[0]; q[7] = cams[j].K_known[1]; q[8] = cams[j].K_known[2];
+                    q[9] = cams[j].K_known[4]; q[10] = cams[j].K_known[5];
+                }
+            if (!pb->d_known) HIP_OK(dmalloc(&pb->d_known, kn.size()));
+            HIP_OK(hipMemcpy(pb->d_known, kn.data(), kn.size() * sizeof(double), hipMemcpyHostToDevice));
+            if (any) pb->opt.jacobian = BSFM_JAC_FD;
+        }
+    }
     pb->began = 0;
     return 0;
 }

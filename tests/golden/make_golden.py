@@ -108,6 +108,36 @@ def mot():
     print("mot_golden:", len(out), "arrays")
 
 
+def known_intrinsics():
+    """Cameras with known intrinsics (sfm_project_rd, sfm.c:339-358: 5-parameter Brown model + own K, then the optional
+    radial term): reference sba_motstr_levmar (its own FD Jacobian) after 1 and 3 iterations, and the reference run_sfm."""
+    out = {}
+    c = dict(m=8, n=60, deg=4)
+    s = B.synth_ba(c["m"], c["n"], c["deg"])
+    cams = s["cams"]
+    for j in (1, 4, 6):
+        cams[j].known_intrinsics = 1
+        f = cams[j].f
+        K = [f * 1.01, 0.3, 1.5, 0.0, f * 0.99, -2.0, 0.0, 0.0, 1.0]
+        for q in range(9):
+            cams[j].K_known[q] = K[q]
+        for q, v in enumerate([-0.02, 0.005, 1e-4, -2e-4, 1e-3]):
+            cams[j].k_known[q] = v
+    vm = B.dense_vmask(c["n"], c["m"], s["rowptr"], s["colidx"])
+    ca = O.cams_to_arrays(cams)
+    for k, v in ca.items():
+        out[f"cam_{k}"] = v
+    out["cam_known"] = np.array([cams[j].known_intrinsics for j in range(c["m"])], np.uint8)
+    out["cam_K_known"] = np.array([list(cams[j].K_known) for j in range(c["m"])])
+    out["cam_k_known"] = np.array([list(cams[j].k_known) for j in range(c["m"])])
+    out["rowptr"] = s["rowptr"]; out["colidx"] = s["colidx"]; out["proj"] = s["proj"]; out["pts"] = s["pts"]
+    for it in (1, 3, 150):
+        r = O.ref_sba(c["n"], c["m"], vm, s["proj"], cams, s["pts"], itmax=it, jac_mode=0)
+        out[f"fd_it{it}_p"] = r["p"]; out[f"fd_it{it}_info"] = r["info"]
+    np.savez_compressed(os.path.join(HERE, "known_golden.npz"), **out)
+    print("known_golden:", len(out), "arrays", out["fd_it150_info"])
+
+
 def parse_bundle(path):
     toks = open(path).read().split("\n")
     assert toks[0].startswith("# Bundle file v0.3")
@@ -224,6 +254,6 @@ def model():
 if __name__ == "__main__":
     assert O.have_ref(), "build oracle/_ref first (make -C oracle ref)"
     only = sys.argv[1:]
-    for fn in (ba_cases, kermit, matcher, model, exports, mot):
+    for fn in (ba_cases, kermit, matcher, model, exports, mot, known_intrinsics):
         if not only or fn.__name__ in only:
             fn()

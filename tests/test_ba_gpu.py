@@ -519,3 +519,37 @@ def test_resident_problem_reuse_and_caller_stream(gpu_bsfm):
     pbs.close()
     hip.hipStreamDestroy(st)
     assert np.array_equal(p3, p1) and np.array_equal(info3, info1)
+
+
+def test_known_intrinsics_cameras_match_reference(gpu_bsfm):
+    """cameras with known intrinsics go through the 5-parameter Brown model and their own K
+    (sfm_project_rd, lib/sfm-driver/sfm.c:339-358).  Fixture = the reference's sba_motstr_levmar (FD Jacobian) on a scene
+    where 3 of 8 cameras have known intrinsics (tests/golden/known_golden.npz)."""
+    B = gpu_bsfm
+    X = np.load(os.path.join(os.path.dirname(__file__), "golden", "known_golden.npz"))
+    m, n = len(X["cam_f"]), len(X["pts"]) // 3
+    cams = O.arrays_to_cams(X["cam_R"], X["cam_t"], X["cam_f"], X["cam_k"])
+    for j in range(m):
+        cams[j].known_intrinsics = int(X["cam_known"][j])
+        for q in range(9):
+            cams[j].K_known[q] = float(X["cam_K_known"][j][q])
+        for q in range(5):
+            cams[j].k_known[q] = float(X["cam_k_known"][j][q])
+    assert X["cam_known"].sum() == 3
+    for it in (1, 3):
+        # asking for the analytic Jacobian must fall back to forward differences for such scenes
+        opt = B.default_options(jacobian=B.JAC_ANALYTIC if it == 3 else B.JAC_FD, verbose=0, itmax=it, opts=REF_OPTS)
+        pb = B.Problem(n, m, X["rowptr"], X["colidx"], X["proj"], cams, X["pts"], options=opt)
+        rc, info = pb.solve()
+        p = pb.download(want_cams=False)[0]
+        pb.close()
+        gi, gp = X[f"fd_it{it}_info"], X[f"fd_it{it}_p"]
+        assert rc == it and list(info[5:10]) == list(gi[5:10])
+        assert abs(info[0] - gi[0]) <= 1e-11 * gi[0] and abs(info[1] - gi[1]) <= 1e-7 * gi[1]
+        assert np.abs(p - gp).max() <= 2e-6 * np.abs(gp).max()
+    # the drop-in boundary accepts them as well (it used to refuse)
+    c2 = B.copy_cameras(cams); pts = X["pts"].copy()
+    vm = B.dense_vmask(n, m, X["rowptr"], X["colidx"])
+    rc, info = B.run_sfm(n, m, 0, vm, X["proj"], 1, 0, 1, 1, c2, pts, eps2=1e-12, options=B.default_options(verbose=0))
+    gi = X["fd_it150_info"]
+    assert rc >= 0 and abs(info[1] - gi[1]) <= 1e-4 * gi[1]        # 38 FD iterations: same stop, cost to 1e-5
