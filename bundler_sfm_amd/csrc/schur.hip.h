@@ -15,6 +15,9 @@
 //     (12 lanes per record), parks them in a wave-private LDS slab (record stride 26 doubles: 16-byte aligned, at
 //     most 2-way bank conflicts), prefetches the next pass into registers while the current pass computes, and the
 //     3 lanes of a triple read their operands from LDS (broadcast where they coincide).
+// (Tried and dropped: dealing whole block rows S_j* to one XCD each (workgroups with blockIdx % 8 == x) so that camera j's
+// records stay in that XCD's L2 across the row's blocks: 2.03 ms either way -- an XCD runs ~6 rows at a time, 12 MB of
+// records against 4 MB of L2.  Also: fetching the record of a diagonal block only once: no gain.)
 // NOTE (gfx950 / hipcc 7.2): the prefetch registers are arrays of plain double -- arrays of the double2 vector
 // struct are not promoted to registers and end up in scratch, which serialises the whole pipeline.
 #pragma once
