@@ -40,6 +40,7 @@ class ProblemDesc(C.Structure):
         ("point_constraints", C.POINTER(C.c_double)), ("point_constraint_weight", C.c_double),
         ("world_size", C.c_int), ("rank", C.c_int), ("nvis_global", C.c_longlong), ("nvars_global", C.c_longlong),
         ("p_packed", C.POINTER(C.c_double)), ("constraints_prescaled", C.c_int), ("fix_points", C.c_int),
+        ("optimize_for_fisheye", C.c_int),
     ]
 
 

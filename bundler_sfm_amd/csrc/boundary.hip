@@ -10,8 +10,8 @@
 //   4. unpack cameras / points in place (sfm.c:876-929);
 //   5. optional Vout/Sout/Uout/Wout export at the solution (lib/sba-1.5/sba_levmar.c:1633-2026).
 // fix_points != 0 selects the camera-only refinement (sba_mot_levmar, sfm.c:839-846); cameras with known intrinsics
-// (sfm.c:339-358) are projected through their own K and Brown distortion.  The one mode the GPU core does not cover, the
-// fisheye projection, fails loudly and leaves every input untouched: there is deliberately no CPU fallback here.
+// (sfm.c:339-358) are projected through their own K and Brown distortion; optimize_for_fisheye != 0 selects the fisheye
+// projection (sfm.c:448-492).  Anything the GPU core cannot run fails loudly: there is deliberately no CPU fallback here.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -215,11 +215,6 @@ int bsfm_run_sfm_ex(int num_pts, int num_cameras, int ncons, char* vmask, double
     for (int i = 0; i < BSFM_INFOSZ; ++i) linfo[i] = 0.0;
     if (!info) info = linfo;
 
-    if (optimize_for_fisheye) {
-        fprintf(stderr, "[bsfm] run_sfm: the fisheye projection (sfm.c:448-492) is not implemented on the GPU core; "
-                        "inputs left untouched\n");
-        return BSFM_ERROR;
-    }
     if (est_focal_length && const_focal_length)
         printf("Error: case of constant focal length has not been implemented.\n");   // sfm.c:521-523
     // 1. vmask -> CRS
@@ -236,6 +231,7 @@ int bsfm_run_sfm_ex(int num_pts, int num_cameras, int ncons, char* vmask, double
     d.point_constraints = reinterpret_cast<const double*>(points_constraints);
     d.point_constraint_weight = point_constraint_weight;
     d.fix_points = fix_points ? 1 : 0;              // sba_mot_levmar: cameras only, no point constraints, no V/S/W
+    d.optimize_for_fisheye = optimize_for_fisheye ? 1 : 0;   // sfm.c:819-851
     d.world_size = 1; d.rank = 0;
 
     bsfm_problem_t* pb = bsfm_problem_create(&d, &opt);

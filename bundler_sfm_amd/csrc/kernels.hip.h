@@ -92,8 +92,7 @@ __global__ void k_cam_table(ModelCfg cfg, int m, const double* __restrict__ pa, 
     ct[CT_K1] = cfg.undistort ? a[col] / cfg.k_scale : 0.0;
     ct[CT_K2] = cfg.undistort ? a[col + 1] / cfg.k_scale : 0.0;
     ct[30] = finit[j]; ct[31] = 0.0;
-    for (int k = 0; k < 11; ++k) ct[CT_KN + k] = known ? known[(size_t)j * 11 + k] : 0.0;     // known-intrinsics block (model.hip.h)
-    ct[CT_KN + 11] = 0.0;
+    for (int k = 0; k < CT_EXT; ++k) ct[CT_KN + k] = known ? known[(size_t)j * CT_EXT + k] : 0.0;   // extended-model block (model.hip.h)
     if (with_fd) {
         for (int k = 0; k < 9; ++k) {
             double d = 0.0;

@@ -34,8 +34,11 @@ constexpr int CT_K1 = 28;
 constexpr int CT_K2 = 29;
 constexpr int CT_D = 32;     // 9  FD steps d = max(|1e-4 a|, 1e-6)
 constexpr int CT_RP = 41;    // 27 rotations for w + d e_k, k = 0..2
-constexpr int CT_KN = 72;    // known-intrinsics flag (0/1), then k_known[5] (CT_KN+1..5) and K_known[0,1,2,4,5] (CT_KN+6..10)
-constexpr int CT_STRIDE = 84;
+constexpr int CT_KN = 72;    // known-intrinsics flag (0/1), then k_known[5] (CT_KN+1..5) and K_known[0,1,2,4,5] (CT_KN+6..10);
+                             // CT_KN+11: 1 when the problem runs the fisheye projection (sfm.c:448-492), CT_KN+12: this camera's
+                             // fisheye flag, CT_KN+13..17: f_cx, f_cy, f_rad, f_angle, f_focal
+constexpr int CT_EXT = 18;   // doubles in the extended-model block at CT_KN
+constexpr int CT_STRIDE = 90;
 
 __device__ __forceinline__ void rot_update(const double* __restrict__ Rinit, double w0, double w1, double w2,
                                            double* __restrict__ R)
@@ -95,7 +98,9 @@ __device__ __forceinline__ void rot_deriv_factor(const double* __restrict__ Rini
 
 // Projection with an explicit rotation / centre / focal / distortion (operation order of sfm.c:316-377).
 // kn = camera-table slot CT_KN: cameras with known intrinsics go through the reference's 5-parameter Brown model and
-// their own K before the (optional) radial term (sfm_project_rd, lib/sfm-driver/sfm.c:339-358).
+// their own K before the (optional) radial term (sfm_project_rd, lib/sfm-driver/sfm.c:339-358).  In fisheye mode
+// (kn[11] != 0; sfm_project_point2_fisheye, sfm.c:448-492) the radial term is NOT applied (sfm_project2, sfm.c:231-299) and
+// cameras flagged fisheye map the pinhole point through the equidistant model (sfm_fisheye_distort, sfm.c:426-446).
 __device__ __forceinline__ void project_core(int explicit_centers, int undistort, const double* __restrict__ R,
                                              double c0, double c1, double c2, double f, double k1, double k2,
                                              double b0, double b1, double b2, double& x0, double& x1,
@@ -127,7 +132,15 @@ __device__ __forceinline__ void project_core(int explicit_centers, int undistort
         p0 = -P0 * f / P2;
         p1 = -P1 * f / P2;
     }
-    if (undistort) {
+    if (kn && kn[11] != 0.0) {
+        if (kn[12] != 0.0) {
+            const double r = sqrt(p0 * p0 + p1 * p1);
+            const double angle = 180.0 * atan(r / kn[17]) / 3.14159265358979323846;
+            const double rnew = kn[15] * angle / (0.5 * kn[16]);
+            p0 = p0 * (rnew / r) + kn[13];
+            p1 = p1 * (rnew / r) + kn[14];
+        }
+    } else if (undistort) {
         const double rsq = (p0 * p0 + p1 * p1) / (f * f);
         const double factor = 1.0 + k1 * rsq + k2 * rsq * rsq;
         p0 *= factor; p1 *= factor;

@@ -69,7 +69,8 @@ struct bsfm_problem {
     int Sdim = 0, ld = 0;
     // device
     double *d_x = nullptr, *d_Rinit = nullptr, *d_finit = nullptr;
-    double *d_known = nullptr;          // m x 11: known-intrinsics flag, k_known[5], K_known[0,1,2,4,5]; null when no camera has them
+    double *d_known = nullptr;          // m x CT_EXT: known-intrinsics / fisheye block of the camera table (model.hip.h); null when unused
+    int fisheye_mode = 0;               // run_sfm(optimize_for_fisheye): sfm_project_point2_fisheye instead of sfm_project_point3
     int *d_obs_cam = nullptr, *d_obs_pt = nullptr, *d_rowptr = nullptr, *d_camptr = nullptr, *d_camobs = nullptr;
     int *d_campos = nullptr, *d_cam_pt = nullptr, *d_cam_cam = nullptr;
     unsigned char *d_ccon = nullptr, *d_pcon = nullptr;
@@ -214,6 +215,31 @@ int build_schur_structure(bsfm_problem* pb, const bsfm_problem_desc_t* d, const 
     }
     HIP_OK(hipMemcpy(pb->d_blk_task0, blk_task0.data(), (nblk + 1) * sizeof(int), hipMemcpyHostToDevice));
     return 0;
+}
+
+// Extended camera-model block (model.hip.h, CT_KN): known intrinsics (sfm.c:339-358) and the fisheye projection
+// (sfm.c:426-492).  Returns false (and leaves `kn` empty) when no camera needs it.
+bool fill_ext_block(const bsfm_camera_params_t* cams, int m, int fisheye_mode, std::vector<double>& kn)
+{
+    bool any = fisheye_mode != 0;
+    for (int j = 0; j < m && !any; ++j) any = cams[j].known_intrinsics != 0;
+    if (!any) return false;
+    kn.assign((size_t)m * CT_EXT, 0.0);
+    for (int j = 0; j < m; ++j) {
+        double* q = &kn[(size_t)j * CT_EXT];
+        if (cams[j].known_intrinsics) {
+            q[0] = 1.0;
+            for (int t = 0; t < 5; ++t) q[1 + t] = cams[j].k_known[t];
+            q[6] = cams[j].K_known[0]; q[7] = cams[j].K_known[1]; q[8] = cams[j].K_known[2];
+            q[9] = cams[j].K_known[4]; q[10] = cams[j].K_known[5];
+        }
+        if (fisheye_mode) {
+            q[11] = 1.0;
+            q[12] = cams[j].fisheye ? 1.0 : 0.0;
+            q[13] = cams[j].f_cx; q[14] = cams[j].f_cy; q[15] = cams[j].f_rad; q[16] = cams[j].f_angle; q[17] = cams[j].f_focal;
+        }
+    }
+    return true;
 }
 
 void pack_params(const bsfm_problem* pb, const bsfm_camera_params_t* cams, const double* pts, int n,
@@ -565,24 +591,15 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     std::vector<double> finit(m);
     for (int j = 0; j < m; ++j) { memcpy(&pb->h_Rinit[9 * (size_t)j], d->cameras[j].R, 9 * sizeof(double)); finit[j] = d->cameras[j].f; }
     ok = ok && up(pb->d_Rinit, pb->h_Rinit.data(), 9 * (size_t)m * sizeof(double)) && up(pb->d_finit, finit.data(), m * sizeof(double));
-    {   // cameras with known intrinsics (sfm.c:339-358): their block of the camera table; the closed-form Jacobian does not
-        // cover that branch, so such problems use the reference's own forward differences
-        bool any = false;
-        for (int j = 0; j < m; ++j) any = any || d->cameras[j].known_intrinsics;
-        if (any) {
-            std::vector<double> kn((size_t)m * 11, 0.0);
-            for (int j = 0; j < m; ++j)
-                if (d->cameras[j].known_intrinsics) {
-                    double* q = &kn[(size_t)j * 11];
-                    q[0] = 1.0;
-                    for (int t = 0; t < 5; ++t) q[1 + t] = d->cameras[j].k_known[t];
-                    q[6] = d->cameras[j].K_known[0]; q[7] = d->cameras[j].K_known[1]; q[8] = d->cameras[j].K_known[2];
-                    q[9] = d->cameras[j].K_known[4]; q[10] = d->cameras[j].K_known[5];
-                }
-            if (dmalloc(&pb->d_known, kn.size()) != hipSuccess) return fail("hipMalloc known intrinsics");
+    {   // cameras with known intrinsics (sfm.c:339-358) and the fisheye projection (sfm.c:426-492): their block of the
+        // camera table; the closed-form Jacobian covers neither, so such problems use the reference's own forward differences
+        pb->fisheye_mode = d->optimize_for_fisheye ? 1 : 0;
+        std::vector<double> kn;
+        if (fill_ext_block(d->cameras, m, pb->fisheye_mode, kn)) {
+            if (dmalloc(&pb->d_known, kn.size()) != hipSuccess) return fail("hipMalloc extended camera model");
             ok = ok && up(pb->d_known, kn.data(), kn.size() * sizeof(double));
             if (pb->opt.jacobian != BSFM_JAC_FD) {
-                if (pb->opt.verbose >= 1) printf("[bsfm] cameras with known intrinsics: using the forward-difference Jacobian\n");
+                if (pb->opt.verbose >= 1) printf("[bsfm] known intrinsics / fisheye projection: using the forward-difference Jacobian\n");
                 pb->opt.jacobian = BSFM_JAC_FD;
             }
         }
@@ -654,19 +671,10 @@ int bsfm_problem_reset_params(bsfm_problem_t* pb, const bsfm_camera_params_t* ca
     HIP_OK(hipMemcpy(pb->d_p, p.data(), p.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(pb->d_Rinit, pb->h_Rinit.data(), pb->h_Rinit.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(pb->d_finit, finit.data(), finit.size() * sizeof(double), hipMemcpyHostToDevice));
-    {   // known-intrinsics block of the new cameras
-        bool any = false;
-        for (int j = 0; j < pb->P.m; ++j) any = any || cams[j].known_intrinsics;
+    {   // extended-model block of the new cameras
+        std::vector<double> kn;
+        const bool any = fill_ext_block(cams, pb->P.m, pb->fisheye_mode, kn);
         if (any || pb->d_known) {
-            std::vector<double> kn((size_t)pb->P.m * 11, 0.0);
-            for (int j = 0; j < pb->P.m; ++j)
-                if (cams[j].known_intrinsics) {
-                    double* q = &kn[(size_t)j * 11];
-                    q[0] = 1.0;
-                    for (int t = 0; t < 5; ++t) q[1 + t] = cams[j].k_known[t];
-                    q[6] = cams[j].K_known[0]; q[7] = cams[j].K_known[1]; q[8] = cams[j].K_known[2];
-                    q[9] = cams[j].K_known[4]; q[10] = cams[j].K_known[5];
-                }
             if (!pb->d_known) HIP_OK(dmalloc(&pb->d_known, kn.size()));
             HIP_OK(hipMemcpy(pb->d_known, kn.data(), kn.size() * sizeof(double), hipMemcpyHostToDevice));
             if (any) pb->opt.jacobian = BSFM_JAC_FD;

@@ -85,7 +85,8 @@ class Problem:
 
     def __init__(self, n, m, rowptr, colidx, proj, cams, pts, mcon=0, est_focal_length=1, undistort=1,
                  explicit_camera_centers=1, use_constraints=0, point_constraints=None, point_constraint_weight=0.0,
-                 options=None, world_size=1, rank=0, nvis_global=0, nvars_global=0, fix_points=0):
+                 options=None, world_size=1, rank=0, nvis_global=0, nvars_global=0, fix_points=0,
+                 optimize_for_fisheye=0):
         self._keep = (np.ascontiguousarray(rowptr, np.int32), np.ascontiguousarray(colidx, np.int32),
                       np.ascontiguousarray(proj, np.float64), cams, np.ascontiguousarray(pts, np.float64),
                       None if point_constraints is None else np.ascontiguousarray(point_constraints, np.float64))
@@ -94,6 +95,7 @@ class Problem:
         d.rowptr, d.colidx, d.projections = _ip(self._keep[0]), _ip(self._keep[1]), _dp(self._keep[2])
         d.est_focal_length, d.undistort, d.explicit_camera_centers = est_focal_length, undistort, explicit_camera_centers
         d.fix_points = fix_points
+        d.optimize_for_fisheye = optimize_for_fisheye
         d.cameras = C.cast(cams, C.POINTER(CameraParams))
         d.points = _dp(self._keep[4])
         d.use_constraints = use_constraints

@@ -160,6 +160,9 @@ typedef struct {
     /* Camera-only refinement (run_sfm's fix_points != 0 -> sba_mot_levmar, lib/sfm-driver/sfm.c:839-846): the points are
      * constants, the normal equations decouple into one cnp x cnp system per camera (sba_levmar.c:2090-2690). */
     int fix_points;
+    /* run_sfm's optimize_for_fisheye (sfm.c:819-851): project with sfm_project_point2_fisheye (sfm.c:448-492) -- pinhole
+     * without the radial term, then the equidistant map of cameras[j].fisheye/f_cx/f_cy/f_rad/f_angle/f_focal. */
+    int optimize_for_fisheye;
 } bsfm_problem_desc_t;
 
 /* Sum-reduce `count` doubles in place across ranks (device pointer); op 0 = sum, 1 = max.

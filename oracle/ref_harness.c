@@ -12,6 +12,7 @@
  *                      analytic Jacobian supplied through SBA's projac hook (jac_mode 1, oracle mode B);
  *                      itmax == 0 runs the reference's own Jacobian checker on it
  *                      (lib/sba-1.5/sba_levmar.c:769-773).
+ *   ref_set_fisheye    switch ref_sba_motstr to the fisheye projection callback (sfm.c:448-492).
  *   ref_sizeof_camera_params   layout check for the ctypes mirror of camera_params_t (sfm.h:32-51).
  */
 #include "sfm.c"          /* resolved through -I$(REF)/lib/sfm-driver */
@@ -39,6 +40,11 @@ static void harness_projac(int j, int i, double *aj, double *bi, double *Aij, do
 }
 
 int ref_sizeof_camera_params(void) { return (int) sizeof(camera_params_t); }
+
+/* ref_sba_motstr projects with sfm_project_point2_fisheye (sfm.c:448-492) instead of sfm_project_point3 while this is
+ * set -- what run_sfm does for optimize_for_fisheye != 0 (sfm.c:829-836); the Jacobian is then always the reference's FD. */
+static int g_fisheye = 0;
+void ref_set_fisheye(int on) { g_fisheye = on; }
 
 void ref_run_sfm(int num_pts, int num_cameras, int ncons, char *vmask, double *projections,
                  int est_focal_length, int const_focal_length, int undistort, int explicit_camera_centers,
@@ -133,7 +139,8 @@ int ref_sba_motstr(int n, int m, int mcon, char *vmask, double *projections,
 
     gettimeofday(&t0, NULL);
     rc = sba_motstr_levmar(n, m, mcon, vmask, params, cnp, 3, projections, NULL, 2,
-                           sfm_project_point3, jac_mode ? harness_projac : NULL, (void *) &globs,
+                           g_fisheye ? sfm_project_point2_fisheye : sfm_project_point3,
+                           (jac_mode && !g_fisheye) ? harness_projac : NULL, (void *) &globs,
                            itmax, verbose, opts, info, use_constraints, cons,
                            use_point_constraints, pcons, Vout, Sout, Uout, Wout);
     gettimeofday(&t1, NULL);

@@ -138,6 +138,50 @@ def known_intrinsics():
     print("known_golden:", len(out), "arrays", out["fd_it150_info"])
 
 
+def fisheye():
+    """run_sfm's optimize_for_fisheye mode (sfm_project_point2_fisheye + sfm_fisheye_distort, sfm.c:426-492): pinhole
+    projection WITHOUT the radial term, then the equidistant map for the cameras flagged fisheye.  The observations of
+    those cameras are pushed through the same map so that the scene stays consistent.  Fixtures: reference
+    sba_motstr_levmar with that callback (its own FD Jacobian) after 1, 3 and 150 iterations, and the verbatim reference
+    run_sfm(optimize_for_fisheye=1)."""
+    out = {}
+    c = dict(m=8, n=60, deg=4)
+    s = B.synth_ba(c["m"], c["n"], c["deg"])
+    cams = s["cams"]
+    fish = (0, 3, 5)
+    for j in fish:
+        cams[j].fisheye = 1
+        cams[j].f_cx = 3.0 + j; cams[j].f_cy = -2.0 + 0.5 * j
+        cams[j].f_rad = 400.0 + 10 * j; cams[j].f_angle = 170.0; cams[j].f_focal = cams[j].f * 1.05
+    proj = s["proj"].copy().reshape(-1, 2)
+    for k, j in enumerate(s["colidx"]):
+        if j in fish:
+            r = np.hypot(*proj[k])
+            ang = 180.0 * np.arctan(r / cams[j].f_focal) / np.pi
+            rnew = cams[j].f_rad * ang / (0.5 * cams[j].f_angle)
+            proj[k] = proj[k] * (rnew / r) + [cams[j].f_cx, cams[j].f_cy]
+    proj = proj.ravel()
+    vm = B.dense_vmask(c["n"], c["m"], s["rowptr"], s["colidx"])
+    ca = O.cams_to_arrays(cams)
+    for k, v in ca.items():
+        out[f"cam_{k}"] = v
+    out["cam_fisheye"] = np.array([cams[j].fisheye for j in range(c["m"])], np.uint8)
+    out["cam_fparams"] = np.array([[cams[j].f_cx, cams[j].f_cy, cams[j].f_rad, cams[j].f_angle, cams[j].f_focal]
+                                   for j in range(c["m"])])
+    out["rowptr"] = s["rowptr"]; out["colidx"] = s["colidx"]; out["proj"] = proj; out["pts"] = s["pts"]
+    for und in (1, 0):
+        for it in (1, 3, 150):
+            r = O.ref_sba(c["n"], c["m"], vm, proj, cams, s["pts"], itmax=it, jac_mode=0, undistort=und, fisheye=True)
+            out[f"u{und}_it{it}_p"] = r["p"]; out[f"u{und}_it{it}_info"] = r["info"]
+        co, po = O.ref_run_sfm(c["n"], c["m"], vm, proj, cams, s["pts"], undistort=und, optimize_for_fisheye=1)
+        ra = O.cams_to_arrays(co)
+        out[f"u{und}_run_R"] = ra["R"]; out[f"u{und}_run_t"] = ra["t"]; out[f"u{und}_run_f"] = ra["f"]
+        out[f"u{und}_run_k"] = ra["k"]; out[f"u{und}_run_pts"] = po
+        print("fisheye undistort", und, out[f"u{und}_it150_info"])
+    np.savez_compressed(os.path.join(HERE, "fisheye_golden.npz"), **out)
+    print("fisheye_golden:", len(out), "arrays")
+
+
 def parse_bundle(path):
     toks = open(path).read().split("\n")
     assert toks[0].startswith("# Bundle file v0.3")
@@ -254,6 +298,6 @@ def model():
 if __name__ == "__main__":
     assert O.have_ref(), "build oracle/_ref first (make -C oracle ref)"
     only = sys.argv[1:]
-    for fn in (ba_cases, kermit, matcher, model, exports, mot, known_intrinsics):
+    for fn in (ba_cases, kermit, matcher, model, exports, mot, known_intrinsics, fisheye):
         if not only or fn.__name__ in only:
             fn()

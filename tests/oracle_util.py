@@ -78,7 +78,7 @@ def copy_cams(cams):
 
 
 def ref_run_sfm(n, m, vmask, proj, cams, pts, ncons=0, est_focal=1, undistort=1, explicit=1, use_constraints=0,
-                point_constraints=None, point_w=0.0, eps2=1e-12, quiet=True, fix_points=0):
+                point_constraints=None, point_w=0.0, eps2=1e-12, quiet=True, fix_points=0, optimize_for_fisheye=0):
     """Verbatim reference run_sfm (oracle mode A). Returns (cams_out, pts_out)."""
     cams = copy_cams(cams)
     pts = np.array(pts, np.float64, copy=True)
@@ -88,7 +88,7 @@ def ref_run_sfm(n, m, vmask, proj, cams, pts, ncons=0, est_focal=1, undistort=1,
     with ctx:
         ref().ref_run_sfm(n, m, ncons, vm.ctypes.data_as(C.c_char_p), _d(proj), est_focal, 0, undistort, explicit,
                           cams, _d(pts), use_constraints, 0 if point_constraints is None else 1,
-                          _d(point_constraints), point_w, fix_points, 0, eps2, None, None, None, None)
+                          _d(point_constraints), point_w, fix_points, optimize_for_fisheye, eps2, None, None, None, None)
     return cams, pts
 
 
@@ -114,8 +114,9 @@ def ref_sba_mot(n, m, vmask, proj, cams, pts, itmax, jac_mode, ncons=0, est_foca
 
 
 def ref_sba(n, m, vmask, proj, cams, pts, itmax, jac_mode, ncons=0, est_focal=1, undistort=1, explicit=1,
-            use_constraints=0, point_constraints=None, point_w=0.0, eps2=1e-12, want_blocks=False, quiet=True):
-    """Reference sba_motstr_levmar with chosen itmax / Jacobian (0 = reference FD, 1 = our analytic via projac).
+            use_constraints=0, point_constraints=None, point_w=0.0, eps2=1e-12, want_blocks=False, quiet=True, fisheye=False):
+    """Reference sba_motstr_levmar with chosen itmax / Jacobian (0 = reference FD, 1 = our analytic via projac);
+    fisheye=True projects with sfm_project_point2_fisheye (sfm.c:448-492), as run_sfm(optimize_for_fisheye=1) does.
     Returns dict(rc, info, p, secs[, U, V, S, W])."""
     cnp = (7 if est_focal else 6) + (2 if undistort else 0)
     cams = copy_cams(cams)
@@ -131,10 +132,12 @@ def ref_sba(n, m, vmask, proj, cams, pts, itmax, jac_mode, ncons=0, est_focal=1,
         W = np.zeros((m * cnp, 3 * n))
     ctx = quiet_stdout() if quiet else contextlib.nullcontext()
     with ctx:
+        ref().ref_set_fisheye(1 if fisheye else 0)
         rc = ref().ref_sba_motstr(n, m, ncons, vm.ctypes.data_as(C.c_char_p), _d(proj), est_focal, undistort, explicit,
                                   cams, _d(pts), use_constraints, 0 if point_constraints is None else 1,
                                   _d(point_constraints), point_w, eps2, itmax, jac_mode, 0 if quiet else 3,
                                   _d(info), _d(p), _d(V), _d(S), _d(U), _d(W), C.byref(secs))
+        ref().ref_set_fisheye(0)
     return dict(rc=rc, info=info, p=p, secs=secs.value, U=U, V=V, S=S, W=W, cnp=cnp)
 
 

@@ -229,10 +229,12 @@ def test_edge_cases(gpu_bsfm):
     assert abs(info[1] - q["info"][1]) <= 1e-9 * q["info"][1]
     assert np.abs(p - q["p"]).max() <= 1e-7 * np.abs(q["p"]).max()
     pb.close()
-    # unsupported modes fail loudly and leave inputs untouched
-    cams = B.copy_cameras(base["cams"]); pts = base["pts"].copy()
-    rc, _ = B.run_sfm(n, m, 0, vm, proj, 1, 0, 1, 1, cams, pts, optimize_for_fisheye=1, options=B.default_options(verbose=0))
-    assert rc == -1 and np.array_equal(pts, base["pts"])
+    # an underdetermined problem (SBA's "fewer measurements than unknowns", sba_levmar.c:724-728) fails loudly and leaves
+    # the inputs untouched
+    cams = B.copy_cameras(base["cams"]); pts = base["pts"][:3].copy()
+    k1 = int(rowptr[1])
+    rc, _ = B.run_sfm(1, m, 0, vm[:1], proj[:2 * k1], 1, 0, 1, 1, cams, pts, options=B.default_options(verbose=0))
+    assert rc == -1 and np.array_equal(pts, base["pts"][:3])
     assert all(list(a.t) == list(b.t) and a.f == b.f for a, b in zip(cams, base["cams"]))
 
 
@@ -553,3 +555,43 @@ def test_known_intrinsics_cameras_match_reference(gpu_bsfm):
     rc, info = B.run_sfm(n, m, 0, vm, X["proj"], 1, 0, 1, 1, c2, pts, eps2=1e-12, options=B.default_options(verbose=0))
     gi = X["fd_it150_info"]
     assert rc >= 0 and abs(info[1] - gi[1]) <= 1e-4 * gi[1]        # 38 FD iterations: same stop, cost to 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("und", [1, 0])
+def test_fisheye_projection_matches_reference(gpu_bsfm, und):
+    """run_sfm(optimize_for_fisheye=1): sfm_project_point2_fisheye (lib/sfm-driver/sfm.c:448-492) = pinhole without the
+    radial term + the equidistant map of the cameras flagged fisheye (sfm_fisheye_distort, sfm.c:426-446).  Fixture = the
+    reference's sba_motstr_levmar driven by that callback (tests/golden/fisheye_golden.npz); with undistort=1 the k1,k2
+    columns of the Jacobian are identically zero, as in the reference."""
+    B = gpu_bsfm
+    X = np.load(os.path.join(os.path.dirname(__file__), "golden", "fisheye_golden.npz"))
+    m, n = len(X["cam_f"]), len(X["pts"]) // 3
+    cams = O.arrays_to_cams(X["cam_R"], X["cam_t"], X["cam_f"], X["cam_k"])
+    for j in range(m):
+        cams[j].fisheye = int(X["cam_fisheye"][j])
+        cams[j].f_cx, cams[j].f_cy, cams[j].f_rad, cams[j].f_angle, cams[j].f_focal = [float(v) for v in X["cam_fparams"][j]]
+    assert X["cam_fisheye"].sum() == 3
+    for it in (1, 3):
+        opt = B.default_options(jacobian=B.JAC_ANALYTIC if it == 3 else B.JAC_FD, verbose=0, itmax=it, opts=REF_OPTS)
+        pb = B.Problem(n, m, X["rowptr"], X["colidx"], X["proj"], cams, X["pts"], undistort=und, options=opt,
+                       optimize_for_fisheye=1)
+        rc, info = pb.solve()
+        p = pb.download(want_cams=False)[0]
+        pb.close()
+        gi, gp = X[f"u{und}_it{it}_info"], X[f"u{und}_it{it}_p"]
+        assert rc == it and list(info[5:10]) == list(gi[5:10])
+        assert abs(info[0] - gi[0]) <= 1e-11 * gi[0] and abs(info[1] - gi[1]) <= 1e-7 * gi[1]
+        assert np.abs(p - gp).max() <= 2e-6 * np.abs(gp).max()
+    # the drop-in boundary against the verbatim reference run_sfm
+    c2 = B.copy_cameras(cams); pts = X["pts"].copy()
+    vm = B.dense_vmask(n, m, X["rowptr"], X["colidx"])
+    rc, info = B.run_sfm(n, m, 0, vm, X["proj"], 1, 0, und, 1, c2, pts, optimize_for_fisheye=1, eps2=1e-12,
+                         options=B.default_options(verbose=0))
+    gi = X[f"u{und}_it150_info"]
+    assert rc >= 0 and info[6] == gi[6] and abs(info[5] - gi[5]) <= 2 and abs(info[1] - gi[1]) <= 1e-6 * gi[1]
+    got = O.cams_to_arrays(c2)
+    assert np.abs(got["f"] - X[f"u{und}_run_f"]).max() <= 1e-5 * np.abs(X[f"u{und}_run_f"]).max()
+    assert np.abs(got["R"] - X[f"u{und}_run_R"]).max() <= 1e-6
+    assert np.abs(got["t"] - X[f"u{und}_run_t"]).max() <= 1e-5 * max(1.0, np.abs(X[f"u{und}_run_t"]).max())
+    assert np.abs(pts - X[f"u{und}_run_pts"]).max() <= 1e-5 * max(1.0, np.abs(X[f"u{und}_run_pts"]).max())
