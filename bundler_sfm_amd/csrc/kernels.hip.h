@@ -612,6 +612,51 @@ __global__ __launch_bounds__(256) void k_point_outliers(int n, const int* __rest
     flag[i] = f; err[i] = ev;
 }
 
+// Ray-angle pruning of RemoveBadPointsAndCameras (src/Bundle.cpp:4190-4261): per point the largest angle between the rays
+// to two of its cameras, r = (X - c) * (1 / |X - c|) (matrix_diff, matrix_norm, matrix_scale), angle = acos(clamp(r1.r2,
+// -1 + 1e-8, 1 - 1e-8)).  The unit rays are formed once per observation (the reference re-forms the second ray inside the
+// pair loop -- same values); acos is monotone, so the largest angle is the acos of the smallest clamped dot product.
+__global__ __launch_bounds__(256) void k_obs_rays(int nvis, int cnp, const int* __restrict__ obs_cam, const int* __restrict__ obs_pt,
+        const double* __restrict__ pa, const double* __restrict__ pb, double* __restrict__ rays)
+{
+#pragma clang fp contract(off)
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nvis) return;
+    const double* c = pa + (size_t)obs_cam[k] * cnp;
+    const double* X = pb + (size_t)obs_pt[k] * 3;
+    const double r0 = X[0] - c[0], r1 = X[1] - c[1], r2 = X[2] - c[2];
+    double sum = 0.0;
+    sum += r0 * r0; sum += r1 * r1; sum += r2 * r2;
+    const double s = 1.0 / sqrt(sum);
+    rays[3 * (size_t)k] = r0 * s; rays[3 * (size_t)k + 1] = r1 * s; rays[3 * (size_t)k + 2] = r2 * s;
+}
+
+__global__ __launch_bounds__(256) void k_point_ray_angle(int n, const int* __restrict__ rowptr, const double* __restrict__ rays,
+        double half_thr_deg, double* __restrict__ angle_deg, unsigned char* __restrict__ prune)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int k0 = rowptr[i], k1 = rowptr[i + 1];
+    const double hi = 1.0 - 1.0e-8, lo = -1.0 + 1.0e-8;
+    bool any = false;
+    double dmin = hi;
+    for (int a = k0; a < k1; ++a) {
+        const double a0 = rays[3 * (size_t)a], a1 = rays[3 * (size_t)a + 1], a2 = rays[3 * (size_t)a + 2];
+        for (int b = a + 1; b < k1; ++b) {
+            double dot = 0.0;
+            dot += a0 * rays[3 * (size_t)b]; dot += a1 * rays[3 * (size_t)b + 1]; dot += a2 * rays[3 * (size_t)b + 2];
+            dot = dot < lo ? lo : (dot > hi ? hi : dot);
+            if (!any || dot < dmin) dmin = dot;
+            any = true;
+        }
+    }
+    // max_angle starts at 0.0 and only grows (Bundle.cpp:4205,4225-4227); acos(hi) > 0, so any pair sets it
+    const double deg = any ? acos(dmin) * (180.0 / 3.14159265358979323846) : 0.0;
+    angle_deg[i] = deg;
+    prune[i] = (k1 > k0 && deg < half_thr_deg) ? 1 : 0;
+}
+
 // Camera-only refinement (points fixed): (U_j + mu I) da_j = ea_j, one thread per camera, Cholesky in registers
 // (the reference calls sba_Axb_Chol on every U_j, sba_levmar.c:2499-2513); a non-positive pivot raises flag[1].
 template <int CNP>

@@ -1074,6 +1074,31 @@ int bsfm_problem_outlier_stats(bsfm_problem_t* pb, double min_thr, double max_th
     return ok ? 0 : BSFM_ERROR;
 }
 
+int bsfm_problem_ray_angles(bsfm_problem_t* pb, double ray_angle_threshold, double* max_angle_deg, unsigned char* prune,
+                            int* num_pruned)
+{
+    const int m = pb->P.m, n = pb->P.n, nvis = pb->P.nvis;
+    if (pb->mot) { fprintf(stderr, "[bsfm] ray angles: the camera-only problem does not hold the points on the device\n"); return BSFM_ERROR; }
+    double *rays = nullptr, *deg = nullptr; unsigned char* flag = nullptr;
+    auto cleanup = [&] { for (void* q : { (void*)rays, (void*)deg, (void*)flag }) if (q) (void)hipFree(q); };
+    if (dmalloc(&rays, (size_t)3 * nvis + 1) != hipSuccess || dmalloc(&deg, (size_t)n + 1) != hipSuccess ||
+        dmalloc(&flag, (size_t)n + 1) != hipSuccess) { cleanup(); return BSFM_ERROR; }
+    if (nvis > 0)
+        hipLaunchKernelGGL(k_obs_rays, dim3(grid_for(nvis, 256)), dim3(256), 0, pb->stream, nvis, pb->cnp, pb->d_obs_cam, pb->d_obs_pt,
+                           pb->d_p, pb->d_p + (size_t)m * pb->cnp, rays);
+    if (n > 0)
+        hipLaunchKernelGGL(k_point_ray_angle, dim3(grid_for(n, 256)), dim3(256), 0, pb->stream, n, pb->d_rowptr, rays,
+                           0.5 * ray_angle_threshold, deg, flag);
+    if (hipStreamSynchronize(pb->stream) != hipSuccess) { cleanup(); return BSFM_ERROR; }
+    std::vector<unsigned char> hf((size_t)n);
+    bool ok = n == 0 || hipMemcpy(hf.data(), flag, (size_t)n, hipMemcpyDeviceToHost) == hipSuccess;
+    if (max_angle_deg && n > 0) ok = ok && hipMemcpy(max_angle_deg, deg, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+    if (prune && n > 0) memcpy(prune, hf.data(), (size_t)n);
+    if (num_pruned) { int c = 0; for (int i = 0; i < n; ++i) c += hf[i]; *num_pruned = c; }
+    cleanup();
+    return ok ? 0 : BSFM_ERROR;
+}
+
 int bsfm_eval_residuals(bsfm_problem_t* pb, double* e_out, double* cost)
 {
     launch_cam_table(pb, pb->d_p, pb->d_camtab);

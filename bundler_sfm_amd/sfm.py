@@ -181,6 +181,18 @@ class Problem:
         out["global_mean"] = gm.value
         return out
 
+    def ray_angles(self, ray_angle_threshold=2.0):
+        """RemoveBadPointsAndCameras' ray-angle test (src/Bundle.cpp:4190-4261) at the current parameters.
+        Returns dict(angle_deg (n), prune (n, uint8), num_pruned)."""
+        out = dict(angle_deg=np.zeros(self.n), prune=np.zeros(self.n, np.uint8))
+        cnt = C.c_int()
+        rc = lib.bsfm_problem_ray_angles(self.h, float(ray_angle_threshold), _dp(out["angle_deg"]),
+                                         out["prune"].ctypes.data_as(C.POINTER(C.c_ubyte)), C.byref(cnt))
+        if rc != 0:
+            raise RuntimeError("bsfm_problem_ray_angles failed")
+        out["num_pruned"] = cnt.value
+        return out
+
     def residuals(self):
         e = np.zeros(2 * self.nvis)
         cost = C.c_double()

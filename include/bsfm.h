@@ -209,6 +209,12 @@ int bsfm_eval_residuals(bsfm_problem_t *pb, double *e_out, double *cost);
 int bsfm_problem_outlier_stats(bsfm_problem_t *pb, double min_thr, double max_thr,
                                int *cam_nobs, double *cam_mean, double *cam_kth80, double *cam_kth50, double *cam_thresh,
                                unsigned char *point_outlier, double *point_err, double *global_mean);
+/* Ray-angle pruning of BundlerApp::RemoveBadPointsAndCameras (src/Bundle.cpp:4190-4261) at the resident parameters: per
+ * point the largest angle (degrees) between the rays X_i - c_j to any two of its cameras; prune[i] = 1 when the point has
+ * views and that angle is below 0.5 * ray_angle_threshold (Bundler's m_ray_angle_threshold = 2.0, BundlerApp.h:83).
+ * Camera centres are parameters 0..2 (explicit_camera_centers, as Bundler always runs).  Any output may be NULL. */
+int bsfm_problem_ray_angles(bsfm_problem_t *pb, double ray_angle_threshold, double *max_angle_deg, unsigned char *prune,
+                            int *num_pruned);
 int bsfm_eval_normal_equations(bsfm_problem_t *pb, double mu, double *U, double *ea, double *V, double *eb,
                                double *J, double *S, double *E);
 /* Dense SPD solve on the device with the production Cholesky: A (n x n, symmetric, row-major, host),

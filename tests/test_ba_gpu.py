@@ -426,6 +426,50 @@ def test_post_solve_outlier_statistics(gpu_bsfm, with_pcons):
     assert np.abs(st["err"] - err).max() <= 1e-9 * max(1.0, err.max())
 
 
+def test_ray_angle_pruning(gpu_bsfm):
+    """SURVEY 8(f).1, second half: RemoveBadPointsAndCameras (src/Bundle.cpp:4190-4261).  CPU side restates the
+    reference loop (unit rays by multiplying with 1/norm, dot in index order, CLAMP to +-(1 - 1e-8), acos, RAD2DEG, prune
+    when below half the threshold); some points are pulled far away so that their rays become nearly parallel."""
+    import math
+    B = gpu_bsfm
+    c = load_case("band")
+    m, n = c["m"], c["n"]
+    pts = c["pts"].copy().reshape(-1, 3)
+    ca = O.cams_to_arrays(c["cams"])
+    far = np.arange(0, n, 7)
+    centre = ca["t"].mean(axis=0)
+    pts[far] = centre + (pts[far] - centre) * 400.0               # distant points: tiny parallax
+    pb = B.Problem(n, m, c["rowptr"], c["colidx"], c["proj"], c["cams"], pts.ravel(), est_focal_length=c["est"],
+                   undistort=c["und"], options=B.default_options(verbose=0))
+    thr = 2.0
+    st = pb.ray_angles(thr)
+    pb.close()
+    ang = np.zeros(n); prune = np.zeros(n, np.uint8)
+    for i in range(n):
+        k0, k1 = c["rowptr"][i], c["rowptr"][i + 1]
+        rays = []
+        for k in range(k0, k1):
+            r = pts[i] - ca["t"][c["colidx"][k]]
+            s = 0.0
+            for q in range(3):
+                s += r[q] * r[q]
+            rays.append(r * (1.0 / math.sqrt(s)))
+        mx = 0.0
+        for a in range(len(rays)):
+            for b in range(a + 1, len(rays)):
+                d = 0.0
+                for q in range(3):
+                    d += rays[a][q] * rays[b][q]
+                d = min(max(d, -1.0 + 1.0e-8), 1.0 - 1.0e-8)
+                mx = max(mx, math.acos(d))
+        ang[i] = mx * (180.0 / math.pi)
+        prune[i] = 1 if (k1 > k0 and ang[i] < 0.5 * thr) else 0
+    assert np.abs(st["angle_deg"] - ang).max() <= 1e-9            # acos near 1 amplifies the last ulp of the dot product
+    assert np.abs(ang - 0.5 * thr).min() > 1e-6                   # nobody sits on the threshold: flags must agree exactly
+    assert np.array_equal(st["prune"], prune) and st["num_pruned"] == int(prune.sum())
+    assert 0 < prune.sum() < n
+
+
 MOT = np.load(os.path.join(os.path.dirname(__file__), "golden", "mot_golden.npz"))
 REF_OPTS = [1e-3, 1e-10, 1e-12, 1e-12, 0.0, 4e-2]     # what run_sfm passes (sfm.c:705-714, eps2 = 1e-12 as in the fixtures)
 
