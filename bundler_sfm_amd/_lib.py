@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libbsfm_hip.so")
 
 INFOSZ = 10
 JAC_FD, JAC_ANALYTIC = 0, 1
+SOLVER_DENSE, SOLVER_AUTO = 0, 1
 
 
 class CameraParams(C.Structure):
@@ -27,7 +28,7 @@ class CameraParams(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("jacobian", C.c_int), ("itmax", C.c_int), ("verbose", C.c_int),
-                ("opts", C.c_double * 6), ("potrf_backend", C.c_int)]
+                ("opts", C.c_double * 6), ("potrf_backend", C.c_int), ("reduced_solver", C.c_int)]
 
 
 class ProblemDesc(C.Structure):

@@ -25,6 +25,7 @@
 #include "kernels.hip.h"
 #include "schur.hip.h"
 #include "potrf.hip.h"
+#include "compsolve.hip.h"
 
 using namespace bsfm;
 
@@ -104,6 +105,7 @@ struct bsfm_problem {
     hipStream_t stream = nullptr; bool own_stream = false;
     bsfm_allreduce_fn allreduce = nullptr; void* allreduce_ctx = nullptr;
     PotrfWorkspace potrf;
+    CompSolver comps;                   // opt-in: independent camera groups solved one workgroup each (compsolve.hip.h)
     // LM state (names follow sba_levmar.c)
     int itno = 0, stop = 0, nu = 2, nfev = 0, njev = 0, nlss = 0, began = 0, error = 0;
     double mu = 0.0, p_eL2 = 0.0, init_p_eL2 = 0.0, eab_inf = 0.0, dp_L2 = DBL_MAX, p_L2 = 0.0, maxdiag = DBL_MIN;
@@ -127,9 +129,12 @@ void free_all(bsfm_problem* pb)
     if (pb->h_scal) (void)hipHostFree(pb->h_scal);
     if (pb->h_flags) (void)hipHostFree(pb->h_flags);
     potrf_free(pb->potrf);
+    comp_free(pb->comps);
     if (pb->ev_ok) for (int i = 0; i < PH_COUNT; ++i) { (void)hipEventDestroy(pb->ev[i][0]); (void)hipEventDestroy(pb->ev[i][1]); }
     if (pb->own_stream && pb->stream) stream_pool().release(pb->stream);
 }
+
+int setup_components(bsfm_problem* pb, const std::vector<int>& bj, const std::vector<int>& bk);
 
 // Builds the co-visibility triple list bucketed by reduced-camera block (j <= k), in (j,k) order and,
 // inside a block, in point order -- the order the reference visits them (sba_levmar.c:1218-1268).
@@ -197,6 +202,7 @@ int build_schur_structure(bsfm_problem* pb, const bsfm_problem_desc_t* d, const 
     blk_task0[nblk] = (int)tasks.size();
     pb->ntriples = (int)total; pb->ntasks = (int)tasks.size(); pb->nblk = nblk;
     pb->h_blk_j = blk_j; pb->h_blk_k = blk_k;
+    if (pb->world == 1 && setup_components(pb, blk_j, blk_k)) return BSFM_ERROR;   // world > 1: after the block-union exchange
     HIP_OK(dmalloc(&pb->d_triples, total)); HIP_OK(dmalloc(&pb->d_tasks, tasks.size()));
     HIP_OK(dmalloc(&pb->d_blk_j, nblk)); HIP_OK(dmalloc(&pb->d_blk_k, nblk)); HIP_OK(dmalloc(&pb->d_blk_task0, nblk + 1));
     HIP_OK(dmalloc(&pb->d_partials, tasks.size() * (size_t)pb->cnp * pb->cnp));
@@ -393,6 +399,19 @@ int compute_normal_blocks(bsfm_problem* pb)
     return 0;
 }
 
+// Opt-in structure-aware reduced solve (compsolve.hip.h): groups of cameras that share no point with the rest.
+int setup_components(bsfm_problem* pb, const std::vector<int>& bj, const std::vector<int>& bk)
+{
+    if (pb->opt.reduced_solver != BSFM_SOLVER_AUTO || pb->opt.potrf_backend != 0) return 0;
+    if (comp_setup(pb->comps, pb->P.m - pb->P.mcon, pb->cnp, bj, bk, pb->P.mcon)) return BSFM_ERROR;
+    if (pb->opt.verbose >= 2) {
+        if (pb->comps.active) printf("[bsfm] reduced camera system: %d independent camera groups (largest %d unknowns), solved group by group\n",
+                                     pb->comps.ncomp, pb->comps.maxdim);
+        else printf("[bsfm] reduced camera system: connected (or a group too large for LDS), dense Cholesky\n");
+    }
+    return 0;
+}
+
 // Union over ranks of the non-empty reduced-camera blocks.  The hook only sums, so the all-gather is a sum of
 // disjoint segments: rank r writes key+1 of its blocks into segment r of a world x maxcount buffer (0 = empty slot).
 int exchange_block_union(bsfm_problem* pb)
@@ -430,6 +449,7 @@ int exchange_block_union(bsfm_problem* pb)
         HIP_OK(hipMemcpy(pb->d_gblk_k, gk.data(), (size_t)ng * sizeof(int), hipMemcpyHostToDevice));
     }
     pb->ngblk = ng;
+    if (setup_components(pb, gj, gk)) return BSFM_ERROR;          // same structure on every rank
     if (pb->opt.verbose >= 2)
         printf("[bsfm] rank %d: %d local / %d global reduced-camera blocks, %.1f MB per exchange (dense S: %.1f MB)\n", pb->rank,
                pb->nblk, ng, ng * pb->cnp * pb->cnp * 8e-6, (double)pb->ld * pb->ld * 8e-6);
@@ -446,7 +466,8 @@ int compute_schur(bsfm_problem* pb, double mu)
     const bool packed = pb->world > 1 && pb->allreduce;
     if (packed && pb->ngblk < 0 && exchange_block_union(pb)) return BSFM_ERROR;
     if (pb->export_full_s) (void)hipMemsetAsync(pb->d_S, 0, (size_t)pb->ld * pb->ld * sizeof(double), pb->stream);
-    else { const int nt = pb->ld / POTRF_NB; hipLaunchKernelGGL(k_zero_lower_tiles, dim3(nt * (nt + 1) / 2), dim3(256), 0, pb->stream, pb->d_S, pb->ld); }
+    else if (!pb->comps.active) {   // (the group-by-group solve never writes S: blocks that are structurally empty stay zero)
+        const int nt = pb->ld / POTRF_NB; hipLaunchKernelGGL(k_zero_lower_tiles, dim3(nt * (nt + 1) / 2), dim3(256), 0, pb->stream, pb->d_S, pb->ld); }
     if (packed) (void)hipMemsetAsync(pb->d_G, 0, ((size_t)pb->ngblk * cnp * cnp + (size_t)pb->ld) * sizeof(double), pb->stream);
     double* Edst = packed ? pb->d_G + (size_t)pb->ngblk * cnp * cnp : pb->d_E;     // packed: E rides behind the blocks
     if (mm > 0)
@@ -502,6 +523,8 @@ void bsfm_default_options(bsfm_options_t* opt)
     opt->opts[3] = 1.0e-12; opt->opts[4] = 0.0; opt->opts[5] = 4.0e-2;   // sfm.c:705-714
     opt->potrf_backend = 0;
     if (const char* e = getenv("BSFM_POTRF")) if (!strcmp(e, "rocsolver")) opt->potrf_backend = 1;
+    opt->reduced_solver = BSFM_SOLVER_DENSE;
+    if (const char* e = getenv("BSFM_REDUCED_SOLVER")) if (!strcmp(e, "auto")) opt->reduced_solver = BSFM_SOLVER_AUTO;
 }
 
 int bsfm_device_count(void)
@@ -889,7 +912,9 @@ int bsfm_lm_iterate(bsfm_problem_t* pb, int iters)
             ph_end(pb, PH_SCHUR);
             ph_begin(pb, PH_SOLVE);
             // S dpa = E, Cholesky (sba_Axb_Chol, lib/sba-1.5/sba_lapack.c:374-485); info -> d_flags[1]
-            if (potrf_solve(pb->potrf, pb->d_S, pb->ld, pb->Sdim, pb->d_E, d_dpa + (size_t)P.mcon * cnp, pb->d_flags + 1, pb->stream)) return BSFM_ERROR;
+            if (pb->comps.active) {
+                if (comp_solve(pb->comps, pb->potrf, cnp, pb->d_S, pb->ld, pb->d_E, d_dpa + (size_t)P.mcon * cnp, pb->d_flags + 1, pb->stream)) return BSFM_ERROR;
+            } else if (potrf_solve(pb->potrf, pb->d_S, pb->ld, pb->Sdim, pb->d_E, d_dpa + (size_t)P.mcon * cnp, pb->d_flags + 1, pb->stream)) return BSFM_ERROR;
             ph_end(pb, PH_SOLVE);
             if (P.mcon > 0) (void)hipMemsetAsync(d_dpa, 0, (size_t)P.mcon * cnp * sizeof(double), pb->stream);
             ph_begin(pb, PH_BACKSUB);

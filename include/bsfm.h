@@ -65,6 +65,8 @@ enum {
                               which passes projac=NULL, sfm.c:820-828) */
 };
 
+enum { BSFM_SOLVER_DENSE = 0, BSFM_SOLVER_AUTO = 1 };
+
 typedef struct {
     int jacobian;        /* BSFM_JAC_FD (default for run_sfm) or BSFM_JAC_ANALYTIC */
     int itmax;           /* default 150  (MAX_ITERS, sfm.c:814) */
@@ -72,6 +74,10 @@ typedef struct {
     double opts[6];      /* tau, eps1, eps2, eps3, eps4, eps5 (sfm.c:705-714); eps2 is overwritten by the
                             run_sfm argument */
     int potrf_backend;   /* 0 = own MFMA-f64 tiled Cholesky (default), 1 = rocSOLVER cross-check (dlopen) */
+    int reduced_solver;  /* BSFM_SOLVER_DENSE (default): Cholesky of the whole dense S, the reference's algorithm
+                            (sba_Axb_Chol); BSFM_SOLVER_AUTO: when the cameras fall into groups that share no point
+                            (S block diagonal up to a permutation, every group <= 128 unknowns) solve group by group,
+                            otherwise dense.  Same solution up to rounding.  Env: BSFM_REDUCED_SOLVER=auto|dense. */
 } bsfm_options_t;
 
 void bsfm_default_options(bsfm_options_t *opt);

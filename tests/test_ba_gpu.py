@@ -639,3 +639,40 @@ def test_fisheye_projection_matches_reference(gpu_bsfm, und):
     assert np.abs(got["R"] - X[f"u{und}_run_R"]).max() <= 1e-6
     assert np.abs(got["t"] - X[f"u{und}_run_t"]).max() <= 1e-5 * max(1.0, np.abs(X[f"u{und}_run_t"]).max())
     assert np.abs(pts - X[f"u{und}_run_pts"]).max() <= 1e-5 * max(1.0, np.abs(X[f"u{und}_run_pts"]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mcon", [0, 3])
+def test_group_by_group_reduced_solve_matches_dense(gpu_bsfm, mcon):
+    """Opt-in reduced solver (compsolve.hip.h): the SURVEY 8(d) generator makes each point visible in the cameras
+    (j0 + d m/deg) mod m, so the cameras fall into m/deg groups that share no point and S is block diagonal up to a
+    permutation.  Solving group by group must reproduce the dense Cholesky path (same LM trajectory, solution equal to
+    rounding) and the oracle; a connected scene must silently stay on the dense path."""
+    B = gpu_bsfm
+    s = B.synth_ba(40, 400, 4)                       # 10 groups of 4 cameras
+    vm = B.dense_vmask(400, 40, s["rowptr"], s["colidx"])
+    groups = {tuple(sorted(set(s["colidx"][s["rowptr"][i]:s["rowptr"][i + 1]] % 10))) for i in range(400)}
+    assert all(len(g) == 1 for g in groups)          # every point stays inside one residue class mod 10
+    res = {}
+    for mode in (B.SOLVER_DENSE, B.SOLVER_AUTO):
+        opt = B.default_options(jacobian=B.JAC_ANALYTIC, verbose=0, itmax=6, reduced_solver=mode)
+        pb = B.Problem(400, 40, s["rowptr"], s["colidx"], s["proj"], s["cams"], s["pts"], mcon=mcon, options=opt)
+        rc, info = pb.solve()
+        res[mode] = (rc, info.copy(), pb.download(want_cams=False)[0], pb.phase_ms("potrf"))
+        pb.close()
+    (rc0, i0, p0, _), (rc1, i1, p1, _) = res[B.SOLVER_DENSE], res[B.SOLVER_AUTO]
+    assert rc0 == rc1 and list(i0[5:10]) == list(i1[5:10])
+    assert abs(i0[1] - i1[1]) <= 1e-10 * i0[1]
+    assert np.abs(p0 - p1).max() <= 1e-9 * np.abs(p0).max()
+    q = O.port_run_sfm(400, 40, vm, s["proj"], s["cams"], s["pts"], itmax=6, jac_mode=1, ncons=mcon)
+    assert abs(i1[1] - q["info"][1]) <= 1e-9 * q["info"][1] and np.abs(p1 - q["p"]).max() <= 1e-7 * np.abs(q["p"]).max()
+    # connected scene (banded visibility): auto == dense bit for bit, because it IS the dense path
+    c = load_case("band")
+    out = []
+    for mode in (B.SOLVER_DENSE, B.SOLVER_AUTO):
+        opt = B.default_options(jacobian=B.JAC_ANALYTIC, verbose=0, itmax=3, reduced_solver=mode)
+        pb = B.Problem(c["n"], c["m"], c["rowptr"], c["colidx"], c["proj"], c["cams"], c["pts"], est_focal_length=c["est"],
+                       undistort=c["und"], use_constraints=c["cons"], options=opt)
+        pb.solve()
+        out.append(pb.download(want_cams=False)[0]); pb.close()
+    assert np.array_equal(out[0], out[1])
