@@ -65,7 +65,7 @@ SYMBOLS = [
     "bsfm_default_options", "run_sfm", "bsfm_run_sfm_ex", "bsfm_sba_motstr_levmar", "bsfm_sba_mot_levmar", "bsfm_problem_create", "bsfm_problem_destroy",
     "bsfm_problem_set_allreduce", "bsfm_problem_set_stream", "bsfm_problem_reset_params", "bsfm_lm_begin",
     "bsfm_lm_iterate", "bsfm_lm_finish", "bsfm_lm_solve_attempts", "bsfm_lm_last_kernel_ms",
-    "bsfm_problem_download", "bsfm_problem_cnp", "bsfm_problem_nvis", "bsfm_eval_residuals", "bsfm_problem_outlier_stats", "bsfm_problem_ray_angles",
+    "bsfm_problem_download", "bsfm_problem_cnp", "bsfm_problem_nvis", "bsfm_eval_residuals", "bsfm_problem_outlier_stats", "bsfm_problem_ray_angles", "bsfm_triangulate_batch",
     "bsfm_eval_normal_equations", "bsfm_dense_chol_solve", "bsfm_match_keys_l2", "bsfm_key_match_full",
     "bsfm_key_match_full_sharded", "bsfm_merge_match_files",
     "bsfm_device_count", "bsfm_version", "bsfm_device_synchronize", "bsfm_synth_ba", "bsfm_synth_keys",
@@ -120,6 +120,9 @@ def _load():
     lib.bsfm_problem_outlier_stats.restype = C.c_int
     lib.bsfm_problem_ray_angles.argtypes = [vp, C.c_double, dp, C.POINTER(C.c_ubyte), C.POINTER(C.c_int)]
     lib.bsfm_problem_ray_angles.restype = C.c_int
+    lib.bsfm_triangulate_batch.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), dp, C.POINTER(C.c_int), C.c_int, dp, dp, dp, dp,
+                                           C.POINTER(C.c_int)]
+    lib.bsfm_triangulate_batch.restype = C.c_int
     lib.bsfm_eval_normal_equations.argtypes = [vp, C.c_double, dp, dp, dp, dp, dp, dp, dp]
     lib.bsfm_eval_normal_equations.restype = C.c_int
     lib.bsfm_dense_chol_solve.argtypes = [C.c_int, dp, dp, dp, C.c_int]

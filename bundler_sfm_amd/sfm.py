@@ -80,6 +80,25 @@ def run_sfm(num_pts, num_cameras, ncons, vmask, projections, est_focal_length, c
     return rc, info
 
 
+TRI_N, TRI_N_REFINE, TRI_PAIR = 0, 1, 2
+
+
+def triangulate_batch(mode, view_ptr, p, R, t, X=None, view_cam=None):
+    """Batched triangulate_n / triangulate_n_refine / triangulate (lib/imagelib/triangulate.c) on the GPU.
+    view_ptr (npoints+1), p (2 per view), R / t per view (view_cam None) or per camera.  Returns (X, error, info)."""
+    view_ptr = np.ascontiguousarray(view_ptr, np.int32)
+    npts = len(view_ptr) - 1
+    p = np.ascontiguousarray(p, np.float64); R = np.ascontiguousarray(R, np.float64); t = np.ascontiguousarray(t, np.float64)
+    X = np.zeros(3 * npts) if X is None else np.array(X, np.float64, copy=True).ravel()
+    err = np.zeros(npts); info = np.zeros(npts, np.int32)
+    cam = None if view_cam is None else np.ascontiguousarray(view_cam, np.int32)
+    rc = lib.bsfm_triangulate_batch(mode, npts, _ip(view_ptr), _dp(p), _ip(cam), 0 if cam is None else R.size // 9,
+                                    _dp(R), _dp(t), _dp(X), _dp(err), _ip(info))
+    if rc != 0:
+        raise RuntimeError("bsfm_triangulate_batch failed")
+    return X, err, info
+
+
 class Problem:
     """Device-resident BA problem (sparse CRS boundary)."""
 

@@ -227,6 +227,22 @@ int bsfm_eval_normal_equations(bsfm_problem_t *pb, double mu, double *U, double 
  * b (n) -> x (n). Returns 0, or k>0 if the leading minor k is not positive definite (dpotrf's info). */
 int bsfm_dense_chol_solve(int n, const double *A, const double *b, double *x, int backend);
 
+/* ---- 3b. batched multi-view triangulation -------------------------------------------- */
+/* npoints independent points; point i owns views view_ptr[i] .. view_ptr[i+1]-1.  View v observes the normalised image
+ * point p[2v], p[2v+1] in the camera with rotation R (9, row-major) and translation t (3): x = (R X + t).xy / (R X + t).z.
+ * view_cam == NULL: R / t hold one entry per VIEW (the argument layout of triangulate_n, lib/imagelib/triangulate.h:38-43);
+ * otherwise view_cam[v] indexes R / t of ncams cameras.  Modes:
+ *   BSFM_TRI_N         triangulate_n         lib/imagelib/triangulate.c:181-272  linear least squares + lmdif polish (tol 1e-5)
+ *   BSFM_TRI_N_REFINE  triangulate_n_refine  lib/imagelib/triangulate.c:133-178  lmdif polish of the point passed in X
+ *   BSFM_TRI_PAIR      triangulate           lib/imagelib/triangulate.c:281-338  exactly two views, tol 1e-10
+ * X (3*npoints, in/out), error (npoints or NULL: rms reprojection error; BSFM_TRI_PAIR: sum of squares),
+ * info (npoints or NULL: MINPACK's lmdif1 code).  Host pointers.  Returns 0 or BSFM_ERROR (nothing written). */
+#define BSFM_TRI_N 0
+#define BSFM_TRI_N_REFINE 1
+#define BSFM_TRI_PAIR 2
+int bsfm_triangulate_batch(int mode, int npoints, const int *view_ptr, const double *p, const int *view_cam, int ncams,
+                           const double *R, const double *t, double *X, double *error, int *info);
+
 /* ---- 4. matcher ------------------------------------------------------------------------------------- */
 /* Exact 2-NN ratio test between two descriptor sets (128-D uchar, squared L2 in int32):
  * keeps (i, nn0) iff (double)d0 < ratio*ratio*(double)d1 (src/keys2a.cpp:362). out_pairs gets up to

@@ -13,6 +13,8 @@
  *                      itmax == 0 runs the reference's own Jacobian checker on it
  *                      (lib/sba-1.5/sba_levmar.c:769-773).
  *   ref_set_fisheye    switch ref_sba_motstr to the fisheye projection callback (sfm.c:448-492).
+ *   ref_triangulate    the reference's triangulate_n / triangulate_n_refine / triangulate
+ *                      (lib/imagelib/triangulate.c:181-272, 133-178, 281-338), one point per call.
  *   ref_sizeof_camera_params   layout check for the ctypes mirror of camera_params_t (sfm.h:32-51).
  */
 #include "sfm.c"          /* resolved through -I$(REF)/lib/sfm-driver */
@@ -247,4 +249,18 @@ void ref_project_point(int est_focal, int undistort, int explicit_centers, camer
     sfm_project_point3(0, 0, aj, bi, xij, &globs);
     global_last_ws = global_last_Rs = NULL;
     cam->f_scale = fs; cam->k_scale = ks;
+}
+
+/* ---- multi-view triangulation ---------------------------------------------------------------------- */
+#include "triangulate.h"
+
+/* mode 0 = triangulate_n, 1 = triangulate_n_refine (X holds the start), 2 = triangulate (two views; error = sum of squares).
+ * p: 2*nviews, R: 9*nviews, t: 3*nviews; X: 3 (in/out); err: 1. */
+void ref_triangulate(int mode, int nviews, double *p, double *R, double *t, double *X, double *err)
+{
+    v3_t r;
+    if (mode == 0) r = triangulate_n(nviews, (v2_t *) p, R, t, err);
+    else if (mode == 1) r = triangulate_n_refine(v3_new(X[0], X[1], X[2]), nviews, (v2_t *) p, R, t, err);
+    else r = triangulate(v2_new(p[0], p[1]), v2_new(p[2], p[3]), R, t, R + 9, t + 3, err);
+    X[0] = Vx(r); X[1] = Vy(r); X[2] = Vz(r);
 }

@@ -182,6 +182,46 @@ def fisheye():
     print("fisheye_golden:", len(out), "arrays")
 
 
+def triangulation():
+    """the reference's triangulate_n / triangulate_n_refine / triangulate (lib/imagelib/triangulate.c) on a
+    ragged batch of points seen by 2..12 of 40 ring cameras, normalised observations with noise; a few points are far away
+    (small parallax).  One call of the reference per point."""
+    rng = np.random.default_rng(11)
+    s = B.synth_ba(40, 400, 4)
+    ca = O.cams_to_arrays(s["cams"])
+    Rc = ca["R"].reshape(-1, 3, 3); tc = np.einsum("mij,mj->mi", Rc, -ca["t"])          # t = -R c
+    npts = 300
+    Xtrue = rng.uniform(-1, 1, (npts, 3))
+    Xtrue[::17] *= 40.0                                                                  # distant points
+    deg = rng.integers(2, 13, npts)
+    view_ptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    view_cam = np.concatenate([np.sort(rng.choice(40, d, replace=False)) for d in deg]).astype(np.int32)
+    P = np.einsum("vij,vj->vi", Rc[view_cam], np.repeat(Xtrue, deg, axis=0)) + tc[view_cam]
+    p = P[:, :2] / P[:, 2:3] + rng.normal(0, 5e-4, (len(view_cam), 2))
+    out = dict(view_ptr=view_ptr, view_cam=view_cam, p=p.ravel(), R=ca["R"].ravel(), t=tc.ravel())
+    X0 = Xtrue + rng.normal(0, 0.02, Xtrue.shape)
+    out["X0"] = X0.ravel()
+    for mode, tag in ((0, "n"), (1, "refine")):
+        Xs, es = [], []
+        for i in range(npts):
+            v = slice(view_ptr[i], view_ptr[i + 1])
+            X, e = O.ref_triangulate(mode, p[v], ca["R"][view_cam[v]], tc[view_cam[v]], X0[i])
+            Xs.append(X); es.append(e)
+        out[f"{tag}_X"] = np.array(Xs).ravel(); out[f"{tag}_err"] = np.array(es)
+    # two-view variant: the first two views of every point
+    vp2 = (2 * np.arange(npts + 1)).astype(np.int32)
+    sel = np.concatenate([[view_ptr[i], view_ptr[i] + 1] for i in range(npts)])
+    Xs, es = [], []
+    for i in range(npts):
+        v = sel[2 * i:2 * i + 2]
+        X, e = O.ref_triangulate(2, p[v], ca["R"][view_cam[v]], tc[view_cam[v]])
+        Xs.append(X); es.append(e)
+    out["pair_sel"] = sel.astype(np.int32); out["pair_ptr"] = vp2
+    out["pair_X"] = np.array(Xs).ravel(); out["pair_err"] = np.array(es)
+    np.savez_compressed(os.path.join(HERE, "triangulate_golden.npz"), **out)
+    print("triangulate_golden:", npts, "points,", len(view_cam), "views; rms err median", np.median(out["n_err"]))
+
+
 def parse_bundle(path):
     toks = open(path).read().split("\n")
     assert toks[0].startswith("# Bundle file v0.3")
@@ -298,6 +338,6 @@ def model():
 if __name__ == "__main__":
     assert O.have_ref(), "build oracle/_ref first (make -C oracle ref)"
     only = sys.argv[1:]
-    for fn in (ba_cases, kermit, matcher, model, exports, mot, known_intrinsics, fisheye):
+    for fn in (ba_cases, kermit, matcher, model, exports, mot, known_intrinsics, fisheye, triangulation):
         if not only or fn.__name__ in only:
             fn()

@@ -303,3 +303,15 @@ def port_match(k1, k2, ratio=0.6):
     cnt = port().oracle_match_keys(len(k1), k1.ctypes.data_as(u), len(k2), k2.ctypes.data_as(u), ratio,
                                    out.ctypes.data_as(C.POINTER(C.c_int)), len(k1))
     return out[:cnt].copy()
+
+
+def ref_triangulate(mode, p, R, t, X0=None):
+    """The reference's triangulate_n (mode 0) / triangulate_n_refine (1) / triangulate (2) on ONE point
+    (lib/imagelib/triangulate.c).  p: (nviews, 2), R: (nviews, 9), t: (nviews, 3).  Returns (X, err)."""
+    p = np.ascontiguousarray(p, np.float64).copy(); R = np.ascontiguousarray(R, np.float64).copy()
+    t = np.ascontiguousarray(t, np.float64).copy()
+    X = np.zeros(3) if X0 is None else np.array(X0, np.float64, copy=True)
+    err = np.zeros(1)
+    with quiet_stdout():
+        ref().ref_triangulate(int(mode), len(p), _d(p), _d(R), _d(t), _d(X), _d(err))
+    return X, err[0]
