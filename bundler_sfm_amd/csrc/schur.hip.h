@@ -18,6 +18,11 @@
 // (Tried and dropped: dealing whole block rows S_j* to one XCD each (workgroups with blockIdx % 8 == x) so that camera j's
 // records stay in that XCD's L2 across the row's blocks: 2.03 ms either way -- an XCD runs ~6 rows at a time, 12 MB of
 // records against 4 MB of L2.  Also: fetching the record of a diagonal block only once: no gain.)
+// Launch order (solver.hip:build_schur_structure): the counters showed 10.6 GB fetched past L2 per launch for 12 GB of gathers
+// (profiles/r01_cfg3_fd_v6_pmc_traffic.json) -- in block order the ~11 tasks that read one record run far apart and on
+// different XCDs.  Tasks are therefore launched sorted by the first point they touch (tasks over the same points become
+// neighbours) and each XCD (blockIdx % 8) is handed one contiguous stretch of that order, so a record is fetched into ONE L2
+// and found there by the other tasks that need it.  Output slots stay in block order: sums are bit-identical.
 // NOTE (gfx950 / hipcc 7.2): the prefetch registers are arrays of plain double -- arrays of the double2 vector
 // struct are not promoted to registers and end up in scratch, which serialises the whole pipeline.
 #pragma once
@@ -45,6 +50,7 @@ __global__ __launch_bounds__(256) void k_schur_tasks_v2(DevProblem P, const Schu
     const int task = blockIdx.x * 4 + wave;
     if (task >= ntasks) return;
     const SchurTask tk = tasks[task];
+    if (tk.out < 0) return;
     double* recA = sm[wave];
     double* recB = recA + SCH_PASS * RS;
     double* vin = recB + SCH_PASS * RS;
@@ -165,14 +171,14 @@ __global__ __launch_bounds__(256) void k_schur_tasks_v2(DevProblem P, const Schu
         }
     }
     if (grp == 0) {
-        double* out = partials + (size_t)task * CNP * CNP;
+        double* out = partials + (size_t)tk.out * CNP * CNP;
 #pragma unroll
         for (int a = 0; a < NR; ++a) {
             const int row = r + 3 * a;
             if (row < CNP) {
 #pragma unroll
                 for (int c = 0; c < CNP; ++c) out[row * CNP + c] = acc[a][c];
-                if (diag) epart[(size_t)task * CNP + row] = acce[a];
+                if (diag) epart[(size_t)tk.out * CNP + row] = acce[a];
             }
         }
     }

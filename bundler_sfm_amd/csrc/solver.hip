@@ -92,6 +92,7 @@ struct bsfm_problem {
     // schur structure
     int ntriples = 0, ntasks = 0, nblk = 0;
     int2* d_triples = nullptr; SchurTask* d_tasks = nullptr; int* d_tri_pt = nullptr;
+    int nslots = 0;                     // entries of d_tasks (launch order, padded to whole workgroups)
     int *d_blk_j = nullptr, *d_blk_k = nullptr, *d_blk_task0 = nullptr;
     // multi-GPU exchange of the reduced camera system: the UNION over ranks of the non-empty blocks S_jk (j <= k),
     // one cnp x cnp sum per block, is what crosses xGMI -- not the dense (9m)^2 matrix
@@ -197,10 +198,11 @@ int build_schur_structure(bsfm_problem* pb, const bsfm_problem_desc_t* d, const 
     for (int b = 0; b < nblk; ++b) {
         blk_task0[b] = (int)tasks.size();
         for (int s = blk_start[b]; s < blk_start[b + 1]; s += SCHUR_CHUNK)
-            tasks.push_back({ s, std::min(SCHUR_CHUNK, blk_start[b + 1] - s), blk_j[b] == blk_k[b] ? 1 : 0 });
+            tasks.push_back({ s, std::min(SCHUR_CHUNK, blk_start[b + 1] - s), blk_j[b] == blk_k[b] ? 1 : 0, (int)tasks.size() });
     }
     blk_task0[nblk] = (int)tasks.size();
     pb->ntriples = (int)total; pb->ntasks = (int)tasks.size(); pb->nblk = nblk;
+    pb->nslots = pb->ntasks;
     pb->h_blk_j = blk_j; pb->h_blk_k = blk_k;
     if (pb->world == 1 && setup_components(pb, blk_j, blk_k)) return BSFM_ERROR;   // world > 1: after the block-union exchange
     HIP_OK(dmalloc(&pb->d_triples, total)); HIP_OK(dmalloc(&pb->d_tasks, tasks.size()));
@@ -214,7 +216,31 @@ int build_schur_structure(bsfm_problem* pb, const bsfm_problem_desc_t* d, const 
         HIP_OK(dmalloc(&pb->d_tri_pt, total));
         if (total) HIP_OK(hipMemcpy(pb->d_tri_pt, tri_pt.data(), total * sizeof(int), hipMemcpyHostToDevice));
     }
-    if (!tasks.empty()) HIP_OK(hipMemcpy(pb->d_tasks, tasks.data(), tasks.size() * sizeof(SchurTask), hipMemcpyHostToDevice));
+    if (!tasks.empty()) {
+        // Launch order (schur.hip.h): sort by the first point a task touches, then give every XCD (workgroup index % 8, four
+        // tasks per workgroup) one contiguous stretch of that order.  BSFM_SCHUR_ORDER=block keeps the block order.
+        const char* eo = getenv("BSFM_SCHUR_ORDER");
+        std::vector<SchurTask> launch;
+        if (eo && !strcmp(eo, "block")) launch = tasks;
+        else {
+            std::vector<int> ord(tasks.size());
+            for (size_t q = 0; q < ord.size(); ++q) ord[q] = (int)q;
+            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return cam_pt[triples[tasks[a].start].x] < cam_pt[triples[tasks[b].start].x]; });
+            const int nwg = ((int)tasks.size() + 3) / 4, nx = 8;
+            launch.assign((size_t)nwg * 4, SchurTask{ 0, 0, 0, -1 });
+            int next = 0;                                   // next workgroup-sized piece of the sorted order
+            for (int x = 0; x < nx; ++x)
+                for (int wg = x; wg < nwg; wg += nx, ++next)
+                    for (int w = 0; w < 4; ++w) {
+                        const size_t src = (size_t)next * 4 + w;
+                        if (src < ord.size()) launch[(size_t)wg * 4 + w] = tasks[ord[src]];
+                    }
+        }
+        pb->nslots = (int)launch.size();
+        (void)hipFree(pb->d_tasks); pb->d_tasks = nullptr;
+        HIP_OK(dmalloc(&pb->d_tasks, launch.size()));
+        HIP_OK(hipMemcpy(pb->d_tasks, launch.data(), launch.size() * sizeof(SchurTask), hipMemcpyHostToDevice));
+    }
     if (nblk) {
         HIP_OK(hipMemcpy(pb->d_blk_j, blk_j.data(), nblk * sizeof(int), hipMemcpyHostToDevice));
         HIP_OK(hipMemcpy(pb->d_blk_k, blk_k.data(), nblk * sizeof(int), hipMemcpyHostToDevice));
@@ -474,8 +500,8 @@ int compute_schur(bsfm_problem* pb, double mu)
         hipLaunchKernelGGL(k_rhs_init, dim3(grid_for((size_t)mm * cnp, 256)), dim3(256), 0, pb->stream, mm * cnp, P.mcon * cnp,
                            lead, pb->d_ea, Edst);
     if (pb->ntasks > 0) {
-        DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks_v2<C>), dim3((pb->ntasks + 3) / 4), dim3(256), 0, pb->stream,
-                                              P, pb->d_tasks, pb->ntasks, pb->d_triples, pb->d_tri_pt, pb->d_partials, pb->d_epart));
+        DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks_v2<C>), dim3((pb->nslots + 3) / 4), dim3(256), 0, pb->stream,
+                                              P, pb->d_tasks, pb->nslots, pb->d_triples, pb->d_tri_pt, pb->d_partials, pb->d_epart));
         if (packed) {
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_pack<C>), dim3(pb->nblk), dim3(128), 0, pb->stream, pb->nblk,
                                                   pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0, pb->d_partials, pb->d_epart,
