@@ -34,7 +34,7 @@ constexpr int SCH_PASS = 21;          // triples in flight per wave (3 lanes eac
 constexpr int SCH_MAXT = 168;         // triples per task (SCHUR_CHUNK in solver.hip)
 
 template <int CNP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_schur_tasks_v2(DevProblem P, const SchurTask* __restrict__ tasks, int ntasks,
+__global__ __launch_bounds__(256) void k_schur_tasks_v2(DevProblem P, const SchurTask* __restrict__ tasks, int ntasks,
         const int2* __restrict__ triples, const int* __restrict__ tri_pt, double* __restrict__ partials,
         double* __restrict__ epart)
 {
