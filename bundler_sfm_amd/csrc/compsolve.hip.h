@@ -127,6 +127,7 @@ inline int comp_solve(const CompSolver& cs, PotrfWorkspace& w, int cnp, const do
                       int* d_info, hipStream_t st)
 {
     if (w.ev0) (void)hipEventRecord(w.ev0, st);
+    (void)hipGetLastError();                          // drop stale state (e.g. hipErrorNotReady of an earlier event query)
     hipLaunchKernelGGL(k_comp_solve, dim3(cs.ncomp), dim3(256), cs.lds, st, cnp, cs.maxdim, cs.stride, cs.d_ptr, cs.d_cams,
                        S, ld, E, x_out, d_info);
     if (w.ev1) (void)hipEventRecord(w.ev1, st);
