@@ -4,6 +4,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -50,6 +51,9 @@ def test_no_gpu_fails_loudly(bsfm, capfd):
     assert "no usable HIP device" in capfd.readouterr().err
     rc, _ = bsfm.dense_chol_solve(np.eye(4), np.ones(4))
     assert rc == -1
+    with pytest.raises(RuntimeError):             # batched triangulation: same rule
+        bsfm.triangulate_batch(bsfm.TRI_N, np.array([0, 2], np.int32), np.zeros(4), np.tile(np.eye(3).ravel(), 2), np.zeros(6))
+    assert "no usable HIP device" in capfd.readouterr().err
 
 
 def test_synth_scene_is_deterministic_and_sorted(bsfm):
