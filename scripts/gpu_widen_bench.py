@@ -1,0 +1,66 @@
+"""Timings of the SURVEY 8(f) rows at the benchmark size (1 000 cameras / 500 000 points / 5 000 000 observations), next
+to the reference on this host where the reference has the function: post-solve outlier statistics, ray-angle pruning,
+camera-only refinement (fix_points), batched triangulation.  Usage: python scripts/gpu_widen_bench.py [cams points deg]"""
+import sys, time, numpy as np
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import bundler_sfm_amd as B
+import oracle_util as O
+
+m, n, deg = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (1000, 500000, 10)
+s = B.synth_ba(m, n, deg)
+nvis = int(s["rowptr"][-1])
+sync = B.lib.bsfm_device_synchronize
+
+
+def timed(f, reps=5):
+    f(); sync()
+    t = time.perf_counter()
+    for _ in range(reps):
+        f()
+    sync()
+    return (time.perf_counter() - t) / reps
+
+
+opt = B.default_options(verbose=0, itmax=3)
+pb = B.Problem(n, m, s["rowptr"], s["colidx"], s["proj"], s["cams"], s["pts"], options=opt)
+pb.solve()
+t_out = timed(lambda: pb.outlier_stats(8.0, 16.0))
+t_ray = timed(lambda: pb.ray_angles(2.0))
+print(f"outlier statistics (RunSFM_SBA, Bundle.cpp:659-913): {1e3 * t_out:.2f} ms for {nvis} observations incl. download of "
+      f"{m} camera rows + {n} point flags = {nvis / t_out / 1e9:.2f} G obs/s")
+print(f"ray-angle pruning (RemoveBadPointsAndCameras, Bundle.cpp:4190-4261): {1e3 * t_ray:.2f} ms for {n} points / "
+      f"{n * deg * (deg - 1) // 2} ray pairs")
+pb.close()
+
+# camera-only refinement (sba_mot_levmar): per-iteration time through the resident API
+opt = B.default_options(verbose=0, itmax=1000, opts=[1e-3, 0.0, 0.0, 0.0, 0.0, -1.0])
+pb = B.Problem(n, m, s["rowptr"], s["colidx"], s["proj"], s["cams"], s["pts"], options=opt, fix_points=1)
+pb.lm_begin(); pb.lm_iterate(2); sync()
+t = time.perf_counter(); pb.lm_iterate(10); sync(); t_mot = (time.perf_counter() - t) / 10
+print(f"camera-only LM iteration (fix_points, sba_mot_levmar): {1e3 * t_mot:.3f} ms")
+pb.close()
+
+# triangulation: every point of the scene from its observations (normalised by the true intrinsics, noise kept)
+ca = O.cams_to_arrays(s["cams"])
+Rc = ca["R"].reshape(-1, 3, 3); tc = np.einsum("mij,mj->mi", Rc, -ca["t"])
+cam = s["colidx"]
+pts = s["pts"].reshape(-1, 3)
+P = np.einsum("vij,vj->vi", Rc[cam], np.repeat(pts, np.diff(s["rowptr"]), axis=0)) + tc[cam]
+p = P[:, :2] / P[:, 2:3] + np.random.default_rng(1).normal(0, 5e-4, (nvis, 2))
+args = (B.TRI_N, s["rowptr"], p.ravel(), ca["R"].ravel(), tc.ravel())
+B.triangulate_batch(*args, view_cam=cam)
+t = time.perf_counter(); X, err, info = B.triangulate_batch(*args, view_cam=cam); t_tri = time.perf_counter() - t
+print(f"triangulate_n batch: {n} points x {deg} views in {1e3 * t_tri:.1f} ms incl. upload/download = {n / t_tri / 1e6:.2f} M points/s; "
+      f"median rms error {np.median(err):.2e}; lmdif codes {np.bincount(info)}")
+if O.have_ref():
+    k = 2000
+    t = time.perf_counter()
+    for i in range(k):
+        v = slice(s["rowptr"][i], s["rowptr"][i + 1])
+        O.ref_triangulate(0, p[v], ca["R"][cam[v]], tc[cam[v]])
+    t_ref = (time.perf_counter() - t) / k
+    print(f"reference triangulate_n on this host (through ctypes): {1e6 * t_ref:.1f} us per point = {1 / t_ref / 1e6:.4f} M points/s")
+    small = B.synth_ba(200, 50000, 10)
+    vm = B.dense_vmask(50000, 200, small["rowptr"], small["colidx"])
+    r = O.ref_sba_mot(50000, 200, vm, small["proj"], small["cams"], small["pts"], itmax=3, jac_mode=0)
+    print(f"reference sba_mot_levmar, 200 cams / 50 000 pts / 500 000 obs: {1e3 * r['secs'] / max(r['info'][5], 1):.0f} ms per iteration")
