@@ -741,6 +741,7 @@ double bsfm_lm_last_kernel_ms(const bsfm_problem_t* pb, const char* phase)
 {
     for (int i = 0; i < PH_COUNT; ++i)
         if (!strcmp(phase, kPhaseNames[i])) return pb->ph_cnt[i] ? pb->ph_ms[i] / pb->ph_cnt[i] : -1.0;
+    if (!strcmp(phase, "groups")) return pb->comps.active ? (double)pb->comps.ncomp : 0.0;   // group-by-group reduced solve in use?
     if (!strcmp(phase, "potrf")) return pb->potrf.cnt ? pb->potrf.ms / pb->potrf.cnt : -1.0;
     if (!strcmp(phase, "syrk")) return pb->potrf.syrk_cnt ? pb->potrf.syrk_ms / (double)pb->potrf.syrk_cnt : -1.0;
     if (!strcmp(phase, "syrk_gflop")) return pb->potrf.syrk_cnt ? pb->potrf.syrk_flops * 1e-9 / (double)pb->potrf.syrk_cnt : -1.0;

@@ -190,7 +190,8 @@ int bsfm_lm_begin(bsfm_problem_t *pb);
 int bsfm_lm_iterate(bsfm_problem_t *pb, int iters);
 int bsfm_lm_finish(bsfm_problem_t *pb, double info[BSFM_INFOSZ]);
 int bsfm_lm_solve_attempts(const bsfm_problem_t *pb);   /* linear systems solved so far (info[9]) */
-double bsfm_lm_last_kernel_ms(const bsfm_problem_t *pb, const char *phase); /* HIP-event time of a phase in the last iteration */
+double bsfm_lm_last_kernel_ms(const bsfm_problem_t *pb, const char *phase); /* HIP-event time of a phase in the last iteration;
+                                                    "groups": camera groups solved separately (0 = dense reduced solve) */
 
 /* Download results: packed parameter vector p (m*cnp + 3n, reference layout sfm.c:652-703), and/or
  * updated cameras (R <- dR(w) R, t <- c, f, k as sfm.c:876-922) and points. Any pointer may be NULL. */

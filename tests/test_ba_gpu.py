@@ -658,9 +658,10 @@ def test_group_by_group_reduced_solve_matches_dense(gpu_bsfm, mcon):
         opt = B.default_options(jacobian=B.JAC_ANALYTIC, verbose=0, itmax=6, reduced_solver=mode)
         pb = B.Problem(400, 40, s["rowptr"], s["colidx"], s["proj"], s["cams"], s["pts"], mcon=mcon, options=opt)
         rc, info = pb.solve()
-        res[mode] = (rc, info.copy(), pb.download(want_cams=False)[0], pb.phase_ms("potrf"))
+        res[mode] = (rc, info.copy(), pb.download(want_cams=False)[0], pb.phase_ms("groups"))
         pb.close()
-    (rc0, i0, p0, _), (rc1, i1, p1, _) = res[B.SOLVER_DENSE], res[B.SOLVER_AUTO]
+    (rc0, i0, p0, g0), (rc1, i1, p1, g1) = res[B.SOLVER_DENSE], res[B.SOLVER_AUTO]
+    assert g0 == 0 and g1 == 10                      # 10 groups of 4 (mcon = 3: three of them lose their fixed camera)
     assert rc0 == rc1 and list(i0[5:10]) == list(i1[5:10])
     assert abs(i0[1] - i1[1]) <= 1e-10 * i0[1]
     assert np.abs(p0 - p1).max() <= 1e-9 * np.abs(p0).max()
@@ -674,5 +675,6 @@ def test_group_by_group_reduced_solve_matches_dense(gpu_bsfm, mcon):
         pb = B.Problem(c["n"], c["m"], c["rowptr"], c["colidx"], c["proj"], c["cams"], c["pts"], est_focal_length=c["est"],
                        undistort=c["und"], use_constraints=c["cons"], options=opt)
         pb.solve()
+        assert pb.phase_ms("groups") == 0
         out.append(pb.download(want_cams=False)[0]); pb.close()
     assert np.array_equal(out[0], out[1])

@@ -26,7 +26,7 @@ def _free_port():
 
 
 def _scene(B):
-    m, n = 14, 700
+    m, n = 15, 700                                    # deg 5: cameras j0 + 3 d -> three groups (mod 3) that share no point
     s = B.synth_ba(m, n, 5)
     keep = np.ones(len(s["colidx"]), bool)
     keep[np.arange(0, len(keep), 9)] = False          # ragged shards
@@ -51,6 +51,7 @@ def _solve(B, sc, lo, hi, world, rank, hook=None, jac=None):
     pb.lm_iterate(ITERS)
     rc, info = pb.lm_finish()
     p = pb.download(want_cams=False)[0]
+    info = np.append(info, pb.phase_ms("groups"))           # number of independent camera groups solved separately (0 = dense)
     pb.close()
     return p, info
 
@@ -82,11 +83,16 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_match_single_rank(tmp_path):
+@pytest.mark.parametrize("solver", ["dense", "auto"])
+def test_two_ranks_one_gpu_match_single_rank(tmp_path, monkeypatch, solver):
+    """solver = auto: the scene's cameras fall into three groups (camera index mod 3), found on every rank from the job-wide block
+    union after the first exchange and then solved group by group (compsolve.hip.h)."""
     import torch
     import torch.multiprocessing as mp
     import bundler_sfm_amd as B
+    monkeypatch.setenv("BSFM_REDUCED_SOLVER", solver)          # read by bsfm_default_options, inherited by the workers
     sc = _scene(B)
+    assert all(len(set(sc["colidx"][sc["rowptr"][i]:sc["rowptr"][i + 1]] % 3)) == 1 for i in range(sc["n"]))
     p1, info1 = _solve(B, sc, 0, sc["n"], 1, 0)
     assert info1[1] < 0.05 * info1[0]                      # the LM run actually converged somewhere
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
@@ -96,6 +102,7 @@ def test_two_ranks_one_gpu_match_single_rank(tmp_path):
         # every rank ends with the same cameras (replicated) and the global cost
         assert abs(r[k]["info"][1] - info1[1]) <= 1e-9 * info1[1]
         assert r[k]["info"][5] == info1[5]
+        assert r[k]["info"][-1] == (3 if solver == "auto" else 0) and info1[-1] == r[k]["info"][-1]
         cam = r[k]["p"][:9 * m]
         assert np.abs(cam - p1[:9 * m]).max() <= 1e-8 * np.abs(p1[:9 * m]).max()
         lo, hi = int(r[k]["lo"]), int(r[k]["hi"])
