@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--jacobian", choices=["fd", "analytic"], default="fd",
                     help="fd = the reference's forward differences (run_sfm default), analytic = closed form")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reduced-solver", choices=["dense", "auto"], default="dense",
+                    help="dense (default, the reference's algorithm: Cholesky of the whole reduced camera system) or auto "
+                         "(independent camera groups solved separately when the scene has them)")
     ap.add_argument("--no-structure-aware", action="store_true", help="skip the extra (non-headline) run with the opt-in group-by-group reduced solve")
     ap.add_argument("--cpu-sample", default="200,50000", help="cams,points of the bounded CPU-reference sample")
     return ap.parse_args()
@@ -157,7 +160,8 @@ def main():
     pts = s["pts"][3 * lo:3 * hi]
     opt = B.default_options(jacobian=B.JAC_FD if args.jacobian == "fd" else B.JAC_ANALYTIC, verbose=0,
                             itmax=args.warmup + args.steps + 1000,
-                            opts=[1e-3, 0.0, 0.0, 0.0, 0.0, -1.0])
+                            opts=[1e-3, 0.0, 0.0, 0.0, 0.0, -1.0],
+                            reduced_solver=B.SOLVER_AUTO if args.reduced_solver == "auto" else B.SOLVER_DENSE)
     t_create = time.time()
     pb = B.Problem(hi - lo, m, rp, ci, pr, s["cams"], pts, options=opt, world_size=world, rank=rank,
                    nvis_global=nvis_global, nvars_global=m * cnp + 3 * n)
@@ -240,6 +244,7 @@ def main():
             "config": {"workload": f"synthetic BA {m} cams / {n} pts / {nvis_global} obs (BASELINE.json configs[2]), "
                                    f"cnp=9, {args.jacobian} Jacobian, point-sharded x{world}",
                        "cameras": m, "points": n, "observations": nvis_global, "jacobian": args.jacobian,
+                       "reduced_solver": args.reduced_solver,
                        "solve_attempts_per_step": round(att / max(done, 1), 3), "problem_create_s": round(t_create, 2)},
             "phases_ms": phases, "hbm_kernels": hbm, "final_cost": info[1], "initial_cost": info[0],
             "roofline": roof,
@@ -251,7 +256,7 @@ def main():
                 out["cpu_baseline"] = {"error": repr(exc)}
         else:
             out["cpu_baseline"] = None
-        if world == 1 and not args.no_structure_aware:
+        if world == 1 and not args.no_structure_aware and args.reduced_solver == "dense":
             # NOT the headline: the same problem with the opt-in group-by-group reduced solve (compsolve.hip.h).  This
             # generator's cameras fall into m/deg groups that share no point, so S is block diagonal up to a permutation;
             # `value` above is measured with the reference's algorithm (dense Cholesky of the whole S).
