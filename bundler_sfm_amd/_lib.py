@@ -31,6 +31,11 @@ class Options(C.Structure):
                 ("opts", C.c_double * 6), ("potrf_backend", C.c_int), ("reduced_solver", C.c_int)]
 
 
+class RandState(C.Structure):
+    """bsfm_rand_t: glibc random() TYPE_3 state."""
+    _fields_ = [("s", C.c_uint * 31), ("fi", C.c_int), ("ri", C.c_int)]
+
+
 class ProblemDesc(C.Structure):
     _fields_ = [
         ("n", C.c_int), ("m", C.c_int), ("mcon", C.c_int),
@@ -65,7 +70,8 @@ SYMBOLS = [
     "bsfm_default_options", "run_sfm", "bsfm_run_sfm_ex", "bsfm_sba_motstr_levmar", "bsfm_sba_mot_levmar", "bsfm_problem_create", "bsfm_problem_destroy",
     "bsfm_problem_set_allreduce", "bsfm_problem_set_stream", "bsfm_problem_reset_params", "bsfm_lm_begin",
     "bsfm_lm_iterate", "bsfm_lm_finish", "bsfm_lm_solve_attempts", "bsfm_lm_last_kernel_ms",
-    "bsfm_problem_download", "bsfm_problem_cnp", "bsfm_problem_nvis", "bsfm_eval_residuals", "bsfm_problem_outlier_stats", "bsfm_problem_ray_angles", "bsfm_triangulate_batch",
+    "bsfm_problem_download", "bsfm_problem_cnp", "bsfm_problem_nvis", "bsfm_eval_residuals", "bsfm_problem_outlier_stats", "bsfm_problem_ray_angles", "bsfm_triangulate_batch", "bsfm_rand_seed", "bsfm_rand_next", "bsfm_fmatrix_ransac_batch",
+    "bsfm_estimate_fmatrix_batch",
     "bsfm_eval_normal_equations", "bsfm_dense_chol_solve", "bsfm_match_keys_l2", "bsfm_key_match_full",
     "bsfm_key_match_full_sharded", "bsfm_merge_match_files",
     "bsfm_device_count", "bsfm_version", "bsfm_device_synchronize", "bsfm_synth_ba", "bsfm_synth_keys",
@@ -123,6 +129,16 @@ def _load():
     lib.bsfm_triangulate_batch.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), dp, C.POINTER(C.c_int), C.c_int, dp, dp, dp, dp,
                                            C.POINTER(C.c_int)]
     lib.bsfm_triangulate_batch.restype = C.c_int
+    lib.bsfm_rand_seed.argtypes = [C.POINTER(RandState), C.c_uint]
+    lib.bsfm_rand_seed.restype = None
+    lib.bsfm_rand_next.argtypes = [C.POINTER(RandState)]
+    lib.bsfm_rand_next.restype = C.c_int
+    lib.bsfm_fmatrix_ransac_batch.argtypes = [C.c_int, C.POINTER(C.c_int), dp, dp, C.c_int, C.c_double, C.c_double,
+                                              C.POINTER(RandState), dp, C.POINTER(C.c_int)]
+    lib.bsfm_fmatrix_ransac_batch.restype = C.c_int
+    lib.bsfm_estimate_fmatrix_batch.argtypes = [C.c_int, C.POINTER(C.c_int), dp, dp, C.c_int, C.c_double, C.POINTER(RandState), dp,
+                                                C.POINTER(C.c_int), C.POINTER(C.c_ubyte), C.POINTER(C.c_int)]
+    lib.bsfm_estimate_fmatrix_batch.restype = C.c_int
     lib.bsfm_eval_normal_equations.argtypes = [vp, C.c_double, dp, dp, dp, dp, dp, dp, dp]
     lib.bsfm_eval_normal_equations.restype = C.c_int
     lib.bsfm_dense_chol_solve.argtypes = [C.c_int, dp, dp, dp, C.c_int]

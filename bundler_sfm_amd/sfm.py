@@ -99,6 +99,44 @@ def triangulate_batch(mode, view_ptr, p, R, t, X=None, view_cam=None):
     return X, err, info
 
 
+class Rand:
+    """glibc rand() restated (bsfm_rand_t): Rand(seed).next() == srand(seed); rand()."""
+
+    def __init__(self, seed=1):
+        self.st = _lib.RandState()
+        lib.bsfm_rand_seed(C.byref(self.st), seed)
+
+    def next(self):
+        return lib.bsfm_rand_next(C.byref(self.st))
+
+
+def fmatrix_ransac_batch(match_ptr, a_xy, b_xy, num_trials, threshold, success_ratio, rng):
+    """estimate_fmatrix_ransac_matches (lib/imagelib/fmatrix.c:293-475) over a batch of pairs. Returns (F (npairs, 9), inliers)."""
+    match_ptr = np.ascontiguousarray(match_ptr, np.int32)
+    npairs = len(match_ptr) - 1
+    a = np.ascontiguousarray(a_xy, np.float64); b = np.ascontiguousarray(b_xy, np.float64)
+    F = np.zeros((npairs, 9)); cnt = np.zeros(npairs, np.int32)
+    rc = lib.bsfm_fmatrix_ransac_batch(npairs, _ip(match_ptr), _dp(a), _dp(b), num_trials, threshold, success_ratio,
+                                       C.byref(rng.st), _dp(F), _ip(cnt))
+    if rc != 0:
+        raise RuntimeError("bsfm_fmatrix_ransac_batch failed")
+    return F, cnt
+
+
+def estimate_fmatrix_batch(match_ptr, k1_xy, k2_xy, num_trials, threshold, rng):
+    """EstimateFMatrix (src/Epipolar.cpp:118-237) over a batch of pairs. Returns (F (npairs, 9), num_inliers, inlier flags, lm info)."""
+    match_ptr = np.ascontiguousarray(match_ptr, np.int32)
+    npairs = len(match_ptr) - 1
+    k1 = np.ascontiguousarray(k1_xy, np.float64); k2 = np.ascontiguousarray(k2_xy, np.float64)
+    F = np.zeros((npairs, 9)); cnt = np.zeros(npairs, np.int32); inl = np.zeros(max(int(match_ptr[-1]), 1), np.uint8)
+    info = np.zeros(npairs, np.int32)
+    rc = lib.bsfm_estimate_fmatrix_batch(npairs, _ip(match_ptr), _dp(k1), _dp(k2), num_trials, threshold, C.byref(rng.st), _dp(F),
+                                         _ip(cnt), inl.ctypes.data_as(C.POINTER(C.c_ubyte)), _ip(info))
+    if rc != 0:
+        raise RuntimeError("bsfm_estimate_fmatrix_batch failed")
+    return F, cnt, inl[:int(match_ptr[-1])], info
+
+
 class Problem:
     """Device-resident BA problem (sparse CRS boundary)."""
 

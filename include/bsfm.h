@@ -244,6 +244,30 @@ int bsfm_dense_chol_solve(int n, const double *A, const double *b, double *x, in
 int bsfm_triangulate_batch(int mode, int npoints, const int *view_ptr, const double *p, const int *view_cam, int ncams,
                            const double *R, const double *t, double *X, double *error, int *info);
 
+/* ---- 3c. batched epipolar geometry ---------------------------------------------------- */
+/* glibc's rand() restated (random(), TYPE_3 additive feedback; srand(seed) == bsfm_rand_seed): the reference draws its
+ * RANSAC samples with rand() (lib/imagelib/fmatrix.c:352), so a caller that wants the reference's samples seeds this the
+ * way it seeds rand() (Bundler never calls srand: seed 1) and hands the state from call to call. */
+typedef struct { unsigned int s[31]; int fi, ri; } bsfm_rand_t;
+void bsfm_rand_seed(bsfm_rand_t *st, unsigned int seed);
+int bsfm_rand_next(bsfm_rand_t *st);
+/* estimate_fmatrix_ransac_matches (lib/imagelib/fmatrix.c:293-475, essential = 0) for npairs image pairs in order: pair p
+ * owns matches match_ptr[p] .. match_ptr[p+1]-1; match q pairs the point (a_xy[2q], a_xy[2q+1], 1) of the FIRST point
+ * argument with (b_xy[2q], b_xy[2q+1], 1) of the second (EstimateFMatrix passes k2 first, src/Epipolar.cpp:149).
+ * Per pair: F (9, row-major; untouched when the pair has fewer than 8 matches or no trial finds an inlier) and the inlier
+ * count of the best trial.  `rng` advances exactly as rand() would in the reference, early exits included. */
+int bsfm_fmatrix_ransac_batch(int npairs, const int *match_ptr, const double *a_xy, const double *b_xy, int num_trials,
+                              double threshold, double success_ratio, bsfm_rand_t *rng, double *F, int *inliers_max);
+/* EstimateFMatrix (src/Epipolar.cpp:118-237, essential = false) for npairs image pairs in order: pairs with fewer than 20
+ * matches are turned away; RANSAC as above with (k2, k1) and success ratio 0.95; inliers of its matrix; non-linear
+ * refinement on them (refine_fmatrix_nonlinear_matches, lib/imagelib/fmatrix.c:637-659: lmdif, tol 1e-12, rank-2
+ * projection inside the residual); inliers of the refined matrix.  k1_xy / k2_xy: keypoint positions of the two images,
+ * 2 doubles per match.  Out: F (9 per pair; untouched where nothing was estimated), num_inliers (per pair), inlier
+ * (1 byte per match), lm_info (per pair, MINPACK's code; may be NULL). */
+int bsfm_estimate_fmatrix_batch(int npairs, const int *match_ptr, const double *k1_xy, const double *k2_xy, int num_trials,
+                                double threshold, bsfm_rand_t *rng, double *F, int *num_inliers, unsigned char *inlier,
+                                int *lm_info);
+
 /* ---- 4. matcher ------------------------------------------------------------------------------------- */
 /* Exact 2-NN ratio test between two descriptor sets (128-D uchar, squared L2 in int32):
  * keeps (i, nn0) iff (double)d0 < ratio*ratio*(double)d1 (src/keys2a.cpp:362). out_pairs gets up to

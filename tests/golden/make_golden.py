@@ -222,6 +222,47 @@ def triangulation():
     print("triangulate_golden:", npts, "points,", len(view_cam), "views; rms err median", np.median(out["n_err"]))
 
 
+def fmatrix():
+    """the reference's estimate_fmatrix_ransac_matches and the EstimateFMatrix call sequence
+    (lib/imagelib/fmatrix.c, src/Epipolar.cpp:118-237) on synthetic image pairs: two views of a random point cloud, pixel
+    noise, a share of gross outliers; pairs below the 8- and 20-match limits, one pair with repeated key positions, one so
+    clean that the trial loop is left early (ratio > 0.95).  One srand(seed) per pair; also the first outputs of rand()."""
+    rng = np.random.default_rng(21)
+
+    def make_pair(n, out_frac, noise=0.7, dup=0):
+        X = rng.uniform(-1, 1, (n, 3)) + [0, 0, 5]
+        f = 800.0
+        th = rng.uniform(0.1, 0.4)
+        Rm = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+        t = np.array([-1.0, rng.uniform(-0.2, 0.2), rng.uniform(-0.2, 0.2)])
+        P1 = X; P2 = (Rm @ X.T).T + t
+        a = f * P1[:, :2] / P1[:, 2:3] + rng.normal(0, noise, (n, 2)); b = f * P2[:, :2] / P2[:, 2:3] + rng.normal(0, noise, (n, 2))
+        k = int(out_frac * n); b[:k] = rng.uniform(-400, 400, (k, 2))
+        if dup:
+            a[-dup:] = a[:dup]                                   # the same key matched twice: the sample loop must re-draw
+        return a, b
+    spec = [(60, 0.3, 0), (200, 0.5, 0), (35, 0.0, 0), (300, 0.2, 0), (7, 0.0, 0), (25, 0.1, 0), (120, 0.02, 0), (19, 0.0, 0),
+            (80, 0.25, 6), (500, 0.4, 0), (40, 0.0, 0), (150, 0.6, 0)]
+    pairs = [make_pair(n, o, dup=d) for n, o, d in spec]
+    T, thr = 512, 9.0
+    out = dict(match_ptr=np.concatenate([[0], np.cumsum([len(a) for a, _ in pairs])]).astype(np.int32),
+               k1=np.concatenate([a for a, _ in pairs]).ravel(), k2=np.concatenate([b for _, b in pairs]).ravel(),
+               num_trials=T, threshold=thr, seeds=np.arange(len(pairs)) + 100)
+    out["rand_seed1"] = O.ref_rand_sequence(1, 1000); out["rand_seed4242"] = O.ref_rand_sequence(4242, 1000)
+    rc, rF, eF, eFr, en, ein = [], [], [], [], [], []
+    for q, (a, b) in enumerate(pairs):
+        c, F = O.ref_fm_ransac(100 + q, b, a, T, thr, 0.95)     # (k2, k1) as EstimateFMatrix passes them
+        rc.append(c); rF.append(F)
+        il, Fr, Ff = O.ref_fm_estimate(100 + q, a, b, T, thr)
+        flag = np.zeros(len(a), np.uint8); flag[il] = 1
+        en.append(len(il)); ein.append(flag); eF.append(Ff); eFr.append(Fr)
+    out["ransac_count"] = np.array(rc, np.int32); out["ransac_F"] = np.array(rF)
+    out["est_count"] = np.array(en, np.int32); out["est_inlier"] = np.concatenate(ein); out["est_F"] = np.array(eF)
+    out["est_F_ransac"] = np.array(eFr)
+    np.savez_compressed(os.path.join(HERE, "fmatrix_golden.npz"), **out)
+    print("fmatrix_golden:", len(pairs), "pairs; ransac inliers", rc, "final inliers", en)
+
+
 def parse_bundle(path):
     toks = open(path).read().split("\n")
     assert toks[0].startswith("# Bundle file v0.3")
@@ -338,6 +379,6 @@ def model():
 if __name__ == "__main__":
     assert O.have_ref(), "build oracle/_ref first (make -C oracle ref)"
     only = sys.argv[1:]
-    for fn in (ba_cases, kermit, matcher, model, exports, mot, known_intrinsics, fisheye, triangulation):
+    for fn in (ba_cases, kermit, matcher, model, exports, mot, known_intrinsics, fisheye, triangulation, fmatrix):
         if not only or fn.__name__ in only:
             fn()

@@ -26,6 +26,24 @@ def have_ref():
     return os.path.exists(REF_PATH)
 
 
+FMREF_PATH = os.path.join(os.path.dirname(REF_PATH), "libfmref.so")
+_fmref = None
+
+
+def have_fmref():
+    return os.path.exists(FMREF_PATH)
+
+
+def fmref():
+    global _fmref
+    if _fmref is None:
+        _fmref = C.CDLL(FMREF_PATH)
+        _fmref.ref_fm_ransac.restype = C.c_int
+        _fmref.ref_fm_estimate.restype = C.c_int
+        _fmref.ref_fm_residual.restype = C.c_double
+    return _fmref
+
+
 def have_port():
     return os.path.exists(PORT_PATH)
 
@@ -315,3 +333,32 @@ def ref_triangulate(mode, p, R, t, X0=None):
     with quiet_stdout():
         ref().ref_triangulate(int(mode), len(p), _d(p), _d(R), _d(t), _d(X), _d(err))
     return X, err[0]
+
+
+def _xy1(xy):
+    xy = np.asarray(xy, np.float64).reshape(-1, 2)
+    return np.concatenate([xy, np.ones((len(xy), 1))], axis=1).ravel().copy()
+
+
+def ref_fm_ransac(seed, a_xy, b_xy, num_trials, threshold, success_ratio):
+    """srand(seed); estimate_fmatrix_ransac_matches (lib/imagelib/fmatrix.c:293-475). Returns (inliers_max, F)."""
+    a = _xy1(a_xy); b = _xy1(b_xy); F = np.zeros(9)
+    with quiet_stdout():
+        c = fmref().ref_fm_ransac(C.c_uint(seed), len(a) // 3, _d(a), _d(b), num_trials, C.c_double(threshold), C.c_double(success_ratio), _d(F))
+    return c, F
+
+
+def ref_fm_estimate(seed, k1_xy, k2_xy, num_trials, threshold):
+    """srand(seed); the call sequence of EstimateFMatrix (src/Epipolar.cpp:118-237). Returns (inlier indices, F_ransac, F)."""
+    k1 = _xy1(k1_xy); k2 = _xy1(k2_xy); n = len(k1) // 3
+    Fr = np.zeros(9); F = np.zeros(9); il = np.zeros(max(n, 1), np.int32)
+    with quiet_stdout():
+        c = fmref().ref_fm_estimate(C.c_uint(seed), n, _d(k1), _d(k2), num_trials, C.c_double(threshold), _d(Fr), _d(F),
+                                    il.ctypes.data_as(C.POINTER(C.c_int)))
+    return il[:c].copy(), Fr, F
+
+
+def ref_rand_sequence(seed, n):
+    out = np.zeros(n, np.int32)
+    fmref().ref_rand_sequence(C.c_uint(seed), n, out.ctypes.data_as(C.POINTER(C.c_int)))
+    return out

@@ -49,6 +49,8 @@ def test_no_gpu_fails_loudly(bsfm, capfd):
         raised = True
     assert raised, "problem creation must fail without a HIP device (no CPU fallback)"
     assert "no usable HIP device" in capfd.readouterr().err
+    with pytest.raises(RuntimeError):             # ... and epipolar geometry
+        bsfm.fmatrix_ransac_batch(np.array([0, 8], np.int32), np.zeros(16), np.zeros(16), 4, 9.0, 0.95, bsfm.Rand(1))
     rc, _ = bsfm.dense_chol_solve(np.eye(4), np.ones(4))
     assert rc == -1
     with pytest.raises(RuntimeError):             # batched triangulation: same rule
