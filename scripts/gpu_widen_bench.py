@@ -64,3 +64,29 @@ if O.have_ref():
     vm = B.dense_vmask(50000, 200, small["rowptr"], small["colidx"])
     r = O.ref_sba_mot(50000, 200, vm, small["proj"], small["cams"], small["pts"], itmax=3, jac_mode=0)
     print(f"reference sba_mot_levmar, 200 cams / 50 000 pts / 500 000 obs: {1e3 * r['secs'] / max(r['info'][5], 1):.0f} ms per iteration")
+
+# epipolar geometry: EstimateFMatrix over a batch of image pairs (2048 trials, threshold 9 as Bundler runs it)
+rng = np.random.default_rng(5)
+def _pair(nm, out_frac):
+    X = rng.uniform(-1, 1, (nm, 3)) + [0, 0, 5]
+    th = rng.uniform(0.1, 0.4)
+    Rm = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    P2 = (Rm @ X.T).T + [-1.0, 0.1, 0.1]
+    a = 800 * X[:, :2] / X[:, 2:3] + rng.normal(0, 0.7, (nm, 2)); b = 800 * P2[:, :2] / P2[:, 2:3] + rng.normal(0, 0.7, (nm, 2))
+    k = int(out_frac * nm); b[:k] = rng.uniform(-400, 400, (k, 2))
+    return a, b
+npairs = 512
+prs = [_pair(int(rng.integers(50, 400)), rng.uniform(0.1, 0.5)) for _ in range(npairs)]
+ptr = np.concatenate([[0], np.cumsum([len(a) for a, _ in prs])]).astype(np.int32)
+K1 = np.concatenate([a for a, _ in prs]).ravel(); K2 = np.concatenate([b for _, b in prs]).ravel()
+B.estimate_fmatrix_batch(ptr[:3], K1[:2 * ptr[2]], K2[:2 * ptr[2]], 2048, 9.0, B.Rand(1))
+t = time.perf_counter(); F, cnt, inl, info = B.estimate_fmatrix_batch(ptr, K1, K2, 2048, 9.0, B.Rand(1)); t_fm = time.perf_counter() - t
+print(f"EstimateFMatrix batch: {npairs} pairs ({ptr[-1]} matches, 2048 trials each) in {1e3 * t_fm:.1f} ms = {1e3 * t_fm / npairs:.3f} ms/pair; "
+      f"mean inlier share {cnt.sum() / ptr[-1]:.2f}")
+if O.have_fmref():
+    k = 24
+    t = time.perf_counter()
+    for q in range(k):
+        O.ref_fm_estimate(1, prs[q][0], prs[q][1], 2048, 9.0)
+    t_ref = (time.perf_counter() - t) / k
+    print(f"reference EstimateFMatrix sequence on this host: {1e3 * t_ref:.2f} ms/pair")
