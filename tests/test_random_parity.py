@@ -1,0 +1,78 @@
+"""Randomised parity sweep: small problems with random visibility (ragged rows, cameras with very few observations), random
+model flags (cnp = 6 / 7 / 8 / 9), fixed leading cameras, both Jacobians and both reduced solvers, three LM iterations each,
+GPU (through the C-ABI) against the plain-C restatement of the reference (oracle/sba_oracle.c, itself pinned to the
+reference's iterates in tests/test_oracle.py).  Seeds are fixed: a failure names its case."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_util as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(B, seed):
+    rng = np.random.default_rng(1000 + seed)
+    m = int(rng.integers(3, 36))
+    n = int(rng.integers(10 * m, 14 * m))
+    est, und = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    cnp = 6 + est + 2 * und
+    mcon = int(rng.integers(0, min(3, m - 1)))
+    base = B.synth_ba(max(m, 2), n, 2)
+    cams = base["cams"]
+    kmax = min(m, 8)
+    rows = [np.sort(rng.choice(m, int(rng.integers(2, kmax + 1)), replace=False)) for _ in range(n)]
+    if seed % 3 == 0 and m > 6:                       # two camera groups that share no point (group-by-group solver)
+        half = m // 2
+        rows = [np.sort(rng.choice(half, min(half, len(r)), replace=False)) + (half if i % 2 else 0) if len(r) <= half else r[:2]
+                for i, r in enumerate(rows)]
+        rows = [r if len(r) >= 2 else np.array([0, 1]) + (half if i % 2 else 0) for i, r in enumerate(rows)]
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    colidx = np.concatenate(rows).astype(np.int32)
+    pts = base["pts"].reshape(-1, 3).copy()
+    ca = O.cams_to_arrays(cams)
+    dp = C.POINTER(C.c_double)
+    proj = np.zeros((len(colidx), 2)); x = np.zeros(2)
+    k = 0
+    for i, r in enumerate(rows):
+        b = np.ascontiguousarray(pts[i])
+        for j in r:
+            a = np.zeros(9)
+            a[:3] = ca["t"][j]
+            c = 6
+            if est:
+                a[6] = ca["f"][j] * 0.001; c = 7
+            if und:
+                a[c] = ca["k"][j][0] * 5.0; a[c + 1] = ca["k"][j][1] * 5.0
+            Rj = np.ascontiguousarray(ca["R"][j])
+            O.port().oracle_project(est, und, 1, Rj.ctypes.data_as(dp), float(ca["f"][j]), a.ctypes.data_as(dp), b.ctypes.data_as(dp),
+                                    x.ctypes.data_as(dp))
+            proj[k] = x; k += 1
+    proj += rng.normal(0, 0.4, proj.shape)
+    pts0 = pts + rng.normal(0, 0.01, pts.shape)
+    return dict(m=m, n=n, est=est, und=und, cnp=cnp, mcon=mcon, rowptr=rowptr, colidx=colidx, proj=proj.ravel(), cams=cams,
+                pts=pts0.ravel(), jac=int(rng.integers(0, 2)), auto=int(rng.integers(0, 2)))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_problem_matches_oracle(gpu_bsfm, seed):
+    B = gpu_bsfm
+    c = _case(B, seed)
+    vm = B.dense_vmask(c["n"], c["m"], c["rowptr"], c["colidx"])
+    q = O.port_run_sfm(c["n"], c["m"], vm, c["proj"], c["cams"], c["pts"], itmax=3, jac_mode=c["jac"], ncons=c["mcon"],
+                       est_focal=c["est"], undistort=c["und"])
+    opt = B.default_options(jacobian=B.JAC_ANALYTIC if c["jac"] else B.JAC_FD, verbose=0, itmax=3,
+                            reduced_solver=B.SOLVER_AUTO if c["auto"] else B.SOLVER_DENSE)
+    pb = B.Problem(c["n"], c["m"], c["rowptr"], c["colidx"], c["proj"], c["cams"], c["pts"], mcon=c["mcon"],
+                   est_focal_length=c["est"], undistort=c["und"], options=opt)
+    rc, info = pb.solve()
+    p = pb.download(want_cams=False)[0]
+    groups = pb.phase_ms("groups")
+    pb.close()
+    tag = {k: c[k] for k in ("m", "n", "cnp", "mcon", "jac", "auto")}
+    assert list(info[5:10]) == list(q["info"][5:10]), (tag, info, q["info"])
+    assert abs(info[0] - q["info"][0]) <= 1e-10 * q["info"][0] and abs(info[1] - q["info"][1]) <= 1e-8 * q["info"][1], tag
+    assert np.abs(p - q["p"]).max() <= 1e-6 * np.abs(q["p"]).max(), tag
+    if c["auto"] and seed % 3 == 0 and c["m"] > 6:
+        assert groups >= 2, tag
