@@ -3,7 +3,7 @@
 // S_jk (j <= k) receives sum_i Y_ij W_ik^T = sum_i A_ij^T (B_ij V*_i^-1 B_ik^T) A_ik over the points seen by both cameras
 // (lib/sba-1.5/sba_levmar.c:1182-1302; W is never materialised).  The co-visibility triples (record of (i,j), record of
 // (i,k), point i) were bucketed and ordered once per problem by block; a task = <= 168 triples of ONE block = one wave,
-// 3 lanes per triple (lane r owns output rows r, r+3, r+6), 21 triples per pass, the 21 lane groups are folded with
+// 3 lanes per triple (lane r owns output columns r, r+3, r+6), 21 triples per pass, the 21 lane groups are folded with
 // shuffles.  No atomics anywhere: partials are summed in task order by k_schur_assemble => run-to-run deterministic.
 // Tasks of DIAGONAL blocks (j == k) also accumulate this task's part of the reduced right-hand side
 // e_j = ea_j - sum_i A_ij^T (B_ij V*_i^-1 eb_i) (sba_levmar.c:1320-1339): B_ij V*_i^-1 is already there, so E costs one
@@ -129,27 +129,29 @@ __global__ __launch_bounds__(256) void k_schur_tasks_v2(DevProblem P, const Schu
             const double m01 = c00 * Bb[3] + c01 * Bb[4] + c02 * Bb[5];
             const double m10 = c10 * Bb[0] + c11 * Bb[1] + c12 * Bb[2];
             const double m11 = c10 * Bb[3] + c11 * Bb[4] + c12 * Bb[5];
-            double T0[CNP], T1[CNP];
-#pragma unroll
-            for (int c = 0; c < CNP; ++c) {
-                const double b0 = Jb[c], b1 = Jb[CNP + c];
-                T0[c] = m00 * b0 + m01 * b1;
-                T1[c] = m10 * b0 + m11 * b1;
-            }
-            double g0 = 0.0, g1 = 0.0;
-            if (diag) {
-                const double e0 = ebin[grp * 4], e1 = ebin[grp * 4 + 1], e2 = ebin[grp * 4 + 2];
-                g0 = c00 * e0 + c01 * e1 + c02 * e2;
-                g1 = c10 * e0 + c11 * e1 + c12 * e2;
-            }
+            // lane r owns the COLUMNS r, r+3, r+6 of the block (all rows): it needs T = M Jb only for those columns
+            double t0[NR], t1[NR];
 #pragma unroll
             for (int a = 0; a < NR; ++a) {
-                const int row = r + 3 * a;
-                if (row < CNP) {
-                    const double a0 = Ja[row], a1 = Ja[CNP + row];
+                const int col = r + 3 * a;
+                const double b0 = col < CNP ? Jb[col] : 0.0, b1 = col < CNP ? Jb[CNP + col] : 0.0;
+                t0[a] = m00 * b0 + m01 * b1;
+                t1[a] = m10 * b0 + m11 * b1;
+            }
 #pragma unroll
-                    for (int c = 0; c < CNP; ++c) acc[a][c] += a0 * T0[c] + a1 * T1[c];
-                    acce[a] += a0 * g0 + a1 * g1;
+            for (int row = 0; row < CNP; ++row) {
+                const double a0 = Ja[row], a1 = Ja[CNP + row];
+#pragma unroll
+                for (int a = 0; a < NR; ++a) acc[a][row] += a0 * t0[a] + a1 * t1[a];
+            }
+            if (diag) {                             // e_j: this lane's rows r, r+3, r+6
+                const double e0 = ebin[grp * 4], e1 = ebin[grp * 4 + 1], e2 = ebin[grp * 4 + 2];
+                const double g0 = c00 * e0 + c01 * e1 + c02 * e2;
+                const double g1 = c10 * e0 + c11 * e1 + c12 * e2;
+#pragma unroll
+                for (int a = 0; a < NR; ++a) {
+                    const int row = r + 3 * a;
+                    if (row < CNP) acce[a] += Ja[row] * g0 + Ja[CNP + row] * g1;
                 }
             }
         }
@@ -174,11 +176,11 @@ __global__ __launch_bounds__(256) void k_schur_tasks_v2(DevProblem P, const Schu
         double* out = partials + (size_t)tk.out * CNP * CNP;
 #pragma unroll
         for (int a = 0; a < NR; ++a) {
-            const int row = r + 3 * a;
-            if (row < CNP) {
+            const int col = r + 3 * a;              // acc[a][row] = entry (row, col) of the block; e_j row = col's index
+            if (col < CNP) {
 #pragma unroll
-                for (int c = 0; c < CNP; ++c) out[row * CNP + c] = acc[a][c];
-                if (diag) epart[(size_t)tk.out * CNP + row] = acce[a];
+                for (int c = 0; c < CNP; ++c) out[c * CNP + col] = acc[a][c];
+                if (diag) epart[(size_t)tk.out * CNP + col] = acce[a];
             }
         }
     }
