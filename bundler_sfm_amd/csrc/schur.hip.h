@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_schur_tasks_v2(DevProblem P, const Schu
             for (int row = 0; row < CNP; ++row) {
                 const double a0 = Ja[row], a1 = Ja[CNP + row];
 #pragma unroll
-                for (int a = 0; a < NR; ++a) acc[a][row] += a0 * t0[a] + a1 * t1[a];
+                for (int a = 0; a < NR; ++a) acc[a][row] = fma(a1, t1[a], fma(a0, t0[a], acc[a][row]));   // two FMAs, not mul + fma + add
             }
             if (diag) {                             // e_j: this lane's rows r, r+3, r+6
                 const double e0 = ebin[grp * 4], e1 = ebin[grp * 4 + 1], e2 = ebin[grp * 4 + 2];
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_schur_tasks_v2(DevProblem P, const Schu
 #pragma unroll
                 for (int a = 0; a < NR; ++a) {
                     const int row = r + 3 * a;
-                    if (row < CNP) acce[a] += Ja[row] * g0 + Ja[CNP + row] * g1;
+                    if (row < CNP) acce[a] = fma(Ja[CNP + row], g1, fma(Ja[row], g0, acce[a]));
                 }
             }
         }
