@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void k_schur_tasks_v2(DevProblem P, const Schu
         tq[3 * t] = tr.x; tq[3 * t + 1] = tr.y; tq[3 * t + 2] = tri_pt[tk.start + t];
     }
     const int grp = lane / 3, r = lane - 3 * grp;
+    __builtin_assume(r >= 0 && r <= 2);          // lets the column tests (r + 3 a < CNP) fold where they always hold
     double acc[NR][CNP], acce[NR];
 #pragma unroll
     for (int a = 0; a < NR; ++a) {
@@ -77,34 +78,37 @@ __global__ __launch_bounds__(256) void k_schur_tasks_v2(DevProblem P, const Schu
     const int vrec = lane / 3, vpart = lane - 3 * vrec;
     double pa[NA][2], pb[NA][2], pv[2], pe = 0.0;
 
+// No predication in the staging: a lane whose slot lies beyond the pass (the last 4 of the 256 chunk slots, or any slot past a
+// short final pass) is CLAMPED onto the last valid record -- it loads and parks a duplicate of what the rightful lane
+// handles (same address, same value).  That keeps ~12 exec-mask blocks per pass out of the loop.
 #define BSFM_SCH_ISSUE(p0_)                                                                                         \
     {                                                                                                               \
-        const int np_ = min(SCH_PASS, tk.count - (p0_));                                                            \
+        const int last_ = min(SCH_PASS, tk.count - (p0_)) - 1;                                                      \
         _Pragma("unroll") for (int q = 0; q < NA; ++q) {                                                            \
-            if (srec[q] < np_) {                                                                                    \
-                const double2 ta = *reinterpret_cast<const double2*>(P.Jc + (size_t)tq[3 * ((p0_) + srec[q])] * JS + 2 * spart[q]);     \
-                const double2 tb = *reinterpret_cast<const double2*>(P.Jc + (size_t)tq[3 * ((p0_) + srec[q]) + 1] * JS + 2 * spart[q]); \
-                pa[q][0] = ta.x; pa[q][1] = ta.y; pb[q][0] = tb.x; pb[q][1] = tb.y;                                 \
-            }                                                                                                       \
+            const int rq_ = min(srec[q], last_);                                                                    \
+            const double2 ta = *reinterpret_cast<const double2*>(P.Jc + (size_t)tq[3 * ((p0_) + rq_)] * JS + 2 * spart[q]);     \
+            const double2 tb = *reinterpret_cast<const double2*>(P.Jc + (size_t)tq[3 * ((p0_) + rq_) + 1] * JS + 2 * spart[q]); \
+            pa[q][0] = ta.x; pa[q][1] = ta.y; pb[q][0] = tb.x; pb[q][1] = tb.y;                                     \
         }                                                                                                           \
-        if (vrec < np_) {                                                                                           \
-            const double2 tv = *reinterpret_cast<const double2*>(P.Vinv + (size_t)tq[3 * ((p0_) + vrec) + 2] * 6 + 2 * vpart); \
+        {                                                                                                           \
+            const int rv_ = min(vrec, last_);                                                                       \
+            const double2 tv = *reinterpret_cast<const double2*>(P.Vinv + (size_t)tq[3 * ((p0_) + rv_) + 2] * 6 + 2 * vpart); \
             pv[0] = tv.x; pv[1] = tv.y;                                                                             \
-            if (diag) pe = P.eb[(size_t)tq[3 * ((p0_) + vrec) + 2] * 3 + vpart];                                    \
+            if (diag) pe = P.eb[(size_t)tq[3 * ((p0_) + rv_) + 2] * 3 + vpart];                                     \
         }                                                                                                           \
     }
 #define BSFM_SCH_PARK(p0_)                                                                                          \
     {                                                                                                               \
-        const int np_ = min(SCH_PASS, tk.count - (p0_));                                                            \
+        const int last_ = min(SCH_PASS, tk.count - (p0_)) - 1;                                                      \
         _Pragma("unroll") for (int q = 0; q < NA; ++q) {                                                            \
-            if (srec[q] < np_) {                                                                                    \
-                *reinterpret_cast<double2*>(recA + srec[q] * RS + 2 * spart[q]) = make_double2(pa[q][0], pa[q][1]); \
-                *reinterpret_cast<double2*>(recB + srec[q] * RS + 2 * spart[q]) = make_double2(pb[q][0], pb[q][1]); \
-            }                                                                                                       \
+            const int rq_ = min(srec[q], last_);                                                                    \
+            *reinterpret_cast<double2*>(recA + rq_ * RS + 2 * spart[q]) = make_double2(pa[q][0], pa[q][1]);         \
+            *reinterpret_cast<double2*>(recB + rq_ * RS + 2 * spart[q]) = make_double2(pb[q][0], pb[q][1]);         \
         }                                                                                                           \
-        if (vrec < np_) {                                                                                           \
-            *reinterpret_cast<double2*>(vin + vrec * 6 + 2 * vpart) = make_double2(pv[0], pv[1]);                   \
-            if (diag) ebin[vrec * 4 + vpart] = pe;                                                                  \
+        {                                                                                                           \
+            const int rv_ = min(vrec, last_);                                                                       \
+            *reinterpret_cast<double2*>(vin + rv_ * 6 + 2 * vpart) = make_double2(pv[0], pv[1]);                    \
+            if (diag) ebin[rv_ * 4 + vpart] = pe;                                                                   \
         }                                                                                                           \
     }
 
