@@ -103,17 +103,25 @@ def test_shared_rand_stream_against_live_reference(gpu_bsfm):
     ref = O.fmref()
     est = ref.estimate_fmatrix_ransac_matches; est.restype = C.c_int
     dp = C.POINTER(C.c_double)
+    # the fixture's pairs plus one whose first image has a single key position (every draw after the first is a repeat:
+    # the reference gives up after 1000 re-draws inside the first trial and returns 0 -- with the generator advanced)
+    ptr = list(G["match_ptr"]); k1s = [G["k1"].reshape(-1, 2)]; k2s = [G["k2"].reshape(-1, 2)]
+    k1s.append(np.random.default_rng(1).uniform(-100, 100, (12, 2))); k2s.append(np.tile([[3.0, 4.0]], (12, 1)))
+    ptr.append(ptr[-1] + 12)
+    extra = _pair(0)
+    k1s.append(extra[0]); k2s.append(extra[1]); ptr.append(ptr[-1] + len(extra[0]))       # and a normal pair behind it
+    K1 = np.concatenate(k1s); K2 = np.concatenate(k2s); ptr = np.array(ptr, np.int32)
     libc.srand(31)
     want = []
     with O.quiet_stdout():
-        for q in range(NP):
-            k1, k2 = _pair(q)
+        for q in range(len(ptr) - 1):
+            k1, k2 = K1[ptr[q]:ptr[q + 1]], K2[ptr[q]:ptr[q + 1]]
             a = O._xy1(k2); b = O._xy1(k1); F = np.zeros(9)
             want.append(est(len(k1), a.ctypes.data_as(dp), b.ctypes.data_as(dp), 200, C.c_double(THR), C.c_double(0.95), 0, F.ctypes.data_as(dp)))
     nxt = libc.rand()
     r = B.Rand(31)
-    _, cnt = B.fmatrix_ransac_batch(G["match_ptr"], G["k2"], G["k1"], 200, THR, 0.95, r)
-    assert list(cnt) == want
+    _, cnt = B.fmatrix_ransac_batch(ptr, K2.ravel(), K1.ravel(), 200, THR, 0.95, r)
+    assert list(cnt) == want and want[NP] == 0 and want[NP + 1] > 0
     assert r.next() == nxt
 
 
