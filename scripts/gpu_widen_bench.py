@@ -1,8 +1,9 @@
 """Timings of the SURVEY 8(f) rows at the benchmark size (1 000 cameras / 500 000 points / 5 000 000 observations), next
 to the reference on this host where the reference has the function: post-solve outlier statistics, ray-angle pruning,
 camera-only refinement (fix_points), batched triangulation.  Usage: python scripts/gpu_widen_bench.py [cams points deg]"""
-import sys, time, numpy as np
-sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import os, sys, time, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
 import bundler_sfm_amd as B
 import oracle_util as O
 
