@@ -28,6 +28,10 @@
 // column index and explicit FMAs brought the pass to ~235 instructions (96 FP64) and the kernel from 1.86 to 1.67 ms.  L2 read
 // latency (268 cycles average) and the TLB (0.05 % misses) are not in the way; what remains is LDS traffic (every lane of a
 // triple reads the shared B / V^-1 operands) against two waves per SIMD.
+// Split timing (kernel variants, not kept): staging alone (loads + parking, no arithmetic) 1.3 ms, arithmetic alone (no global
+// loads after the first pass) 1.2 ms, together 1.55 ms -- the two halves already overlap well and are of equal weight: 12 GB
+// of 16-byte gathers per launch through L1 / L2 (9 TB/s) on one side, LDS reads + FMAs on the other.  Going faster needs
+// fewer gathers AND fewer LDS reads at once, i.e. records staged once per point chunk and shared by all blocks they feed.
 // NOTE (gfx950 / hipcc 7.2): the prefetch registers are arrays of plain double -- arrays of the double2 vector
 // struct are not promoted to registers and end up in scratch, which serialises the whole pipeline.
 #pragma once
