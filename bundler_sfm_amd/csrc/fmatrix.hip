@@ -299,18 +299,19 @@ template <typename T> struct DevBuf {
 };
 
 // The sample loop of fmatrix.c:343-375 for all trials of one pair.  Returns false when the reference would have given up
-// (1000 re-draws inside one trial: estimate_fmatrix_ransac_matches returns 0 at once); `after[t]` = generator state after
-// trial t was drawn.
-bool draw_samples(bsfm_rand_t& rng, int n, const double* a, const double* b, int ntrials, int* out, std::vector<bsfm_rand_t>& after,
+// (1000 re-draws inside one trial: estimate_fmatrix_ransac_matches returns 0 at once); `after[t]` = rand() calls consumed up to and including
+// trial t.
+bool draw_samples(bsfm_rand_t& rng, int n, const double* a, const double* b, int ntrials, int* out, std::vector<int>& after,
                   int* gave_up_at)
 {
     after.resize(ntrials);
+    int drawn = 0;
     for (int t = 0; t < ntrials; ++t) {
         int* idxs = out + (size_t)t * 8;
         int round = 0;
         for (int j = 0; j < 8; ++j) {
             if (round == 1000) { for (int q = t; q < ntrials; ++q) out[(size_t)q * 8] = -1; *gave_up_at = t; return false; }
-            const int idx = bsfm_rand_next(&rng) % n;
+            const int idx = bsfm_rand_next(&rng) % n; ++drawn;
             bool reselect = false;
             for (int k = 0; k < j; ++k) {
                 const int o = idxs[k];
@@ -319,7 +320,7 @@ bool draw_samples(bsfm_rand_t& rng, int n, const double* a, const double* b, int
             if (reselect) { ++round; --j; continue; }
             idxs[j] = idx;
         }
-        after[t] = rng;
+        after[t] = drawn;
     }
     *gave_up_at = -1;
     return true;
@@ -348,7 +349,9 @@ extern "C" int bsfm_fmatrix_ransac_batch(int npairs, const int* match_ptr, const
     const size_t per = (size_t)num_trials;
     if (!dsm.alloc(CHUNK * per * 8) || !dcnt.alloc(CHUNK * per) || !dF.alloc(CHUNK * per * 9)) { fprintf(stderr, "[bsfm] fmatrix ransac: device allocation failed\n"); return BSFM_ERROR; }
     std::vector<int> hs(CHUNK * per * 8), hc(CHUNK * per);
-    std::vector<std::vector<bsfm_rand_t>> after(CHUNK);
+    std::vector<std::vector<int>> after(CHUNK);
+    std::vector<bsfm_rand_t> start(CHUNK + 1);       // generator state at the start of each pair of the chunk (and behind the last)
+    auto state_after = [&](int q, int t) { bsfm_rand_t st = start[q]; for (int i = 0; i < after[q][t]; ++i) (void)bsfm_rand_next(&st); return st; };
     std::vector<int> gave_up(CHUNK);
     std::vector<int> cptr(CHUNK + 1);
     int p0 = 0;
@@ -359,6 +362,7 @@ extern "C" int bsfm_fmatrix_ransac_batch(int npairs, const int* match_ptr, const
         bsfm_rand_t spec = *rng;
         for (int q = 0; q < np; ++q) {
             const int m0 = match_ptr[p0 + q], n = match_ptr[p0 + q + 1] - m0;
+            start[q] = spec;
             if (n < 8) {                             // fmatrix.c:313-317: fails before any draw
                 for (size_t t = 0; t < per; ++t) hs[((size_t)q * per + t) * 8] = -1;
                 after[q].clear(); gave_up[q] = -2;
@@ -366,6 +370,7 @@ extern "C" int bsfm_fmatrix_ransac_batch(int npairs, const int* match_ptr, const
             }
             draw_samples(spec, n, a_xy + 2 * (size_t)m0, b_xy + 2 * (size_t)m0, num_trials, hs.data() + (size_t)q * per * 8, after[q], &gave_up[q]);
         }
+        start[np] = spec;
         for (int q = 0; q <= np; ++q) cptr[q] = match_ptr[p0 + q];
         if (!dsm.up(hs.data(), (size_t)np * per * 8) || hipMemcpy(dptr.p, cptr.data(), (np + 1) * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return BSFM_ERROR;
         const int bpp = (num_trials + 63) / 64;
@@ -389,7 +394,7 @@ extern "C" int bsfm_fmatrix_ransac_batch(int npairs, const int* match_ptr, const
                 // `return 0` from inside the sample loop (fmatrix.c:349-350): no F is copied out, and the generator has
                 // consumed the draws of the aborted trial too -- replay that trial from the state before it
                 inliers_max[p0 + q] = 0;
-                bsfm_rand_t st = gave_up[q] > 0 ? after[q][gave_up[q] - 1] : *rng;
+                bsfm_rand_t st = gave_up[q] > 0 ? state_after(q, gave_up[q] - 1) : *rng;
                 const int m0 = match_ptr[p0 + q];
                 const double* a = a_xy + 2 * (size_t)m0; const double* b = b_xy + 2 * (size_t)m0;
                 int idxs[8], round = 0;
@@ -408,7 +413,7 @@ extern "C" int bsfm_fmatrix_ransac_batch(int npairs, const int* match_ptr, const
             }
             inliers_max[p0 + q] = best_cnt;
             if (best >= 0 && !dF.down(F + 9 * (size_t)(p0 + q), 9, ((size_t)q * per + best) * 9)) return BSFM_ERROR;
-            *rng = after[q][last];
+            *rng = (last == num_trials - 1) ? start[q + 1] : state_after(q, last);   // replay only after an early exit
             if (early && last < num_trials - 1) break;                             // left early: the speculation behind it is void
         }
         p0 += accepted;
