@@ -19,11 +19,13 @@
 // operations of dgetf2 / dgetrs), the rank-2 projection is a one-sided Jacobi SVD of the 3 x 3 matrix, and the thread then
 // walks over all matches of its pair (the 64 lanes of a wave read the same match: broadcast loads) counting residuals below
 // the threshold.  Trials are independent; the host picks, per pair, the first trial with the largest count among the trials
-// the reference would have run.  The non-linear refinement is one thread per pair on lmdif.hip.h (8 unknowns): each Jacobian
-// pass projects the 9 perturbed matrices to rank 2 once and then streams over the pair's inliers.
+// the reference would have run.  The non-linear refinement is one WAVE per pair on lmdif.hip.h (8 unknowns): each Jacobian
+// pass projects the 9 perturbed matrices to rank 2 once, the lanes share the pair's inliers and merge their triangular
+// factors with a butterfly TSQR (FmFcnWave).
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "../../include/bsfm.h"
@@ -258,8 +260,111 @@ struct FmFcn {
     }
 };
 
+// The same functor for one WAVE per pair: every lane runs lm_lmdif<8> on identical data (uniform control flow); only the two
+// passes over the matches are shared out -- lane l takes the matches l, l + 64, ... -- and combined with xor-butterflies in
+// which both partners of a step compute the SAME expression (sum a + b resp. fold the factor of the higher lane into the one
+// of the lower lane), so that all lanes hold bit-identical results afterwards and never diverge.  The butterfly on the
+// triangular factors is a TSQR: R of the stacked [R_lo; R_hi] by folding the 8 rows of R_hi into R_lo with Givens rotations.
+struct FmFcnWave : FmFcn {
+    int lane;
+    __device__ static double wsum(double v)
+    {
+        for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s, 64);
+        return v;
+    }
+    __device__ double fnorm(const double* x) const
+    {
+        double F2[9];
+        project(x, F2);
+        double s = 0.0;
+        for (int q = lane; q < n; q += 64)
+            if (in(q)) { const double f = sqrt(fm_residual(F2, a[2 * q], a[2 * q + 1], b[2 * q], b[2 * q + 1])); s += f * f; }
+        return sqrt(wsum(s));
+    }
+    __device__ void jac_qr(const double* x, bsfm_lm::QrN<8>& Q) const
+    {
+        const double eps = sqrt(bsfm_lm::LM_EPSMCH);
+        double h[8], F2[9][9], xp[8];
+        project(x, F2[8]);
+        for (int j = 0; j < 8; ++j) {
+            h[j] = eps * fabs(x[j]); if (h[j] == 0.0) h[j] = eps;
+            for (int k = 0; k < 8; ++k) xp[k] = x[k];
+            xp[j] = x[j] + h[j];
+            project(xp, F2[j]);
+        }
+        Q.clear();
+        for (int q = lane; q < n; q += 64) {
+            if (!in(q)) continue;
+            const double rx = a[2 * q], ry = a[2 * q + 1], lx = b[2 * q], ly = b[2 * q + 1];
+            const double f0 = sqrt(fm_residual(F2[8], rx, ry, lx, ly));
+            double row[8];
+            for (int j = 0; j < 8; ++j) row[j] = (sqrt(fm_residual(F2[j], rx, ry, lx, ly)) - f0) / h[j];
+            Q.add_row(row, f0);
+        }
+        for (int s = 1; s < 64; s <<= 1) {
+            bsfm_lm::QrN<8> O;                                  // the partner's factor
+            for (int i = 0; i < 8; ++i) {
+                O.q[i] = __shfl_xor(Q.q[i], s, 64);
+                for (int j = 0; j < 8; ++j) O.r[i][j] = j >= i ? __shfl_xor(Q.r[i][j], s, 64) : 0.0;
+            }
+            const bool low = (lane & s) == 0;                   // this lane is the lower one of the pair
+            bsfm_lm::QrN<8> base, top;
+            for (int i = 0; i < 8; ++i) {
+                base.q[i] = low ? Q.q[i] : O.q[i]; top.q[i] = low ? O.q[i] : Q.q[i];
+                for (int j = 0; j < 8; ++j) { base.r[i][j] = low ? Q.r[i][j] : O.r[i][j]; top.r[i][j] = low ? O.r[i][j] : Q.r[i][j]; }
+            }
+            for (int i = 0; i < 8; ++i) {
+                double row[8];
+                for (int j = 0; j < 8; ++j) row[j] = top.r[i][j];
+                base.add_row(row, top.q[i]);
+            }
+            Q = base;
+        }
+    }
+};
+
+// One wave per pair (see FmFcnWave); count < 0 on entry marks a pair to skip.
+__global__ __launch_bounds__(64) void k_fm_refine_wave(int npairs, const int* __restrict__ match_ptr, const double* __restrict__ a_xy,
+        const double* __restrict__ b_xy, double threshold, double* __restrict__ F, int* __restrict__ count,
+        unsigned char* __restrict__ inlier, int* __restrict__ info_out)
+{
+    const int p = blockIdx.x, lane = threadIdx.x;
+    if (p >= npairs) return;
+    const int m0 = match_ptr[p], n = match_ptr[p + 1] - m0;
+    if (count[p] < 0) {                                         // uniform: every lane reads the same word
+        for (int q = lane; q < n; q += 64) inlier[m0 + q] = 0;
+        if (lane == 0) count[p] = 0;
+        return;
+    }
+    FmFcnWave fcn;
+    fcn.lane = lane;
+    fcn.a = a_xy + 2 * (size_t)m0; fcn.b = b_xy + 2 * (size_t)m0; fcn.n = n; fcn.thr = threshold;
+    for (int j = 0; j < 9; ++j) fcn.F0[j] = F[9 * (size_t)p + j];
+    fcn.scale = fcn.F0[8];
+    double mm = 0.0;
+    for (int q = lane; q < n; q += 64) mm += fcn.in(q) ? 1.0 : 0.0;
+    fcn.m = (int)FmFcnWave::wsum(mm);
+    double x[8];
+    for (int j = 0; j < 8; ++j) x[j] = fcn.F0[j];
+    const int info = bsfm_lm::lm_lmdif<8>(fcn, x, 1.0e-12);
+    double Fo[9];
+    fcn.project(x, Fo);
+    double c = 0.0;
+    for (int q = lane; q < n; q += 64) {
+        const bool in = fm_residual(Fo, fcn.a[2 * q], fcn.a[2 * q + 1], fcn.b[2 * q], fcn.b[2 * q + 1]) < threshold;
+        inlier[m0 + q] = in ? 1 : 0; c += in ? 1.0 : 0.0;
+    }
+    c = FmFcnWave::wsum(c);
+    __syncthreads();                                            // all lanes are done reading F0 / count before they are overwritten
+    if (lane == 0) {
+        for (int j = 0; j < 9; ++j) F[9 * (size_t)p + j] = Fo[j];
+        count[p] = (int)c;
+        if (info_out) info_out[p] = info;
+    }
+}
+
 // EstimateFMatrix after the RANSAC (src/Epipolar.cpp:153-231): inliers of F, refinement on them, inliers of the result.
-// One thread per pair; count < 0 on entry marks a pair to skip.
+// One thread per pair (kept as a cross-check, BSFM_FM_REFINE=thread); count < 0 on entry marks a pair to skip.
 __global__ __launch_bounds__(64) void k_fm_refine(int npairs, const int* __restrict__ match_ptr, const double* __restrict__ a_xy,
         const double* __restrict__ b_xy, double threshold, double* __restrict__ F, int* __restrict__ count,
         unsigned char* __restrict__ inlier, int* __restrict__ info_out)
@@ -460,7 +565,11 @@ extern "C" int bsfm_estimate_fmatrix_batch(int npairs, const int* match_ptr, con
         !din.alloc(nm) || !dptr.up(sptr.data(), ns + 1) || !dcnt.up(cnt.data(), ns) || !da.up(sa.data(), 2 * nm) || !db.up(sb.data(), 2 * nm) ||
         !dF.up(Fs.data(), 9 * (size_t)ns)) { fprintf(stderr, "[bsfm] estimate fmatrix: device allocation failed\n"); return BSFM_ERROR; }
     (void)hipMemset(dinfo.p, 0, ns * sizeof(int));
-    hipLaunchKernelGGL(k_fm_refine, dim3((ns + 63) / 64), dim3(64), 0, 0, ns, dptr.p, da.p, db.p, threshold, dF.p, dcnt.p, din.p, dinfo.p);
+    const char* er = getenv("BSFM_FM_REFINE");
+    if (er && !strcmp(er, "thread"))
+        hipLaunchKernelGGL(k_fm_refine, dim3((ns + 63) / 64), dim3(64), 0, 0, ns, dptr.p, da.p, db.p, threshold, dF.p, dcnt.p, din.p, dinfo.p);
+    else
+        hipLaunchKernelGGL(k_fm_refine_wave, dim3(ns), dim3(64), 0, 0, ns, dptr.p, da.p, db.p, threshold, dF.p, dcnt.p, din.p, dinfo.p);
     if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "[bsfm] estimate fmatrix: kernel failed\n"); return BSFM_ERROR; }
     std::vector<unsigned char> hin(nm);
     std::vector<int> hinfo(ns);
