@@ -678,3 +678,31 @@ def test_group_by_group_reduced_solve_matches_dense(gpu_bsfm, mcon):
         assert pb.phase_ms("groups") == 0
         out.append(pb.download(want_cams=False)[0]); pb.close()
     assert np.array_equal(out[0], out[1])
+
+
+@pytest.mark.gpu
+def test_group_solver_with_a_camera_that_sees_nothing(gpu_bsfm):
+    """A camera without observations is a group of its own (S_jj = mu I from the diagonal fill): the group-by-group solver
+    must treat it exactly like the dense path does."""
+    B = gpu_bsfm
+    m, n = 9, 120
+    base = B.synth_ba(m, n, 3)                       # cameras j0 + 3 d: three groups
+    ci = base["colidx"].reshape(n, 3); pr = base["proj"].reshape(n, 3, 2)
+    rows, proj, keep_pt = [], [], []
+    for i in range(n):
+        sel = [q for q in range(3) if ci[i, q] != 4]  # camera 4 loses every observation
+        if len(sel) >= 2:
+            rows.append(ci[i, sel]); proj.append(pr[i, sel]); keep_pt.append(i)
+    pts = base["pts"].reshape(-1, 3)[keep_pt].ravel()
+    rowptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    colidx = np.concatenate(rows).astype(np.int32); proj = np.concatenate(proj).ravel()
+    out = []
+    for mode in (B.SOLVER_DENSE, B.SOLVER_AUTO):
+        opt = B.default_options(jacobian=B.JAC_ANALYTIC, verbose=0, itmax=4, reduced_solver=mode)
+        pb = B.Problem(len(rows), m, rowptr, colidx, proj, base["cams"], pts, options=opt)
+        rc, info = pb.solve()
+        out.append((rc, list(info[5:10]), info[1], pb.download(want_cams=False)[0], pb.phase_ms("groups")))
+        pb.close()
+    assert out[0][4] == 0 and out[1][4] == 4         # three camera groups + the lonely camera
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    assert abs(out[0][2] - out[1][2]) <= 1e-12 * out[0][2] and np.abs(out[0][3] - out[1][3]).max() <= 1e-12
