@@ -484,6 +484,10 @@ __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __re
 // waits for its first two columns (9.5 vs 9.0 ms): the bulk stream idles while the chain and side streams prepare the
 // second panel of a pair, and their own kernels get heavier.)
 
+// (Tried and dropped: taking the tile inverse off the chain -- the chain kernel factors only, a side-stream launch inverts,
+// and the chain's own panel tile comes from a 16-row block substitution against L (8 workgroups, inverse diagonal blocks
+// from the factorisation).  Correct, but ~10 % slower at every size from 2 to 70 tile columns: the extra chain -> side
+// event hop (~12 us) and the separate 150 KB-LDS launch cost more than the 12.5 us of inverse they remove from the chain.)
 // Diagonal tile: Cholesky factor AND its inverse in ONE 512-thread workgroup -- the serial critical path of the
 // factorisation, so it is blocked to keep the truly serial work tiny:
 //   * the 128x128 tile lives in LDS (row stride 132 doubles) as 8x8 blocks of 16x16;
