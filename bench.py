@@ -8,10 +8,21 @@
 
 A "step" is ONE outer Levenberg-Marquardt iteration of the resident problem: Jacobian, U/V/ea/eb blocks, and
 at least one {Schur complement, dense Cholesky solve, back-substitution, cost evaluation} attempt, with the
-observations already resident in HBM.  The stop rules are disabled (eps1 = eps2 = eps3 = 0, eps5 < 0) so that
-exactly W + K iterations run; nothing inside an iteration is skipped.  Multi-GPU shards POINTS (with all their
+observations already resident in HBM.  The stop rules are disabled (eps1 = eps2 = eps3 = 0, eps5 < 0); the reference's
+rule 4 (eps4 = 0) cannot be, and fires once the problem has converged -- the problem is then reset to its initial parameters
+(`restarts_after_convergence` in the line) so that exactly W + K full iterations run; nothing inside an iteration is skipped.  Multi-GPU shards POINTS (with all their
 observations) across ranks, cameras are replicated, and the reduced camera system is summed with RCCL
 (torch.distributed "nccl") -- a fixed total problem, i.e. strong scaling.
+
+The collective is the library's own (bundler_sfm_amd/csrc/comm.hip: RCCL over xGMI, ncclCommInitRank from the launcher's
+RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT, all-reduces enqueued on the compute stream) -- no torch in the loop; the
+torch.distributed hook of round 1 remains only as a fallback when the communicator cannot be created (`collective` in the
+line says which one ran).
+
+Also in the line (N = 1): `cpu_baseline` (the reference's own SBA at the headline config from the committed
+profiles/*_cpu_baseline_cfg3.json measured on the GPU box's host, plus a small live sample of this run), `connected_scene`
+(the same size with banded visibility: a connected camera graph), `matcher` (BASELINE.json configs[4]: KeyMatchFull all-pairs,
+500 images x 5 000 keys, with its own roofline and CPU baseline).  `--workload match` prints the matcher line alone.
 
 Prints ONE JSON line on rank 0 (metric/value/roofline/cpu_baseline ...).
 """
@@ -46,7 +57,14 @@ def parse():
                     help="dense (default, the reference's algorithm: Cholesky of the whole reduced camera system) or auto "
                          "(independent camera groups solved separately when the scene has them)")
     ap.add_argument("--no-structure-aware", action="store_true", help="skip the extra (non-headline) run with the opt-in group-by-group reduced solve")
-    ap.add_argument("--cpu-sample", default="200,50000", help="cams,points of the bounded CPU-reference sample")
+    ap.add_argument("--cpu-sample", default="200,50000", help="cams,points of the bounded live CPU-reference sample")
+    ap.add_argument("--workload", choices=["ba", "match"], default="ba", help="ba (default, the headline metric) or match (KeyMatchFull, configs[4])")
+    ap.add_argument("--no-matcher", action="store_true", help="skip the matcher object of the BA line")
+    ap.add_argument("--no-connected", action="store_true", help="skip the connected-scene object of the BA line")
+    ap.add_argument("--match-images", type=int, default=500)
+    ap.add_argument("--match-keys", type=int, default=5000)
+    ap.add_argument("--match-cpu-pairs", type=int, default=60, help="image pairs of the bounded CPU (reference ANN) sample")
+    ap.add_argument("--collective", choices=["native", "torch"], default="native")
     return ap.parse_args()
 
 
@@ -107,49 +125,139 @@ def pmc_mfma(kernel):
 
 
 def cpu_baseline(sample):
-    """Reference SBA (oracle/_ref = the reference's own C sources) on a bounded sample, 1 thread."""
+    """`cpu_baseline` of the line.  Headline number: the reference's own SBA (oracle/_ref, lib/sba-1.5 -DTIMINGS + vendored CLAPACK,
+    one thread) AT 1 000 cameras / 500 000 points / 5 M observations, itmax = 3, measured once per round on the GPU box's host by
+    scripts/cpu_baseline_cfg3.py and committed as profiles/*_cpu_baseline_cfg3.json (one iteration takes minutes, so the default
+    run of this script cannot hold it: "cached").  Beside it a small LIVE sample timed in this very run."""
+    import glob
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_util as O
     import bundler_sfm_amd as B
-    if not O.have_ref():
-        return None
-    m, n = sample
-    s = B.synth_ba(m, n, 10)
-    vm = B.dense_vmask(n, m, s["rowptr"], s["colidx"])
-    itmax = 3
-    r = O.ref_sba(n, m, vm, s["proj"], s["cams"], s["pts"], itmax=itmax, jac_mode=0)
-    its = max(int(r["info"][5]), 1)
-    return {"value": its / r["secs"], "unit": "LM iterations/s", "cores": 1, "kind": "reference",
-            "sample": f"reference sba_motstr_levmar (FD Jacobian, vendored CLAPACK, gcc -O3), {m} cams / {n} pts / "
-                      f"{10 * n} obs, itmax={itmax}: {r['secs']:.1f} s wall = {1e3 * r['secs'] / its:.0f} ms/iter",
-            "host_cpus": os.cpu_count()}
+    out = None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_cpu_baseline_cfg3.json")))
+    if files:
+        try:
+            d = json.load(open(files[-1]))
+            c = d["config"]
+            out = {"value": d["iterations_per_s"], "unit": "LM iterations/s", "cores": 1, "kind": "reference", "cached": True,
+                   "source": "profiles/" + os.path.basename(files[-1]),
+                   "sample": f"reference sba_motstr_levmar (FD Jacobian, -DTIMINGS, vendored CLAPACK, gcc -O3, 1 thread) at "
+                             f"{c['cameras']} cams / {c['points']} pts / {c['observations']} obs, itmax={c['itmax']}: "
+                             f"{d['sba_s']:.0f} s = {d['ms_per_iteration']:.0f} ms/iter on {d['host_cpu']} ({d['host_cpus']} cpus); "
+                             "measured on the GPU box's host by scripts/cpu_baseline_cfg3.py, cached because one iteration takes minutes",
+                   "ms_per_iteration": d["ms_per_iteration"], "phases_s_mean": d.get("phases_s_mean"), "host_cpu": d["host_cpu"]}
+        except Exception as exc:
+            out = {"error": "cached headline baseline unreadable: " + repr(exc)}
+    live = None
+    if O.have_ref():
+        m, n = sample
+        s = B.synth_ba(m, n, 10)
+        vm = B.dense_vmask(n, m, s["rowptr"], s["colidx"])
+        itmax = 3
+        r = O.ref_sba(n, m, vm, s["proj"], s["cams"], s["pts"], itmax=itmax, jac_mode=0)
+        its = max(int(r["info"][5]), 1)
+        live = {"value": round(its / r["secs"], 4), "unit": "LM iterations/s", "cores": 1, "kind": "reference",
+                "sample": f"live in this run: {m} cams / {n} pts / {10 * n} obs, itmax={itmax}: {r['secs']:.1f} s = "
+                          f"{1e3 * r['secs'] / its:.0f} ms/iter", "host_cpus": os.cpu_count()}
+    if out is None:
+        return live
+    out["live_sample"] = live
+    return out
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    torch = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+I8_MFMA_PEAK_TOPS = 3944.0     # v_mfma_i32_16x16x64_i8, measured ceiling (MI355X_MICROARCH.md, matrix-core table)
 
+
+def synth_key_set(B, images, nkeys):
+    import ctypes as C
+    U = C.POINTER(C.c_ubyte)
+    keys, prev = [], None
+    for i in range(images):
+        k = np.zeros((nkeys, 128), np.uint8)
+        B.lib.bsfm_synth_keys(nkeys, 9000 + i, None if prev is None else prev.ctypes.data_as(U), 0 if prev is None else len(prev),
+                              k.ctypes.data_as(U))
+        keys.append(k); prev = k
+    return keys
+
+
+def matcher_leg(args, passes=1):
+    """BASELINE.json configs[4]: KeyMatchFull, `images` x `nkeys` SIFT-like keys, all pairs (j < i), 128-D uchar L2 2-NN + ratio
+    test, text output as the reference writes it.  A step = one pass over all pairs with the descriptors resident in HBM.
+    roofline: int8 MFMA ops (2 x 128 per descriptor distance) of the k_match_l2 launches over their HIP-event time."""
+    import ctypes as C
+    import tempfile
     import bundler_sfm_amd as B
-    if B.lib.bsfm_device_count() <= 0:
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    if world > 1:
-        # the library resolves the current device through the HIP runtime torch already initialised
-        pass
+    U = C.POINTER(C.c_ubyte)
+    images, nkeys = args.match_images, args.match_keys
+    t0 = time.perf_counter()
+    keys = synth_key_set(B, images, nkeys)
+    t_gen = time.perf_counter() - t0
+    arr = (U * images)(*[k.ctypes.data_as(U) for k in keys])
+    nks = np.full(images, nkeys, np.int32)
+    t0 = time.perf_counter()
+    ms = B.lib.bsfm_match_set_create(images, nks.ctypes.data_as(C.POINTER(C.c_int)), arr)
+    if not ms:
+        raise RuntimeError("bsfm_match_set_create failed")
+    t_up = time.perf_counter() - t0
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    out_path = os.path.join(tmpdir, f"bsfm_bench_matches_{os.getpid()}.txt").encode()
+    pairs_total = images * (images - 1) // 2
+    # warm-up on the same set (first launch: code object load), then `passes` timed whole passes
+    B.lib.bsfm_match_set_run(ms, 0.6, 3, out_path, 0, 1)
+    B.lib.bsfm_device_synchronize()
+    t0 = time.perf_counter()
+    blocks = 0
+    for _ in range(passes):
+        blocks = B.lib.bsfm_match_set_run(ms, 0.6, -1, out_path, 0, 1)
+    B.lib.bsfm_device_synchronize()
+    el = (time.perf_counter() - t0) / passes
+    kms, dist, npairs, nl = C.c_double(), C.c_double(), C.c_longlong(), C.c_int()
+    B.lib.bsfm_match_set_stats(ms, C.byref(kms), C.byref(dist), C.byref(npairs), C.byref(nl))
+    B.lib.bsfm_match_set_destroy(ms)
+    size = os.path.getsize(out_path)
+    os.unlink(out_path)
+    ops = dist.value * 256.0
+    ach = ops / (kms.value * 1e-3) / 1e12 if kms.value > 0 else None
+    out = {"metric": "KeyMatchFull image pairs/sec", "value": round(pairs_total / el, 1), "unit": "image pairs/s",
+           "ms_per_step": round(1e3 * el, 2), "steps": passes, "dtype": "u8 (int8 MFMA, int32 accumulation)", "data": "synthetic",
+           "config": {"workload": f"KeyMatchFull all pairs, {images} images x {nkeys} keys (BASELINE.json configs[4]), ratio 0.6, "
+                                  "exact 2-NN, matches.init.txt written", "images": images, "keys_per_image": nkeys,
+                      "image_pairs": pairs_total, "pair_blocks_written": blocks, "output_bytes": size,
+                      "key_generation_s": round(t_gen, 2), "upload_and_stats_s": round(t_up, 3)},
+           "roofline": None if ach is None else {
+               "bound": "mfma", "kernel": "k_match_l2", "achieved": round(ach, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
+               "frac": round(ach / I8_MFMA_PEAK_TOPS, 4), "traffic": None,
+               "alg_ops_per_launch": ops / max(nl.value, 1), "launches": nl.value, "avg_launch_ms": round(kms.value / max(nl.value, 1), 4),
+               "kernel_ms_per_pass": round(kms.value, 2), "us_per_image_pair": round(1e3 * kms.value / max(npairs.value, 1), 3),
+               "note": "achieved = 2 x 128 int8 ops per descriptor distance x distances of the launches / HIP-event time of the launches "
+                       "(match_l2.hip); peak = measured v_mfma_i32_16x16x64_i8 ceiling; compulsory HBM traffic is the 320 MB key set "
+                       "(L2 / Infinity Cache resident), so the kernel is compute-bound"}}
+    # CPU baseline: the reference's own matcher (ANN kd-tree priority search, 200 visits, src/keys2a.cpp:347-372) on a bounded
+    # sample of the same pairs, 1 thread; tree construction per database image included as in KeyMatchFull's loop
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_util as O
+        if os.path.exists(O.REF_KM_PATH):
+            secs, cnt = 0.0, 0
+            i = images - 1
+            while cnt < args.match_cpu_pairs and i > 0:
+                for j in range(min(i, 4)):
+                    t1 = time.perf_counter()
+                    O.ref_match(keys[j], keys[i], 0.6, 200)
+                    secs += time.perf_counter() - t1; cnt += 1
+                i -= 1
+            out["cpu_baseline"] = {"value": round(cnt / secs, 3), "unit": "image pairs/s", "cores": 1, "kind": "reference",
+                                   "sample": f"reference MatchKeys (ANN kd-tree, 200-visit priority search) on {cnt} of the {pairs_total} "
+                                             f"pairs, tree build included: {secs:.1f} s", "host_cpus": os.cpu_count()}
+    except Exception as exc:
+        out["cpu_baseline"] = {"error": repr(exc)}
+    return out
 
-    m, n, deg = args.cams, args.points, args.deg
-    s = B.synth_ba(m, n, deg)
+
+def run_ba(B, args, s, world, rank, comm, hook_setup, sync, reduced_solver, jac, label):
+    """One timed BA run on scene `s`; returns (dict for the line, Problem timing extras)."""
+    import ctypes as C
+    m, n = args.cams, args.points
     nvis_global = int(s["rowptr"][-1])
     cnp = 9
     lo, hi = shard_points(s["rowptr"], world, rank)
@@ -158,16 +266,84 @@ def main():
     ci = s["colidx"][k0:k1]
     pr = s["proj"][2 * k0:2 * k1]
     pts = s["pts"][3 * lo:3 * hi]
-    opt = B.default_options(jacobian=B.JAC_FD if args.jacobian == "fd" else B.JAC_ANALYTIC, verbose=0,
-                            itmax=args.warmup + args.steps + 1000,
-                            opts=[1e-3, 0.0, 0.0, 0.0, 0.0, -1.0],
-                            reduced_solver=B.SOLVER_AUTO if args.reduced_solver == "auto" else B.SOLVER_DENSE)
+    opt = B.default_options(jacobian=jac, verbose=0, itmax=args.warmup + args.steps + 1000,
+                            opts=[1e-3, 0.0, 0.0, 0.0, 0.0, -1.0], reduced_solver=reduced_solver)
     t_create = time.time()
     pb = B.Problem(hi - lo, m, rp, ci, pr, s["cams"], pts, options=opt, world_size=world, rank=rank,
                    nvis_global=nvis_global, nvars_global=m * cnp + 3 * n)
     t_create = time.time() - t_create
-
     if world > 1:
+        if comm:
+            B.lib.bsfm_problem_set_comm(pb.h, comm)
+        else:
+            hook_setup(pb)
+    if pb.lm_begin() != 0:
+        raise SystemExit("lm_begin failed")
+
+    def iterate_exactly(k):
+        """Runs exactly k LM iterations.  The stop rules are disabled except the reference's rule 4 (eps4 = 0,
+        sba_levmar.c:1567), which fires on rounding noise once the problem has converged (after ~20 iterations on this scene):
+        the problem is then put back to its initial parameters and iterating goes on, so every counted step is a full
+        iteration on live data."""
+        done_, restarts_, att_, stop_ = 0, 0, 0, 0
+        while done_ < k:
+            before = int(pb.lm_finish()[1][5]); a0 = pb.attempts()
+            stop_ = pb.lm_iterate(k - done_)
+            done_ += int(pb.lm_finish()[1][5]) - before; att_ += pb.attempts() - a0
+            if done_ < k:
+                if pb.reset_params(s["cams"], pts) != 0 or pb.lm_begin() != 0:
+                    raise SystemExit("restart failed")
+                restarts_ += 1
+                if restarts_ > k:
+                    break
+        return done_, restarts_, att_, stop_
+
+    iterate_exactly(args.warmup)
+    sync()
+    t0 = time.perf_counter()
+    done, restarts, att, stop = iterate_exactly(args.steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    rc, info = pb.lm_finish()
+    return dict(pb=pb, elapsed=elapsed, done=done, stop=stop, att=att, info=info, t_create=t_create, lo=lo, hi=hi, rp=rp, k0=k0, k1=k1,
+                nvis_global=nvis_global, restarts=restarts)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import ctypes as C
+    import bundler_sfm_amd as B
+    if B.lib.bsfm_device_count() <= 0:
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if args.workload == "match":
+        if rank == 0:
+            print(json.dumps(dict(matcher_leg(args, passes=max(1, args.steps // 4)), n_gpus=1, higher_is_better=True, scaling="weak",
+                                  vs_baseline=None)))
+        return
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    # ---- collective: the library's own communicator (comm.hip, RCCL over xGMI); torch hook only as a fallback
+    comm, dist, torch, collective = None, None, None, "none"
+    if world > 1:
+        if args.collective == "native":
+            comm = B.lib.bsfm_comm_create_from_env()
+            if comm:
+                collective = "library communicator: " + B.lib.bsfm_comm_transport(comm).decode() + " (ncclAllReduce enqueued on the compute stream)"
+            elif rank == 0:
+                print("[bench] WARNING: library communicator unavailable, falling back to the torch.distributed hook", file=sys.stderr)
+        if not comm:
+            import torch
+            import torch.distributed as dist
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            collective = "torch.distributed all_reduce hook (fallback)"
+
+    def hook_setup(pb):
         def hook(dev_ptr, count, op, _ctx):
             class _Buf:
                 __cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (dev_ptr, False), "version": 2}
@@ -178,31 +354,35 @@ def main():
         pb.set_allreduce(hook)
 
     def sync():
+        B.lib.bsfm_device_synchronize()
         if world > 1:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-        else:
+            if comm:
+                B.lib.bsfm_comm_barrier(comm)
+            else:
+                torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
             B.lib.bsfm_device_synchronize()
 
-    if pb.lm_begin() != 0:
-        raise SystemExit("lm_begin failed")
-    pb.lm_iterate(args.warmup)
-    att0 = pb.attempts()
-    sync()
-    t0 = time.perf_counter()
-    stop = pb.lm_iterate(args.steps)
-    sync()
-    elapsed = time.perf_counter() - t0
-    att = pb.attempts() - att0
-    rc, info = pb.lm_finish()
-    done = int(info[5]) - args.warmup
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+    def max_over_ranks(v):
+        if world == 1:
+            return v
+        if comm:
+            buf = (C.c_double * 1)(v)
+            B.lib.bsfm_comm_allreduce_host(comm, buf, 1, 1)
+            return float(buf[0])
+        tt = torch.tensor([v], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        return float(tt.item())
+
+    m, n, deg = args.cams, args.points, args.deg
+    cnp = 9
+    jac = B.JAC_FD if args.jacobian == "fd" else B.JAC_ANALYTIC
+    s = B.synth_ba(m, n, deg)
+    r = run_ba(B, args, s, world, rank, comm, hook_setup, sync, B.SOLVER_AUTO if args.reduced_solver == "auto" else B.SOLVER_DENSE, jac, "headline")
+    pb, info, done = r["pb"], r["info"], r["done"]
+    elapsed = max_over_ranks(r["elapsed"])
+    nvis_global = r["nvis_global"]
     if done != args.steps:
-        print(f"[bench] WARNING: ran {done} of {args.steps} steps (stop={stop})", file=sys.stderr)
+        print(f"[bench] WARNING: rank {rank} ran {done} of {args.steps} steps (stop={r['stop']})", file=sys.stderr)
 
     if rank == 0:
         sdim = m * cnp
@@ -213,29 +393,38 @@ def main():
         roof = None
         if syrk_ms and syrk_ms > 0:
             lib_gflop = pb.phase_ms("syrk_gflop")       # the library's own count of what it launched
-            assert abs(lib_gflop * 1e9 - flops_launch) <= 1e-9 * flops_launch, (lib_gflop, flops_launch)
-            ach = flops_launch / (syrk_ms * 1e-3) / 1e12
+            lib_flops = lib_gflop * 1e9
+            ach = lib_flops / (syrk_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "k_syrk_update", "achieved": round(ach, 3), "peak": FP64_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic("k_syrk_update"),
                     "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                     "this command (scripts/profile_round.sh -> profiles/*_pmc_traffic.json; 2 x FETCH_SIZE "
-                                    "per the gfx950 correction); algorithmic C traffic is 2 x 128 KB per tile",
-                    "mfma_counters": pmc_mfma("k_syrk_update"), "launches_per_solve": nlaunch, "avg_launch_ms": round(syrk_ms, 4),
-                    "alg_flop_per_launch": flops_launch}
+                                    "per the gfx950 correction), NOT measured in this run; algorithmic C traffic is 2 x 128 KB per tile",
+                    "mfma_counters": pmc_mfma("k_syrk_update"), "launches_per_solve": pb.phase_ms("syrk_launches"), "avg_launch_ms": round(syrk_ms, 4),
+                    "alg_flop_per_launch": lib_flops,
+                    "whole_factorisation": {"flop": sdim ** 3 / 3.0, "solve_ms": phases["solve"],
+                                            "TFLOPs": round(sdim ** 3 / 3.0 / (phases["solve"] * 1e-3) / 1e12, 2) if phases["solve"] > 0 else None,
+                                            "frac": round(sdim ** 3 / 3.0 / (phases["solve"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if phases["solve"] > 0 else None}}
         # HBM-bound streaming kernels against the 8 TB/s roof: algorithmic bytes / HIP-event time
-        nv_loc, np_loc, js = float(k1 - k0), float(hi - lo), 2 * cnp + 6
+        rp = r["rp"]
+        nv_loc, np_loc, js = float(r["k1"] - r["k0"]), float(r["hi"] - r["lo"]), 2 * cnp + 6
         deg2 = float(np.sum(np.diff(rp).astype(np.float64) * (np.diff(rp) + 1) / 2))        # co-visibility triples
         alg = {"jacobian": nv_loc * (8 * js + 8 + 24), "cam_blocks": nv_loc * (16 * cnp + 16 + 4),
                "point_blocks": nv_loc * (48 + 16 + 4) + np_loc * 72, "backsub": nv_loc * (8 * js + 8) + np_loc * 120,
-               "residual": nv_loc * 56, "schur": deg2 * (2 * 8 * js + 48) + nv_loc * 24}
+               "residual": nv_loc * 56}
         hbm = {}
         for ph, nbytes in alg.items():
             ms = phases.get(ph, 0.0)
             if ms and ms > 0:
                 gbs = nbytes / (ms * 1e-3) / 1e9
                 hbm[ph] = {"alg_GB": round(nbytes / 1e9, 3), "ms": ms, "GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / 8000.0, 3)}
-        hbm["note"] = ("algorithmic bytes per phase over its HIP-event time; schur counts the record gathers of all co-visibility "
-                       "triples (served by L2/Infinity Cache: its unique footprint is the 8*js bytes per observation)")
+        hbm["note"] = "algorithmic bytes per phase (DESIGN.md section 4) over its HIP-event time"
+        schur_flop = deg2 * 486.0                       # 486 flop per co-visibility pair with the symmetry used
+        schur = {"ms": phases["schur"], "triples": deg2, "useful_flop": schur_flop,
+                 "TFLOPs": round(schur_flop / (phases["schur"] * 1e-3) / 1e12, 2) if phases["schur"] > 0 else None,
+                 "frac_of_fp64_peak": round(schur_flop / (phases["schur"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if phases["schur"] > 0 else None,
+                 "unique_footprint_GB": round((nv_loc * 8 * js + np_loc * 72) / 1e9, 3),
+                 "note": "record gathers of the triples are served by L2 / Infinity Cache; against HBM only the unique footprint counts"}
         out = {
             "metric": "BA LM iterations/sec", "value": round(done / elapsed, 4), "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -244,9 +433,12 @@ def main():
             "config": {"workload": f"synthetic BA {m} cams / {n} pts / {nvis_global} obs (BASELINE.json configs[2]), "
                                    f"cnp=9, {args.jacobian} Jacobian, point-sharded x{world}",
                        "cameras": m, "points": n, "observations": nvis_global, "jacobian": args.jacobian,
-                       "reduced_solver": args.reduced_solver,
-                       "solve_attempts_per_step": round(att / max(done, 1), 3), "problem_create_s": round(t_create, 2)},
-            "phases_ms": phases, "hbm_kernels": hbm, "final_cost": info[1], "initial_cost": info[0],
+                       "reduced_solver": args.reduced_solver, "collective": collective,
+                       "solve_attempts_per_step": round(r["att"] / max(done, 1), 3), "restarts_after_convergence": r["restarts"],
+                       "problem_create_s": round(r["t_create"], 3),
+                       "problem_create_ms": {k: round(pb.phase_ms("create_" + k), 2) for k in ("total", "upload", "index", "alloc")},
+                       "index_build_device_ms": round(pb.phase_ms("index_build"), 3)},
+            "phases_ms": phases, "hbm_kernels": hbm, "schur": schur, "final_cost": info[1], "initial_cost": info[0],
             "roofline": roof,
         }
         if not args.no_cpu_baseline and world == 1:
@@ -256,33 +448,55 @@ def main():
                 out["cpu_baseline"] = {"error": repr(exc)}
         else:
             out["cpu_baseline"] = None
-        if world == 1 and not args.no_structure_aware and args.reduced_solver == "dense":
+    pb.close()
+
+    if world == 1 and rank == 0:
+        if not args.no_structure_aware and args.reduced_solver == "dense":
             # NOT the headline: the same problem with the opt-in group-by-group reduced solve (compsolve.hip.h).  This
             # generator's cameras fall into m/deg groups that share no point, so S is block diagonal up to a permutation;
             # `value` above is measured with the reference's algorithm (dense Cholesky of the whole S).
             try:
-                opt2 = B.default_options(jacobian=opt.jacobian, verbose=0, itmax=opt.itmax, opts=list(opt.opts),
-                                         reduced_solver=B.SOLVER_AUTO)
-                pb2 = B.Problem(hi - lo, m, rp, ci, pr, s["cams"], pts, options=opt2)
-                pb2.lm_begin(); pb2.lm_iterate(args.warmup)
-                B.lib.bsfm_device_synchronize()
-                t1 = time.perf_counter(); pb2.lm_iterate(args.steps); B.lib.bsfm_device_synchronize()
-                el2 = time.perf_counter() - t1
-                _, info2 = pb2.lm_finish()
-                d2 = int(info2[5]) - args.warmup
+                r2 = run_ba(B, args, s, 1, 0, None, None, lambda: B.lib.bsfm_device_synchronize(), B.SOLVER_AUTO, jac, "structure_aware")
+                pb2, info2, d2 = r2["pb"], r2["info"], r2["done"]
                 out["structure_aware"] = {"reduced_solver": "auto (independent camera groups, one workgroup each)",
-                                          "iterations_per_s": round(d2 / el2, 3), "ms_per_step": round(1e3 * el2 / max(d2, 1), 4),
+                                          "iterations_per_s": round(d2 / r2["elapsed"], 3), "ms_per_step": round(1e3 * r2["elapsed"] / max(d2, 1), 4),
                                           "solve_ms": round(pb2.phase_ms("solve"), 4), "schur_ms": round(pb2.phase_ms("schur"), 4),
                                           "final_cost": info2[1],
                                           "final_cost_rel_diff_vs_dense": abs(info2[1] - info[1]) / info[1]}
                 pb2.close()
             except Exception as exc:
                 out["structure_aware"] = {"error": repr(exc)}
+        if not args.no_connected:
+            # Second scene of the same size whose camera graph is CONNECTED (banded visibility: every point is seen from a window of
+            # 50 neighbouring cameras), so the reduced camera system is a band and not 100 independent cliques: different Schur
+            # task mix (more, smaller blocks), nothing for a structure-aware solver to exploit.  Dense reduced solve.
+            try:
+                sb = B.synth_ba(m, n, deg, banded=True)
+                r3 = run_ba(B, args, sb, 1, 0, None, None, lambda: B.lib.bsfm_device_synchronize(), B.SOLVER_DENSE, jac, "connected")
+                pb3, info3, d3 = r3["pb"], r3["info"], r3["done"]
+                sc = pb3.export_schur()
+                out["connected_scene"] = {"workload": f"banded visibility (window of 50 cameras), {m} cams / {n} pts / {int(sb['rowptr'][-1])} obs, dense reduced solve",
+                                          "iterations_per_s": round(d3 / r3["elapsed"], 3), "ms_per_step": round(1e3 * r3["elapsed"] / max(d3, 1), 4),
+                                          "steps": d3, "solve_attempts_per_step": round(r3["att"] / max(d3, 1), 3),
+                                          "phases_ms": {ph: round(pb3.phase_ms(ph), 4) for ph in ("jacobian", "cam_blocks", "point_blocks", "schur", "solve", "backsub", "residual")},
+                                          "reduced_camera_blocks": int(len(sc["blk_j"])), "schur_tasks": int(sc["ntasks"]),
+                                          "initial_cost": info3[0], "final_cost": info3[1], "problem_create_s": round(r3["t_create"], 3)}
+                pb3.close()
+            except Exception as exc:
+                out["connected_scene"] = {"error": repr(exc)}
+        if not args.no_matcher:
+            try:
+                out["matcher"] = matcher_leg(args, passes=1)
+            except Exception as exc:
+                out["matcher"] = {"error": repr(exc)}
+    if rank == 0:
         print(json.dumps(out))
-    pb.close()
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        sync()
+        if comm:
+            B.lib.bsfm_comm_destroy(comm)
+        else:
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

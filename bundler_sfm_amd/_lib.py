@@ -28,7 +28,7 @@ class CameraParams(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("jacobian", C.c_int), ("itmax", C.c_int), ("verbose", C.c_int),
-                ("opts", C.c_double * 6), ("potrf_backend", C.c_int), ("reduced_solver", C.c_int)]
+                ("opts", C.c_double * 6), ("potrf_backend", C.c_int), ("reduced_solver", C.c_int), ("num_gpus", C.c_int)]
 
 
 class RandState(C.Structure):
@@ -68,12 +68,16 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 # every symbol include/bsfm.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
     "bsfm_default_options", "run_sfm", "bsfm_run_sfm_ex", "bsfm_sba_motstr_levmar", "bsfm_sba_mot_levmar", "bsfm_problem_create", "bsfm_problem_destroy",
+    "bsfm_comm_create_from_env", "bsfm_comm_create_all", "bsfm_comm_destroy", "bsfm_comm_rank", "bsfm_comm_world", "bsfm_comm_transport",
+    "bsfm_comm_allreduce", "bsfm_comm_allreduce_host", "bsfm_comm_barrier", "bsfm_problem_set_comm",
     "bsfm_problem_set_allreduce", "bsfm_problem_set_stream", "bsfm_problem_reset_params", "bsfm_lm_begin",
     "bsfm_lm_iterate", "bsfm_lm_finish", "bsfm_lm_solve_attempts", "bsfm_lm_last_kernel_ms",
-    "bsfm_problem_download", "bsfm_problem_cnp", "bsfm_problem_nvis", "bsfm_eval_residuals", "bsfm_problem_outlier_stats", "bsfm_problem_ray_angles", "bsfm_triangulate_batch", "bsfm_rand_seed", "bsfm_rand_next", "bsfm_fmatrix_ransac_batch",
+    "bsfm_problem_download", "bsfm_problem_export_index", "bsfm_problem_schur_sizes", "bsfm_problem_export_schur", "bsfm_crs_from_vmask",
+    "bsfm_problem_cnp", "bsfm_problem_nvis", "bsfm_eval_residuals", "bsfm_problem_outlier_stats", "bsfm_problem_ray_angles", "bsfm_triangulate_batch", "bsfm_rand_seed", "bsfm_rand_next", "bsfm_fmatrix_ransac_batch",
     "bsfm_estimate_fmatrix_batch",
     "bsfm_eval_normal_equations", "bsfm_dense_chol_solve", "bsfm_match_keys_l2", "bsfm_key_match_full",
-    "bsfm_key_match_full_sharded", "bsfm_merge_match_files",
+    "bsfm_key_match_full_sharded", "bsfm_merge_match_files", "bsfm_match_set_create", "bsfm_match_set_run", "bsfm_match_set_stats",
+    "bsfm_match_set_destroy",
     "bsfm_device_count", "bsfm_version", "bsfm_device_synchronize", "bsfm_synth_ba", "bsfm_synth_keys",
 ]
 
@@ -148,6 +152,53 @@ def _load():
     lib.bsfm_match_keys_l2.restype = C.c_int
     lib.bsfm_key_match_full.argtypes = [C.c_int, ip, C.POINTER(ucp), C.c_double, C.c_int, C.c_char_p]
     lib.bsfm_key_match_full.restype = C.c_int
+    lib.bsfm_key_match_full_sharded.argtypes = [C.c_int, ip, C.POINTER(ucp), C.c_double, C.c_int, C.c_char_p, C.c_int, C.c_int]
+    lib.bsfm_key_match_full_sharded.restype = C.c_int
+    lib.bsfm_merge_match_files.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_char_p]
+    lib.bsfm_merge_match_files.restype = C.c_int
+    lib.bsfm_match_set_create.argtypes = [C.c_int, ip, C.POINTER(ucp)]
+    lib.bsfm_match_set_create.restype = vp
+    lib.bsfm_match_set_run.argtypes = [vp, C.c_double, C.c_int, C.c_char_p, C.c_int, C.c_int]
+    lib.bsfm_match_set_run.restype = C.c_int
+    lib.bsfm_match_set_stats.argtypes = [vp, dp, dp, C.POINTER(C.c_longlong), ip]
+    lib.bsfm_match_set_stats.restype = C.c_int
+    lib.bsfm_match_set_destroy.argtypes = [vp]
+    lib.bsfm_match_set_destroy.restype = None
+    lib.bsfm_comm_create_from_env.argtypes = []
+    lib.bsfm_comm_create_from_env.restype = vp
+    lib.bsfm_comm_create_all.argtypes = [C.c_int, ip, C.POINTER(vp)]
+    lib.bsfm_comm_create_all.restype = C.c_int
+    lib.bsfm_comm_destroy.argtypes = [vp]
+    lib.bsfm_comm_destroy.restype = None
+    lib.bsfm_comm_rank.argtypes = [vp]
+    lib.bsfm_comm_rank.restype = C.c_int
+    lib.bsfm_comm_world.argtypes = [vp]
+    lib.bsfm_comm_world.restype = C.c_int
+    lib.bsfm_comm_transport.argtypes = [vp]
+    lib.bsfm_comm_transport.restype = C.c_char_p
+    lib.bsfm_comm_allreduce.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
+    lib.bsfm_comm_allreduce.restype = C.c_int
+    lib.bsfm_comm_allreduce_host.argtypes = [vp, dp, C.c_int, C.c_int]
+    lib.bsfm_comm_allreduce_host.restype = C.c_int
+    lib.bsfm_comm_barrier.argtypes = [vp]
+    lib.bsfm_comm_barrier.restype = C.c_int
+    lib.bsfm_problem_set_comm.argtypes = [vp, vp]
+    lib.bsfm_problem_set_comm.restype = None
+    ccp, pcp = C.POINTER(CameraConstraints), C.POINTER(PointConstraints)
+    lib.bsfm_sba_motstr_levmar.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, dp, C.c_int, C.c_int, dp, dp, C.c_int, C.c_int, vp,
+                                           C.c_int, C.c_int, dp, dp, C.c_int, ccp, C.c_int, pcp, dp, dp, dp, dp]
+    lib.bsfm_sba_motstr_levmar.restype = C.c_int
+    lib.bsfm_sba_mot_levmar.argtypes = [C.c_int, C.c_int, C.c_int, C.c_char_p, dp, C.c_int, dp, dp, C.c_int, C.c_int, vp,
+                                        C.c_int, C.c_int, dp, dp, C.c_int, ccp]
+    lib.bsfm_sba_mot_levmar.restype = C.c_int
+    lib.bsfm_problem_export_index.argtypes = [vp, ip, ip, ip, ip, ip, ip, ip, ip]
+    lib.bsfm_problem_export_index.restype = C.c_int
+    lib.bsfm_problem_schur_sizes.argtypes = [vp, ip, ip, ip, ip]
+    lib.bsfm_problem_schur_sizes.restype = C.c_int
+    lib.bsfm_problem_export_schur.argtypes = [vp, ip, ip, ip, ip, ip, ip]
+    lib.bsfm_problem_export_schur.restype = C.c_int
+    lib.bsfm_crs_from_vmask.argtypes = [C.c_int, C.c_int, C.c_char_p, ip, ip]
+    lib.bsfm_crs_from_vmask.restype = C.c_int
     lib.bsfm_device_count.argtypes = []
     lib.bsfm_device_count.restype = C.c_int
     lib.bsfm_device_synchronize.argtypes = []

@@ -16,6 +16,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <thread>
+#include <algorithm>
+#include <hip/hip_runtime_api.h>
 #include "../../include/bsfm.h"
 
 namespace {
@@ -60,9 +63,100 @@ void export_blocks(bsfm_problem_t* pb, int n, int mcon, int cnp, const std::vect
     }
 }
 
+// ---- run_sfm on several GPUs of this node, inside one process -------------------------------------------------
+// Points -- with all their observations -- are dealt to the ranks in contiguous ranges balanced by sum d_i^2 (the Schur work);
+// the cameras are replicated; one host thread per GPU drives its shard's LM loop; U || ea, the packed union of the
+// reduced-camera blocks || E and a few scalars are summed with RCCL over xGMI (comm.hip) on the compute streams; every rank
+// factors the same reduced camera system, so the replicas stay bit-identical and no broadcast is needed.
+struct MultiArgs {
+    int n, m, ncons; const std::vector<int>* rowptr; const std::vector<int>* colidx; const double* projections;
+    int est_focal_length, undistort, explicit_camera_centers;
+    bsfm_camera_params_t* cams; double* pts;
+    int use_constraints, use_point_constraints; const double* point_constraints; double point_constraint_weight;
+    int optimize_for_fisheye;
+};
+
+int run_multi(int G, const std::vector<int>& devs, const MultiArgs& a, const bsfm_options_t& opt, double info[BSFM_INFOSZ])
+{
+    const int n = a.n, m = a.m;
+    const std::vector<int>& rp = *a.rowptr; const std::vector<int>& ci = *a.colidx;
+    const int cnp = (a.est_focal_length ? 7 : 6) + (a.undistort ? 2 : 0);
+    std::vector<int> bounds((size_t)G + 1, n);
+    {
+        std::vector<double> w((size_t)n + 1, 0.0);
+        for (int i = 0; i < n; ++i) { const double d = rp[i + 1] - rp[i]; w[i + 1] = w[i] + d * d; }
+        bounds[0] = 0;
+        for (int g = 1; g < G; ++g)
+            bounds[g] = (int)(std::lower_bound(w.begin() + 1, w.end(), w[n] * g / G) - (w.begin() + 1));
+        for (int g = 1; g <= G; ++g) bounds[g] = std::max(bounds[g], bounds[g - 1]);
+    }
+    std::vector<bsfm_comm_t*> comms((size_t)G, nullptr);
+    if (bsfm_comm_create_all(G, devs.data(), comms.data()) != 0) { fprintf(stderr, "[bsfm] run_sfm: cannot set up the %d-GPU communicator\n", G); return BSFM_ERROR; }
+    std::vector<int> rcs((size_t)G, BSFM_ERROR);
+    std::vector<std::vector<double>> infos((size_t)G, std::vector<double>(BSFM_INFOSZ, 0.0));
+    std::vector<bsfm_camera_params_t> cam_out((size_t)m);
+    auto worker = [&](int g) {
+        if (hipSetDevice(devs[g]) != hipSuccess) return;
+        const int lo = bounds[g], hi = bounds[g + 1], k0 = rp[lo];
+        std::vector<int> lrp((size_t)(hi - lo) + 1);
+        for (int i = lo; i <= hi; ++i) lrp[i - lo] = rp[i] - k0;
+        bsfm_problem_desc_t d;
+        memset(&d, 0, sizeof(d));
+        d.n = hi - lo; d.m = m; d.mcon = a.ncons;
+        d.rowptr = lrp.data(); d.colidx = ci.data() + k0; d.projections = a.projections + 2 * (size_t)k0;
+        d.est_focal_length = a.est_focal_length; d.undistort = a.undistort; d.explicit_camera_centers = a.explicit_camera_centers;
+        d.cameras = a.cams; d.points = a.pts + 3 * (size_t)lo;
+        d.use_constraints = a.use_constraints; d.use_point_constraints = a.use_point_constraints;
+        d.point_constraints = a.point_constraints ? a.point_constraints + 3 * (size_t)lo : nullptr;
+        d.point_constraint_weight = a.point_constraint_weight;
+        d.optimize_for_fisheye = a.optimize_for_fisheye;
+        d.world_size = G; d.rank = g; d.nvis_global = (long long)ci.size(); d.nvars_global = (long long)m * cnp + 3LL * n;
+        bsfm_options_t o = opt;
+        if (g != 0) o.verbose = 0;
+        bsfm_problem_t* pb = bsfm_problem_create(&d, &o);
+        double okflag = pb ? 0.0 : 1.0;                                   // every rank must have its problem, or nobody starts
+        if (bsfm_comm_allreduce_host(comms[g], &okflag, 1, 1) != 0) okflag = 1.0;
+        if (okflag == 0.0) {
+            bsfm_problem_set_comm(pb, comms[g]);
+            int rc = bsfm_lm_begin(pb);
+            if (rc == 0) bsfm_lm_iterate(pb, o.itmax);
+            rc = bsfm_lm_finish(pb, infos[g].data());
+            if (rc != BSFM_ERROR || infos[g][5] > 0) {
+                if (g == 0) { memcpy(cam_out.data(), a.cams, (size_t)m * sizeof(bsfm_camera_params_t)); bsfm_problem_download(pb, nullptr, cam_out.data(), nullptr); }
+                bsfm_problem_download(pb, nullptr, nullptr, d.n ? a.pts + 3 * (size_t)lo : nullptr);      // disjoint slices of init_pts
+            }
+            rcs[g] = rc;
+        }
+        if (pb) bsfm_problem_destroy(pb);
+    };
+    std::vector<std::thread> th;
+    for (int g = 1; g < G; ++g) th.emplace_back(worker, g);
+    int saved = 0; (void)hipGetDevice(&saved);
+    worker(0);
+    for (auto& t : th) t.join();
+    (void)hipSetDevice(saved);
+    for (int g = 0; g < G; ++g) bsfm_comm_destroy(comms[g]);
+    for (int g = 0; g < G; ++g) if (rcs[g] == BSFM_ERROR && infos[g][5] <= 0) { for (int q = 0; q < BSFM_INFOSZ; ++q) info[q] = infos[0][q]; return BSFM_ERROR; }
+    memcpy(a.cams, cam_out.data(), (size_t)m * sizeof(bsfm_camera_params_t));     // only after every rank has finished reading the inputs
+    for (int q = 0; q < BSFM_INFOSZ; ++q) info[q] = infos[0][q];
+    return rcs[0];
+}
+
 }  // namespace
 
 extern "C" {
+
+// dense vmask -> CRS exactly as run_sfm does it internally (test entry for the ordering contract).
+// rowptr (n + 1) / colidx (nvis) may be NULL to query the count only.  Host-only, needs no device.
+int bsfm_crs_from_vmask(int n, int m, const char* vmask, int* rowptr, int* colidx)
+{
+    if (n < 0 || m <= 0 || !vmask) return BSFM_ERROR;
+    std::vector<int> rp, ci;
+    vmask_to_crs(n, m, vmask, rp, ci);
+    if (rowptr) memcpy(rowptr, rp.data(), rp.size() * sizeof(int));
+    if (colidx && !ci.empty()) memcpy(colidx, ci.data(), ci.size() * sizeof(int));
+    return (int)ci.size();
+}
 
 int bsfm_sba_motstr_levmar(int n, int m, int mcon, char* vmask, double* p, int cnp, int pnp,
                            double* x, double* covx, int mnp, int camera_model, const void* model_data,
@@ -221,6 +315,29 @@ int bsfm_run_sfm_ex(int num_pts, int num_cameras, int ncons, char* vmask, double
     std::vector<int> rowptr, colidx;
     vmask_to_crs(num_pts, num_cameras, vmask, rowptr, colidx);
 
+    // more than one GPU asked for (opt.num_gpus / BSFM_NUM_GPUS; -1 = all visible): shard the points inside this process.  The
+    // camera-only refinement and the covariance export stay on one GPU.
+    {
+        int G = opt.num_gpus, ndev = bsfm_device_count();
+        if (G < 0) G = ndev;
+        if (G > 1 && !fix_points && !(Vout || Sout || Uout || Wout) && ndev > 0 && num_pts >= G) {
+            std::vector<int> devs((size_t)G);
+            const bool share = getenv("BSFM_ALLOW_SHARED_DEVICE") != nullptr;      // test rigs: several ranks on one GPU (loopback transport)
+            if (G > ndev && !share) { fprintf(stderr, "[bsfm] run_sfm: %d GPUs asked for, %d visible: using %d\n", G, ndev, ndev); G = ndev; devs.resize((size_t)G); }
+            for (int g = 0; g < G; ++g) devs[g] = g % ndev;
+            if (G > 1) {
+                MultiArgs a = { num_pts, num_cameras, ncons, &rowptr, &colidx, projections, est_focal_length, undistort, explicit_camera_centers,
+                                init_camera_params, reinterpret_cast<double*>(init_pts), use_constraints, use_point_constraints,
+                                reinterpret_cast<const double*>(points_constraints), point_constraint_weight, optimize_for_fisheye ? 1 : 0 };
+                const int rc = run_multi(G, devs, a, opt, info);
+                if (opt.verbose >= 1) {
+                    printf("[run_sfm] Number of iterations: %d\n", (int)info[5]);   // sfm.c:872-873
+                    printf("info[6] = %0.3f\n", info[6]);
+                }
+                return rc;
+            }
+        }
+    }
     bsfm_problem_desc_t d;
     memset(&d, 0, sizeof(d));
     d.n = num_pts; d.m = num_cameras; d.mcon = ncons;

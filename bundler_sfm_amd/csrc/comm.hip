@@ -1,0 +1,269 @@
+// comm.hip -- the collective behind the multi-GPU path, on the C/C++ side of the boundary (north star: "host code stays C/C++ ...
+// observations shard across the 8 GPUs of one node with RCCL reduce over xGMI into the camera-block J^T J").
+//
+// One communicator object per rank; the LM driver (solver.hip) enqueues its exchanges on the problem's own compute stream --
+// no host hop, no stream synchronisation around the collective.  Three ways to get one:
+//   * bsfm_comm_create_from_env      one rank per PROCESS, launched the way `python -m torch.distributed.run` / mpirun do it:
+//                                    RANK, WORLD_SIZE, LOCAL_RANK, MASTER_PORT from the environment; rank 0 draws the
+//                                    ncclUniqueId and hands it over through a file under /dev/shm (single node);
+//   * bsfm_comm_create_all           one rank per THREAD of one process (ncclCommInitAll over the visible devices): what
+//                                    run_sfm uses when it is asked for more than one GPU (boundary.hip);
+//   * the loopback transport         ranks of one process that share ONE device (RCCL refuses duplicate devices in a
+//                                    communicator): a barrier + a peer-summing kernel, summed in rank order on every rank.  Only
+//                                    there so that the multi-rank control flow can be tested on a 1-GPU box.
+// RCCL is dlopen'ed (librccl.so) on first use: single-GPU runs never load it.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <unistd.h>
+#include <sys/stat.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <mutex>
+#include <condition_variable>
+#include <chrono>
+#include <thread>
+#include "../../include/bsfm.h"
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+Rccl& rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        r.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!r.lib) r.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!r.lib) { fprintf(stderr, "[bsfm] multi-GPU: cannot load librccl.so: %s\n", dlerror()); return; }
+        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+        r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.lib, "ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+        r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.AllReduce && r.GetErrorString;
+        if (!r.ok) fprintf(stderr, "[bsfm] multi-GPU: librccl.so lacks an expected symbol\n");
+    });
+    return r;
+}
+
+// ---- loopback transport: in-process ranks on one device -------------------------------------------------------------------
+struct Loopback {
+    int world = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0; long generation = 0;
+    std::vector<double*> bufs;          // this round's buffers, by rank
+    std::vector<double*> scratch;       // per-rank result buffers
+    std::vector<size_t> scratch_cap;
+    int refs = 0;
+    void barrier()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        const long gen = generation;
+        if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != gen; });
+    }
+};
+
+__global__ void k_peer_reduce(int world, size_t count, int op, double* const* __restrict__ srcs, double* __restrict__ dst)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double v = srcs[0][i];
+    for (int r = 1; r < world; ++r) { const double t = srcs[r][i]; v = op == 0 ? v + t : (t > v ? t : v); }      // rank order: same bits on every rank
+    dst[i] = v;
+}
+
+}  // namespace
+
+struct bsfm_comm {
+    int rank = 0, world = 1, device = 0;
+    ncclComm_t nccl = nullptr;          // RCCL transport
+    Loopback* loop = nullptr;           // loopback transport (shared by the ranks of one process)
+    double** d_srcs = nullptr;          // loopback: device array of the ranks' buffer pointers
+    double* d_small = nullptr;          // staging for host-scalar reductions
+    std::string id_file;                // rank 0 of a process group removes it on destroy
+};
+
+namespace {
+
+int comm_alloc_common(bsfm_comm* c)
+{
+    if (hipMalloc((void**)&c->d_small, 256 * sizeof(double)) != hipSuccess) return -1;
+    if (c->loop && hipMalloc((void**)&c->d_srcs, (size_t)c->world * sizeof(double*)) != hipSuccess) return -1;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bsfm_comm_rank(const bsfm_comm_t* c) { return c ? c->rank : 0; }
+int bsfm_comm_world(const bsfm_comm_t* c) { return c ? c->world : 1; }
+const char* bsfm_comm_transport(const bsfm_comm_t* c) { return !c ? "none" : (c->nccl ? "rccl" : (c->loop ? "loopback" : "none")); }
+
+void bsfm_comm_destroy(bsfm_comm_t* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->nccl && rccl().ok) (void)rccl().CommDestroy(c->nccl);
+    if (c->d_small) (void)hipFree(c->d_small);
+    if (c->d_srcs) (void)hipFree(c->d_srcs);
+    if (c->loop) {
+        bool last;
+        { std::lock_guard<std::mutex> lk(c->loop->mu); last = --c->loop->refs == 0; }
+        if (last) { for (double* p : c->loop->scratch) if (p) (void)hipFree(p); delete c->loop; }
+    }
+    if (!c->id_file.empty() && c->rank == 0) (void)unlink(c->id_file.c_str());
+    delete c;
+}
+
+// In-place all-reduce of `count` doubles at device pointer `buf`, enqueued on `stream` (op 0 = sum, 1 = max).
+int bsfm_comm_allreduce(bsfm_comm_t* c, void* buf, size_t count, int op, void* stream)
+{
+    if (!c || c->world <= 1 || count == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (c->nccl) {
+        const ncclResult_t r = rccl().AllReduce(buf, buf, count, ncclDouble, op == 0 ? ncclSum : ncclMax, c->nccl, st);
+        if (r != ncclSuccess) { fprintf(stderr, "[bsfm] ncclAllReduce failed: %s\n", rccl().GetErrorString(r)); return BSFM_ERROR; }
+        return 0;
+    }
+    if (c->loop) {
+        Loopback* L = c->loop;
+        if (hipStreamSynchronize(st) != hipSuccess) return BSFM_ERROR;      // this rank's contribution is complete
+        {
+            std::lock_guard<std::mutex> lk(L->mu);
+            L->bufs[c->rank] = (double*)buf;
+            if (L->scratch_cap[c->rank] < count) {
+                if (L->scratch[c->rank]) (void)hipFree(L->scratch[c->rank]);
+                if (hipMalloc((void**)&L->scratch[c->rank], count * sizeof(double)) != hipSuccess) return BSFM_ERROR;
+                L->scratch_cap[c->rank] = count;
+            }
+        }
+        L->barrier();                                                        // every rank's pointer is published
+        std::vector<double*> h(L->bufs);
+        if (hipMemcpyAsync(c->d_srcs, h.data(), (size_t)c->world * sizeof(double*), hipMemcpyHostToDevice, st) != hipSuccess) return BSFM_ERROR;
+        hipLaunchKernelGGL(k_peer_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, c->world, count, op,
+                           (double* const*)c->d_srcs, L->scratch[c->rank]);
+        if (hipStreamSynchronize(st) != hipSuccess) return BSFM_ERROR;
+        L->barrier();                                                        // every rank has read every buffer
+        if (hipMemcpyAsync(buf, L->scratch[c->rank], count * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return BSFM_ERROR;
+        return 0;
+    }
+    return BSFM_ERROR;
+}
+
+// Host scalars (count <= 256): staged through a small device buffer, synchronous.  op 0 = sum, 1 = max.
+int bsfm_comm_allreduce_host(bsfm_comm_t* c, double* vals, int count, int op)
+{
+    if (!c || c->world <= 1 || count <= 0) return 0;
+    if (count > 256) return BSFM_ERROR;
+    (void)hipSetDevice(c->device);
+    if (hipMemcpy(c->d_small, vals, (size_t)count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return BSFM_ERROR;
+    if (bsfm_comm_allreduce(c, c->d_small, (size_t)count, op, nullptr) != 0) return BSFM_ERROR;
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return BSFM_ERROR;
+    if (hipMemcpy(vals, c->d_small, (size_t)count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return BSFM_ERROR;
+    return 0;
+}
+
+int bsfm_comm_barrier(bsfm_comm_t* c)
+{
+    double one = 1.0;
+    return bsfm_comm_allreduce_host(c, &one, 1, 0);
+}
+
+// One rank per process.  Environment (what torch.distributed.run / mpirun wrappers export): RANK, WORLD_SIZE, LOCAL_RANK,
+// MASTER_PORT.  The 128-byte ncclUniqueId travels through /dev/shm/bsfm_nccl_<MASTER_PORT>_<parent pid>.id (all ranks of a
+// launcher share the parent process; BSFM_COMM_ID_FILE overrides the path), written atomically by rank 0.
+bsfm_comm_t* bsfm_comm_create_from_env(void)
+{
+    const char* er = getenv("RANK"); const char* ew = getenv("WORLD_SIZE"); const char* el = getenv("LOCAL_RANK");
+    const int world = ew ? atoi(ew) : 1, rank = er ? atoi(er) : 0, local = el ? atoi(el) : rank;
+    if (world < 1 || rank < 0 || rank >= world) { fprintf(stderr, "[bsfm] comm: bad RANK / WORLD_SIZE\n"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { fprintf(stderr, "[bsfm] comm: no HIP device\n"); return nullptr; }
+    bsfm_comm* c = new bsfm_comm();
+    c->rank = rank; c->world = world; c->device = local % ndev;
+    if (hipSetDevice(c->device) != hipSuccess) { delete c; return nullptr; }
+    if (world == 1 && !getenv("BSFM_COMM_FORCE_RCCL")) { if (comm_alloc_common(c)) { bsfm_comm_destroy(c); return nullptr; } return c; }
+    if (!rccl().ok) { delete c; return nullptr; }
+    std::string path;
+    if (const char* e = getenv("BSFM_COMM_ID_FILE")) path = e;
+    else {
+        const char* port = getenv("MASTER_PORT");
+        char buf[256];
+        snprintf(buf, sizeof(buf), "/dev/shm/bsfm_nccl_%s_%ld.id", port ? port : "0", (long)getppid());
+        path = buf;
+    }
+    c->id_file = path;
+    ncclUniqueId id;
+    if (rank == 0) {
+        if (rccl().GetUniqueId(&id) != ncclSuccess) { fprintf(stderr, "[bsfm] comm: ncclGetUniqueId failed\n"); delete c; return nullptr; }
+        const std::string tmp = path + ".tmp";
+        FILE* f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(&id, sizeof(id), 1, f) != 1) { fprintf(stderr, "[bsfm] comm: cannot write %s\n", tmp.c_str()); if (f) fclose(f); delete c; return nullptr; }
+        fclose(f);
+        if (rename(tmp.c_str(), path.c_str()) != 0) { fprintf(stderr, "[bsfm] comm: cannot publish %s\n", path.c_str()); delete c; return nullptr; }
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        bool got = false;
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 120.0) {
+            FILE* f = fopen(path.c_str(), "rb");
+            if (f) { got = fread(&id, sizeof(id), 1, f) == 1; fclose(f); if (got) break; }
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
+        if (!got) { fprintf(stderr, "[bsfm] comm: rank %d timed out waiting for %s\n", rank, path.c_str()); delete c; return nullptr; }
+    }
+    const ncclResult_t r = rccl().CommInitRank(&c->nccl, world, id, rank);
+    if (r != ncclSuccess) { fprintf(stderr, "[bsfm] ncclCommInitRank failed: %s\n", rccl().GetErrorString(r)); c->nccl = nullptr; bsfm_comm_destroy(c); return nullptr; }
+    if (comm_alloc_common(c)) { bsfm_comm_destroy(c); return nullptr; }
+    return c;
+}
+
+// One rank per thread of THIS process: fills comms[0 .. ndev-1] for the devices devs[.] (the caller's threads then each take one
+// and call hipSetDevice(devs[g]) themselves).  Distinct devices -> ncclCommInitAll; a repeated device -> loopback transport.
+int bsfm_comm_create_all(int ndev, const int* devs, bsfm_comm_t** comms)
+{
+    if (ndev < 1 || !devs || !comms) return BSFM_ERROR;
+    bool distinct = true;
+    for (int a = 0; a < ndev; ++a) for (int b = a + 1; b < ndev; ++b) if (devs[a] == devs[b]) distinct = false;
+    int saved = 0; (void)hipGetDevice(&saved);
+    for (int g = 0; g < ndev; ++g) { comms[g] = new bsfm_comm(); comms[g]->rank = g; comms[g]->world = ndev; comms[g]->device = devs[g]; }
+    auto fail = [&] { for (int g = 0; g < ndev; ++g) { bsfm_comm_destroy(comms[g]); comms[g] = nullptr; } (void)hipSetDevice(saved); return BSFM_ERROR; };
+    if (ndev > 1) {
+        if (distinct) {
+            if (!rccl().ok) return fail();
+            std::vector<ncclComm_t> nc((size_t)ndev);
+            const ncclResult_t r = rccl().CommInitAll(nc.data(), ndev, devs);
+            if (r != ncclSuccess) { fprintf(stderr, "[bsfm] ncclCommInitAll failed: %s\n", rccl().GetErrorString(r)); return fail(); }
+            for (int g = 0; g < ndev; ++g) comms[g]->nccl = nc[g];
+        } else {
+            Loopback* L = new Loopback();
+            L->world = ndev; L->bufs.assign((size_t)ndev, nullptr); L->scratch.assign((size_t)ndev, nullptr); L->scratch_cap.assign((size_t)ndev, 0);
+            L->refs = ndev;
+            for (int g = 0; g < ndev; ++g) comms[g]->loop = L;
+        }
+    }
+    for (int g = 0; g < ndev; ++g) {
+        if (hipSetDevice(devs[g]) != hipSuccess || comm_alloc_common(comms[g])) return fail();
+    }
+    (void)hipSetDevice(saved);
+    return 0;
+}
+
+}  // extern "C"

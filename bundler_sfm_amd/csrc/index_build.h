@@ -1,0 +1,39 @@
+// index_build.h -- interface of the device-side index construction (index_build.hip) used by solver.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+
+namespace bsfm {
+
+// diag: the task's block is S_jj (it also produces its part of e_j); out: slot of its partial sums (tasks of a block hold
+// consecutive slots, which fixes the summation order; the array itself is in LAUNCH order, see index_build.hip) or -1 = padding
+struct SchurTask { int start; int count; int diag; int out; };
+
+constexpr int SCHUR_CHUNK = 168;      // co-visibility triples per task = 8 passes of 21 (schur.hip.h)
+
+// Everything the LM kernels index with, built on the device from the CRS (rowptr, colidx) the caller hands over.
+// All pointers are device memory owned by the receiver (hipFree each one that is non-null).
+struct DeviceIndex {
+    int* obs_pt = nullptr;        // nvis: point of observation k
+    int* camptr = nullptr;        // m + 1
+    int* camobs = nullptr;        // nvis: camera-major position -> observation (the traversal order of sba_crsm_col_elmidxs)
+    int* campos = nullptr;        // nvis: observation -> camera-major position
+    int* cam_pt = nullptr;        // nvis: camera-major position -> point
+    int* cam_cam = nullptr;       // nvis: camera-major position -> camera
+    // Schur structure (absent for the camera-only problem)
+    int2* triples = nullptr;      // ntriples: (camera-major position of (i,j), of (i,k)), grouped by block (j <= k)
+    int* tri_pt = nullptr;        // ntriples: point i of the triple
+    SchurTask* tasks = nullptr;   // nslots, launch order
+    int* blk_j = nullptr; int* blk_k = nullptr; int* blk_task0 = nullptr;     // nblk, nblk, nblk + 1
+    int ntriples = 0, ntasks = 0, nblk = 0, nslots = 0;
+    std::vector<int> h_blk_j, h_blk_k;      // host copies of the block list (component analysis / multi-GPU union)
+    double build_ms = 0.0;        // device time of the whole construction (HIP events)
+};
+
+// rowptr (n+1) / colidx (nvis) are DEVICE arrays.  Returns 0, or -1 with a message on stderr (bad CRS, allocation failure,
+// more than 2^31-1 co-visibility triples).  order_by_block != 0 keeps the tasks in block order (BSFM_SCHUR_ORDER=block).
+int build_index_device(int n, int m, int mcon, int nvis, const int* d_rowptr, const int* d_colidx, bool want_schur,
+                       int order_by_block, DeviceIndex& out, hipStream_t st);
+void free_index_device(DeviceIndex& ix);
+
+}  // namespace bsfm

@@ -1,0 +1,344 @@
+// index_build.hip -- index bookkeeping of the bundle-adjustment core, built ON THE DEVICE (integer work, bit-exact).
+//
+// What it replaces in the reference (paths relative to the reference tree):
+//   * struct sba_crsm + the fill loop                        lib/sba-1.5/sba_levmar.c:653-663, lib/sba-1.5/sba.h:70-78
+//   * sba_crsm_col_elmidxs (camera-major traversal, re-derived by binary search for every camera in every U_j / Q / Jacobian
+//     loop)                                                  lib/sba-1.5/sba_crsm.c:183-212
+//   * the co-visibility search inside the Schur loop (range test + sba_crsm_elmidxp per camera pair and point)
+//                                                            lib/sba-1.5/sba_levmar.c:1218-1268
+// The observation order is the reference's contract (k-th set bit of vmask in row-major order = k-th measurement), so every
+// array here is a pure function of (rowptr, colidx): camera-major order = stable sort of the observations by camera (points
+// ascending inside a camera, exactly the order sba_crsm_col_elmidxs returns them); Schur triples = all pairs (a <= b) of the
+// free cameras of a point, stable-sorted by block (j, k) so that inside a block they stay in point order -- the order the
+// reference accumulates Y_ij W_ik^T in.  Round 1 built all of this with single-threaded host loops (0.4 - 7.4 s at
+// 1 000 cameras / 5 M observations, paid by every run_sfm call); here it is a handful of kernels plus rocPRIM's stable radix
+// sort / scan / run-length primitives (through the hipcub headers), a few milliseconds.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <cstdio>
+#include <cstdlib>
+#include <climits>
+#include <algorithm>
+#include "index_build.h"
+
+namespace bsfm {
+namespace {
+
+#define IX_OK(call)                                                                                     \
+    do { hipError_t _e = (call); if (_e != hipSuccess) {                                               \
+        fprintf(stderr, "[bsfm] index build: HIP error %s at %s:%d\n", hipGetErrorName(_e), __FILE__, __LINE__); \
+        return -1; } } while (0)
+
+inline int grid_for(size_t count, int block) { return (int)std::max<size_t>(1, (count + block - 1) / block); }
+inline int bits_for(unsigned long long maxval) { int b = 1; while (b < 64 && (maxval >> b)) ++b; return b; }
+
+// flag bit 0: rowptr not monotone / out of range; bit 1: colidx out of range; bit 2: colidx not strictly ascending in a row
+__global__ void k_validate_rows(int n, int m, int nvis, const int* __restrict__ rowptr, const int* __restrict__ colidx, int* __restrict__ flag)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r0 = rowptr[i], r1 = rowptr[i + 1];
+    if (r0 < 0 || r1 < r0 || r1 > nvis) { atomicOr(flag, 1); return; }
+    int prev = -1;
+    for (int k = r0; k < r1; ++k) {
+        const int c = colidx[k];
+        if (c < 0 || c >= m) { atomicOr(flag, 2); return; }
+        if (c <= prev) { atomicOr(flag, 4); return; }
+        prev = c;
+    }
+}
+
+// obs_pt, and the number of co-visibility triples of every point: c (c + 1) / 2 with c = cameras >= mcon of the point
+// (colidx ascends inside a row, so the free cameras are a suffix)
+__global__ void k_rows(int n, int mcon, const int* __restrict__ rowptr, const int* __restrict__ colidx, int* __restrict__ obs_pt,
+                       long long* __restrict__ tcount)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r0 = rowptr[i], r1 = rowptr[i + 1];
+    int c = 0;
+    for (int k = r0; k < r1; ++k) { obs_pt[k] = i; c += colidx[k] >= mcon; }
+    if (tcount) tcount[i] = (long long)c * (c + 1) / 2;
+}
+
+__global__ void k_iota(int cnt, int* __restrict__ v)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < cnt) v[k] = k;
+}
+
+// camptr[j] = first camera-major position whose camera is >= j (lower bound in the sorted camera array)
+__global__ void k_camptr(int m, int nvis, const int* __restrict__ cam_sorted, int* __restrict__ camptr)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > m) return;
+    int lo = 0, hi = nvis;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (cam_sorted[mid] < j) lo = mid + 1; else hi = mid; }
+    camptr[j] = lo;
+}
+
+__global__ void k_cam_maps(int nvis, const int* __restrict__ camobs, const int* __restrict__ obs_pt, int* __restrict__ campos,
+                           int* __restrict__ cam_pt)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nvis) return;
+    const int k = camobs[t];
+    campos[k] = t;
+    cam_pt[t] = obs_pt[k];
+}
+
+// one thread per point: its triples in (a, b >= a) order at offset toff[i]; key = block (j - mcon) * mm + (k - mcon),
+// value = (camera-major position of (i, j), of (i, k)) packed low / high
+template <typename KeyT>
+__global__ void k_gen_triples(int n, int mcon, int mm, const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                              const int* __restrict__ campos, const long long* __restrict__ toff, KeyT* __restrict__ keys,
+                              unsigned long long* __restrict__ vals)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r1 = rowptr[i + 1];
+    int r0 = rowptr[i];
+    while (r0 < r1 && colidx[r0] < mcon) ++r0;
+    long long o = toff[i];
+    for (int a = r0; a < r1; ++a) {
+        const unsigned long long ja = (unsigned long long)(colidx[a] - mcon) * (unsigned long long)mm;
+        const unsigned pa = (unsigned)campos[a];
+        for (int b = a; b < r1; ++b, ++o) {
+            keys[o] = (KeyT)(ja + (unsigned long long)(colidx[b] - mcon));
+            vals[o] = ((unsigned long long)(unsigned)campos[b] << 32) | pa;
+        }
+    }
+}
+
+template <typename KeyT>
+__global__ void k_blocks(int nblk, int mcon, int mm, const KeyT* __restrict__ ukeys, const int* __restrict__ counts,
+                         int* __restrict__ blk_j, int* __restrict__ blk_k, int* __restrict__ ntask)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk) return;
+    const unsigned long long key = (unsigned long long)ukeys[b];
+    blk_j[b] = mcon + (int)(key / (unsigned long long)mm);
+    blk_k[b] = mcon + (int)(key % (unsigned long long)mm);
+    ntask[b] = (counts[b] + SCHUR_CHUNK - 1) / SCHUR_CHUNK;
+}
+
+// tasks in block order; blk_start / blk_task0 are the exclusive scans of the triple and task counts (entry nblk = totals)
+__global__ void k_tasks(int nblk, const int* __restrict__ blk_start, const int* __restrict__ blk_task0, const int* __restrict__ blk_j,
+                        const int* __restrict__ blk_k, SchurTask* __restrict__ tasks)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk) return;
+    const int s0 = blk_start[b], s1 = blk_start[b + 1], diag = blk_j[b] == blk_k[b] ? 1 : 0;
+    int t = blk_task0[b];
+    for (int s = s0; s < s1; s += SCHUR_CHUNK, ++t) {
+        SchurTask tk; tk.start = s; tk.count = min(SCHUR_CHUNK, s1 - s); tk.diag = diag; tk.out = t;
+        tasks[t] = tk;
+    }
+}
+
+__global__ void k_tri_pt(int ntri, const unsigned long long* __restrict__ vals, const int* __restrict__ cam_pt, int* __restrict__ tri_pt)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < ntri) tri_pt[s] = cam_pt[(unsigned)(vals[s] & 0xffffffffULL)];
+}
+
+__global__ void k_task_keys(int ntasks, const SchurTask* __restrict__ tasks, const int* __restrict__ tri_pt, int* __restrict__ keys)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ntasks) keys[t] = tri_pt[tasks[t].start];
+}
+
+// Launch order (schur.hip.h): tasks sorted by the first point they touch (`ord`), then every XCD (workgroup index % 8, four
+// tasks per workgroup) gets ONE contiguous stretch of that order: the workgroups wg = x, x + 8, x + 16 ... take consecutive
+// four-task pieces.  Slots past the end are padding (out = -1).
+__global__ void k_launch_order(int ntasks, int nwg, const SchurTask* __restrict__ tasks, const int* __restrict__ ord,
+                               SchurTask* __restrict__ launch)
+{
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nwg * 4) return;
+    const int wg = slot >> 2, w = slot & 3, x = wg & 7;
+    int next = wg >> 3;
+    for (int r = 0; r < x; ++r) next += nwg > r ? (nwg - r + 7) / 8 : 0;
+    const long long src = (long long)next * 4 + w;
+    SchurTask tk; tk.start = 0; tk.count = 0; tk.diag = 0; tk.out = -1;
+    if (src < ntasks) tk = tasks[ord[src]];
+    launch[slot] = tk;
+}
+
+struct Scratch {           // temporaries of one build; freed on every exit path
+    std::vector<void*> ptrs;
+    ~Scratch() { for (void* p : ptrs) if (p) (void)hipFree(p); }
+    template <typename T> hipError_t alloc(T** p, size_t count)
+    {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) ptrs.push_back(*p);
+        return e;
+    }
+};
+
+template <typename T> hipError_t keep(T** p, size_t count) { return hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T)); }
+
+template <typename KeyT>
+int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int* d_colidx, const long long* d_toff, long long total,
+                int order_by_block, DeviceIndex& ix, hipStream_t st)
+{
+    const int mm = m - mcon;
+    Scratch tmp;
+    const size_t nt = (size_t)total;
+    ix.ntriples = (int)total;
+    IX_OK(keep(&ix.triples, nt)); IX_OK(keep(&ix.tri_pt, nt));
+    if (total == 0) {
+        ix.ntasks = ix.nblk = ix.nslots = 0;
+        IX_OK(keep(&ix.tasks, 1)); IX_OK(keep(&ix.blk_j, 1)); IX_OK(keep(&ix.blk_k, 1)); IX_OK(keep(&ix.blk_task0, 1));
+        IX_OK(hipMemsetAsync(ix.blk_task0, 0, sizeof(int), st));
+        return 0;
+    }
+    KeyT *keys_in = nullptr, *keys_out = nullptr; unsigned long long* vals_in = nullptr;
+    IX_OK(tmp.alloc(&keys_in, nt)); IX_OK(tmp.alloc(&keys_out, nt)); IX_OK(tmp.alloc(&vals_in, nt));
+    hipLaunchKernelGGL((k_gen_triples<KeyT>), dim3(grid_for(n, 128)), dim3(128), 0, st, n, mcon, mm, d_rowptr, d_colidx, ix.campos,
+                       d_toff, keys_in, vals_in);
+    // stable sort by block key; the values land directly in the triple array (int2 = low / high word)
+    unsigned long long* vals_out = reinterpret_cast<unsigned long long*>(ix.triples);
+    const int kbits = bits_for((unsigned long long)mm * (unsigned long long)mm - 1ULL);
+    size_t tb = 0;
+    IX_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in, keys_out, vals_in, vals_out, (int)nt, 0, kbits, st));
+    void* d_tmp = nullptr;
+    IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_tmp), tb));
+    IX_OK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, keys_in, keys_out, vals_in, vals_out, (int)nt, 0, kbits, st));
+    // blocks = runs of equal keys
+    KeyT* ukeys = keys_in;                     // reuse: the unsorted keys are no longer needed
+    int *counts = nullptr, *nruns = nullptr;
+    IX_OK(tmp.alloc(&counts, nt + 1)); IX_OK(tmp.alloc(&nruns, 1));
+    size_t rb = 0;
+    IX_OK(hipcub::DeviceRunLengthEncode::Encode(nullptr, rb, keys_out, ukeys, counts, nruns, (int)nt, st));
+    void* d_rle = nullptr;
+    IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_rle), rb));
+    IX_OK(hipcub::DeviceRunLengthEncode::Encode(d_rle, rb, keys_out, ukeys, counts, nruns, (int)nt, st));
+    int nblk = 0;
+    IX_OK(hipMemcpyAsync(&nblk, nruns, sizeof(int), hipMemcpyDeviceToHost, st));
+    IX_OK(hipStreamSynchronize(st));
+    ix.nblk = nblk;
+    IX_OK(keep(&ix.blk_j, (size_t)nblk)); IX_OK(keep(&ix.blk_k, (size_t)nblk)); IX_OK(keep(&ix.blk_task0, (size_t)nblk + 1));
+    int *ntask = nullptr, *blk_start = nullptr;
+    IX_OK(tmp.alloc(&ntask, (size_t)nblk + 1)); IX_OK(tmp.alloc(&blk_start, (size_t)nblk + 1));
+    IX_OK(hipMemsetAsync(ntask + nblk, 0, sizeof(int), st));
+    IX_OK(hipMemsetAsync(counts + nblk, 0, sizeof(int), st));          // counts has nt + 1 >= nblk + 1 entries
+    hipLaunchKernelGGL((k_blocks<KeyT>), dim3(grid_for(nblk, 256)), dim3(256), 0, st, nblk, mcon, mm, ukeys, counts, ix.blk_j, ix.blk_k, ntask);
+    size_t sb = 0;
+    IX_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, ntask, ix.blk_task0, nblk + 1, st));
+    void* d_scan = nullptr;
+    IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_scan), sb));
+    IX_OK(hipcub::DeviceScan::ExclusiveSum(d_scan, sb, ntask, ix.blk_task0, nblk + 1, st));
+    IX_OK(hipcub::DeviceScan::ExclusiveSum(d_scan, sb, counts, blk_start, nblk + 1, st));
+    int ntasks = 0;
+    IX_OK(hipMemcpyAsync(&ntasks, ix.blk_task0 + nblk, sizeof(int), hipMemcpyDeviceToHost, st));
+    IX_OK(hipStreamSynchronize(st));
+    ix.ntasks = ntasks;
+    SchurTask* tasks = nullptr;
+    IX_OK(hipMalloc((void**)&tasks, std::max<size_t>(1, (size_t)ntasks) * sizeof(SchurTask)));
+    hipLaunchKernelGGL(k_tasks, dim3(grid_for(nblk, 256)), dim3(256), 0, st, nblk, blk_start, ix.blk_task0, ix.blk_j, ix.blk_k, tasks);
+    hipLaunchKernelGGL(k_tri_pt, dim3(grid_for(nt, 256)), dim3(256), 0, st, (int)nt, vals_out, ix.cam_pt, ix.tri_pt);
+    if (order_by_block) { ix.tasks = tasks; ix.nslots = ntasks; }
+    else {
+        tmp.ptrs.push_back(tasks);
+        int *tk_in = nullptr, *tk_out = nullptr, *id_in = nullptr, *ord = nullptr;
+        IX_OK(tmp.alloc(&tk_in, (size_t)ntasks)); IX_OK(tmp.alloc(&tk_out, (size_t)ntasks));
+        IX_OK(tmp.alloc(&id_in, (size_t)ntasks)); IX_OK(tmp.alloc(&ord, (size_t)ntasks));
+        hipLaunchKernelGGL(k_task_keys, dim3(grid_for(ntasks, 256)), dim3(256), 0, st, ntasks, tasks, ix.tri_pt, tk_in);
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(ntasks, 256)), dim3(256), 0, st, ntasks, id_in);
+        size_t ob = 0;
+        const int pbits = bits_for((unsigned long long)std::max(n, 1) - 1ULL);
+        IX_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, ob, tk_in, tk_out, id_in, ord, ntasks, 0, pbits, st));
+        void* d_ob = nullptr;
+        IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_ob), ob));
+        IX_OK(hipcub::DeviceRadixSort::SortPairs(d_ob, ob, tk_in, tk_out, id_in, ord, ntasks, 0, pbits, st));
+        const int nwg = (ntasks + 3) / 4;
+        ix.nslots = nwg * 4;
+        IX_OK(keep(&ix.tasks, (size_t)ix.nslots));
+        hipLaunchKernelGGL(k_launch_order, dim3(grid_for((size_t)ix.nslots, 256)), dim3(256), 0, st, ntasks, nwg, tasks, ord, ix.tasks);
+    }
+    ix.h_blk_j.resize((size_t)nblk); ix.h_blk_k.resize((size_t)nblk);
+    if (nblk) {
+        IX_OK(hipMemcpyAsync(ix.h_blk_j.data(), ix.blk_j, (size_t)nblk * sizeof(int), hipMemcpyDeviceToHost, st));
+        IX_OK(hipMemcpyAsync(ix.h_blk_k.data(), ix.blk_k, (size_t)nblk * sizeof(int), hipMemcpyDeviceToHost, st));
+    }
+    IX_OK(hipStreamSynchronize(st));          // temporaries are freed when `tmp` goes out of scope
+    return 0;
+}
+
+}  // namespace
+
+void free_index_device(DeviceIndex& ix)
+{
+    void* ptrs[] = { ix.obs_pt, ix.camptr, ix.camobs, ix.campos, ix.cam_pt, ix.cam_cam, ix.triples, ix.tri_pt, ix.tasks,
+                     ix.blk_j, ix.blk_k, ix.blk_task0 };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    ix = DeviceIndex();
+}
+
+int build_index_device(int n, int m, int mcon, int nvis, const int* d_rowptr, const int* d_colidx, bool want_schur,
+                       int order_by_block, DeviceIndex& ix, hipStream_t st)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    if (e0) (void)hipEventRecord(e0, st);
+    Scratch tmp;
+    int* flag = nullptr;
+    IX_OK(tmp.alloc(&flag, 1));
+    IX_OK(hipMemsetAsync(flag, 0, sizeof(int), st));
+    if (n > 0) hipLaunchKernelGGL(k_validate_rows, dim3(grid_for(n, 256)), dim3(256), 0, st, n, m, nvis, d_rowptr, d_colidx, flag);
+    int hflag = 0;
+    IX_OK(hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    IX_OK(hipStreamSynchronize(st));
+    if (hflag) {
+        fprintf(stderr, "[bsfm] bad visibility index:%s%s%s\n", (hflag & 1) ? " rowptr not monotone" : "",
+                (hflag & 2) ? " colidx out of range" : "", (hflag & 4) ? " colidx not strictly ascending in a row" : "");
+        return -1;
+    }
+    IX_OK(keep(&ix.obs_pt, (size_t)nvis)); IX_OK(keep(&ix.camptr, (size_t)m + 1)); IX_OK(keep(&ix.camobs, (size_t)nvis));
+    IX_OK(keep(&ix.campos, (size_t)nvis)); IX_OK(keep(&ix.cam_pt, (size_t)nvis)); IX_OK(keep(&ix.cam_cam, (size_t)nvis));
+    long long* tcount = nullptr; long long* toff = nullptr;
+    if (want_schur) { IX_OK(tmp.alloc(&tcount, (size_t)n + 1)); IX_OK(tmp.alloc(&toff, (size_t)n + 1)); IX_OK(hipMemsetAsync(tcount, 0, ((size_t)n + 1) * sizeof(long long), st)); }
+    if (n > 0) hipLaunchKernelGGL(k_rows, dim3(grid_for(n, 256)), dim3(256), 0, st, n, mcon, d_rowptr, d_colidx, ix.obs_pt, tcount);
+    // camera-major order: stable sort of the observations by camera
+    if (nvis > 0) {
+        int* iota = nullptr;
+        IX_OK(tmp.alloc(&iota, (size_t)nvis));
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(nvis, 256)), dim3(256), 0, st, nvis, iota);
+        size_t tb = 0;
+        const int cbits = bits_for((unsigned long long)m - 1ULL);
+        IX_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, d_colidx, ix.cam_cam, iota, ix.camobs, nvis, 0, cbits, st));
+        void* d_tmp = nullptr;
+        IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_tmp), tb));
+        IX_OK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_colidx, ix.cam_cam, iota, ix.camobs, nvis, 0, cbits, st));
+        hipLaunchKernelGGL(k_cam_maps, dim3(grid_for(nvis, 256)), dim3(256), 0, st, nvis, ix.camobs, ix.obs_pt, ix.campos, ix.cam_pt);
+    }
+    hipLaunchKernelGGL(k_camptr, dim3(grid_for((size_t)m + 1, 256)), dim3(256), 0, st, m, nvis, ix.cam_cam, ix.camptr);
+    if (want_schur) {
+        size_t sb = 0;
+        IX_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, tcount, toff, n + 1, st));
+        void* d_scan = nullptr;
+        IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_scan), sb));
+        IX_OK(hipcub::DeviceScan::ExclusiveSum(d_scan, sb, tcount, toff, n + 1, st));
+        long long total = 0;
+        IX_OK(hipMemcpyAsync(&total, toff + n, sizeof(long long), hipMemcpyDeviceToHost, st));
+        IX_OK(hipStreamSynchronize(st));
+        if (total > (long long)INT_MAX) { fprintf(stderr, "[bsfm] too many co-visibility triples (%lld)\n", total); return -1; }
+        const unsigned long long maxkey = (unsigned long long)(m - mcon) * (unsigned long long)(m - mcon);
+        const int rc = maxkey <= 0xffffffffULL
+            ? build_schur<unsigned int>(n, m, mcon, nvis, d_rowptr, d_colidx, toff, total, order_by_block, ix, st)
+            : build_schur<unsigned long long>(n, m, mcon, nvis, d_rowptr, d_colidx, toff, total, order_by_block, ix, st);
+        if (rc) return rc;
+    }
+    if (e1) {
+        (void)hipEventRecord(e1, st);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e0 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ix.build_ms = ms;
+    } else IX_OK(hipStreamSynchronize(st));
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    return 0;
+}
+
+}  // namespace bsfm

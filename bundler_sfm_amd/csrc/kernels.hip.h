@@ -30,12 +30,9 @@
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include "model.hip.h"
+#include "index_build.h"      // SchurTask, SCHUR_CHUNK, the device-side index construction
 
 namespace bsfm {
-
-// diag: the task's block is S_jj (it also produces its part of e_j); out: slot of its partial sums (tasks of a block hold
-// consecutive slots, which fixes the summation order; the array itself is in LAUNCH order, see solver.hip) or -1 = padding
-struct SchurTask { int start; int count; int diag; int out; };
 
 struct DevProblem {
     ModelCfg cfg;

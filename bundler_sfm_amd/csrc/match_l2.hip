@@ -301,31 +301,72 @@ extern "C" int bsfm_merge_match_files(int count, const char* const* paths, const
     return blocks;
 }
 
+// ---- resident key set: descriptors + per-key statistics stay in HBM across calls (the measurement boundary of bench.py:
+// "inputs already resident in HBM when the timed region starts"; bsfm_key_match_full* = create + run + destroy)
+struct bsfm_match_set {
+    int num_images = 0;
+    std::vector<int> num_keys;
+    std::vector<size_t> off;
+    size_t tot = 0;
+    DevKeys d;
+    // measurement of the last run: HIP-event time of the k_match_l2 launches, their distance count, pairs searched
+    double kernel_ms = 0.0; double distances = 0.0; long long pairs = 0; int launches = 0;
+};
+
+extern "C" bsfm_match_set_t* bsfm_match_set_create(int num_images, const int* num_keys, const unsigned char* const* keys)
+{
+    if (!have_device() || num_images < 0) return nullptr;
+    bsfm_match_set* ms = new bsfm_match_set();
+    ms->num_images = num_images;
+    ms->num_keys.assign(num_keys, num_keys + num_images);
+    ms->off.assign((size_t)num_images + 1, 0);
+    for (int i = 0; i < num_images; ++i) ms->off[i + 1] = ms->off[i] + (size_t)std::max(num_keys[i], 0);
+    ms->tot = ms->off[num_images];
+    if (ms->tot > 0x7fffffffULL) { fprintf(stderr, "[bsfm] too many keys\n"); delete ms; return nullptr; }
+    if (ms->tot == 0) return ms;
+    bool ok = hipMalloc((void**)&ms->d.keys, ms->tot * 128) == hipSuccess && hipMalloc((void**)&ms->d.qstat, ms->tot * sizeof(int)) == hipSuccess;
+    for (int i = 0; i < num_images && ok; ++i)
+        if (num_keys[i] > 0) ok = hipMemcpy(ms->d.keys + ms->off[i] * 128, keys[i], (size_t)num_keys[i] * 128, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_key_stats, dim3((unsigned)((ms->tot + 255) / 256)), dim3(256), 0, 0, ms->d.keys, (int)ms->tot, ms->d.qstat);
+        ok = hipDeviceSynchronize() == hipSuccess;          // key upload + statistics (null stream) before any pipeline stream starts
+    }
+    if (!ok) { fprintf(stderr, "[bsfm] matcher: key upload failed\n"); delete ms; return nullptr; }
+    return ms;
+}
+
+extern "C" void bsfm_match_set_destroy(bsfm_match_set_t* ms) { delete ms; }
+
+extern "C" int bsfm_match_set_stats(const bsfm_match_set_t* ms, double* kernel_ms, double* distances, long long* pairs, int* launches)
+{
+    if (!ms) return BSFM_ERROR;
+    if (kernel_ms) *kernel_ms = ms->kernel_ms;
+    if (distances) *distances = ms->distances;
+    if (pairs) *pairs = ms->pairs;
+    if (launches) *launches = ms->launches;
+    return 0;
+}
+
 // rank / world_size: this call handles the database images i with i % world_size == rank (each with all its j < i), so
 // the pair list is split without any exchange (matcher = embarrassingly parallel, descriptors replicated).
-extern "C" int bsfm_key_match_full_sharded(int num_images, const int* num_keys, const unsigned char* const* keys,
-                                           double ratio, int window_radius, const char* out_path, int rank, int world_size)
+extern "C" int bsfm_match_set_run(bsfm_match_set_t* ms, double ratio, int window_radius, const char* out_path, int rank, int world_size)
 {
-    if (world_size < 1 || rank < 0 || rank >= world_size) return BSFM_ERROR;
-    if (!have_device()) return BSFM_ERROR;
+    if (!ms || world_size < 1 || rank < 0 || rank >= world_size) return BSFM_ERROR;
     FILE* f = fopen(out_path, "w");
     if (!f) { printf("Could not open %s for writing.\n", out_path); return BSFM_ERROR; }   // KeyMatchFull.cpp:86-89
-    std::vector<size_t> off(num_images + 1, 0);
-    int maxk = 0;
-    for (int i = 0; i < num_images; ++i) { off[i + 1] = off[i] + (size_t)std::max(num_keys[i], 0); maxk = std::max(maxk, num_keys[i]); }
-    const size_t tot = off[num_images];
+    const int num_images = ms->num_images;
+    const int* num_keys = ms->num_keys.data();
+    const std::vector<size_t>& off = ms->off;
+    const size_t tot = ms->tot;
+    DevKeys& d = ms->d;
+    ms->kernel_ms = 0.0; ms->distances = 0.0; ms->pairs = 0; ms->launches = 0;
     if (tot == 0) { fclose(f); return 0; }
-    if (tot > 0x7fffffffULL) { fprintf(stderr, "[bsfm] too many keys\n"); fclose(f); return BSFM_ERROR; }
-    DevKeys d;
-    HIPM(hipMalloc((void**)&d.keys, tot * 128)); HIPM(hipMalloc((void**)&d.qstat, tot * sizeof(int)));
-    for (int i = 0; i < num_images; ++i)
-        if (num_keys[i] > 0) HIPM(hipMemcpy(d.keys + off[i] * 128, keys[i], (size_t)num_keys[i] * 128, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_key_stats, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, d.keys, (int)tot, d.qstat);
     // Two-slot pipeline on one stream: while the GPU scans database image k, the host turns the nearest-neighbour table of
     // image k-1 into text (own integer formatter: the text, not the search, was the larger part of the wall time).
     struct Slot {
         PairDesc* h_pairs = nullptr; PairDesc* d_pairs = nullptr; int* h_nn = nullptr; int* d_nn = nullptr;
-        hipEvent_t done = nullptr; int image = -1; size_t npairs = 0; std::vector<int> js; bool busy = false;
+        hipEvent_t done = nullptr, k0 = nullptr, k1 = nullptr; int image = -1; size_t npairs = 0; std::vector<int> js; bool busy = false;
+        double dist = 0.0;
     } slots[2];
     hipStream_t st = nullptr;
     auto release = [&] {
@@ -335,6 +376,8 @@ extern "C" int bsfm_key_match_full_sharded(int num_images, const int* num_keys, 
             if (s.d_pairs) (void)hipFree(s.d_pairs);
             if (s.d_nn) (void)hipFree(s.d_nn);
             if (s.done) (void)hipEventDestroy(s.done);
+            if (s.k0) (void)hipEventDestroy(s.k0);
+            if (s.k1) (void)hipEventDestroy(s.k1);
         }
         if (st) (void)hipStreamDestroy(st);
     };
@@ -345,9 +388,9 @@ extern "C" int bsfm_key_match_full_sharded(int num_images, const int* num_keys, 
         ok = ok && hipMalloc((void**)&s.d_pairs, (size_t)num_images * sizeof(PairDesc)) == hipSuccess;
         ok = ok && hipMalloc((void**)&s.d_nn, tot * sizeof(int)) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreate(&s.k0) == hipSuccess && hipEventCreate(&s.k1) == hipSuccess;
     }
     if (!ok) { fprintf(stderr, "[bsfm] matcher: allocation failed\n"); release(); fclose(f); return BSFM_ERROR; }
-    (void)hipDeviceSynchronize();          // key upload + statistics (null stream) before the pipeline stream starts
     int total_pairs_written = 0;
     std::vector<char> text;
     auto put_int = [&](int v, char sep) {
@@ -360,6 +403,7 @@ extern "C" int bsfm_key_match_full_sharded(int num_images, const int* num_keys, 
     auto drain = [&](Slot& s) -> bool {
         if (!s.busy) return true;
         if (hipEventSynchronize(s.done) != hipSuccess) return false;
+        { float kms = 0.f; if (hipEventElapsedTime(&kms, s.k0, s.k1) == hipSuccess && kms >= 0.f) { ms->kernel_ms += kms; ms->distances += s.dist; ms->pairs += (long long)s.npairs; ms->launches++; } }
         text.clear();
         for (size_t p = 0; p < s.npairs; ++p) {
             const int* row = s.h_nn + s.h_pairs[p].out_off;
@@ -398,8 +442,11 @@ extern "C" int bsfm_key_match_full_sharded(int num_images, const int* num_keys, 
             continue;
         }
         ok = ok && hipMemcpyAsync(s.d_pairs, s.h_pairs, s.npairs * sizeof(PairDesc), hipMemcpyHostToDevice, st) == hipSuccess;
+        ok = ok && hipEventRecord(s.k0, st) == hipSuccess;
         hipLaunchKernelGGL(k_match_l2, dim3(blk), dim3(256), 0, st, d.keys, d.qstat, s.d_pairs, (int)s.npairs,
                            (int)off[i], num_keys[i], ratio * ratio, s.d_nn, 1);
+        ok = ok && hipEventRecord(s.k1, st) == hipSuccess;
+        s.dist = (double)out * (double)num_keys[i];        // query keys of all pairs x database keys
         ok = ok && hipMemcpyAsync(s.h_nn, s.d_nn, out * sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess;
         ok = ok && hipEventRecord(s.done, st) == hipSuccess;
         s.busy = true;
@@ -410,4 +457,16 @@ extern "C" int bsfm_key_match_full_sharded(int num_images, const int* num_keys, 
     if (!ok) { fprintf(stderr, "[bsfm] matcher: HIP error in the pair pipeline\n"); fclose(f); return BSFM_ERROR; }
     fclose(f);
     return total_pairs_written;
+}
+
+extern "C" int bsfm_key_match_full_sharded(int num_images, const int* num_keys, const unsigned char* const* keys,
+                                           double ratio, int window_radius, const char* out_path, int rank, int world_size)
+{
+    if (world_size < 1 || rank < 0 || rank >= world_size) return BSFM_ERROR;
+    if (!have_device()) return BSFM_ERROR;
+    bsfm_match_set_t* ms = bsfm_match_set_create(num_images, num_keys, keys);
+    if (!ms) return BSFM_ERROR;
+    const int rc = bsfm_match_set_run(ms, ratio, window_radius, out_path, rank, world_size);
+    bsfm_match_set_destroy(ms);
+    return rc;
 }

@@ -20,6 +20,7 @@
 #include <mutex>
 #include <utility>
 #include <dlfcn.h>
+#include <chrono>
 
 #include "../../include/bsfm.h"
 #include "kernels.hip.h"
@@ -43,7 +44,6 @@ namespace {
 
 constexpr double SBA_EPSILON_SQ = 1E-12 * 1E-12;   // lib/sba-1.5/sba_levmar.c:35-36
 constexpr double SBA_ONE_THIRD = 0.3333333334;     // lib/sba-1.5/sba_levmar.c:38
-constexpr int SCHUR_CHUNK = 168;                   // triples per task = 8 passes of 21
 
 enum Phase { PH_JAC = 0, PH_CAMBLK, PH_PTBLK, PH_INVERT, PH_SCHUR, PH_SOLVE, PH_BACKSUB, PH_RESID, PH_COUNT };
 const char* kPhaseNames[PH_COUNT] = { "jacobian", "cam_blocks", "point_blocks", "point_invert", "schur",
@@ -105,6 +105,7 @@ struct bsfm_problem {
     std::vector<double> h_Rinit;
     hipStream_t stream = nullptr; bool own_stream = false;
     bsfm_allreduce_fn allreduce = nullptr; void* allreduce_ctx = nullptr;
+    bsfm_comm_t* comm = nullptr;        // library-side collective (comm.hip: RCCL over xGMI); takes precedence over the hook
     PotrfWorkspace potrf;
     CompSolver comps;                   // opt-in: independent camera groups solved one workgroup each (compsolve.hip.h)
     // LM state (names follow sba_levmar.c)
@@ -114,6 +115,8 @@ struct bsfm_problem {
     hipEvent_t ev[PH_COUNT][2]; bool ev_ok = false;
     double ph_ms[PH_COUNT]; int ph_cnt[PH_COUNT];
     int red_blocks = 0;
+    double index_build_ms = 0.0;        // device time of the index construction (index_build.hip)
+    double create_ms[4] = { 0, 0, 0, 0 };   // host wall time of problem_create: total, upload, index, allocation
 };
 
 namespace {
@@ -137,115 +140,23 @@ void free_all(bsfm_problem* pb)
 
 int setup_components(bsfm_problem* pb, const std::vector<int>& bj, const std::vector<int>& bk);
 
-// Builds the co-visibility triple list bucketed by reduced-camera block (j <= k), in (j,k) order and,
-// inside a block, in point order -- the order the reference visits them (sba_levmar.c:1218-1268).
-int build_schur_structure(bsfm_problem* pb, const bsfm_problem_desc_t* d, const std::vector<int>& campos,
-                          const std::vector<int>& cam_pt)
+// Takes over the arrays of the device-side index construction (index_build.hip): camera-major maps and, unless the problem is
+// camera-only, the co-visibility triples bucketed by reduced-camera block (j <= k) in (j,k) order and, inside a block, in
+// point order -- the order the reference visits them (sba_levmar.c:1218-1268) -- cut into tasks of <= SCHUR_CHUNK triples.
+int adopt_index(bsfm_problem* pb, DeviceIndex& ix)
 {
-    const int n = d->n, m = d->m, mcon = d->mcon, mm = m - mcon;
-    std::vector<int2> triples;
-    std::vector<int> blk_j, blk_k, blk_start;
-    size_t total = 0;
-    for (int i = 0; i < n; ++i) {
-        int cnt = 0;
-        for (int k = d->rowptr[i]; k < d->rowptr[i + 1]; ++k) cnt += (d->colidx[k] >= mcon);
-        total += (size_t)cnt * (cnt + 1) / 2;
-    }
-    if (total > 0x7fffffffULL) { fprintf(stderr, "[bsfm] too many co-visibility triples (%zu)\n", total); return BSFM_ERROR; }
-    triples.resize(total);
-    if ((size_t)mm * mm <= (size_t)1 << 27) {
-        std::vector<unsigned> cnt((size_t)mm * mm + 1, 0u);
-        for (int i = 0; i < n; ++i)
-            for (int a = d->rowptr[i]; a < d->rowptr[i + 1]; ++a) {
-                const int ja = d->colidx[a]; if (ja < mcon) continue;
-                for (int b = a; b < d->rowptr[i + 1]; ++b) ++cnt[(size_t)(ja - mcon) * mm + (d->colidx[b] - mcon) + 1];
-            }
-        for (size_t q = 0; q < (size_t)mm * mm; ++q) {   // exclusive prefix; record the non-empty blocks
-            if (cnt[q + 1]) { blk_j.push_back(mcon + (int)(q / mm)); blk_k.push_back(mcon + (int)(q % mm)); blk_start.push_back((int)cnt[q]); }
-            cnt[q + 1] += cnt[q];
-        }
-        std::vector<unsigned> cur(cnt.begin(), cnt.end() - 1);
-        for (int i = 0; i < n; ++i)
-            for (int a = d->rowptr[i]; a < d->rowptr[i + 1]; ++a) {
-                const int ja = d->colidx[a]; if (ja < mcon) continue;
-                for (int b = a; b < d->rowptr[i + 1]; ++b) {
-                    const size_t key = (size_t)(ja - mcon) * mm + (d->colidx[b] - mcon);
-                    triples[cur[key]++] = make_int2(campos[a], campos[b]);
-                }
-            }
-    } else {
-        struct Rec { unsigned long long key; int a, b; };
-        std::vector<Rec> recs; recs.reserve(total);
-        for (int i = 0; i < n; ++i)
-            for (int a = d->rowptr[i]; a < d->rowptr[i + 1]; ++a) {
-                const int ja = d->colidx[a]; if (ja < mcon) continue;
-                for (int b = a; b < d->rowptr[i + 1]; ++b)
-                    recs.push_back({ (unsigned long long)(ja - mcon) * mm + (d->colidx[b] - mcon), a, b });
-            }
-        std::stable_sort(recs.begin(), recs.end(), [](const Rec& x, const Rec& y) { return x.key < y.key; });
-        for (size_t q = 0; q < recs.size(); ++q) {
-            if (q == 0 || recs[q].key != recs[q - 1].key) {
-                blk_j.push_back(mcon + (int)(recs[q].key / mm)); blk_k.push_back(mcon + (int)(recs[q].key % mm));
-                blk_start.push_back((int)q);
-            }
-            triples[q] = make_int2(campos[recs[q].a], campos[recs[q].b]);
-        }
-    }
-    blk_start.push_back((int)total);
-    const int nblk = (int)blk_j.size();
-    std::vector<SchurTask> tasks;
-    std::vector<int> blk_task0(nblk + 1);
-    for (int b = 0; b < nblk; ++b) {
-        blk_task0[b] = (int)tasks.size();
-        for (int s = blk_start[b]; s < blk_start[b + 1]; s += SCHUR_CHUNK)
-            tasks.push_back({ s, std::min(SCHUR_CHUNK, blk_start[b + 1] - s), blk_j[b] == blk_k[b] ? 1 : 0, (int)tasks.size() });
-    }
-    blk_task0[nblk] = (int)tasks.size();
-    pb->ntriples = (int)total; pb->ntasks = (int)tasks.size(); pb->nblk = nblk;
-    pb->nslots = pb->ntasks;
-    pb->h_blk_j = blk_j; pb->h_blk_k = blk_k;
-    if (pb->world == 1 && setup_components(pb, blk_j, blk_k)) return BSFM_ERROR;   // world > 1: after the block-union exchange
-    HIP_OK(dmalloc(&pb->d_triples, total)); HIP_OK(dmalloc(&pb->d_tasks, tasks.size()));
-    HIP_OK(dmalloc(&pb->d_blk_j, nblk)); HIP_OK(dmalloc(&pb->d_blk_k, nblk)); HIP_OK(dmalloc(&pb->d_blk_task0, nblk + 1));
-    HIP_OK(dmalloc(&pb->d_partials, tasks.size() * (size_t)pb->cnp * pb->cnp));
-    HIP_OK(dmalloc(&pb->d_epart, tasks.size() * (size_t)pb->cnp));
-    if (total) HIP_OK(hipMemcpy(pb->d_triples, triples.data(), total * sizeof(int2), hipMemcpyHostToDevice));
-    {   // point index of every triple (V*^-1 lookup without a dependent gather through cam_pt)
-        std::vector<int> tri_pt(total);
-        for (size_t q = 0; q < total; ++q) tri_pt[q] = cam_pt[triples[q].x];
-        HIP_OK(dmalloc(&pb->d_tri_pt, total));
-        if (total) HIP_OK(hipMemcpy(pb->d_tri_pt, tri_pt.data(), total * sizeof(int), hipMemcpyHostToDevice));
-    }
-    if (!tasks.empty()) {
-        // Launch order (schur.hip.h): sort by the first point a task touches, then give every XCD (workgroup index % 8, four
-        // tasks per workgroup) one contiguous stretch of that order.  BSFM_SCHUR_ORDER=block keeps the block order.
-        const char* eo = getenv("BSFM_SCHUR_ORDER");
-        std::vector<SchurTask> launch;
-        if (eo && !strcmp(eo, "block")) launch = tasks;
-        else {
-            std::vector<int> ord(tasks.size());
-            for (size_t q = 0; q < ord.size(); ++q) ord[q] = (int)q;
-            std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return cam_pt[triples[tasks[a].start].x] < cam_pt[triples[tasks[b].start].x]; });
-            const int nwg = ((int)tasks.size() + 3) / 4, nx = 8;
-            launch.assign((size_t)nwg * 4, SchurTask{ 0, 0, 0, -1 });
-            int next = 0;                                   // next workgroup-sized piece of the sorted order
-            for (int x = 0; x < nx; ++x)
-                for (int wg = x; wg < nwg; wg += nx, ++next)
-                    for (int w = 0; w < 4; ++w) {
-                        const size_t src = (size_t)next * 4 + w;
-                        if (src < ord.size()) launch[(size_t)wg * 4 + w] = tasks[ord[src]];
-                    }
-        }
-        pb->nslots = (int)launch.size();
-        (void)hipFree(pb->d_tasks); pb->d_tasks = nullptr;
-        HIP_OK(dmalloc(&pb->d_tasks, launch.size()));
-        HIP_OK(hipMemcpy(pb->d_tasks, launch.data(), launch.size() * sizeof(SchurTask), hipMemcpyHostToDevice));
-    }
-    if (nblk) {
-        HIP_OK(hipMemcpy(pb->d_blk_j, blk_j.data(), nblk * sizeof(int), hipMemcpyHostToDevice));
-        HIP_OK(hipMemcpy(pb->d_blk_k, blk_k.data(), nblk * sizeof(int), hipMemcpyHostToDevice));
-    }
-    HIP_OK(hipMemcpy(pb->d_blk_task0, blk_task0.data(), (nblk + 1) * sizeof(int), hipMemcpyHostToDevice));
+    pb->d_obs_pt = ix.obs_pt; pb->d_camptr = ix.camptr; pb->d_camobs = ix.camobs; pb->d_campos = ix.campos;
+    pb->d_cam_pt = ix.cam_pt; pb->d_cam_cam = ix.cam_cam;
+    pb->d_triples = ix.triples; pb->d_tri_pt = ix.tri_pt; pb->d_tasks = ix.tasks;
+    pb->d_blk_j = ix.blk_j; pb->d_blk_k = ix.blk_k; pb->d_blk_task0 = ix.blk_task0;
+    pb->ntriples = ix.ntriples; pb->ntasks = ix.ntasks; pb->nblk = ix.nblk; pb->nslots = ix.nslots;
+    pb->h_blk_j.swap(ix.h_blk_j); pb->h_blk_k.swap(ix.h_blk_k);
+    pb->index_build_ms = ix.build_ms;
+    ix = DeviceIndex();                                  // ownership moved: free_all releases the arrays
+    if (pb->mot) return 0;
+    if (pb->world == 1 && setup_components(pb, pb->h_blk_j, pb->h_blk_k)) return BSFM_ERROR;   // world > 1: after the block-union exchange
+    HIP_OK(dmalloc(&pb->d_partials, (size_t)pb->ntasks * pb->cnp * pb->cnp));
+    HIP_OK(dmalloc(&pb->d_epart, (size_t)pb->ntasks * pb->cnp));
     return 0;
 }
 
@@ -338,12 +249,20 @@ int read_scalars(bsfm_problem* pb)
     return 0;
 }
 
-// cross-rank reductions of host scalars go through the same device hook (tiny device buffer)
+inline bool has_collective(const bsfm_problem* pb) { return pb->world > 1 && (pb->comm || pb->allreduce); }
+
+// cross-rank reductions of host scalars go through the same device path (tiny device buffer)
 int allreduce_host(bsfm_problem* pb, double* vals, int count, int op)
 {
-    if (pb->world <= 1 || !pb->allreduce) return 0;
+    if (!has_collective(pb)) return 0;
     double* tmp = pb->d_scal + SC_COUNT;   // spare slots
     HIP_OK(hipMemcpyAsync(tmp, vals, count * sizeof(double), hipMemcpyHostToDevice, pb->stream));
+    if (pb->comm) {
+        if (bsfm_comm_allreduce(pb->comm, tmp, (size_t)count, op, pb->stream) != 0) return BSFM_ERROR;
+        HIP_OK(hipMemcpyAsync(vals, tmp, count * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+        HIP_OK(hipStreamSynchronize(pb->stream));
+        return 0;
+    }
     HIP_OK(hipStreamSynchronize(pb->stream));
     if (pb->allreduce(tmp, (size_t)count, op, pb->allreduce_ctx) != 0) return BSFM_ERROR;
     HIP_OK(hipMemcpy(vals, tmp, count * sizeof(double), hipMemcpyDeviceToHost));
@@ -353,16 +272,22 @@ int allreduce_host(bsfm_problem* pb, double* vals, int count, int op)
 // The maxima ride the same SUM as an all-gather: value q of rank r sits in slot q*world + r, zeros elsewhere.
 int allreduce_mixed(bsfm_problem* pb, double* sums, int ns, double* maxs, int nm)
 {
-    if (pb->world <= 1 || !pb->allreduce) return 0;
+    if (!has_collective(pb)) return 0;
     const int count = ns + nm * pb->world;
     std::vector<double> h((size_t)count, 0.0);
     for (int q = 0; q < ns; ++q) h[q] = sums[q];
     for (int q = 0; q < nm; ++q) h[ns + q * pb->world + pb->rank] = maxs[q];
     double* tmp = pb->d_mixed;
     HIP_OK(hipMemcpyAsync(tmp, h.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice, pb->stream));
-    HIP_OK(hipStreamSynchronize(pb->stream));
-    if (pb->allreduce(tmp, (size_t)count, 0, pb->allreduce_ctx) != 0) return BSFM_ERROR;
-    HIP_OK(hipMemcpy(h.data(), tmp, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    if (pb->comm) {
+        if (bsfm_comm_allreduce(pb->comm, tmp, (size_t)count, 0, pb->stream) != 0) return BSFM_ERROR;
+        HIP_OK(hipMemcpyAsync(h.data(), tmp, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+        HIP_OK(hipStreamSynchronize(pb->stream));
+    } else {
+        HIP_OK(hipStreamSynchronize(pb->stream));
+        if (pb->allreduce(tmp, (size_t)count, 0, pb->allreduce_ctx) != 0) return BSFM_ERROR;
+        HIP_OK(hipMemcpy(h.data(), tmp, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    }
     for (int q = 0; q < ns; ++q) sums[q] = h[q];
     for (int q = 0; q < nm; ++q) {
         double m = h[ns + q * pb->world];
@@ -373,7 +298,8 @@ int allreduce_mixed(bsfm_problem* pb, double* sums, int ns, double* maxs, int nm
 }
 int allreduce_dev(bsfm_problem* pb, double* dbuf, size_t count, int op)
 {
-    if (pb->world <= 1 || !pb->allreduce) return 0;
+    if (!has_collective(pb)) return 0;
+    if (pb->comm) return bsfm_comm_allreduce(pb->comm, dbuf, count, op, pb->stream);      // enqueued on the compute stream: no host hop
     HIP_OK(hipStreamSynchronize(pb->stream));
     if (pb->allreduce(dbuf, count, op, pb->allreduce_ctx) != 0) { fprintf(stderr, "[bsfm] allreduce hook failed\n"); return BSFM_ERROR; }
     return 0;
@@ -453,6 +379,7 @@ int exchange_block_union(bsfm_problem* pb)
     HIP_OK(dmalloc(&dseg, total));
     HIP_OK(hipMemcpy(dseg, seg.data(), total * sizeof(double), hipMemcpyHostToDevice));
     if (total && allreduce_dev(pb, dseg, total, 0)) { (void)hipFree(dseg); return BSFM_ERROR; }
+    HIP_OK(hipStreamSynchronize(pb->stream));        // the library-side collective is only ENQUEUED on the compute stream
     HIP_OK(hipMemcpy(seg.data(), dseg, total * sizeof(double), hipMemcpyDeviceToHost));
     (void)hipFree(dseg);
     std::vector<long long> keys;
@@ -489,7 +416,7 @@ int compute_schur(bsfm_problem* pb, double mu)
     DevProblem& P = pb->P;
     const int mm = P.m - P.mcon;
     const int lead = pb->rank == 0 ? 1 : 0;
-    const bool packed = pb->world > 1 && pb->allreduce;
+    const bool packed = has_collective(pb);
     if (packed && pb->ngblk < 0 && exchange_block_union(pb)) return BSFM_ERROR;
     if (pb->export_full_s) (void)hipMemsetAsync(pb->d_S, 0, (size_t)pb->ld * pb->ld * sizeof(double), pb->stream);
     else if (!pb->comps.active) {   // (the group-by-group solve never writes S: blocks that are structurally empty stay zero)
@@ -551,6 +478,8 @@ void bsfm_default_options(bsfm_options_t* opt)
     if (const char* e = getenv("BSFM_POTRF")) if (!strcmp(e, "rocsolver")) opt->potrf_backend = 1;
     opt->reduced_solver = BSFM_SOLVER_DENSE;
     if (const char* e = getenv("BSFM_REDUCED_SOLVER")) if (!strcmp(e, "auto")) opt->reduced_solver = BSFM_SOLVER_AUTO;
+    opt->num_gpus = 0;
+    if (const char* e = getenv("BSFM_NUM_GPUS")) opt->num_gpus = atoi(e);
 }
 
 int bsfm_device_count(void)
@@ -571,6 +500,15 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
         return nullptr;
     }
     if (!d || d->n < 0 || d->m <= 0 || d->mcon < 0 || d->mcon > d->m) { fprintf(stderr, "[bsfm] bad problem description\n"); return nullptr; }
+    if (!d->rowptr || !d->cameras || (d->n > 0 && (!d->points && !d->p_packed))) { fprintf(stderr, "[bsfm] bad problem description: rowptr / cameras / points missing\n"); return nullptr; }
+    if (d->rowptr[0] != 0 || d->rowptr[d->n] < 0) { fprintf(stderr, "[bsfm] bad problem description: rowptr[0] must be 0 and rowptr[n] >= 0\n"); return nullptr; }
+    if (d->rowptr[d->n] > 0 && (!d->colidx || !d->projections)) { fprintf(stderr, "[bsfm] bad problem description: colidx / projections missing\n"); return nullptr; }
+    {   // int32 indexing everywhere ("all indexing is int32"): refuse sizes that would overflow it
+        const long long nv = 9LL * d->m + 3LL * d->n, no = 2LL * d->rowptr[d->n];
+        if (nv > 0x7fffffffLL || no > 0x7fffffffLL) { fprintf(stderr, "[bsfm] problem too large for 32-bit indexing (%lld unknowns, %lld measurements)\n", nv, no); return nullptr; }
+    }
+    const auto t_create0 = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     bsfm_problem* pb = new bsfm_problem();
     if (opt_in) pb->opt = *opt_in; else bsfm_default_options(&pb->opt);
     auto fail = [&](const char* why) -> bsfm_problem_t* {
@@ -595,30 +533,33 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     pb->Sdim = (m - d->mcon) * cnp;
     pb->ld = std::max(POTRF_NB, (pb->Sdim + POTRF_NB - 1) / POTRF_NB * POTRF_NB);
 
-    // ---- index bookkeeping (bit-exact integer work; validated against the CRS the reference builds)
-    for (int i = 0; i < n; ++i) {
-        if (d->rowptr[i + 1] < d->rowptr[i]) return fail("rowptr not monotone");
-        for (int k = d->rowptr[i]; k < d->rowptr[i + 1]; ++k) {
-            if (d->colidx[k] < 0 || d->colidx[k] >= m) return fail("colidx out of range");
-            if (k > d->rowptr[i] && d->colidx[k] <= d->colidx[k - 1]) return fail("colidx not strictly ascending in a row");
-        }
-    }
-    std::vector<int> obs_pt(nvis), camptr(m + 1, 0), camobs(nvis);
-    for (int i = 0; i < n; ++i) for (int k = d->rowptr[i]; k < d->rowptr[i + 1]; ++k) { obs_pt[k] = i; ++camptr[d->colidx[k] + 1]; }
-    for (int j = 0; j < m; ++j) camptr[j + 1] += camptr[j];
-    std::vector<int> campos(nvis), cam_pt(nvis), cam_cam(nvis);
-    { std::vector<int> cur(camptr.begin(), camptr.end() - 1);
-      for (int k = 0; k < nvis; ++k) { const int t = cur[d->colidx[k]]++; camobs[t] = k; campos[k] = t; cam_pt[t] = obs_pt[k]; cam_cam[t] = d->colidx[k]; } }
-
     if (!(pb->stream = stream_pool().acquire())) return fail("stream");
     pb->own_stream = true;
 #define DM(ptr, cnt) if (dmalloc(&ptr, (size_t)(cnt)) != hipSuccess) return fail("hipMalloc " #ptr)
-    DM(pb->d_x, 2 * (size_t)nvis); DM(pb->d_obs_cam, nvis); DM(pb->d_obs_pt, nvis); DM(pb->d_rowptr, n + 1);
-    DM(pb->d_camptr, m + 1); DM(pb->d_camobs, nvis); DM(pb->d_Rinit, 9 * (size_t)m); DM(pb->d_finit, m);
+    auto up = [&](void* dst, const void* src, size_t bytes) { return bytes == 0 || hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess; };
+    // ---- index bookkeeping (bit-exact integer work, built on the device from the caller's CRS; index_build.hip)
+    const auto t_up0 = std::chrono::steady_clock::now();
+    DM(pb->d_rowptr, n + 1); DM(pb->d_obs_cam, nvis); DM(pb->d_x, 2 * (size_t)nvis);
+    if (!(up(pb->d_rowptr, d->rowptr, ((size_t)n + 1) * sizeof(int)) && up(pb->d_obs_cam, d->colidx, (size_t)nvis * sizeof(int)) &&
+          up(pb->d_x, d->projections, 2 * (size_t)nvis * sizeof(double)))) return fail("upload of the visibility index");
+    pb->create_ms[1] = ms_since(t_up0);
+    {
+        const auto t_ix0 = std::chrono::steady_clock::now();
+        const char* eo = getenv("BSFM_SCHUR_ORDER");
+        DeviceIndex ix;
+        if (build_index_device(n, m, d->mcon, nvis, pb->d_rowptr, pb->d_obs_cam, !pb->mot, (eo && !strcmp(eo, "block")) ? 1 : 0, ix, pb->stream) != 0) {
+            free_index_device(ix);
+            return fail("index construction");
+        }
+        if (adopt_index(pb, ix) != 0) return fail("schur structure");
+        pb->create_ms[2] = ms_since(t_ix0);
+    }
+    const auto t_al0 = std::chrono::steady_clock::now();
+    DM(pb->d_Rinit, 9 * (size_t)m); DM(pb->d_finit, m);
     DM(pb->d_p, pb->nvars_local); DM(pb->d_pdp, pb->nvars_local); DM(pb->d_dp, pb->nvars_local);
     DM(pb->d_camtab, (size_t)m * CT_STRIDE); DM(pb->d_camtab_trial, (size_t)m * CT_STRIDE);
     DM(pb->d_e, 2 * (size_t)nvis); DM(pb->d_hx, 2 * (size_t)nvis);
-    DM(pb->d_Jc, (size_t)nvis * P.js); DM(pb->d_campart, (size_t)m * CAM_SPLIT * (cnp * (cnp + 1) / 2 + cnp)); DM(pb->d_campos, nvis); DM(pb->d_cam_pt, nvis); DM(pb->d_cam_cam, nvis); DM(pb->d_U, (size_t)m * cnp * cnp + (size_t)m * cnp); pb->d_ea = pb->d_U + (size_t)m * cnp * cnp;   /* one buffer: one exchange */
+    DM(pb->d_Jc, (size_t)nvis * P.js); DM(pb->d_campart, (size_t)m * CAM_SPLIT * (cnp * (cnp + 1) / 2 + cnp)); DM(pb->d_U, (size_t)m * cnp * cnp + (size_t)m * cnp); pb->d_ea = pb->d_U + (size_t)m * cnp * cnp;   /* one buffer: one exchange */
     DM(pb->d_V, 6 * (size_t)n); DM(pb->d_Vinv, 6 * (size_t)n); DM(pb->d_eb, 3 * (size_t)n);
     DM(pb->d_S, (size_t)pb->ld * pb->ld); DM(pb->d_E, pb->ld);
     pb->red_blocks = std::max(grid_for(nvis, RES_BLOCK), std::max(grid_for(n, 256), 1024));
@@ -626,16 +567,11 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
 #undef DM
     if (hipHostMalloc((void**)&pb->h_scal, (SC_COUNT + 16) * sizeof(double)) != hipSuccess) return fail("pinned");
     if (hipHostMalloc((void**)&pb->h_flags, 4 * sizeof(int)) != hipSuccess) return fail("pinned");
-    (void)hipMemset(pb->d_scal, 0, (SC_COUNT + 16) * sizeof(double)); (void)hipMemset(pb->d_flags, 0, 4 * sizeof(int));
-    (void)hipMemset(pb->d_S, 0, (size_t)pb->ld * pb->ld * sizeof(double)); (void)hipMemset(pb->d_E, 0, pb->ld * sizeof(double));
-    (void)hipMemset(pb->d_dp, 0, pb->nvars_local * sizeof(double));
-
-    auto up = [&](void* dst, const void* src, size_t bytes) { return bytes == 0 || hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess; };
-    bool ok = up(pb->d_x, d->projections, 2 * (size_t)nvis * sizeof(double)) && up(pb->d_obs_cam, d->colidx, nvis * sizeof(int)) &&
-              up(pb->d_obs_pt, obs_pt.data(), nvis * sizeof(int)) && up(pb->d_rowptr, d->rowptr, (n + 1) * sizeof(int)) &&
-              up(pb->d_camptr, camptr.data(), (m + 1) * sizeof(int)) && up(pb->d_camobs, camobs.data(), nvis * sizeof(int)) &&
-              up(pb->d_campos, campos.data(), nvis * sizeof(int)) && up(pb->d_cam_pt, cam_pt.data(), nvis * sizeof(int)) &&
-              up(pb->d_cam_cam, cam_cam.data(), nvis * sizeof(int));
+    (void)hipMemsetAsync(pb->d_scal, 0, (SC_COUNT + 16) * sizeof(double), pb->stream); (void)hipMemsetAsync(pb->d_flags, 0, 4 * sizeof(int), pb->stream);
+    (void)hipMemsetAsync(pb->d_S, 0, (size_t)pb->ld * pb->ld * sizeof(double), pb->stream); (void)hipMemsetAsync(pb->d_E, 0, pb->ld * sizeof(double), pb->stream);
+    (void)hipMemsetAsync(pb->d_dp, 0, pb->nvars_local * sizeof(double), pb->stream);
+    pb->create_ms[3] = ms_since(t_al0);
+    bool ok = true;
     pb->h_Rinit.resize(9 * (size_t)m);
     std::vector<double> finit(m);
     for (int j = 0; j < m; ++j) { memcpy(&pb->h_Rinit[9 * (size_t)j], d->cameras[j].R, 9 * sizeof(double)); finit[j] = d->cameras[j].f; }
@@ -682,7 +618,6 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     P.camptr = pb->d_camptr; P.camobs = pb->d_camobs; P.campos = pb->d_campos; P.cam_pt = pb->d_cam_pt; P.cam_cam = pb->d_cam_cam; P.Rinit = pb->d_Rinit; P.finit = pb->d_finit;
     P.ccon = pb->d_ccon; P.cval = pb->d_cval; P.cw = pb->d_cw; P.pcon = pb->d_pcon; P.pval = pb->d_pval;
     P.Jc = pb->d_Jc; P.U = pb->d_U; P.ea = pb->d_ea; P.V = pb->d_V; P.Vinv = pb->d_Vinv; P.eb = pb->d_eb;
-    if (build_schur_structure(pb, d, campos, cam_pt) != 0) return fail("schur structure");
     if (potrf_init(pb->potrf, pb->ld, pb->opt.potrf_backend) != 0) return fail("potrf workspace");
     pb->ev_ok = true;
     for (int i = 0; i < PH_COUNT; ++i) {
@@ -690,6 +625,7 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
         pb->ph_ms[i] = 0.0; pb->ph_cnt[i] = 0;
     }
     (void)hipDeviceSynchronize();
+    pb->create_ms[0] = ms_since(t_create0);
     return pb;
 }
 
@@ -702,6 +638,7 @@ void bsfm_problem_destroy(bsfm_problem_t* pb)
 }
 
 void bsfm_problem_set_allreduce(bsfm_problem_t* pb, bsfm_allreduce_fn fn, void* ctx) { pb->allreduce = fn; pb->allreduce_ctx = ctx; }
+void bsfm_problem_set_comm(bsfm_problem_t* pb, bsfm_comm_t* comm) { pb->comm = comm; }
 
 void bsfm_problem_set_stream(bsfm_problem_t* pb, void* s)
 {
@@ -733,6 +670,39 @@ int bsfm_problem_reset_params(bsfm_problem_t* pb, const bsfm_camera_params_t* ca
     return 0;
 }
 
+// ---- test entries for the index bookkeeping: the arrays the kernels actually index with, straight from HBM
+int bsfm_problem_export_index(bsfm_problem_t* pb, int* rowptr, int* colidx, int* obs_pt, int* camptr, int* camobs, int* campos,
+                              int* cam_pt, int* cam_cam)
+{
+    const size_t nv = (size_t)pb->P.nvis;
+    HIP_OK(hipStreamSynchronize(pb->stream));
+    auto down = [](int* dst, const int* src, size_t cnt) { return !dst || cnt == 0 || hipMemcpy(dst, src, cnt * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess; };
+    const bool ok = down(rowptr, pb->d_rowptr, (size_t)pb->P.n + 1) && down(colidx, pb->d_obs_cam, nv) && down(obs_pt, pb->d_obs_pt, nv) &&
+                    down(camptr, pb->d_camptr, (size_t)pb->P.m + 1) && down(camobs, pb->d_camobs, nv) && down(campos, pb->d_campos, nv) &&
+                    down(cam_pt, pb->d_cam_pt, nv) && down(cam_cam, pb->d_cam_cam, nv);
+    return ok ? 0 : BSFM_ERROR;
+}
+
+int bsfm_problem_schur_sizes(const bsfm_problem_t* pb, int* ntriples, int* nblk, int* ntasks, int* nslots)
+{
+    if (ntriples) *ntriples = pb->ntriples;
+    if (nblk) *nblk = pb->nblk;
+    if (ntasks) *ntasks = pb->ntasks;
+    if (nslots) *nslots = pb->nslots;
+    return 0;
+}
+
+int bsfm_problem_export_schur(bsfm_problem_t* pb, int* triples, int* tri_pt, int* blk_j, int* blk_k, int* blk_task0, int* tasks)
+{
+    if (pb->mot) return BSFM_ERROR;
+    HIP_OK(hipStreamSynchronize(pb->stream));
+    auto down = [](void* dst, const void* src, size_t bytes) { return !dst || bytes == 0 || hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess; };
+    const bool ok = down(triples, pb->d_triples, (size_t)pb->ntriples * sizeof(int2)) && down(tri_pt, pb->d_tri_pt, (size_t)pb->ntriples * sizeof(int)) &&
+                    down(blk_j, pb->d_blk_j, (size_t)pb->nblk * sizeof(int)) && down(blk_k, pb->d_blk_k, (size_t)pb->nblk * sizeof(int)) &&
+                    down(blk_task0, pb->d_blk_task0, ((size_t)pb->nblk + 1) * sizeof(int)) && down(tasks, pb->d_tasks, (size_t)pb->nslots * sizeof(SchurTask));
+    return ok ? 0 : BSFM_ERROR;
+}
+
 int bsfm_problem_cnp(const bsfm_problem_t* pb) { return pb->cnp; }
 long long bsfm_problem_nvis(const bsfm_problem_t* pb) { return pb->P.nvis; }
 int bsfm_lm_solve_attempts(const bsfm_problem_t* pb) { return pb->nlss; }
@@ -746,6 +716,13 @@ double bsfm_lm_last_kernel_ms(const bsfm_problem_t* pb, const char* phase)
     if (!strcmp(phase, "syrk")) return pb->potrf.syrk_cnt ? pb->potrf.syrk_ms / (double)pb->potrf.syrk_cnt : -1.0;
     if (!strcmp(phase, "syrk_gflop")) return pb->potrf.syrk_cnt ? pb->potrf.syrk_flops * 1e-9 / (double)pb->potrf.syrk_cnt : -1.0;
     if (!strcmp(phase, "syrk_launches")) return pb->potrf.cnt ? (double)pb->potrf.syrk_cnt / (double)pb->potrf.cnt : -1.0;
+    // bsfm_problem_create: host wall time (total / upload of the visibility index / index construction / allocation) and the
+    // device time of the index construction alone
+    if (!strcmp(phase, "create_total")) return pb->create_ms[0];
+    if (!strcmp(phase, "create_upload")) return pb->create_ms[1];
+    if (!strcmp(phase, "create_index")) return pb->create_ms[2];
+    if (!strcmp(phase, "create_alloc")) return pb->create_ms[3];
+    if (!strcmp(phase, "index_build")) return pb->index_build_ms;
     return -1.0;
 }
 

@@ -161,7 +161,7 @@ class Problem:
         d.point_constraint_weight = point_constraint_weight
         d.world_size, d.rank, d.nvis_global, d.nvars_global = world_size, rank, nvis_global, nvars_global
         self.options = options if options is not None else default_options()
-        self.n, self.m = n, m
+        self.n, self.m, self.mcon = n, m, mcon
         self.h = lib.bsfm_problem_create(C.byref(d), C.byref(self.options))
         if not self.h:
             raise RuntimeError("bsfm_problem_create failed (no HIP device or invalid input); there is no CPU fallback")
@@ -259,18 +259,39 @@ class Problem:
 
     def normal_equations(self, mu=0.0, want_J=False):
         cnp, m, n = self.cnp, self.m, self.n
-        mm = m  # mcon handled by the library (S is (m-mcon)*cnp wide)
         U = np.zeros((m, cnp, cnp)); ea = np.zeros((m, cnp)); V = np.zeros((n, 3, 3)); eb = np.zeros((n, 3))
         J = np.zeros((self.nvis, 2 * cnp + 6)) if want_J else None
-        sd = (m - self._mcon()) * cnp
+        sd = (m - self.mcon) * cnp          # the library writes S / E for the free cameras only
         S = np.zeros((sd, sd)); E = np.zeros(sd)
         rc = lib.bsfm_eval_normal_equations(self.h, mu, _dp(U), _dp(ea), _dp(V), _dp(eb), _dp(J), _dp(S), _dp(E))
         if rc != 0:
             raise RuntimeError("bsfm_eval_normal_equations failed")
         return dict(U=U, ea=ea, V=V, eb=eb, J=J, S=S, E=E)
 
-    def _mcon(self):
-        return getattr(self, "mcon", 0)
+    def export_index(self):
+        """The index arrays the kernels use, downloaded from HBM."""
+        nv = self.nvis
+        out = dict(rowptr=np.zeros(self.n + 1, np.int32), colidx=np.zeros(nv, np.int32), obs_pt=np.zeros(nv, np.int32),
+                   camptr=np.zeros(self.m + 1, np.int32), camobs=np.zeros(nv, np.int32), campos=np.zeros(nv, np.int32),
+                   cam_pt=np.zeros(nv, np.int32), cam_cam=np.zeros(nv, np.int32))
+        rc = lib.bsfm_problem_export_index(self.h, *[_ip(out[k]) for k in ("rowptr", "colidx", "obs_pt", "camptr", "camobs", "campos",
+                                                                       "cam_pt", "cam_cam")])
+        if rc != 0:
+            raise RuntimeError("bsfm_problem_export_index failed")
+        return out
+
+    def export_schur(self):
+        """Co-visibility triples / blocks / tasks of the Schur complement as resident on the device."""
+        sz = [C.c_int() for _ in range(4)]
+        lib.bsfm_problem_schur_sizes(self.h, *[C.byref(v) for v in sz])
+        nt, nb, ntask, nslots = [v.value for v in sz]
+        out = dict(triples=np.zeros((nt, 2), np.int32), tri_pt=np.zeros(nt, np.int32), blk_j=np.zeros(nb, np.int32),
+                   blk_k=np.zeros(nb, np.int32), blk_task0=np.zeros(nb + 1, np.int32), tasks=np.zeros((nslots, 4), np.int32))
+        rc = lib.bsfm_problem_export_schur(self.h, *[_ip(out[k]) for k in ("triples", "tri_pt", "blk_j", "blk_k", "blk_task0", "tasks")])
+        if rc != 0:
+            raise RuntimeError("bsfm_problem_export_schur failed")
+        out["ntasks"] = ntask
+        return out
 
 
 def dense_chol_solve(A, b, backend=0):

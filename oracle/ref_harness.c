@@ -47,6 +47,11 @@ int ref_sizeof_camera_params(void) { return (int) sizeof(camera_params_t); }
  * set -- what run_sfm does for optimize_for_fisheye != 0 (sfm.c:829-836); the Jacobian is then always the reference's FD. */
 static int g_fisheye = 0;
 void ref_set_fisheye(int on) { g_fisheye = on; }
+/* eps1 of the next ref_sba_motstr calls (run_sfm's value 1e-10, sfm.c:706, unless set).  A huge eps1 makes the reference stop
+ * with code 1 before its first step (lib/sba-1.5/sba_levmar.c:1117-1121) -- with Sout != NULL it then exports U, V and the
+ * UNDAMPED reduced camera system at the INITIAL parameters: the fixture for the Schur complement at the headline size. */
+static double g_eps1 = 1.0e-10;
+void ref_set_eps1(double eps1) { g_eps1 = eps1; }
 
 void ref_run_sfm(int num_pts, int num_cameras, int ncons, char *vmask, double *projections,
                  int est_focal_length, int const_focal_length, int undistort, int explicit_camera_centers,
@@ -95,7 +100,7 @@ int ref_sba_motstr(int n, int m, int mcon, char *vmask, double *projections,
     }
     memcpy(params + cnp * m, pts, sizeof(double) * 3 * n);
 
-    opts[0] = 1.0e-3; opts[1] = 1.0e-10; opts[2] = eps2; opts[3] = 1.0e-12; opts[4] = 0.0; opts[5] = 4.0e-2;
+    opts[0] = 1.0e-3; opts[1] = g_eps1; opts[2] = eps2; opts[3] = 1.0e-12; opts[4] = 0.0; opts[5] = 4.0e-2;
 
     if (use_constraints) {
         cons = (camera_constraints_t *) malloc(m * sizeof(camera_constraints_t));
@@ -263,4 +268,52 @@ void ref_triangulate(int mode, int nviews, double *p, double *R, double *t, doub
     else if (mode == 1) r = triangulate_n_refine(v3_new(X[0], X[1], X[2]), nviews, (v2_t *) p, R, t, err);
     else r = triangulate(v2_new(p[0], p[1]), v2_new(p[2], p[3]), R, t, R + 9, t + 3, err);
     X[0] = Vx(r); X[1] = Vy(r); X[2] = Vz(r);
+}
+
+/* ---- index bookkeeping --------------------------------------------------------------------------
+ * The reference's own visibility index: sba_crsm_alloc + the fill loop of sba_motstr_levmar_x (lib/sba-1.5/sba_levmar.c:653-663,
+ * restated here because it is inline in that function), then the camera-major traversal every U_j / Q / Jacobian loop uses,
+ * sba_crsm_col_elmidxs (lib/sba-1.5/sba_crsm.c:183-212): for camera j the list of (val index, point) pairs in ascending point
+ * order.  Outputs: rowptr (n+1), colidx (nvis), val (nvis), camptr (m+1), camobs (nvis: idxij.val[rcidxs[.]] in traversal
+ * order), campt (nvis: rcsubs in traversal order).  Returns nvis. */
+int ref_crsm_index(int n, int m, char *vmask, int *rowptr, int *colidx, int *val, int *camptr, int *camobs, int *campt)
+{
+    struct sba_crsm idxij;
+    int i, j, k, ii, nvis, jj, nnz, t = 0;
+    int *rcidxs, *rcsubs;
+    for (i = nvis = 0, jj = n * m; i < jj; ++i) nvis += (vmask[i] != 0);
+    sba_crsm_alloc(&idxij, n, m, nvis);
+    for (i = k = 0; i < n; ++i) {
+        idxij.rowptr[i] = k;
+        ii = i * m;
+        for (j = 0; j < m; ++j)
+            if (vmask[ii + j]) { idxij.val[k] = k; idxij.colidx[k++] = j; }
+    }
+    idxij.rowptr[n] = nvis;
+    memcpy(rowptr, idxij.rowptr, (n + 1) * sizeof(int));
+    memcpy(colidx, idxij.colidx, nvis * sizeof(int));
+    memcpy(val, idxij.val, nvis * sizeof(int));
+    rcidxs = (int *) malloc((n > m ? n : m) * sizeof(int) + sizeof(int));
+    rcsubs = (int *) malloc((n > m ? n : m) * sizeof(int) + sizeof(int));
+    for (j = 0; j < m; ++j) {
+        camptr[j] = t;
+        nnz = sba_crsm_col_elmidxs(&idxij, j, rcidxs, rcsubs);
+        for (i = 0; i < nnz; ++i) { camobs[t] = idxij.val[rcidxs[i]]; campt[t] = rcsubs[i]; ++t; }
+    }
+    camptr[m] = t;
+    free(rcidxs); free(rcsubs);
+    sba_crsm_free(&idxij);
+    return nvis;
+}
+
+/* ---- post-solve statistics of RunSFM_SBA ----------------------------------------------------------------
+ * The two reference routines the statistics loop of src/Bundle.cpp:659-913 is built on: the final projection
+ * sfm_project_rd (lib/sfm-driver/sfm.c:302-380; Bundle.cpp:736 calls it with the camera's R, its k, 1/f scaling done by the
+ * caller) and kth_element_copy (lib/imagelib/qsort.c:152-203, compiled into this library by oracle/Makefile). */
+extern double kth_element_copy(int n, int k, double *arr);
+double ref_kth_element_copy(int n, int k, double *arr) { return kth_element_copy(n, k, arr); }
+void ref_sfm_project_rd(camera_params_t *cam, double *K, double *k, double *R, double *dt, double *b, double *p,
+                        int undistort, int explicit_centers)
+{
+    sfm_project_rd(cam, K, k, R, dt, b, p, undistort, explicit_centers);
 }

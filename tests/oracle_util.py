@@ -362,3 +362,45 @@ def ref_rand_sequence(seed, n):
     out = np.zeros(n, np.int32)
     fmref().ref_rand_sequence(C.c_uint(seed), n, out.ctypes.data_as(C.POINTER(C.c_int)))
     return out
+
+
+def ref_crsm_index(n, m, vmask):
+    """The reference's own visibility index (oracle/ref_harness.c:ref_crsm_index): struct sba_crsm filled as
+    lib/sba-1.5/sba_levmar.c:653-663 and the camera-major traversal of sba_crsm_col_elmidxs (lib/sba-1.5/sba_crsm.c:183-212)."""
+    vm = np.ascontiguousarray(vmask, np.uint8)
+    nvis = int((vm != 0).sum())
+    ip = C.POINTER(C.c_int)
+    out = dict(rowptr=np.zeros(n + 1, np.int32), colidx=np.zeros(max(nvis, 1), np.int32), val=np.zeros(max(nvis, 1), np.int32),
+               camptr=np.zeros(m + 1, np.int32), camobs=np.zeros(max(nvis, 1), np.int32), campt=np.zeros(max(nvis, 1), np.int32))
+    fn = ref().ref_crsm_index
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_int, C.c_char_p, ip, ip, ip, ip, ip, ip]
+    got = fn(n, m, vm.ctypes.data_as(C.c_char_p), *[out[k].ctypes.data_as(ip) for k in ("rowptr", "colidx", "val", "camptr", "camobs", "campt")])
+    assert got == nvis
+    for k in ("colidx", "val", "camobs", "campt"):
+        out[k] = out[k][:nvis]
+    return out
+
+
+def ref_kth_element_copy(arr, k):
+    """kth_element_copy of lib/imagelib/qsort.c:152-203 (compiled into oracle/_ref/libsfmref.so)."""
+    a = np.ascontiguousarray(arr, np.float64).copy()
+    fn = ref().ref_kth_element_copy
+    fn.restype = C.c_double
+    fn.argtypes = [C.c_int, C.c_int, _dp]
+    return fn(len(a), int(k), _d(a))
+
+
+def ref_project_rd(cam, b, undistort=1, explicit_centers=1):
+    """sfm_project_rd (lib/sfm-driver/sfm.c:302-380) called as src/Bundle.cpp:726-739 calls it: K = diag(f, f, 1), dt = the
+    camera's t (centre), the camera's own R and k."""
+    K = np.array([cam.f, 0, 0, 0, cam.f, 0, 0, 0, 1.0])
+    k = np.array(list(cam.k), np.float64); R = np.array(list(cam.R), np.float64); dt = np.array(list(cam.t), np.float64)
+    bb = np.array(b, np.float64); p = np.zeros(2)
+    fn = ref().ref_sfm_project_rd
+    fn.restype = None
+    fn.argtypes = [_cp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_int, C.c_int]
+    one = (CameraParams * 1)()
+    C.memmove(one, C.byref(cam), C.sizeof(CameraParams))
+    fn(one, _d(K), _d(k), _d(R), _d(dt), _d(bb), _d(p), undistort, explicit_centers)
+    return p

@@ -22,6 +22,8 @@ def test_library_loads_and_exports_header(bsfm):
     for s in syms:
         assert hasattr(bsfm.lib, s), f"{s} declared in include/bsfm.h but not exported"
     assert sorted(bsfm._lib.SYMBOLS) == syms
+    for s in syms:      # every entry is called through declared argument types (no hand-wrapped doubles / pointers)
+        assert getattr(bsfm.lib, s).argtypes is not None, f"{s}: no ctypes argtypes declared in bundler_sfm_amd/_lib.py"
 
 
 def test_camera_struct_layout_matches_reference(bsfm):

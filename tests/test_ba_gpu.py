@@ -23,7 +23,6 @@ def make_problem(B, c, jac, **kw):
     opt = B.default_options(jacobian=jac, verbose=0, **kw)
     pb = B.Problem(c["n"], c["m"], c["rowptr"], c["colidx"], c["proj"], c["cams"], c["pts"], mcon=c["ncons"],
                    est_focal_length=c["est"], undistort=c["und"], use_constraints=c["cons"], options=opt)
-    pb.mcon = c["ncons"]
     return pb
 
 

@@ -54,3 +54,56 @@ def test_cross_check_backend_agrees(gpu_bsfm):
     rc1, x1 = gpu_bsfm.dense_chol_solve(A, b, 1)
     assert rc0 == 0 and rc1 == 0
     assert np.abs(x0 - x1).max() <= 1e-11 * np.abs(x1).max()
+
+
+@pytest.mark.timeout(900)
+def test_solve_at_the_headline_order_9000(gpu_bsfm):
+    """n = 9 000 = 71 tile columns: the size of the reduced camera system of BASELINE.json configs[2] -- three-stream
+    lookahead schedule, ring of 4 panel buffers, 68 bulk launches, persistent backward substitution over 71 workgroups."""
+    n = 9000
+    rng = np.random.default_rng(9000)
+    # low-rank-plus-diagonal SPD matrix with a wide spectrum (building A A^T at this order on the host would take minutes)
+    F = rng.standard_normal((n, 64))
+    d = np.exp(rng.uniform(np.log(1e-2), np.log(1e2), n))
+    A = (F * np.linspace(0.5, 2.0, 64)) @ F.T
+    A[np.diag_indices(n)] += d
+    b = rng.standard_normal(n)
+    rc, x = gpu_bsfm.dense_chol_solve(A, b)
+    assert rc == 0
+    r = A @ x - b
+    assert np.abs(r).max() <= 1e-11 * (np.abs(A).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max())     # backward error
+    # forward check through Woodbury: A = D + G G^T with G = F diag(sqrt(w))
+    G = F * np.sqrt(np.linspace(0.5, 2.0, 64))
+    Dib = b / d; DiG = G / d[:, None]
+    xw = Dib - DiG @ np.linalg.solve(np.eye(64) + G.T @ DiG, G.T @ Dib)
+    assert np.abs(x - xw).max() <= 1e-9 * np.abs(xw).max()
+
+
+@pytest.mark.timeout(600)
+def test_ill_conditioned_reduced_camera_system(gpu_bsfm):
+    """The matrix the factorisation really sees: the reduced camera system of a CONNECTED scene (banded visibility, no camera
+    held fixed, so the undamped S has the 7-dimensional gauge null space) with the small first-iteration damping
+    mu = 1e-3 * max diag (sba_levmar.c:1124-1128).  The panel uses an explicit inverse of the diagonal factor tile
+    (potrf.hip.h), so the check is the backward error a backward-stable dpotrf/dpotrs pair would deliver, and agreement with
+    LAPACK's solution to within cond * eps."""
+    import scipy.linalg as sl
+    B = gpu_bsfm
+    m, n = 400, 40000
+    s = B.synth_ba(m, n, 8, banded=True)
+    pb = B.Problem(n, m, s["rowptr"], s["colidx"], s["proj"], s["cams"], s["pts"], options=B.default_options(jacobian=1, verbose=0))
+    ne0 = pb.normal_equations(mu=0.0)
+    maxdiag = max(np.abs(np.einsum("jkk->jk", ne0["U"])).max(), np.abs(np.einsum("ikk->ik", ne0["V"])).max())
+    mu = 1e-3 * maxdiag
+    ne = pb.normal_equations(mu=mu)
+    pb.close()
+    S, E = ne["S"], ne["E"]
+    assert np.abs(S - S.T).max() == 0.0
+    w = np.linalg.eigvalsh(S)
+    cond = w[-1] / w[0]
+    assert w[0] > 0 and cond > 1e6, cond                 # genuinely ill-conditioned, still positive definite
+    rc, x = B.dense_chol_solve(S, E)
+    assert rc == 0
+    ref = sl.cho_solve(sl.cho_factor(S, lower=True), E)
+    nrm = np.abs(S).sum(axis=1).max()
+    assert np.abs(S @ x - E).max() <= 1e-11 * (nrm * np.abs(x).max() + np.abs(E).max())
+    assert np.abs(x - ref).max() <= 20 * cond * np.finfo(float).eps * np.abs(ref).max()

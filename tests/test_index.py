@@ -1,0 +1,138 @@
+"""Index bookkeeping, bit-exact.
+
+The PRODUCT's arrays -- the CRS run_sfm derives from the dense vmask, and the camera-major index / co-visibility structure the
+device-side construction (bundler_sfm_amd/csrc/index_build.hip) leaves in HBM -- are compared with the REFERENCE'S OWN
+struct sba_crsm (lib/sba-1.5/sba_levmar.c:653-663) and its camera-major traversal sba_crsm_col_elmidxs
+(lib/sba-1.5/sba_crsm.c:183-212), compiled into oracle/_ref/libsfmref.so (oracle/ref_harness.c:ref_crsm_index).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_util as O
+
+needs_ref = pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+
+
+def random_vmask(rng, n, m, density, mcon_rows=True):
+    vm = (rng.random((n, m)) < density).astype(np.uint8)
+    if n > 4:
+        vm[1, :] = 0                       # a point nobody sees
+        vm[2, :] = 1                       # a point everybody sees
+    if m > 3:
+        vm[:, m - 1] = 0                   # a camera without observations
+    return vm
+
+
+def product_crs(B, vm):
+    n, m = vm.shape
+    ip = C.POINTER(C.c_int)
+    nvis = B.lib.bsfm_crs_from_vmask(n, m, vm.ctypes.data_as(C.c_char_p), None, None)
+    rp = np.zeros(n + 1, np.int32); ci = np.zeros(max(nvis, 1), np.int32)
+    assert B.lib.bsfm_crs_from_vmask(n, m, vm.ctypes.data_as(C.c_char_p), rp.ctypes.data_as(ip), ci.ctypes.data_as(ip)) == nvis
+    return rp, ci[:nvis]
+
+
+@needs_ref
+@pytest.mark.parametrize("n,m,density,seed", [(300, 40, 0.2, 1), (57, 9, 0.6, 2), (1, 5, 1.0, 3), (1000, 130, 0.03, 4)])
+def test_crs_from_vmask_is_the_reference_crsm(bsfm, n, m, density, seed):
+    vm = random_vmask(np.random.default_rng(seed), n, m, density)
+    rp, ci = product_crs(bsfm, vm)
+    r = O.ref_crsm_index(n, m, vm)
+    assert np.array_equal(rp, r["rowptr"]) and np.array_equal(ci, r["colidx"])
+    assert np.array_equal(r["val"], np.arange(len(ci)))          # val[k] = k: the observation ordering contract
+
+
+def schur_restatement(rowptr, colidx, campos, mcon, m):
+    """numpy restatement of the order the reference visits the co-visibility pairs in (sba_levmar.c:1182-1268): block (j, k),
+    j <= k, and inside a block ascending point index."""
+    keys, vals, pts = [], [], []
+    mm = m - mcon
+    for i in range(len(rowptr) - 1):
+        ks = [k for k in range(rowptr[i], rowptr[i + 1]) if colidx[k] >= mcon]
+        for a in range(len(ks)):
+            for b in range(a, len(ks)):
+                keys.append((colidx[ks[a]] - mcon) * mm + (colidx[ks[b]] - mcon)); vals.append((campos[ks[a]], campos[ks[b]])); pts.append(i)
+    keys = np.array(keys, np.int64); order = np.argsort(keys, kind="stable")
+    return keys[order], np.array(vals, np.int32).reshape(-1, 2)[order], np.array(pts, np.int32)[order]
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("n,m,density,mcon,seed", [(300, 40, 0.2, 0, 1), (57, 9, 0.6, 2, 2), (400, 64, 0.1, 0, 5), (2000, 130, 0.03, 3, 4)])
+def test_device_index_is_the_reference_index(gpu_bsfm, n, m, density, mcon, seed):
+    B = gpu_bsfm
+    rng = np.random.default_rng(seed)
+    vm = random_vmask(rng, n, m, density)
+    rp, ci = product_crs(B, vm)
+    nvis = len(ci)
+    s = B.synth_ba(m, n, 3)
+    # nobs >= nvars is not needed to build the index; the LM is never started here
+    pb = B.Problem(n, m, rp, ci, rng.standard_normal(2 * nvis), s["cams"], s["pts"], mcon=mcon, options=B.default_options(verbose=0))
+    ix = pb.export_index()
+    r = O.ref_crsm_index(n, m, vm)
+    assert np.array_equal(ix["rowptr"], r["rowptr"]) and np.array_equal(ix["colidx"], r["colidx"])
+    assert np.array_equal(ix["camptr"], r["camptr"])
+    assert np.array_equal(ix["camobs"], r["camobs"])             # traversal order of sba_crsm_col_elmidxs, camera by camera
+    assert np.array_equal(ix["cam_pt"], r["campt"])
+    assert np.array_equal(ix["campos"][ix["camobs"]], np.arange(nvis))
+    assert np.array_equal(ix["obs_pt"], np.repeat(np.arange(n), np.diff(rp)))
+    assert np.array_equal(ix["cam_cam"], ci[ix["camobs"]])
+    # co-visibility structure
+    sc = pb.export_schur()
+    keys, vals, pts = schur_restatement(rp, ci, ix["campos"], mcon, m)
+    assert np.array_equal(sc["triples"], vals) and np.array_equal(sc["tri_pt"], pts)
+    ukeys, starts = np.unique(keys, return_index=True)
+    mm = m - mcon
+    assert np.array_equal(sc["blk_j"], mcon + ukeys // mm) and np.array_equal(sc["blk_k"], mcon + ukeys % mm)
+    counts = np.diff(np.append(starts, len(keys)))
+    ntask = (counts + 167) // 168
+    assert np.array_equal(sc["blk_task0"], np.concatenate([[0], np.cumsum(ntask)]))
+    tasks = sc["tasks"]; real = tasks[tasks[:, 3] >= 0]
+    assert len(real) == sc["ntasks"] == int(ntask.sum())
+    by_slot = real[np.argsort(real[:, 3])]
+    assert np.array_equal(by_slot[:, 3], np.arange(len(real)))
+    exp = []
+    for b in range(len(ukeys)):
+        for t in range(ntask[b]):
+            s0 = starts[b] + 168 * t
+            exp.append((s0, min(168, starts[b] + counts[b] - s0), int(sc["blk_j"][b] == sc["blk_k"][b])))
+    assert np.array_equal(by_slot[:, :3], np.array(exp, np.int32).reshape(-1, 3))
+    # launch order: sorted by the first point a task touches, one contiguous stretch per XCD (workgroup % 8)
+    nwg = len(tasks) // 4
+    first_pt = np.where(tasks[:, 3] >= 0, pts[np.clip(tasks[:, 0], 0, max(len(pts) - 1, 0))] if len(pts) else 0, 1 << 30)
+    for x in range(8):
+        seq = np.concatenate([first_pt[4 * wg:4 * wg + 4] for wg in range(x, nwg, 8)]) if nwg > x else np.zeros(0)
+        seq = seq[seq < (1 << 30)]
+        assert (np.diff(seq) >= 0).all()
+    pb.close()
+
+
+@pytest.mark.gpu
+def test_device_index_at_the_headline_size(gpu_bsfm):
+    """1 000 cameras / 500 000 points / 5 M observations: camera-major order = stable sort by camera (what
+    sba_crsm_col_elmidxs enumerates), Schur structure checked through its invariants; also reports the build time."""
+    B = gpu_bsfm
+    m, n = 1000, 500000
+    s = B.synth_ba(m, n, 10)
+    pb = B.Problem(n, m, s["rowptr"], s["colidx"], s["proj"], s["cams"], s["pts"], options=B.default_options(verbose=0))
+    ix = pb.export_index()
+    order = np.argsort(s["colidx"], kind="stable").astype(np.int32)
+    assert np.array_equal(ix["camobs"], order)
+    assert np.array_equal(ix["camptr"], np.concatenate([[0], np.cumsum(np.bincount(s["colidx"], minlength=m))]))
+    assert np.array_equal(ix["campos"][order], np.arange(len(order)))
+    sc = pb.export_schur()
+    assert len(sc["triples"]) == n * 55
+    cam = ix["cam_cam"]
+    j = cam[sc["triples"][:, 0]].astype(np.int64); k = cam[sc["triples"][:, 1]].astype(np.int64)
+    key = j * m + k
+    assert (j <= k).all() and (np.diff(key) >= 0).all()                       # grouped by block in (j, k) order
+    same = np.diff(key) == 0
+    assert (np.diff(sc["tri_pt"])[same] > 0).all()                            # point order inside a block
+    assert np.array_equal(ix["cam_pt"][sc["triples"][:, 0]], sc["tri_pt"]) and np.array_equal(ix["cam_pt"][sc["triples"][:, 1]], sc["tri_pt"])
+    print("index build: %.2f ms on the device, problem_create %.1f ms wall (upload %.1f, index %.1f, allocation %.1f)" % (
+        pb.phase_ms("index_build"), pb.phase_ms("create_total"), pb.phase_ms("create_upload"), pb.phase_ms("create_index"),
+        pb.phase_ms("create_alloc")))
+    assert pb.phase_ms("index_build") < 100.0
+    pb.close()

@@ -213,3 +213,59 @@ def test_sharded_matcher_merges_to_the_single_run_file(gpu_bsfm, tmp_path):
     assert B.lib.bsfm_merge_match_files(world, cp, str(merged).encode()) == n_single
     assert merged.read_bytes() == single.read_bytes()
     assert B.lib.bsfm_key_match_full_sharded(len(sizes), ip, arr, C.c_double(0.6), -1, paths[0], 3, 3) < 0     # bad rank
+
+
+# ---- BASELINE.json configs[4] shape (5 000 keys per image) and database images beyond one 8 192-key scan segment -------------
+# Fixtures: the reference's exact search (tests/golden/make_match_cfg5_golden.py); descriptors regenerated from their seeds.
+CFG5 = {"p5000a": (5000, 502, 5000, 501), "p5000b": (5000, 504, 5000, 503), "seg2": (2000, 508, 9000, 507),
+        "seg3": (3000, 506, 17000, 505)}
+_cfg5_path = os.path.join(HERE, "golden", "match_cfg5_golden.npz")
+MG5 = np.load(_cfg5_path) if os.path.exists(_cfg5_path) else None
+
+
+def cfg5_keys(B, name):
+    n1, s1, n2, s2 = CFG5[name]
+    k2 = synth_keys(B, n2, s2)
+    return synth_keys(B, n1, s1, dup=k2), k2
+
+
+def test_oracle_equals_reference_exact_search_at_5000_keys(bsfm):
+    assert MG5 is not None, "tests/golden/match_cfg5_golden.npz missing"
+    k1, k2 = cfg5_keys(bsfm, "p5000a")
+    assert np.array_equal(O.port_match(k1, k2), MG5["p5000a_exact"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(CFG5))
+def test_gpu_matches_reference_exact_search_at_config5_sizes(gpu_bsfm, name):
+    """Bit-identical to MatchKeys(..., max_pts_visit = 0) (src/keys2a.cpp:347-372) for two 5 000 x 5 000 pairs and for database
+    images of 9 000 and 17 000 keys (2 and 3 segments of the kernel's 8 192-key scan loop, match_l2.hip)."""
+    assert MG5 is not None, "tests/golden/match_cfg5_golden.npz missing"
+    k1, k2 = cfg5_keys(gpu_bsfm, name)
+    cnt, got = gpu_match(gpu_bsfm, k1, k2)
+    ref = MG5[f"{name}_exact"]
+    assert cnt == len(ref) and np.array_equal(got, ref)
+    if name.startswith("seg"):          # matches must come from every segment of the database image
+        segs = set((ref[:, 1] // 8192).tolist())
+        assert segs == set(range((CFG5[name][2] + 8191) // 8192))
+
+
+@pytest.mark.gpu
+def test_gpu_best_and_second_best_in_different_segments(gpu_bsfm):
+    """The running top-2 is kept per 8 192-key segment and merged afterwards: plant the nearest and the second nearest
+    neighbour of a query in different segments (and a tie across segments) and compare with the exhaustive oracle."""
+    B = gpu_bsfm
+    k2 = synth_keys(B, 20000, 77)
+    k1 = synth_keys(B, 64, 78)
+    rng = np.random.default_rng(5)
+    for q in range(64):
+        a, b = int(rng.integers(0, 8192)), int(rng.integers(8192, 20000))
+        if q % 2:
+            a, b = b, a
+        near = k1[q].astype(np.int32)
+        k2[a] = np.clip(near + rng.integers(-2, 3, 128), 0, 255).astype(np.uint8)             # nearest
+        k2[b] = np.clip(near + rng.integers(-(3 + q % 5), 4 + q % 5, 128), 0, 255).astype(np.uint8)   # runner-up: ratio test decides
+    k2[19999] = k2[100]                                                                      # exact duplicate across segments
+    cnt, got = gpu_match(B, k1, k2)
+    ref = O.port_match(k1, k2)
+    assert cnt == len(ref) and np.array_equal(got, ref)

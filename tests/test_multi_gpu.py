@@ -111,3 +111,78 @@ def test_two_ranks_one_gpu_match_single_rank(tmp_path, monkeypatch, solver):
         # the exchange is the packed block union (<= lower triangle: m(m+1)/2 blocks of 81), never the dense (9m)^2 matrix
         assert int(r[k]["max_count"]) <= max(81 * m * (m + 1) // 2, 81 * m)
     assert np.array_equal(r[0]["p"][:9 * m], r[1]["p"][:9 * m])      # bitwise identical replicas
+
+
+# ---- the collective on the C/C++ side of the boundary (comm.hip) ------------------------------------------------------------
+def test_run_sfm_over_two_in_process_ranks_matches_one_gpu(monkeypatch):
+    """run_sfm itself on "2 GPUs": opt.num_gpus = 2 makes the library shard the points over two host threads inside the one
+    process (boundary.hip:run_multi).  Both ranks sit on the single device of this box, so the communicator falls back from
+    ncclCommInitAll to its loopback transport (BSFM_ALLOW_SHARED_DEVICE) -- the whole multi-rank control flow (sharding,
+    U || ea exchange, block-union exchange, packed reduced system, scalar decisions, per-rank download) is the production one."""
+    import bundler_sfm_amd as B
+    monkeypatch.setenv("BSFM_ALLOW_SHARED_DEVICE", "1")
+    m, n = 24, 1500
+    s = B.synth_ba(m, n, 6, banded=True)
+    vm = B.dense_vmask(n, m, s["rowptr"], s["colidx"])
+    outs = []
+    for g in (1, 2, 3):
+        cams = B.copy_cameras(s["cams"]); pts = s["pts"].copy()
+        opt = B.default_options(jacobian=B.JAC_ANALYTIC, verbose=0, itmax=8, num_gpus=g)
+        rc, info = B.run_sfm(n, m, 0, vm, s["proj"], 1, 0, 1, 1, cams, pts, eps2=1e-12, options=opt)
+        assert rc >= 0
+        outs.append((info, np.array([list(c.R) + list(c.t) + [c.f] + list(c.k) for c in cams]), pts))
+    i1, c1, p1 = outs[0]
+    assert i1[1] < 0.05 * i1[0]
+    for info, cam, pts in outs[1:]:
+        assert list(info[5:10]) == list(i1[5:10])                       # same iterations / stop code / counters
+        assert abs(info[1] - i1[1]) <= 1e-9 * i1[1]
+        assert np.abs(cam - c1).max() <= 1e-8 * np.abs(c1).max()
+        assert np.abs(pts - p1).max() <= 1e-8
+
+
+def _rccl_world1(out):
+    import ctypes as C
+    import bundler_sfm_amd as B
+    c = B.lib.bsfm_comm_create_from_env()
+    res = dict(ok=bool(c), transport="", sum=0.0, idfile=os.environ["BSFM_COMM_ID_FILE"])
+    if c:
+        res["transport"] = B.lib.bsfm_comm_transport(c).decode()
+        v = (C.c_double * 3)(1.0, 2.0, 3.5)
+        rc = B.lib.bsfm_comm_allreduce_host(c, v, 3, 0)
+        res["sum"] = float(v[0] + v[1] + v[2]) if rc == 0 else -1.0
+        res["exists_before_destroy"] = os.path.exists(res["idfile"])
+        # a BA problem that BELIEVES it is one of two ranks but reduces over this one-rank communicator: the exchange path
+        # (packed block union, ncclAllReduce on the compute stream) runs end to end through RCCL
+        s = B.synth_ba(12, 300, 6)
+        pb = B.Problem(300, 12, s["rowptr"], s["colidx"], s["proj"], s["cams"], s["pts"], world_size=2, rank=0,
+                       options=B.default_options(jacobian=1, verbose=0, itmax=4))
+        B.lib.bsfm_problem_set_comm(pb.h, c)
+        rc2, info = pb.solve()
+        pb2 = B.Problem(300, 12, s["rowptr"], s["colidx"], s["proj"], s["cams"], s["pts"], options=B.default_options(jacobian=1, verbose=0, itmax=4))
+        rc3, info3 = pb2.solve()
+        res["ba"] = [float(info[1]), float(info3[1]), int(rc2), int(rc3)]
+        pb.close(); pb2.close()
+        B.lib.bsfm_comm_destroy(c)
+        res["exists_after_destroy"] = os.path.exists(res["idfile"])
+    import json
+    json.dump(res, open(out, "w"))
+
+
+def test_rccl_communicator_from_env_world_size_one(tmp_path):
+    """bsfm_comm_create_from_env with RCCL forced on for a world of one rank: dlopen of librccl.so, ncclUniqueId hand-over file,
+    ncclCommInitRank, ncclAllReduce enqueued on the problem's stream.  (More ranks need more GPUs than this box has; the
+    N-rank path differs only in the value of WORLD_SIZE.)"""
+    import json
+    import subprocess
+    out = tmp_path / "res.json"
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_PORT="29876", BSFM_COMM_FORCE_RCCL="1",
+               BSFM_COMM_ID_FILE=str(tmp_path / "nccl.id"), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    code = f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {HERE!r}); import test_multi_gpu as t; t._rccl_world1({str(out)!r})"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.load(open(out))
+    assert res["ok"] and res["transport"] == "rccl"
+    assert res["sum"] == 6.5
+    assert res["exists_before_destroy"] and not res["exists_after_destroy"]
+    c_two, c_one, rc2, rc3 = res["ba"]
+    assert rc2 == rc3 and abs(c_two - c_one) <= 1e-12 * c_one
