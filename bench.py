@@ -100,10 +100,18 @@ def pmc_summary():
         return None, None
 
 
+def _kernel_entry(d, kernel):
+    """Entry of `kernel` in a PMC summary; template instances are listed as name<args> (the one with most launches wins)."""
+    if not d:
+        return None
+    cands = [v for k, v in d["kernels"].items() if k == kernel or k.startswith(kernel + "<")]
+    return max(cands, key=lambda v: v.get("launches", 0)) if cands else None
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from that summary; None when no summary is committed."""
     d, _ = pmc_summary()
-    k = d["kernels"].get(kernel) if d else None
+    k = _kernel_entry(d, kernel)
     return None if not k else round(k["traffic_bytes"])
 
 
@@ -111,7 +119,7 @@ def pmc_mfma(kernel):
     """MFMA-busy evidence of `kernel` from the same summary: SQ_VALU_MFMA_BUSY_CYCLES per launch (summed over SIMDs),
     its share of all SIMD cycles of the device (GRBM_GUI_ACTIVE is summed over the 8 XCDs) and of the busy CU cycles."""
     d, name = pmc_summary()
-    c = (d["kernels"].get(kernel) or {}).get("counters") if d else None
+    c = (_kernel_entry(d, kernel) or {}).get("counters")
     if not c or "SQ_VALU_MFMA_BUSY_CYCLES" not in c:
         return None
     out = {"source": "profiles/" + name, "SQ_VALU_MFMA_BUSY_CYCLES": round(c["SQ_VALU_MFMA_BUSY_CYCLES"])}

@@ -279,6 +279,9 @@ void free_index_device(DeviceIndex& ix)
 int build_index_device(int n, int m, int mcon, int nvis, const int* d_rowptr, const int* d_colidx, bool want_schur,
                        int order_by_block, DeviceIndex& ix, hipStream_t st)
 {
+    // rocPRIM checks hipGetLastError() after its launches: a stale error of an EARLIER, unrelated call in this thread (e.g.
+    // hipEventElapsedTime on a never-recorded phase event -> hipErrorInvalidHandle) would be reported as a sort failure
+    (void)hipGetLastError();
     hipEvent_t e0 = nullptr, e1 = nullptr;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     if (e0) (void)hipEventRecord(e0, st);

@@ -107,6 +107,7 @@ struct PotrfWorkspace {
     hipEvent_t* sy0 = nullptr; hipEvent_t* sy1 = nullptr; int sy_used = 0;
     double syrk_ms = 0.0; long long syrk_cnt = 0;
     double* sy_flops = nullptr; double syrk_flops = 0.0;     // flops of each timed launch / running sum
+    int syrk_nt = 1;            // non-temporal C traffic in the bulk kernel (BSFM_SYRK_NT=0 switches it off)
     long long* dbg = nullptr;   // optional device buffer: cycle stamps of k_potrf_diag phases (BSFM_DEBUG_DIAG=1)
 };
 
@@ -431,6 +432,11 @@ __global__ __launch_bounds__(256, 1) void k_chain_tile32(double* __restrict__ S,
 // Trailing update: S_ij -= P_a P_b^T for k < j <= i (a = i-k-1, b = j-k-1), one tile per workgroup.
 // part 1 = only the first trailing column (b == 0, grid T): the tiles the NEXT panel needs (lookahead stream);
 // part 2 = every other tile (b >= 1) except S_{k+2,k+2}, grid T(T-1)/2 - 1: the bulk, on the update stream.
+// NT: the C tile is touched exactly once per launch (128 KB in, 128 KB out per workgroup, 64 workgroups in flight per XCD = 16 MB
+// against 4 MB of L2) while the panel tiles are re-read by every workgroup of a tile row / column: non-temporal loads and stores
+// for C keep the use-once stream from evicting the panel out of L2 (r01 counters: the surplus of HBM traffic over the algorithmic
+// C bytes was panel tiles missing L2).  BSFM_SYRK_NT=0 selects the plain variant (same binary) for A/B measurements.
+template <bool NT>
 __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __restrict__ S, int ld, int k, const double* __restrict__ panel, int part)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __re
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[q][u] = cp[16 * u];
+            for (int u = 0; u < 4; ++u) acc[q][u] = NT ? __builtin_nontemporal_load(cp + 16 * u) : cp[16 * u];
             cp += 4 * (size_t)ld;
         }
     }
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __re
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) Sl[16 * u] = acc[q][u];
+        for (int u = 0; u < 4; ++u) { if (NT) __builtin_nontemporal_store(acc[q][u], Sl + 16 * u); else Sl[16 * u] = acc[q][u]; }
         Sl += 4 * (size_t)ld;
     }
 }
@@ -856,6 +862,7 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_tile32<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(T32_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
     w.sy0 = new hipEvent_t[w.nblk]; w.sy1 = new hipEvent_t[w.nblk]; w.sy_flops = new double[w.nblk];
     for (int i = 0; i < w.nblk; ++i) { (void)hipEventCreate(&w.sy0[i]); (void)hipEventCreate(&w.sy1[i]); }
+    if (const char* e = getenv("BSFM_SYRK_NT")) w.syrk_nt = atoi(e) != 0;
     if (getenv("BSFM_DEBUG_DIAG")) { (void)hipMalloc((void**)&w.dbg, 8 * sizeof(long long)); }
     if (backend == 1) {
         // cross-check backend only: rocSOLVER through dlopen, never linked
@@ -935,7 +942,8 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         (void)hipStreamWaitEvent(w.s2, w.evP[k], 0);
         if (T > 2) {
             (void)hipEventRecord(w.sy0[w.sy_used], w.s2);
-            hipLaunchKernelGGL(k_syrk_update, dim3(T * (T - 1) / 2 - 1), dim3(512), lds_bytes, w.s2, S, ld, k, pk, 2);
+            if (w.syrk_nt) hipLaunchKernelGGL(k_syrk_update<true>, dim3(T * (T - 1) / 2 - 1), dim3(512), lds_bytes, w.s2, S, ld, k, pk, 2);
+            else hipLaunchKernelGGL(k_syrk_update<false>, dim3(T * (T - 1) / 2 - 1), dim3(512), lds_bytes, w.s2, S, ld, k, pk, 2);
             (void)hipEventRecord(w.sy1[w.sy_used], w.s2);
             w.sy_flops[w.sy_used++] = tile_flops * (T * (T - 1) / 2 - 1);
         }

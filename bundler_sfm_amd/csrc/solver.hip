@@ -313,6 +313,7 @@ void collect_phase_times(bsfm_problem* pb)
         if (hipEventElapsedTime(&ms, pb->ev[i][0], pb->ev[i][1]) == hipSuccess && ms >= 0.f) { pb->ph_ms[i] += ms; pb->ph_cnt[i]++; }
     }
     potrf_collect_time(pb->potrf);
+    (void)hipGetLastError();      // phases that did not run this iteration leave hipErrorInvalidHandle behind: do not let it stick
 }
 
 // J, U/ea, V/eb at the current p
