@@ -19,6 +19,8 @@
 #include <cstdlib>
 #include <climits>
 #include <algorithm>
+#include <mutex>
+#include <chrono>
 #include "index_build.h"
 
 namespace bsfm {
@@ -165,12 +167,28 @@ __global__ void k_launch_order(int ntasks, int nwg, const SchurTask* __restrict_
     launch[slot] = tk;
 }
 
-struct Scratch {           // temporaries of one build; freed on every exit path
+// Temporaries of one build come from the device's stream-ordered memory pool (hipMallocAsync): the pool keeps what it is given
+// back (release threshold = unlimited, set once), so the ~0.9 GB of sort buffers cost an allocation only on the FIRST run_sfm
+// call of a process -- an incremental reconstruction calls run_sfm hundreds of times.  Freed on every exit path.
+struct Scratch {
+    hipStream_t st = nullptr;
     std::vector<void*> ptrs;
-    ~Scratch() { for (void* p : ptrs) if (p) (void)hipFree(p); }
+    explicit Scratch(hipStream_t s) : st(s)
+    {
+        static std::once_flag once[64];
+        int dev = 0; (void)hipGetDevice(&dev);
+        std::call_once(once[dev & 63], [dev] {
+            hipMemPool_t pool = nullptr;
+            if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+                unsigned long long thr = ~0ULL;
+                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+            }
+        });
+    }
+    ~Scratch() { for (void* p : ptrs) if (p) (void)hipFreeAsync(p, st); }
     template <typename T> hipError_t alloc(T** p, size_t count)
     {
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T));
+        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T), st);
         if (e == hipSuccess) ptrs.push_back(*p);
         return e;
     }
@@ -183,7 +201,7 @@ int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int
                 int order_by_block, DeviceIndex& ix, hipStream_t st)
 {
     const int mm = m - mcon;
-    Scratch tmp;
+    Scratch tmp(st);
     const size_t nt = (size_t)total;
     ix.ntriples = (int)total;
     IX_OK(keep(&ix.triples, nt)); IX_OK(keep(&ix.tri_pt, nt));
@@ -235,12 +253,12 @@ int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int
     IX_OK(hipStreamSynchronize(st));
     ix.ntasks = ntasks;
     SchurTask* tasks = nullptr;
-    IX_OK(hipMalloc((void**)&tasks, std::max<size_t>(1, (size_t)ntasks) * sizeof(SchurTask)));
+    if (order_by_block) IX_OK(hipMalloc((void**)&tasks, std::max<size_t>(1, (size_t)ntasks) * sizeof(SchurTask)));
+    else IX_OK(tmp.alloc(&tasks, (size_t)ntasks));
     hipLaunchKernelGGL(k_tasks, dim3(grid_for(nblk, 256)), dim3(256), 0, st, nblk, blk_start, ix.blk_task0, ix.blk_j, ix.blk_k, tasks);
     hipLaunchKernelGGL(k_tri_pt, dim3(grid_for(nt, 256)), dim3(256), 0, st, (int)nt, vals_out, ix.cam_pt, ix.tri_pt);
     if (order_by_block) { ix.tasks = tasks; ix.nslots = ntasks; }
     else {
-        tmp.ptrs.push_back(tasks);
         int *tk_in = nullptr, *tk_out = nullptr, *id_in = nullptr, *ord = nullptr;
         IX_OK(tmp.alloc(&tk_in, (size_t)ntasks)); IX_OK(tmp.alloc(&tk_out, (size_t)ntasks));
         IX_OK(tmp.alloc(&id_in, (size_t)ntasks)); IX_OK(tmp.alloc(&ord, (size_t)ntasks));
@@ -285,7 +303,7 @@ int build_index_device(int n, int m, int mcon, int nvis, const int* d_rowptr, co
     hipEvent_t e0 = nullptr, e1 = nullptr;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     if (e0) (void)hipEventRecord(e0, st);
-    Scratch tmp;
+    Scratch tmp(st);
     int* flag = nullptr;
     IX_OK(tmp.alloc(&flag, 1));
     IX_OK(hipMemsetAsync(flag, 0, sizeof(int), st));
@@ -333,6 +351,7 @@ int build_index_device(int n, int m, int mcon, int nvis, const int* d_rowptr, co
             : build_schur<unsigned long long>(n, m, mcon, nvis, d_rowptr, d_colidx, toff, total, order_by_block, ix, st);
         if (rc) return rc;
     }
+    if (getenv("BSFM_DEBUG_INDEX")) fprintf(stderr, "[bsfm] index build: n %d m %d nvis %d triples %d blocks %d tasks %d\n", n, m, nvis, ix.ntriples, ix.nblk, ix.ntasks);
     if (e1) {
         (void)hipEventRecord(e1, st);
         (void)hipEventSynchronize(e1);

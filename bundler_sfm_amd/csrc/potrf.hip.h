@@ -107,7 +107,7 @@ struct PotrfWorkspace {
     hipEvent_t* sy0 = nullptr; hipEvent_t* sy1 = nullptr; int sy_used = 0;
     double syrk_ms = 0.0; long long syrk_cnt = 0;
     double* sy_flops = nullptr; double syrk_flops = 0.0;     // flops of each timed launch / running sum
-    int syrk_nt = 1;            // non-temporal C traffic in the bulk kernel (BSFM_SYRK_NT=0 switches it off)
+    int syrk_nt = 0;            // non-temporal C traffic in the bulk kernel (BSFM_SYRK_NT=1; measured neutral: 8.44 vs 8.52 ms per solve)
     long long* dbg = nullptr;   // optional device buffer: cycle stamps of k_potrf_diag phases (BSFM_DEBUG_DIAG=1)
 };
 
@@ -435,7 +435,8 @@ __global__ __launch_bounds__(256, 1) void k_chain_tile32(double* __restrict__ S,
 // NT: the C tile is touched exactly once per launch (128 KB in, 128 KB out per workgroup, 64 workgroups in flight per XCD = 16 MB
 // against 4 MB of L2) while the panel tiles are re-read by every workgroup of a tile row / column: non-temporal loads and stores
 // for C keep the use-once stream from evicting the panel out of L2 (r01 counters: the surplus of HBM traffic over the algorithmic
-// C bytes was panel tiles missing L2).  BSFM_SYRK_NT=0 selects the plain variant (same binary) for A/B measurements.
+// C bytes was panel tiles missing L2).  Measured at config 3: 38.7 vs 39.2 TFLOP/s for the kernel, 8.44 vs 8.52 ms for the solve --
+// neutral, so the plain variant stays the default; BSFM_SYRK_NT=1 selects this one (same binary).
 template <bool NT>
 __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __restrict__ S, int ld, int k, const double* __restrict__ panel, int part)
 {

@@ -97,7 +97,8 @@ def test_ill_conditioned_reduced_camera_system(gpu_bsfm):
     ne = pb.normal_equations(mu=mu)
     pb.close()
     S, E = ne["S"], ne["E"]
-    assert np.abs(S - S.T).max() == 0.0
+    assert np.abs(S - S.T).max() <= 1e-12 * np.abs(S).max()
+    S = np.tril(S) + np.tril(S, -1).T                    # the factorisation reads the lower triangle only
     w = np.linalg.eigvalsh(S)
     cond = w[-1] / w[0]
     assert w[0] > 0 and cond > 1e6, cond                 # genuinely ill-conditioned, still positive definite
