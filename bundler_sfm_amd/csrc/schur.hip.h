@@ -199,4 +199,202 @@ __global__ __launch_bounds__(256) void k_schur_tasks_v2(DevProblem P, const Schu
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Round 2: the same tasks with the contraction on the FP64 matrix cores (v_mfma_f64_4x4x4_4b).
+// Per S block the sum over the task's co-visibility triples is a skinny GEMM with a long reduction dimension,
+//     D[a][b] = sum_rows X[row][a] * Yh[row][b],   rows = (triple p, image row h):  X = A_ij (2 x cnp per triple, straight from the
+//     staged record),  Yh[2p+h] = ( (B_ij V*^-1 B_ik^T) A_ik )[h]  ||  (B_ij V*^-1 eb_i)[h]  -- the 2 x 2 core times A_ik, plus the
+//     right-hand-side column for diagonal blocks,
+// so D[0..cnp)[0..cnp) is the task's part of sum_i Y_ij W_ik^T and D[.][cnp] its part of sum_i Y_ij eb_i (sba_levmar.c:1182-1339).
+// v2 did all of it on the VALU with 3 lanes per triple, each re-reading the shared B / B' / V^-1 operands from LDS (LDS pipe 53 %
+// busy, 208 VGPRs, 2 waves per SIMD).  Here 4 lanes per triple form the core once and write 2 x (cnp + 1) doubles of Yh to LDS; the
+// reduction over the pass's 32 rows is 8 x NI matrix instructions whose operands are single 8-byte LDS reads (X directly from the
+// staged record, Yh from its own area); the accumulators are NI doubles per lane, so the kernel needs ~1/3 of v2's registers and
+// three workgroups fit a CU (LDS-bound: 13 KB per wave).
+// Operand layout of the instruction (probed, potrf.hip.h): lane l = 16 kk + 4 g + r supplies A[g][i = r][kk] and B[g][kk][j = r] of the
+// four independent 4 x 4 x 4 products g; D[g][i][j] comes back at lane 16 i + 4 g + j.  The (cnp + 1)-column output is cut into 4 x 4
+// sub-blocks (br, bc); product slot g of instruction q takes sub-block 4 q + g of the row-major list.
+constexpr int SCM_PASS = 16;          // triples per pass (4 lanes each)
+
+template <int CNP>
+__global__ __launch_bounds__(256, 3) void k_schur_tasks_mfma(DevProblem P, const SchurTask* __restrict__ tasks, int ntasks,
+        const int2* __restrict__ triples, const int* __restrict__ tri_pt, double* __restrict__ partials,
+        double* __restrict__ epart)
+{
+    constexpr int JS = 2 * CNP + 6;            // doubles per Jacobian record
+    constexpr int RS = JS + 2;                 // LDS record stride (doubles), 16-byte aligned
+    constexpr int CH = JS / 2;                 // 16-byte chunks per record
+    constexpr int NA = (SCM_PASS * CH + 63) / 64;      // staging rounds for one record stream
+    constexpr int YS = 12;                     // row stride of Yh (doubles)
+    constexpr int RB = (CNP + 3) / 4;          // 4-row sub-blocks of the output
+    constexpr int CB = (CNP + 1 + 3) / 4;      // 4-column sub-blocks incl. the right-hand-side column
+    constexpr int NSB = RB * CB;
+    constexpr int NI = (NSB + 3) / 4;          // matrix instructions per 4 reduction rows
+    constexpr int SLAB = 2 * SCM_PASS * RS + SCM_PASS * 6 + SCM_PASS * 4 + 2 * SCM_PASS * YS;
+    __shared__ __attribute__((aligned(16))) double sm[4][SLAB];
+    __shared__ int sm_tri[4][3 * SCH_MAXT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int task = blockIdx.x * 4 + wave;
+    if (task >= ntasks) return;
+    const SchurTask tk = tasks[task];
+    if (tk.out < 0) return;
+    double* recA = sm[wave];
+    double* recB = recA + SCM_PASS * RS;
+    double* vin = recB + SCM_PASS * RS;
+    double* ebin = vin + SCM_PASS * 6;          // eb_i of the pass's points (diagonal-block tasks only), stride 4
+    double* Yh = ebin + SCM_PASS * 4;           // [2 * SCM_PASS][YS]
+    int* tq = sm_tri[wave];
+    const bool diag = tk.diag != 0;
+    for (int t = lane; t < tk.count; t += 64) {         // all triples of the task -> LDS (qa, qb, pt)
+        const int2 tr = triples[tk.start + t];
+        tq[3 * t] = tr.x; tq[3 * t + 1] = tr.y; tq[3 * t + 2] = tri_pt[tk.start + t];
+    }
+    // The whole slab starts as zeros: Yh's padding columns stay zero for the task, and record rows past the end of a short
+    // task are multiplied (by zero rows of Yh) without ever having been staged -- uninitialised LDS could hold NaN patterns.
+    for (int t = lane; t < SLAB; t += 64) recA[t] = 0.0;
+
+    // ---- roles of this lane
+    // (1) staging: chunk c = lane + 64 q -> record c / CH, 16-byte part c % CH
+    int srec[NA], spart[NA];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) { const int c = lane + 64 * q; srec[q] = c / CH; spart[q] = c - srec[q] * CH; }
+    const int vrec = lane / 3, vpart = lane - 3 * vrec;           // V^-1 / eb: 3 lanes per triple (lanes 0..47)
+    // (2) core: triple cp of the pass, lane cq of its four: output columns cq, cq + 4, cq + 8 of Yh (+ the rhs column on lane CNP & 3)
+    const int cp = lane >> 2, cq = lane & 3;
+    // (3) matrix instruction operands: reduction row kk, product slot g, index r
+    const int kk = lane >> 4, g = (lane >> 2) & 3, r = lane & 3;
+    int xoff[NI], yoff[NI];
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+        const int sb = min(4 * q + g, NSB - 1);                   // spare slots of the last instruction repeat the last sub-block
+        const int br = sb / CB, bc = sb - br * CB;
+        xoff[q] = (kk >> 1) * RS + (kk & 1) * CNP + 4 * br + r;    // X[row 4 K4 + kk][4 br + r] inside the staged record
+        yoff[q] = kk * YS + 4 * bc + r;
+    }
+    double acc[NI];
+#pragma unroll
+    for (int q = 0; q < NI; ++q) acc[q] = 0.0;
+    // Register sets 0 and 1 alternate between passes (one pass of gathers in flight; two in flight measured no faster: 1.68 vs
+    // 1.59 ms at config 3 -- the kernel is not bound by the latency of its gathers).
+    double pa[2][NA][2], pb[2][NA][2], pv[2][2], pe[2] = { 0.0, 0.0 };
+
+#define BSFM_SCM_ISSUE(p0_, S_)                                                                                     \
+    {                                                                                                               \
+        const int last_ = min(SCM_PASS, tk.count - (p0_)) - 1;                                                      \
+        _Pragma("unroll") for (int q = 0; q < NA; ++q) {                                                            \
+            const int rq_ = min(srec[q], last_);                                                                    \
+            const double2 ta = *reinterpret_cast<const double2*>(P.Jc + (size_t)tq[3 * ((p0_) + rq_)] * JS + 2 * spart[q]);     \
+            const double2 tb = *reinterpret_cast<const double2*>(P.Jc + (size_t)tq[3 * ((p0_) + rq_) + 1] * JS + 2 * spart[q]); \
+            pa[S_][q][0] = ta.x; pa[S_][q][1] = ta.y; pb[S_][q][0] = tb.x; pb[S_][q][1] = tb.y;                     \
+        }                                                                                                           \
+        {                                                                                                           \
+            const int rv_ = min(vrec, last_);                                                                       \
+            const double2 tv = *reinterpret_cast<const double2*>(P.Vinv + (size_t)tq[3 * ((p0_) + rv_) + 2] * 6 + 2 * vpart); \
+            pv[S_][0] = tv.x; pv[S_][1] = tv.y;                                                                     \
+            if (diag) pe[S_] = P.eb[(size_t)tq[3 * ((p0_) + rv_) + 2] * 3 + vpart];                                 \
+        }                                                                                                           \
+    }
+#define BSFM_SCM_PARK(p0_, S_)                                                                                      \
+    {                                                                                                               \
+        const int last_ = min(SCM_PASS, tk.count - (p0_)) - 1;                                                      \
+        _Pragma("unroll") for (int q = 0; q < NA; ++q) {                                                            \
+            const int rq_ = min(srec[q], last_);                                                                    \
+            *reinterpret_cast<double2*>(recA + rq_ * RS + 2 * spart[q]) = make_double2(pa[S_][q][0], pa[S_][q][1]); \
+            *reinterpret_cast<double2*>(recB + rq_ * RS + 2 * spart[q]) = make_double2(pb[S_][q][0], pb[S_][q][1]); \
+        }                                                                                                           \
+        if (lane < 3 * SCM_PASS) {                                                                                  \
+            const int rv_ = min(vrec, last_);                                                                       \
+            *reinterpret_cast<double2*>(vin + rv_ * 6 + 2 * vpart) = make_double2(pv[S_][0], pv[S_][1]);            \
+            if (diag) ebin[rv_ * 4 + vpart] = pe[S_];                                                               \
+        }                                                                                                           \
+    }
+// the 2 x 2 core of triple cp and this lane's columns of Yh, then the reduction over the pass's 2 x SCM_PASS rows on the matrix cores
+#define BSFM_SCM_COMPUTE(p0_)                                                                                       \
+    {                                                                                                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* records parked (same wave: LDS operations complete in order) */ \
+        {                                                                                                           \
+            const bool live = (p0_) + cp < tk.count;                                                                \
+            const double* Ja = recA + cp * RS;                                                                      \
+            const double* Jb = recB + cp * RS;                                                                      \
+            const double* vi = vin + cp * 6;                                                                        \
+            const double i00 = vi[0], i01 = vi[1], i02 = vi[2], i11 = vi[3], i12 = vi[4], i22 = vi[5];              \
+            const double* Ba = Ja + 2 * CNP;                                                                        \
+            const double* Bb = Jb + 2 * CNP;                                                                        \
+            const double c00 = Ba[0] * i00 + Ba[1] * i01 + Ba[2] * i02;                                             \
+            const double c01 = Ba[0] * i01 + Ba[1] * i11 + Ba[2] * i12;                                             \
+            const double c02 = Ba[0] * i02 + Ba[1] * i12 + Ba[2] * i22;                                             \
+            const double c10 = Ba[3] * i00 + Ba[4] * i01 + Ba[5] * i02;                                             \
+            const double c11 = Ba[3] * i01 + Ba[4] * i11 + Ba[5] * i12;                                             \
+            const double c12 = Ba[3] * i02 + Ba[4] * i12 + Ba[5] * i22;                                             \
+            const double m00 = c00 * Bb[0] + c01 * Bb[1] + c02 * Bb[2];                                             \
+            const double m01 = c00 * Bb[3] + c01 * Bb[4] + c02 * Bb[5];                                             \
+            const double m10 = c10 * Bb[0] + c11 * Bb[1] + c12 * Bb[2];                                             \
+            const double m11 = c10 * Bb[3] + c11 * Bb[4] + c12 * Bb[5];                                             \
+            double* y0 = Yh + (2 * cp) * YS;                                                                        \
+            double* y1 = y0 + YS;                                                                                   \
+            _Pragma("unroll") for (int a = 0; a < (CNP + 3) / 4; ++a) {                                             \
+                const int col = cq + 4 * a;                                                                         \
+                if (col < CNP) {                                                                                    \
+                    const double b0 = Jb[col], b1 = Jb[CNP + col];                                                  \
+                    y0[col] = live ? m00 * b0 + m01 * b1 : 0.0;                                                     \
+                    y1[col] = live ? m10 * b0 + m11 * b1 : 0.0;                                                     \
+                }                                                                                                   \
+            }                                                                                                       \
+            if (diag && cq == (CNP & 3)) {                        /* right-hand-side column: B_ij V*^-1 eb_i */     \
+                const double e0 = ebin[cp * 4], e1 = ebin[cp * 4 + 1], e2 = ebin[cp * 4 + 2];                       \
+                y0[CNP] = live ? c00 * e0 + c01 * e1 + c02 * e2 : 0.0;                                              \
+                y1[CNP] = live ? c10 * e0 + c11 * e1 + c12 * e2 : 0.0;                                              \
+            }                                                                                                       \
+        }                                                                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                          \
+        /* operands of two reduction steps are fetched together: one LDS wait per 2 NI matrix instructions, not one per instruction */ \
+        _Pragma("unroll") for (int k4 = 0; k4 < SCM_PASS / 2; k4 += 2) {                                            \
+            double xa[2][NI], yb[2][NI];                                                                            \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                           \
+                _Pragma("unroll") for (int q = 0; q < NI; ++q) {                                                    \
+                    xa[u][q] = recA[2 * (k4 + u) * RS + xoff[q]];                                                   \
+                    yb[u][q] = Yh[4 * (k4 + u) * YS + yoff[q]];                                                     \
+                }                                                                                                   \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                           \
+                _Pragma("unroll") for (int q = 0; q < NI; ++q)                                                      \
+                    acc[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(xa[u][q], yb[u][q], acc[q], 0, 0, 0);               \
+        }                                                                                                           \
+        asm volatile("" ::: "memory");                           /* the next parking must not move above these reads */ \
+    }
+
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the triple list is in LDS, the slab is cleared
+    BSFM_SCM_ISSUE(0, 0)
+    for (int p0 = 0; p0 < tk.count; p0 += 2 * SCM_PASS) {        // one pass of gathers in flight while the previous one is reduced
+        BSFM_SCM_PARK(p0, 0)
+        if (p0 + SCM_PASS < tk.count) BSFM_SCM_ISSUE(p0 + SCM_PASS, 1)
+        BSFM_SCM_COMPUTE(p0)
+        if (p0 + SCM_PASS < tk.count) {
+            BSFM_SCM_PARK(p0 + SCM_PASS, 1)
+            if (p0 + 2 * SCM_PASS < tk.count) BSFM_SCM_ISSUE(p0 + 2 * SCM_PASS, 0)
+            BSFM_SCM_COMPUTE(p0 + SCM_PASS)
+        }
+    }
+#undef BSFM_SCM_ISSUE
+#undef BSFM_SCM_PARK
+#undef BSFM_SCM_COMPUTE
+    // D[g][i][j] of instruction q sits at lane 16 i + 4 g + j
+    {
+        const int i = lane >> 4, j = lane & 3;
+        double* out = partials + (size_t)tk.out * CNP * CNP;
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int sb = 4 * q + g;
+            if (sb < NSB) {
+                const int br = sb / CB, bc = sb - br * CB;
+                const int a = 4 * br + i, b = 4 * bc + j;
+                if (a < CNP) {
+                    if (b < CNP) out[a * CNP + b] = acc[q];
+                    else if (b == CNP && diag) epart[(size_t)tk.out * CNP + a] = acc[q];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace bsfm

@@ -428,8 +428,14 @@ int compute_schur(bsfm_problem* pb, double mu)
         hipLaunchKernelGGL(k_rhs_init, dim3(grid_for((size_t)mm * cnp, 256)), dim3(256), 0, pb->stream, mm * cnp, P.mcon * cnp,
                            lead, pb->d_ea, Edst);
     if (pb->ntasks > 0) {
-        DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks_v2<C>), dim3((pb->nslots + 3) / 4), dim3(256), 0, pb->stream,
-                                              P, pb->d_tasks, pb->nslots, pb->d_triples, pb->d_tri_pt, pb->d_partials, pb->d_epart));
+        static const bool use_v2 = [] { const char* e = getenv("BSFM_SCHUR_KERNEL"); return e && !strcmp(e, "v2"); }();   // round-1 VALU kernel, for A/B runs
+        if (use_v2) {
+            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks_v2<C>), dim3((pb->nslots + 3) / 4), dim3(256), 0, pb->stream,
+                                                  P, pb->d_tasks, pb->nslots, pb->d_triples, pb->d_tri_pt, pb->d_partials, pb->d_epart));
+        } else {
+            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks_mfma<C>), dim3((pb->nslots + 3) / 4), dim3(256), 0, pb->stream,
+                                                  P, pb->d_tasks, pb->nslots, pb->d_triples, pb->d_tri_pt, pb->d_partials, pb->d_epart));
+        }
         if (packed) {
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_pack<C>), dim3(pb->nblk), dim3(128), 0, pb->stream, pb->nblk,
                                                   pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0, pb->d_partials, pb->d_epart,
