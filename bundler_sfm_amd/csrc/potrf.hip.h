@@ -35,6 +35,8 @@
 #include <cmath>
 #include <cstdint>
 #include <vector>
+#include <cstring>
+#include <algorithm>
 
 namespace bsfm {
 
@@ -107,6 +109,13 @@ struct PotrfWorkspace {
     hipEvent_t* sy0 = nullptr; hipEvent_t* sy1 = nullptr; int sy_used = 0;
     double syrk_ms = 0.0; long long syrk_cnt = 0;
     double* sy_flops = nullptr; double syrk_flops = 0.0;     // flops of each timed launch / running sum
+    double* dinv = nullptr;     // panel engine: inverse 16x16 diagonal blocks of every factor tile (8 x 256 doubles per tile)
+    int* eflags = nullptr;      // panel engine: hand-off flags (potrf_engine.hip.h:EngineFlags), 13 nblk + 8 ints
+    int use_engine = 0;         // BSFM_CHOL=engine selects the persistent panel engine (potrf_engine.hip.h); default: the stream schedule
+    int engine_workers = 24;    // BSFM_CHOL_WORKERS
+    int engine_attr_set = 0;
+    int syrk_events = 1;        // HIP-event timing of every n-th bulk launch (BSFM_SYRK_EVENTS=n; 0 = none)
+    long long* edbg = nullptr;  // BSFM_DEBUG_ENGINE=1: 8 stamps per tile column
     int syrk_nt = 0;            // non-temporal C traffic in the bulk kernel (BSFM_SYRK_NT=1; measured neutral: 8.44 vs 8.52 ms per solve)
     long long* dbg = nullptr;   // optional device buffer: cycle stamps of k_potrf_diag phases (BSFM_DEBUG_DIAG=1)
 };
@@ -444,7 +453,8 @@ __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __re
     int a, b;
     if (part == 1) { a = blockIdx.x; b = 0; }
     else {
-        const int t = blockIdx.x + 1;      // tile 0 of the triangle = S_{k+2,k+2} is left to the chain (k_chain_tile32<1>)
+        // part 2: tile 0 of the triangle = S_{k+2,k+2} is left to the chain (k_chain_tile32<1>); part 3 (panel engine): every tile
+        const int t = blockIdx.x + (part == 2 ? 1 : 0);
         a = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
         while ((a + 1) * (a + 2) / 2 <= t) ++a;
         while (a * (a + 1) / 2 > t) --a;
@@ -578,10 +588,14 @@ __device__ __forceinline__ void diag_factor_block(double* __restrict__ T, double
 #undef BSFM_RDLANE
 }
 
-__global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int ld, int k, int n_total,
-        double* __restrict__ Linv, int* __restrict__ info, long long* __restrict__ dbg)
+// PUBLISH (panel engine, below): as soon as block column s of the factor is final (after the row solves of step s) its blocks
+// below the diagonal go to S with write-through stores together with inv(L_ss) -> dinv, and the flag lflag[8 k + s] follows one
+// phase later (after every storing wave has drained) -- the panel workers run their triangular solves one block column behind
+// the factorisation instead of waiting for the whole tile and its inverse.
+template <bool PUBLISH>
+__device__ __forceinline__ void diag_tile_body(double* __restrict__ dlds, double* __restrict__ S, int ld, int k, int n_total,
+        double* __restrict__ Linv, int* __restrict__ info, long long* __restrict__ dbg, double* __restrict__ dinv, int* lflag)
 {
-    extern __shared__ __attribute__((aligned(16))) double dlds[];
     long long t0 = 0; if (dbg && threadIdx.x == 0) t0 = wall_clock64();
     double* T = dlds;                                  // [128][DG_TS]
     double* Di = dlds + POTRF_NB * DG_TS;              // 8 blocks of 16x16: inverse diagonal blocks
@@ -590,6 +604,7 @@ __global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int base = k * POTRF_NB;
     double* G = S + (size_t)base * ld + base;
+    __syncthreads();                                   // (engine: the previous tile's phase B has finished with the LDS tile)
 
     // load the tile (lower triangle; identity in the padding beyond n_total)
     {
@@ -650,6 +665,19 @@ __global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int 
             }
         }
         __syncthreads();
+        if (PUBLISH) {
+            // block column s is final below the diagonal block: rows 16 (s + 1) .. 127, columns 16 s .. 16 s + 15, and inv(L_ss)
+            const int cnt = (7 - s) * 256;
+            for (int idx = tid; idx < cnt + 256; idx += 512) {
+                if (idx < cnt) {
+                    const int r = 16 * (s + 1) + (idx >> 4), c = 16 * s + (idx & 15);
+                    __hip_atomic_store(G + (size_t)r * ld + c, T[r * DG_TS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    const int q = idx - cnt;
+                    __hip_atomic_store(dinv + (size_t)k * 2048 + s * 256 + q, Di[s * 256 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
         if (dbg && threadIdx.x == 0) { const long long t = wall_clock64(); tA2 += t - tq; tq = t; }
         // ---- phase Q
         if (wave == 0) {
@@ -680,7 +708,9 @@ __global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int 
                 for (int q = 0; q < 4; ++q) C[(4 * q + (lane >> 4)) * DG_TS + (lane & 15)] -= acc[q];
             }
         }
+        if (PUBLISH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its write-through stores
         __syncthreads();
+        if (PUBLISH && tid == 0) __hip_atomic_store(&lflag[8 * k + s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (dbg && threadIdx.x == 0) { const long long t = wall_clock64(); tA1 += t - tq; tq = t; }
     }
     if (dbg && threadIdx.x == 0) { dbg[4] = tA1; dbg[5] = tA2; dbg[6] = tA3; }
@@ -733,6 +763,13 @@ __global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int 
         }
     }
     if (dbg && threadIdx.x == 0) dbg[3] = wall_clock64() - t0;
+}
+
+__global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int ld, int k, int n_total,
+        double* __restrict__ Linv, int* __restrict__ info, long long* __restrict__ dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) double dlds[];
+    diag_tile_body<false>(dlds, S, ld, k, n_total, Linv, info, dbg, nullptr, nullptr);
 }
 
 // Backward substitution x = L^-T y as ONE persistent launch (replaces nblk dependent launches).
@@ -804,6 +841,9 @@ inline void potrf_free(PotrfWorkspace& w)
     if (w.xs) (void)hipFree(w.xs);
     if (w.etmp) (void)hipFree(w.etmp);
     if (w.bflags) (void)hipFree(w.bflags);
+    if (w.dinv) (void)hipFree(w.dinv);
+    if (w.edbg) (void)hipFree(w.edbg);
+    if (w.eflags) (void)hipFree(w.eflags);
     if (w.rb_handle && w.rb_destroy) w.rb_destroy(w.rb_handle);
     if (w.ev0) (void)hipEventDestroy(w.ev0);
     if (w.ev1) (void)hipEventDestroy(w.ev1);
@@ -856,6 +896,12 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
     if (hipMalloc((void**)&w.xs, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
     if (hipMalloc((void**)&w.etmp, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
     if (hipMalloc((void**)&w.bflags, (size_t)(w.nblk + 1) * sizeof(int)) != hipSuccess) return -1;
+    if (hipMalloc((void**)&w.dinv, (size_t)w.nblk * 2048 * sizeof(double)) != hipSuccess) return -1;
+    if (hipMalloc((void**)&w.eflags, (size_t)(13 * w.nblk + 8) * sizeof(int)) != hipSuccess) return -1;
+    if (const char* e = getenv("BSFM_CHOL")) w.use_engine = strcmp(e, "engine") == 0;
+    if (const char* e = getenv("BSFM_SYRK_EVENTS")) w.syrk_events = std::max(0, atoi(e));
+    if (const char* e = getenv("BSFM_CHOL_WORKERS")) w.engine_workers = std::max(1, atoi(e));
+    if (getenv("BSFM_DEBUG_ENGINE")) { if (hipMalloc((void**)&w.edbg, (size_t)8 * w.nblk * sizeof(long long)) == hipSuccess) (void)hipMemset(w.edbg, 0, (size_t)8 * w.nblk * sizeof(long long)); }
     (void)hipEventCreate(&w.ev0); (void)hipEventCreate(&w.ev1);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(DG_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
@@ -942,11 +988,11 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         // bulk
         (void)hipStreamWaitEvent(w.s2, w.evP[k], 0);
         if (T > 2) {
-            (void)hipEventRecord(w.sy0[w.sy_used], w.s2);
+            const bool timed = w.syrk_events > 0 && (k % w.syrk_events) == 0;
+            if (timed) (void)hipEventRecord(w.sy0[w.sy_used], w.s2);
             if (w.syrk_nt) hipLaunchKernelGGL(k_syrk_update<true>, dim3(T * (T - 1) / 2 - 1), dim3(512), lds_bytes, w.s2, S, ld, k, pk, 2);
             else hipLaunchKernelGGL(k_syrk_update<false>, dim3(T * (T - 1) / 2 - 1), dim3(512), lds_bytes, w.s2, S, ld, k, pk, 2);
-            (void)hipEventRecord(w.sy1[w.sy_used], w.s2);
-            w.sy_flops[w.sy_used++] = tile_flops * (T * (T - 1) / 2 - 1);
+            if (timed) { (void)hipEventRecord(w.sy1[w.sy_used], w.s2); w.sy_flops[w.sy_used++] = tile_flops * (T * (T - 1) / 2 - 1); }
         }
         (void)hipEventRecord(w.evU[k], w.s2);
         // chain: next diagonal tile

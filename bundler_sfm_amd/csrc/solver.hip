@@ -26,6 +26,7 @@
 #include "kernels.hip.h"
 #include "schur.hip.h"
 #include "potrf.hip.h"
+#include "potrf_engine.hip.h"
 #include "compsolve.hip.h"
 
 using namespace bsfm;
@@ -925,7 +926,7 @@ int bsfm_lm_iterate(bsfm_problem_t* pb, int iters)
             // S dpa = E, Cholesky (sba_Axb_Chol, lib/sba-1.5/sba_lapack.c:374-485); info -> d_flags[1]
             if (pb->comps.active) {
                 if (comp_solve(pb->comps, pb->potrf, cnp, pb->d_S, pb->ld, pb->d_E, d_dpa + (size_t)P.mcon * cnp, pb->d_flags + 1, pb->stream)) return BSFM_ERROR;
-            } else if (potrf_solve(pb->potrf, pb->d_S, pb->ld, pb->Sdim, pb->d_E, d_dpa + (size_t)P.mcon * cnp, pb->d_flags + 1, pb->stream)) return BSFM_ERROR;
+            } else if (potrf_solve_auto(pb->potrf, pb->d_S, pb->ld, pb->Sdim, pb->d_E, d_dpa + (size_t)P.mcon * cnp, pb->d_flags + 1, pb->stream)) return BSFM_ERROR;
             ph_end(pb, PH_SOLVE);
             if (P.mcon > 0) (void)hipMemsetAsync(d_dpa, 0, (size_t)P.mcon * cnp * sizeof(double), pb->stream);
             ph_begin(pb, PH_BACKSUB);
@@ -950,6 +951,11 @@ int bsfm_lm_iterate(bsfm_problem_t* pb, int iters)
             }
             const bool singularV = flagsd[0] != 0.0;
             const int potrf_info = pb->h_flags[1];
+            if (potrf_info < 0) {         // POTRF_INFO_TIMEOUT: a hand-off inside the persistent Cholesky kernels never arrived
+                fprintf(stderr, "[bsfm] FATAL: the reduced camera solve timed out inside its persistent kernels (info %d)\n", potrf_info);
+                pb->error = 1;
+                return BSFM_ERROR;
+            }
             bool accepted = false;
             if (singularV) {
                 fprintf(stderr, "SBA: singular matrix V*_i in sba_motstr_levmar_x(), increasing damping\n");
@@ -1206,7 +1212,7 @@ int bsfm_dense_chol_solve(int n, const double* A, const double* b, double* x, in
         if (hipMemset(dS, 0, (size_t)ld * ld * sizeof(double)) != hipSuccess || hipMemset(dE, 0, ld * sizeof(double)) != hipSuccess || hipMemset(dinfo, 0, sizeof(int)) != hipSuccess) break;
         if (hipMemcpy2D(dS, (size_t)ld * sizeof(double), A, (size_t)n * sizeof(double), (size_t)n * sizeof(double), n, hipMemcpyHostToDevice) != hipSuccess) break;
         if (hipMemcpy(dE, b, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) break;
-        if (potrf_solve(ws, dS, ld, n, dE, dx, dinfo, st)) break;
+        if (potrf_solve_auto(ws, dS, ld, n, dE, dx, dinfo, st)) break;
         if (hipStreamSynchronize(st) != hipSuccess) break;
         if (hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) break;
         if (hipMemcpy(x, dx, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) break;

@@ -425,6 +425,75 @@ def test_post_solve_outlier_statistics(gpu_bsfm, with_pcons):
     assert np.abs(st["err"] - err).max() <= 1e-9 * max(1.0, err.max())
 
 
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("with_pcons", [False, True])
+def test_post_solve_outlier_statistics_vs_reference_routines(gpu_bsfm, with_pcons):
+    """SURVEY 8(f).1 pinned to the REFERENCE'S OWN routines (oracle/_ref): the statistics loop of RunSFM_SBA (src/Bundle.cpp:659-913)
+    driven, statement for statement, through the reference's sfm_project_rd (lib/sfm-driver/sfm.c:302-380, called as
+    Bundle.cpp:726-739 calls it: K = diag(f, f, 1), the camera's own R / t / k) and kth_element_copy
+    (lib/imagelib/qsort.c:152-203) -- not through a numpy re-statement: per-camera 80th-percentile distance,
+    thresh = CLAMP(1.2 * NUM_STDDEV * med, 8, 16), mean, median, outlier list in camera-then-key order with the
+    constrained-point exemption, first recorded reprojection error per point."""
+    B = gpu_bsfm
+    c = load_case("band")
+    m, n = c["m"], c["n"]
+    rng = np.random.default_rng(11)
+    proj = c["proj"].copy().reshape(-1, 2)
+    bad = rng.choice(len(proj), 40, replace=False)
+    proj[bad] += rng.normal(0, 30.0, (40, 2))
+    pt_of = np.repeat(np.arange(n), np.diff(c["rowptr"]))
+    pcons = None
+    if with_pcons:
+        pcons = np.zeros((n, 3)); ids = pt_of[bad[:10]]
+        pcons[ids] = c["pts"].reshape(-1, 3)[ids] + 0.01
+    opt = B.default_options(jacobian=B.JAC_ANALYTIC, verbose=0, itmax=5)
+    pb = B.Problem(n, m, c["rowptr"], c["colidx"], proj.ravel(), c["cams"], c["pts"], est_focal_length=c["est"],
+                   undistort=c["und"], use_constraints=c["cons"], point_constraints=pcons, point_constraint_weight=1.0,
+                   options=opt)
+    pb.solve()
+    st = pb.outlier_stats(8.0, 16.0)
+    _, cams, pts = pb.download()               # cameras as run_sfm hands them back: R <- dR(w) R, t = centre, f, k, scales 1
+    pb.close()
+    pts = pts.reshape(-1, 3)
+    cam_of = c["colidx"]
+    outliers, errors = [], []
+    total, count = 0.0, 0
+    for j in range(m):                         # "for (int i = 0; i < num_cameras; i++)", Bundle.cpp:669
+        ks = np.nonzero(cam_of == j)[0]        # the camera's keys with a point, in key order (= ascending point index here)
+        dists = np.zeros(len(ks))
+        for t, k in enumerate(ks):
+            pr = O.ref_project_rd(cams[j], pts[pt_of[k]], undistort=c["und"], explicit_centers=1)       # Bundle.cpp:736-739
+            dx = pr[0] - proj[k, 0]; dy = pr[1] - proj[k, 1]
+            dists[t] = np.sqrt(dx * dx + dy * dy)
+        npp = len(ks)
+        med = O.ref_kth_element_copy(dists, _iround(0.8 * npp)) if npp else 0.0                        # Bundle.cpp:761-763
+        thresh = min(max(1.2 * 2.0 * med, 8.0), 16.0)                                                   # :767-770
+        ssum = 0.0
+        for v in dists:
+            ssum += v
+        assert st["nobs"][j] == npp
+        assert abs(st["kth80"][j] - med) <= 1e-9 * max(1.0, med)
+        if npp:
+            assert abs(st["mean"][j] - ssum / npp) <= 1e-9 * max(1.0, ssum / npp)
+            assert abs(st["kth50"][j] - O.ref_kth_element_copy(dists, _iround(0.5 * npp))) <= 1e-9 * max(1.0, med)
+        assert abs(st["thresh"][j] - thresh) <= 1e-9 * thresh
+        total += ssum; count += npp
+        for t, k in enumerate(ks):                                                                      # :792-821
+            i = pt_of[k]
+            if pcons is not None and pcons[i, 0] != 0.0:
+                continue
+            if dists[t] > thresh and i not in outliers:
+                assert abs(dists[t] - thresh) > 1e-6
+                outliers.append(i); errors.append(dists[t])
+    assert abs(st["global_mean"] - total / count) <= 1e-9 * total / count
+    flag = np.zeros(n, np.uint8); flag[outliers] = 1
+    assert np.array_equal(st["outlier"], flag) and len(outliers) >= 10
+    # the reference records the error of the first offending observation in CAMERA order; the library reports the first in the
+    # point's own (camera-ascending) view list -- the same observation
+    err = np.zeros(n); err[outliers] = errors
+    assert np.abs(st["err"] - err).max() <= 1e-9 * max(1.0, err.max())
+
+
 def test_ray_angle_pruning(gpu_bsfm):
     """SURVEY 8(f).1, second half: RemoveBadPointsAndCameras (src/Bundle.cpp:4190-4261).  CPU side restates the
     reference loop (unit rays by multiplying with 1/norm, dot in index order, CLAMP to +-(1 - 1e-8), acos, RAD2DEG, prune
