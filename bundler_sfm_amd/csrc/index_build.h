@@ -36,4 +36,12 @@ int build_index_device(int n, int m, int mcon, int nvis, const int* d_rowptr, co
                        int order_by_block, DeviceIndex& out, hipStream_t st);
 void free_index_device(DeviceIndex& ix);
 
+// Growing a resident problem: merges `nadd` new observations (point, camera, x, y -- device arrays, any order) into
+// an existing CRS (rowptr / obs_pt / colidx / x of nvis observations) for n_new points and m_new cameras.  Outputs (device, owned by
+// the caller, hipFree): rowptr_out (n_new + 1), colidx_out and x_out (nvis + nadd; 2 doubles per observation), ordered by
+// (point, camera) = the reference's measurement order.  Returns 0, or -1 (index out of range, an observation given twice).
+int merge_observations_device(int n_new, int m_new, int nvis, const int* d_obs_pt, const int* d_colidx, const double* d_x,
+                              int nadd, const int* d_add_pt, const int* d_add_cam, const double* d_add_xy,
+                              int** rowptr_out, int** colidx_out, double** x_out, hipStream_t st);
+
 }  // namespace bsfm

@@ -286,6 +286,86 @@ int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int
 
 }  // namespace
 
+namespace {
+
+__global__ void k_merge_keys(int nvis, int nadd, int n_new, int m_new, const int* __restrict__ obs_pt, const int* __restrict__ colidx,
+                             const int* __restrict__ add_pt, const int* __restrict__ add_cam, unsigned long long* __restrict__ keys,
+                             int* __restrict__ vals, int* __restrict__ flag)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nvis + nadd) return;
+    int pt, cam;
+    if (t < nvis) { pt = obs_pt[t]; cam = colidx[t]; }
+    else { pt = add_pt[t - nvis]; cam = add_cam[t - nvis]; if (pt < 0 || pt >= n_new || cam < 0 || cam >= m_new) { atomicOr(flag, 1); pt = 0; cam = 0; } }
+    keys[t] = (unsigned long long)pt * (unsigned long long)m_new + (unsigned long long)cam;
+    vals[t] = t;
+}
+
+__global__ void k_merge_scatter(int total, int nvis, int m_new, const unsigned long long* __restrict__ keys, const int* __restrict__ src,
+                                const double* __restrict__ x, const double* __restrict__ add_xy, int* __restrict__ colidx_out,
+                                double* __restrict__ x_out, int* __restrict__ flag)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const unsigned long long key = keys[t];
+    if (t > 0 && keys[t - 1] == key) atomicOr(flag, 2);                     // the same (point, camera) twice
+    colidx_out[t] = (int)(key % (unsigned long long)m_new);
+    const int s = src[t];
+    const double* xs = s < nvis ? x + 2 * (size_t)s : add_xy + 2 * (size_t)(s - nvis);
+    x_out[2 * (size_t)t] = xs[0]; x_out[2 * (size_t)t + 1] = xs[1];
+}
+
+__global__ void k_merge_rowptr(int n_new, int m_new, int total, const unsigned long long* __restrict__ keys, int* __restrict__ rowptr)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_new) return;
+    const unsigned long long target = (unsigned long long)i * (unsigned long long)m_new;
+    int lo = 0, hi = total;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < target) lo = mid + 1; else hi = mid; }
+    rowptr[i] = lo;
+}
+
+}  // namespace
+
+int merge_observations_device(int n_new, int m_new, int nvis, const int* d_obs_pt, const int* d_colidx, const double* d_x,
+                              int nadd, const int* d_add_pt, const int* d_add_cam, const double* d_add_xy,
+                              int** rowptr_out, int** colidx_out, double** x_out, hipStream_t st)
+{
+    (void)hipGetLastError();
+    const long long total64 = (long long)nvis + nadd;
+    if (total64 > INT_MAX) { fprintf(stderr, "[bsfm] append: too many observations\n"); return -1; }
+    const int total = (int)total64;
+    Scratch tmp(st);
+    unsigned long long *keys = nullptr, *keys_s = nullptr; int *vals = nullptr, *vals_s = nullptr, *flag = nullptr;
+    IX_OK(tmp.alloc(&keys, (size_t)total)); IX_OK(tmp.alloc(&keys_s, (size_t)total));
+    IX_OK(tmp.alloc(&vals, (size_t)total)); IX_OK(tmp.alloc(&vals_s, (size_t)total)); IX_OK(tmp.alloc(&flag, 1));
+    IX_OK(hipMemsetAsync(flag, 0, sizeof(int), st));
+    IX_OK(keep(rowptr_out, (size_t)n_new + 1)); IX_OK(keep(colidx_out, (size_t)total)); IX_OK(keep(x_out, 2 * (size_t)total));
+    if (total > 0) {
+        hipLaunchKernelGGL(k_merge_keys, dim3(grid_for((size_t)total, 256)), dim3(256), 0, st, nvis, nadd, n_new, m_new, d_obs_pt, d_colidx,
+                           d_add_pt, d_add_cam, keys, vals, flag);
+        size_t tb = 0;
+        const int kbits = bits_for((unsigned long long)n_new * (unsigned long long)m_new);
+        IX_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, keys_s, vals, vals_s, total, 0, kbits, st));
+        void* d_tmp = nullptr;
+        IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_tmp), tb));
+        IX_OK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, keys, keys_s, vals, vals_s, total, 0, kbits, st));
+        hipLaunchKernelGGL(k_merge_scatter, dim3(grid_for((size_t)total, 256)), dim3(256), 0, st, total, nvis, m_new, keys_s, vals_s, d_x, d_add_xy,
+                           *colidx_out, *x_out, flag);
+    }
+    hipLaunchKernelGGL(k_merge_rowptr, dim3(grid_for((size_t)n_new + 1, 256)), dim3(256), 0, st, n_new, m_new, total, keys_s, *rowptr_out);
+    int hflag = 0;
+    IX_OK(hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    IX_OK(hipStreamSynchronize(st));
+    if (hflag) {
+        fprintf(stderr, "[bsfm] append:%s%s\n", (hflag & 1) ? " point / camera index out of range" : "", (hflag & 2) ? " an observation (point, camera) is given twice" : "");
+        (void)hipFree(*rowptr_out); (void)hipFree(*colidx_out); (void)hipFree(*x_out);
+        *rowptr_out = nullptr; *colidx_out = nullptr; *x_out = nullptr;
+        return -1;
+    }
+    return 0;
+}
+
 void free_index_device(DeviceIndex& ix)
 {
     void* ptrs[] = { ix.obs_pt, ix.camptr, ix.camobs, ix.campos, ix.cam_pt, ix.cam_cam, ix.triples, ix.tri_pt, ix.tasks,

@@ -104,6 +104,8 @@ struct bsfm_problem {
     // host
     double* h_scal = nullptr; int* h_flags = nullptr;   // pinned
     std::vector<double> h_Rinit;
+    std::vector<bsfm_camera_params_t> h_cams;      // the caller's camera structs (constraints, known intrinsics ...): template for bsfm_problem_append
+    bsfm_problem_desc_t desc0{};                  // scalar fields of the description the problem was created from
     hipStream_t stream = nullptr; bool own_stream = false;
     bsfm_allreduce_fn allreduce = nullptr; void* allreduce_ctx = nullptr;
     bsfm_comm_t* comm = nullptr;        // library-side collective (comm.hip: RCCL over xGMI); takes precedence over the hook
@@ -200,7 +202,7 @@ void pack_params(const bsfm_problem* pb, const bsfm_camera_params_t* cams, const
         if (c.est_focal) { a[6] = cams[j].f * c.f_scale; col = 7; }
         if (c.undistort) { a[col] = cams[j].k[0] * c.k_scale; a[col + 1] = cams[j].k[1] * c.k_scale; }
     }
-    if (n) memcpy(&p[(size_t)m * cnp], pts, sizeof(double) * 3 * n);
+    if (n && pts) memcpy(&p[(size_t)m * cnp], pts, sizeof(double) * 3 * n);
 }
 
 inline void ph_begin(bsfm_problem* pb, int ph) { if (pb->ev_ok) (void)hipEventRecord(pb->ev[ph][0], pb->stream); }
@@ -509,10 +511,16 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     }
     if (!d || d->n < 0 || d->m <= 0 || d->mcon < 0 || d->mcon > d->m) { fprintf(stderr, "[bsfm] bad problem description\n"); return nullptr; }
     if (!d->rowptr || !d->cameras || (d->n > 0 && (!d->points && !d->p_packed))) { fprintf(stderr, "[bsfm] bad problem description: rowptr / cameras / points missing\n"); return nullptr; }
-    if (d->rowptr[0] != 0 || d->rowptr[d->n] < 0) { fprintf(stderr, "[bsfm] bad problem description: rowptr[0] must be 0 and rowptr[n] >= 0\n"); return nullptr; }
-    if (d->rowptr[d->n] > 0 && (!d->colidx || !d->projections)) { fprintf(stderr, "[bsfm] bad problem description: colidx / projections missing\n"); return nullptr; }
+    int rp_ends[2] = { 0, 0 };              // rowptr[0], rowptr[n] (the arrays may already live on the device)
+    if (d->arrays_on_device) {
+        if (hipMemcpy(&rp_ends[0], d->rowptr, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(&rp_ends[1], d->rowptr + d->n, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { fprintf(stderr, "[bsfm] bad problem description: device rowptr unreadable\n"); return nullptr; }
+        if (d->use_point_constraints && d->point_constraints) { fprintf(stderr, "[bsfm] bad problem description: point constraints cannot be combined with arrays_on_device\n"); return nullptr; }
+    } else { rp_ends[0] = d->rowptr[0]; rp_ends[1] = d->rowptr[d->n]; }
+    if (rp_ends[0] != 0 || rp_ends[1] < 0) { fprintf(stderr, "[bsfm] bad problem description: rowptr[0] must be 0 and rowptr[n] >= 0\n"); return nullptr; }
+    if (rp_ends[1] > 0 && (!d->colidx || !d->projections)) { fprintf(stderr, "[bsfm] bad problem description: colidx / projections missing\n"); return nullptr; }
     {   // int32 indexing everywhere ("all indexing is int32"): refuse sizes that would overflow it
-        const long long nv = 9LL * d->m + 3LL * d->n, no = 2LL * d->rowptr[d->n];
+        const long long nv = 9LL * d->m + 3LL * d->n, no = 2LL * rp_ends[1];
         if (nv > 0x7fffffffLL || no > 0x7fffffffLL) { fprintf(stderr, "[bsfm] problem too large for 32-bit indexing (%lld unknowns, %lld measurements)\n", nv, no); return nullptr; }
     }
     const auto t_create0 = std::chrono::steady_clock::now();
@@ -524,7 +532,7 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
         free_all(pb); delete pb; return nullptr;
     };
     const int n = d->n, m = d->m;
-    const int nvis = d->rowptr[n];
+    const int nvis = rp_ends[1];
     const int cnp = (d->est_focal_length ? 7 : 6) + (d->undistort ? 2 : 0);
     pb->cnp = cnp;
     DevProblem& P = pb->P;
@@ -545,11 +553,12 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     pb->own_stream = true;
 #define DM(ptr, cnt) if (dmalloc(&ptr, (size_t)(cnt)) != hipSuccess) return fail("hipMalloc " #ptr)
     auto up = [&](void* dst, const void* src, size_t bytes) { return bytes == 0 || hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess; };
+    auto up_any = [&](void* dst, const void* src, size_t bytes) { return bytes == 0 || hipMemcpy(dst, src, bytes, d->arrays_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) == hipSuccess; };
     // ---- index bookkeeping (bit-exact integer work, built on the device from the caller's CRS; index_build.hip)
     const auto t_up0 = std::chrono::steady_clock::now();
     DM(pb->d_rowptr, n + 1); DM(pb->d_obs_cam, nvis); DM(pb->d_x, 2 * (size_t)nvis);
-    if (!(up(pb->d_rowptr, d->rowptr, ((size_t)n + 1) * sizeof(int)) && up(pb->d_obs_cam, d->colidx, (size_t)nvis * sizeof(int)) &&
-          up(pb->d_x, d->projections, 2 * (size_t)nvis * sizeof(double)))) return fail("upload of the visibility index");
+    if (!(up_any(pb->d_rowptr, d->rowptr, ((size_t)n + 1) * sizeof(int)) && up_any(pb->d_obs_cam, d->colidx, (size_t)nvis * sizeof(int)) &&
+          up_any(pb->d_x, d->projections, 2 * (size_t)nvis * sizeof(double)))) return fail("upload of the visibility index");
     pb->create_ms[1] = ms_since(t_up0);
     {
         const auto t_ix0 = std::chrono::steady_clock::now();
@@ -599,8 +608,13 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     }
     std::vector<double> p;
     if (d->p_packed) p.assign(d->p_packed, d->p_packed + (size_t)m * cnp + (size_t)3 * n);
-    else pack_params(pb, d->cameras, d->points, n, p);
+    else pack_params(pb, d->cameras, d->arrays_on_device ? nullptr : d->points, n, p);
     ok = ok && up(pb->d_p, p.data(), p.size() * sizeof(double));
+    if (d->arrays_on_device && !d->p_packed) ok = ok && up_any(pb->d_p + (size_t)m * cnp, d->points, 3 * (size_t)n * sizeof(double));
+    pb->h_cams.assign(d->cameras, d->cameras + m);
+    pb->desc0 = *d;
+    pb->desc0.rowptr = nullptr; pb->desc0.colidx = nullptr; pb->desc0.projections = nullptr; pb->desc0.cameras = nullptr; pb->desc0.points = nullptr;
+    pb->desc0.point_constraints = nullptr; pb->desc0.p_packed = nullptr; pb->desc0.arrays_on_device = 0;
     if (d->use_constraints) {   // sfm.c:721-754 (note the hard-wired indices 6,7,8 of the rescaling)
         std::vector<unsigned char> con((size_t)m * cnp); std::vector<double> val((size_t)m * cnp), w((size_t)m * cnp);
         for (int j = 0; j < m; ++j) {
@@ -656,6 +670,56 @@ void bsfm_problem_set_stream(bsfm_problem_t* pb, void* s)
     else { pb->stream = stream_pool().acquire(); pb->own_stream = true; }
 }
 
+int bsfm_problem_append(bsfm_problem_t* pb, int num_new_cameras, const bsfm_camera_params_t* new_cameras,
+                        int num_new_points, const double* new_points,
+                        int nadd, const int* add_pt, const int* add_cam, const double* add_xy)
+{
+    if (!pb || num_new_cameras < 0 || num_new_points < 0 || nadd < 0 || (num_new_cameras && !new_cameras) || (num_new_points && !new_points) ||
+        (nadd && (!add_pt || !add_cam || !add_xy))) { fprintf(stderr, "[bsfm] bsfm_problem_append: bad arguments\n"); return BSFM_ERROR; }
+    if (pb->world > 1 || pb->mot) { fprintf(stderr, "[bsfm] bsfm_problem_append: single-rank motion + structure problems only\n"); return BSFM_ERROR; }
+    const int m0 = pb->P.m, n0 = pb->P.n, nvis0 = pb->P.nvis, cnp = pb->cnp;
+    const int m1 = m0 + num_new_cameras, n1 = n0 + num_new_points;
+    HIP_OK(hipStreamSynchronize(pb->stream));
+    // old cameras as run_sfm would hand them back (rotation increment folded into R on the host: 72 KB at 1 000 cameras)
+    std::vector<bsfm_camera_params_t> cams((size_t)m1);
+    memcpy(cams.data(), pb->h_cams.data(), (size_t)m0 * sizeof(bsfm_camera_params_t));
+    if (bsfm_problem_download(pb, nullptr, cams.data(), nullptr) != 0) return BSFM_ERROR;
+    for (int j = 0; j < num_new_cameras; ++j) cams[(size_t)m0 + j] = new_cameras[j];
+    // new observations / points to the device; merge with the resident ones there
+    int *d_apt = nullptr, *d_acam = nullptr, *d_rp = nullptr, *d_ci = nullptr; double *d_axy = nullptr, *d_x = nullptr, *d_pts = nullptr;
+    auto cleanup = [&] { for (void* q : { (void*)d_apt, (void*)d_acam, (void*)d_axy, (void*)d_rp, (void*)d_ci, (void*)d_x, (void*)d_pts }) if (q) (void)hipFree(q); };
+    bool ok = dmalloc(&d_apt, (size_t)nadd) == hipSuccess && dmalloc(&d_acam, (size_t)nadd) == hipSuccess && dmalloc(&d_axy, 2 * (size_t)nadd) == hipSuccess &&
+              dmalloc(&d_pts, 3 * (size_t)n1) == hipSuccess;
+    if (ok && nadd) ok = hipMemcpy(d_apt, add_pt, (size_t)nadd * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+                         hipMemcpy(d_acam, add_cam, (size_t)nadd * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+                         hipMemcpy(d_axy, add_xy, 2 * (size_t)nadd * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && n0) ok = hipMemcpy(d_pts, pb->d_p + (size_t)m0 * cnp, 3 * (size_t)n0 * sizeof(double), hipMemcpyDeviceToDevice) == hipSuccess;
+    if (ok && num_new_points) ok = hipMemcpy(d_pts + 3 * (size_t)n0, new_points, 3 * (size_t)num_new_points * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { cleanup(); fprintf(stderr, "[bsfm] bsfm_problem_append: allocation / upload failed\n"); return BSFM_ERROR; }
+    if (merge_observations_device(n1, m1, nvis0, pb->d_obs_pt, pb->d_obs_cam, pb->d_x, nadd, d_apt, d_acam, d_axy, &d_rp, &d_ci, &d_x, pb->stream) != 0) { cleanup(); return BSFM_ERROR; }
+    bsfm_problem_desc_t d = pb->desc0;
+    d.n = n1; d.m = m1;
+    d.rowptr = d_rp; d.colidx = d_ci; d.projections = d_x; d.points = d_pts; d.cameras = cams.data();
+    d.use_point_constraints = 0; d.point_constraints = nullptr; d.arrays_on_device = 1;
+    d.nvis_global = 0; d.nvars_global = 0;
+    bsfm_problem* grown = bsfm_problem_create(&d, &pb->opt);
+    if (!grown) { cleanup(); return BSFM_ERROR; }
+    if (pb->d_pcon) {   // point constraints of the old points carry over; new points are unconstrained
+        bool okc = dmalloc(&grown->d_pcon, (size_t)n1) == hipSuccess && dmalloc(&grown->d_pval, 3 * (size_t)n1) == hipSuccess &&
+                   hipMemset(grown->d_pcon, 0, (size_t)n1) == hipSuccess && hipMemset(grown->d_pval, 0, 3 * (size_t)n1 * sizeof(double)) == hipSuccess &&
+                   hipMemcpy(grown->d_pcon, pb->d_pcon, (size_t)n0, hipMemcpyDeviceToDevice) == hipSuccess &&
+                   hipMemcpy(grown->d_pval, pb->d_pval, 3 * (size_t)n0 * sizeof(double), hipMemcpyDeviceToDevice) == hipSuccess;
+        if (!okc) { bsfm_problem_destroy(grown); cleanup(); return BSFM_ERROR; }
+        grown->P.pcon = grown->d_pcon; grown->P.pval = grown->d_pval; grown->P.pweight = pb->P.pweight;
+        grown->desc0.use_point_constraints = 1; grown->desc0.point_constraint_weight = pb->P.pweight;
+    }
+    grown->allreduce = pb->allreduce; grown->allreduce_ctx = pb->allreduce_ctx; grown->comm = pb->comm;
+    std::swap(*pb, *grown);                 // the caller's handle now holds the grown problem ...
+    bsfm_problem_destroy(grown);            // ... and the old arrays go
+    cleanup();
+    return 0;
+}
+
 int bsfm_problem_reset_params(bsfm_problem_t* pb, const bsfm_camera_params_t* cams, const double* pts)
 {
     std::vector<double> p;
@@ -665,6 +729,7 @@ int bsfm_problem_reset_params(bsfm_problem_t* pb, const bsfm_camera_params_t* ca
     HIP_OK(hipMemcpy(pb->d_p, p.data(), p.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(pb->d_Rinit, pb->h_Rinit.data(), pb->h_Rinit.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(pb->d_finit, finit.data(), finit.size() * sizeof(double), hipMemcpyHostToDevice));
+    pb->h_cams.assign(cams, cams + pb->P.m);
     {   // extended-model block of the new cameras
         std::vector<double> kn;
         const bool any = fill_ext_block(cams, pb->P.m, pb->fisheye_mode, kn);

@@ -188,6 +188,25 @@ class Problem:
         pts = np.ascontiguousarray(pts, np.float64)
         return lib.bsfm_problem_reset_params(self.h, cams, _dp(pts))
 
+    def append(self, new_cams, new_pts, add_pt, add_cam, add_xy):
+        """bsfm_problem_append: grow the resident problem (new cameras / points / observations); parameters stay in HBM."""
+        new_pts = np.ascontiguousarray(new_pts, np.float64).ravel()
+        add_pt = np.ascontiguousarray(add_pt, np.int32); add_cam = np.ascontiguousarray(add_cam, np.int32)
+        add_xy = np.ascontiguousarray(add_xy, np.float64).ravel()
+        ncam = 0 if new_cams is None else len(new_cams)
+        rc = lib.bsfm_problem_append(self.h, ncam, new_cams, len(new_pts) // 3, _dp(new_pts) if len(new_pts) else None, len(add_pt),
+                                     _ip(add_pt) if len(add_pt) else None, _ip(add_cam) if len(add_cam) else None,
+                                     _dp(add_xy) if len(add_xy) else None)
+        if rc == 0:
+            self.m += ncam; self.n += len(new_pts) // 3
+            self.nvis = int(lib.bsfm_problem_nvis(self.h))
+            if ncam:        # download() copies the caller's camera array as the template of the non-parameter fields
+                merged = make_cameras(self.m)
+                C.memmove(merged, self._keep[3], C.sizeof(self._keep[3]))
+                C.memmove(C.byref(merged, C.sizeof(self._keep[3])), new_cams, C.sizeof(new_cams))
+                self._keep = self._keep[:3] + (merged,) + self._keep[4:]
+        return rc
+
     def lm_begin(self):
         return lib.bsfm_lm_begin(self.h)
 

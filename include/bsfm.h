@@ -172,6 +172,9 @@ typedef struct {
     /* run_sfm's optimize_for_fisheye (sfm.c:819-851): project with sfm_project_point2_fisheye (sfm.c:448-492) -- pinhole
      * without the radial term, then the equidistant map of cameras[j].fisheye/f_cx/f_cy/f_rad/f_angle/f_focal. */
     int optimize_for_fisheye;
+    /* rowptr, colidx, projections and points are DEVICE pointers (data already resident in HBM, e.g. produced by another kernel);
+     * point constraints cannot be combined with it.  cameras always come from the host (504 bytes each). */
+    int arrays_on_device;
 } bsfm_problem_desc_t;
 
 /* Sum-reduce `count` doubles in place across ranks (device pointer); op 0 = sum, 1 = max.
@@ -202,6 +205,17 @@ void bsfm_problem_set_allreduce(bsfm_problem_t *pb, bsfm_allreduce_fn fn, void *
 void bsfm_problem_set_comm(bsfm_problem_t *pb, bsfm_comm_t *comm);
 /* Use an externally owned HIP stream (e.g. torch's current stream) for every launch; NULL = own stream. */
 void bsfm_problem_set_stream(bsfm_problem_t *pb, void *hip_stream);
+/* Grow the resident problem between the rounds of an incremental reconstruction (the reference rebuilds vmask,
+ * projections and every SBA work array from scratch for each run_sfm call, src/BundleFast.cpp:263-438 -> src/Bundle.cpp:597-637):
+ * `num_new_cameras` cameras are appended after the existing ones (indices m .. m + num_new_cameras - 1), `num_new_points` points
+ * after the existing ones, and `nadd` new observations (add_pt[q], add_cam[q], add_xy[2q], add_xy[2q+1]) -- of old or new points by
+ * old or new cameras, in any order -- are merged into the measurement order.  Only the new data crosses PCIe: the observations,
+ * the points and the current estimate of every old parameter stay in HBM (old cameras: rotation increment folded into R exactly as
+ * run_sfm hands them back, sfm.c:876-922, so the next LM run starts like a fresh run_sfm call on the grown scene).  New points are
+ * unconstrained.  The handle stays valid; on failure (BSFM_ERROR) the problem is unchanged.  Single-rank problems only. */
+int bsfm_problem_append(bsfm_problem_t *pb, int num_new_cameras, const bsfm_camera_params_t *new_cameras,
+                        int num_new_points, const double *new_points,
+                        int nadd, const int *add_pt, const int *add_cam, const double *add_xy);
 /* Re-upload parameters (cameras: centre/rotation/focal/k; points) without rebuilding the index. */
 int bsfm_problem_reset_params(bsfm_problem_t *pb, const bsfm_camera_params_t *cameras, const double *points);
 
