@@ -74,7 +74,7 @@ SYMBOLS = [
     "bsfm_lm_iterate", "bsfm_lm_finish", "bsfm_lm_solve_attempts", "bsfm_lm_last_kernel_ms",
     "bsfm_problem_download", "bsfm_problem_export_index", "bsfm_problem_schur_sizes", "bsfm_problem_export_schur", "bsfm_crs_from_vmask",
     "bsfm_problem_cnp", "bsfm_problem_nvis", "bsfm_eval_residuals", "bsfm_problem_outlier_stats", "bsfm_problem_ray_angles", "bsfm_triangulate_batch", "bsfm_rand_seed", "bsfm_rand_next", "bsfm_fmatrix_ransac_batch",
-    "bsfm_estimate_fmatrix_batch",
+    "bsfm_estimate_fmatrix_batch", "bsfm_compute_tracks",
     "bsfm_eval_normal_equations", "bsfm_dense_chol_solve", "bsfm_match_keys_l2", "bsfm_key_match_full",
     "bsfm_key_match_full_sharded", "bsfm_merge_match_files", "bsfm_match_set_create", "bsfm_match_set_run", "bsfm_match_set_stats",
     "bsfm_match_set_destroy",
@@ -145,6 +145,8 @@ def _load():
     lib.bsfm_estimate_fmatrix_batch.argtypes = [C.c_int, C.POINTER(C.c_int), dp, dp, C.c_int, C.c_double, C.POINTER(RandState), dp,
                                                 C.POINTER(C.c_int), C.POINTER(C.c_ubyte), C.POINTER(C.c_int)]
     lib.bsfm_estimate_fmatrix_batch.restype = C.c_int
+    lib.bsfm_compute_tracks.argtypes = [C.c_int, ip, C.c_int, ip, ip, ip, ip, C.c_int, ip, ip, C.c_int, C.c_int, ip]
+    lib.bsfm_compute_tracks.restype = C.c_int
     lib.bsfm_eval_normal_equations.argtypes = [vp, C.c_double, dp, dp, dp, dp, dp, dp, dp]
     lib.bsfm_eval_normal_equations.restype = C.c_int
     lib.bsfm_dense_chol_solve.argtypes = [C.c_int, dp, dp, dp, C.c_int]

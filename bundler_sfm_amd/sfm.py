@@ -137,6 +137,22 @@ def estimate_fmatrix_batch(match_ptr, k1_xy, k2_xy, num_trials, threshold, rng):
     return F, cnt, inl[:int(match_ptr[-1])], info
 
 
+def compute_tracks(num_keys, pair_i, pair_j, match_ptr, matches, new_image_start=0):
+    """bsfm_compute_tracks (BundlerApp::ComputeTracks).  Returns (track_ptr, views[nviews, 2] = (image, key))."""
+    nk = np.ascontiguousarray(num_keys, np.int32); pi = np.ascontiguousarray(pair_i, np.int32); pj = np.ascontiguousarray(pair_j, np.int32)
+    mp = np.ascontiguousarray(match_ptr, np.int32); mt = np.ascontiguousarray(matches, np.int32)
+    nv = C.c_int()
+    nt = lib.bsfm_compute_tracks(len(nk), _ip(nk), len(pi), _ip(pi), _ip(pj), _ip(mp), _ip(mt), new_image_start, None, None, 0, 0, C.byref(nv))
+    if nt < 0:
+        raise RuntimeError("bsfm_compute_tracks failed")
+    tp = np.zeros(nt + 1, np.int32); vw = np.zeros((max(nv.value, 1), 2), np.int32)
+    got = lib.bsfm_compute_tracks(len(nk), _ip(nk), len(pi), _ip(pi), _ip(pj), _ip(mp), _ip(mt), new_image_start, _ip(tp), _ip(vw), nt, nv.value,
+                                  C.byref(nv))
+    if got != nt:
+        raise RuntimeError("bsfm_compute_tracks failed")
+    return tp, vw[:nv.value]
+
+
 class Problem:
     """Device-resident BA problem (sparse CRS boundary)."""
 

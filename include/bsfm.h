@@ -319,6 +319,18 @@ int bsfm_estimate_fmatrix_batch(int npairs, const int *match_ptr, const double *
                                 double threshold, bsfm_rand_t *rng, double *F, int *num_inliers, unsigned char *inlier,
                                 int *lm_info);
 
+/* ---- 3d. track building ------------------------------------------------------------------- */
+/* BundlerApp::ComputeTracks (src/ComputeTracks.cpp:36-313) on the match table as BaseApp::LoadMatchTable holds it (src/BundleIO.cpp:112-166:
+ * one list per image pair pair_i[p] < pair_j[p], matches[2q] = key index in image pair_i, matches[2q+1] = key index in image pair_j), made
+ * symmetric as MakeMatchListsSymmetric does (src/MatchTracks.cpp:337-392).  Tracks come back in the reference's numbering: track t owns
+ * views track_ptr[t] .. track_ptr[t+1]-1, each (image, key), in the order the reference's breadth-first search claimed them.  Inside a pair a
+ * key may occur at most once on either side (what PruneDoubleMatches leaves, src/MatchTracks.cpp:394-440); otherwise BSFM_ERROR.  Returns
+ * the number of tracks (*num_views = total views); with track_ptr or views NULL only the counts are computed.  new_image_start is accepted
+ * for signature parity and, as in the reference, has no effect. */
+int bsfm_compute_tracks(int num_images, const int *num_keys, int num_pairs, const int *pair_i, const int *pair_j,
+                        const int *match_ptr, const int *matches, int new_image_start,
+                        int *track_ptr, int *views, int max_tracks, int max_views, int *num_views);
+
 /* ---- 4. matcher ------------------------------------------------------------------------------------- */
 /* Exact 2-NN ratio test between two descriptor sets (128-D uchar, squared L2 in int32):
  * keeps (i, nn0) iff (double)d0 < ratio*ratio*(double)d1 (src/keys2a.cpp:362). out_pairs gets up to

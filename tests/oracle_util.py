@@ -404,3 +404,55 @@ def ref_project_rd(cam, b, undistort=1, explicit_centers=1):
     C.memmove(one, C.byref(cam), C.sizeof(CameraParams))
     fn(one, _d(K), _d(k), _d(R), _d(dt), _d(bb), _d(p), undistort, explicit_centers)
     return p
+
+
+TRACKSREF_PATH = os.path.join(os.path.dirname(REF_PATH), "libtracksref.so")
+
+
+def have_tracksref():
+    return os.path.exists(TRACKSREF_PATH)
+
+
+def read_match_table(path):
+    """matches.init.txt as BaseApp::LoadMatchTable reads it (src/BundleIO.cpp:112-166): blocks "i1 i2 / n / k1 k2 ...".
+    Returns (pair_i, pair_j, match_ptr, matches[n, 2])."""
+    tok = open(path).read().split()
+    pi, pj, ptr, mt = [], [], [0], []
+    q = 0
+    while q < len(tok):
+        i1, i2, n = int(tok[q]), int(tok[q + 1]), int(tok[q + 2]); q += 3
+        pi.append(i1); pj.append(i2)
+        mt.append(np.array(tok[q:q + 2 * n], np.int32).reshape(n, 2)); q += 2 * n
+        ptr.append(ptr[-1] + n)
+    return (np.array(pi, np.int32), np.array(pj, np.int32), np.array(ptr, np.int32),
+            np.concatenate(mt) if mt else np.zeros((0, 2), np.int32))
+
+
+def prune_double_matches(match_ptr, matches):
+    """PruneDoubleMatches (src/MatchTracks.cpp:394-440), the part that edits the lists: inside a pair, a match whose second index was
+    already seen is dropped (first occurrence wins)."""
+    ptr, out = [0], []
+    for p in range(len(match_ptr) - 1):
+        seen, keep = set(), []
+        for a, b in matches[match_ptr[p]:match_ptr[p + 1]]:
+            if int(b) not in seen:
+                seen.add(int(b)); keep.append((a, b))
+        out += keep; ptr.append(len(out))
+    return np.array(ptr, np.int32), np.array(out, np.int32).reshape(-1, 2)
+
+
+def ref_compute_tracks(num_keys, pair_i, pair_j, match_ptr, matches, new_image_start=0):
+    """The reference's BundlerApp::ComputeTracks (oracle/ref_tracks.cpp).  Returns (track_ptr, views[nviews, 2] = (image, key))."""
+    lib = C.CDLL(TRACKSREF_PATH)
+    ip = C.POINTER(C.c_int)
+    nk = np.ascontiguousarray(num_keys, np.int32)
+    total = int(nk.sum())
+    tp = np.zeros(total + 2, np.int32); vw = np.zeros((max(total, 1), 2), np.int32)
+    mt = np.ascontiguousarray(matches, np.int32)
+    with quiet_stdout():
+        nt = lib.ref_compute_tracks(len(nk), nk.ctypes.data_as(ip), len(pair_i), np.ascontiguousarray(pair_i, np.int32).ctypes.data_as(ip),
+                                    np.ascontiguousarray(pair_j, np.int32).ctypes.data_as(ip),
+                                    np.ascontiguousarray(match_ptr, np.int32).ctypes.data_as(ip), mt.ctypes.data_as(ip), new_image_start,
+                                    tp.ctypes.data_as(ip), vw.ctypes.data_as(ip), total + 1, max(total, 1))
+    assert nt >= 0
+    return tp[:nt + 1].copy(), vw[:tp[nt]].copy()
