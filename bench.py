@@ -470,7 +470,8 @@ def main():
                                           "iterations_per_s": round(d2 / r2["elapsed"], 3), "ms_per_step": round(1e3 * r2["elapsed"] / max(d2, 1), 4),
                                           "solve_ms": round(pb2.phase_ms("solve"), 4), "schur_ms": round(pb2.phase_ms("schur"), 4),
                                           "final_cost": info2[1],
-                                          "final_cost_rel_diff_vs_dense": abs(info2[1] - info[1]) / info[1]}
+                                          "final_cost_rel_diff_vs_dense": abs(info2[1] - info[1]) / info[1],
+                                          "problem_create_s_warm_process": round(r2["t_create"], 3)}
                 pb2.close()
             except Exception as exc:
                 out["structure_aware"] = {"error": repr(exc)}

@@ -161,19 +161,33 @@ __global__ __launch_bounds__(256) void k_jacobian(ModelCfg cfg, int nvis,
     // broadcast), gather their point (24 bytes, the point array is L2-resident) and write consecutive 192-byte records.
     // ONE copy of the Jacobian: the camera-side consumers (U/ea, Schur tasks) stream it, the point-side ones gather
     // whole records through campos[].
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= nvis) return;
+    const int tt = blockIdx.x * 256 + threadIdx.x;
+    const int t = min(tt, nvis - 1);                         // the last workgroup's surplus threads repeat the last record (never stored)
     const double* ct = camtab + (size_t)cam_cam[t] * CT_STRIDE;
     const double* b = pb + (size_t)cam_pt[t] * 3;
     double A[2 * CNP], B[6], x0, x1;
     if (FD) jac_fd<CNP, KNOWN>(cfg, ct, b[0], b[1], b[2], A, B, x0, x1);
     else    jac_analytic<CNP>(cfg, ct, b[0], b[1], b[2], A, B, x0, x1);
     constexpr int JS = 2 * CNP + 6;
-    double2* outc = reinterpret_cast<double2*>(Jc + (size_t)t * JS);     // JS is even -> 16-byte aligned records
+    // The 256 records of a workgroup are contiguous in Jc (camera-major positions t0 .. t0+255): they are transposed through LDS so
+    // that every store instruction writes 64 x 16 consecutive bytes (a lane-per-record store touches 64 different cache lines per
+    // instruction, 16 bytes of each: the kernel was bound by those write transactions, 0.43 ms for 960 MB).
+    constexpr int CH = JS / 2;                               // 16-byte chunks per record
+    constexpr int LS = CH + 1;                               // LDS row stride in chunks (odd: conflict-free column writes)
+    __shared__ double2 stage[256 * LS];
+    double2* mine = stage + threadIdx.x * LS;
 #pragma unroll
-    for (int q = 0; q < CNP; ++q) outc[q] = make_double2(A[2 * q], A[2 * q + 1]);
+    for (int q = 0; q < CNP; ++q) mine[q] = make_double2(A[2 * q], A[2 * q + 1]);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) outc[CNP + q] = make_double2(B[2 * q], B[2 * q + 1]);
+    for (int q = 0; q < 3; ++q) mine[CNP + q] = make_double2(B[2 * q], B[2 * q + 1]);
+    __syncthreads();
+    const int t0 = blockIdx.x * 256;
+    const int nrec = min(256, nvis - t0);
+    double2* outc = reinterpret_cast<double2*>(Jc + (size_t)t0 * JS);     // JS is even -> 16-byte aligned records
+    for (int c = threadIdx.x; c < nrec * CH; c += 256) {
+        const int rec = c / CH, part = c - rec * CH;
+        outc[c] = stage[rec * LS + part];
+    }
 }
 
 // N 16-byte loads of 2N consecutive doubles.  Jacobian records are 16-byte aligned (even length, 2*cnp even), which
