@@ -73,7 +73,7 @@ SYMBOLS = [
     "bsfm_problem_set_allreduce", "bsfm_problem_set_stream", "bsfm_problem_reset_params", "bsfm_problem_append", "bsfm_lm_begin",
     "bsfm_lm_iterate", "bsfm_lm_finish", "bsfm_lm_solve_attempts", "bsfm_lm_last_kernel_ms",
     "bsfm_problem_download", "bsfm_problem_export_index", "bsfm_problem_schur_sizes", "bsfm_problem_export_schur", "bsfm_crs_from_vmask",
-    "bsfm_problem_cnp", "bsfm_problem_nvis", "bsfm_eval_residuals", "bsfm_problem_outlier_stats", "bsfm_problem_ray_angles", "bsfm_triangulate_batch", "bsfm_rand_seed", "bsfm_rand_next", "bsfm_fmatrix_ransac_batch",
+    "bsfm_problem_cnp", "bsfm_problem_num_cameras", "bsfm_problem_num_points", "bsfm_problem_nvis", "bsfm_eval_residuals", "bsfm_problem_outlier_stats", "bsfm_problem_ray_angles", "bsfm_triangulate_batch", "bsfm_rand_seed", "bsfm_rand_next", "bsfm_fmatrix_ransac_batch",
     "bsfm_estimate_fmatrix_batch", "bsfm_compute_tracks",
     "bsfm_eval_normal_equations", "bsfm_dense_chol_solve", "bsfm_match_keys_l2", "bsfm_key_match_full",
     "bsfm_key_match_full_sharded", "bsfm_merge_match_files", "bsfm_match_set_create", "bsfm_match_set_run", "bsfm_match_set_stats",
@@ -124,6 +124,10 @@ def _load():
     lib.bsfm_problem_download.restype = C.c_int
     lib.bsfm_problem_cnp.argtypes = [vp]
     lib.bsfm_problem_cnp.restype = C.c_int
+    lib.bsfm_problem_num_cameras.argtypes = [vp]
+    lib.bsfm_problem_num_cameras.restype = C.c_int
+    lib.bsfm_problem_num_points.argtypes = [vp]
+    lib.bsfm_problem_num_points.restype = C.c_int
     lib.bsfm_problem_nvis.argtypes = [vp]
     lib.bsfm_problem_nvis.restype = C.c_longlong
     lib.bsfm_eval_residuals.argtypes = [vp, dp, dp]

@@ -44,11 +44,29 @@ void vmask_to_crs(int n, int m, const char* vmask, std::vector<int>& rowptr, std
 void export_blocks(bsfm_problem_t* pb, int n, int mcon, int cnp, const std::vector<int>& rowptr, const std::vector<int>& colidx,
                    double* Vout, double* Sout, double* Uout, double* Wout)
 {
-    if (!(Sout || Uout || Vout || Wout)) return;
+    // The reference exports only when Sout != NULL (sba_levmar.c:1633); without it Vout keeps the V of the last iteration
+    // (sba_levmar.c:1039-1051), Uout / Wout stay untouched.  Bundler passes all four or none (BundleTwo.cpp:1768,1902).
+    if (!Sout) {
+        if (Vout) bsfm_eval_normal_equations(pb, 0.0, nullptr, nullptr, Vout, nullptr, nullptr, nullptr, nullptr);
+        return;
+    }
     const size_t nvis = colidx.size();
+    const int m = (int)bsfm_problem_num_cameras(pb);
     std::vector<double> J;
     if (Wout) J.resize(nvis * (size_t)(2 * cnp + 6));
-    bsfm_eval_normal_equations(pb, 0.0, Uout, nullptr, Vout, nullptr, Wout ? J.data() : nullptr, Sout, nullptr);
+    std::vector<double> Sred;                          // the library's S covers the free cameras only, row stride (m - mcon) cnp
+    const size_t sd = (size_t)(m - mcon) * cnp, sm = (size_t)m * cnp;
+    if (mcon > 0) Sred.resize(sd * sd);
+    bsfm_eval_normal_equations(pb, 0.0, Uout, nullptr, Vout, nullptr, Wout ? J.data() : nullptr, mcon > 0 ? Sred.data() : Sout, nullptr);
+    if (mcon > 0) {
+        // Sout is an (m cnp)^2 buffer (sba.h:137).  The reference copies its (m - mcon) cnp wide S into it with stride m cnp
+        // (sba_levmar.c:2017-2022), which scrambles the blocks when mcon > 0 -- Bundler never exports with fixed cameras.  Here the
+        // reduced system of the free cameras is embedded at its natural place, the blocks of the fixed cameras are zero, and U_j
+        // of a fixed camera is zero as in the reference (cleared and skipped for j < mcon, :1646-1648).
+        memset(Sout, 0, sm * sm * sizeof(double));
+        for (size_t r = 0; r < sd; ++r) memcpy(Sout + ((size_t)mcon * cnp + r) * sm + (size_t)mcon * cnp, Sred.data() + r * sd, sd * sizeof(double));
+        if (Uout) memset(Uout, 0, (size_t)mcon * cnp * cnp * sizeof(double));
+    }
     if (Wout) {   // Wout[(j*cnp+ii)*3*n + 3*i + jj] = (A_ij^T B_ij)[ii][jj]  (sba_levmar.c:1836-1846)
         const int js = 2 * cnp + 6;
         for (int i = 0; i < n; ++i)

@@ -495,7 +495,7 @@ extern "C" int bsfm_fmatrix_ransac_batch(int npairs, const int* match_ptr, const
                 if (c[t] > best_cnt) { best_cnt = c[t]; best = t; }
                 if ((double)c[t] / n > success_ratio) { last = t; early = true; break; }
             }
-            if (gave_up[q] >= 0) {
+            if (gave_up[q] >= 0 && !early) {       // (an early exit BEFORE the aborted trial wins: the reference never reached that trial)
                 // `return 0` from inside the sample loop (fmatrix.c:349-350): no F is copied out, and the generator has
                 // consumed the draws of the aborted trial too -- replay that trial from the state before it
                 inliers_max[p0 + q] = 0;
@@ -518,7 +518,7 @@ extern "C" int bsfm_fmatrix_ransac_batch(int npairs, const int* match_ptr, const
             }
             inliers_max[p0 + q] = best_cnt;
             if (best >= 0 && !dF.down(F + 9 * (size_t)(p0 + q), 9, ((size_t)q * per + best) * 9)) return BSFM_ERROR;
-            *rng = (last == num_trials - 1) ? start[q + 1] : state_after(q, last);   // replay only after an early exit
+            *rng = (last == num_trials - 1 && gave_up[q] < 0) ? start[q + 1] : state_after(q, last);   // replay only after an early exit
             if (early && last < num_trials - 1) break;                             // left early: the speculation behind it is void
         }
         p0 += accepted;

@@ -777,6 +777,8 @@ int bsfm_problem_export_schur(bsfm_problem_t* pb, int* triples, int* tri_pt, int
 }
 
 int bsfm_problem_cnp(const bsfm_problem_t* pb) { return pb->cnp; }
+int bsfm_problem_num_cameras(const bsfm_problem_t* pb) { return pb->P.m; }
+int bsfm_problem_num_points(const bsfm_problem_t* pb) { return pb->P.n; }
 long long bsfm_problem_nvis(const bsfm_problem_t* pb) { return pb->P.nvis; }
 int bsfm_lm_solve_attempts(const bsfm_problem_t* pb) { return pb->nlss; }
 

@@ -248,6 +248,8 @@ int bsfm_problem_export_schur(bsfm_problem_t *pb, int *triples, int *tri_pt, int
 /* dense vmask -> CRS exactly as run_sfm does it (host only); returns nvis, rowptr / colidx may be NULL. */
 int bsfm_crs_from_vmask(int n, int m, const char *vmask, int *rowptr, int *colidx);
 int bsfm_problem_cnp(const bsfm_problem_t *pb);
+int bsfm_problem_num_cameras(const bsfm_problem_t *pb);      /* grows with bsfm_problem_append */
+int bsfm_problem_num_points(const bsfm_problem_t *pb);
 long long bsfm_problem_nvis(const bsfm_problem_t *pb);
 
 /* Component entries used by the parity tests (each one launches the production kernels):
