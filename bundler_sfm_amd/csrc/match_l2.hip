@@ -34,18 +34,21 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr int QB = 128;            // queries per workgroup
 constexpr int BIG = 0x3fffffff;
+constexpr size_t KEY_SLACK = 64;        // keys of slack behind the last image: the scan prefetches whole tiles (k_match_l2)
 
 #define HIPM(call)                                                                                   \
     do { hipError_t _e = (call); if (_e != hipSuccess) {                                             \
         fprintf(stderr, "[bsfm] HIP error %s at %s:%d\n", hipGetErrorName(_e), __FILE__, __LINE__); \
         return BSFM_ERROR; } } while (0)
 
-// per key: q = |x|^2 - 256 * sum(x - 128)   (the query side subtracts the constant 2*128^3 later)
-__global__ void k_key_stats(const unsigned char* __restrict__ keys, int n, int* __restrict__ q)
+// per key: q = |x|^2 - 256 * sum(x - 128)   (the query side subtracts the constant 2*128^3 later).  The descriptor is rewritten
+// IN PLACE as signed bytes x - 128 (one xor per word), the operand format of the matrix instruction: the scan kernel then
+// feeds what it loads straight into the MFMA (the flip was 8 VALU instructions per wave and tile of the VALU-bound scan).
+__global__ void k_key_stats(unsigned char* __restrict__ keys, int n, int* __restrict__ q)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint4* p = reinterpret_cast<const uint4*>(keys + (size_t)i * 128);
+    uint4* p = reinterpret_cast<uint4*>(keys + (size_t)i * 128);
     int sq = 0, s = 0;
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
@@ -55,6 +58,7 @@ __global__ void k_key_stats(const unsigned char* __restrict__ keys, int n, int* 
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int b = 0; b < 4; ++b) { const int x = (u[c] >> (8 * b)) & 255; sq += x * x; s += x - 128; }
+        p[w] = make_uint4(v.x ^ 0x80808080u, v.y ^ 0x80808080u, v.z ^ 0x80808080u, v.w ^ 0x80808080u);
     }
     q[i] = sq - 256 * s;
 }
@@ -65,27 +69,41 @@ __device__ __forceinline__ v4i load_frag(const unsigned char* __restrict__ keys,
 {
     const uint4 v = *reinterpret_cast<const uint4*>(keys + (size_t)key * 128 + 64 * kstep + 16 * (lane >> 4));
     v4i r;
-    r.x = (int)(v.x ^ 0x80808080u); r.y = (int)(v.y ^ 0x80808080u);
-    r.z = (int)(v.z ^ 0x80808080u); r.w = (int)(v.w ^ 0x80808080u);
+    r.x = (int)v.x; r.y = (int)v.y; r.z = (int)v.z; r.w = (int)v.w;      // already signed bytes (k_key_stats)
+    return r;
+}
+
+__device__ __forceinline__ uint4 load_raw(const unsigned char* __restrict__ keys, int key, int lane, int kstep)
+{
+    return *reinterpret_cast<const uint4*>(keys + (size_t)key * 128 + 64 * kstep + 16 * (lane >> 4));
+}
+__device__ __forceinline__ v4i flip(const uint4 v)          // the loaded words as the MFMA operand (signed bytes already)
+{
+    v4i r;
+    r.x = (int)v.x; r.y = (int)v.y; r.z = (int)v.z; r.w = (int)v.w;
     return r;
 }
 
 // nn_out[out_off + query] = index of the accepted nearest neighbour in the database image, or -1.
-__global__ __launch_bounds__(256) void k_match_l2(const unsigned char* __restrict__ keys, const int* __restrict__ qstat,
+__global__ __launch_bounds__(256, 2) void k_match_l2(const unsigned char* __restrict__ keys, const int* __restrict__ qstat,
         const PairDesc* __restrict__ pairs, int npairs, int db_off, int db_n, double ratio_sq, int* __restrict__ nn_out, int one)
 {
     constexpr int NG = QB / 16;                       // row groups of 16 queries held by every wave
-    __shared__ int st_d0[QB][4], st_d1[QB][4], st_i0[QB][4];     // running (best, second, index) per query and wave
-    __shared__ int s_pair;
-    if (threadIdx.x == 0) {          // locate the pair this block belongs to
+    constexpr int XS = 65;                            // row stride (uint2) of the exchange buffer: 64 column classes + 1 pad
+    __shared__ uint2 xch[QB * XS];                    // per segment: every (query row, column class) slot's packed (best, second)
+    // Locate the pair this block belongs to: a binary search on the pairs' first-block numbers that every thread runs on
+    // uniform addresses (scalar loads, no barrier; one thread searching + a barrier kept 255 threads idle for 9 round trips).
+    int s_pair = 0;
+    {
         int lo = 0, hi = npairs - 1;
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pairs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
         s_pair = lo;
     }
-    for (int t = threadIdx.x; t < QB * 4; t += 256) { (&st_d0[0][0])[t] = BIG; (&st_d1[0][0])[t] = BIG; (&st_i0[0][0])[t] = -1; }
-    __syncthreads();
     const PairDesc pd = pairs[s_pair];
     const int qbase = (blockIdx.x - pd.blk0) * QB;
+    // running (nearest, second nearest, column) of query row threadIdx.x / 2, kept by the two threads that merge that row
+    const int row_qa = qstat[pd.q_off + min(qbase + (int)(threadIdx.x >> 1), pd.q_n - 1)] - 2 * 128 * 128 * 128;
+    int row_d0 = BIG, row_d1 = BIG, row_idx = -1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned char* qkeys = keys + (size_t)pd.q_off * 128;
     const unsigned char* dkeys = keys + (size_t)db_off * 128;
@@ -125,91 +143,105 @@ __global__ __launch_bounds__(256) void k_match_l2(const unsigned char* __restric
 #pragma unroll
             for (int r = 0; r < 4; ++r) { b0[g][r] = 0xffffffffu; b1[g][r] = 0xffffffffu; }
         const int seg_end = min(db_n, seg + SEG);
-        // software pipeline: the B fragments of tile t+1 are in flight while tile t is multiplied and ranked
+        // software pipeline: the B fragments of tile t+1 are in flight while tile t is multiplied and ranked.  The loads stay RAW
+        // (no sign flip, no select on the loaded statistic) until the top of the next trip: anything computed from them here
+        // makes the compiler wait for the data before the current tile's MFMAs, which serialises L2 latency and arithmetic
+        // (round 2: that was half of the kernel's time)
+        // (running pointers, no clamp: the key and statistic arrays carry one tile of slack behind the last image, and what
+        //  is loaded past the database image only ever meets DEADQ)
         const int colf = seg + 16 * wave + (lane & 15);
-        const int col0 = min(colf, db_n - 1);
-        v4i nf0 = load_frag(dkeys, col0, lane, 0), nf1 = load_frag(dkeys, col0, lane, 1);
-        int nqb = colf < db_n ? qstat[db_off + col0] + EBIAS : DEADQ;
+        const unsigned char* kp = dkeys + (size_t)colf * 128 + 16 * (lane >> 4);
+        const int* qp = qstat + db_off + colf;
+        uint4 rf0 = *reinterpret_cast<const uint4*>(kp), rf1 = *reinterpret_cast<const uint4*>(kp + 64);
+        int rqb = *qp;
+        int coln = colf;
         for (int tile = seg; tile < seg_end; tile += 64) {
-            const v4i bf0 = nf0, bf1 = nf1;
-            const int qbb = nqb;
+            const v4i bf0 = flip(rf0), bf1 = flip(rf1);
+            const int qbb = coln < db_n ? rqb + EBIAS : DEADQ;
             if (tile + 64 < seg_end) {
-                const int coln = tile + 64 + 16 * wave + (lane & 15);
-                const int colc = min(coln, db_n - 1);
-                nf0 = load_frag(dkeys, colc, lane, 0); nf1 = load_frag(dkeys, colc, lane, 1);
-                nqb = coln < db_n ? qstat[db_off + colc] + EBIAS : DEADQ;
+                kp += 64 * 128; qp += 64; coln += 64;
+                rf0 = *reinterpret_cast<const uint4*>(kp); rf1 = *reinterpret_cast<const uint4*>(kp + 64);
+                rqb = *qp;
             }
             // key = ((qb + BIAS - 2 dot) << TB) | tile = K - (dot << (TB + 1)) with K = ((qb + BIAS) << TB) | tile: the low TB
             // bits are untouched by the subtraction, so ONE 24-bit multiply-add per distance builds the packed key
             const int K = (int)(((unsigned)qbb << TB) | (unsigned)((tile - seg) >> 6));
+            // Group g + 1 is multiplied while group g is ranked: each matrix instruction is followed by six independent VALU
+            // instructions (the order is pinned with sched_barrier), enough to cover its 4 passes, so neither the dependent
+            // second k-step nor the ranking ever waits for the matrix pipe.
+            v4i acc = { 0, 0, 0, 0 };
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[0][0], bf0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[0][1], bf1, acc, 0, 0, 0);
+#define BSFM_RANK(R)                                                                                                      \
+                {   /* (no inline asm on the accumulator itself: the compiler must see the MFMA -> VALU dependency) */     \
+                    const unsigned key = (unsigned)(__mul24(acc[R], mscale) + K);        /* v_mad_i32_i24 */              \
+                    unsigned m;                                                                                           \
+                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(b0[g][R]), "v"(b1[g][R]), "v"(key));                  \
+                    b1[g][R] = m;                                                                                         \
+                    b0[g][R] = min(b0[g][R], key);                                                                        \
+                }
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                v4i acc = { 0, 0, 0, 0 };
-                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[g][0], bf0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[g][1], bf1, acc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    // (no inline asm on the accumulator itself: the compiler must see the MFMA -> VALU dependency to place
-                    //  the hazard wait states)
-                    const unsigned key = (unsigned)(__mul24(acc[r], mscale) + K);        // v_mad_i32_i24
-                    unsigned m;
-                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(b0[g][r]), "v"(b1[g][r]), "v"(key));
-                    b1[g][r] = m;
-                    b0[g][r] = min(b0[g][r], key);
-                }
+                v4i nacc = { 0, 0, 0, 0 };
+                if (g + 1 < NG) nacc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[g + 1][0], bf0, nacc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                BSFM_RANK(0) BSFM_RANK(1)
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 1 < NG) nacc = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[g + 1][1], bf1, nacc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                BSFM_RANK(2) BSFM_RANK(3)
+                __builtin_amdgcn_sched_barrier(0);
+                acc = nacc;
             }
+#undef BSFM_RANK
         }
-        // The 16 column classes of a row sit in the 16 lanes (lane & 15) of a quarter wave: butterfly-merge their packed
-        // pairs (the lane id of the best travels along), then lane 0 of each quarter folds the segment's result into the
-        // wave's slot of the per-query state in LDS (d = e + qa; nobody else touches that slot: no barrier).
+        // Segment merge through LDS: slot (row, column class 16 wave + lane % 16) goes to xch[row][class]; then two threads per
+        // query row scan 32 classes each (6 VALU per class), combine with one DPP swap, and the even thread folds the segment's
+        // (best, second, column) into the row's running state, which lives in ITS registers.  (Round 2: the 16-lane butterfly
+        // on all 32 slots of every lane cost 1 400 VALU instructions per wave, a tenth of the kernel.)
+        __syncthreads();                               // the previous segment's readers are done
 #pragma unroll
         for (int g = 0; g < NG; ++g)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                unsigned k0 = b0[g][r], k1 = b1[g][r];
-                int l0 = lane & 15;
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) {
-                    const unsigned o0 = (unsigned)__shfl_xor((int)k0, m, 64), o1 = (unsigned)__shfl_xor((int)k1, m, 64);
-                    const int ol = __shfl_xor(l0, m, 64);
-                    k1 = min(max(k0, o0), min(k1, o1));
-                    const bool take = o0 < k0 || (o0 == k0 && ol < l0);
-                    l0 = take ? ol : l0;
-                    k0 = min(k0, o0);
-                }
-                if ((lane & 15) == 0) {
-                    const int row = 16 * g + 4 * (lane >> 4) + r;
-                    const int qrow = min(qbase + row, pd.q_n - 1);
-                    const int qa = qstat[pd.q_off + qrow] - 2 * 128 * 128 * 128;
-                    const unsigned e0 = k0 >> TB, e1 = k1 >> TB;
-                    const int c0 = e0 >= DEADTHR ? BIG : (int)e0 - EBIAS + qa;
-                    const int c1 = e1 >= DEADTHR ? BIG : (int)e1 - EBIAS + qa;
-                    const int ci = seg + (int)((k0 & ((1u << TB) - 1)) << 6) + 16 * wave + l0;
-                    const int d0 = st_d0[row][wave], d1 = st_d1[row][wave];
-                    if (c0 < d0) { st_d1[row][wave] = min(d0, c1); st_d0[row][wave] = c0; st_i0[row][wave] = ci; }
-                    else st_d1[row][wave] = min(d1, c0);
-                }
+            for (int r = 0; r < 4; ++r)
+                xch[(16 * g + 4 * (lane >> 4) + r) * XS + 16 * wave + (lane & 15)] = make_uint2(b0[g][r], b1[g][r]);
+        __syncthreads();
+        {
+            const int half = threadIdx.x & 1;
+            const uint2* src = xch + (threadIdx.x >> 1) * XS + 32 * half;
+            unsigned k0 = 0xffffffffu, k1 = 0xffffffffu; int cls = 0;
+#pragma unroll 8
+            for (int e = 0; e < 32; ++e) {
+                const uint2 o = src[e];
+                k1 = min(max(k0, o.x), min(k1, o.y));
+                cls = o.x < k0 ? 32 * half + e : cls;
+                k0 = min(k0, o.x);
             }
+            {   // the other half of the row sits in the neighbouring lane
+                const unsigned o0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k0, 0xB1, 0xf, 0xf, false);
+                const unsigned o1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k1, 0xB1, 0xf, 0xf, false);
+                const int oc = __builtin_amdgcn_update_dpp(0, cls, 0xB1, 0xf, 0xf, false);
+                k1 = min(max(k0, o0), min(k1, o1));
+                cls = o0 < k0 ? oc : cls;
+                k0 = min(k0, o0);
+            }
+            const unsigned e0 = k0 >> TB, e1 = k1 >> TB;
+            const int c0 = e0 >= DEADTHR ? BIG : (int)e0 - EBIAS + row_qa;
+            const int c1 = e1 >= DEADTHR ? BIG : (int)e1 - EBIAS + row_qa;
+            const int ci = seg + (int)((k0 & ((1u << TB) - 1)) << 6) + cls;
+            if (c0 < row_d0) { row_d1 = min(row_d0, c1); row_d0 = c0; row_idx = ci; }
+            else row_d1 = min(row_d1, c0);
+        }
     }
-    __syncthreads();
-    if (threadIdx.x < QB) {
-        const int row = threadIdx.x, q = qbase + row;
+    if ((threadIdx.x & 1) == 0) {
+        const int q = qbase + (threadIdx.x >> 1);
         if (q < pd.q_n) {
-            int d0 = BIG, d1 = BIG, idx = -1;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const int c0 = st_d0[row][w], c1 = st_d1[row][w], ci = st_i0[row][w];
-                // insert the partial list (c0 <= c1) into the running (d0 <= d1)
-                if (c0 < d0) { d1 = d0; d0 = c0; idx = ci; }
-                else if (c0 < d1) d1 = c0;
-                if (c1 < d1) d1 = c1;
-            }
             bool ok;
             {
 #pragma clang fp contract(off)
-                ok = ((double)d0) < ratio_sq * ((double)d1);      // src/keys2a.cpp:362
+                ok = ((double)row_d0) < ratio_sq * ((double)row_d1);      // src/keys2a.cpp:362
             }
-            nn_out[pd.out_off + q] = ok ? idx : -1;
+            nn_out[pd.out_off + q] = ok ? row_idx : -1;
         }
     }
 }
@@ -242,7 +274,7 @@ extern "C" int bsfm_match_keys_l2(int n1, const unsigned char* k1, int n2, const
     if (n1 == 0) return 0;
     DevKeys d;
     const size_t tot = (size_t)n1 + n2;
-    HIPM(hipMalloc((void**)&d.keys, tot * 128)); HIPM(hipMalloc((void**)&d.qstat, tot * sizeof(int)));
+    HIPM(hipMalloc((void**)&d.keys, (tot + KEY_SLACK) * 128)); HIPM(hipMalloc((void**)&d.qstat, (tot + KEY_SLACK) * sizeof(int)));
     HIPM(hipMalloc((void**)&d.pairs, sizeof(PairDesc))); HIPM(hipMalloc((void**)&d.nn, (size_t)n1 * sizeof(int)));
     HIPM(hipMemcpy(d.keys, k1, (size_t)n1 * 128, hipMemcpyHostToDevice));
     HIPM(hipMemcpy(d.keys + (size_t)n1 * 128, k2, (size_t)n2 * 128, hipMemcpyHostToDevice));
@@ -324,7 +356,7 @@ extern "C" bsfm_match_set_t* bsfm_match_set_create(int num_images, const int* nu
     ms->tot = ms->off[num_images];
     if (ms->tot > 0x7fffffffULL) { fprintf(stderr, "[bsfm] too many keys\n"); delete ms; return nullptr; }
     if (ms->tot == 0) return ms;
-    bool ok = hipMalloc((void**)&ms->d.keys, ms->tot * 128) == hipSuccess && hipMalloc((void**)&ms->d.qstat, ms->tot * sizeof(int)) == hipSuccess;
+    bool ok = hipMalloc((void**)&ms->d.keys, (ms->tot + KEY_SLACK) * 128) == hipSuccess && hipMalloc((void**)&ms->d.qstat, (ms->tot + KEY_SLACK) * sizeof(int)) == hipSuccess;
     for (int i = 0; i < num_images && ok; ++i)
         if (num_keys[i] > 0) ok = hipMemcpy(ms->d.keys + ms->off[i] * 128, keys[i], (size_t)num_keys[i] * 128, hipMemcpyHostToDevice) == hipSuccess;
     if (ok) {
