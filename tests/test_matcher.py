@@ -114,6 +114,32 @@ def test_key_match_full_text_is_byte_identical(gpu_bsfm, tmp_path):
     assert out.read_text() == "".join(expect)
 
 
+@pytest.mark.gpu
+def test_many_small_images_block_to_pair_lookup(gpu_bsfm, tmp_path):
+    """200 images of 100..169 keys (one or two query blocks each): the launch for database image i carries up to 199 pairs, so
+    the kernel's block -> pair search (match_l2.hip, head of k_match_l2) runs over a long, ragged table; text vs the oracle loop."""
+    B = gpu_bsfm
+    sizes = [100 + (7 * i) % 70 for i in range(200)]
+    keys = []
+    prev = None
+    for i, nk in enumerate(sizes):
+        k = synth_keys(B, nk, 5000 + i, dup=prev)
+        keys.append(k)
+        prev = k
+    arr = (U * len(sizes))(*[k.ctypes.data_as(U) for k in keys])
+    nks = np.array(sizes, np.int32)
+    out = tmp_path / "matches.init.txt"
+    rc = B.lib.bsfm_key_match_full(len(sizes), nks.ctypes.data_as(C.POINTER(C.c_int)), arr, 0.6, -1, str(out).encode())
+    expect = []
+    for i in range(len(sizes)):
+        for j in range(i):
+            mt = O.port_match(keys[j], keys[i])
+            if len(mt) >= 16:
+                expect.append(f"{j} {i}\n{len(mt)}\n" + "".join(f"{a} {b}\n" for a, b in mt))
+    assert rc == len(expect) and len(expect) >= 60
+    assert out.read_text() == "".join(expect)
+
+
 def _write_key_file(path, keys, gz=False):
     """Lowe's ASCII .key format (keys2a.cpp:183-190): 'num 128', then per key 'row col scale ori' and the 128 bytes
     on 7 lines (6 x 20 + 8)."""
