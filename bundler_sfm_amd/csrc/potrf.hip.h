@@ -92,6 +92,12 @@ struct PotrfWorkspace {
     hipStream_t sd = nullptr;  // side stream: the part of panel k / first trailing column the NEXT diagonal tile does not need
     hipEvent_t* evP = nullptr; hipEvent_t* evU = nullptr;   // panel k complete (side stream) / trailing update k done
     hipEvent_t* evT = nullptr; hipEvent_t* evC = nullptr;   // first panel tile of step k ready (chain) / first trailing column done (side)
+    hipStream_t sb = nullptr;    // split chain: the stream of the explicit inverses
+    hipEvent_t* evB = nullptr;   // split chain: inverse of tile k done
+    hipEvent_t* evA = nullptr;   // split chain: diagonal tile k factored (its explicit inverse follows on the side stream)
+    int chain_split = 0;         // BSFM_CHAIN=split: factor-only diagonal kernel, first panel tile by block substitution (k_chain_trsm32), explicit
+                                 // inverse on its own stream.  Opt-in: the chain kernels get shorter (52 + 15.5 -> 37 + 12 us) but the solve gets
+                                 // SLOWER (10.5-11.0 vs 8.55 ms at config 3): see the note at k_chain_trsm32
     double* linv = nullptr;    // nblk tiles: inverse of each diagonal factor tile
     double* y = nullptr;       // ld
     double* xs = nullptr;      // ld
@@ -434,6 +440,104 @@ __global__ __launch_bounds__(256, 1) void k_chain_tile32(double* __restrict__ S,
     }
 }
 
+// Round 2: the first panel tile WITHOUT the explicit inverse.  P_0 = S_{k+1,k} L_kk^-T by right-looking block substitution
+//   X_s = R_s inv(L_ss)^T ;  R_J -= X_s L_Js^T  (J > s),   s = 0 .. 7,
+// so the chain no longer waits for inv(L_kk) (12.5 us of every diagonal tile; the inverse moves to the side stream, where the
+// rest of the panel and the substitutions still use it).  One WAVE owns 8 rows of the tile; all it needs of L_kk (28 blocks) and
+// the 8 inverse diagonal blocks are fetched as MFMA B fragments in ONE global round trip (176 doubles per lane: the workgroups
+// run one wave per SIMD, 512 VGPRs), the rows stay in the accumulators, and the only LDS traffic is the 8 x 16 slab that turns an
+// accumulator block into an A fragment.  No barrier: the waves are independent.  Grid 4 x 256 threads.
+// The k index of the products is permuted (k = 4 kq + ks for lane quarter kq in k-step ks) on both operands, which makes every
+// fragment four consecutive doubles.
+// MEASURED (config 3, profiles/r02_chain_split_timeline.txt): the kernel itself does what it was built for -- 12 us against 15.5 us
+// for the GEMM with the inverse, and the diagonal kernel drops from 52 to 37 us -- but the chain period grows from 88 to 110-120 us:
+// the next step's first panel tile needs column k+1 of the trailing matrix, which the SIDE stream completes (rest of panel k by
+// GEMM with the inverse, then the column update), and that path now starts with the inverse kernel (21 us + an event hop) instead
+// of finding the inverse ready; the fourth stream it runs on shares a hardware queue with the side stream (4 queues per process),
+// and every extra event adds 6-18 us of hand-off.  Making the side path independent of the inverse means running the WHOLE panel
+// by substitution (this kernel over T tiles) -- not done.  Kept opt-in (BSFM_CHAIN=split) with a parity test.
+constexpr int TR32_XS = 18;                                   // LDS row stride of the 8 x 16 slab
+__global__ __launch_bounds__(256, 1) void k_chain_trsm32(double* __restrict__ S, int ld, int k, const double* __restrict__ dinv,
+                                                         double* __restrict__ panel)
+{
+    __shared__ __attribute__((aligned(16))) double slab[4][8 * TR32_XS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i4 = lane >> 4, g = (lane >> 2) & 3, j = lane & 3;       // accumulator layout: row 4 t + i4, column 16 J + 4 g + j
+    const int kq = lane >> 4, r = lane & 3;                            // operand layout: A row r / B column 4 g + r, k = 4 kq + ks
+    const int row0 = 32 * (int)blockIdx.x + 8 * wave;
+    double* Sik = S + ((size_t)(k + 1) * POTRF_NB + row0) * ld + (size_t)k * POTRF_NB;
+    const double* Lkk = S + ((size_t)k * POTRF_NB) * ld + (size_t)k * POTRF_NB;
+    const double* dk = dinv + (size_t)k * 2048;
+    double* xw = slab[wave];
+    double R[2][8], bl[28][4], bd[8][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int J = 0; J < 8; ++J) R[t][J] = Sik[(size_t)(4 * t + i4) * ld + 16 * J + 4 * g + j];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const double2 d0 = *reinterpret_cast<const double2*>(dk + s * 256 + (4 * g + r) * 16 + 4 * kq);
+        const double2 d1 = *reinterpret_cast<const double2*>(dk + s * 256 + (4 * g + r) * 16 + 4 * kq + 2);
+        bd[s][0] = d0.x; bd[s][1] = d0.y; bd[s][2] = d1.x; bd[s][3] = d1.y;
+    }
+#pragma unroll
+    for (int s = 0; s < 7; ++s)
+#pragma unroll
+        for (int J = s + 1; J < 8; ++J) {
+            const int q = s * (15 - s) / 2 + (J - s - 1);
+            const double* lp = Lkk + (size_t)(16 * J + 4 * g + r) * ld + 16 * s + 4 * kq;
+            const double2 l0 = *reinterpret_cast<const double2*>(lp);
+            const double2 l1 = *reinterpret_cast<const double2*>(lp + 2);
+            bl[q][0] = l0.x; bl[q][1] = l0.y; bl[q][2] = l1.x; bl[q][3] = l1.y;
+        }
+    double* Pk = panel + (size_t)row0 * POTRF_NB;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        // accumulator block s -> A fragments
+#pragma unroll
+        for (int t = 0; t < 2; ++t) xw[(4 * t + i4) * TR32_XS + 4 * g + j] = R[t][s];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        double a[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const double2 a0 = *reinterpret_cast<const double2*>(xw + (4 * t + r) * TR32_XS + 4 * kq);
+            const double2 a1 = *reinterpret_cast<const double2*>(xw + (4 * t + r) * TR32_XS + 4 * kq + 2);
+            a[t][0] = a0.x; a[t][1] = a0.y; a[t][2] = a1.x; a[t][3] = a1.y;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        double x[2] = { 0.0, 0.0 };
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) x[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[t][ks], bd[s][ks], x[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            Sik[(size_t)(4 * t + i4) * ld + 16 * s + 4 * g + j] = x[t];
+            Pk[(size_t)(4 * t + i4) * POTRF_NB + 16 * s + 4 * g + j] = x[t];
+        }
+        if (s < 7) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) xw[(4 * t + i4) * TR32_XS + 4 * g + j] = -x[t];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const double2 a0 = *reinterpret_cast<const double2*>(xw + (4 * t + r) * TR32_XS + 4 * kq);
+                const double2 a1 = *reinterpret_cast<const double2*>(xw + (4 * t + r) * TR32_XS + 4 * kq + 2);
+                a[t][0] = a0.x; a[t][1] = a0.y; a[t][2] = a1.x; a[t][3] = a1.y;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int J = s + 1; J < 8; ++J) {
+                const int q = s * (15 - s) / 2 + (J - s - 1);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) R[t][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[t][ks], bl[q][ks], R[t][J], 0, 0, 0);
+            }
+        }
+    }
+}
+
 // (Also tried and dropped: an XCD-aware blockIdx -> tile order (super-tiles of 8x8 tiles per XCD chunk).  +8-11 % for the
 // kernel alone on the whole device (scripts/ubench_syrk.hip), exactly 0 in the factorisation -- with the CU-masked bulk
 // stream (35.0 TFLOP/s either way) and again without the mask (38.4 vs 38.5).  Nor do 64-row half-tile workgroups for the
@@ -592,7 +696,9 @@ __device__ __forceinline__ void diag_factor_block(double* __restrict__ T, double
 // below the diagonal go to S with write-through stores together with inv(L_ss) -> dinv, and the flag lflag[8 k + s] follows one
 // phase later (after every storing wave has drained) -- the panel workers run their triangular solves one block column behind
 // the factorisation instead of waiting for the whole tile and its inverse.
-template <bool PUBLISH>
+// PHASES: 3 = factor + inverse in one go (round 1); 1 = factor only, inv(L_ss) blocks exported to `dinv` (the chain continues with a
+// block substitution against them, k_chain_trsm32); 2 = inverse only, from the factor tile in S and the exported blocks (side stream).
+template <bool PUBLISH, int PHASES = 3>
 __device__ __forceinline__ void diag_tile_body(double* __restrict__ dlds, double* __restrict__ S, int ld, int k, int n_total,
         double* __restrict__ Linv, int* __restrict__ info, long long* __restrict__ dbg, double* __restrict__ dinv, int* lflag)
 {
@@ -606,6 +712,17 @@ __device__ __forceinline__ void diag_tile_body(double* __restrict__ dlds, double
     double* G = S + (size_t)base * ld + base;
     __syncthreads();                                   // (engine: the previous tile's phase B has finished with the LDS tile)
 
+    if (PHASES == 2) {
+        // factor tile (lower triangle) and inverse diagonal blocks back into LDS
+#pragma unroll 8
+        for (int it = 0; it < 32; ++it) {
+            const int idx = tid + 512 * it, r = idx >> 7, c = idx & 127;
+            T[r * DG_TS + c] = c <= r ? G[(size_t)r * ld + c] : 0.0;
+        }
+        for (int idx = tid; idx < 2048; idx += 512) Di[idx] = dinv[(size_t)k * 2048 + idx];
+        __syncthreads();
+    }
+    if (PHASES != 2) {
     // load the tile (lower triangle; identity in the padding beyond n_total)
     {
         double v[32];
@@ -721,8 +838,14 @@ __device__ __forceinline__ void diag_tile_body(double* __restrict__ dlds, double
         const int idx = tid + 512 * it, r = idx >> 7, c = idx & 127;
         if (c <= r) G[(size_t)r * ld + c] = T[r * DG_TS + c];
     }
+    if (PHASES == 1) {
+        for (int idx = tid; idx < 2048; idx += 512) dinv[(size_t)k * 2048 + idx] = Di[idx];
+        if (dbg && threadIdx.x == 0) dbg[2] = wall_clock64() - t0;
+        return;
+    }
     __syncthreads();
     if (dbg && threadIdx.x == 0) dbg[2] = wall_clock64() - t0;
+    }   // PHASES != 2
     // ---- phase B: inverse, wave J owns block column J
     double* Li = Linv + (size_t)k * POTRF_NB * POTRF_NB;
     {
@@ -770,6 +893,20 @@ __global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int 
 {
     extern __shared__ __attribute__((aligned(16))) double dlds[];
     diag_tile_body<false>(dlds, S, ld, k, n_total, Linv, info, dbg, nullptr, nullptr);
+}
+
+// split form (round 2): factor only (+ inverse diagonal blocks -> dinv) on the chain; the explicit inverse on the side stream
+__global__ __launch_bounds__(512) void k_potrf_diag_a(double* __restrict__ S, int ld, int k, int n_total, double* __restrict__ dinv,
+        int* __restrict__ info, long long* __restrict__ dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) double dlds[];
+    diag_tile_body<false, 1>(dlds, S, ld, k, n_total, nullptr, info, dbg, dinv, nullptr);
+}
+__global__ __launch_bounds__(512) void k_potrf_diag_b(double* __restrict__ S, int ld, int k, int n_total, double* __restrict__ Linv,
+        double* __restrict__ dinv)
+{
+    extern __shared__ __attribute__((aligned(16))) double dlds[];
+    diag_tile_body<false, 2>(dlds, S, ld, k, n_total, Linv, nullptr, nullptr, dinv, nullptr);
 }
 
 // Backward substitution x = L^-T y as ONE persistent launch (replaces nblk dependent launches).
@@ -851,10 +988,13 @@ inline void potrf_free(PotrfWorkspace& w)
     delete[] w.sy0; delete[] w.sy1; delete[] w.sy_flops;
     for (int i = 0; w.evP && i <= w.nblk; ++i) {
         (void)hipEventDestroy(w.evP[i]); (void)hipEventDestroy(w.evU[i]); (void)hipEventDestroy(w.evT[i]); (void)hipEventDestroy(w.evC[i]);
+        if (w.evA) (void)hipEventDestroy(w.evA[i]);
+        if (w.evB) (void)hipEventDestroy(w.evB[i]);
     }
-    delete[] w.evP; delete[] w.evU; delete[] w.evT; delete[] w.evC;
+    delete[] w.evP; delete[] w.evU; delete[] w.evT; delete[] w.evC; delete[] w.evA; delete[] w.evB;
     if (w.s2) { if (w.s2_masked) (void)hipStreamDestroy(w.s2); else stream_pool().release(w.s2); }
     stream_pool().release(w.sd);
+    if (w.sb) stream_pool().release(w.sb);
     w = PotrfWorkspace();
 }
 
@@ -884,11 +1024,13 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
     }
     if (!(w.sd = stream_pool().acquire())) return -1;
     w.evP = new hipEvent_t[w.nblk + 1]; w.evU = new hipEvent_t[w.nblk + 1];
-    w.evT = new hipEvent_t[w.nblk + 1]; w.evC = new hipEvent_t[w.nblk + 1];
+    w.evT = new hipEvent_t[w.nblk + 1]; w.evC = new hipEvent_t[w.nblk + 1]; w.evA = new hipEvent_t[w.nblk + 1]; w.evB = new hipEvent_t[w.nblk + 1];
     for (int i = 0; i <= w.nblk; ++i) {
         if (hipEventCreateWithFlags(&w.evP[i], hipEventDisableTiming) != hipSuccess) return -1;
         if (hipEventCreateWithFlags(&w.evU[i], hipEventDisableTiming) != hipSuccess) return -1;
         if (hipEventCreateWithFlags(&w.evT[i], hipEventDisableTiming) != hipSuccess) return -1;
+        if (hipEventCreateWithFlags(&w.evA[i], hipEventDisableTiming) != hipSuccess) return -1;
+        if (hipEventCreateWithFlags(&w.evB[i], hipEventDisableTiming) != hipSuccess) return -1;
         if (hipEventCreateWithFlags(&w.evC[i], hipEventDisableTiming) != hipSuccess) return -1;
     }
     if (hipMalloc((void**)&w.linv, (size_t)w.nblk * tile * sizeof(double)) != hipSuccess) return -1;
@@ -905,6 +1047,12 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
     (void)hipEventCreate(&w.ev0); (void)hipEventCreate(&w.ev1);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(DG_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag_a), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(DG_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag_b), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(DG_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    if (const char* e = getenv("BSFM_CHAIN")) w.chain_split = strcmp(e, "split") == 0;
+    if (w.chain_split && !(w.sb = stream_pool().acquire())) return -1;     // (only then: a fourth stream changes the queue mapping of the others)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_tile32<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(T32_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_tile32<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(T32_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
     w.sy0 = new hipEvent_t[w.nblk]; w.sy1 = new hipEvent_t[w.nblk]; w.sy_flops = new double[w.nblk];
@@ -969,20 +1117,36 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
     (void)hipEventRecord(w.evU[w.nblk], st);                 // everything queued before the solve (S, E ready)
     (void)hipStreamWaitEvent(w.s2, w.evU[w.nblk], 0);
     (void)hipStreamWaitEvent(w.sd, w.evU[w.nblk], 0);
-    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, 0, n, w.linv, d_info, w.dbg);
+    const bool split = w.chain_split != 0 && nblk > 1;
+    if (split) {
+        hipLaunchKernelGGL(k_potrf_diag_a, dim3(1), dim3(512), diag_lds, st, S, ld, 0, n, w.dinv, d_info, w.dbg);
+        (void)hipEventRecord(w.evA[0], st);
+    } else {
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, 0, n, w.linv, d_info, w.dbg);
+    }
     for (int k = 0; k + 1 < nblk; ++k) {
         const int T = nblk - k - 1;                          // tile rows below the diagonal tile k
         double* pk = panel_of(k);
         const double* Lk = w.linv + (size_t)k * tl;
+        if (split) {
+            // side: the explicit inverse of tile k (the rest of the panel, y_k and the backward substitution use it)
+            (void)hipStreamWaitEvent(w.sb, w.evA[k], 0);
+            hipLaunchKernelGGL(k_potrf_diag_b, dim3(1), dim3(512), diag_lds, w.sb, S, ld, k, n, w.linv, w.dinv);
+            (void)hipEventRecord(w.evB[k], w.sb);
+            (void)hipStreamWaitEvent(w.sd, w.evB[k], 0);
+        }
         // chain: first panel tile (its column k was completed by the side stream of step k-1)
         if (k > 0) (void)hipStreamWaitEvent(st, w.evC[k - 1], 0);
-        hipLaunchKernelGGL(k_chain_tile32<0>, dim3(16), dim3(256), lds32, st, S, ld, k, Lk, pk, (const double*)nullptr, (const double*)nullptr);
+        if (split) hipLaunchKernelGGL(k_chain_trsm32, dim3(4), dim3(256), 0, st, S, ld, k, (const double*)w.dinv, pk);
+        else hipLaunchKernelGGL(k_chain_tile32<0>, dim3(16), dim3(256), lds32, st, S, ld, k, Lk, pk, (const double*)nullptr, (const double*)nullptr);
         (void)hipEventRecord(w.evT[k], st);
         // side: rest of the panel and y_k (the extra workgroup), then the rest of the first trailing column
-        (void)hipStreamWaitEvent(w.sd, w.evT[k], 0);
-        hipLaunchKernelGGL(k_trsm_panel64, dim3(2 * (T - 1) + 2), dim3(256), lds64, w.sd, S, ld, k, Lk, pk, 1, 2 * (T - 1), w.etmp, w.y);
+        if (!split) (void)hipStreamWaitEvent(w.sd, w.evT[k], 0);
+        // (split: the block substitution writes L_{k+1,k} to S itself, so the workgroup that copies slot 0 of the compact panel is not launched)
+        hipLaunchKernelGGL(k_trsm_panel64, dim3(2 * (T - 1) + (split ? 1 : 2)), dim3(256), lds64, w.sd, S, ld, k, Lk, pk, 1, 2 * (T - 1), w.etmp, w.y);
         (void)hipEventRecord(w.evP[k], w.sd);
         if (k > 0) (void)hipStreamWaitEvent(w.sd, w.evU[k - 1], 0);   // column k+1 was last written by the bulk of step k-1
+        if (split) (void)hipStreamWaitEvent(w.sd, w.evT[k], 0);       // slot 0 of the compact panel (B operand of the column update)
         hipLaunchKernelGGL(k_syrk_col64, dim3(2 * (T - 1) + T), dim3(256), lds64, w.sd, S, ld, k, pk, 1, 2 * (T - 1), w.etmp, w.y);
         (void)hipEventRecord(w.evC[k], w.sd);
         // bulk
@@ -1002,7 +1166,12 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         // of the chain <-> side events: no faster.)
         hipLaunchKernelGGL(k_chain_tile32<1>, dim3(10), dim3(256), lds32, st, S, ld, k, Lk, pk,
                            k > 0 ? (const double*)panel_of(k - 1) : (const double*)nullptr, (const double*)nullptr);
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, k + 1, n, w.linv, d_info, w.dbg);
+        if (split && k + 2 < nblk) {
+            hipLaunchKernelGGL(k_potrf_diag_a, dim3(1), dim3(512), diag_lds, st, S, ld, k + 1, n, w.dinv, d_info, w.dbg);
+            (void)hipEventRecord(w.evA[k + 1], st);
+        } else {
+            hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, k + 1, n, w.linv, d_info, w.dbg);
+        }
     }
     // y of the last tile: E_last is final once the side stream has drained
     if (nblk > 1) { (void)hipStreamWaitEvent(st, w.evC[nblk - 2], 0); (void)hipStreamWaitEvent(st, w.evU[nblk - 2], 0); }

@@ -10,7 +10,7 @@ jac = [i for i, r in enumerate(rows) if 'k_jacobian' in r['Kernel_Name']] + [len
 seg, diag = [], []
 for a, b in reversed(list(zip(jac, jac[1:]))):
     cand = rows[a:b]
-    d = [r for r in cand if name(r) == 'k_potrf_diag']
+    d = [r for r in cand if name(r) in ('k_potrf_diag', 'k_potrf_diag_a')]      # chain tiles (the split chain's inverse kernel is k_potrf_diag_b)
     if len(d) > len(diag):
         seg, diag = cand, d
     if len(diag) >= 2 and len(d) == len(diag) and cand is not seg:
