@@ -37,6 +37,7 @@
 #include <vector>
 #include <cstring>
 #include <algorithm>
+#include <mutex>
 
 namespace bsfm {
 
@@ -605,6 +606,10 @@ __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __re
 // waits for its first two columns (9.5 vs 9.0 ms): the bulk stream idles while the chain and side streams prepare the
 // second panel of a pair, and their own kernels get heavier.)
 
+// (Tried and dropped, round 2: TWO bulk streams, tile rows shared out by the parity of the global tile row, so that the ragged last
+// round of one launch -- a launch runs ceil(tiles / 512) rounds of workgroups, 4.45 -> 5 at T = 68 -- is filled by the other stream's
+// launch.  Solve 10.5 ms instead of 8.55 with 4 hardware queues, 13.2 ms with GPU_MAX_HW_QUEUES=8: the two launches interleave on
+// every CU and each runs at 23-27 TFLOP/s.)
 // (Tried and dropped: taking the tile inverse off the chain -- the chain kernel factors only, a side-stream launch inverts,
 // and the chain's own panel tile comes from a 16-row block substitution against L (8 workgroups, inverse diagonal blocks
 // from the factorisation).  Correct, but ~10 % slower at every size from 2 to 70 tile columns: the extra chain -> side

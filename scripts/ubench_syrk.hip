@@ -147,7 +147,7 @@ int main()
         }
         printf("%-34s grid %5d  %8.3f ms  %7.2f TFLOP/s\n", name, grid, best, flop / (best * 1e-3) / 1e12);
     };
-    run("shipped k_syrk_update part 2", [&] { hipLaunchKernelGGL(k_syrk_update, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2); }, flop1);
+    run("shipped k_syrk_update part 2", [&] { hipLaunchKernelGGL(k_syrk_update<false>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2); }, flop1);
     // (a rank-256 two-panel variant measured 46.6 vs 42.9 TFLOP/s here; dropped, see potrf.hip.h)
     run("same, mode 0 copy", [&] { hipLaunchKernelGGL(k_var<0>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, flop1);
     run("no C epilogue", [&] { hipLaunchKernelGGL(k_var<1>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, flop1);
@@ -176,7 +176,7 @@ int main()
             hipStreamSynchronize(sm);
             hipEventRecord(e0, sm); hipLaunchKernelGGL(k_mapped, dim3(grid), dim3(512), lds_bytes, sm, S, ld, 0, panel, dm); hipEventRecord(e1, sm); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); printf("masked stream, G=8 map: %.3f ms %.2f TFLOP/s\n", ms, flop1 / (ms * 1e-3) / 1e12);
-            hipEventRecord(e0, sm); hipLaunchKernelGGL(k_syrk_update, dim3(grid), dim3(512), lds_bytes, sm, S, ld, 0, panel, 2); hipEventRecord(e1, sm); hipEventSynchronize(e1);
+            hipEventRecord(e0, sm); hipLaunchKernelGGL(k_syrk_update<false>, dim3(grid), dim3(512), lds_bytes, sm, S, ld, 0, panel, 2); hipEventRecord(e1, sm); hipEventSynchronize(e1);
             hipEventElapsedTime(&ms, e0, e1); printf("masked stream, shipped order: %.3f ms %.2f TFLOP/s\n", ms, flop1 / (ms * 1e-3) / 1e12);
         }
     }
