@@ -57,6 +57,45 @@ __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_var(double* __restrict__
         }
 }
 
+// MODE 6: workgroups alternate between "accumulators start as C" (store-only epilogue) and "accumulators start at 0"
+// (load / subtract / store epilogue): the two workgroups of a CU then have their C traffic at opposite ends of their life.
+template <int SEL>   // 0: by blockIdx parity  1: all prologue (= shipped)  2: all epilogue
+__global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_mix(double* __restrict__ S, int ld, int k, const double* __restrict__ panel)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int t = blockIdx.x + 1;
+    int a = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= t) ++a;
+    while (a * (a + 1) / 2 > t) --a;
+    int b = t - a * (a + 1) / 2;
+    ++a; ++b;
+    const int i = k + 1 + a, j = k + 1 + b;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
+    double* Sij = S + ((size_t)i * POTRF_NB) * ld + (size_t)j * POTRF_NB;
+    const bool pro = SEL == 1 || (SEL == 0 && (blockIdx.x & 1) == 0);
+    double acc[8][4];
+    {
+        const double* cp = Sij + (size_t)(wr + (lane >> 4)) * ld + wc + (lane & 15);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[q][u] = pro ? cp[16 * u] : 0.0;
+            cp += 4 * (size_t)ld;
+        }
+    }
+    gemm_nt_128<true>(panel + (size_t)a * POTRF_NB * POTRF_NB, POTRF_NB, panel + (size_t)b * POTRF_NB * POTRF_NB, POTRF_NB, POTRF_NB, lds, acc);
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    double* Sl = Sij + (size_t)(((tid2 >> 7) << 5) + ((tid2 & 63) >> 4)) * ld + (((tid2 >> 6) & 1) << 6) + (tid2 & 15);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Sl[16 * u] = pro ? acc[q][u] : Sl[16 * u] + acc[q][u];
+        Sl += 4 * (size_t)ld;
+    }
+}
+
 // XCD-aware order: supertiles of G x G tiles, the list cut into nx contiguous chunks, chunk x served by the workgroups
 // with blockIdx % nx == x (round-robin dispatch of workgroups over the XCDs).
 static void build_map(int n, int G, int nx, std::vector<int2>& out)
@@ -147,6 +186,14 @@ int main()
         }
         printf("%-34s grid %5d  %8.3f ms  %7.2f TFLOP/s\n", name, grid, best, flop / (best * 1e-3) / 1e12);
     };
+    {   // warm-up ramp: the same launch 40 times, time of each (the first runs in a process are ~10 % slower than the steady state)
+        printf("ramp (ms):");
+        for (int r = 0; r < 40; ++r) {
+            hipEventRecord(e0, 0); hipLaunchKernelGGL(k_syrk_update<false>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2); hipEventRecord(e1, 0); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); printf(" %.3f", ms);
+        }
+        printf("\n");
+    }
     run("shipped k_syrk_update part 2", [&] { hipLaunchKernelGGL(k_syrk_update<false>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2); }, flop1);
     // (a rank-256 two-panel variant measured 46.6 vs 42.9 TFLOP/s here; dropped, see potrf.hip.h)
     run("same, mode 0 copy", [&] { hipLaunchKernelGGL(k_var<0>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, flop1);
@@ -155,6 +202,11 @@ int main()
     run("K x8, no epilogue", [&] { hipLaunchKernelGGL(k_var<3>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, 8 * flop1);
     run("all WGs same tiles (L2 hits), no epi", [&] { hipLaunchKernelGGL(k_var<4>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, flop1);
     run("lda=0 (L1 hits), no epilogue", [&] { hipLaunchKernelGGL(k_var<5>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, flop1);
+    run("mix: prologue / epilogue by parity", [&] { hipLaunchKernelGGL(k_mix<0>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel); }, flop1);
+    run("mix kernel, all prologue", [&] { hipLaunchKernelGGL(k_mix<1>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel); }, flop1);
+    run("mix kernel, all epilogue", [&] { hipLaunchKernelGGL(k_mix<2>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel); }, flop1);
+    run("shipped k_syrk_update again", [&] { hipLaunchKernelGGL(k_syrk_update<false>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2); }, flop1);
+    run("mix kernel, all prologue again", [&] { hipLaunchKernelGGL(k_mix<1>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel); }, flop1);
     for (int G : {8}) {
         std::vector<int2> hm; build_map(T - 1, G, 8, hm);
         int2* dm; hipMalloc((void**)&dm, hm.size() * sizeof(int2)); hipMemcpy(dm, hm.data(), hm.size() * sizeof(int2), hipMemcpyHostToDevice);
