@@ -503,6 +503,7 @@ __global__ __launch_bounds__(256) void k_cam_step(int count, int fixed, double m
 {
     __shared__ double sm[3][4];
     double s_dp = 0, s_p = 0, s_dl = 0;
+#pragma unroll 4
     for (int t = threadIdx.x; t < count; t += 256) {
         const double d = (t < fixed) ? 0.0 : dpa[t], p = pa[t];
         pdpa[t] = p + d;
@@ -784,10 +785,12 @@ __global__ __launch_bounds__(256) void k_iter_final(DevProblem P, const double* 
         if (t == 0) { scal[s_eabinf_b] = ra; scal[s_maxdiag_v] = rv; scal[s_pl2_b] = rs; }
     }
     double ea = 0.0, ud = -DBL_MAX, ps = 0.0;
+#pragma unroll 4
     for (int q = t; q < P.m * cnp; q += 256) {
         const double x = fabs(P.ea[q]); ea = x > ea ? x : ea;
         ps += pa[q] * pa[q];
     }
+#pragma unroll 4
     for (int q = P.mcon * cnp + t; q < P.m * cnp; q += 256) {
         const int j = q / cnp, jj = q % cnp;
         const double x = P.U[(size_t)j * cnp * cnp + jj * cnp + jj];
@@ -829,6 +832,7 @@ __global__ __launch_bounds__(256) void k_step_sums(int count, int fixed, double 
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         double s = 0.0;
+#pragma unroll 8
         for (int t = threadIdx.x; t < nbp; t += 256) s += part[(size_t)c * nbp + t];
         q[c] = block_sum4(s, sm);
     }
@@ -841,6 +845,7 @@ __global__ __launch_bounds__(256) void k_reduce_sum_max(const double* __restrict
 {
     __shared__ double sm[4];
     double s = 0.0, m = 0.0;
+#pragma unroll 8
     for (int t = threadIdx.x; t < count; t += 256) { s += in_sum[t]; if (in_max) { const double v = in_max[t]; m = v > m ? v : m; } }
     const double rs = block_sum4(s, sm), rm = block_max4(m, sm);
     if (threadIdx.x == 0) { *out_sum = rs; if (in_max) *out_max = rm; }
