@@ -70,7 +70,7 @@ SYMBOLS = [
     "bsfm_default_options", "run_sfm", "bsfm_run_sfm_ex", "bsfm_sba_motstr_levmar", "bsfm_sba_mot_levmar", "bsfm_problem_create", "bsfm_problem_destroy",
     "bsfm_comm_create_from_env", "bsfm_comm_create_all", "bsfm_comm_destroy", "bsfm_comm_rank", "bsfm_comm_world", "bsfm_comm_transport",
     "bsfm_comm_allreduce", "bsfm_comm_allreduce_host", "bsfm_comm_barrier", "bsfm_problem_set_comm",
-    "bsfm_problem_set_allreduce", "bsfm_problem_set_stream", "bsfm_problem_reset_params", "bsfm_problem_append", "bsfm_lm_begin",
+    "bsfm_problem_set_allreduce", "bsfm_problem_set_stream", "bsfm_problem_reset_params", "bsfm_problem_append", "bsfm_problem_remove_points", "bsfm_lm_begin",
     "bsfm_lm_iterate", "bsfm_lm_finish", "bsfm_lm_solve_attempts", "bsfm_lm_last_kernel_ms",
     "bsfm_problem_download", "bsfm_problem_export_index", "bsfm_problem_schur_sizes", "bsfm_problem_export_schur", "bsfm_crs_from_vmask",
     "bsfm_problem_cnp", "bsfm_problem_num_cameras", "bsfm_problem_num_points", "bsfm_problem_nvis", "bsfm_eval_residuals", "bsfm_problem_outlier_stats", "bsfm_problem_ray_angles", "bsfm_triangulate_batch", "bsfm_rand_seed", "bsfm_rand_next", "bsfm_fmatrix_ransac_batch",
@@ -110,6 +110,8 @@ def _load():
     lib.bsfm_problem_reset_params.restype = C.c_int
     lib.bsfm_problem_append.argtypes = [vp, C.c_int, cp, C.c_int, dp, C.c_int, ip, ip, dp]
     lib.bsfm_problem_append.restype = C.c_int
+    lib.bsfm_problem_remove_points.argtypes = [vp, C.POINTER(C.c_ubyte), ip]
+    lib.bsfm_problem_remove_points.restype = C.c_int
     lib.bsfm_lm_begin.argtypes = [vp]
     lib.bsfm_lm_begin.restype = C.c_int
     lib.bsfm_lm_iterate.argtypes = [vp, C.c_int]

@@ -44,4 +44,13 @@ int merge_observations_device(int n_new, int m_new, int nvis, const int* d_obs_p
                               int nadd, const int* d_add_pt, const int* d_add_cam, const double* d_add_xy,
                               int** rowptr_out, int** colidx_out, double** x_out, hipStream_t st);
 
+// Shrinking a resident problem (the outlier loop of RunSFM_SBA, src/Bundle.cpp:784-913): drops the points with
+// d_remove[i] != 0 (device, n bytes) and all their observations; the others keep their order.  Outputs (device, owned by the caller,
+// hipFree): the CRS of the kept points, remap_out (n: new index or -1); *n_keep / *nvis_keep.  Returns 0 or -1.
+int compact_points_device(int n, int nvis, const int* d_rowptr, const int* d_obs_pt, const int* d_colidx, const double* d_x,
+                          const unsigned char* d_remove, int** rowptr_out, int** colidx_out, double** x_out, int** remap_out,
+                          int* n_keep, int* nvis_keep, hipStream_t st);
+// dst[remap[i]] = src[i] for the kept rows of a per-point array with rows of width_bytes
+int gather_kept_device(int n, const int* d_remap, int width_bytes, const void* src, void* dst, hipStream_t st);
+
 }  // namespace bsfm

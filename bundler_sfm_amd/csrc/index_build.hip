@@ -366,6 +366,85 @@ int merge_observations_device(int n_new, int m_new, int nvis, const int* d_obs_p
     return 0;
 }
 
+// ---- shrinking (the outlier loop of RunSFM_SBA drops whole points, src/Bundle.cpp:784-913) ------------------------
+namespace {
+__global__ void k_keep_counts(int n, const int* __restrict__ rowptr, const unsigned char* __restrict__ remove, int* __restrict__ pk, int* __restrict__ oc)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    const bool keep_it = i < n && remove[i] == 0;
+    pk[i] = keep_it ? 1 : 0;
+    oc[i] = keep_it ? rowptr[i + 1] - rowptr[i] : 0;
+}
+__global__ void k_compact_rows(int n, const unsigned char* __restrict__ remove, const int* __restrict__ pnew, const int* __restrict__ onew,
+                               int* __restrict__ rowptr_out, int* __restrict__ remap)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { rowptr_out[pnew[n]] = onew[n]; return; }
+    const bool keep_it = remove[i] == 0;
+    remap[i] = keep_it ? pnew[i] : -1;
+    if (keep_it) rowptr_out[pnew[i]] = onew[i];
+}
+__global__ void k_compact_obs(int nvis, const int* __restrict__ obs_pt, const int* __restrict__ rowptr, const int* __restrict__ colidx,
+                              const double* __restrict__ x, const unsigned char* __restrict__ remove, const int* __restrict__ onew,
+                              int* __restrict__ colidx_out, double* __restrict__ x_out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nvis) return;
+    const int i = obs_pt[k];
+    if (remove[i]) return;
+    const int dst = onew[i] + (k - rowptr[i]);
+    colidx_out[dst] = colidx[k];
+    x_out[2 * (size_t)dst] = x[2 * (size_t)k]; x_out[2 * (size_t)dst + 1] = x[2 * (size_t)k + 1];
+}
+__global__ void k_gather_kept(int n, const int* __restrict__ remap, int width, const unsigned char* __restrict__ src, unsigned char* __restrict__ dst)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)n * width) return;
+    const int i = (int)(t / width), b = (int)(t % width);
+    const int q = remap[i];
+    if (q >= 0) dst[(size_t)q * width + b] = src[(size_t)i * width + b];
+}
+}  // namespace
+
+int compact_points_device(int n, int nvis, const int* d_rowptr, const int* d_obs_pt, const int* d_colidx, const double* d_x,
+                          const unsigned char* d_remove, int** rowptr_out, int** colidx_out, double** x_out, int** remap_out,
+                          int* n_keep, int* nvis_keep, hipStream_t st)
+{
+    (void)hipGetLastError();
+    Scratch tmp(st);
+    int *pk = nullptr, *oc = nullptr, *pnew = nullptr, *onew = nullptr;
+    IX_OK(tmp.alloc(&pk, (size_t)n + 1)); IX_OK(tmp.alloc(&oc, (size_t)n + 1)); IX_OK(tmp.alloc(&pnew, (size_t)n + 1)); IX_OK(tmp.alloc(&onew, (size_t)n + 1));
+    hipLaunchKernelGGL(k_keep_counts, dim3(grid_for((size_t)n + 1, 256)), dim3(256), 0, st, n, d_rowptr, d_remove, pk, oc);
+    size_t sb = 0;
+    IX_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, pk, pnew, n + 1, st));
+    void* d_scan = nullptr;
+    IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_scan), sb));
+    IX_OK(hipcub::DeviceScan::ExclusiveSum(d_scan, sb, pk, pnew, n + 1, st));
+    IX_OK(hipcub::DeviceScan::ExclusiveSum(d_scan, sb, oc, onew, n + 1, st));
+    int h[2] = { 0, 0 };
+    IX_OK(hipMemcpyAsync(&h[0], pnew + n, sizeof(int), hipMemcpyDeviceToHost, st));
+    IX_OK(hipMemcpyAsync(&h[1], onew + n, sizeof(int), hipMemcpyDeviceToHost, st));
+    IX_OK(hipStreamSynchronize(st));
+    *n_keep = h[0]; *nvis_keep = h[1];
+    IX_OK(keep(rowptr_out, (size_t)h[0] + 1)); IX_OK(keep(colidx_out, (size_t)h[1])); IX_OK(keep(x_out, 2 * (size_t)h[1])); IX_OK(keep(remap_out, (size_t)n));
+    hipLaunchKernelGGL(k_compact_rows, dim3(grid_for((size_t)n + 1, 256)), dim3(256), 0, st, n, d_remove, pnew, onew, *rowptr_out, *remap_out);
+    if (nvis > 0)
+        hipLaunchKernelGGL(k_compact_obs, dim3(grid_for((size_t)nvis, 256)), dim3(256), 0, st, nvis, d_obs_pt, d_rowptr, d_colidx, d_x, d_remove, onew,
+                           *colidx_out, *x_out);
+    IX_OK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int gather_kept_device(int n, const int* d_remap, int width_bytes, const void* src, void* dst, hipStream_t st)
+{
+    if (n <= 0 || width_bytes <= 0) return 0;
+    hipLaunchKernelGGL(k_gather_kept, dim3(grid_for((size_t)n * (size_t)width_bytes, 256)), dim3(256), 0, st, n, d_remap, width_bytes,
+                       static_cast<const unsigned char*>(src), static_cast<unsigned char*>(dst));
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 void free_index_device(DeviceIndex& ix)
 {
     void* ptrs[] = { ix.obs_pt, ix.camptr, ix.camobs, ix.campos, ix.cam_pt, ix.cam_cam, ix.triples, ix.tri_pt, ix.tasks,

@@ -720,6 +720,51 @@ int bsfm_problem_append(bsfm_problem_t* pb, int num_new_cameras, const bsfm_came
     return 0;
 }
 
+int bsfm_problem_remove_points(bsfm_problem_t* pb, const unsigned char* remove, int* remap_out)
+{
+    if (!pb || !remove) { fprintf(stderr, "[bsfm] bsfm_problem_remove_points: bad arguments\n"); return BSFM_ERROR; }
+    if (pb->world > 1 || pb->mot) { fprintf(stderr, "[bsfm] bsfm_problem_remove_points: single-rank motion + structure problems only\n"); return BSFM_ERROR; }
+    const int m = pb->P.m, n0 = pb->P.n, nvis0 = pb->P.nvis, cnp = pb->cnp;
+    HIP_OK(hipStreamSynchronize(pb->stream));
+    int nrem = 0;
+    for (int i = 0; i < n0; ++i) nrem += remove[i] != 0;
+    if (nrem == 0) { if (remap_out) for (int i = 0; i < n0; ++i) remap_out[i] = i; return 0; }
+    // cameras as run_sfm would hand them back (rotation increment folded into R on the host), as in bsfm_problem_append
+    std::vector<bsfm_camera_params_t> cams(pb->h_cams);
+    if (bsfm_problem_download(pb, nullptr, cams.data(), nullptr) != 0) return BSFM_ERROR;
+    unsigned char* d_rm = nullptr; int *d_rp = nullptr, *d_ci = nullptr, *d_remap = nullptr; double *d_x = nullptr, *d_pts = nullptr;
+    auto cleanup = [&] { for (void* q : { (void*)d_rm, (void*)d_rp, (void*)d_ci, (void*)d_remap, (void*)d_x, (void*)d_pts }) if (q) (void)hipFree(q); };
+    if (dmalloc(&d_rm, (size_t)n0) != hipSuccess || hipMemcpy(d_rm, remove, (size_t)n0, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return BSFM_ERROR; }
+    int n1 = 0, nvis1 = 0;
+    if (compact_points_device(n0, nvis0, pb->d_rowptr, pb->d_obs_pt, pb->d_obs_cam, pb->d_x, d_rm, &d_rp, &d_ci, &d_x, &d_remap, &n1, &nvis1, pb->stream) != 0) { cleanup(); return BSFM_ERROR; }
+    bool ok = dmalloc(&d_pts, 3 * (size_t)std::max(n1, 1)) == hipSuccess &&
+              gather_kept_device(n0, d_remap, 3 * (int)sizeof(double), pb->d_p + (size_t)m * cnp, d_pts, pb->stream) == 0 &&
+              hipStreamSynchronize(pb->stream) == hipSuccess;
+    if (ok && remap_out) ok = hipMemcpy(remap_out, d_remap, (size_t)n0 * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) { cleanup(); fprintf(stderr, "[bsfm] bsfm_problem_remove_points: allocation / copy failed\n"); return BSFM_ERROR; }
+    bsfm_problem_desc_t d = pb->desc0;
+    d.n = n1; d.m = m;
+    d.rowptr = d_rp; d.colidx = d_ci; d.projections = d_x; d.points = d_pts; d.cameras = cams.data();
+    d.use_point_constraints = 0; d.point_constraints = nullptr; d.arrays_on_device = 1;
+    d.nvis_global = 0; d.nvars_global = 0;
+    bsfm_problem* small = bsfm_problem_create(&d, &pb->opt);
+    if (!small) { cleanup(); return BSFM_ERROR; }
+    if (pb->d_pcon) {   // point constraints follow their points
+        bool okc = dmalloc(&small->d_pcon, (size_t)std::max(n1, 1)) == hipSuccess && dmalloc(&small->d_pval, 3 * (size_t)std::max(n1, 1)) == hipSuccess &&
+                   gather_kept_device(n0, d_remap, 1, pb->d_pcon, small->d_pcon, pb->stream) == 0 &&
+                   gather_kept_device(n0, d_remap, 3 * (int)sizeof(double), pb->d_pval, small->d_pval, pb->stream) == 0 &&
+                   hipStreamSynchronize(pb->stream) == hipSuccess;
+        if (!okc) { bsfm_problem_destroy(small); cleanup(); return BSFM_ERROR; }
+        small->P.pcon = small->d_pcon; small->P.pval = small->d_pval; small->P.pweight = pb->P.pweight;
+        small->desc0.use_point_constraints = 1; small->desc0.point_constraint_weight = pb->P.pweight;
+    }
+    small->allreduce = pb->allreduce; small->allreduce_ctx = pb->allreduce_ctx; small->comm = pb->comm;
+    std::swap(*pb, *small);
+    bsfm_problem_destroy(small);
+    cleanup();
+    return nrem;
+}
+
 int bsfm_problem_reset_params(bsfm_problem_t* pb, const bsfm_camera_params_t* cams, const double* pts)
 {
     std::vector<double> p;

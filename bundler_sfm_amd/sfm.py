@@ -223,6 +223,18 @@ class Problem:
                 self._keep = self._keep[:3] + (merged,) + self._keep[4:]
         return rc
 
+    def remove_points(self, remove):
+        """bsfm_problem_remove_points: drop the flagged points and all their observations on the device (the outlier loop of
+        RunSFM_SBA); returns (number removed, remap: new index of every old point or -1)."""
+        remove = np.ascontiguousarray(remove, np.uint8)
+        assert len(remove) == self.n
+        remap = np.zeros(self.n, np.int32)
+        rc = lib.bsfm_problem_remove_points(self.h, remove.ctypes.data_as(C.POINTER(C.c_ubyte)), _ip(remap))
+        if rc > 0:
+            self.n = int(lib.bsfm_problem_num_points(self.h))
+            self.nvis = int(lib.bsfm_problem_nvis(self.h))
+        return rc, remap
+
     def lm_begin(self):
         return lib.bsfm_lm_begin(self.h)
 

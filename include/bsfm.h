@@ -247,6 +247,13 @@ int bsfm_problem_schur_sizes(const bsfm_problem_t *pb, int *ntriples, int *nblk,
 int bsfm_problem_export_schur(bsfm_problem_t *pb, int *triples, int *tri_pt, int *blk_j, int *blk_k, int *blk_task0, int *tasks);
 /* dense vmask -> CRS exactly as run_sfm does it (host only); returns nvis, rowptr / colidx may be NULL. */
 int bsfm_crs_from_vmask(int n, int m, const char *vmask, int *rowptr, int *colidx);
+/* Shrinking a resident problem -- the other half of the RunSFM_SBA outlier loop (src/Bundle.cpp:784-913: the points flagged by
+ * the per-camera thresholds are dropped with all their views, then run_sfm runs again; bsfm_problem_outlier_stats delivers the
+ * flags): removes the points with remove[i] != 0 (host array, n entries) and every observation of them ON THE DEVICE; the
+ * remaining points keep their order, cameras, parameters and constraints stay in HBM, the index is rebuilt there.  remap_out
+ * (may be NULL, n entries) receives the new index of every old point or -1 (Bundler's remap table).  The next bsfm_lm_begin /
+ * bsfm_problem_solve starts from the resident parameters.  Returns the number of points removed, < 0 on error. */
+int bsfm_problem_remove_points(bsfm_problem_t *pb, const unsigned char *remove, int *remap_out);
 int bsfm_problem_cnp(const bsfm_problem_t *pb);
 int bsfm_problem_num_cameras(const bsfm_problem_t *pb);      /* grows with bsfm_problem_append */
 int bsfm_problem_num_points(const bsfm_problem_t *pb);

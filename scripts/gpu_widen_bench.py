@@ -31,6 +31,12 @@ print(f"outlier statistics (RunSFM_SBA, Bundle.cpp:659-913): {1e3 * t_out:.2f} m
       f"{m} camera rows + {n} point flags = {nvis / t_out / 1e9:.2f} G obs/s")
 print(f"ray-angle pruning (RemoveBadPointsAndCameras, Bundle.cpp:4190-4261): {1e3 * t_ray:.2f} ms for {n} points / "
       f"{n * deg * (deg - 1) // 2} ray pairs")
+# one pass of the outlier loop on the resident problem: drop 2 000 flagged points (and their observations) on the device
+flags = np.zeros(n, np.uint8); flags[np.random.default_rng(0).choice(n, 2000, replace=False)] = 1
+sync(); t = time.perf_counter(); got, _ = pb.remove_points(flags); sync(); t_rm = time.perf_counter() - t
+print(f"bsfm_problem_remove_points: {got} of {n} points (+ {nvis - pb.nvis} observations) dropped, index rebuilt on the device: "
+      f"{1e3 * t_rm:.1f} ms (the reference's caller rebuilds vmask / projections on the host and run_sfm re-derives every index: "
+      f"see problem_create in the bench line)")
 pb.close()
 
 # camera-only refinement (sba_mot_levmar): per-iteration time through the resident API
