@@ -251,8 +251,8 @@ int bsfm_crs_from_vmask(int n, int m, const char *vmask, int *rowptr, int *colid
  * the per-camera thresholds are dropped with all their views, then run_sfm runs again; bsfm_problem_outlier_stats delivers the
  * flags): removes the points with remove[i] != 0 (host array, n entries) and every observation of them ON THE DEVICE; the
  * remaining points keep their order, cameras, parameters and constraints stay in HBM, the index is rebuilt there.  remap_out
- * (may be NULL, n entries) receives the new index of every old point or -1 (Bundler's remap table).  The next bsfm_lm_begin /
- * bsfm_problem_solve starts from the resident parameters.  Returns the number of points removed, < 0 on error. */
+ * (may be NULL, n entries) receives the new index of every old point or -1 (Bundler's remap table).  The next bsfm_lm_begin
+ * starts from the resident parameters.  Returns the number of points removed, < 0 on error. */
 int bsfm_problem_remove_points(bsfm_problem_t *pb, const unsigned char *remove, int *remap_out);
 int bsfm_problem_cnp(const bsfm_problem_t *pb);
 int bsfm_problem_num_cameras(const bsfm_problem_t *pb);      /* grows with bsfm_problem_append */
