@@ -21,6 +21,7 @@
 //     test runs in FP64 exactly as the reference writes it.
 //   * KeyMatchFull: all pairs (j < i) of one database image i go into ONE launch (grid = sum of query blocks).
 #include <hip/hip_runtime.h>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -381,18 +382,23 @@ extern "C" int bsfm_match_set_stats(const bsfm_match_set_t* ms, double* kernel_m
 
 // rank / world_size: this call handles the database images i with i % world_size == rank (each with all its j < i), so
 // the pair list is split without any exchange (matcher = embarrassingly parallel, descriptors replicated).
-extern "C" int bsfm_match_set_run(bsfm_match_set_t* ms, double ratio, int window_radius, const char* out_path, int rank, int world_size)
+namespace {
+struct MatchTable { std::vector<int> pi, pj, m, ptr; bool overflow = false; };
+}
+// out_path -> the reference's text; tab -> the same pairs in memory (either may be absent)
+static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_radius, const char* out_path, MatchTable* tab, int rank, int world_size)
 {
     if (!ms || world_size < 1 || rank < 0 || rank >= world_size) return BSFM_ERROR;
-    FILE* f = fopen(out_path, "w");
-    if (!f) { printf("Could not open %s for writing.\n", out_path); return BSFM_ERROR; }   // KeyMatchFull.cpp:86-89
+    FILE* f = out_path ? fopen(out_path, "w") : nullptr;
+    if (out_path && !f) { printf("Could not open %s for writing.\n", out_path); return BSFM_ERROR; }   // KeyMatchFull.cpp:86-89
+    if (tab) tab->ptr.assign(1, 0);
     const int num_images = ms->num_images;
     const int* num_keys = ms->num_keys.data();
     const std::vector<size_t>& off = ms->off;
     const size_t tot = ms->tot;
     DevKeys& d = ms->d;
     ms->kernel_ms = 0.0; ms->distances = 0.0; ms->pairs = 0; ms->launches = 0;
-    if (tot == 0) { fclose(f); return 0; }
+    if (tot == 0) { if (f) fclose(f); return 0; }
     // Two-slot pipeline on one stream: while the GPU scans database image k, the host turns the nearest-neighbour table of
     // image k-1 into text (own integer formatter: the text, not the search, was the larger part of the wall time).
     struct Slot {
@@ -443,12 +449,20 @@ extern "C" int bsfm_match_set_run(bsfm_match_set_t* ms, double ratio, int window
             int cnt = 0;
             for (int q = 0; q < qn; ++q) cnt += row[q] >= 0;
             if (cnt >= 16) {   // KeyMatchFull.cpp:131-142: "j i\n", count, "idx_j idx_i" lines
-                put_int(s.js[p], ' '); put_int(s.image, '\n'); put_int(cnt, '\n');
-                for (int q = 0; q < qn; ++q) if (row[q] >= 0) { put_int(q, ' '); put_int(row[q], '\n'); }
+                if (f) {
+                    put_int(s.js[p], ' '); put_int(s.image, '\n'); put_int(cnt, '\n');
+                    for (int q = 0; q < qn; ++q) if (row[q] >= 0) { put_int(q, ' '); put_int(row[q], '\n'); }
+                }
+                if (tab) {
+                    tab->pi.push_back(s.js[p]); tab->pj.push_back(s.image);
+                    for (int q = 0; q < qn; ++q) if (row[q] >= 0) { tab->m.push_back(q); tab->m.push_back(row[q]); }
+                    if (tab->m.size() / 2 > (size_t)INT_MAX) tab->overflow = true;
+                    tab->ptr.push_back((int)(tab->m.size() / 2));
+                }
                 ++total_pairs_written;
             }
         }
-        if (!text.empty()) fwrite(text.data(), 1, text.size(), f);
+        if (f && !text.empty()) fwrite(text.data(), 1, text.size(), f);
         s.busy = false;
         return true;
     };
@@ -486,10 +500,38 @@ extern "C" int bsfm_match_set_run(bsfm_match_set_t* ms, double ratio, int window
     }
     ok = ok && drain(slots[turn & 1]) && drain(slots[(turn + 1) & 1]);
     release();
-    if (!ok) { fprintf(stderr, "[bsfm] matcher: HIP error in the pair pipeline\n"); fclose(f); return BSFM_ERROR; }
-    fclose(f);
+    if (!ok) { fprintf(stderr, "[bsfm] matcher: HIP error in the pair pipeline\n"); if (f) fclose(f); return BSFM_ERROR; }
+    if (f) fclose(f);
     return total_pairs_written;
 }
+
+extern "C" int bsfm_match_set_run(bsfm_match_set_t* ms, double ratio, int window_radius, const char* out_path, int rank, int world_size)
+{
+    if (!out_path) return BSFM_ERROR;
+    return match_set_run_impl(ms, ratio, window_radius, out_path, nullptr, rank, world_size);
+}
+
+// The same search with the result IN MEMORY (the match table feeds bsfm_fmatrix_ransac_batch / bsfm_compute_tracks
+// without the text round trip of matches.init.txt, src/BundleIO.cpp:112-166).  Arrays are malloc'ed here: bsfm_free them.
+extern "C" int bsfm_match_set_run_table(bsfm_match_set_t* ms, double ratio, int window_radius, int rank, int world_size,
+                                        int** pair_i, int** pair_j, int** match_ptr, int** matches)
+{
+    if (!pair_i || !pair_j || !match_ptr || !matches) return BSFM_ERROR;
+    MatchTable tab;
+    const int rc = match_set_run_impl(ms, ratio, window_radius, nullptr, &tab, rank, world_size);
+    if (rc < 0) return rc;
+    if (tab.overflow) { fprintf(stderr, "[bsfm] bsfm_match_set_run_table: more than 2^31-1 matches; shard the run (rank / world_size)\n"); return BSFM_ERROR; }
+    auto dup = [](const void* src, size_t bytes) { void* q = malloc(bytes ? bytes : 1); if (q && bytes) memcpy(q, src, bytes); return q; };
+    if (tab.ptr.empty()) tab.ptr.assign(1, 0);
+    *pair_i = static_cast<int*>(dup(tab.pi.data(), tab.pi.size() * sizeof(int)));
+    *pair_j = static_cast<int*>(dup(tab.pj.data(), tab.pj.size() * sizeof(int)));
+    *match_ptr = static_cast<int*>(dup(tab.ptr.data(), tab.ptr.size() * sizeof(int)));
+    *matches = static_cast<int*>(dup(tab.m.data(), tab.m.size() * sizeof(int)));
+    if (!*pair_i || !*pair_j || !*match_ptr || !*matches) { free(*pair_i); free(*pair_j); free(*match_ptr); free(*matches); return BSFM_ERROR; }
+    return rc;
+}
+
+extern "C" void bsfm_free(void* p) { free(p); }
 
 extern "C" int bsfm_key_match_full_sharded(int num_images, const int* num_keys, const unsigned char* const* keys,
                                            double ratio, int window_radius, const char* out_path, int rank, int world_size)

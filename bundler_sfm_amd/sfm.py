@@ -137,6 +137,31 @@ def estimate_fmatrix_batch(match_ptr, k1_xy, k2_xy, num_trials, threshold, rng):
     return F, cnt, inl[:int(match_ptr[-1])], info
 
 
+def match_table(keys, ratio=0.6, window_radius=-1):
+    """bsfm_match_set_create + bsfm_match_set_run_table: the KeyMatchFull search with the match table in memory.
+    keys: list of (n_i, 128) uint8 arrays.  Returns (pair_i, pair_j, match_ptr, matches[n, 2])."""
+    U = C.POINTER(C.c_ubyte)
+    keys = [np.ascontiguousarray(k, np.uint8) for k in keys]
+    arr = (U * len(keys))(*[k.ctypes.data_as(U) for k in keys])
+    nks = np.array([len(k) for k in keys], np.int32)
+    ms = lib.bsfm_match_set_create(len(keys), _ip(nks), arr)
+    if not ms:
+        raise RuntimeError("bsfm_match_set_create failed")
+    IP = C.POINTER(C.c_int)
+    pi, pj, ptr, mt = IP(), IP(), IP(), IP()
+    rc = lib.bsfm_match_set_run_table(ms, float(ratio), int(window_radius), 0, 1, C.byref(pi), C.byref(pj), C.byref(ptr), C.byref(mt))
+    lib.bsfm_match_set_destroy(ms)
+    if rc < 0:
+        raise RuntimeError("bsfm_match_set_run_table failed")
+    out_ptr = np.ctypeslib.as_array(ptr, (rc + 1,)).copy()
+    nm = int(out_ptr[-1])
+    res = (np.ctypeslib.as_array(pi, (max(rc, 1),))[:rc].copy(), np.ctypeslib.as_array(pj, (max(rc, 1),))[:rc].copy(), out_ptr,
+           np.ctypeslib.as_array(mt, (max(2 * nm, 1),))[:2 * nm].copy().reshape(nm, 2))
+    for q in (pi, pj, ptr, mt):
+        lib.bsfm_free(q)
+    return res
+
+
 def compute_tracks(num_keys, pair_i, pair_j, match_ptr, matches, new_image_start=0):
     """bsfm_compute_tracks (BundlerApp::ComputeTracks).  Returns (track_ptr, views[nviews, 2] = (image, key))."""
     nk = np.ascontiguousarray(num_keys, np.int32); pi = np.ascontiguousarray(pair_i, np.int32); pj = np.ascontiguousarray(pair_j, np.int32)

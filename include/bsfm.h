@@ -367,6 +367,14 @@ typedef struct bsfm_match_set bsfm_match_set_t;
 bsfm_match_set_t *bsfm_match_set_create(int num_images, const int *num_keys, const unsigned char *const *keys);
 int bsfm_match_set_run(bsfm_match_set_t *ms, double ratio, int window_radius, const char *out_path, int rank, int world_size);
 int bsfm_match_set_stats(const bsfm_match_set_t *ms, double *kernel_ms, double *distances, long long *pairs, int *launches);
+/* The same search with the match table in memory instead of text: pair p = images pair_i[p] < pair_j[p] in the
+ * order of the text file, its matches matches[2q] (key of pair_i) / matches[2q+1] (key of pair_j) for q in match_ptr[p] ..
+ * match_ptr[p+1]-1 -- the layout bsfm_compute_tracks and BaseApp::LoadMatchTable (src/BundleIO.cpp:112-166) use.  Only pairs
+ * with >= 16 matches appear (KeyMatchFull.cpp:131).  The four arrays are allocated by the library: release with bsfm_free.
+ * Returns the number of pairs. */
+int bsfm_match_set_run_table(bsfm_match_set_t *ms, double ratio, int window_radius, int rank, int world_size,
+                             int **pair_i, int **pair_j, int **match_ptr, int **matches);
+void bsfm_free(void *p);
 void bsfm_match_set_destroy(bsfm_match_set_t *ms);
 
 /* ---- utilities --------------------------------------------------------------------------------------- */

@@ -295,3 +295,34 @@ def test_gpu_best_and_second_best_in_different_segments(gpu_bsfm):
     cnt, got = gpu_match(B, k1, k2)
     ref = O.port_match(k1, k2)
     assert cnt == len(ref) and np.array_equal(got, ref)
+
+
+@pytest.mark.gpu
+def test_match_table_in_memory_equals_the_text_file_and_feeds_the_track_builder(gpu_bsfm, tmp_path):
+    """SURVEY 8(f).4: bsfm_match_set_run_table hands over what matches.init.txt would hold (BaseApp::LoadMatchTable's layout,
+    src/BundleIO.cpp:112-166) without the text round trip, and bsfm_compute_tracks takes it as is."""
+    import oracle_util as O2
+    B = gpu_bsfm
+    sizes = [300, 0, 257, 400, 64, 350, 290]
+    keys, prev = [], None
+    for i, nk in enumerate(sizes):
+        k = synth_keys(B, nk, 2000 + i, dup=prev) if nk else np.zeros((0, 128), np.uint8)
+        keys.append(k)
+        if nk:
+            prev = k
+    arr = (U * len(sizes))(*[k.ctypes.data_as(U) for k in keys])
+    nks = np.array(sizes, np.int32)
+    out = tmp_path / "matches.init.txt"
+    rc = B.lib.bsfm_key_match_full(len(sizes), nks.ctypes.data_as(C.POINTER(C.c_int)), arr, 0.6, -1, str(out).encode())
+    pi_t, pj_t, ptr_t, mt_t = O2.read_match_table(str(out))
+    pi, pj, ptr, mt = B.match_table(keys, 0.6)
+    assert rc == len(pi) > 0
+    assert np.array_equal(pi, pi_t) and np.array_equal(pj, pj_t) and np.array_equal(ptr, ptr_t) and np.array_equal(mt, mt_t)
+    assert (pi < pj).all()
+    # straight into the track builder (after the reference's PruneDoubleMatches, src/MatchTracks.cpp:394-440)
+    ptr_p, mt_p = O2.prune_double_matches(ptr, mt)
+    tp, vw = B.compute_tracks(nks, pi, pj, ptr_p, mt_p)
+    assert len(tp) - 1 > 0 and tp[-1] == len(vw)
+    if O2.have_tracksref():
+        rtp, rvw = O2.ref_compute_tracks(nks, pi, pj, ptr_p, mt_p)
+        assert np.array_equal(tp, rtp) and np.array_equal(vw, rvw)
