@@ -401,8 +401,21 @@ inline int potrf_solve_engine(PotrfWorkspace& w, double* S, int ld, int n, const
 }
 
 // Round 2 default: the panel engine; BSFM_CHOL=streams (or the rocSOLVER cross-check backend) keeps round 1's schedule.
+}  // namespace bsfm
+#include "potrf_blocked.hip.h"
+namespace bsfm {
+
 inline int potrf_solve_auto(PotrfWorkspace& w, double* S, int ld, int n, const double* E, double* x_out, int* d_info, hipStream_t st)
 {
+    if (n > 0 && w.backend == 0) {
+        const char* e = getenv("BSFM_CHOL");
+        if (e && !strcmp(e, "blocked")) {          // two-level blocking (potrf_blocked.hip.h), opt-in
+            BlockedState& b = blocked_state(w);
+            const int nblk = (n + POTRF_NB - 1) / POTRF_NB;
+            if (!b.ready && blocked_init(w, b) != 0) return -1;
+            if (nblk >= b.min_tiles && nblk <= POTRF_MAX_TILES) return potrf_solve_blocked(w, b, S, ld, n, E, x_out, d_info, st);
+        }
+    }
     if (n > 0 && w.backend == 0 && w.use_engine && (n + POTRF_NB - 1) / POTRF_NB <= POTRF_MAX_TILES)
         return potrf_solve_engine(w, S, ld, n, E, x_out, d_info, st);
     return potrf_solve(w, S, ld, n, E, x_out, d_info, st);

@@ -135,6 +135,7 @@ void free_all(bsfm_problem* pb)
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (pb->h_scal) (void)hipHostFree(pb->h_scal);
     if (pb->h_flags) (void)hipHostFree(pb->h_flags);
+    blocked_release(pb->potrf);
     potrf_free(pb->potrf);
     comp_free(pb->comps);
     if (pb->ev_ok) for (int i = 0; i < PH_COUNT; ++i) { (void)hipEventDestroy(pb->ev[i][0]); (void)hipEventDestroy(pb->ev[i][1]); }
@@ -1332,6 +1333,7 @@ int bsfm_dense_chol_solve(int n, const double* A, const double* b, double* x, in
     } while (0);
     if (dS) (void)hipFree(dS); if (dE) (void)hipFree(dE); if (dx) (void)hipFree(dx); if (dinfo) (void)hipFree(dinfo);
     if (st) (void)hipStreamDestroy(st);
+    blocked_release(ws);
     potrf_free(ws);
     return rc;
 }
