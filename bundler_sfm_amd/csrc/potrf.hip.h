@@ -75,6 +75,9 @@ constexpr int POTRF_MAX_TILES = 240;   // k_bwd_persistent needs one resident wo
 #ifndef BSFM_SYRK_WPS
 #define BSFM_SYRK_WPS 4      // waves per SIMD the bulk tile kernel is compiled for (4 = two workgroups per CU)
 #endif
+#ifndef BSFM_GEMM_MFMA16
+#define BSFM_GEMM_MFMA16 1
+#endif
 #ifndef BSFM_GEMM_KC
 #define BSFM_GEMM_KC 16
 #endif
@@ -166,10 +169,36 @@ __device__ __forceinline__ void gemm_nt_128(const double* __restrict__ A, int ld
         }
         __syncthreads();
         if (kc + GEMM_KC < K) { BSFM_GLOAD(kc + GEMM_KC) }
+#if BSFM_GEMM_MFMA16
+        // v_mfma_f64_16x16x4_f64 with the accumulators in VGPRs: 77.9 TFLOP/s on gfx950 (scripts/ubench_mfma16_agpr.hip; round 1 had
+        // measured 36 and dismissed the instruction -- that loop's accumulators had been allocated to AGPRs, which halves its rate).
+        // A[i][k] at lane i + 16 k, B[k][j] at lane j + 16 k, D[i][j]: register r of lane l holds row 4 r + (l >> 4), column l & 15
+        // (scripts/probe_mfma16.hip) -- for a 16-row block that is exactly the acc[t = 4 bi + r][u] layout of the 4x4x4 form below, so the
+        // C loads / stores of every caller stay as they are.  Per k-step of 4: 2 + 4 fragment reads for 8 matrix instructions (the 4x4x4 form:
+        // 8 + 4 reads for 32).
 #pragma unroll
         for (int kk = 0; kk < GEMM_KC; kk += 4) {
-            // v_mfma_f64_4x4x4_4b: 4 independent 4x4x4 blocks g = (lane>>2)&3 per instruction, the full-rate FP64
-            // matrix op on gfx950 (measured 72.7 TFLOP/s vs 36 for v_mfma_f64_16x16x4).  Lane l = 16k + 4g + r:
+            typedef double v4d_ __attribute__((ext_vector_type(4)));
+            double b[4], a2[2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                b[u] = Bs[(wc + 16 * u + (lane & 15)) * GEMM_LDS_STRIDE + kk + (lane >> 4)];
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+                a2[bi] = As[(wr + 16 * bi + (lane & 15)) * GEMM_LDS_STRIDE + kk + (lane >> 4)];
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v4d_ c = { acc[4 * bi][u], acc[4 * bi + 1][u], acc[4 * bi + 2][u], acc[4 * bi + 3][u] };
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[bi], b[u], c, 0, 0, 0);
+                    acc[4 * bi][u] = c[0]; acc[4 * bi + 1][u] = c[1]; acc[4 * bi + 2][u] = c[2]; acc[4 * bi + 3][u] = c[3];
+                }
+        }
+#else
+#pragma unroll
+        for (int kk = 0; kk < GEMM_KC; kk += 4) {
+            // v_mfma_f64_4x4x4_4b: 4 independent 4x4x4 blocks g = (lane>>2)&3 per instruction.  Lane l = 16k + 4g + r:
             //   A[g][i=r][k], B[g][k][j=r]  ->  D[g][i][j] at lane 16i + 4g + j   (probed: scripts/probe_mfma4.hip).
             // B fragment: 16 output columns (4 per block); A fragment: 4 output rows replicated over the blocks.
             double b[4];
@@ -184,6 +213,7 @@ __device__ __forceinline__ void gemm_nt_128(const double* __restrict__ A, int ld
                     acc[t][u] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b[u], acc[t][u], 0, 0, 0);
             }
         }
+#endif
     }
 #undef BSFM_GLOAD
 }

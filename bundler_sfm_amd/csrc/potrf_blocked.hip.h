@@ -9,8 +9,8 @@
 //   N_next(k)     panel k -> the columns [max(k+2, be), be + D) of the NEXT outer panel: the lookahead that lets the chain cross an
 //                 outer boundary without waiting for a wide update                                              (stream s3, k = 128)
 //   F(b)          the D finished panels of outer panel b -> every column >= be + D, ONCE, as rank-128 D updates  (stream s3):
-//                 column strips of 8 tiles; the strip's diagonal block by k_far_diag (own kernel, K = 128 D straight from S), the
-//                 rectangle below it by rocblas_dgemm (plain library GEMM; dlopen'ed like the rocSOLVER cross-check backend).
+//                 k_far_tri (own kernel, one read + one write of C per 128 D steps), or with BSFM_CHOL_FAR=rocblas one rocblas_dgemm per
+//                 column strip of 8 tiles (plain library GEMM; dlopen'ed like the rocSOLVER cross-check backend).
 // Every tile still receives every earlier panel exactly once; the order in which a tile receives them differs from potrf_solve's, so
 // the two agree to rounding, and a run is bit-reproducible (stream order + events fix the order per tile).
 // Tile (k+2, k+2) is skipped by the near launches of step k as in potrf_solve (the chain's own tile kernel applies panel k to it).
@@ -23,6 +23,8 @@
 // of the wide stream's mask (BSFM_FAR_RESERVE_CUS) made it worse (25 ms), as did GPU_MAX_HW_QUEUES=8 (27 ms; with 4 queues the wide stream
 // shares the side stream's queue).  The structure needs wide-update kernels that co-reside with the chain's -- an own 256-wide
 // macro-tile kernel with a small LDS footprint -- before it can pay; kept opt-in as the correct starting point.
+// With k_far_tri (same footprint as k_syrk_update, 58 TFLOP/s on the rank-512 update) it is 14.7-17 ms: the workgroups of a launch start
+// and retire together, so no slot frees up for the 200-250 us a rank-512 workgroup lives, and the chain's kernels wait that long.
 #pragma once
 #include "potrf.hip.h"
 
@@ -100,10 +102,55 @@ __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_far_diag(double* __restr
     }
 }
 
+// panels [bs, be) -> every tile (i, j), i >= j >= f0: ONE read and ONE write of the C tile for (be - bs) x 128 accumulation steps.
+// Operands: the compact panel copies of the ring (slot q & 7, tile a = row q + 1 + a), one 128-step product per panel with the
+// accumulators kept -- with the 16x16x4 matrix instruction this loop holds 62 TFLOP/s (scripts/ubench_syrk.hip, "K x8"), and its
+// workgroups are k_syrk_update's (36 KB of LDS, two per CU), so the chain's kernels still find room next to them.
+__global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_far_tri(double* __restrict__ S, int ld, int bs, int be, int f0,
+                                                                const double* __restrict__ ring, size_t pstride)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int t = blockIdx.x;
+    int a = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= t) ++a;
+    while (a * (a + 1) / 2 > t) --a;
+    const int b = t - a * (a + 1) / 2;
+    const int i = f0 + a, j = f0 + b;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
+    double* Sij = S + ((size_t)i * POTRF_NB) * ld + (size_t)j * POTRF_NB;
+    double acc[8][4];
+    {
+        const double* cp = Sij + (size_t)(wr + (lane >> 4)) * ld + wc + (lane & 15);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[q][u] = cp[16 * u];
+            cp += 4 * (size_t)ld;
+        }
+    }
+    constexpr size_t TL = (size_t)POTRF_NB * POTRF_NB;
+#pragma unroll 1
+    for (int q = bs; q < be; ++q) {
+        const double* pq = ring + (size_t)(q & 7) * pstride;
+        gemm_nt_128<true>(pq + (size_t)(i - q - 1) * TL, POTRF_NB, pq + (size_t)(j - q - 1) * TL, POTRF_NB, POTRF_NB, lds, acc);
+    }
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    double* Sl = Sij + (size_t)(((tid2 >> 7) << 5) + ((tid2 & 63) >> 4)) * ld + (((tid2 >> 6) & 1) << 6) + (tid2 & 15);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Sl[16 * u] = acc[q][u];
+        Sl += 4 * (size_t)ld;
+    }
+}
+
 struct BlockedState {
     int enabled = 0;            // BSFM_CHOL=blocked
     int D = 4;                  // tile columns per outer panel (BSFM_CHOL_D)
     int strip = 8;              // tile columns per far strip (BSFM_CHOL_STRIP)
+    int far_rocblas = 0;        // BSFM_CHOL_FAR=rocblas: wide updates as rocblas_dgemm strips instead of k_far_tri
     int min_tiles = 24;         // below this many tile columns the plain schedule runs
     hipStream_t s3 = nullptr; bool s3_masked = false;
     double* panel8 = nullptr;   // ring of 8 compact panel copies (the far stream may lag the chain by more than one outer panel)
@@ -133,6 +180,7 @@ inline int blocked_init(PotrfWorkspace& w, BlockedState& b)
     if (b.ready) return 0;
     if (const char* e = getenv("BSFM_CHOL_D")) b.D = std::max(2, std::min(8, atoi(e)));
     if (const char* e = getenv("BSFM_CHOL_STRIP")) b.strip = std::max(2, atoi(e));
+    if (const char* e = getenv("BSFM_CHOL_FAR")) b.far_rocblas = !strcmp(e, "rocblas");
     if (const char* e = getenv("BSFM_CHOL_MIN_TILES")) b.min_tiles = std::max(2 * b.D + 1, atoi(e));
     b.rb_lib = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
     if (!b.rb_lib) { fprintf(stderr, "[bsfm] BSFM_CHOL=blocked: librocblas.so unavailable (%s)\n", dlerror()); return -1; }
@@ -143,7 +191,7 @@ inline int blocked_init(PotrfWorkspace& w, BlockedState& b)
     if (!create || !b.rb_set_stream || !b.rb_dgemm || create(&b.rb_handle) != 0) { fprintf(stderr, "[bsfm] BSFM_CHOL=blocked: rocBLAS symbols missing\n"); return -1; }
     {   // The wide updates are long-running library kernels that fill every CU they may use: keep some CUs out of their reach so
         // that the chain / side kernels (16, 10, 1 workgroups; the diagonal tile needs a whole CU's LDS) never queue behind them
-        int reserve = 32;
+        int reserve = 0;
         if (const char* e = getenv("BSFM_FAR_RESERVE_CUS")) reserve = atoi(e);
         int dev = 0; (void)hipGetDevice(&dev);
         hipDeviceProp_t prop;
@@ -163,6 +211,7 @@ inline int blocked_init(PotrfWorkspace& w, BlockedState& b)
     for (auto& e : b.ev3) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
     if (hipEventCreate(&b.f0) != hipSuccess || hipEventCreate(&b.f1) != hipSuccess) return -1;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_cols), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 128 * GEMM_LDS_STRIDE * sizeof(double))) != hipSuccess) return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_far_tri), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 128 * GEMM_LDS_STRIDE * sizeof(double))) != hipSuccess) return -1;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_far_diag), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 128 * GEMM_LDS_STRIDE * sizeof(double))) != hipSuccess) return -1;
     b.ready = true;
     return 0;
@@ -267,6 +316,11 @@ inline int potrf_solve_blocked(PotrfWorkspace& w, BlockedState& B, double* S, in
             (void)hipStreamWaitEvent(B.s3, w.evP[k], 0);             // the last panel of the outer panel (the earlier ones precede it on sd)
             if (!timed_far) (void)hipEventRecord(B.f0, B.s3);
             double flops = 0.0;
+            if (!B.far_rocblas) {
+                const int Tf = nblk - f0;
+                hipLaunchKernelGGL(k_far_tri, dim3(Tf * (Tf + 1) / 2), dim3(512), lds_bytes, B.s3, S, ld, bs, be, f0, (const double*)B.panel8, pstride);
+                flops += tile_flops * (be - bs) * (Tf * (Tf + 1) / 2);
+            } else
             for (int c0 = f0; c0 < nblk; c0 += B.strip) {
                 // One GEMM per column strip, from the strip's own first row down: the part above the diagonal inside the strip's
                 // diagonal block is computed too (5 % extra flops at 8-tile strips) and lands in tiles / half tiles nobody reads --
