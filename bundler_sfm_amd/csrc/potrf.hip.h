@@ -99,6 +99,11 @@ struct PotrfWorkspace {
     hipStream_t sb = nullptr;    // split chain: the stream of the explicit inverses
     hipEvent_t* evB = nullptr;   // split chain: inverse of tile k done
     hipEvent_t* evA = nullptr;   // split chain: diagonal tile k factored (its explicit inverse follows on the side stream)
+    int pair_min_rows = 0;       // BSFM_SYRK_PAIR=rows: paired (rank-256) bulk launches while at least this many tile rows remain.  Off by default:
+                                 // third attempt at rank-256 (this one with the 16x16x4 loop, 61 vs 44 TFLOP/s for the kernel alone), third loss --
+                                 // 8.67 / 8.83 / 8.99 ms per solve with rows = 50 / 40 / 30 against 8.46: in the factorisation the paired launches
+                                 // reach 43 TFLOP/s, not 61 (two different panels per tile, and their two-round workgroups hold the slots the
+                                 // chain's kernels wait for twice as long)
     int chain_split = 0;         // BSFM_CHAIN=split: factor-only diagonal kernel, first panel tile by block substitution (k_chain_trsm32), explicit
                                  // inverse on its own stream.  Opt-in: the chain kernels get shorter (52 + 15.5 -> 37 + 12 us) but the solve gets
                                  // SLOWER (10.5-11.0 vs 8.55 ms at config 3): see the note at k_chain_trsm32
@@ -334,8 +339,10 @@ __global__ __launch_bounds__(256, 1) void k_trsm_panel64(double* __restrict__ S,
 }
 
 // First trailing column, two halves per tile: S_{k+1+a, k+1} -= P_a P_0^T.
+// cofs = 1 (paired bulk launches, see potrf_solve): the SECOND trailing column, S_{k+1+a, k+2} -= P_a P_1^T for a >= 2 (launched with
+// a0 = 2 and without the forward-substitution workgroups).
 __global__ __launch_bounds__(256, 1) void k_syrk_col64(double* __restrict__ S, int ld, int k, const double* __restrict__ panel,
-        int a0, int ngemm, double* __restrict__ E, const double* __restrict__ y)
+        int a0, int ngemm, double* __restrict__ E, const double* __restrict__ y, int cofs)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if ((int)blockIdx.x >= ngemm) {
@@ -360,14 +367,15 @@ __global__ __launch_bounds__(256, 1) void k_syrk_col64(double* __restrict__ S, i
         for (int u = 0; u < 4; ++u) acc[t][u] = 0.0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 64;
-    double* Sij = S + ((size_t)(k + 1 + a) * POTRF_NB + 64 * half) * ld + (size_t)(k + 1) * POTRF_NB;
+    double* Sij = S + ((size_t)(k + 1 + a) * POTRF_NB + 64 * half) * ld + (size_t)(k + 1 + cofs) * POTRF_NB;
     double cin[8][4];                     // the C tile is fetched up front as well
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             cin[t][u] = Sij[(size_t)(wr + 4 * t + (lane >> 4)) * ld + wc + 16 * u + (lane & 15)];
-    gemm_nt_64(panel + (size_t)a * POTRF_NB * POTRF_NB + (size_t)(64 * half) * POTRF_NB, POTRF_NB, panel, POTRF_NB, lds, acc);
+    gemm_nt_64(panel + (size_t)a * POTRF_NB * POTRF_NB + (size_t)(64 * half) * POTRF_NB, POTRF_NB,
+               panel + (size_t)cofs * POTRF_NB * POTRF_NB, POTRF_NB, lds, acc);
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -581,8 +589,11 @@ __global__ __launch_bounds__(256, 1) void k_chain_trsm32(double* __restrict__ S,
 // for C keep the use-once stream from evicting the panel out of L2 (r01 counters: the surplus of HBM traffic over the algorithmic
 // C bytes was panel tiles missing L2).  Measured at config 3: 38.7 vs 39.2 TFLOP/s for the kernel, 8.44 vs 8.52 ms for the solve --
 // neutral, so the plain variant stays the default; BSFM_SYRK_NT=1 selects this one (same binary).
+// pprev != nullptr: a PAIRED launch -- panel k-1 (compact copy pprev, tile a+1 = the same tile row) is applied in the same pass over
+// C: one read and one write of the tile for 256 accumulation steps (with the 16x16x4 loop: 61 instead of 44 TFLOP/s for the kernel alone).
 template <bool NT>
-__global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __restrict__ S, int ld, int k, const double* __restrict__ panel, int part)
+__global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __restrict__ S, int ld, int k, const double* __restrict__ panel, int part,
+                                                                    const double* __restrict__ pprev)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     int a, b;
@@ -616,6 +627,9 @@ __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __re
     }
     gemm_nt_128<true>(panel + (size_t)a * POTRF_NB * POTRF_NB, POTRF_NB, panel + (size_t)b * POTRF_NB * POTRF_NB, POTRF_NB,
                       POTRF_NB, lds, acc);
+    if (pprev)
+        gemm_nt_128<true>(pprev + (size_t)(a + 1) * POTRF_NB * POTRF_NB, POTRF_NB, pprev + (size_t)(b + 1) * POTRF_NB * POTRF_NB, POTRF_NB,
+                          POTRF_NB, lds, acc);
     // the store address is recomputed from an opaque copy of the thread id: keeping the load addresses alive across
     // the K loop would push the kernel over its 128-VGPR budget (and the staging registers into scratch)
     int tid2 = threadIdx.x;
@@ -629,7 +643,8 @@ __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __re
     }
 }
 
-// (Tried twice and dropped: rank-256 bulk launches that apply panels k and k+1 in one pass over C.  The kernel alone runs at
+// (Tried twice and dropped -- and a third time in round 2, kept behind BSFM_SYRK_PAIR, see PotrfWorkspace::pair_min_rows: rank-256
+// bulk launches that apply panels k and k+1 in one pass over C.  The kernel alone runs at
 // 46.6 instead of 42.9 TFLOP/s (C traffic per flop halves), but the factorisation got slower both times -- with the
 // two-stream schedule (10.9 vs 10.1 ms) and again on the three-stream schedule with the skipped launch's work moved to
 // the side kernel (K = 256) and the chain tile kernel (three panels) and the launch split so that the side stream only
@@ -1086,6 +1101,7 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
                             (int)(DG_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag_b), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(DG_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    if (const char* e = getenv("BSFM_SYRK_PAIR")) w.pair_min_rows = atoi(e);
     if (const char* e = getenv("BSFM_CHAIN")) w.chain_split = strcmp(e, "split") == 0;
     if (w.chain_split && !(w.sb = stream_pool().acquire())) return -1;     // (only then: a fourth stream changes the queue mapping of the others)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_tile32<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(T32_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
@@ -1153,6 +1169,9 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
     (void)hipStreamWaitEvent(w.s2, w.evU[w.nblk], 0);
     (void)hipStreamWaitEvent(w.sd, w.evU[w.nblk], 0);
     const bool split = w.chain_split != 0 && nblk > 1;
+    // steps 0 .. Kp-1 pair their bulk launches (Kp even): as long as at least pair_min_rows tile rows remain, where the bulk stream bounds
+    // the factorisation; the chain-bound tail keeps one launch per step (a paired launch lasts two rounds)
+    const int Kp = (w.pair_min_rows > 0 && !split && nblk - w.pair_min_rows > 1) ? ((nblk - w.pair_min_rows) & ~1) : 0;
     if (split) {
         hipLaunchKernelGGL(k_potrf_diag_a, dim3(1), dim3(512), diag_lds, st, S, ld, 0, n, w.dinv, d_info, w.dbg);
         (void)hipEventRecord(w.evA[0], st);
@@ -1182,16 +1201,24 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         (void)hipEventRecord(w.evP[k], w.sd);
         if (k > 0) (void)hipStreamWaitEvent(w.sd, w.evU[k - 1], 0);   // column k+1 was last written by the bulk of step k-1
         if (split) (void)hipStreamWaitEvent(w.sd, w.evT[k], 0);       // slot 0 of the compact panel (B operand of the column update)
-        hipLaunchKernelGGL(k_syrk_col64, dim3(2 * (T - 1) + T), dim3(256), lds64, w.sd, S, ld, k, pk, 1, 2 * (T - 1), w.etmp, w.y);
+        hipLaunchKernelGGL(k_syrk_col64, dim3(2 * (T - 1) + T), dim3(256), lds64, w.sd, S, ld, k, pk, 1, 2 * (T - 1), w.etmp, w.y, 0);
         (void)hipEventRecord(w.evC[k], w.sd);
+        // PAIRED bulk launches (steps k < Kp): the bulk launch of an even step is skipped and the odd step's launch applies both
+        // panels in one pass over C (k_syrk_update with pprev).  What the skipped launch owed before the pair's second step goes
+        // elsewhere: column k+2 (rows >= k+3) to the side stream right here, tile (k+3, k+3) -- tile 0 of the paired launch -- to the
+        // chain's tile kernel of step k+2 (three panels: prev2).  Everything else of panel k is not needed before step k+2.
+        const bool paired = k < Kp, even = (k & 1) == 0;
+        if (paired && even && T >= 3)
+            hipLaunchKernelGGL(k_syrk_col64, dim3(2 * (T - 2)), dim3(256), lds64, w.sd, S, ld, k, pk, 2, 2 * (T - 2), w.etmp, w.y, 1);
         // bulk
         (void)hipStreamWaitEvent(w.s2, w.evP[k], 0);
-        if (T > 2) {
+        if (T > 2 && !(paired && even)) {
+            const double* pprev = paired ? (const double*)panel_of(k - 1) : (const double*)nullptr;
             const bool timed = w.syrk_events > 0 && (k % w.syrk_events) == 0;
             if (timed) (void)hipEventRecord(w.sy0[w.sy_used], w.s2);
-            if (w.syrk_nt) hipLaunchKernelGGL(k_syrk_update<true>, dim3(T * (T - 1) / 2 - 1), dim3(512), lds_bytes, w.s2, S, ld, k, pk, 2);
-            else hipLaunchKernelGGL(k_syrk_update<false>, dim3(T * (T - 1) / 2 - 1), dim3(512), lds_bytes, w.s2, S, ld, k, pk, 2);
-            if (timed) { (void)hipEventRecord(w.sy1[w.sy_used], w.s2); w.sy_flops[w.sy_used++] = tile_flops * (T * (T - 1) / 2 - 1); }
+            if (w.syrk_nt) hipLaunchKernelGGL(k_syrk_update<true>, dim3(T * (T - 1) / 2 - 1), dim3(512), lds_bytes, w.s2, S, ld, k, pk, 2, pprev);
+            else hipLaunchKernelGGL(k_syrk_update<false>, dim3(T * (T - 1) / 2 - 1), dim3(512), lds_bytes, w.s2, S, ld, k, pk, 2, pprev);
+            if (timed) { (void)hipEventRecord(w.sy1[w.sy_used], w.s2); w.sy_flops[w.sy_used++] = tile_flops * (T * (T - 1) / 2 - 1) * (paired ? 2.0 : 1.0); }
         }
         (void)hipEventRecord(w.evU[k], w.s2);
         // chain: next diagonal tile
@@ -1199,8 +1226,10 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         // is already ordered before this point: the chain waited for evC[k-1] above, and the side stream recorded it after
         // having waited for evU[k-2] itself.  (Tried: hipStreamWriteValue32 / hipStreamWaitValue32 on signal memory instead
         // of the chain <-> side events: no faster.)
+        // (k even, 2 <= k <= Kp: tile (k+1, k+1) was tile 0 of the paired launch of steps k-2, k-1 -> it takes panel k-2 here as well)
         hipLaunchKernelGGL(k_chain_tile32<1>, dim3(10), dim3(256), lds32, st, S, ld, k, Lk, pk,
-                           k > 0 ? (const double*)panel_of(k - 1) : (const double*)nullptr, (const double*)nullptr);
+                           k > 0 ? (const double*)panel_of(k - 1) : (const double*)nullptr,
+                           (k >= 2 && (k & 1) == 0 && k <= Kp) ? (const double*)panel_of(k - 2) : (const double*)nullptr);
         if (split && k + 2 < nblk) {
             hipLaunchKernelGGL(k_potrf_diag_a, dim3(1), dim3(512), diag_lds, st, S, ld, k + 1, n, w.dinv, d_info, w.dbg);
             (void)hipEventRecord(w.evA[k + 1], st);

@@ -285,7 +285,7 @@ inline int potrf_solve_blocked(PotrfWorkspace& w, BlockedState& B, double* S, in
         (void)hipEventRecord(w.evP[k], w.sd);
         if (k > 0) (void)hipStreamWaitEvent(w.sd, w.evU[k - 1], 0);   // column k+1: the near launch of step k-1 (s2) ...
         wait_s3_cols(w.sd, k + 1, k + 2);                             // ... and whatever the far stream did to it
-        hipLaunchKernelGGL(k_syrk_col64, dim3(2 * (T - 1) + T), dim3(256), lds64, w.sd, S, ld, k, pk, 1, 2 * (T - 1), w.etmp, w.y);
+        hipLaunchKernelGGL(k_syrk_col64, dim3(2 * (T - 1) + T), dim3(256), lds64, w.sd, S, ld, k, pk, 1, 2 * (T - 1), w.etmp, w.y, 0);
         (void)hipEventRecord(w.evC[k], w.sd);
         // near, current outer panel: columns [k+2, be)
         (void)hipStreamWaitEvent(w.s2, w.evP[k], 0);

@@ -370,8 +370,8 @@ inline int potrf_solve_engine(PotrfWorkspace& w, double* S, int ld, int n, const
         if (T >= 2) {
             const int tiles = T * (T - 1) / 2;               // columns k+2 .. : every tile (i, j), i >= j, diagonal tiles included
             (void)hipEventRecord(w.sy0[w.sy_used], w.s2);
-            if (w.syrk_nt) hipLaunchKernelGGL(k_syrk_update<true>, dim3(tiles), dim3(512), lds_bytes, w.s2, S, ld, k, w.panel + (size_t)(k & 3) * pstride, 3);
-            else hipLaunchKernelGGL(k_syrk_update<false>, dim3(tiles), dim3(512), lds_bytes, w.s2, S, ld, k, w.panel + (size_t)(k & 3) * pstride, 3);
+            if (w.syrk_nt) hipLaunchKernelGGL(k_syrk_update<true>, dim3(tiles), dim3(512), lds_bytes, w.s2, S, ld, k, w.panel + (size_t)(k & 3) * pstride, 3, (const double*)nullptr);
+            else hipLaunchKernelGGL(k_syrk_update<false>, dim3(tiles), dim3(512), lds_bytes, w.s2, S, ld, k, w.panel + (size_t)(k & 3) * pstride, 3, (const double*)nullptr);
             (void)hipEventRecord(w.sy1[w.sy_used], w.s2);
             w.sy_flops[w.sy_used++] = tile_flops * tiles;
         }

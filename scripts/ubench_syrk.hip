@@ -12,7 +12,7 @@
 #include "potrf.hip.h"
 using namespace bsfm;
 
-template <int MODE>   // 0: as shipped  1: no C epilogue (one value per lane written)  2: K loop 8x (K=1024)  3: 8x + no epilogue
+template <int MODE>   // 0: as shipped  1: no C epilogue (one value per lane written)  2: K loop 8x (K=1024)  3: 8x + no epilogue  6 / 7: K loop 2x / 4x
 __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_var(double* __restrict__ S, int ld, int k, const double* __restrict__ panel, double* sink)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_var(double* __restrict__
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[q][u] = 0.0;
     if (MODE == 4) { a = 1; b = 1; }          // every workgroup reads the same two tiles: pure L2 hits, no epilogue
-    const int reps = (MODE == 2 || MODE == 3) ? 8 : 1;
+    const int reps = (MODE == 2 || MODE == 3) ? 8 : (MODE == 6 ? 2 : (MODE == 7 ? 4 : 1));
     if (MODE == 5) {                           // lda = 0: all rows alias one 128-byte line (L1 hits): no memory cost at all
         gemm_nt_128(panel, 0, panel, 0, POTRF_NB, lds, acc);
     } else
@@ -189,23 +189,25 @@ int main()
     {   // warm-up ramp: the same launch 40 times, time of each (the first runs in a process are ~10 % slower than the steady state)
         printf("ramp (ms):");
         for (int r = 0; r < 40; ++r) {
-            hipEventRecord(e0, 0); hipLaunchKernelGGL(k_syrk_update<false>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2); hipEventRecord(e1, 0); hipEventSynchronize(e1);
+            hipEventRecord(e0, 0); hipLaunchKernelGGL(k_syrk_update<false>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2, (const double*)nullptr); hipEventRecord(e1, 0); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); printf(" %.3f", ms);
         }
         printf("\n");
     }
-    run("shipped k_syrk_update part 2", [&] { hipLaunchKernelGGL(k_syrk_update<false>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2); }, flop1);
+    run("shipped k_syrk_update part 2", [&] { hipLaunchKernelGGL(k_syrk_update<false>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2, (const double*)nullptr); }, flop1);
     // (a rank-256 two-panel variant measured 46.6 vs 42.9 TFLOP/s here; dropped, see potrf.hip.h)
     run("same, mode 0 copy", [&] { hipLaunchKernelGGL(k_var<0>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, flop1);
     run("no C epilogue", [&] { hipLaunchKernelGGL(k_var<1>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, flop1);
     run("K x8 (1024) with epilogue", [&] { hipLaunchKernelGGL(k_var<2>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, 8 * flop1);
+    run("K x2 (256) with epilogue", [&] { hipLaunchKernelGGL(k_var<6>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, 2 * flop1);
+    run("K x4 (512) with epilogue", [&] { hipLaunchKernelGGL(k_var<7>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, 4 * flop1);
     run("K x8, no epilogue", [&] { hipLaunchKernelGGL(k_var<3>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, 8 * flop1);
     run("all WGs same tiles (L2 hits), no epi", [&] { hipLaunchKernelGGL(k_var<4>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, flop1);
     run("lda=0 (L1 hits), no epilogue", [&] { hipLaunchKernelGGL(k_var<5>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, flop1);
     run("mix: prologue / epilogue by parity", [&] { hipLaunchKernelGGL(k_mix<0>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel); }, flop1);
     run("mix kernel, all prologue", [&] { hipLaunchKernelGGL(k_mix<1>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel); }, flop1);
     run("mix kernel, all epilogue", [&] { hipLaunchKernelGGL(k_mix<2>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel); }, flop1);
-    run("shipped k_syrk_update again", [&] { hipLaunchKernelGGL(k_syrk_update<false>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2); }, flop1);
+    run("shipped k_syrk_update again", [&] { hipLaunchKernelGGL(k_syrk_update<false>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2, (const double*)nullptr); }, flop1);
     run("mix kernel, all prologue again", [&] { hipLaunchKernelGGL(k_mix<1>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel); }, flop1);
     for (int G : {8}) {
         std::vector<int2> hm; build_map(T - 1, G, 8, hm);
@@ -228,7 +230,7 @@ int main()
             hipStreamSynchronize(sm);
             hipEventRecord(e0, sm); hipLaunchKernelGGL(k_mapped, dim3(grid), dim3(512), lds_bytes, sm, S, ld, 0, panel, dm); hipEventRecord(e1, sm); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); printf("masked stream, G=8 map: %.3f ms %.2f TFLOP/s\n", ms, flop1 / (ms * 1e-3) / 1e12);
-            hipEventRecord(e0, sm); hipLaunchKernelGGL(k_syrk_update<false>, dim3(grid), dim3(512), lds_bytes, sm, S, ld, 0, panel, 2); hipEventRecord(e1, sm); hipEventSynchronize(e1);
+            hipEventRecord(e0, sm); hipLaunchKernelGGL(k_syrk_update<false>, dim3(grid), dim3(512), lds_bytes, sm, S, ld, 0, panel, 2, (const double*)nullptr); hipEventRecord(e1, sm); hipEventSynchronize(e1);
             hipEventElapsedTime(&ms, e0, e1); printf("masked stream, shipped order: %.3f ms %.2f TFLOP/s\n", ms, flop1 / (ms * 1e-3) / 1e12);
         }
     }
