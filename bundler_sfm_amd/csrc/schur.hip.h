@@ -37,7 +37,21 @@
 #pragma once
 #include "kernels.hip.h"
 
+#ifndef BSFM_SCHUR_MFMA16
+#define BSFM_SCHUR_MFMA16 1
+#endif
+
 namespace bsfm {
+
+// value of lane Q of every quad (DPP quad_perm [Q, Q, Q, Q]): two 32-bit moves, no LDS
+template <int Q>
+__device__ __forceinline__ double quad_bcast(double v)
+{
+    constexpr int ctrl = Q | (Q << 2) | (Q << 4) | (Q << 6);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 
 constexpr int SCH_PASS = 21;          // triples in flight per wave (3 lanes each)
 constexpr int SCH_MAXT = 168;         // triples per task (SCHUR_CHUNK in solver.hip)
@@ -230,7 +244,7 @@ __global__ __launch_bounds__(256, 3) void k_schur_tasks_mfma(DevProblem P, const
     constexpr int CB = (CNP + 1 + 3) / 4;      // 4-column sub-blocks incl. the right-hand-side column
     constexpr int NSB = RB * CB;
     constexpr int NI = (NSB + 3) / 4;          // matrix instructions per 4 reduction rows
-    constexpr int SLAB = 2 * SCM_PASS * RS + SCM_PASS * 6 + SCM_PASS * 4 + 2 * SCM_PASS * YS;
+    constexpr int SLAB = 2 * SCM_PASS * RS + SCM_PASS * 6 + SCM_PASS * 4 + 2 * SCM_PASS * YS + 2;   // (+2: a word that stays zero, see MFMA16)
     __shared__ __attribute__((aligned(16))) double sm[4][SLAB];
     __shared__ int sm_tri[4][3 * SCH_MAXT];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -263,6 +277,19 @@ __global__ __launch_bounds__(256, 3) void k_schur_tasks_mfma(DevProblem P, const
     const int cp = lane >> 2, cq = lane & 3;
     // (3) matrix instruction operands: reduction row kk, product slot g, index r
     const int kk = lane >> 4, g = (lane >> 2) & 3, r = lane & 3;
+#if BSFM_SCHUR_MFMA16
+    // ONE v_mfma_f64_16x16x4_f64 per 4 reduction rows covers the whole CNP x (CNP + 1) block (A[i][k] at lane i + 16 k, B[k][j] at lane
+    // j + 16 k: scripts/probe_mfma16.hip): 2 operand reads per lane and step instead of 2 NI -- the kernel is bound by the LDS pipeline
+    // (SQ_LDS_IDX_ACTIVE = 85 % of its duration with the 4x4x4 form, whose NI = 3 instructions per step re-read the slab three times).
+    typedef double v4d_ __attribute__((ext_vector_type(4)));
+    // Lanes beyond the block read one zero word (stride 0: a broadcast; letting them read the finite numbers that follow in the slab
+    // at the common stride -- which pairs the reads into ds_read2_b64 -- measured slower, 1.48 vs 1.43 ms).
+    const int oi = lane & 15;                                     // output row of the A operand / output column of the B operand
+    const int xbase = oi < CNP ? (kk >> 1) * RS + (kk & 1) * CNP + oi : SLAB - 1, xstep = oi < CNP ? 2 * RS : 0;
+    const int ybase = oi < YS ? (int)(Yh - recA) + kk * YS + oi : SLAB - 1, ystep = oi < YS ? 4 * YS : 0;
+    v4d_ acc16 = { 0.0, 0.0, 0.0, 0.0 };
+    (void)g; (void)r; (void)NI;
+#else
     int xoff[NI], yoff[NI];
 #pragma unroll
     for (int q = 0; q < NI; ++q) {
@@ -274,6 +301,7 @@ __global__ __launch_bounds__(256, 3) void k_schur_tasks_mfma(DevProblem P, const
     double acc[NI];
 #pragma unroll
     for (int q = 0; q < NI; ++q) acc[q] = 0.0;
+#endif
     // Register sets 0 and 1 alternate between passes (one pass of gathers in flight; two in flight measured no faster: 1.68 vs
     // 1.59 ms at config 3 -- the kernel is not bound by the latency of its gathers).
     double pa[2][NA][2], pb[2][NA][2], pv[2][2], pe[2] = { 0.0, 0.0 };
@@ -308,6 +336,30 @@ __global__ __launch_bounds__(256, 3) void k_schur_tasks_mfma(DevProblem P, const
             if (diag) ebin[rv_ * 4 + vpart] = pe[S_];                                                               \
         }                                                                                                           \
     }
+#if BSFM_SCHUR_MFMA16
+#define BSFM_SCM_REDUCE                                                                                             \
+        {                                                                                                           \
+            double xa[SCM_PASS / 2], yb[SCM_PASS / 2];                                                              \
+            _Pragma("unroll") for (int k4 = 0; k4 < SCM_PASS / 2; ++k4) { xa[k4] = recA[xbase + k4 * xstep]; yb[k4] = recA[ybase + k4 * ystep]; } \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+            _Pragma("unroll") for (int k4 = 0; k4 < SCM_PASS / 2; ++k4)                                             \
+                acc16 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k4], yb[k4], acc16, 0, 0, 0);                       \
+        }
+#else
+#define BSFM_SCM_REDUCE                                                                                             \
+        _Pragma("unroll") for (int k4 = 0; k4 < SCM_PASS / 2; k4 += 2) {                                            \
+            double xa[2][NI], yb[2][NI];                                                                            \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                           \
+                _Pragma("unroll") for (int q = 0; q < NI; ++q) {                                                    \
+                    xa[u][q] = recA[2 * (k4 + u) * RS + xoff[q]];                                                   \
+                    yb[u][q] = Yh[4 * (k4 + u) * YS + yoff[q]];                                                     \
+                }                                                                                                   \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                           \
+                _Pragma("unroll") for (int q = 0; q < NI; ++q)                                                      \
+                    acc[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(xa[u][q], yb[u][q], acc[q], 0, 0, 0);               \
+        }
+#endif
 // the 2 x 2 core of triple cp and this lane's columns of Yh, then the reduction over the pass's 2 x SCM_PASS rows on the matrix cores
 #define BSFM_SCM_COMPUTE(p0_)                                                                                       \
     {                                                                                                               \
@@ -316,20 +368,28 @@ __global__ __launch_bounds__(256, 3) void k_schur_tasks_mfma(DevProblem P, const
             const bool live = (p0_) + cp < tk.count;                                                                \
             const double* Ja = recA + cp * RS;                                                                      \
             const double* Jb = recB + cp * RS;                                                                      \
-            const double* vi = vin + cp * 6;                                                                        \
-            const double i00 = vi[0], i01 = vi[1], i02 = vi[2], i11 = vi[3], i12 = vi[4], i22 = vi[5];              \
-            const double* Ba = Ja + 2 * CNP;                                                                        \
-            const double* Bb = Jb + 2 * CNP;                                                                        \
-            const double c00 = Ba[0] * i00 + Ba[1] * i01 + Ba[2] * i02;                                             \
-            const double c01 = Ba[0] * i01 + Ba[1] * i11 + Ba[2] * i12;                                             \
-            const double c02 = Ba[0] * i02 + Ba[1] * i12 + Ba[2] * i22;                                             \
-            const double c10 = Ba[3] * i00 + Ba[4] * i01 + Ba[5] * i02;                                             \
-            const double c11 = Ba[3] * i01 + Ba[4] * i11 + Ba[5] * i12;                                             \
-            const double c12 = Ba[3] * i02 + Ba[4] * i12 + Ba[5] * i22;                                             \
-            const double m00 = c00 * Bb[0] + c01 * Bb[1] + c02 * Bb[2];                                             \
-            const double m01 = c00 * Bb[3] + c01 * Bb[4] + c02 * Bb[5];                                             \
-            const double m10 = c10 * Bb[0] + c11 * Bb[1] + c12 * Bb[2];                                             \
-            const double m11 = c10 * Bb[3] + c11 * Bb[4] + c12 * Bb[5];                                             \
+            /* ONE lane of the triple's four forms the 2 x 2 core (18 LDS reads); its neighbours take it by DPP quad broadcast -- the \
+               kernel is LDS-bound, and all four lanes reading the same B blocks and V^-1 was a third of its LDS traffic.  The forming \
+               lane is the one that also owns the right-hand-side column (cq == CNP & 3), so c00 .. c12 never leave it. */            \
+            double c00 = 0.0, c01 = 0.0, c02 = 0.0, c10 = 0.0, c11 = 0.0, c12 = 0.0, m00 = 0.0, m01 = 0.0, m10 = 0.0, m11 = 0.0;     \
+            if (cq == (CNP & 3)) {                                                                                  \
+                const double* vi = vin + cp * 6;                                                                    \
+                const double i00 = vi[0], i01 = vi[1], i02 = vi[2], i11 = vi[3], i12 = vi[4], i22 = vi[5];          \
+                const double* Ba = Ja + 2 * CNP;                                                                    \
+                const double* Bb = Jb + 2 * CNP;                                                                    \
+                c00 = Ba[0] * i00 + Ba[1] * i01 + Ba[2] * i02;                                                      \
+                c01 = Ba[0] * i01 + Ba[1] * i11 + Ba[2] * i12;                                                      \
+                c02 = Ba[0] * i02 + Ba[1] * i12 + Ba[2] * i22;                                                      \
+                c10 = Ba[3] * i00 + Ba[4] * i01 + Ba[5] * i02;                                                      \
+                c11 = Ba[3] * i01 + Ba[4] * i11 + Ba[5] * i12;                                                      \
+                c12 = Ba[3] * i02 + Ba[4] * i12 + Ba[5] * i22;                                                      \
+                m00 = c00 * Bb[0] + c01 * Bb[1] + c02 * Bb[2];                                                      \
+                m01 = c00 * Bb[3] + c01 * Bb[4] + c02 * Bb[5];                                                      \
+                m10 = c10 * Bb[0] + c11 * Bb[1] + c12 * Bb[2];                                                      \
+                m11 = c10 * Bb[3] + c11 * Bb[4] + c12 * Bb[5];                                                      \
+            }                                                                                                       \
+            m00 = quad_bcast<CNP & 3>(m00); m01 = quad_bcast<CNP & 3>(m01);                                         \
+            m10 = quad_bcast<CNP & 3>(m10); m11 = quad_bcast<CNP & 3>(m11);                                         \
             double* y0 = Yh + (2 * cp) * YS;                                                                        \
             double* y1 = y0 + YS;                                                                                   \
             _Pragma("unroll") for (int a = 0; a < (CNP + 3) / 4; ++a) {                                             \
@@ -348,18 +408,7 @@ __global__ __launch_bounds__(256, 3) void k_schur_tasks_mfma(DevProblem P, const
         }                                                                                                           \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                          \
         /* operands of two reduction steps are fetched together: one LDS wait per 2 NI matrix instructions, not one per instruction */ \
-        _Pragma("unroll") for (int k4 = 0; k4 < SCM_PASS / 2; k4 += 2) {                                            \
-            double xa[2][NI], yb[2][NI];                                                                            \
-            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                           \
-                _Pragma("unroll") for (int q = 0; q < NI; ++q) {                                                    \
-                    xa[u][q] = recA[2 * (k4 + u) * RS + xoff[q]];                                                   \
-                    yb[u][q] = Yh[4 * (k4 + u) * YS + yoff[q]];                                                     \
-                }                                                                                                   \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
-            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                           \
-                _Pragma("unroll") for (int q = 0; q < NI; ++q)                                                      \
-                    acc[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(xa[u][q], yb[u][q], acc[q], 0, 0, 0);               \
-        }                                                                                                           \
+        BSFM_SCM_REDUCE                                                                                             \
         asm volatile("" ::: "memory");                           /* the next parking must not move above these reads */ \
     }
 
@@ -378,6 +427,22 @@ __global__ __launch_bounds__(256, 3) void k_schur_tasks_mfma(DevProblem P, const
 #undef BSFM_SCM_ISSUE
 #undef BSFM_SCM_PARK
 #undef BSFM_SCM_COMPUTE
+#undef BSFM_SCM_REDUCE
+#if BSFM_SCHUR_MFMA16
+    // D[a][b]: register r of lane l holds row a = 4 r + (l >> 4), column b = l & 15
+    {
+        double* out = partials + (size_t)tk.out * CNP * CNP;
+        const int b = lane & 15;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int a = 4 * rr + (lane >> 4);
+            if (a < CNP) {
+                if (b < CNP) out[a * CNP + b] = acc16[rr];
+                else if (b == CNP && diag) epart[(size_t)tk.out * CNP + a] = acc16[rr];
+            }
+        }
+    }
+#else
     // D[g][i][j] of instruction q sits at lane 16 i + 4 g + j
     {
         const int i = lane >> 4, j = lane & 3;
@@ -395,6 +460,7 @@ __global__ __launch_bounds__(256, 3) void k_schur_tasks_mfma(DevProblem P, const
             }
         }
     }
+#endif
 }
 
 }  // namespace bsfm
