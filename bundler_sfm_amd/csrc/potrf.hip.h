@@ -670,7 +670,7 @@ __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __re
 //   * phase B, inverse: X = inv(L) by block forward substitution, ONE WAVE PER BLOCK COLUMN J and no barriers:
 //     X[I][J] = -inv(L_II) * sum_{K=J}^{I-1} L[I][K] X[K][J]; X[K][J]^T is parked in the unused upper block T[J][K]
 //     so that every product is of the A * Bt^T ("NT") form the MFMA fragments read directly from LDS.
-constexpr int DG_TS = 132;                                   // LDS row stride of the tile (doubles)
+constexpr int DG_TS = 134;                                   // LDS row stride of the tile (doubles): 132 -> 134 takes the inverse phase from 12.6 to 10.6 us (bank conflicts of the 16x16 operand reads; 136 is 10 us WORSE, 129 / 130 / 138 / 140 within 1 us of 134)
 constexpr int DG_LDS_DOUBLES = POTRF_NB * DG_TS + 8 * 256;
 
 __device__ __forceinline__ double rsqrt_f64(double v)
