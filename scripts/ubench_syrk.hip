@@ -201,6 +201,13 @@ int main()
     run("K x8 (1024) with epilogue", [&] { hipLaunchKernelGGL(k_var<2>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, 8 * flop1);
     run("K x2 (256) with epilogue", [&] { hipLaunchKernelGGL(k_var<6>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, 2 * flop1);
     run("K x4 (512) with epilogue", [&] { hipLaunchKernelGGL(k_var<7>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, 4 * flop1);
+    {   // one workgroup per CU (90 KB of dynamic LDS requested): what a wide update would reach if it left half of every CU to the chain
+        const size_t big = 90 * 1024;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_var<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_var<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big);
+        run("K x4 (512), ONE workgroup per CU", [&] { hipLaunchKernelGGL(k_var<7>, dim3(grid), dim3(512), big, 0, S, ld, 0, panel, sink); }, 4 * flop1);
+        run("K = 128, ONE workgroup per CU", [&] { hipLaunchKernelGGL(k_var<0>, dim3(grid), dim3(512), big, 0, S, ld, 0, panel, sink); }, flop1);
+    }
     run("K x8, no epilogue", [&] { hipLaunchKernelGGL(k_var<3>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, 8 * flop1);
     run("all WGs same tiles (L2 hits), no epi", [&] { hipLaunchKernelGGL(k_var<4>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, flop1);
     run("lda=0 (L1 hits), no epilogue", [&] { hipLaunchKernelGGL(k_var<5>, dim3(grid), dim3(512), lds_bytes, 0, S, ld, 0, panel, sink); }, flop1);
