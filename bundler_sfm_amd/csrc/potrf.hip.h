@@ -400,7 +400,8 @@ __global__ __launch_bounds__(256, 1) void k_syrk_col64(double* __restrict__ S, i
 constexpr int T32_STRIDE = 132;
 constexpr int T32_LDS_DOUBLES = 2 * 32 * T32_STRIDE;
 template <int MODE>
-__global__ __launch_bounds__(256, 1) void k_chain_tile32(double* __restrict__ S, int ld, int k, const double* __restrict__ Linv,
+__global__ __launch_bounds__(256, 2) void k_chain_tile32(   // (2: a 256-register budget keeps the 16x16x4 accumulators in VGPRs; their AGPR form is half rate)
+        double* __restrict__ S, int ld, int k, const double* __restrict__ Linv,
                                                          double* __restrict__ panel, const double* __restrict__ prev,
                                                          const double* __restrict__ prev2)
 {
@@ -445,7 +446,9 @@ __global__ __launch_bounds__(256, 1) void k_chain_tile32(double* __restrict__ S,
     }
     BSFM_T32_FETCH(0)
     double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+#if !BSFM_GEMM_MFMA16
     const double* ap = As + (wr + (lane & 3)) * T32_STRIDE + (lane >> 4);
+#endif
     const double* bp = Bs + (wc + (lane & 15)) * T32_STRIDE + (lane >> 4);
 #pragma unroll 1
     for (int sg = 0; sg < nseg; ++sg) {
@@ -459,11 +462,21 @@ __global__ __launch_bounds__(256, 1) void k_chain_tile32(double* __restrict__ S,
         }
         __syncthreads();
         if (sg + 1 < nseg) BSFM_T32_FETCH(sg + 1)      // in flight during this segment's products
+#if BSFM_GEMM_MFMA16
+        {   // one v_mfma_f64_16x16x4 per k-step (the wave's 16 x 16 block is one accumulator tuple): 2 LDS reads instead of 5
+            typedef double v4d_ __attribute__((ext_vector_type(4)));
+            const double* ap16 = As + (wr + (lane & 15)) * T32_STRIDE + (lane >> 4);
+            v4d_ c = { acc[0], acc[1], acc[2], acc[3] };
+            for (int kk = 0; kk < K0; kk += 4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap16[kk], bp[kk], c, 0, 0, 0);
+            acc[0] = c[0]; acc[1] = c[1]; acc[2] = c[2]; acc[3] = c[3];
+        }
+#else
         for (int kk = 0; kk < K0; kk += 4) {
             const double b = bp[kk];
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(ap[4 * t * T32_STRIDE + kk], b, acc[t], 0, 0, 0);
         }
+#endif
     }
 #undef BSFM_T32_FETCH
 #pragma unroll
@@ -682,8 +695,23 @@ __device__ __forceinline__ double rsqrt_f64(double v)
 }
 
 // acc[a] += A(16x16, row stride sa) * Bt(16x16, row stride sb)^T ; acc[a] holds rows 4a + (lane>>4), col lane&15.
+// (v_mfma_f64_16x16x4: its accumulator registers are exactly this layout, and a 16 x 16 x 16 product takes 8 LDS reads and 4 matrix
+//  instructions instead of 20 and 16 with the 4x4x4 form -- the diagonal-tile kernel is sensitive to LDS latency, not to the matrix pipe.)
 __device__ __forceinline__ void mma16_nt(double (&acc)[4], const double* A, int sa, const double* Bt, int sb, int lane)
 {
+#if BSFM_GEMM_MFMA16
+    typedef double v4d_ __attribute__((ext_vector_type(4)));
+    v4d_ c = { acc[0], acc[1], acc[2], acc[3] };
+    double av[4], bv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        av[q] = A[(lane & 15) * sa + 4 * q + (lane >> 4)];
+        bv[q] = Bt[(lane & 15) * sb + 4 * q + (lane >> 4)];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], c, 0, 0, 0);
+    acc[0] = c[0]; acc[1] = c[1]; acc[2] = c[2]; acc[3] = c[3];
+#else
 #pragma unroll
     for (int kk = 0; kk < 16; kk += 4) {
         const double b = Bt[(lane & 15) * sb + kk + (lane >> 4)];
@@ -693,6 +721,7 @@ __device__ __forceinline__ void mma16_nt(double (&acc)[4], const double* A, int 
             acc[a] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b, acc[a], 0, 0, 0);
         }
     }
+#endif
 }
 
 // ---- A1: wave 0 factors the diagonal block (s,s) in registers, ONE LANE PER ROW (lanes 16.. mirror lane & 15):
