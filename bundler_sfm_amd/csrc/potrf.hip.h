@@ -466,9 +466,13 @@ __global__ __launch_bounds__(256, 2) void k_chain_tile32(   // (2: a 256-registe
         {   // one v_mfma_f64_16x16x4 per k-step (the wave's 16 x 16 block is one accumulator tuple): 2 LDS reads instead of 5
             typedef double v4d_ __attribute__((ext_vector_type(4)));
             const double* ap16 = As + (wr + (lane & 15)) * T32_STRIDE + (lane >> 4);
-            v4d_ c = { acc[0], acc[1], acc[2], acc[3] };
-            for (int kk = 0; kk < K0; kk += 4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap16[kk], bp[kk], c, 0, 0, 0);
-            acc[0] = c[0]; acc[1] = c[1]; acc[2] = c[2]; acc[3] = c[3];
+            // two accumulator tuples (even / odd k-steps): a dependent 16x16x4 waits for its predecessor's write-back, two chains hide it
+            v4d_ c = { acc[0], acc[1], acc[2], acc[3] }, c2 = { 0.0, 0.0, 0.0, 0.0 };
+            for (int kk = 0; kk < K0; kk += 8) {
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap16[kk], bp[kk], c, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap16[kk + 4], bp[kk + 4], c2, 0, 0, 0);
+            }
+            acc[0] = c[0] + c2[0]; acc[1] = c[1] + c2[1]; acc[2] = c[2] + c2[2]; acc[3] = c[3] + c2[3];
         }
 #else
         for (int kk = 0; kk < K0; kk += 4) {
