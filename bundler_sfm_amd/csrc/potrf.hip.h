@@ -82,7 +82,10 @@ constexpr int POTRF_MAX_TILES = 240;   // k_bwd_persistent needs one resident wo
 #define BSFM_GEMM_KC 16
 #endif
 constexpr int GEMM_KC = BSFM_GEMM_KC;             // K chunk of the bulk 128x128 tile kernel
-constexpr int GEMM_LDS_STRIDE = GEMM_KC + (GEMM_KC == 16 ? 2 : 4);   // 18: conflict-free; 36: 16-byte aligned rows, <= 2-way conflicts
+#ifndef BSFM_GEMM_STRIDE
+#define BSFM_GEMM_STRIDE (GEMM_KC + (GEMM_KC == 16 ? 2 : 4))
+#endif
+constexpr int GEMM_LDS_STRIDE = BSFM_GEMM_STRIDE;   // 18: best for both fragment forms (16x16x4, kernel alone at k = 1 024: 18 -> 62.2, 20 -> 59.4 TFLOP/s); 36: 16-byte aligned rows
 constexpr int G64_KC = 16;                        // the latency-critical 64-row chain kernels keep 16-wide chunks
 constexpr int G64_STRIDE = G64_KC + 2;
 
