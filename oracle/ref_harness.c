@@ -52,6 +52,11 @@ void ref_set_fisheye(int on) { g_fisheye = on; }
  * UNDAMPED reduced camera system at the INITIAL parameters: the fixture for the Schur complement at the headline size. */
 static double g_eps1 = 1.0e-10;
 void ref_set_eps1(double eps1) { g_eps1 = eps1; }
+/* tau (opts[0]) of the next ref_sba_motstr calls; run_sfm's value 1e-3 (sfm.c:705) unless set.  tau = 0 gives mu = 0: with a point
+ * nobody observes V*_i is the zero matrix, dsytrf reports it, and the reference walks its "singular V*_i => more damping" branch
+ * (lib/sba-1.5/sba_levmar.c:1156-1161, 1584-1611) until nu overflows (stop 6). */
+static double g_tau = 1.0e-3;
+void ref_set_tau(double tau) { g_tau = tau; }
 
 void ref_run_sfm(int num_pts, int num_cameras, int ncons, char *vmask, double *projections,
                  int est_focal_length, int const_focal_length, int undistort, int explicit_camera_centers,
@@ -100,7 +105,7 @@ int ref_sba_motstr(int n, int m, int mcon, char *vmask, double *projections,
     }
     memcpy(params + cnp * m, pts, sizeof(double) * 3 * n);
 
-    opts[0] = 1.0e-3; opts[1] = g_eps1; opts[2] = eps2; opts[3] = 1.0e-12; opts[4] = 0.0; opts[5] = 4.0e-2;
+    opts[0] = g_tau; opts[1] = g_eps1; opts[2] = eps2; opts[3] = 1.0e-12; opts[4] = 0.0; opts[5] = 4.0e-2;
 
     if (use_constraints) {
         cons = (camera_constraints_t *) malloc(m * sizeof(camera_constraints_t));

@@ -263,6 +263,73 @@ def fmatrix():
     print("fmatrix_golden:", len(pairs), "pairs; ransac inliers", rc, "final inliers", en)
 
 
+def prune_scene():
+    """The scene of tests/test_ba_gpu.py::test_ray_angle_pruning: the "band" case with every 7th point pushed 400 x away from the
+    camera centroid (tiny parallax)."""
+    from test_oracle import load_case
+    c = load_case("band")
+    pts = c["pts"].copy().reshape(-1, 3)
+    ca = O.cams_to_arrays(c["cams"])
+    far = np.arange(0, c["n"], 7)
+    centre = ca["t"].mean(axis=0)
+    pts[far] = centre + (pts[far] - centre) * 400.0
+    return c, pts
+
+
+def prune():
+    """Ray-angle pruning (SURVEY 8(f).1): the reference's BundlerApp::RemoveBadPointsAndCameras (src/Bundle.cpp:4190-4261) itself,
+    oracle/_ref/libpruneref.so, at two thresholds."""
+    c, pts = prune_scene()
+    out = {}
+    for thr in (2.0, 3.5):
+        k, flag, ang = O.ref_remove_bad_points(c["n"], c["m"], c["rowptr"], c["colidx"], c["cams"], pts, thr)
+        out[f"num_pruned_{thr}"] = np.array([k]); out[f"prune_{thr}"] = flag; out[f"angle_deg_{thr}"] = ang
+    np.savez_compressed(os.path.join(HERE, "prune_golden.npz"), **out)
+    print("prune_golden.npz:", {k: (v.sum() if v.dtype == np.uint8 else v.ravel()[:2]) for k, v in out.items()})
+
+
+def failure_scenes():
+    """Two scenes that force the LM failure branches (used by tests/test_ba_gpu.py and by failures() below).
+    A: camera 3, parameter 0 carries a constraint of weight -1e8: U_3 is indefinite, dpotrf stops at that pivot (info > 0) until
+       mu has grown past 1e8 -- eight rejected systems before the first solve goes through (sba_levmar.c:1368-1377, 1584-1611).
+    B: point 100 is observed by nobody and tau = 0 (mu = 0): V*_100 is the zero matrix, sba_symat_invert_BK reports it
+       (sba_levmar.c:1138-1162), the damping loop doubles nu with mu stuck at 0 until nu overflows: stop 6, no system solved."""
+    m, n, deg = 12, 300, 5
+    s = B.synth_ba(m, n, deg)
+    camsA = O.copy_cams(s["cams"])
+    for c in camsA:
+        for q in range(9):
+            c.constrained[q] = 0
+    camsA[3].constrained[0] = 1; camsA[3].constraints[0] = camsA[3].t[0]; camsA[3].weights[0] = -1.0e8
+    A = dict(m=m, n=n, rowptr=np.array(s["rowptr"], np.int32), colidx=np.array(s["colidx"], np.int32), proj=s["proj"], cams=camsA,
+             pts=np.array(s["pts"], np.float64), use_constraints=1, tau=1.0e-3)
+    rp = np.array(s["rowptr"])
+    rp2 = np.concatenate([rp[:101], [rp[100]], rp[101:]]).astype(np.int32)
+    pts = np.array(s["pts"]).reshape(-1, 3)
+    pts2 = np.vstack([pts[:100], [[0.1, 0.2, 0.3]], pts[100:]])
+    Bs = dict(m=m, n=n + 1, rowptr=rp2, colidx=np.array(s["colidx"], np.int32), proj=s["proj"], cams=s["cams"], pts=pts2.ravel().copy(),
+              use_constraints=0, tau=0.0)
+    return dict(A=A, B=Bs)
+
+
+def failures():
+    """LM failure branches against the reference itself (oracle/_ref): failure_golden.npz."""
+    import ctypes as C
+    out = {}
+    O.ref().ref_set_tau.argtypes = [C.c_double]
+    for name, sc in failure_scenes().items():
+        vm = B.dense_vmask(sc["n"], sc["m"], sc["rowptr"], sc["colidx"])
+        O.ref().ref_set_tau(sc["tau"])
+        for tag, jm in (("an", 1), ("fd", 0)):
+            for it in (1, 6):
+                r = O.ref_sba(sc["n"], sc["m"], vm, sc["proj"], sc["cams"], sc["pts"], itmax=it, jac_mode=jm,
+                              use_constraints=sc["use_constraints"])
+                out[f"{name}_{tag}_{it}_info"] = r["info"]; out[f"{name}_{tag}_{it}_p"] = r["p"]; out[f"{name}_{tag}_{it}_rc"] = np.array([r["rc"]])
+                print(name, tag, it, r["rc"], r["info"])
+        O.ref().ref_set_tau(1.0e-3)
+    np.savez_compressed(os.path.join(HERE, "failure_golden.npz"), **out)
+
+
 def parse_bundle(path):
     toks = open(path).read().split("\n")
     assert toks[0].startswith("# Bundle file v0.3")
@@ -379,6 +446,6 @@ def model():
 if __name__ == "__main__":
     assert O.have_ref(), "build oracle/_ref first (make -C oracle ref)"
     only = sys.argv[1:]
-    for fn in (ba_cases, kermit, matcher, model, exports, mot, known_intrinsics, fisheye, triangulation, fmatrix):
+    for fn in (ba_cases, kermit, matcher, model, exports, mot, known_intrinsics, fisheye, triangulation, fmatrix, prune, failures):
         if not only or fn.__name__ in only:
             fn()

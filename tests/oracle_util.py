@@ -456,3 +456,27 @@ def ref_compute_tracks(num_keys, pair_i, pair_j, match_ptr, matches, new_image_s
                                     tp.ctypes.data_as(ip), vw.ctypes.data_as(ip), total + 1, max(total, 1))
     assert nt >= 0
     return tp[:nt + 1].copy(), vw[:tp[nt]].copy()
+
+
+PRUNEREF_PATH = os.path.join(os.path.dirname(REF_PATH), "libpruneref.so")
+
+
+def have_pruneref():
+    return os.path.exists(PRUNEREF_PATH)
+
+
+def ref_remove_bad_points(n, m, rowptr, colidx, cams, pts, threshold):
+    """The reference's BundlerApp::RemoveBadPointsAndCameras (src/Bundle.cpp:4190-4261, compiled from where it lies into
+    oracle/_ref/libpruneref.so by oracle/ref_prune.cpp).  Returns (num_pruned, prune[n] uint8, max ray angle per point in degrees)."""
+    lib = C.CDLL(PRUNEREF_PATH)
+    ip = C.POINTER(C.c_int)
+    rp = np.ascontiguousarray(rowptr, np.int32); ci = np.ascontiguousarray(colidx, np.int32)
+    P = np.ascontiguousarray(pts, np.float64).ravel()
+    prune = np.zeros(n, np.uint8); ang = np.zeros(n)
+    lib.ref_remove_bad_points.restype = C.c_int
+    lib.ref_remove_bad_points.argtypes = [C.c_int, C.c_int, ip, ip, _cp, _dp, C.c_double, C.POINTER(C.c_ubyte), _dp]
+    cc = copy_cams(cams)
+    with quiet_stdout():
+        k = lib.ref_remove_bad_points(n, m, rp.ctypes.data_as(ip), ci.ctypes.data_as(ip), cc, _d(P), float(threshold),
+                                      prune.ctypes.data_as(C.POINTER(C.c_ubyte)), _d(ang))
+    return k, prune, ang

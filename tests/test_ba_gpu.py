@@ -9,6 +9,7 @@ Tolerances (FP64 everywhere; SURVEY/BASELINE parity gates):
   index / counters (iterations, solves, stop code) bit-exact for the first iterations
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -494,48 +495,75 @@ def test_post_solve_outlier_statistics_vs_reference_routines(gpu_bsfm, with_pcon
     assert np.abs(st["err"] - err).max() <= 1e-9 * max(1.0, err.max())
 
 
-def test_ray_angle_pruning(gpu_bsfm):
-    """SURVEY 8(f).1, second half: RemoveBadPointsAndCameras (src/Bundle.cpp:4190-4261).  CPU side restates the
-    reference loop (unit rays by multiplying with 1/norm, dot in index order, CLAMP to +-(1 - 1e-8), acos, RAD2DEG, prune
-    when below half the threshold); some points are pulled far away so that their rays become nearly parallel."""
-    import math
+@pytest.mark.parametrize("thr", [2.0, 3.5])
+def test_ray_angle_pruning(gpu_bsfm, thr):
+    """SURVEY 8(f).1, second half, pinned to the REFERENCE'S OWN BundlerApp::RemoveBadPointsAndCameras (src/Bundle.cpp:4190-4261,
+    compiled from where it lies by oracle/ref_prune.cpp -> oracle/_ref/libpruneref.so): committed fixture
+    tests/golden/prune_golden.npz (tests/golden/make_golden.py prune) and, where oracle/_ref is present, a live call on the same
+    scene.  Some points are pulled far away so that their rays become nearly parallel.  Flags and the count must agree exactly; the
+    largest ray angle per point to 1e-9 degrees (acos near 1 amplifies the last ulp of the dot product)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import prune_scene
     B = gpu_bsfm
-    c = load_case("band")
+    c, pts = prune_scene()
     m, n = c["m"], c["n"]
-    pts = c["pts"].copy().reshape(-1, 3)
-    ca = O.cams_to_arrays(c["cams"])
-    far = np.arange(0, n, 7)
-    centre = ca["t"].mean(axis=0)
-    pts[far] = centre + (pts[far] - centre) * 400.0               # distant points: tiny parallax
     pb = B.Problem(n, m, c["rowptr"], c["colidx"], c["proj"], c["cams"], pts.ravel(), est_focal_length=c["est"],
                    undistort=c["und"], options=B.default_options(verbose=0))
-    thr = 2.0
     st = pb.ray_angles(thr)
     pb.close()
-    ang = np.zeros(n); prune = np.zeros(n, np.uint8)
-    for i in range(n):
-        k0, k1 = c["rowptr"][i], c["rowptr"][i + 1]
-        rays = []
-        for k in range(k0, k1):
-            r = pts[i] - ca["t"][c["colidx"][k]]
-            s = 0.0
-            for q in range(3):
-                s += r[q] * r[q]
-            rays.append(r * (1.0 / math.sqrt(s)))
-        mx = 0.0
-        for a in range(len(rays)):
-            for b in range(a + 1, len(rays)):
-                d = 0.0
-                for q in range(3):
-                    d += rays[a][q] * rays[b][q]
-                d = min(max(d, -1.0 + 1.0e-8), 1.0 - 1.0e-8)
-                mx = max(mx, math.acos(d))
-        ang[i] = mx * (180.0 / math.pi)
-        prune[i] = 1 if (k1 > k0 and ang[i] < 0.5 * thr) else 0
-    assert np.abs(st["angle_deg"] - ang).max() <= 1e-9            # acos near 1 amplifies the last ulp of the dot product
-    assert np.abs(ang - 0.5 * thr).min() > 1e-6                   # nobody sits on the threshold: flags must agree exactly
-    assert np.array_equal(st["prune"], prune) and st["num_pruned"] == int(prune.sum())
-    assert 0 < prune.sum() < n
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "prune_golden.npz"))
+    refs = [(int(G[f"num_pruned_{thr}"][0]), G[f"prune_{thr}"], G[f"angle_deg_{thr}"])]
+    if O.have_pruneref():
+        refs.append(O.ref_remove_bad_points(n, m, c["rowptr"], c["colidx"], c["cams"], pts, thr))
+        assert refs[1][0] == refs[0][0] and np.array_equal(refs[1][1], refs[0][1]) and np.array_equal(refs[1][2], refs[0][2])
+    for k, prune, ang in refs:
+        assert np.abs(st["angle_deg"] - ang).max() <= 1e-9
+        assert np.abs(ang - 0.5 * thr).min() > 1e-6               # nobody sits on the threshold: flags must agree exactly
+        assert np.array_equal(st["prune"], prune) and st["num_pruned"] == k == int(prune.sum())
+        assert 0 < prune.sum() < n
+
+
+@pytest.mark.parametrize("scene", ["A", "B"])
+@pytest.mark.parametrize("tag", ["an", "fd"])
+def test_lm_failure_branches_vs_reference(gpu_bsfm, scene, tag):
+    """The two failure branches of the LM loop, forced INSIDE an LM run, against the reference itself (fixture
+    tests/golden/failure_golden.npz from oracle/_ref; tests/golden/make_golden.py failures) and the live CPU oracle:
+      A: dpotrf fails (info > 0) => issolved = 0 => more damping (sba_levmar.c:1368-1377, 1584-1611) -- eight rejected linear systems
+         before the first accepted step (an indefinite U_3 through a constraint of weight -1e8);
+      B: singular V*_i => more damping without a linear system (sba_levmar.c:1138-1162), mu stuck at 0 (tau = 0) until nu overflows:
+         stop 6, ||dp|| = DBL_MAX, parameters untouched.
+    Counters (iterations, stop code, function / Jacobian evaluations, linear systems) bit-exact, costs 1e-9, parameters 1e-7 / 1e-6."""
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import failure_scenes
+    B = gpu_bsfm
+    sc = failure_scenes()[scene]
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "failure_golden.npz"))
+    jac = B.JAC_ANALYTIC if tag == "an" else B.JAC_FD
+    tol = 1e-7 if tag == "an" else 1e-6
+    vm = B.dense_vmask(sc["n"], sc["m"], sc["rowptr"], sc["colidx"])
+    O.port().oracle_set_tau.argtypes = [__import__("ctypes").c_double]
+    for it in (1, 6):
+        opt = B.default_options(jacobian=jac, verbose=0, itmax=it, opts=[sc["tau"], 1e-10, 1e-12, 1e-12, 0.0, 4e-2])
+        pb = B.Problem(sc["n"], sc["m"], sc["rowptr"], sc["colidx"], sc["proj"], sc["cams"], sc["pts"],
+                       use_constraints=sc["use_constraints"], options=opt)
+        rc, info = pb.solve()
+        p = pb.download(want_cams=False)[0]
+        pb.close()
+        O.port().oracle_set_tau(sc["tau"])
+        q = O.port_run_sfm(sc["n"], sc["m"], vm, sc["proj"], sc["cams"], sc["pts"], itmax=it, jac_mode=1 if tag == "an" else 0,
+                           use_constraints=sc["use_constraints"])
+        O.port().oracle_set_tau(-1.0)
+        for gi, gp, grc in ((G[f"{scene}_{tag}_{it}_info"], G[f"{scene}_{tag}_{it}_p"], int(G[f"{scene}_{tag}_{it}_rc"][0])),
+                            (q["info"], q["p"], q["rc"])):
+            assert rc == grc, (rc, grc, info, gi)
+            assert list(info[5:10]) == list(gi[5:10]), (info, gi)          # iterations, stop, nfev, njev, nlss
+            assert abs(info[0] - gi[0]) <= 1e-12 * abs(gi[0]) and abs(info[1] - gi[1]) <= 1e-9 * abs(gi[1])
+            assert info[3] == gi[3] or abs(info[3] - gi[3]) <= 1e-5 * abs(gi[3])      # ||dp||^2 (DBL_MAX when no step was ever computed)
+            assert np.abs(p - gp).max() <= tol * np.abs(gp).max()
+        if scene == "A" and it == 6:
+            assert info[9] == 14 and info[5] == 6            # 8 rejected + 6 accepted systems
+        if scene == "B" and it == 6:
+            assert info[6] == 6 and info[9] == 0 and np.array_equal(p[sc["m"] * 9:], np.asarray(sc["pts"]).ravel())
 
 
 MOT = np.load(os.path.join(os.path.dirname(__file__), "golden", "mot_golden.npz"))

@@ -67,7 +67,7 @@ def _worker(rank, world, port, out_dir):
     O.port().oracle_set_tau.argtypes = [__import__("ctypes").c_double]
     O.port().oracle_set_tau(1e-3 * float(maxdiag[0]) / local_maxdiag)
     q = O.port_run_sfm(*args, itmax=1, jac_mode=1, want_dumps=True)
-    O.port().oracle_set_tau(0.0)
+    O.port().oracle_set_tau(-1.0)
     mu_r = float(q["mu"][0])
     assert abs(mu_r - 1e-3 * float(maxdiag[0])) <= 1e-12 * mu_r
     S = torch.from_numpy(q["S"] - mu_r * np.eye(q["S"].shape[0]))
