@@ -18,10 +18,28 @@
 #include <vector>
 #include <thread>
 #include <algorithm>
+#include <chrono>
 #include <hip/hip_runtime_api.h>
 #include "../../include/bsfm.h"
+#include "index_build.h"
 
 namespace {
+
+// wall milliseconds of the phases of the last bsfm_run_sfm_ex call of this thread (bsfm_run_sfm_last_ms)
+thread_local double g_run_ms[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+enum { RM_TOTAL = 0, RM_CRS, RM_CRS_UPLOAD, RM_CRS_KERNELS, RM_CREATE, RM_LM, RM_DOWNLOAD, RM_CRS_ON_DEVICE };
+inline double ms_since(std::chrono::steady_clock::time_point t0)
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// masks of at least this many bytes are turned into the CRS on the device (index_build.hip:crs_from_vmask_device); smaller ones by
+// the host loop below (a 14-camera call of incremental Bundler has a few KB of mask: one upload + three launches would cost more)
+size_t vmask_device_min()
+{
+    static const size_t v = [] { const char* e = getenv("BSFM_VMASK_DEVICE_MIN"); return e ? (size_t)atoll(e) : (size_t)1 << 20; }();
+    return v;
+}
 
 // dense vmask -> CRS: the k-th set bit in row-major order is the k-th measurement (sba_levmar.c:653-663)
 void vmask_to_crs(int n, int m, const char* vmask, std::vector<int>& rowptr, std::vector<int>& colidx)
@@ -174,6 +192,31 @@ int bsfm_crs_from_vmask(int n, int m, const char* vmask, int* rowptr, int* colid
     if (rowptr) memcpy(rowptr, rp.data(), rp.size() * sizeof(int));
     if (colidx && !ci.empty()) memcpy(colidx, ci.data(), ci.size() * sizeof(int));
     return (int)ci.size();
+}
+
+// The same CRS built ON THE DEVICE (index_build.hip:crs_from_vmask_device: what run_sfm uses for masks of scale) and copied back:
+// the test entry that pins the device path to the reference's ordering contract bit for bit.  Needs a HIP device.
+int bsfm_crs_from_vmask_device(int n, int m, const char* vmask, int* rowptr, int* colidx, double* ms_out)
+{
+    if (n < 0 || m <= 0 || !vmask) return BSFM_ERROR;
+    if (bsfm_device_count() <= 0) { fprintf(stderr, "[bsfm] bsfm_crs_from_vmask_device: no HIP device\n"); return BSFM_ERROR; }
+    int *d_rp = nullptr, *d_ci = nullptr, nvis = 0;
+    if (bsfm::crs_from_vmask_device(n, m, vmask, &d_rp, &d_ci, &nvis, ms_out, nullptr) != 0) return BSFM_ERROR;
+    bool ok = true;
+    if (rowptr) ok = hipMemcpy(rowptr, d_rp, ((size_t)n + 1) * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok && colidx && nvis) ok = hipMemcpy(colidx, d_ci, (size_t)nvis * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d_rp); (void)hipFree(d_ci);
+    return ok ? nvis : BSFM_ERROR;
+}
+
+// wall milliseconds of the last bsfm_run_sfm_ex / run_sfm call of the calling thread: "total", "crs" (vmask -> CRS, of which
+// "crs_upload" / "crs_kernels" when it ran on the device: "crs_on_device" = 1), "create" (bsfm_problem_create: uploads, index
+// construction, allocation), "lm" (all LM iterations), "download" (parameters back + optional export + teardown)
+double bsfm_run_sfm_last_ms(const char* phase)
+{
+    static const char* names[8] = { "total", "crs", "crs_upload", "crs_kernels", "create", "lm", "download", "crs_on_device" };
+    for (int q = 0; q < 8; ++q) if (phase && !strcmp(phase, names[q])) return g_run_ms[q];
+    return -1.0;
 }
 
 int bsfm_sba_motstr_levmar(int n, int m, int mcon, char* vmask, double* p, int cnp, int pnp,
@@ -329,9 +372,39 @@ int bsfm_run_sfm_ex(int num_pts, int num_cameras, int ncons, char* vmask, double
 
     if (est_focal_length && const_focal_length)
         printf("Error: case of constant focal length has not been implemented.\n");   // sfm.c:521-523
-    // 1. vmask -> CRS
+    // 1. vmask -> CRS: on the device for masks of scale (the 500 MB mask of 1 000 cameras x 500 000 points is uploaded once and
+    //    counted / scanned / compacted there), by the host loop for the small calls of incremental reconstruction
+    const auto t_all = std::chrono::steady_clock::now();
+    for (double& v : g_run_ms) v = 0.0;
     std::vector<int> rowptr, colidx;
-    vmask_to_crs(num_pts, num_cameras, vmask, rowptr, colidx);
+    int *d_rp = nullptr, *d_ci = nullptr;                     // device CRS (owned here)
+    struct DevCrsGuard { int*& a; int*& b; ~DevCrsGuard() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } crs_guard{ d_rp, d_ci };
+    bool host_crs = true;
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        const size_t mask_bytes = (size_t)std::max(num_pts, 0) * (size_t)std::max(num_cameras, 0);
+        if (vmask && num_pts > 0 && num_cameras > 0 && mask_bytes >= vmask_device_min() && bsfm_device_count() > 0) {
+            int nvis = 0; double ms3[3] = { 0, 0, 0 };
+            if (bsfm::crs_from_vmask_device(num_pts, num_cameras, vmask, &d_rp, &d_ci, &nvis, ms3, nullptr) == 0) {
+                host_crs = false;
+                g_run_ms[RM_CRS_UPLOAD] = ms3[0]; g_run_ms[RM_CRS_KERNELS] = ms3[1]; g_run_ms[RM_CRS_ON_DEVICE] = 1.0;
+            } else fprintf(stderr, "[bsfm] run_sfm: device-side vmask -> CRS failed, using the host loop\n");
+        }
+        if (host_crs) vmask_to_crs(num_pts, num_cameras, vmask, rowptr, colidx);
+        g_run_ms[RM_CRS] = ms_since(t0);
+    }
+    // host copies of a device-built CRS, only for the paths that index with them on the host (multi-GPU sharding, W export)
+    auto need_host_crs = [&]() -> bool {
+        if (host_crs) return true;
+        int nvis = 0;
+        rowptr.resize((size_t)num_pts + 1);
+        if (hipMemcpy(rowptr.data(), d_rp, rowptr.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return false;
+        nvis = rowptr[num_pts];
+        colidx.resize((size_t)nvis);
+        if (nvis && hipMemcpy(colidx.data(), d_ci, (size_t)nvis * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return false;
+        host_crs = true;
+        return true;
+    };
 
     // more than one GPU asked for (opt.num_gpus / BSFM_NUM_GPUS; -1 = all visible): shard the points inside this process.  The
     // camera-only refinement and the covariance export stay on one GPU.
@@ -344,6 +417,7 @@ int bsfm_run_sfm_ex(int num_pts, int num_cameras, int ncons, char* vmask, double
             if (G > ndev && !share) { fprintf(stderr, "[bsfm] run_sfm: %d GPUs asked for, %d visible: using %d\n", G, ndev, ndev); G = ndev; devs.resize((size_t)G); }
             for (int g = 0; g < G; ++g) devs[g] = g % ndev;
             if (G > 1) {
+                if (!need_host_crs()) return BSFM_ERROR;
                 MultiArgs a = { num_pts, num_cameras, ncons, &rowptr, &colidx, projections, est_focal_length, undistort, explicit_camera_centers,
                                 init_camera_params, reinterpret_cast<double*>(init_pts), use_constraints, use_point_constraints,
                                 reinterpret_cast<const double*>(points_constraints), point_constraint_weight, optimize_for_fisheye ? 1 : 0 };
@@ -359,7 +433,9 @@ int bsfm_run_sfm_ex(int num_pts, int num_cameras, int ncons, char* vmask, double
     bsfm_problem_desc_t d;
     memset(&d, 0, sizeof(d));
     d.n = num_pts; d.m = num_cameras; d.mcon = ncons;
-    d.rowptr = rowptr.data(); d.colidx = colidx.data(); d.projections = projections;
+    if (host_crs) { d.rowptr = rowptr.data(); d.colidx = colidx.data(); }
+    else { d.rowptr = d_rp; d.colidx = d_ci; d.arrays_on_device = BSFM_INDEX_ON_DEVICE; }
+    d.projections = projections;
     d.est_focal_length = est_focal_length; d.undistort = undistort; d.explicit_camera_centers = explicit_camera_centers;
     d.cameras = init_camera_params; d.points = reinterpret_cast<const double*>(init_pts);
     d.use_constraints = use_constraints; d.use_point_constraints = use_point_constraints;
@@ -369,22 +445,32 @@ int bsfm_run_sfm_ex(int num_pts, int num_cameras, int ncons, char* vmask, double
     d.optimize_for_fisheye = optimize_for_fisheye ? 1 : 0;   // sfm.c:819-851
     d.world_size = 1; d.rank = 0;
 
+    const auto t_cr = std::chrono::steady_clock::now();
     bsfm_problem_t* pb = bsfm_problem_create(&d, &opt);
     if (!pb) return BSFM_ERROR;
+    g_run_ms[RM_CREATE] = ms_since(t_cr);
+    const auto t_lm = std::chrono::steady_clock::now();
     int rc = bsfm_lm_begin(pb);
     if (rc == 0) bsfm_lm_iterate(pb, opt.itmax);
     rc = bsfm_lm_finish(pb, info);
+    g_run_ms[RM_LM] = ms_since(t_lm);
     if (opt.verbose >= 1) {
         printf("[run_sfm] Number of iterations: %d\n", (int)info[5]);   // sfm.c:872-873
         printf("info[6] = %0.3f\n", info[6]);
     }
     const int cnp = bsfm_problem_cnp(pb);
+    const auto t_dl = std::chrono::steady_clock::now();
     if (rc != BSFM_ERROR || info[5] > 0) {
         // the reference copies the parameter vector back unconditionally (sfm.c:876-929)
         bsfm_problem_download(pb, nullptr, init_camera_params, fix_points ? nullptr : reinterpret_cast<double*>(init_pts));
     }
-    if (!fix_points) export_blocks(pb, num_pts, ncons, cnp, rowptr, colidx, Vout, Sout, Uout, Wout);
+    if (!fix_points && (Vout || Sout || Uout || Wout)) {
+        if (Sout && Wout && !need_host_crs()) { bsfm_problem_destroy(pb); return BSFM_ERROR; }
+        export_blocks(pb, num_pts, ncons, cnp, rowptr, colidx, Vout, Sout, Uout, Wout);
+    }
     bsfm_problem_destroy(pb);
+    g_run_ms[RM_DOWNLOAD] = ms_since(t_dl);
+    g_run_ms[RM_TOTAL] = ms_since(t_all);
     return rc;
 }
 

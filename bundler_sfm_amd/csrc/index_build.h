@@ -53,4 +53,10 @@ int compact_points_device(int n, int nvis, const int* d_rowptr, const int* d_obs
 // dst[remap[i]] = src[i] for the kept rows of a per-point array with rows of width_bytes
 int gather_kept_device(int n, const int* d_remap, int width_bytes, const void* src, void* dst, hipStream_t st);
 
+// Dense visibility mask (host, n*m bytes, row-major, the reference's vmask) -> CRS ON THE DEVICE: uploads the mask and builds
+// rowptr (n + 1) / colidx (nvis) there (device arrays owned by the caller, hipFree).  Bit-identical to the reference's fill loop
+// (lib/sba-1.5/sba_levmar.c:642-663).  ms_out (optional): upload / kernels / total wall milliseconds.  Returns 0 or -1.
+int crs_from_vmask_device(int n, int m, const char* h_vmask, int** d_rowptr_out, int** d_colidx_out, int* nvis_out, double ms_out[3],
+                          hipStream_t st);
+
 }  // namespace bsfm

@@ -14,9 +14,10 @@
 // 1 000 cameras / 5 M observations, paid by every run_sfm call); here it is a handful of kernels plus rocPRIM's stable radix
 // sort / scan / run-length primitives (through the hipcub headers), a few milliseconds.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include "prim.hip.h"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <climits>
 #include <algorithm>
 #include <mutex>
@@ -170,28 +171,52 @@ __global__ void k_launch_order(int ntasks, int nwg, const SchurTask* __restrict_
 // Temporaries of one build come from the device's stream-ordered memory pool (hipMallocAsync): the pool keeps what it is given
 // back (release threshold = unlimited, set once), so the ~0.9 GB of sort buffers cost an allocation only on the FIRST run_sfm
 // call of a process -- an incremental reconstruction calls run_sfm hundreds of times.  Freed on every exit path.
+// Temporaries come from a PRIVATE stream-ordered pool per device (release threshold unlimited, so the ~0.9 GB of sort buffers of one
+// problem_create are still there for the next run_sfm call).  Round 2 raised the threshold of the process-wide DEFAULT pool instead,
+// which changed the host application's own allocation behaviour; the default pool is no longer touched.
+inline hipMemPool_t scratch_pool()
+{
+    static hipMemPool_t pools[64] = {};
+    static std::once_flag once[64];
+    int dev = 0; (void)hipGetDevice(&dev);
+    const int slot = dev & 63;
+    std::call_once(once[slot], [dev, slot] {
+        hipMemPoolProps props;
+        memset(&props, 0, sizeof(props));
+        props.allocType = hipMemAllocationTypePinned;
+        props.handleTypes = hipMemHandleTypeNone;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = dev;
+        hipMemPool_t pool = nullptr;
+        if (hipMemPoolCreate(&pool, &props) == hipSuccess && pool) {
+            unsigned long long thr = ~0ULL;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+            pools[slot] = pool;
+        } else (void)hipGetLastError();          // no private pool: plain hipMallocAsync on the default pool, untouched
+    });
+    return pools[slot];
+}
+
 struct Scratch {
     hipStream_t st = nullptr;
+    hipMemPool_t pool = nullptr;
     std::vector<void*> ptrs;
-    explicit Scratch(hipStream_t s) : st(s)
-    {
-        static std::once_flag once[64];
-        int dev = 0; (void)hipGetDevice(&dev);
-        std::call_once(once[dev & 63], [dev] {
-            hipMemPool_t pool = nullptr;
-            if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
-                unsigned long long thr = ~0ULL;
-                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
-            }
-        });
-    }
+    explicit Scratch(hipStream_t s) : st(s), pool(scratch_pool()) {}
     ~Scratch() { for (void* p : ptrs) if (p) (void)hipFreeAsync(p, st); }
     template <typename T> hipError_t alloc(T** p, size_t count)
     {
-        hipError_t e = hipMallocAsync(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T), st);
+        const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+        hipError_t e = pool ? hipMallocFromPoolAsync(reinterpret_cast<void**>(p), bytes, pool, st) : hipMallocAsync(reinterpret_cast<void**>(p), bytes, st);
         if (e == hipSuccess) ptrs.push_back(*p);
         return e;
     }
+};
+
+// destroys its events on every exit path (the early returns of build_index_device leaked them)
+struct EventPair {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    EventPair() { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); }
+    ~EventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
 };
 
 template <typename T> hipError_t keep(T** p, size_t count) { return hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T)); }
@@ -219,19 +244,19 @@ int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int
     unsigned long long* vals_out = reinterpret_cast<unsigned long long*>(ix.triples);
     const int kbits = bits_for((unsigned long long)mm * (unsigned long long)mm - 1ULL);
     size_t tb = 0;
-    IX_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys_in, keys_out, vals_in, vals_out, (int)nt, 0, kbits, st));
+    IX_OK(prim::sort_pairs(nullptr, tb, keys_in, keys_out, vals_in, vals_out, (int)nt, 0, kbits, st));
     void* d_tmp = nullptr;
     IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_tmp), tb));
-    IX_OK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, keys_in, keys_out, vals_in, vals_out, (int)nt, 0, kbits, st));
+    IX_OK(prim::sort_pairs(d_tmp, tb, keys_in, keys_out, vals_in, vals_out, (int)nt, 0, kbits, st));
     // blocks = runs of equal keys
     KeyT* ukeys = keys_in;                     // reuse: the unsorted keys are no longer needed
     int *counts = nullptr, *nruns = nullptr;
     IX_OK(tmp.alloc(&counts, nt + 1)); IX_OK(tmp.alloc(&nruns, 1));
     size_t rb = 0;
-    IX_OK(hipcub::DeviceRunLengthEncode::Encode(nullptr, rb, keys_out, ukeys, counts, nruns, (int)nt, st));
+    IX_OK(prim::run_length_encode(nullptr, rb, keys_out, ukeys, counts, nruns, (int)nt, st));
     void* d_rle = nullptr;
     IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_rle), rb));
-    IX_OK(hipcub::DeviceRunLengthEncode::Encode(d_rle, rb, keys_out, ukeys, counts, nruns, (int)nt, st));
+    IX_OK(prim::run_length_encode(d_rle, rb, keys_out, ukeys, counts, nruns, (int)nt, st));
     int nblk = 0;
     IX_OK(hipMemcpyAsync(&nblk, nruns, sizeof(int), hipMemcpyDeviceToHost, st));
     IX_OK(hipStreamSynchronize(st));
@@ -243,11 +268,11 @@ int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int
     IX_OK(hipMemsetAsync(counts + nblk, 0, sizeof(int), st));          // counts has nt + 1 >= nblk + 1 entries
     hipLaunchKernelGGL((k_blocks<KeyT>), dim3(grid_for(nblk, 256)), dim3(256), 0, st, nblk, mcon, mm, ukeys, counts, ix.blk_j, ix.blk_k, ntask);
     size_t sb = 0;
-    IX_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, ntask, ix.blk_task0, nblk + 1, st));
+    IX_OK(prim::exclusive_sum(nullptr, sb, ntask, ix.blk_task0, nblk + 1, st));
     void* d_scan = nullptr;
     IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_scan), sb));
-    IX_OK(hipcub::DeviceScan::ExclusiveSum(d_scan, sb, ntask, ix.blk_task0, nblk + 1, st));
-    IX_OK(hipcub::DeviceScan::ExclusiveSum(d_scan, sb, counts, blk_start, nblk + 1, st));
+    IX_OK(prim::exclusive_sum(d_scan, sb, ntask, ix.blk_task0, nblk + 1, st));
+    IX_OK(prim::exclusive_sum(d_scan, sb, counts, blk_start, nblk + 1, st));
     int ntasks = 0;
     IX_OK(hipMemcpyAsync(&ntasks, ix.blk_task0 + nblk, sizeof(int), hipMemcpyDeviceToHost, st));
     IX_OK(hipStreamSynchronize(st));
@@ -266,10 +291,10 @@ int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int
         hipLaunchKernelGGL(k_iota, dim3(grid_for(ntasks, 256)), dim3(256), 0, st, ntasks, id_in);
         size_t ob = 0;
         const int pbits = bits_for((unsigned long long)std::max(n, 1) - 1ULL);
-        IX_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, ob, tk_in, tk_out, id_in, ord, ntasks, 0, pbits, st));
+        IX_OK(prim::sort_pairs(nullptr, ob, tk_in, tk_out, id_in, ord, ntasks, 0, pbits, st));
         void* d_ob = nullptr;
         IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_ob), ob));
-        IX_OK(hipcub::DeviceRadixSort::SortPairs(d_ob, ob, tk_in, tk_out, id_in, ord, ntasks, 0, pbits, st));
+        IX_OK(prim::sort_pairs(d_ob, ob, tk_in, tk_out, id_in, ord, ntasks, 0, pbits, st));
         const int nwg = (ntasks + 3) / 4;
         ix.nslots = nwg * 4;
         IX_OK(keep(&ix.tasks, (size_t)ix.nslots));
@@ -346,10 +371,10 @@ int merge_observations_device(int n_new, int m_new, int nvis, const int* d_obs_p
                            d_add_pt, d_add_cam, keys, vals, flag);
         size_t tb = 0;
         const int kbits = bits_for((unsigned long long)n_new * (unsigned long long)m_new);
-        IX_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys, keys_s, vals, vals_s, total, 0, kbits, st));
+        IX_OK(prim::sort_pairs(nullptr, tb, keys, keys_s, vals, vals_s, total, 0, kbits, st));
         void* d_tmp = nullptr;
         IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_tmp), tb));
-        IX_OK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, keys, keys_s, vals, vals_s, total, 0, kbits, st));
+        IX_OK(prim::sort_pairs(d_tmp, tb, keys, keys_s, vals, vals_s, total, 0, kbits, st));
         hipLaunchKernelGGL(k_merge_scatter, dim3(grid_for((size_t)total, 256)), dim3(256), 0, st, total, nvis, m_new, keys_s, vals_s, d_x, d_add_xy,
                            *colidx_out, *x_out, flag);
     }
@@ -418,11 +443,11 @@ int compact_points_device(int n, int nvis, const int* d_rowptr, const int* d_obs
     IX_OK(tmp.alloc(&pk, (size_t)n + 1)); IX_OK(tmp.alloc(&oc, (size_t)n + 1)); IX_OK(tmp.alloc(&pnew, (size_t)n + 1)); IX_OK(tmp.alloc(&onew, (size_t)n + 1));
     hipLaunchKernelGGL(k_keep_counts, dim3(grid_for((size_t)n + 1, 256)), dim3(256), 0, st, n, d_rowptr, d_remove, pk, oc);
     size_t sb = 0;
-    IX_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, pk, pnew, n + 1, st));
+    IX_OK(prim::exclusive_sum(nullptr, sb, pk, pnew, n + 1, st));
     void* d_scan = nullptr;
     IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_scan), sb));
-    IX_OK(hipcub::DeviceScan::ExclusiveSum(d_scan, sb, pk, pnew, n + 1, st));
-    IX_OK(hipcub::DeviceScan::ExclusiveSum(d_scan, sb, oc, onew, n + 1, st));
+    IX_OK(prim::exclusive_sum(d_scan, sb, pk, pnew, n + 1, st));
+    IX_OK(prim::exclusive_sum(d_scan, sb, oc, onew, n + 1, st));
     int h[2] = { 0, 0 };
     IX_OK(hipMemcpyAsync(&h[0], pnew + n, sizeof(int), hipMemcpyDeviceToHost, st));
     IX_OK(hipMemcpyAsync(&h[1], onew + n, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -459,8 +484,8 @@ int build_index_device(int n, int m, int mcon, int nvis, const int* d_rowptr, co
     // rocPRIM checks hipGetLastError() after its launches: a stale error of an EARLIER, unrelated call in this thread (e.g.
     // hipEventElapsedTime on a never-recorded phase event -> hipErrorInvalidHandle) would be reported as a sort failure
     (void)hipGetLastError();
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    EventPair evp;
+    hipEvent_t e0 = evp.e0, e1 = evp.e1;
     if (e0) (void)hipEventRecord(e0, st);
     Scratch tmp(st);
     int* flag = nullptr;
@@ -487,19 +512,19 @@ int build_index_device(int n, int m, int mcon, int nvis, const int* d_rowptr, co
         hipLaunchKernelGGL(k_iota, dim3(grid_for(nvis, 256)), dim3(256), 0, st, nvis, iota);
         size_t tb = 0;
         const int cbits = bits_for((unsigned long long)m - 1ULL);
-        IX_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, d_colidx, ix.cam_cam, iota, ix.camobs, nvis, 0, cbits, st));
+        IX_OK(prim::sort_pairs(nullptr, tb, d_colidx, ix.cam_cam, iota, ix.camobs, nvis, 0, cbits, st));
         void* d_tmp = nullptr;
         IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_tmp), tb));
-        IX_OK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_colidx, ix.cam_cam, iota, ix.camobs, nvis, 0, cbits, st));
+        IX_OK(prim::sort_pairs(d_tmp, tb, d_colidx, ix.cam_cam, iota, ix.camobs, nvis, 0, cbits, st));
         hipLaunchKernelGGL(k_cam_maps, dim3(grid_for(nvis, 256)), dim3(256), 0, st, nvis, ix.camobs, ix.obs_pt, ix.campos, ix.cam_pt);
     }
     hipLaunchKernelGGL(k_camptr, dim3(grid_for((size_t)m + 1, 256)), dim3(256), 0, st, m, nvis, ix.cam_cam, ix.camptr);
     if (want_schur) {
         size_t sb = 0;
-        IX_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, sb, tcount, toff, n + 1, st));
+        IX_OK(prim::exclusive_sum(nullptr, sb, tcount, toff, n + 1, st));
         void* d_scan = nullptr;
         IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_scan), sb));
-        IX_OK(hipcub::DeviceScan::ExclusiveSum(d_scan, sb, tcount, toff, n + 1, st));
+        IX_OK(prim::exclusive_sum(d_scan, sb, tcount, toff, n + 1, st));
         long long total = 0;
         IX_OK(hipMemcpyAsync(&total, toff + n, sizeof(long long), hipMemcpyDeviceToHost, st));
         IX_OK(hipStreamSynchronize(st));
@@ -517,8 +542,135 @@ int build_index_device(int n, int m, int mcon, int nvis, const int* d_rowptr, co
         float ms = 0.f;
         if (e0 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ix.build_ms = ms;
     } else IX_OK(hipStreamSynchronize(st));
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
+    return 0;
+}
+
+// ---- dense visibility mask -> CRS on the device ------------------------------------------
+// The reference's contract (lib/sba-1.5/sba_levmar.c:642-663): the k-th non-zero byte of vmask in row-major order is measurement k;
+// rowptr[i] = number of non-zero bytes before row i, colidx[k] = column of the k-th one.  At 1 000 cameras / 500 000 points the mask
+// is 500 MB and round 2 scanned it twice, byte by byte, on one host thread.  Here the mask is treated as ONE flat byte string of
+// n*m bytes (independent of m): pass 1 counts the non-zero bytes of every 4 KB piece (one 256-thread workgroup) (16 bytes per lane, SWAR test on the four
+// words), rocPRIM scans the piece counts, pass 2 repeats the count inside the piece (wave prefix by DPP-free shuffles + a 4-entry
+// LDS scan), writes the column of every set byte to its slot and the row pointer of every row that starts inside the lane's 16
+// bytes.  Integer work, bit-identical to the host loop (tests/test_index.py).
+namespace {
+
+__device__ __forceinline__ unsigned nz_mask(unsigned w)          // bit 7 of every non-zero byte
+{
+    return (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u;
+}
+
+
+__global__ __launch_bounds__(256) void k_vmask_count(const uint4* __restrict__ vm, size_t nwords16, int* __restrict__ piece_count)
+{
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int c = 0;
+    if (q < nwords16) {
+        const uint4 w = vm[q];
+        c = __popc(nz_mask(w.x)) + __popc(nz_mask(w.y)) + __popc(nz_mask(w.z)) + __popc(nz_mask(w.w));
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    __shared__ int ws[4];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) piece_count[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ __launch_bounds__(256) void k_vmask_fill(const uint4* __restrict__ vm, size_t nwords16, size_t total_bytes, int n, int m,
+                                                    const int* __restrict__ piece_off, int* __restrict__ rowptr, int* __restrict__ colidx)
+{
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned wd[4] = { 0u, 0u, 0u, 0u };
+    if (q < nwords16) { const uint4 w = vm[q]; wd[0] = w.x; wd[1] = w.y; wd[2] = w.z; wd[3] = w.w; }
+    unsigned mk[4];
+    int c = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { mk[t] = nz_mask(wd[t]); c += __popc(mk[t]); }
+    // exclusive prefix of c over the workgroup
+    int incl = c;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    __shared__ int ws[4];
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    int base = piece_off[blockIdx.x];
+    for (int w2 = 0; w2 < wave; ++w2) base += ws[w2];
+    int k = base + incl - c;                          // slot of this lane's first set byte
+    if (q >= nwords16) return;
+    const size_t b0 = q * 16;                         // first byte of this lane
+    // row pointers of the rows that start inside [b0, b0 + 16): rowptr[i] = set bytes before byte i*m
+    {
+        size_t i = (b0 + (size_t)m - 1) / (size_t)m;
+        for (; i <= (size_t)n && i * (size_t)m < b0 + 16; ++i) {
+            const int off = (int)(i * (size_t)m - b0);          // 0 .. 15
+            int before = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int lo = 4 * t;
+                if (off >= lo + 4) before += __popc(mk[t]);
+                else if (off > lo) before += __popc(mk[t] & ((1u << (8 * (off - lo))) - 1u));
+            }
+            rowptr[i] = k + before;
+        }
+    }
+    if (c == 0) return;
+    unsigned col = (unsigned)(b0 % (size_t)m);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (b0 + 4 * t + b < total_bytes && (mk[t] >> (8 * b + 7)) & 1u) colidx[k++] = (int)col;
+            if (++col == (unsigned)m) col = 0;
+        }
+}
+
+}  // namespace
+
+int crs_from_vmask_device(int n, int m, const char* h_vmask, int** d_rowptr_out, int** d_colidx_out, int* nvis_out, double ms_out[3],
+                          hipStream_t st)
+{
+    (void)hipGetLastError();
+    *d_rowptr_out = nullptr; *d_colidx_out = nullptr; *nvis_out = 0;
+    if (ms_out) ms_out[0] = ms_out[1] = ms_out[2] = 0.0;
+    const size_t total = (size_t)n * (size_t)m;
+    const size_t nwords16 = (total + 15) / 16, padded = nwords16 * 16;
+    const size_t npieces = std::max<size_t>(1, (nwords16 + 255) / 256);
+    if (npieces > (size_t)INT_MAX) { fprintf(stderr, "[bsfm] visibility mask too large\n"); return -1; }
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    Scratch tmp(st);
+    char* d_vm = nullptr; int* d_cnt = nullptr; int* d_off = nullptr;
+    IX_OK(tmp.alloc(&d_vm, padded)); IX_OK(tmp.alloc(&d_cnt, npieces + 1)); IX_OK(tmp.alloc(&d_off, npieces + 1));
+    if (padded > total) IX_OK(hipMemsetAsync(d_vm + (padded - 16), 0, 16, st));
+    if (total) IX_OK(hipMemcpyAsync(d_vm, h_vmask, total, hipMemcpyHostToDevice, st));
+    IX_OK(hipStreamSynchronize(st));
+    if (ms_out) ms_out[0] = ms_since(t0);                               // upload (pageable host memory: staged by the runtime)
+    const auto t1 = std::chrono::steady_clock::now();
+    IX_OK(hipMemsetAsync(d_cnt + npieces, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_vmask_count, dim3((unsigned)npieces), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_vm), nwords16, d_cnt);
+    size_t sb = 0;
+    IX_OK(prim::exclusive_sum(nullptr, sb, d_cnt, d_off, npieces + 1, st));
+    void* d_scan = nullptr;
+    IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_scan), sb));
+    IX_OK(prim::exclusive_sum(d_scan, sb, d_cnt, d_off, npieces + 1, st));
+    int nvis = 0;
+    IX_OK(hipMemcpyAsync(&nvis, d_off + npieces, sizeof(int), hipMemcpyDeviceToHost, st));
+    IX_OK(hipStreamSynchronize(st));
+    if (nvis < 0) { fprintf(stderr, "[bsfm] visibility mask: more than 2^31-1 observations\n"); return -1; }
+    int *rp = nullptr, *ci = nullptr;
+    IX_OK(keep(&rp, (size_t)n + 1));
+    if (keep(&ci, (size_t)nvis) != hipSuccess) { (void)hipFree(rp); return -1; }
+    hipLaunchKernelGGL(k_vmask_fill, dim3((unsigned)npieces), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_vm), nwords16, total, n, m,
+                       d_off, rp, ci);
+    // rows that start at or beyond the last byte (only i = n when n*m is a multiple of 16, and every row of an empty mask) point at nvis
+    if ((size_t)n * (size_t)m >= padded || total == 0) {
+        const int last = nvis;
+        if (total == 0) { std::vector<int> z((size_t)n + 1, 0); if (hipMemcpyAsync(rp, z.data(), z.size() * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(rp); (void)hipFree(ci); return -1; } }
+        else if (hipMemcpyAsync(rp + n, &last, sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) { (void)hipFree(rp); (void)hipFree(ci); return -1; }
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(rp); (void)hipFree(ci); return -1; }
+    if (ms_out) { ms_out[1] = ms_since(t1); ms_out[2] = ms_since(t0); }
+    *d_rowptr_out = rp; *d_colidx_out = ci; *nvis_out = nvis;
     return 0;
 }
 

@@ -513,10 +513,12 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     if (!d || d->n < 0 || d->m <= 0 || d->mcon < 0 || d->mcon > d->m) { fprintf(stderr, "[bsfm] bad problem description\n"); return nullptr; }
     if (!d->rowptr || !d->cameras || (d->n > 0 && (!d->points && !d->p_packed))) { fprintf(stderr, "[bsfm] bad problem description: rowptr / cameras / points missing\n"); return nullptr; }
     int rp_ends[2] = { 0, 0 };              // rowptr[0], rowptr[n] (the arrays may already live on the device)
-    if (d->arrays_on_device) {
+    const bool index_dev = d->arrays_on_device != 0;                        // rowptr / colidx are device pointers
+    const bool data_dev = d->arrays_on_device == BSFM_ARRAYS_ON_DEVICE;     // ... projections and points as well
+    if (index_dev) {
         if (hipMemcpy(&rp_ends[0], d->rowptr, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(&rp_ends[1], d->rowptr + d->n, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { fprintf(stderr, "[bsfm] bad problem description: device rowptr unreadable\n"); return nullptr; }
-        if (d->use_point_constraints && d->point_constraints) { fprintf(stderr, "[bsfm] bad problem description: point constraints cannot be combined with arrays_on_device\n"); return nullptr; }
+        if (data_dev && d->use_point_constraints && d->point_constraints) { fprintf(stderr, "[bsfm] bad problem description: point constraints cannot be combined with arrays_on_device\n"); return nullptr; }
     } else { rp_ends[0] = d->rowptr[0]; rp_ends[1] = d->rowptr[d->n]; }
     if (rp_ends[0] != 0 || rp_ends[1] < 0) { fprintf(stderr, "[bsfm] bad problem description: rowptr[0] must be 0 and rowptr[n] >= 0\n"); return nullptr; }
     if (rp_ends[1] > 0 && (!d->colidx || !d->projections)) { fprintf(stderr, "[bsfm] bad problem description: colidx / projections missing\n"); return nullptr; }
@@ -554,11 +556,12 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     pb->own_stream = true;
 #define DM(ptr, cnt) if (dmalloc(&ptr, (size_t)(cnt)) != hipSuccess) return fail("hipMalloc " #ptr)
     auto up = [&](void* dst, const void* src, size_t bytes) { return bytes == 0 || hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess; };
-    auto up_any = [&](void* dst, const void* src, size_t bytes) { return bytes == 0 || hipMemcpy(dst, src, bytes, d->arrays_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) == hipSuccess; };
+    auto up_any = [&](void* dst, const void* src, size_t bytes) { return bytes == 0 || hipMemcpy(dst, src, bytes, data_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) == hipSuccess; };
+    auto up_idx = [&](void* dst, const void* src, size_t bytes) { return bytes == 0 || hipMemcpy(dst, src, bytes, index_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) == hipSuccess; };
     // ---- index bookkeeping (bit-exact integer work, built on the device from the caller's CRS; index_build.hip)
     const auto t_up0 = std::chrono::steady_clock::now();
     DM(pb->d_rowptr, n + 1); DM(pb->d_obs_cam, nvis); DM(pb->d_x, 2 * (size_t)nvis);
-    if (!(up_any(pb->d_rowptr, d->rowptr, ((size_t)n + 1) * sizeof(int)) && up_any(pb->d_obs_cam, d->colidx, (size_t)nvis * sizeof(int)) &&
+    if (!(up_idx(pb->d_rowptr, d->rowptr, ((size_t)n + 1) * sizeof(int)) && up_idx(pb->d_obs_cam, d->colidx, (size_t)nvis * sizeof(int)) &&
           up_any(pb->d_x, d->projections, 2 * (size_t)nvis * sizeof(double)))) return fail("upload of the visibility index");
     pb->create_ms[1] = ms_since(t_up0);
     {
@@ -609,9 +612,9 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     }
     std::vector<double> p;
     if (d->p_packed) p.assign(d->p_packed, d->p_packed + (size_t)m * cnp + (size_t)3 * n);
-    else pack_params(pb, d->cameras, d->arrays_on_device ? nullptr : d->points, n, p);
+    else pack_params(pb, d->cameras, data_dev ? nullptr : d->points, n, p);
     ok = ok && up(pb->d_p, p.data(), p.size() * sizeof(double));
-    if (d->arrays_on_device && !d->p_packed) ok = ok && up_any(pb->d_p + (size_t)m * cnp, d->points, 3 * (size_t)n * sizeof(double));
+    if (data_dev && !d->p_packed) ok = ok && up_any(pb->d_p + (size_t)m * cnp, d->points, 3 * (size_t)n * sizeof(double));
     pb->h_cams.assign(d->cameras, d->cameras + m);
     pb->desc0 = *d;
     pb->desc0.rowptr = nullptr; pb->desc0.colidx = nullptr; pb->desc0.projections = nullptr; pb->desc0.cameras = nullptr; pb->desc0.points = nullptr;

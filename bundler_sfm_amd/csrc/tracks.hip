@@ -18,7 +18,7 @@
 // Precondition (what PruneDoubleMatches, src/MatchTracks.cpp:394-440, and the matcher guarantee): inside a pair every key index occurs at most
 // once on either side -- otherwise the reference's own result depends on the order std::sort leaves equal elements in; refused loudly.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include "prim.hip.h"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -226,10 +226,10 @@ extern "C" int bsfm_compute_tracks(int num_images, const int* num_keys, int num_
     {   // adjacency: edges sorted by (source, destination)
         size_t tb = 0;
         const int kbits = 32 + bits_for((unsigned long long)F);
-        TK_OK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, d_ek, d_ek2, E2, 0, kbits, st));
+        TK_OK(bsfm::prim::sort_keys(nullptr, tb, d_ek, d_ek2, E2, 0, kbits, st));
         char* d_tmp = nullptr;
         TK_OK(B.alloc(&d_tmp, tb));
-        TK_OK(hipcub::DeviceRadixSort::SortKeys(d_tmp, tb, d_ek, d_ek2, E2, 0, kbits, st));
+        TK_OK(bsfm::prim::sort_keys(d_tmp, tb, d_ek, d_ek2, E2, 0, kbits, st));
     }
     int hflag[4] = { 0, 0, 0, 0 };
     TK_OK(hipMemcpy(hflag, d_flag, sizeof(hflag), hipMemcpyDeviceToHost));
@@ -257,10 +257,10 @@ extern "C" int bsfm_compute_tracks(int num_images, const int* num_keys, int num_
     hipLaunchKernelGGL(k_node_keys, dim3(grid_for((size_t)F, 256)), dim3(256), 0, st, F, d_adj, d_label, d_nk1);
     {
         size_t tb = 0;
-        TK_OK(hipcub::DeviceRadixSort::SortKeys(nullptr, tb, d_nk1, d_nk2, F, 0, 64, st));
+        TK_OK(bsfm::prim::sort_keys(nullptr, tb, d_nk1, d_nk2, F, 0, 64, st));
         char* d_tmp = nullptr;
         TK_OK(B.alloc(&d_tmp, tb));
-        TK_OK(hipcub::DeviceRadixSort::SortKeys(d_tmp, tb, d_nk1, d_nk2, F, 0, 64, st));
+        TK_OK(bsfm::prim::sort_keys(d_tmp, tb, d_nk1, d_nk2, F, 0, 64, st));
     }
     // number of nodes = features with matches (their keys sort ahead of the ~0 fillers): count on the host from adj_ptr is not available
     // without a download, so count the edges' distinct sources with a tiny reduction: nnodes = #(adj rows non-empty)
@@ -276,10 +276,10 @@ extern "C" int bsfm_compute_tracks(int num_images, const int* num_keys, int num_
         for (int t = 0; t < nnodes; ++t) iota[t] = t;
         TK_OK(hipMemcpy(d_iota, iota.data(), iota.size() * sizeof(int), hipMemcpyHostToDevice));
         size_t tb = 0;
-        TK_OK(hipcub::DeviceSelect::Flagged(nullptr, tb, d_iota, d_start, d_cstart, d_cnt, nnodes, st));
+        TK_OK(bsfm::prim::select_flagged(nullptr, tb, d_iota, d_start, d_cstart, d_cnt, nnodes, st));
         char* d_tmp = nullptr;
         TK_OK(B.alloc(&d_tmp, tb));
-        TK_OK(hipcub::DeviceSelect::Flagged(d_tmp, tb, d_iota, d_start, d_cstart, d_cnt, nnodes, st));
+        TK_OK(bsfm::prim::select_flagged(d_tmp, tb, d_iota, d_start, d_cstart, d_cnt, nnodes, st));
     }
     int ncomp = 0;
     TK_OK(hipMemcpy(&ncomp, d_cnt, sizeof(int), hipMemcpyDeviceToHost));
@@ -294,10 +294,10 @@ extern "C" int bsfm_compute_tracks(int num_images, const int* num_keys, int num_
     hipLaunchKernelGGL(k_track_keys, dim3(grid_for((size_t)nnodes, 256)), dim3(256), 0, st, nnodes, d_seg, d_out, d_tk1);
     {
         size_t tb = 0;
-        TK_OK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, d_tk1, d_tk2, d_iota, d_pos, nnodes, 0, 64, st));
+        TK_OK(bsfm::prim::sort_pairs(nullptr, tb, d_tk1, d_tk2, d_iota, d_pos, nnodes, 0, 64, st));
         char* d_tmp = nullptr;
         TK_OK(B.alloc(&d_tmp, tb));
-        TK_OK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_tk1, d_tk2, d_iota, d_pos, nnodes, 0, 64, st));
+        TK_OK(bsfm::prim::sort_pairs(d_tmp, tb, d_tk1, d_tk2, d_iota, d_pos, nnodes, 0, 64, st));
     }
     std::vector<int> h_seg((size_t)nnodes);
     TK_OK(hipMemcpy(h_seg.data(), d_seg, h_seg.size() * sizeof(int), hipMemcpyDeviceToHost));
@@ -310,10 +310,10 @@ extern "C" int bsfm_compute_tracks(int num_images, const int* num_keys, int num_
     hipLaunchKernelGGL(k_track_len, dim3(grid_for((size_t)ntracks + 1, 256)), dim3(256), 0, st, ntracks, d_pos, d_seg, d_len);
     {
         size_t tb = 0;
-        TK_OK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, d_len, d_tptr, ntracks + 1, st));
+        TK_OK(bsfm::prim::exclusive_sum(nullptr, tb, d_len, d_tptr, ntracks + 1, st));
         char* d_tmp = nullptr;
         TK_OK(B.alloc(&d_tmp, tb));
-        TK_OK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, d_len, d_tptr, ntracks + 1, st));
+        TK_OK(bsfm::prim::exclusive_sum(d_tmp, tb, d_len, d_tptr, ntracks + 1, st));
     }
     int* d_views = nullptr;
     TK_OK(B.alloc(&d_views, 2 * (size_t)std::max<long long>(nviews, 1)));

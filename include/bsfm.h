@@ -143,6 +143,8 @@ int bsfm_sba_mot_levmar(int n, int m, int mcon, char *vmask, double *p, int cnp,
 /* ---- 3. resident-problem API ------------------------------------------------------------------------ */
 typedef struct bsfm_problem bsfm_problem_t;
 
+#define BSFM_ARRAYS_ON_DEVICE 1
+#define BSFM_INDEX_ON_DEVICE 2
 typedef struct {
     int n, m, mcon;              /* points, cameras, leading fixed cameras (SBA's mcon) */
     const int *rowptr;           /* n+1: CRS row pointers, one row per point (sba_levmar.c:653-663) */
@@ -172,8 +174,10 @@ typedef struct {
     /* run_sfm's optimize_for_fisheye (sfm.c:819-851): project with sfm_project_point2_fisheye (sfm.c:448-492) -- pinhole
      * without the radial term, then the equidistant map of cameras[j].fisheye/f_cx/f_cy/f_rad/f_angle/f_focal. */
     int optimize_for_fisheye;
-    /* rowptr, colidx, projections and points are DEVICE pointers (data already resident in HBM, e.g. produced by another kernel);
-     * point constraints cannot be combined with it.  cameras always come from the host (504 bytes each). */
+    /* 1 (BSFM_ARRAYS_ON_DEVICE): rowptr, colidx, projections and points are DEVICE pointers (data already resident in HBM, e.g.
+     * produced by another kernel); point constraints cannot be combined with it.  2 (BSFM_INDEX_ON_DEVICE): only rowptr and colidx
+     * are device pointers (run_sfm builds them there from the dense mask), everything else comes from the host.  cameras always
+     * come from the host (504 bytes each). */
     int arrays_on_device;
 } bsfm_problem_desc_t;
 
@@ -247,6 +251,13 @@ int bsfm_problem_schur_sizes(const bsfm_problem_t *pb, int *ntriples, int *nblk,
 int bsfm_problem_export_schur(bsfm_problem_t *pb, int *triples, int *tri_pt, int *blk_j, int *blk_k, int *blk_task0, int *tasks);
 /* dense vmask -> CRS exactly as run_sfm does it (host only); returns nvis, rowptr / colidx may be NULL. */
 int bsfm_crs_from_vmask(int n, int m, const char *vmask, int *rowptr, int *colidx);
+/* The same CRS built ON THE DEVICE (what run_sfm does for masks of at least 1 MB, BSFM_VMASK_DEVICE_MIN: upload, count / scan /
+ * compaction kernels; replaces the two single-thread passes over the n*m bytes of lib/sba-1.5/sba_levmar.c:642-663) and copied
+ * back; bit-identical to bsfm_crs_from_vmask.  ms_out (3 doubles or NULL): upload / kernels / total wall ms.  Needs a HIP device. */
+int bsfm_crs_from_vmask_device(int n, int m, const char *vmask, int *rowptr, int *colidx, double *ms_out);
+/* Wall milliseconds of the phases of the calling thread's last run_sfm / bsfm_run_sfm_ex call: "total", "crs" ("crs_upload",
+ * "crs_kernels", "crs_on_device"), "create", "lm", "download"; -1 for an unknown name. */
+double bsfm_run_sfm_last_ms(const char *phase);
 /* Shrinking a resident problem -- the other half of the RunSFM_SBA outlier loop (src/Bundle.cpp:784-913: the points flagged by
  * the per-camera thresholds are dropped with all their views, then run_sfm runs again; bsfm_problem_outlier_stats delivers the
  * flags): removes the points with remove[i] != 0 (host array, n entries) and every observation of them ON THE DEVICE; the

@@ -44,6 +44,54 @@ def test_crs_from_vmask_is_the_reference_crsm(bsfm, n, m, density, seed):
     assert np.array_equal(r["val"], np.arange(len(ci)))          # val[k] = k: the observation ordering contract
 
 
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("n,m,density,seed", [(300, 40, 0.2, 1), (57, 9, 0.6, 2), (1, 5, 1.0, 3), (1000, 130, 0.03, 4), (4096, 16, 0.5, 5),
+                                              (33, 1, 0.5, 6), (700, 1000, 0.01, 7), (5, 3, 0.0, 8), (64, 64, 1.0, 9)])
+def test_device_crs_from_vmask_is_the_reference_crsm(gpu_bsfm, n, m, density, seed):
+    """run_sfm's vmask -> CRS for masks of scale runs ON THE DEVICE (index_build.hip:crs_from_vmask_device: flat byte string, SWAR
+    non-zero test, piece counts scanned by rocPRIM, compaction): bit-identical to the reference's struct sba_crsm
+    (lib/sba-1.5/sba_levmar.c:653-663 via oracle/_ref) and to the host loop, for row lengths below / at / above the 16-byte lane
+    width, empty rows, an empty mask, a full mask, and total sizes that are and are not multiples of 16."""
+    B = gpu_bsfm
+    vm = random_vmask(np.random.default_rng(seed), n, m, density)
+    if density == 0.0:
+        vm[:] = 0
+    if seed == 4:
+        vm[10:20] = 0                                               # empty rows
+    ip = C.POINTER(C.c_int)
+    rp = np.full(n + 1, -7, np.int32); ci = np.full(max(int((vm != 0).sum()), 1), -7, np.int32)
+    nvis = B.lib.bsfm_crs_from_vmask_device(n, m, vm.ctypes.data_as(C.c_char_p), rp.ctypes.data_as(ip), ci.ctypes.data_as(ip), None)
+    assert nvis == int((vm != 0).sum())
+    hrp, hci = product_crs(B, vm)
+    assert np.array_equal(rp, hrp) and np.array_equal(ci[:nvis], hci)
+    r = O.ref_crsm_index(n, m, vm)
+    assert np.array_equal(rp, r["rowptr"]) and np.array_equal(ci[:nvis], r["colidx"])
+
+
+@pytest.mark.gpu
+def test_run_sfm_through_the_device_crs_equals_the_host_crs(gpu_bsfm):
+    """The drop-in run_sfm with the mask turned into the CRS on the device (forced: BSFM_VMASK_DEVICE_MIN=0 would be read once per
+    process, so the scene is made large enough instead: 2 200 points x 500 cameras = 1.1 MB) gives bit-identical results to the
+    resident-problem API fed with the host CRS."""
+    B = gpu_bsfm
+    m, n = 500, 2200
+    s = B.synth_ba(m, n, 8)
+    vm = B.dense_vmask(n, m, s["rowptr"], s["colidx"])
+    assert vm.size >= (1 << 20)
+    cams = B.copy_cameras(s["cams"]); pts = s["pts"].copy()
+    opt = B.default_options(verbose=0, itmax=3)
+    rc, info = B.run_sfm(n, m, 0, vm, s["proj"], 1, 0, 1, 1, cams, pts, eps2=1e-12, options=opt)
+    assert B.lib.bsfm_run_sfm_last_ms(b"crs_on_device") == 1.0 and B.lib.bsfm_run_sfm_last_ms(b"total") > 0.0
+    opt2 = B.default_options(verbose=0, itmax=3); opt2.opts[2] = 1e-12
+    pb = B.Problem(n, m, s["rowptr"], s["colidx"], s["proj"], s["cams"], s["pts"], options=opt2)
+    rc2, info2 = pb.solve()
+    p, cams2, pts2 = pb.download()
+    pb.close()
+    assert rc == rc2 and list(info) == list(info2)
+    assert np.array_equal(pts, pts2)
+
+
 def schur_restatement(rowptr, colidx, campos, mcon, m):
     """numpy restatement of the order the reference visits the co-visibility pairs in (sba_levmar.c:1182-1268): block (j, k),
     j <= k, and inside a block ascending point index."""
