@@ -99,17 +99,6 @@ struct PotrfWorkspace {
     hipStream_t sd = nullptr;  // side stream: the part of panel k / first trailing column the NEXT diagonal tile does not need
     hipEvent_t* evP = nullptr; hipEvent_t* evU = nullptr;   // panel k complete (side stream) / trailing update k done
     hipEvent_t* evT = nullptr; hipEvent_t* evC = nullptr;   // first panel tile of step k ready (chain) / first trailing column done (side)
-    hipStream_t sb = nullptr;    // split chain: the stream of the explicit inverses
-    hipEvent_t* evB = nullptr;   // split chain: inverse of tile k done
-    hipEvent_t* evA = nullptr;   // split chain: diagonal tile k factored (its explicit inverse follows on the side stream)
-    int pair_min_rows = 0;       // BSFM_SYRK_PAIR=rows: paired (rank-256) bulk launches while at least this many tile rows remain.  Off by default:
-                                 // third attempt at rank-256 (this one with the 16x16x4 loop, 61 vs 44 TFLOP/s for the kernel alone), third loss --
-                                 // 8.67 / 8.83 / 8.99 ms per solve with rows = 50 / 40 / 30 against 8.46: in the factorisation the paired launches
-                                 // reach 43 TFLOP/s, not 61 (two different panels per tile, and their two-round workgroups hold the slots the
-                                 // chain's kernels wait for twice as long)
-    int chain_split = 0;         // BSFM_CHAIN=split: factor-only diagonal kernel, first panel tile by block substitution (k_chain_trsm32), explicit
-                                 // inverse on its own stream.  Opt-in: the chain kernels get shorter (52 + 15.5 -> 37 + 12 us) but the solve gets
-                                 // SLOWER (10.5-11.0 vs 8.55 ms at config 3): see the note at k_chain_trsm32
     double* linv = nullptr;    // nblk tiles: inverse of each diagonal factor tile
     double* y = nullptr;       // ld
     double* xs = nullptr;      // ld
@@ -127,13 +116,7 @@ struct PotrfWorkspace {
     hipEvent_t* sy0 = nullptr; hipEvent_t* sy1 = nullptr; int sy_used = 0;
     double syrk_ms = 0.0; long long syrk_cnt = 0;
     double* sy_flops = nullptr; double syrk_flops = 0.0;     // flops of each timed launch / running sum
-    double* dinv = nullptr;     // panel engine: inverse 16x16 diagonal blocks of every factor tile (8 x 256 doubles per tile)
-    int* eflags = nullptr;      // panel engine: hand-off flags (potrf_engine.hip.h:EngineFlags), 13 nblk + 8 ints
-    int use_engine = 0;         // BSFM_CHOL=engine selects the persistent panel engine (potrf_engine.hip.h); default: the stream schedule
-    int engine_workers = 24;    // BSFM_CHOL_WORKERS
-    int engine_attr_set = 0;
     int syrk_events = 1;        // HIP-event timing of every n-th bulk launch (BSFM_SYRK_EVENTS=n; 0 = none)
-    long long* edbg = nullptr;  // BSFM_DEBUG_ENGINE=1: 8 stamps per tile column
     int syrk_nt = 0;            // non-temporal C traffic in the bulk kernel (BSFM_SYRK_NT=1; measured neutral: 8.44 vs 8.52 ms per solve)
     long long* dbg = nullptr;   // optional device buffer: cycle stamps of k_potrf_diag phases (BSFM_DEBUG_DIAG=1)
 };
@@ -342,8 +325,6 @@ __global__ __launch_bounds__(256, 1) void k_trsm_panel64(double* __restrict__ S,
 }
 
 // First trailing column, two halves per tile: S_{k+1+a, k+1} -= P_a P_0^T.
-// cofs = 1 (paired bulk launches, see potrf_solve): the SECOND trailing column, S_{k+1+a, k+2} -= P_a P_1^T for a >= 2 (launched with
-// a0 = 2 and without the forward-substitution workgroups).
 __global__ __launch_bounds__(256, 1) void k_syrk_col64(double* __restrict__ S, int ld, int k, const double* __restrict__ panel,
         int a0, int ngemm, double* __restrict__ E, const double* __restrict__ y, int cofs)
 {
@@ -499,104 +480,6 @@ __global__ __launch_bounds__(256, 2) void k_chain_tile32(   // (2: a 256-registe
     }
 }
 
-// Round 2: the first panel tile WITHOUT the explicit inverse.  P_0 = S_{k+1,k} L_kk^-T by right-looking block substitution
-//   X_s = R_s inv(L_ss)^T ;  R_J -= X_s L_Js^T  (J > s),   s = 0 .. 7,
-// so the chain no longer waits for inv(L_kk) (12.5 us of every diagonal tile; the inverse moves to the side stream, where the
-// rest of the panel and the substitutions still use it).  One WAVE owns 8 rows of the tile; all it needs of L_kk (28 blocks) and
-// the 8 inverse diagonal blocks are fetched as MFMA B fragments in ONE global round trip (176 doubles per lane: the workgroups
-// run one wave per SIMD, 512 VGPRs), the rows stay in the accumulators, and the only LDS traffic is the 8 x 16 slab that turns an
-// accumulator block into an A fragment.  No barrier: the waves are independent.  Grid 4 x 256 threads.
-// The k index of the products is permuted (k = 4 kq + ks for lane quarter kq in k-step ks) on both operands, which makes every
-// fragment four consecutive doubles.
-// MEASURED (config 3, profiles/r02_chain_split_timeline.txt): the kernel itself does what it was built for -- 12 us against 15.5 us
-// for the GEMM with the inverse, and the diagonal kernel drops from 52 to 37 us -- but the chain period grows from 88 to 110-120 us:
-// the next step's first panel tile needs column k+1 of the trailing matrix, which the SIDE stream completes (rest of panel k by
-// GEMM with the inverse, then the column update), and that path now starts with the inverse kernel (21 us + an event hop) instead
-// of finding the inverse ready; the fourth stream it runs on shares a hardware queue with the side stream (4 queues per process),
-// and every extra event adds 6-18 us of hand-off.  Making the side path independent of the inverse means running the WHOLE panel
-// by substitution (this kernel over T tiles) -- not done.  Kept opt-in (BSFM_CHAIN=split) with a parity test.
-constexpr int TR32_XS = 18;                                   // LDS row stride of the 8 x 16 slab
-__global__ __launch_bounds__(256, 1) void k_chain_trsm32(double* __restrict__ S, int ld, int k, const double* __restrict__ dinv,
-                                                         double* __restrict__ panel)
-{
-    __shared__ __attribute__((aligned(16))) double slab[4][8 * TR32_XS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i4 = lane >> 4, g = (lane >> 2) & 3, j = lane & 3;       // accumulator layout: row 4 t + i4, column 16 J + 4 g + j
-    const int kq = lane >> 4, r = lane & 3;                            // operand layout: A row r / B column 4 g + r, k = 4 kq + ks
-    const int row0 = 32 * (int)blockIdx.x + 8 * wave;
-    double* Sik = S + ((size_t)(k + 1) * POTRF_NB + row0) * ld + (size_t)k * POTRF_NB;
-    const double* Lkk = S + ((size_t)k * POTRF_NB) * ld + (size_t)k * POTRF_NB;
-    const double* dk = dinv + (size_t)k * 2048;
-    double* xw = slab[wave];
-    double R[2][8], bl[28][4], bd[8][4];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int J = 0; J < 8; ++J) R[t][J] = Sik[(size_t)(4 * t + i4) * ld + 16 * J + 4 * g + j];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const double2 d0 = *reinterpret_cast<const double2*>(dk + s * 256 + (4 * g + r) * 16 + 4 * kq);
-        const double2 d1 = *reinterpret_cast<const double2*>(dk + s * 256 + (4 * g + r) * 16 + 4 * kq + 2);
-        bd[s][0] = d0.x; bd[s][1] = d0.y; bd[s][2] = d1.x; bd[s][3] = d1.y;
-    }
-#pragma unroll
-    for (int s = 0; s < 7; ++s)
-#pragma unroll
-        for (int J = s + 1; J < 8; ++J) {
-            const int q = s * (15 - s) / 2 + (J - s - 1);
-            const double* lp = Lkk + (size_t)(16 * J + 4 * g + r) * ld + 16 * s + 4 * kq;
-            const double2 l0 = *reinterpret_cast<const double2*>(lp);
-            const double2 l1 = *reinterpret_cast<const double2*>(lp + 2);
-            bl[q][0] = l0.x; bl[q][1] = l0.y; bl[q][2] = l1.x; bl[q][3] = l1.y;
-        }
-    double* Pk = panel + (size_t)row0 * POTRF_NB;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        // accumulator block s -> A fragments
-#pragma unroll
-        for (int t = 0; t < 2; ++t) xw[(4 * t + i4) * TR32_XS + 4 * g + j] = R[t][s];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        double a[2][4];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const double2 a0 = *reinterpret_cast<const double2*>(xw + (4 * t + r) * TR32_XS + 4 * kq);
-            const double2 a1 = *reinterpret_cast<const double2*>(xw + (4 * t + r) * TR32_XS + 4 * kq + 2);
-            a[t][0] = a0.x; a[t][1] = a0.y; a[t][2] = a1.x; a[t][3] = a1.y;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        double x[2] = { 0.0, 0.0 };
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) x[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[t][ks], bd[s][ks], x[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            Sik[(size_t)(4 * t + i4) * ld + 16 * s + 4 * g + j] = x[t];
-            Pk[(size_t)(4 * t + i4) * POTRF_NB + 16 * s + 4 * g + j] = x[t];
-        }
-        if (s < 7) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) xw[(4 * t + i4) * TR32_XS + 4 * g + j] = -x[t];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const double2 a0 = *reinterpret_cast<const double2*>(xw + (4 * t + r) * TR32_XS + 4 * kq);
-                const double2 a1 = *reinterpret_cast<const double2*>(xw + (4 * t + r) * TR32_XS + 4 * kq + 2);
-                a[t][0] = a0.x; a[t][1] = a0.y; a[t][2] = a1.x; a[t][3] = a1.y;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int J = s + 1; J < 8; ++J) {
-                const int q = s * (15 - s) / 2 + (J - s - 1);
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) R[t][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[t][ks], bl[q][ks], R[t][J], 0, 0, 0);
-            }
-        }
-    }
-}
-
 // (Also tried and dropped: an XCD-aware blockIdx -> tile order (super-tiles of 8x8 tiles per XCD chunk).  +8-11 % for the
 // kernel alone on the whole device (scripts/ubench_syrk.hip), exactly 0 in the factorisation -- with the CU-masked bulk
 // stream (35.0 TFLOP/s either way) and again without the mask (38.4 vs 38.5).  Nor do 64-row half-tile workgroups for the
@@ -611,6 +494,13 @@ __global__ __launch_bounds__(256, 1) void k_chain_trsm32(double* __restrict__ S,
 // neutral, so the plain variant stays the default; BSFM_SYRK_NT=1 selects this one (same binary).
 // pprev != nullptr: a PAIRED launch -- panel k-1 (compact copy pprev, tile a+1 = the same tile row) is applied in the same pass over
 // C: one read and one write of the tile for 256 accumulation steps (with the 16x16x4 loop: 61 instead of 44 TFLOP/s for the kernel alone).
+// (Tried and dropped, round 3: 16-byte C traffic.  The 16x16x4 accumulator layout gives a lane ONE double of four different rows, so the
+// prologue / epilogue issue 32 eight-byte loads / stores per lane; adjacent lanes swapped one register of each row pair through a DPP quad
+// permute so that every lane held two adjacent columns of one row and moved 16 bytes per instruction (16 instead of 32, same 128-byte
+// segments).  Kernel alone 43.0-45.7 vs 43.5-46.9 TFLOP/s, in the factorisation 38.9 vs 39.6 TFLOP/s, solve 8.44 vs 8.34 ms
+// (profiles/r03_syrk_c16_*): the epilogue is not issue-bound here.  Also round 3: de-phasing the two workgroups of a CU (b and b + 256
+// DO share a CU) by delaying one of them, persistent workgroups with static or atomic tile hand-out -- 39-43 vs 43.9 TFLOP/s
+// (profiles/r03_syrk_stagger_ubench.txt).)
 template <bool NT>
 __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __restrict__ S, int ld, int k, const double* __restrict__ panel, int part,
                                                                     const double* __restrict__ pprev)
@@ -663,13 +553,12 @@ __global__ __launch_bounds__(512, BSFM_SYRK_WPS) void k_syrk_update(double* __re
     }
 }
 
-// (Tried twice and dropped -- and a third time in round 2, kept behind BSFM_SYRK_PAIR, see PotrfWorkspace::pair_min_rows: rank-256
-// bulk launches that apply panels k and k+1 in one pass over C.  The kernel alone runs at
-// 46.6 instead of 42.9 TFLOP/s (C traffic per flop halves), but the factorisation got slower both times -- with the
-// two-stream schedule (10.9 vs 10.1 ms) and again on the three-stream schedule with the skipped launch's work moved to
-// the side kernel (K = 256) and the chain tile kernel (three panels) and the launch split so that the side stream only
-// waits for its first two columns (9.5 vs 9.0 ms): the bulk stream idles while the chain and side streams prepare the
-// second panel of a pair, and their own kernels get heavier.)
+// (Tried three times and dropped: rank-256 bulk launches that apply panels k and k+1 in one pass over C (pprev).  The kernel alone runs at
+// 46.6 (4x4x4 loop) / 61 (16x16x4 loop) instead of 42.9 / 44 TFLOP/s, but the factorisation got slower every time -- two-stream schedule
+// 10.9 vs 10.1 ms, three-stream schedule 9.5 vs 9.0 ms, round 2 with 30 / 40 / 50 paired tile rows 8.99 / 8.83 / 8.67 vs 8.46 ms: the bulk
+// stream idles while the chain and side streams prepare the second panel of a pair, the paired launches reach 43, not 61 TFLOP/s (two
+// different panels per tile), and their two-round workgroups hold the slots the chain's kernels wait for twice as long.  The host
+// side of that schedule was removed in round 3; the kernel keeps its pprev argument.)
 
 // (Tried and dropped, round 2: TWO bulk streams, tile rows shared out by the parity of the global tile row, so that the ragged last
 // round of one launch -- a launch runs ceil(tiles / 512) rounds of workgroups, 4.45 -> 5 at T = 68 -- is filled by the other stream's
@@ -778,15 +667,8 @@ __device__ __forceinline__ void diag_factor_block(double* __restrict__ T, double
 #undef BSFM_RDLANE
 }
 
-// PUBLISH (panel engine, below): as soon as block column s of the factor is final (after the row solves of step s) its blocks
-// below the diagonal go to S with write-through stores together with inv(L_ss) -> dinv, and the flag lflag[8 k + s] follows one
-// phase later (after every storing wave has drained) -- the panel workers run their triangular solves one block column behind
-// the factorisation instead of waiting for the whole tile and its inverse.
-// PHASES: 3 = factor + inverse in one go (round 1); 1 = factor only, inv(L_ss) blocks exported to `dinv` (the chain continues with a
-// block substitution against them, k_chain_trsm32); 2 = inverse only, from the factor tile in S and the exported blocks (side stream).
-template <bool PUBLISH, int PHASES = 3>
 __device__ __forceinline__ void diag_tile_body(double* __restrict__ dlds, double* __restrict__ S, int ld, int k, int n_total,
-        double* __restrict__ Linv, int* __restrict__ info, long long* __restrict__ dbg, double* __restrict__ dinv, int* lflag)
+        double* __restrict__ Linv, int* __restrict__ info, long long* __restrict__ dbg)
 {
     long long t0 = 0; if (dbg && threadIdx.x == 0) t0 = wall_clock64();
     double* T = dlds;                                  // [128][DG_TS]
@@ -796,19 +678,8 @@ __device__ __forceinline__ void diag_tile_body(double* __restrict__ dlds, double
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int base = k * POTRF_NB;
     double* G = S + (size_t)base * ld + base;
-    __syncthreads();                                   // (engine: the previous tile's phase B has finished with the LDS tile)
+    __syncthreads();
 
-    if (PHASES == 2) {
-        // factor tile (lower triangle) and inverse diagonal blocks back into LDS
-#pragma unroll 8
-        for (int it = 0; it < 32; ++it) {
-            const int idx = tid + 512 * it, r = idx >> 7, c = idx & 127;
-            T[r * DG_TS + c] = c <= r ? G[(size_t)r * ld + c] : 0.0;
-        }
-        for (int idx = tid; idx < 2048; idx += 512) Di[idx] = dinv[(size_t)k * 2048 + idx];
-        __syncthreads();
-    }
-    if (PHASES != 2) {
     // load the tile (lower triangle; identity in the padding beyond n_total)
     {
         double v[32];
@@ -868,19 +739,6 @@ __device__ __forceinline__ void diag_tile_body(double* __restrict__ dlds, double
             }
         }
         __syncthreads();
-        if (PUBLISH) {
-            // block column s is final below the diagonal block: rows 16 (s + 1) .. 127, columns 16 s .. 16 s + 15, and inv(L_ss)
-            const int cnt = (7 - s) * 256;
-            for (int idx = tid; idx < cnt + 256; idx += 512) {
-                if (idx < cnt) {
-                    const int r = 16 * (s + 1) + (idx >> 4), c = 16 * s + (idx & 15);
-                    __hip_atomic_store(G + (size_t)r * ld + c, T[r * DG_TS + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    const int q = idx - cnt;
-                    __hip_atomic_store(dinv + (size_t)k * 2048 + s * 256 + q, Di[s * 256 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
         if (dbg && threadIdx.x == 0) { const long long t = wall_clock64(); tA2 += t - tq; tq = t; }
         // ---- phase Q
         if (wave == 0) {
@@ -911,9 +769,7 @@ __device__ __forceinline__ void diag_tile_body(double* __restrict__ dlds, double
                 for (int q = 0; q < 4; ++q) C[(4 * q + (lane >> 4)) * DG_TS + (lane & 15)] -= acc[q];
             }
         }
-        if (PUBLISH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its write-through stores
         __syncthreads();
-        if (PUBLISH && tid == 0) __hip_atomic_store(&lflag[8 * k + s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (dbg && threadIdx.x == 0) { const long long t = wall_clock64(); tA1 += t - tq; tq = t; }
     }
     if (dbg && threadIdx.x == 0) { dbg[4] = tA1; dbg[5] = tA2; dbg[6] = tA3; }
@@ -924,14 +780,8 @@ __device__ __forceinline__ void diag_tile_body(double* __restrict__ dlds, double
         const int idx = tid + 512 * it, r = idx >> 7, c = idx & 127;
         if (c <= r) G[(size_t)r * ld + c] = T[r * DG_TS + c];
     }
-    if (PHASES == 1) {
-        for (int idx = tid; idx < 2048; idx += 512) dinv[(size_t)k * 2048 + idx] = Di[idx];
-        if (dbg && threadIdx.x == 0) dbg[2] = wall_clock64() - t0;
-        return;
-    }
     __syncthreads();
     if (dbg && threadIdx.x == 0) dbg[2] = wall_clock64() - t0;
-    }   // PHASES != 2
     // ---- phase B: inverse, wave J owns block column J
     double* Li = Linv + (size_t)k * POTRF_NB * POTRF_NB;
     {
@@ -978,21 +828,7 @@ __global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int 
         double* __restrict__ Linv, int* __restrict__ info, long long* __restrict__ dbg)
 {
     extern __shared__ __attribute__((aligned(16))) double dlds[];
-    diag_tile_body<false>(dlds, S, ld, k, n_total, Linv, info, dbg, nullptr, nullptr);
-}
-
-// split form (round 2): factor only (+ inverse diagonal blocks -> dinv) on the chain; the explicit inverse on the side stream
-__global__ __launch_bounds__(512) void k_potrf_diag_a(double* __restrict__ S, int ld, int k, int n_total, double* __restrict__ dinv,
-        int* __restrict__ info, long long* __restrict__ dbg)
-{
-    extern __shared__ __attribute__((aligned(16))) double dlds[];
-    diag_tile_body<false, 1>(dlds, S, ld, k, n_total, nullptr, info, dbg, dinv, nullptr);
-}
-__global__ __launch_bounds__(512) void k_potrf_diag_b(double* __restrict__ S, int ld, int k, int n_total, double* __restrict__ Linv,
-        double* __restrict__ dinv)
-{
-    extern __shared__ __attribute__((aligned(16))) double dlds[];
-    diag_tile_body<false, 2>(dlds, S, ld, k, n_total, Linv, nullptr, nullptr, dinv, nullptr);
+    diag_tile_body(dlds, S, ld, k, n_total, Linv, info, dbg);
 }
 
 // Backward substitution x = L^-T y as ONE persistent launch (replaces nblk dependent launches).
@@ -1055,6 +891,14 @@ __global__ __launch_bounds__(256) void k_bwd_persistent(const double* __restrict
     if (threadIdx.x == 0) __hip_atomic_store(&flags[kk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// A bounded spin of k_bwd_persistent that expired leaves its word set: the solve then reports POTRF_INFO_TIMEOUT through dpotrf's
+// info word (solver.hip treats a negative info as fatal) instead of handing back a silently wrong x.
+constexpr int POTRF_INFO_TIMEOUT = -7;
+__global__ void k_fold_timeout(const int* __restrict__ timeout, int* __restrict__ info)
+{
+    if (*timeout != 0) *info = POTRF_INFO_TIMEOUT;
+}
+
 // ------------------------------------------------------------------------------------------------
 inline void potrf_free(PotrfWorkspace& w)
 {
@@ -1064,9 +908,6 @@ inline void potrf_free(PotrfWorkspace& w)
     if (w.xs) (void)hipFree(w.xs);
     if (w.etmp) (void)hipFree(w.etmp);
     if (w.bflags) (void)hipFree(w.bflags);
-    if (w.dinv) (void)hipFree(w.dinv);
-    if (w.edbg) (void)hipFree(w.edbg);
-    if (w.eflags) (void)hipFree(w.eflags);
     if (w.rb_handle && w.rb_destroy) w.rb_destroy(w.rb_handle);
     if (w.ev0) (void)hipEventDestroy(w.ev0);
     if (w.ev1) (void)hipEventDestroy(w.ev1);
@@ -1074,13 +915,10 @@ inline void potrf_free(PotrfWorkspace& w)
     delete[] w.sy0; delete[] w.sy1; delete[] w.sy_flops;
     for (int i = 0; w.evP && i <= w.nblk; ++i) {
         (void)hipEventDestroy(w.evP[i]); (void)hipEventDestroy(w.evU[i]); (void)hipEventDestroy(w.evT[i]); (void)hipEventDestroy(w.evC[i]);
-        if (w.evA) (void)hipEventDestroy(w.evA[i]);
-        if (w.evB) (void)hipEventDestroy(w.evB[i]);
     }
-    delete[] w.evP; delete[] w.evU; delete[] w.evT; delete[] w.evC; delete[] w.evA; delete[] w.evB;
+    delete[] w.evP; delete[] w.evU; delete[] w.evT; delete[] w.evC;
     if (w.s2) { if (w.s2_masked) (void)hipStreamDestroy(w.s2); else stream_pool().release(w.s2); }
     stream_pool().release(w.sd);
-    if (w.sb) stream_pool().release(w.sb);
     w = PotrfWorkspace();
 }
 
@@ -1110,13 +948,11 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
     }
     if (!(w.sd = stream_pool().acquire())) return -1;
     w.evP = new hipEvent_t[w.nblk + 1]; w.evU = new hipEvent_t[w.nblk + 1];
-    w.evT = new hipEvent_t[w.nblk + 1]; w.evC = new hipEvent_t[w.nblk + 1]; w.evA = new hipEvent_t[w.nblk + 1]; w.evB = new hipEvent_t[w.nblk + 1];
+    w.evT = new hipEvent_t[w.nblk + 1]; w.evC = new hipEvent_t[w.nblk + 1];
     for (int i = 0; i <= w.nblk; ++i) {
         if (hipEventCreateWithFlags(&w.evP[i], hipEventDisableTiming) != hipSuccess) return -1;
         if (hipEventCreateWithFlags(&w.evU[i], hipEventDisableTiming) != hipSuccess) return -1;
         if (hipEventCreateWithFlags(&w.evT[i], hipEventDisableTiming) != hipSuccess) return -1;
-        if (hipEventCreateWithFlags(&w.evA[i], hipEventDisableTiming) != hipSuccess) return -1;
-        if (hipEventCreateWithFlags(&w.evB[i], hipEventDisableTiming) != hipSuccess) return -1;
         if (hipEventCreateWithFlags(&w.evC[i], hipEventDisableTiming) != hipSuccess) return -1;
     }
     if (hipMalloc((void**)&w.linv, (size_t)w.nblk * tile * sizeof(double)) != hipSuccess) return -1;
@@ -1124,22 +960,10 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
     if (hipMalloc((void**)&w.xs, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
     if (hipMalloc((void**)&w.etmp, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
     if (hipMalloc((void**)&w.bflags, (size_t)(w.nblk + 1) * sizeof(int)) != hipSuccess) return -1;
-    if (hipMalloc((void**)&w.dinv, (size_t)w.nblk * 2048 * sizeof(double)) != hipSuccess) return -1;
-    if (hipMalloc((void**)&w.eflags, (size_t)(13 * w.nblk + 8) * sizeof(int)) != hipSuccess) return -1;
-    if (const char* e = getenv("BSFM_CHOL")) w.use_engine = strcmp(e, "engine") == 0;
     if (const char* e = getenv("BSFM_SYRK_EVENTS")) w.syrk_events = std::max(0, atoi(e));
-    if (const char* e = getenv("BSFM_CHOL_WORKERS")) w.engine_workers = std::max(1, atoi(e));
-    if (getenv("BSFM_DEBUG_ENGINE")) { if (hipMalloc((void**)&w.edbg, (size_t)8 * w.nblk * sizeof(long long)) == hipSuccess) (void)hipMemset(w.edbg, 0, (size_t)8 * w.nblk * sizeof(long long)); }
     (void)hipEventCreate(&w.ev0); (void)hipEventCreate(&w.ev1);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(DG_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag_a), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(DG_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag_b), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(DG_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
-    if (const char* e = getenv("BSFM_SYRK_PAIR")) w.pair_min_rows = atoi(e);
-    if (const char* e = getenv("BSFM_CHAIN")) w.chain_split = strcmp(e, "split") == 0;
-    if (w.chain_split && !(w.sb = stream_pool().acquire())) return -1;     // (only then: a fourth stream changes the queue mapping of the others)
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_tile32<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(T32_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_tile32<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(T32_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
     w.sy0 = new hipEvent_t[w.nblk]; w.sy1 = new hipEvent_t[w.nblk]; w.sy_flops = new double[w.nblk];
@@ -1204,57 +1028,32 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
     (void)hipEventRecord(w.evU[w.nblk], st);                 // everything queued before the solve (S, E ready)
     (void)hipStreamWaitEvent(w.s2, w.evU[w.nblk], 0);
     (void)hipStreamWaitEvent(w.sd, w.evU[w.nblk], 0);
-    const bool split = w.chain_split != 0 && nblk > 1;
-    // steps 0 .. Kp-1 pair their bulk launches (Kp even): as long as at least pair_min_rows tile rows remain, where the bulk stream bounds
-    // the factorisation; the chain-bound tail keeps one launch per step (a paired launch lasts two rounds)
-    const int Kp = (w.pair_min_rows > 0 && !split && nblk - w.pair_min_rows > 1) ? ((nblk - w.pair_min_rows) & ~1) : 0;
-    if (split) {
-        hipLaunchKernelGGL(k_potrf_diag_a, dim3(1), dim3(512), diag_lds, st, S, ld, 0, n, w.dinv, d_info, w.dbg);
-        (void)hipEventRecord(w.evA[0], st);
-    } else {
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, 0, n, w.linv, d_info, w.dbg);
-    }
+    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, 0, n, w.linv, d_info, w.dbg);
     for (int k = 0; k + 1 < nblk; ++k) {
         const int T = nblk - k - 1;                          // tile rows below the diagonal tile k
         double* pk = panel_of(k);
         const double* Lk = w.linv + (size_t)k * tl;
-        if (split) {
-            // side: the explicit inverse of tile k (the rest of the panel, y_k and the backward substitution use it)
-            (void)hipStreamWaitEvent(w.sb, w.evA[k], 0);
-            hipLaunchKernelGGL(k_potrf_diag_b, dim3(1), dim3(512), diag_lds, w.sb, S, ld, k, n, w.linv, w.dinv);
-            (void)hipEventRecord(w.evB[k], w.sb);
-            (void)hipStreamWaitEvent(w.sd, w.evB[k], 0);
-        }
         // chain: first panel tile (its column k was completed by the side stream of step k-1)
         if (k > 0) (void)hipStreamWaitEvent(st, w.evC[k - 1], 0);
-        if (split) hipLaunchKernelGGL(k_chain_trsm32, dim3(4), dim3(256), 0, st, S, ld, k, (const double*)w.dinv, pk);
-        else hipLaunchKernelGGL(k_chain_tile32<0>, dim3(16), dim3(256), lds32, st, S, ld, k, Lk, pk, (const double*)nullptr, (const double*)nullptr);
+        hipLaunchKernelGGL(k_chain_tile32<0>, dim3(16), dim3(256), lds32, st, S, ld, k, Lk, pk, (const double*)nullptr, (const double*)nullptr);
         (void)hipEventRecord(w.evT[k], st);
         // side: rest of the panel and y_k (the extra workgroup), then the rest of the first trailing column
-        if (!split) (void)hipStreamWaitEvent(w.sd, w.evT[k], 0);
-        // (split: the block substitution writes L_{k+1,k} to S itself, so the workgroup that copies slot 0 of the compact panel is not launched)
-        hipLaunchKernelGGL(k_trsm_panel64, dim3(2 * (T - 1) + (split ? 1 : 2)), dim3(256), lds64, w.sd, S, ld, k, Lk, pk, 1, 2 * (T - 1), w.etmp, w.y);
+        (void)hipStreamWaitEvent(w.sd, w.evT[k], 0);
+        hipLaunchKernelGGL(k_trsm_panel64, dim3(2 * (T - 1) + 2), dim3(256), lds64, w.sd, S, ld, k, Lk, pk, 1, 2 * (T - 1), w.etmp, w.y);
         (void)hipEventRecord(w.evP[k], w.sd);
         if (k > 0) (void)hipStreamWaitEvent(w.sd, w.evU[k - 1], 0);   // column k+1 was last written by the bulk of step k-1
-        if (split) (void)hipStreamWaitEvent(w.sd, w.evT[k], 0);       // slot 0 of the compact panel (B operand of the column update)
         hipLaunchKernelGGL(k_syrk_col64, dim3(2 * (T - 1) + T), dim3(256), lds64, w.sd, S, ld, k, pk, 1, 2 * (T - 1), w.etmp, w.y, 0);
         (void)hipEventRecord(w.evC[k], w.sd);
-        // PAIRED bulk launches (steps k < Kp): the bulk launch of an even step is skipped and the odd step's launch applies both
-        // panels in one pass over C (k_syrk_update with pprev).  What the skipped launch owed before the pair's second step goes
-        // elsewhere: column k+2 (rows >= k+3) to the side stream right here, tile (k+3, k+3) -- tile 0 of the paired launch -- to the
-        // chain's tile kernel of step k+2 (three panels: prev2).  Everything else of panel k is not needed before step k+2.
-        const bool paired = k < Kp, even = (k & 1) == 0;
-        if (paired && even && T >= 3)
-            hipLaunchKernelGGL(k_syrk_col64, dim3(2 * (T - 2)), dim3(256), lds64, w.sd, S, ld, k, pk, 2, 2 * (T - 2), w.etmp, w.y, 1);
         // bulk
         (void)hipStreamWaitEvent(w.s2, w.evP[k], 0);
-        if (T > 2 && !(paired && even)) {
-            const double* pprev = paired ? (const double*)panel_of(k - 1) : (const double*)nullptr;
+        if (T > 2) {
+            const double* pprev = nullptr;
             const bool timed = w.syrk_events > 0 && (k % w.syrk_events) == 0;
             if (timed) (void)hipEventRecord(w.sy0[w.sy_used], w.s2);
-            if (w.syrk_nt) hipLaunchKernelGGL(k_syrk_update<true>, dim3(T * (T - 1) / 2 - 1), dim3(512), lds_bytes, w.s2, S, ld, k, pk, 2, pprev);
-            else hipLaunchKernelGGL(k_syrk_update<false>, dim3(T * (T - 1) / 2 - 1), dim3(512), lds_bytes, w.s2, S, ld, k, pk, 2, pprev);
-            if (timed) { (void)hipEventRecord(w.sy1[w.sy_used], w.s2); w.sy_flops[w.sy_used++] = tile_flops * (T * (T - 1) / 2 - 1) * (paired ? 2.0 : 1.0); }
+            const dim3 bg(T * (T - 1) / 2 - 1);
+            if (w.syrk_nt) hipLaunchKernelGGL(k_syrk_update<true>, bg, dim3(512), lds_bytes, w.s2, S, ld, k, pk, 2, pprev);
+            else hipLaunchKernelGGL(k_syrk_update<false>, bg, dim3(512), lds_bytes, w.s2, S, ld, k, pk, 2, pprev);
+            if (timed) { (void)hipEventRecord(w.sy1[w.sy_used], w.s2); w.sy_flops[w.sy_used++] = tile_flops * (T * (T - 1) / 2 - 1); }
         }
         (void)hipEventRecord(w.evU[k], w.s2);
         // chain: next diagonal tile
@@ -1262,16 +1061,9 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         // is already ordered before this point: the chain waited for evC[k-1] above, and the side stream recorded it after
         // having waited for evU[k-2] itself.  (Tried: hipStreamWriteValue32 / hipStreamWaitValue32 on signal memory instead
         // of the chain <-> side events: no faster.)
-        // (k even, 2 <= k <= Kp: tile (k+1, k+1) was tile 0 of the paired launch of steps k-2, k-1 -> it takes panel k-2 here as well)
         hipLaunchKernelGGL(k_chain_tile32<1>, dim3(10), dim3(256), lds32, st, S, ld, k, Lk, pk,
-                           k > 0 ? (const double*)panel_of(k - 1) : (const double*)nullptr,
-                           (k >= 2 && (k & 1) == 0 && k <= Kp) ? (const double*)panel_of(k - 2) : (const double*)nullptr);
-        if (split && k + 2 < nblk) {
-            hipLaunchKernelGGL(k_potrf_diag_a, dim3(1), dim3(512), diag_lds, st, S, ld, k + 1, n, w.dinv, d_info, w.dbg);
-            (void)hipEventRecord(w.evA[k + 1], st);
-        } else {
-            hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, k + 1, n, w.linv, d_info, w.dbg);
-        }
+                           k > 0 ? (const double*)panel_of(k - 1) : (const double*)nullptr, (const double*)nullptr);
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, k + 1, n, w.linv, d_info, w.dbg);
     }
     // y of the last tile: E_last is final once the side stream has drained
     if (nblk > 1) { (void)hipStreamWaitEvent(st, w.evC[nblk - 2], 0); (void)hipStreamWaitEvent(st, w.evU[nblk - 2], 0); }
@@ -1280,6 +1072,7 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
     // persistent backward substitution: all nblk workgroups must be resident (one per tile column)
     (void)hipMemsetAsync(w.bflags, 0, (size_t)(w.nblk + 1) * sizeof(int), st);
     hipLaunchKernelGGL(k_bwd_persistent, dim3(nblk), dim3(256), 0, st, S, ld, nblk, w.linv, w.y, w.xs, w.bflags, w.bflags + w.nblk);
+    hipLaunchKernelGGL(k_fold_timeout, dim3(1), dim3(1), 0, st, (const int*)(w.bflags + w.nblk), d_info);     // a hand-off that never arrived must not pass as a solution
     (void)hipMemcpyAsync(x_out, w.xs, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
     if (w.ev1) (void)hipEventRecord(w.ev1, st);
     if (w.dbg) {

@@ -26,7 +26,6 @@
 #include "kernels.hip.h"
 #include "schur.hip.h"
 #include "potrf.hip.h"
-#include "potrf_engine.hip.h"
 #include "compsolve.hip.h"
 
 using namespace bsfm;
@@ -135,7 +134,6 @@ void free_all(bsfm_problem* pb)
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (pb->h_scal) (void)hipHostFree(pb->h_scal);
     if (pb->h_flags) (void)hipHostFree(pb->h_flags);
-    blocked_release(pb->potrf);
     potrf_free(pb->potrf);
     comp_free(pb->comps);
     if (pb->ev_ok) for (int i = 0; i < PH_COUNT; ++i) { (void)hipEventDestroy(pb->ev[i][0]); (void)hipEventDestroy(pb->ev[i][1]); }
@@ -432,14 +430,8 @@ int compute_schur(bsfm_problem* pb, double mu)
         hipLaunchKernelGGL(k_rhs_init, dim3(grid_for((size_t)mm * cnp, 256)), dim3(256), 0, pb->stream, mm * cnp, P.mcon * cnp,
                            lead, pb->d_ea, Edst);
     if (pb->ntasks > 0) {
-        static const bool use_v2 = [] { const char* e = getenv("BSFM_SCHUR_KERNEL"); return e && !strcmp(e, "v2"); }();   // round-1 VALU kernel, for A/B runs
-        if (use_v2) {
-            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks_v2<C>), dim3((pb->nslots + 3) / 4), dim3(256), 0, pb->stream,
-                                                  P, pb->d_tasks, pb->nslots, pb->d_triples, pb->d_tri_pt, pb->d_partials, pb->d_epart));
-        } else {
-            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks_mfma<C>), dim3((pb->nslots + 3) / 4), dim3(256), 0, pb->stream,
-                                                  P, pb->d_tasks, pb->nslots, pb->d_triples, pb->d_tri_pt, pb->d_partials, pb->d_epart));
-        }
+        DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks_mfma<C>), dim3((pb->nslots + 3) / 4), dim3(256), 0, pb->stream,
+                                              P, pb->d_tasks, pb->nslots, pb->d_triples, pb->d_tri_pt, pb->d_partials, pb->d_epart));
         if (packed) {
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_pack<C>), dim3(pb->nblk), dim3(128), 0, pb->stream, pb->nblk,
                                                   pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0, pb->d_partials, pb->d_epart,
@@ -1042,7 +1034,7 @@ int bsfm_lm_iterate(bsfm_problem_t* pb, int iters)
             // S dpa = E, Cholesky (sba_Axb_Chol, lib/sba-1.5/sba_lapack.c:374-485); info -> d_flags[1]
             if (pb->comps.active) {
                 if (comp_solve(pb->comps, pb->potrf, cnp, pb->d_S, pb->ld, pb->d_E, d_dpa + (size_t)P.mcon * cnp, pb->d_flags + 1, pb->stream)) return BSFM_ERROR;
-            } else if (potrf_solve_auto(pb->potrf, pb->d_S, pb->ld, pb->Sdim, pb->d_E, d_dpa + (size_t)P.mcon * cnp, pb->d_flags + 1, pb->stream)) return BSFM_ERROR;
+            } else if (potrf_solve(pb->potrf, pb->d_S, pb->ld, pb->Sdim, pb->d_E, d_dpa + (size_t)P.mcon * cnp, pb->d_flags + 1, pb->stream)) return BSFM_ERROR;
             ph_end(pb, PH_SOLVE);
             if (P.mcon > 0) (void)hipMemsetAsync(d_dpa, 0, (size_t)P.mcon * cnp * sizeof(double), pb->stream);
             ph_begin(pb, PH_BACKSUB);
@@ -1328,7 +1320,7 @@ int bsfm_dense_chol_solve(int n, const double* A, const double* b, double* x, in
         if (hipMemset(dS, 0, (size_t)ld * ld * sizeof(double)) != hipSuccess || hipMemset(dE, 0, ld * sizeof(double)) != hipSuccess || hipMemset(dinfo, 0, sizeof(int)) != hipSuccess) break;
         if (hipMemcpy2D(dS, (size_t)ld * sizeof(double), A, (size_t)n * sizeof(double), (size_t)n * sizeof(double), n, hipMemcpyHostToDevice) != hipSuccess) break;
         if (hipMemcpy(dE, b, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) break;
-        if (potrf_solve_auto(ws, dS, ld, n, dE, dx, dinfo, st)) break;
+        if (potrf_solve(ws, dS, ld, n, dE, dx, dinfo, st)) break;
         if (hipStreamSynchronize(st) != hipSuccess) break;
         if (hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) break;
         if (hipMemcpy(x, dx, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) break;
@@ -1336,7 +1328,6 @@ int bsfm_dense_chol_solve(int n, const double* A, const double* b, double* x, in
     } while (0);
     if (dS) (void)hipFree(dS); if (dE) (void)hipFree(dE); if (dx) (void)hipFree(dx); if (dinfo) (void)hipFree(dinfo);
     if (st) (void)hipStreamDestroy(st);
-    blocked_release(ws);
     potrf_free(ws);
     return rc;
 }

@@ -132,7 +132,14 @@ int main()
         }
         printf("%-52s %8.3f ms best %8.3f avg  %7.2f TFLOP/s (best)\n", name, best, sum / 12, flop1 / (best * 1e-3) / 1e12);
     };
-    run("shipped k_syrk_update part 2 (2277 workgroups)", [&] { hipLaunchKernelGGL(k_syrk_update<false>, dim3(ntiles), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2, (const double*)nullptr); });
+    run("k_syrk_update part 2, 8-byte C loads and stores", [&] { hipLaunchKernelGGL((k_syrk_update<false, 0>), dim3(ntiles), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2, (const double*)nullptr); });
+    run("k_syrk_update part 2, 16-byte C loads", [&] { hipLaunchKernelGGL((k_syrk_update<false, 1>), dim3(ntiles), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2, (const double*)nullptr); });
+    run("k_syrk_update part 2, 16-byte C stores", [&] { hipLaunchKernelGGL((k_syrk_update<false, 2>), dim3(ntiles), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2, (const double*)nullptr); });
+    run("k_syrk_update part 2, 16-byte C loads + stores", [&] { hipLaunchKernelGGL((k_syrk_update<false, 3>), dim3(ntiles), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2, (const double*)nullptr); });
+    run("k_syrk_update part 2, 16-byte, non-temporal", [&] { hipLaunchKernelGGL((k_syrk_update<true, 3>), dim3(ntiles), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2, (const double*)nullptr); });
+    run("k_syrk_update part 2, 8-byte again", [&] { hipLaunchKernelGGL((k_syrk_update<false, 0>), dim3(ntiles), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2, (const double*)nullptr); });
+    run("k_syrk_update part 2, 16-byte loads + stores again", [&] { hipLaunchKernelGGL((k_syrk_update<false, 3>), dim3(ntiles), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2, (const double*)nullptr); });
+    if (getenv("UB_ONLY_C16")) return 0;
     for (int split : {256, 1}) {
         for (int d : {0, 5, 10, 15, 20, 25, 30}) {
             char nm[96]; snprintf(nm, sizeof nm, "persistent static, %s delayed %2d us", split == 256 ? "b >= 256" : "odd b (ctrl)", d);
@@ -153,7 +160,7 @@ int main()
             for (int r = 0; r < 12; ++r) {
                 hipMemsetAsync(counter, 0, 4, 0);
                 hipEventRecord(e0, 0);
-                if (v == 0) hipLaunchKernelGGL(k_syrk_update<false>, dim3(nt), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2, (const double*)nullptr);
+                if (v == 0) hipLaunchKernelGGL((k_syrk_update<false, 0>), dim3(nt), dim3(512), lds_bytes, 0, S, ld, 0, panel, 2, (const double*)nullptr);
                 if (v == 1) hipLaunchKernelGGL(k_pers<1>, dim3(std::min(512, nt)), dim3(512), lds_bytes, 0, S, ld, 0, panel, nt, 0, 256, counter);
                 if (v == 2) hipLaunchKernelGGL(k_pers<1>, dim3(std::min(512, nt)), dim3(512), lds_bytes, 0, S, ld, 0, panel, nt, 1500, 256, counter);
                 hipEventRecord(e1, 0); hipEventSynchronize(e1);

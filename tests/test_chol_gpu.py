@@ -116,52 +116,16 @@ def test_ill_conditioned_reduced_camera_system(gpu_bsfm):
     assert np.abs(x - ref).max() <= 20 * cond * np.finfo(float).eps * np.abs(ref).max()
 
 
-def _engine_worker(out):
-    import json
-    res = {}
+def test_backward_substitution_timeout_word_reaches_info(gpu_bsfm):
+    """(Round 3: the opt-in variants of round 2 -- persistent panel engine, split chain, two-level blocking -- were measured slower and
+    removed from the library, scripts/archive/ keeps their source and DESIGN.md section 10 their timelines.)  What is left to pin
+    here: a normal solve reports info = 0 through the same word the persistent backward substitution's timeout is folded into."""
     for n in (1, 129, 1000, 2500):
         A, b = spd(n, 40 + n)
-        os.environ["BSFM_CHOL"] = "streams"
-        rc0, x0 = __import__("bundler_sfm_amd").dense_chol_solve(A, b)
-        os.environ["BSFM_CHOL"] = "engine"
-        rc1, x1 = __import__("bundler_sfm_amd").dense_chol_solve(A, b)
-        os.environ["BSFM_CHOL"] = "streams"; os.environ["BSFM_CHAIN"] = "split"
-        rc2, x2 = __import__("bundler_sfm_amd").dense_chol_solve(A, b)
-        os.environ.pop("BSFM_CHAIN")
-        os.environ["BSFM_CHOL"] = "blocked"; os.environ["BSFM_CHOL_MIN_TILES"] = "9"
-        rc3, x3 = __import__("bundler_sfm_amd").dense_chol_solve(A, b)
-        os.environ["BSFM_CHOL"] = "streams"
-        bad = None
+        rc0, x0 = gpu_bsfm.dense_chol_solve(A, b)
+        assert rc0 == 0
+        ref = np.linalg.solve(A, b)
+        assert np.abs(x0 - ref).max() <= 1e-10 * np.abs(ref).max()
         if n > 200:
             A[150, 150] = -1.0
-            bad = __import__("bundler_sfm_amd").dense_chol_solve(A, b)[0]
-        res[str(n)] = [int(rc0), int(rc1), float(np.abs(x1 - x0).max() / np.abs(x0).max()), bad,
-                       int(rc2), float(np.abs(x2 - x0).max() / np.abs(x0).max()),
-                       int(rc3), float(np.abs(x3 - x0).max() / np.abs(x0).max())]
-    json.dump(res, open(out, "w"))
-
-
-def test_persistent_panel_engine_agrees_with_the_stream_schedule(gpu_bsfm, tmp_path):
-    """(Also BSFM_CHAIN=split, the other opt-in variant of the chain: potrf.hip.h:k_chain_trsm32, and BSFM_CHOL=blocked, the two-level
-    blocking of potrf_blocked.hip.h -- n = 2500 is 20 tile columns = 5 outer panels.)
-    BSFM_CHOL=engine: the chain as two persistent kernels with in-kernel hand-offs (potrf_engine.hip.h), opt-in this round
-    (measured slower than the stream schedule).  Same update order per tile, block substitution instead of
-    the explicit inverse in the panel: agreement to rounding with the default schedule, same not-positive-definite code.
-    Runs in a fresh process: the two persistent kernels and the gated bulk launches must sit on DIFFERENT hardware queues, and
-    a process that has created many HIP streams may alias them (then the engine times out loudly instead of hanging)."""
-    import json
-    import subprocess
-    import sys
-    out = tmp_path / "engine.json"
-    here = os.path.dirname(os.path.abspath(__file__))
-    code = f"import sys; sys.path.insert(0, {os.path.dirname(here)!r}); sys.path.insert(0, {here!r}); import test_chol_gpu as t; t._engine_worker({str(out)!r})"
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=170)
-    assert r.returncode == 0, r.stderr[-2000:]
-    res = json.load(open(out))
-    for n, (rc0, rc1, err, bad, rc2, err2, rc3, err3) in res.items():
-        assert rc0 == 0 and rc1 == 0 and rc2 == 0 and rc3 == 0, (n, rc0, rc1, rc2, rc3)
-        assert err3 <= 1e-11, (n, err3)          # BSFM_CHOL=blocked: two-level blocking, wide updates through rocBLAS (potrf_blocked.hip.h)
-        assert err <= 1e-11, (n, err)
-        assert err2 <= 1e-11, (n, err2)          # BSFM_CHAIN=split: first panel tile by block substitution instead of the explicit inverse
-        if bad is not None:
-            assert bad == 151, (n, bad)
+            assert gpu_bsfm.dense_chol_solve(A, b)[0] == 151
