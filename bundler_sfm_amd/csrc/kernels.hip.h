@@ -19,13 +19,19 @@
 //                                           per-call binary searches, sba_crsm.c:183-212)
 //   camtab[m*72]    per-camera derived row  (model.hip.h)
 //   campos[nvis], cam_pt[nvis], cam_cam[nvis]   observation -> camera-major position; position -> point / camera
-//   Jc[nvis*(2cnp+6)] A_ij (2 x cnp) then B_ij (2 x 3), one contiguous record per observation, stored ONCE, in
-//                    CAMERA-major order (record of observation k at position campos[k]): the Jacobian kernel and the
-//                    camera-side consumers (U_j/ea_j, Schur tasks incl. e_j) stream it, the point-side ones (V_i/eb_i,
-//                    back-substitution) gather whole records
+//   EVERYTHING per observation lives in CAMERA-major order (position t = campos[k] of observation k; round 3):
+//   xc[2*nvis]      the measurements, permuted once at problem_create;  e / hx[2*nvis]  residuals at p / at the trial point
+//   Ac[nvis*2cnp]   A_ij as cnp 16-byte chunks (A[0][c], A[1][c]): the two image rows of a column side by side, which is
+//                   what every consumer multiplies together (U_j = sum of chunk outer products, Yh = M * chunk, A da)
+//   Bc[nvis*8]      64-byte record: B_ij (2 x 3 row-major) || e_ij -- the per-point kernels (V_i / eb_i) fetch exactly one
+//                   64-byte sector per observation instead of 48 + 16 bytes out of two 192-byte-strided streams
+//   Cc[nvis*8]      per solve attempt: C_ij = B_ij V*_i^-1 (2 x 3) || C_ij eb_i (k_schur_prep): the Schur tasks need no
+//                   V*^-1 / eb gathers and no per-triple 3 x 3 work
+//   The camera-side kernels (Jacobian, residual, U_j / ea_j, Schur tasks) stream or gather these by t; the point-side ones
+//   (V_i / eb_i, back-substitution) gather records through campos[].
 //   U[m*cnp*cnp], ea[m*cnp], V[n*6] (packed upper), Vinv[n*6], eb[n*3], S[ld*ld], E[ld]
 // W_ij = A_ij^T B_ij is never materialised (1.08 GB at 5 M observations): every consumer uses the factored
-// form, e.g. Y_ij W_ik^T = A_ij^T (B_ij V*^-1 B_ik^T) A_ik with a 2x2 core, and W_ij^T da = B_ij^T (A_ij da).
+// form, e.g. Y_ij W_ik^T = A_ij^T (C_ij B_ik^T) A_ik with a 2x2 core, and W_ij^T da = B_ij^T (A_ij da).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <float.h>
@@ -37,8 +43,8 @@ namespace bsfm {
 struct DevProblem {
     ModelCfg cfg;
     int n, m, mcon, nvis;
-    int js;                       // J record stride = 2*cnp + 6
-    const double* x;
+    const double* x;              // measurements in observation (CRS) order: only the growing / shrinking of a problem reads it
+    const double* xc;             // measurements in camera-major order
     const int* obs_cam; const int* obs_pt; const int* rowptr;
     const int* camptr; const int* camobs;
     const int* campos;            // obs k -> its position in camera-major order (inverse of camobs)
@@ -50,7 +56,7 @@ struct DevProblem {
     const unsigned char* pcon; const double* pval; double pweight;     // n, 3n (may be null)
     double nvis_global;
     // work arrays
-    double* Jc; double* U; double* ea; double* V; double* Vinv; double* eb;
+    double* Ac; double* Bc; double* Cc; double* U; double* ea; double* V; double* Vinv; double* eb;
 };
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -108,13 +114,14 @@ __global__ void k_cam_table(ModelCfg cfg, int m, const double* __restrict__ pa, 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// residuals e = x - proj(p): one thread per observation, coalesced reads of x / obs_cam / obs_pt,
-// L2-resident gathers of the camera row and the point.  Block partial of sum e^2; with e_prev != null
-// also the block partial of the Snavely pct-change maximum.
+// residuals e = x - proj(p): one thread per CAMERA-major position t (round 3; it was one per observation in CRS order, where the 64
+// lanes of a wave read ~10 different 576-byte camera-table rows -- 0.19 of the HBM roof): neighbouring threads share the camera, so
+// the table row is one broadcast; xc / e are streamed, the point (24 bytes, L2-resident array) is gathered.  Block partial of
+// sum e^2; with e_prev != null also the block partial of the Snavely pct-change maximum (element-wise, so the order is free).
 constexpr int RES_BLOCK = 256;
 template <bool KNOWN>
 __global__ __launch_bounds__(RES_BLOCK) void k_residual(ModelCfg cfg, int nvis,
-        const double* __restrict__ x, const int* __restrict__ obs_cam, const int* __restrict__ obs_pt,
+        const double* __restrict__ xc, const int* __restrict__ cam_cam, const int* __restrict__ cam_pt,
         const double* __restrict__ camtab, const double* __restrict__ pb,
         double* __restrict__ e_out, const double* __restrict__ e_prev, double eps5,
         double* __restrict__ part_cost, double* __restrict__ part_pct)
@@ -123,11 +130,11 @@ __global__ __launch_bounds__(RES_BLOCK) void k_residual(ModelCfg cfg, int nvis,
     const int k = blockIdx.x * RES_BLOCK + threadIdx.x;
     double c = 0.0, pct = 0.0;
     if (k < nvis) {
-        const double* ct = camtab + (size_t)obs_cam[k] * CT_STRIDE;
-        const double* b = pb + (size_t)obs_pt[k] * 3;
+        const double* ct = camtab + (size_t)cam_cam[k] * CT_STRIDE;
+        const double* b = pb + (size_t)cam_pt[k] * 3;
         double h0, h1;
         project_row<KNOWN>(cfg, ct, b[0], b[1], b[2], h0, h1);
-        const double2 xx = reinterpret_cast<const double2*>(x)[k];
+        const double2 xx = reinterpret_cast<const double2*>(xc)[k];
         const double e0 = xx.x - h0, e1 = xx.y - h1;
         reinterpret_cast<double2*>(e_out)[k] = make_double2(e0, e1);
         c = e0 * e0 + e1 * e1;
@@ -150,44 +157,56 @@ __global__ __launch_bounds__(RES_BLOCK) void k_residual(ModelCfg cfg, int nvis,
     }
 }
 
+// camera-major copy of a per-observation array of 16-byte items (measurements at problem_create; exports go the other way)
+__global__ __launch_bounds__(256) void k_permute16(int nvis, const int* __restrict__ src_of, const double* __restrict__ src, double* __restrict__ dst)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < nvis) reinterpret_cast<double2*>(dst)[t] = reinterpret_cast<const double2*>(src)[src_of[t]];
+}
+
 // ---------------------------------------------------------------------------------------------------
-// Jacobian records: one thread per observation.
+// Jacobian: one thread per CAMERA-major position t.  Neighbouring threads share the camera (its 72-double table row is one
+// broadcast), gather their point (24 bytes, the point array is L2-resident) and write consecutive records of the two streams
+// Ac (cnp chunks (A[0][c], A[1][c])) and Bc (B || e, 64 bytes; e is copied from the residual array so that the per-point kernels
+// find it in the same sector as B).
 template <int CNP, bool FD, bool KNOWN>
 __global__ __launch_bounds__(256) void k_jacobian(ModelCfg cfg, int nvis,
         const int* __restrict__ cam_cam, const int* __restrict__ cam_pt,
-        const double* __restrict__ camtab, const double* __restrict__ pb, double* __restrict__ Jc)
+        const double* __restrict__ camtab, const double* __restrict__ pb, const double* __restrict__ e,
+        double* __restrict__ Ac, double* __restrict__ Bc)
 {
-    // One thread per CAMERA-major position t: neighbouring threads share the camera (its 72-double table row is one
-    // broadcast), gather their point (24 bytes, the point array is L2-resident) and write consecutive 192-byte records.
-    // ONE copy of the Jacobian: the camera-side consumers (U/ea, Schur tasks) stream it, the point-side ones gather
-    // whole records through campos[].
     const int tt = blockIdx.x * 256 + threadIdx.x;
     const int t = min(tt, nvis - 1);                         // the last workgroup's surplus threads repeat the last record (never stored)
     const double* ct = camtab + (size_t)cam_cam[t] * CT_STRIDE;
     const double* b = pb + (size_t)cam_pt[t] * 3;
+    const double2 et = reinterpret_cast<const double2*>(e)[t];
     double A[2 * CNP], B[6], x0, x1;
     if (FD) jac_fd<CNP, KNOWN>(cfg, ct, b[0], b[1], b[2], A, B, x0, x1);
     else    jac_analytic<CNP>(cfg, ct, b[0], b[1], b[2], A, B, x0, x1);
-    constexpr int JS = 2 * CNP + 6;
-    // The 256 records of a workgroup are contiguous in Jc (camera-major positions t0 .. t0+255): they are transposed through LDS so
-    // that every store instruction writes 64 x 16 consecutive bytes (a lane-per-record store touches 64 different cache lines per
-    // instruction, 16 bytes of each: the kernel was bound by those write transactions, 0.43 ms for 960 MB).
-    constexpr int CH = JS / 2;                               // 16-byte chunks per record
-    constexpr int LS = CH + 1;                               // LDS row stride in chunks (odd: conflict-free column writes)
-    __shared__ double2 stage[256 * LS];
-    double2* mine = stage + threadIdx.x * LS;
+    // The 256 records of a workgroup are contiguous in both streams: they are transposed through LDS so that every store
+    // instruction writes 64 x 16 consecutive bytes (a lane-per-record store touches 64 different cache lines per instruction,
+    // 16 bytes of each: the kernel was bound by those write transactions, 0.43 ms for 960 MB).
+    constexpr int LA = CNP + 1 - (CNP & 1);                  // LDS row strides in chunks (odd: conflict-free column writes)
+    constexpr int LB = 5;
+    __shared__ double2 stage[256 * (LA + LB)];
+    double2* mineA = stage + threadIdx.x * LA;
+    double2* stageB = stage + 256 * LA;
+    double2* mineB = stageB + threadIdx.x * LB;
 #pragma unroll
-    for (int q = 0; q < CNP; ++q) mine[q] = make_double2(A[2 * q], A[2 * q + 1]);
+    for (int q = 0; q < CNP; ++q) mineA[q] = make_double2(A[q], A[CNP + q]);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) mine[CNP + q] = make_double2(B[2 * q], B[2 * q + 1]);
+    for (int q = 0; q < 3; ++q) mineB[q] = make_double2(B[2 * q], B[2 * q + 1]);
+    mineB[3] = et;
     __syncthreads();
     const int t0 = blockIdx.x * 256;
     const int nrec = min(256, nvis - t0);
-    double2* outc = reinterpret_cast<double2*>(Jc + (size_t)t0 * JS);     // JS is even -> 16-byte aligned records
-    for (int c = threadIdx.x; c < nrec * CH; c += 256) {
-        const int rec = c / CH, part = c - rec * CH;
-        outc[c] = stage[rec * LS + part];
+    double2* outa = reinterpret_cast<double2*>(Ac + (size_t)t0 * 2 * CNP);
+    for (int c = threadIdx.x; c < nrec * CNP; c += 256) {
+        const int rec = c / CNP, part = c - rec * CNP;
+        outa[c] = stage[rec * LA + part];
     }
+    double2* outb = reinterpret_cast<double2*>(Bc + (size_t)t0 * 8);
+    for (int c = threadIdx.x; c < nrec * 4; c += 256) outb[c] = stageB[(c >> 2) * LB + (c & 3)];
 }
 
 // N 16-byte loads of 2N consecutive doubles.  Jacobian records are 16-byte aligned (even length, 2*cnp even), which
@@ -206,20 +225,17 @@ __device__ __forceinline__ void load_pairs(const double* __restrict__ p, double*
 // ---------------------------------------------------------------------------------------------------
 // V_i (packed upper: 00 01 02 11 12 22), eb_i: one thread per point walks its CRS row.
 template <int CNP>
-__global__ __launch_bounds__(256) void k_point_blocks(DevProblem P, const double* __restrict__ e,
-                                                      const double* __restrict__ pb)
+__global__ __launch_bounds__(256) void k_point_blocks(DevProblem P, const double* __restrict__ pb)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P.n) return;
-    constexpr int JS = 2 * CNP + 6;
     double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, g0 = 0, g1 = 0, g2 = 0;
     const int k1 = P.rowptr[i + 1];
     for (int k = P.rowptr[i]; k < k1; ++k) {
-        double B[6], ee[2];
-        load_pairs<3>(P.Jc + (size_t)P.campos[k] * JS + 2 * CNP, B);
-        load_pairs<1>(e + 2 * (size_t)k, ee);
-        const double b0 = B[0], b1 = B[1], b2 = B[2], b3 = B[3], b4 = B[4], b5 = B[5];
-        const double e0 = ee[0], e1 = ee[1];
+        double R[8];                                                   // B (2 x 3) || e: one 64-byte sector
+        load_pairs<4>(P.Bc + (size_t)P.campos[k] * 8, R);
+        const double b0 = R[0], b1 = R[1], b2 = R[2], b3 = R[3], b4 = R[4], b5 = R[5];
+        const double e0 = R[6], e1 = R[7];
         v00 += b0 * b0 + b3 * b3; v01 += b0 * b1 + b3 * b4; v02 += b0 * b2 + b3 * b5;
         v11 += b1 * b1 + b4 * b4; v12 += b1 * b2 + b4 * b5; v22 += b2 * b2 + b5 * b5;
         g0 += b0 * e0 + b3 * e1; g1 += b1 * e0 + b4 * e1; g2 += b2 * e0 + b5 * e1;
@@ -253,7 +269,6 @@ __device__ __forceinline__ void cam_slice(const int* __restrict__ camptr, int j,
 template <int CNP>
 __global__ __launch_bounds__(256) void k_cam_blocks(DevProblem P, const double* __restrict__ e, double* __restrict__ part)
 {
-    constexpr int JS = 2 * CNP + 6;
     constexpr int NU = CNP * (CNP + 1) / 2;
     constexpr int NV = NU + CNP;
     __shared__ double sm[4][NV];
@@ -265,19 +280,18 @@ __global__ __launch_bounds__(256) void k_cam_blocks(DevProblem P, const double* 
         int t0, t1;
         cam_slice(P.camptr, j, s, t0, t1);
         for (int t = t0 + threadIdx.x; t < t1; t += 256) {
-            const int k = P.camobs[t];
-            double a[2 * CNP], ee[2];
-            load_pairs<CNP>(P.Jc + (size_t)t * JS, a);
-            load_pairs<1>(e + 2 * (size_t)k, ee);
+            double a[2 * CNP], ee[2];                                  // a[2 c] = A[0][c], a[2 c + 1] = A[1][c]
+            load_pairs<CNP>(P.Ac + (size_t)t * 2 * CNP, a);
+            load_pairs<1>(e + 2 * (size_t)t, ee);                      // camera-major residuals: streamed, no gather
             const double e0 = ee[0], e1 = ee[1];
             int u = 0;
 #pragma unroll
             for (int r = 0; r < CNP; ++r) {
 #pragma unroll
-                for (int c = r; c < CNP; ++c) { acc[u] += a[r] * a[c] + a[CNP + r] * a[CNP + c]; ++u; }
+                for (int c = r; c < CNP; ++c) { acc[u] += a[2 * r] * a[2 * c] + a[2 * r + 1] * a[2 * c + 1]; ++u; }
             }
 #pragma unroll
-            for (int r = 0; r < CNP; ++r) acc[NU + r] += a[r] * e0 + a[CNP + r] * e1;
+            for (int r = 0; r < CNP; ++r) acc[NU + r] += a[2 * r] * e0 + a[2 * r + 1] * e1;
         }
     }
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -343,6 +357,32 @@ __global__ __launch_bounds__(256) void k_point_invert(int n, double mu, const do
     o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
     o[3] = (a * f - c * c) * id; o[4] = (b * c - a * e) * id; o[5] = (a * d - b * b) * id;
     if (!(fabs(det) > 0.0) || !isfinite(id)) atomicOr(flag, 1);
+}
+
+// Per solve attempt (V*^-1 depends on mu): C_ij = B_ij V*_i^-1 (2 x 3) and r_ij = C_ij eb_i for every observation, camera-major,
+// one 64-byte record.  With it a Schur task forms its 2 x 2 core as C_ij B_ik^T (12 FMAs) from two 48-byte operands instead of
+// gathering V*_i^-1 and doing the 3 x 3 product per co-visibility triple (a point with d cameras is in d (d + 1) / 2 triples), and
+// the reduced right-hand side needs no eb gather: e_j -= sum_i A_ij^T r_ij (sba_levmar.c:1195-1216, 1320-1339: Y_ij = W_ij V*_i^-1).
+__global__ __launch_bounds__(256) void k_schur_prep(int nvis, const int* __restrict__ cam_pt, const double* __restrict__ Bc,
+        const double* __restrict__ Vinv, const double* __restrict__ eb, double* __restrict__ Cc)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nvis) return;
+    double B[6], vi[6];
+    load_pairs<3>(Bc + (size_t)t * 8, B);
+    const int i = cam_pt[t];
+    load_pairs<3>(Vinv + (size_t)i * 6, vi);
+    const double e0 = eb[(size_t)i * 3], e1 = eb[(size_t)i * 3 + 1], e2 = eb[(size_t)i * 3 + 2];
+    const double i00 = vi[0], i01 = vi[1], i02 = vi[2], i11 = vi[3], i12 = vi[4], i22 = vi[5];
+    const double c00 = B[0] * i00 + B[1] * i01 + B[2] * i02;
+    const double c01 = B[0] * i01 + B[1] * i11 + B[2] * i12;
+    const double c02 = B[0] * i02 + B[1] * i12 + B[2] * i22;
+    const double c10 = B[3] * i00 + B[4] * i01 + B[5] * i02;
+    const double c11 = B[3] * i01 + B[4] * i11 + B[5] * i12;
+    const double c12 = B[3] * i02 + B[4] * i12 + B[5] * i22;
+    double2* o = reinterpret_cast<double2*>(Cc + (size_t)t * 8);
+    o[0] = make_double2(c00, c01); o[1] = make_double2(c02, c10); o[2] = make_double2(c11, c12);
+    o[3] = make_double2(c00 * e0 + c01 * e1 + c02 * e2, c10 * e0 + c11 * e1 + c12 * e2);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -456,7 +496,6 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem P, double mu, const 
         const double* __restrict__ pb, double* __restrict__ dpb, double* __restrict__ pdpb,
         double* __restrict__ part /* [3][gridDim.x] */)
 {
-    constexpr int JS = 2 * CNP + 6;
     __shared__ double sm[3][4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     double s_dp = 0.0, s_p = 0.0, s_dl = 0.0;
@@ -467,13 +506,14 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem P, double mu, const 
         for (int k = P.rowptr[i]; k < k1; ++k) {
             const int j = P.obs_cam[k];
             if (j < P.mcon) continue;
-            double A[JS];
-            load_pairs<CNP + 3>(P.Jc + (size_t)P.campos[k] * JS, A);
-            const double* B = A + 2 * CNP;
+            const int t = P.campos[k];
+            double A[2 * CNP], B[6];
+            load_pairs<CNP>(P.Ac + (size_t)t * 2 * CNP, A);
+            load_pairs<3>(P.Bc + (size_t)t * 8, B);
             const double* da = dpa + (size_t)j * CNP;
             double q0 = 0, q1 = 0;
 #pragma unroll
-            for (int c = 0; c < CNP; ++c) { q0 += A[c] * da[c]; q1 += A[CNP + c] * da[c]; }
+            for (int c = 0; c < CNP; ++c) { q0 += A[2 * c] * da[c]; q1 += A[2 * c + 1] * da[c]; }
             w0 += B[0] * q0 + B[3] * q1; w1 += B[1] * q0 + B[4] * q1; w2 += B[2] * q0 + B[5] * q1;
         }
         const double r0 = g[0] - w0, r1 = g[1] - w1, r2 = g[2] - w2;
@@ -547,9 +587,10 @@ __global__ __launch_bounds__(256) void k_obs_dist(int nvis, const double* __rest
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= nvis) return;
-    const double2 ee = reinterpret_cast<const double2*>(e)[k];
+    const int t = campos[k];                                    // the residuals live in camera-major order
+    const double2 ee = reinterpret_cast<const double2*>(e)[t];
     const double d = sqrt(ee.x * ee.x + ee.y * ee.y);
-    dist[k] = d; dist_cm[campos[k]] = d;
+    dist[k] = d; dist_cm[t] = d;
 }
 
 // Per camera: the k-th smallest distance for k = iround(0.8 n) and iround(0.5 n) (kth_element_copy, lib/imagelib/

@@ -37,10 +37,6 @@
 #pragma once
 #include "kernels.hip.h"
 
-#ifndef BSFM_SCHUR_MFMA16
-#define BSFM_SCHUR_MFMA16 1
-#endif
-
 namespace bsfm {
 
 // value of lane Q of every quad (DPP quad_perm [Q, Q, Q, Q]): two 32-bit moves, no LDS
@@ -59,221 +55,119 @@ constexpr int SCH_MAXT = 168;         // triples per task (SCHUR_CHUNK in index_
 // round 3; its description above is kept because the staging scheme is shared.)
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Round 2: the same tasks with the contraction on the FP64 matrix cores (v_mfma_f64_4x4x4_4b).
-// Per S block the sum over the task's co-visibility triples is a skinny GEMM with a long reduction dimension,
-//     D[a][b] = sum_rows X[row][a] * Yh[row][b],   rows = (triple p, image row h):  X = A_ij (2 x cnp per triple, straight from the
-//     staged record),  Yh[2p+h] = ( (B_ij V*^-1 B_ik^T) A_ik )[h]  ||  (B_ij V*^-1 eb_i)[h]  -- the 2 x 2 core times A_ik, plus the
-//     right-hand-side column for diagonal blocks,
-// so D[0..cnp)[0..cnp) is the task's part of sum_i Y_ij W_ik^T and D[.][cnp] its part of sum_i Y_ij eb_i (sba_levmar.c:1182-1339).
-// v2 did all of it on the VALU with 3 lanes per triple, each re-reading the shared B / B' / V^-1 operands from LDS (LDS pipe 53 %
-// busy, 208 VGPRs, 2 waves per SIMD).  Here 4 lanes per triple form the core once and write 2 x (cnp + 1) doubles of Yh to LDS; the
-// reduction over the pass's 32 rows is 8 x NI matrix instructions whose operands are single 8-byte LDS reads (X directly from the
-// staged record, Yh from its own area); the accumulators are NI doubles per lane, so the kernel needs ~1/3 of v2's registers and
-// three workgroups fit a CU (LDS-bound: 13 KB per wave).
-// Operand layout of the instruction (probed, potrf.hip.h): lane l = 16 kk + 4 g + r supplies A[g][i = r][kk] and B[g][kk][j = r] of the
-// four independent 4 x 4 x 4 products g; D[g][i][j] comes back at lane 16 i + 4 g + j.  The (cnp + 1)-column output is cut into 4 x 4
-// sub-blocks (br, bc); product slot g of instruction q takes sub-block 4 q + g of the row-major list.
+// Round 3: k_schur_tasks -- the same tasks, off the LDS pipeline.
+// Round 2's kernel (k_schur_tasks_mfma) parked the raw 192-byte records of both cameras and V*^-1 in a wave-private LDS slab, had
+// the four lanes of a triple read them back piecewise (2 x 2 core, Yh), wrote Yh and re-read everything in matrix-operand layout:
+// ~31 KB of LDS traffic per wave and pass of 16 triples, SQ_LDS_IDX_ACTIVE 85 % of the kernel, 0.12 of the FP64 peak.
+// Here NOTHING raw goes through LDS:
+//   * the four lanes (p, q) of a triple fetch the 16-byte chunks they own STRAIGHT INTO REGISTERS: chunks c0 = q + 4 (p & 1),
+//     c0 ^ 4 (and 8 on q = 0) of A_ij and of A_ik (a chunk = (A[0][c], A[1][c]), kernels.hip.h), chunk q of C_ij || r_ij and of B_ik;
+//   * the 2 x 2 core M = C_ij B_ik^T needs 12 doubles that sit in the quad: 12 DPP quad broadcasts + 12 FMAs (k_schur_prep has
+//     already folded V*^-1 into C, so there is no 3 x 3 work and no V*^-1 / eb gather per triple);
+//   * each lane turns its A_ik chunks into Yh chunks (Yh[h'][c] = M[h'][0] A[0][c] + M[h'][1] A[1][c], 4 FMAs per chunk) and
+//     writes ONLY the two matrix-operand slabs: X[p][c] = its A_ij chunk as it came, Y[p][c] = the Yh chunk (+ the right-hand-side
+//     chunk r_ij in column cnp for diagonal-block tasks).  Rows are 256 bytes apart: the operand reads below are conflict-free by
+//     construction, and the chunk order per lane (c0 depends on p & 1) keeps the two triples of an 8-lane store group on
+//     different banks;
+//   * the block sum D = X^T Y over the pass's 32 rows is 8 x v_mfma_f64_16x16x4.  Row (triple 4 u + kk, image row h) goes to
+//     k-step 2 u + h, slot kk: lane (a, kk) gets BOTH image rows of its operand with ONE 16-byte read per u -- 8 ds_read_b128 per
+//     pass instead of 16 ds_read_b64 (+ 45 reads / writes of the old staging scheme).
+// LDS traffic per wave and pass: 16 triples x (9 + 10) chunks written + 8 x 64 x 16 bytes read = 13 KB (was ~31 KB).
+// The task list, the block order of the partial sums (deterministic: no atomics), the diagonal-block right-hand side and the
+// epilogue are those of round 2.  v_mfma_f64_16x16x4: A[i][k] at lane i + 16 k, B[k][j] at lane j + 16 k, D[i][j]: register r of
+// lane l = row 4 r + (l >> 4), column l & 15 (scripts/probe_mfma16.hip).
 constexpr int SCM_PASS = 16;          // triples per pass (4 lanes each)
+#ifndef BSFM_SCHUR_WPS
+#define BSFM_SCHUR_WPS 3              // waves per SIMD the kernel is compiled for (workgroups per CU)
+#endif
 
 template <int CNP>
-__global__ __launch_bounds__(256, 3) void k_schur_tasks_mfma(DevProblem P, const SchurTask* __restrict__ tasks, int ntasks,
-        const int2* __restrict__ triples, const int* __restrict__ tri_pt, double* __restrict__ partials,
-        double* __restrict__ epart)
+__global__ __launch_bounds__(256, BSFM_SCHUR_WPS) void k_schur_tasks(DevProblem P, const SchurTask* __restrict__ tasks, int ntasks,
+        const int2* __restrict__ triples, double* __restrict__ partials, double* __restrict__ epart)
 {
-    constexpr int JS = 2 * CNP + 6;            // doubles per Jacobian record
-    constexpr int RS = JS + 2;                 // LDS record stride (doubles), 16-byte aligned
-    constexpr int CH = JS / 2;                 // 16-byte chunks per record
-    constexpr int NA = (SCM_PASS * CH + 63) / 64;      // staging rounds for one record stream
-    constexpr int YS = 12;                     // row stride of Yh (doubles)
-    constexpr int RB = (CNP + 3) / 4;          // 4-row sub-blocks of the output
-    constexpr int CB = (CNP + 1 + 3) / 4;      // 4-column sub-blocks incl. the right-hand-side column
-    constexpr int NSB = RB * CB;
-    constexpr int NI = (NSB + 3) / 4;          // matrix instructions per 4 reduction rows
-    constexpr int SLAB = 2 * SCM_PASS * RS + SCM_PASS * 6 + SCM_PASS * 4 + 2 * SCM_PASS * YS + 2;   // (+2: a word that stays zero, see MFMA16)
-    __shared__ __attribute__((aligned(16))) double sm[4][SLAB];
-    __shared__ int sm_tri[4][3 * SCH_MAXT];
+    typedef double d2_ __attribute__((ext_vector_type(2)));
+    typedef double v4d_ __attribute__((ext_vector_type(4)));
+    constexpr int ROWC = 16;                          // chunks per slab row (256 bytes)
+    constexpr bool THIRD = CNP > 8;                   // a ninth chunk exists (lane q = 0 takes it)
+    __shared__ __attribute__((aligned(16))) d2_ smx[4][SCM_PASS * ROWC];
+    __shared__ __attribute__((aligned(16))) d2_ smy[4][SCM_PASS * ROWC];
+    __shared__ int2 sm_tri[4][SCH_MAXT];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int task = blockIdx.x * 4 + wave;
     if (task >= ntasks) return;
     const SchurTask tk = tasks[task];
     if (tk.out < 0) return;
-    double* recA = sm[wave];
-    double* recB = recA + SCM_PASS * RS;
-    double* vin = recB + SCM_PASS * RS;
-    double* ebin = vin + SCM_PASS * 6;          // eb_i of the pass's points (diagonal-block tasks only), stride 4
-    double* Yh = ebin + SCM_PASS * 4;           // [2 * SCM_PASS][YS]
-    int* tq = sm_tri[wave];
+    d2_* X = smx[wave];
+    d2_* Y = smy[wave];
+    int2* tq = sm_tri[wave];
     const bool diag = tk.diag != 0;
-    for (int t = lane; t < tk.count; t += 64) {         // all triples of the task -> LDS (qa, qb, pt)
-        const int2 tr = triples[tk.start + t];
-        tq[3 * t] = tr.x; tq[3 * t + 1] = tr.y; tq[3 * t + 2] = tri_pt[tk.start + t];
-    }
-    // The whole slab starts as zeros: Yh's padding columns stay zero for the task, and record rows past the end of a short
-    // task are multiplied (by zero rows of Yh) without ever having been staged -- uninitialised LDS could hold NaN patterns.
-    for (int t = lane; t < SLAB; t += 64) recA[t] = 0.0;
+    for (int t = lane; t < tk.count; t += 64) tq[t] = triples[tk.start + t];
+    // columns >= cnp of X and > cnp (>= cnp for off-diagonal blocks) of Y are never written: they must read as zeros
+    for (int t = lane; t < SCM_PASS * ROWC; t += 64) { const d2_ z = { 0.0, 0.0 }; X[t] = z; Y[t] = z; }
 
-    // ---- roles of this lane
-    // (1) staging: chunk c = lane + 64 q -> record c / CH, 16-byte part c % CH
-    int srec[NA], spart[NA];
-#pragma unroll
-    for (int q = 0; q < NA; ++q) { const int c = lane + 64 * q; srec[q] = c / CH; spart[q] = c - srec[q] * CH; }
-    const int vrec = lane / 3, vpart = lane - 3 * vrec;           // V^-1 / eb: 3 lanes per triple (lanes 0..47)
-    // (2) core: triple cp of the pass, lane cq of its four: output columns cq, cq + 4, cq + 8 of Yh (+ the rhs column on lane CNP & 3)
-    const int cp = lane >> 2, cq = lane & 3;
-    // (3) matrix instruction operands: reduction row kk, product slot g, index r
-    const int kk = lane >> 4, g = (lane >> 2) & 3, r = lane & 3;
-#if BSFM_SCHUR_MFMA16
-    // ONE v_mfma_f64_16x16x4_f64 per 4 reduction rows covers the whole CNP x (CNP + 1) block (A[i][k] at lane i + 16 k, B[k][j] at lane
-    // j + 16 k: scripts/probe_mfma16.hip): 2 operand reads per lane and step instead of 2 NI -- the kernel is bound by the LDS pipeline
-    // (SQ_LDS_IDX_ACTIVE = 85 % of its duration with the 4x4x4 form, whose NI = 3 instructions per step re-read the slab three times).
-    typedef double v4d_ __attribute__((ext_vector_type(4)));
-    // Lanes beyond the block read one zero word (stride 0: a broadcast; letting them read the finite numbers that follow in the slab
-    // at the common stride -- which pairs the reads into ds_read2_b64 -- measured slower, 1.48 vs 1.43 ms).
-    const int oi = lane & 15;                                     // output row of the A operand / output column of the B operand
-    const int xbase = oi < CNP ? (kk >> 1) * RS + (kk & 1) * CNP + oi : SLAB - 1, xstep = oi < CNP ? 2 * RS : 0;
-    const int ybase = oi < YS ? (int)(Yh - recA) + kk * YS + oi : SLAB - 1, ystep = oi < YS ? 4 * YS : 0;
-    v4d_ acc16 = { 0.0, 0.0, 0.0, 0.0 };
-    (void)g; (void)r; (void)NI;
-#else
-    int xoff[NI], yoff[NI];
-#pragma unroll
-    for (int q = 0; q < NI; ++q) {
-        const int sb = min(4 * q + g, NSB - 1);                   // spare slots of the last instruction repeat the last sub-block
-        const int br = sb / CB, bc = sb - br * CB;
-        xoff[q] = (kk >> 1) * RS + (kk & 1) * CNP + 4 * br + r;    // X[row 4 K4 + kk][4 br + r] inside the staged record
-        yoff[q] = kk * YS + 4 * bc + r;
-    }
-    double acc[NI];
-#pragma unroll
-    for (int q = 0; q < NI; ++q) acc[q] = 0.0;
-#endif
-    // Register sets 0 and 1 alternate between passes (one pass of gathers in flight; two in flight measured no faster: 1.68 vs
-    // 1.59 ms at config 3 -- the kernel is not bound by the latency of its gathers).
-    double pa[2][NA][2], pb[2][NA][2], pv[2][2], pe[2] = { 0.0, 0.0 };
+    const int p = lane >> 2, q = lane & 3;            // triple of the pass, lane of its quad
+    const int c0 = q + 4 * (p & 1), c1 = c0 ^ 4;      // this lane's chunks (a column c < cnp exists)
+    const int l0 = c0 < CNP ? c0 : CNP - 1, l1 = c1 < CNP ? c1 : CNP - 1;      // clamped for the loads
+    const int kk = lane >> 4, oi = lane & 15;         // matrix-operand role: reduction slot, output row / column
+    const d2_* Ac2 = reinterpret_cast<const d2_*>(P.Ac);
+    const d2_* Bc2 = reinterpret_cast<const d2_*>(P.Bc);
+    const d2_* Cc2 = reinterpret_cast<const d2_*>(P.Cc);
+    v4d_ acc0 = { 0.0, 0.0, 0.0, 0.0 }, acc1 = { 0.0, 0.0, 0.0, 0.0 };
 
-#define BSFM_SCM_ISSUE(p0_, S_)                                                                                     \
+    // register sets 0 / 1 alternate between passes: one pass of gathers is in flight while the previous one is reduced
+    d2_ aj[2][3], ak[2][3], cj[2], bk[2];
+#define BSFM_SCH_ISSUE(p0_, S_)                                                                                     \
     {                                                                                                               \
-        const int last_ = min(SCM_PASS, tk.count - (p0_)) - 1;                                                      \
-        _Pragma("unroll") for (int q = 0; q < NA; ++q) {                                                            \
-            const int rq_ = min(srec[q], last_);                                                                    \
-            const double2 ta = *reinterpret_cast<const double2*>(P.Jc + (size_t)tq[3 * ((p0_) + rq_)] * JS + 2 * spart[q]);     \
-            const double2 tb = *reinterpret_cast<const double2*>(P.Jc + (size_t)tq[3 * ((p0_) + rq_) + 1] * JS + 2 * spart[q]); \
-            pa[S_][q][0] = ta.x; pa[S_][q][1] = ta.y; pb[S_][q][0] = tb.x; pb[S_][q][1] = tb.y;                     \
-        }                                                                                                           \
-        {                                                                                                           \
-            const int rv_ = min(vrec, last_);                                                                       \
-            const double2 tv = *reinterpret_cast<const double2*>(P.Vinv + (size_t)tq[3 * ((p0_) + rv_) + 2] * 6 + 2 * vpart); \
-            pv[S_][0] = tv.x; pv[S_][1] = tv.y;                                                                     \
-            if (diag) pe[S_] = P.eb[(size_t)tq[3 * ((p0_) + rv_) + 2] * 3 + vpart];                                 \
-        }                                                                                                           \
+        const int tr_ = min((p0_) + p, tk.count - 1);                                                               \
+        const int2 ab_ = tq[tr_];                                                                                   \
+        const d2_* ra_ = Ac2 + (size_t)ab_.x * CNP;                                                                 \
+        const d2_* rb_ = Ac2 + (size_t)ab_.y * CNP;                                                                 \
+        aj[S_][0] = ra_[l0]; aj[S_][1] = ra_[l1];                                                                   \
+        ak[S_][0] = rb_[l0]; ak[S_][1] = rb_[l1];                                                                   \
+        if (THIRD) { aj[S_][2] = ra_[CNP - 1]; ak[S_][2] = rb_[CNP - 1]; }                                          \
+        cj[S_] = Cc2[(size_t)ab_.x * 4 + q];                                                                        \
+        bk[S_] = Bc2[(size_t)ab_.y * 4 + min(q, 2)];                                                                \
     }
-#define BSFM_SCM_PARK(p0_, S_)                                                                                      \
+#define BSFM_SCH_COMPUTE(p0_, S_)                                                                                   \
     {                                                                                                               \
-        const int last_ = min(SCM_PASS, tk.count - (p0_)) - 1;                                                      \
-        _Pragma("unroll") for (int q = 0; q < NA; ++q) {                                                            \
-            const int rq_ = min(srec[q], last_);                                                                    \
-            *reinterpret_cast<double2*>(recA + rq_ * RS + 2 * spart[q]) = make_double2(pa[S_][q][0], pa[S_][q][1]); \
-            *reinterpret_cast<double2*>(recB + rq_ * RS + 2 * spart[q]) = make_double2(pb[S_][q][0], pb[S_][q][1]); \
-        }                                                                                                           \
-        if (lane < 3 * SCM_PASS) {                                                                                  \
-            const int rv_ = min(vrec, last_);                                                                       \
-            *reinterpret_cast<double2*>(vin + rv_ * 6 + 2 * vpart) = make_double2(pv[S_][0], pv[S_][1]);            \
-            if (diag) ebin[rv_ * 4 + vpart] = pe[S_];                                                               \
-        }                                                                                                           \
-    }
-#if BSFM_SCHUR_MFMA16
-#define BSFM_SCM_REDUCE                                                                                             \
-        {                                                                                                           \
-            double xa[SCM_PASS / 2], yb[SCM_PASS / 2];                                                              \
-            _Pragma("unroll") for (int k4 = 0; k4 < SCM_PASS / 2; ++k4) { xa[k4] = recA[xbase + k4 * xstep]; yb[k4] = recA[ybase + k4 * ystep]; } \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
-            _Pragma("unroll") for (int k4 = 0; k4 < SCM_PASS / 2; ++k4)                                             \
-                acc16 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[k4], yb[k4], acc16, 0, 0, 0);                       \
-        }
-#else
-#define BSFM_SCM_REDUCE                                                                                             \
-        _Pragma("unroll") for (int k4 = 0; k4 < SCM_PASS / 2; k4 += 2) {                                            \
-            double xa[2][NI], yb[2][NI];                                                                            \
-            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                           \
-                _Pragma("unroll") for (int q = 0; q < NI; ++q) {                                                    \
-                    xa[u][q] = recA[2 * (k4 + u) * RS + xoff[q]];                                                   \
-                    yb[u][q] = Yh[4 * (k4 + u) * YS + yoff[q]];                                                     \
-                }                                                                                                   \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
-            _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                           \
-                _Pragma("unroll") for (int q = 0; q < NI; ++q)                                                      \
-                    acc[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(xa[u][q], yb[u][q], acc[q], 0, 0, 0);               \
-        }
-#endif
-// the 2 x 2 core of triple cp and this lane's columns of Yh, then the reduction over the pass's 2 x SCM_PASS rows on the matrix cores
-#define BSFM_SCM_COMPUTE(p0_)                                                                                       \
-    {                                                                                                               \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* records parked (same wave: LDS operations complete in order) */ \
-        {                                                                                                           \
-            const bool live = (p0_) + cp < tk.count;                                                                \
-            const double* Ja = recA + cp * RS;                                                                      \
-            const double* Jb = recB + cp * RS;                                                                      \
-            /* ONE lane of the triple's four forms the 2 x 2 core (18 LDS reads); its neighbours take it by DPP quad broadcast -- the \
-               kernel is LDS-bound, and all four lanes reading the same B blocks and V^-1 was a third of its LDS traffic.  The forming \
-               lane is the one that also owns the right-hand-side column (cq == CNP & 3), so c00 .. c12 never leave it. */            \
-            double c00 = 0.0, c01 = 0.0, c02 = 0.0, c10 = 0.0, c11 = 0.0, c12 = 0.0, m00 = 0.0, m01 = 0.0, m10 = 0.0, m11 = 0.0;     \
-            if (cq == (CNP & 3)) {                                                                                  \
-                const double* vi = vin + cp * 6;                                                                    \
-                const double i00 = vi[0], i01 = vi[1], i02 = vi[2], i11 = vi[3], i12 = vi[4], i22 = vi[5];          \
-                const double* Ba = Ja + 2 * CNP;                                                                    \
-                const double* Bb = Jb + 2 * CNP;                                                                    \
-                c00 = Ba[0] * i00 + Ba[1] * i01 + Ba[2] * i02;                                                      \
-                c01 = Ba[0] * i01 + Ba[1] * i11 + Ba[2] * i12;                                                      \
-                c02 = Ba[0] * i02 + Ba[1] * i12 + Ba[2] * i22;                                                      \
-                c10 = Ba[3] * i00 + Ba[4] * i01 + Ba[5] * i02;                                                      \
-                c11 = Ba[3] * i01 + Ba[4] * i11 + Ba[5] * i12;                                                      \
-                c12 = Ba[3] * i02 + Ba[4] * i12 + Ba[5] * i22;                                                      \
-                m00 = c00 * Bb[0] + c01 * Bb[1] + c02 * Bb[2];                                                      \
-                m01 = c00 * Bb[3] + c01 * Bb[4] + c02 * Bb[5];                                                      \
-                m10 = c10 * Bb[0] + c11 * Bb[1] + c12 * Bb[2];                                                      \
-                m11 = c10 * Bb[3] + c11 * Bb[4] + c12 * Bb[5];                                                      \
-            }                                                                                                       \
-            m00 = quad_bcast<CNP & 3>(m00); m01 = quad_bcast<CNP & 3>(m01);                                         \
-            m10 = quad_bcast<CNP & 3>(m10); m11 = quad_bcast<CNP & 3>(m11);                                         \
-            double* y0 = Yh + (2 * cp) * YS;                                                                        \
-            double* y1 = y0 + YS;                                                                                   \
-            _Pragma("unroll") for (int a = 0; a < (CNP + 3) / 4; ++a) {                                             \
-                const int col = cq + 4 * a;                                                                         \
-                if (col < CNP) {                                                                                    \
-                    const double b0 = Jb[col], b1 = Jb[CNP + col];                                                  \
-                    y0[col] = live ? m00 * b0 + m01 * b1 : 0.0;                                                     \
-                    y1[col] = live ? m10 * b0 + m11 * b1 : 0.0;                                                     \
-                }                                                                                                   \
-            }                                                                                                       \
-            if (diag && cq == (CNP & 3)) {                        /* right-hand-side column: B_ij V*^-1 eb_i */     \
-                const double e0 = ebin[cp * 4], e1 = ebin[cp * 4 + 1], e2 = ebin[cp * 4 + 2];                       \
-                y0[CNP] = live ? c00 * e0 + c01 * e1 + c02 * e2 : 0.0;                                              \
-                y1[CNP] = live ? c10 * e0 + c11 * e1 + c12 * e2 : 0.0;                                              \
-            }                                                                                                       \
-        }                                                                                                           \
+        const bool live_ = (p0_) + p < tk.count;                                                                    \
+        /* C (2 x 3 row-major over the chunks of lanes 0..2) and B likewise, to every lane of the quad */           \
+        const double C00 = quad_bcast<0>(cj[S_].x), C01 = quad_bcast<0>(cj[S_].y), C02 = quad_bcast<1>(cj[S_].x);   \
+        const double C10 = quad_bcast<1>(cj[S_].y), C11 = quad_bcast<2>(cj[S_].x), C12 = quad_bcast<2>(cj[S_].y);   \
+        const double B00 = quad_bcast<0>(bk[S_].x), B01 = quad_bcast<0>(bk[S_].y), B02 = quad_bcast<1>(bk[S_].x);   \
+        const double B10 = quad_bcast<1>(bk[S_].y), B11 = quad_bcast<2>(bk[S_].x), B12 = quad_bcast<2>(bk[S_].y);   \
+        double m00 = C00 * B00 + C01 * B01 + C02 * B02, m01 = C00 * B10 + C01 * B11 + C02 * B12;                    \
+        double m10 = C10 * B00 + C11 * B01 + C12 * B02, m11 = C10 * B10 + C11 * B11 + C12 * B12;                    \
+        if (!live_) { m00 = 0.0; m01 = 0.0; m10 = 0.0; m11 = 0.0; }                                                 \
+        d2_* xr_ = X + p * ROWC;                                                                                    \
+        d2_* yr_ = Y + p * ROWC;                                                                                    \
+        if (c0 < CNP) { xr_[c0] = aj[S_][0]; const d2_ y_ = { m00 * ak[S_][0].x + m01 * ak[S_][0].y, m10 * ak[S_][0].x + m11 * ak[S_][0].y }; yr_[c0] = y_; } \
+        if (c1 < CNP) { xr_[c1] = aj[S_][1]; const d2_ y_ = { m00 * ak[S_][1].x + m01 * ak[S_][1].y, m10 * ak[S_][1].x + m11 * ak[S_][1].y }; yr_[c1] = y_; } \
+        if (THIRD && q == 0) { xr_[CNP - 1] = aj[S_][2]; const d2_ y_ = { m00 * ak[S_][2].x + m01 * ak[S_][2].y, m10 * ak[S_][2].x + m11 * ak[S_][2].y }; yr_[CNP - 1] = y_; } \
+        if (diag && q == 3) { const d2_ r_ = { live_ ? cj[S_].x : 0.0, live_ ? cj[S_].y : 0.0 }; yr_[CNP] = r_; }   \
+        /* same wave: LDS operations complete in order, the reads below see the stores above */                    \
+        d2_ xa_[SCM_PASS / 4], yb_[SCM_PASS / 4];                                                                   \
+        _Pragma("unroll") for (int u = 0; u < SCM_PASS / 4; ++u) { xa_[u] = X[(4 * u + kk) * ROWC + oi]; yb_[u] = Y[(4 * u + kk) * ROWC + oi]; } \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                          \
-        /* operands of two reduction steps are fetched together: one LDS wait per 2 NI matrix instructions, not one per instruction */ \
-        BSFM_SCM_REDUCE                                                                                             \
-        asm volatile("" ::: "memory");                           /* the next parking must not move above these reads */ \
+        _Pragma("unroll") for (int u = 0; u < SCM_PASS / 4; ++u) {                                                  \
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa_[u].x, yb_[u].x, acc0, 0, 0, 0);                         \
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa_[u].y, yb_[u].y, acc1, 0, 0, 0);                         \
+        }                                                                                                           \
+        asm volatile("" ::: "memory");                           /* the next pass's stores must not move above these reads */ \
     }
 
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the triple list is in LDS, the slab is cleared
-    BSFM_SCM_ISSUE(0, 0)
-    for (int p0 = 0; p0 < tk.count; p0 += 2 * SCM_PASS) {        // one pass of gathers in flight while the previous one is reduced
-        BSFM_SCM_PARK(p0, 0)
-        if (p0 + SCM_PASS < tk.count) BSFM_SCM_ISSUE(p0 + SCM_PASS, 1)
-        BSFM_SCM_COMPUTE(p0)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the triple list is in LDS, the slabs are cleared
+    BSFM_SCH_ISSUE(0, 0)
+    for (int p0 = 0; p0 < tk.count; p0 += 2 * SCM_PASS) {
+        if (p0 + SCM_PASS < tk.count) BSFM_SCH_ISSUE(p0 + SCM_PASS, 1)
+        BSFM_SCH_COMPUTE(p0, 0)
         if (p0 + SCM_PASS < tk.count) {
-            BSFM_SCM_PARK(p0 + SCM_PASS, 1)
-            if (p0 + 2 * SCM_PASS < tk.count) BSFM_SCM_ISSUE(p0 + 2 * SCM_PASS, 0)
-            BSFM_SCM_COMPUTE(p0 + SCM_PASS)
+            if (p0 + 2 * SCM_PASS < tk.count) BSFM_SCH_ISSUE(p0 + 2 * SCM_PASS, 0)
+            BSFM_SCH_COMPUTE(p0 + SCM_PASS, 1)
         }
     }
-#undef BSFM_SCM_ISSUE
-#undef BSFM_SCM_PARK
-#undef BSFM_SCM_COMPUTE
-#undef BSFM_SCM_REDUCE
-#if BSFM_SCHUR_MFMA16
+#undef BSFM_SCH_ISSUE
+#undef BSFM_SCH_COMPUTE
     // D[a][b]: register r of lane l holds row a = 4 r + (l >> 4), column b = l & 15
     {
         double* out = partials + (size_t)tk.out * CNP * CNP;
@@ -281,31 +175,13 @@ __global__ __launch_bounds__(256, 3) void k_schur_tasks_mfma(DevProblem P, const
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int a = 4 * rr + (lane >> 4);
+            const double v = acc0[rr] + acc1[rr];
             if (a < CNP) {
-                if (b < CNP) out[a * CNP + b] = acc16[rr];
-                else if (b == CNP && diag) epart[(size_t)tk.out * CNP + a] = acc16[rr];
+                if (b < CNP) out[a * CNP + b] = v;
+                else if (b == CNP && diag) epart[(size_t)tk.out * CNP + a] = v;
             }
         }
     }
-#else
-    // D[g][i][j] of instruction q sits at lane 16 i + 4 g + j
-    {
-        const int i = lane >> 4, j = lane & 3;
-        double* out = partials + (size_t)tk.out * CNP * CNP;
-#pragma unroll
-        for (int q = 0; q < NI; ++q) {
-            const int sb = 4 * q + g;
-            if (sb < NSB) {
-                const int br = sb / CB, bc = sb - br * CB;
-                const int a = 4 * br + i, b = 4 * bc + j;
-                if (a < CNP) {
-                    if (b < CNP) out[a * CNP + b] = acc[q];
-                    else if (b == CNP && diag) epart[(size_t)tk.out * CNP + a] = acc[q];
-                }
-            }
-        }
-    }
-#endif
 }
 
 }  // namespace bsfm

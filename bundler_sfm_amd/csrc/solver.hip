@@ -69,7 +69,7 @@ struct bsfm_problem {
     long long nvis_global = 0, nvars_global = 0;
     int Sdim = 0, ld = 0;
     // device
-    double *d_x = nullptr, *d_Rinit = nullptr, *d_finit = nullptr;
+    double *d_x = nullptr, *d_xc = nullptr, *d_Rinit = nullptr, *d_finit = nullptr;
     double *d_known = nullptr;          // m x CT_EXT: known-intrinsics / fisheye block of the camera table (model.hip.h); null when unused
     int fisheye_mode = 0;               // run_sfm(optimize_for_fisheye): sfm_project_point2_fisheye instead of sfm_project_point3
     int *d_obs_cam = nullptr, *d_obs_pt = nullptr, *d_rowptr = nullptr, *d_camptr = nullptr, *d_camobs = nullptr;
@@ -79,7 +79,7 @@ struct bsfm_problem {
     double *d_p = nullptr, *d_pdp = nullptr, *d_dp = nullptr;
     double *d_camtab = nullptr, *d_camtab_trial = nullptr;
     double *d_e = nullptr, *d_hx = nullptr;
-    double *d_Jc = nullptr, *d_U = nullptr, *d_ea = nullptr, *d_V = nullptr, *d_Vinv = nullptr, *d_eb = nullptr;
+    double *d_Ac = nullptr, *d_Bc = nullptr, *d_Cc = nullptr, *d_U = nullptr, *d_ea = nullptr, *d_V = nullptr, *d_Vinv = nullptr, *d_eb = nullptr;
     double *d_S = nullptr, *d_E = nullptr;
     int export_full_s = 0;              // bsfm_eval_normal_equations hands S out as a full symmetric matrix: clear all of it
     double *d_partials = nullptr;       // schur task partials
@@ -125,8 +125,8 @@ namespace {
 
 void free_all(bsfm_problem* pb)
 {
-    void* ptrs[] = { pb->d_x, pb->d_Rinit, pb->d_finit, pb->d_known, pb->d_obs_cam, pb->d_obs_pt, pb->d_rowptr, pb->d_camptr,
-                     pb->d_camobs, pb->d_campos, pb->d_cam_pt, pb->d_cam_cam, pb->d_Jc, pb->d_ccon, pb->d_pcon, pb->d_cval, pb->d_cw, pb->d_pval, pb->d_p, pb->d_pdp,
+    void* ptrs[] = { pb->d_x, pb->d_xc, pb->d_Rinit, pb->d_finit, pb->d_known, pb->d_obs_cam, pb->d_obs_pt, pb->d_rowptr, pb->d_camptr,
+                     pb->d_camobs, pb->d_campos, pb->d_cam_pt, pb->d_cam_cam, pb->d_Ac, pb->d_Bc, pb->d_Cc, pb->d_ccon, pb->d_pcon, pb->d_cval, pb->d_cw, pb->d_pval, pb->d_p, pb->d_pdp,
                      pb->d_dp, pb->d_camtab, pb->d_camtab_trial, pb->d_e, pb->d_hx, pb->d_U,
                      pb->d_V, pb->d_Vinv, pb->d_eb, pb->d_S, pb->d_E, pb->d_partials, pb->d_epart, pb->d_campart, pb->d_red, pb->d_scal, pb->d_mixed,
                      pb->d_flags, pb->d_triples, pb->d_tri_pt, pb->d_tasks, pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0,
@@ -223,7 +223,7 @@ void launch_cam_table(bsfm_problem* pb, const double* p, double* camtab)
                        pb->d_Rinit, pb->d_finit, pb->d_known, pb->opt.jacobian == BSFM_JAC_FD ? 1 : 0, camtab);
 }
 
-// e_out = x - proj(p); SC slot gets sum e^2 ; optional pct-change vs e_prev into SC_PCT
+// e_out = x - proj(p) (camera-major order); SC slot gets sum e^2 ; optional pct-change vs e_prev into SC_PCT
 void launch_residual(bsfm_problem* pb, const double* camtab, const double* p, double* e_out,
                      const double* e_prev, int cost_slot)
 {
@@ -231,12 +231,12 @@ void launch_residual(bsfm_problem* pb, const double* camtab, const double* p, do
     double* pc = pb->d_red, *pp = pb->d_red + pb->red_blocks;
     const double* pbpts = p + (size_t)pb->P.m * pb->cnp;
     if (pb->P.nvis > 0 && pb->d_known)
-        hipLaunchKernelGGL(k_residual<true>, dim3(nb), dim3(RES_BLOCK), 0, pb->stream, pb->P.cfg, pb->P.nvis, pb->d_x,
-                           pb->d_obs_cam, pb->d_obs_pt, camtab, pbpts, e_out, e_prev, pb->opt.opts[5], pc,
+        hipLaunchKernelGGL(k_residual<true>, dim3(nb), dim3(RES_BLOCK), 0, pb->stream, pb->P.cfg, pb->P.nvis, pb->d_xc,
+                           pb->d_cam_cam, pb->d_cam_pt, camtab, pbpts, e_out, e_prev, pb->opt.opts[5], pc,
                            e_prev ? pp : nullptr);
     if (pb->P.nvis > 0 && !pb->d_known)
-        hipLaunchKernelGGL(k_residual<false>, dim3(nb), dim3(RES_BLOCK), 0, pb->stream, pb->P.cfg, pb->P.nvis, pb->d_x,
-                           pb->d_obs_cam, pb->d_obs_pt, camtab, pbpts, e_out, e_prev, pb->opt.opts[5], pc,
+        hipLaunchKernelGGL(k_residual<false>, dim3(nb), dim3(RES_BLOCK), 0, pb->stream, pb->P.cfg, pb->P.nvis, pb->d_xc,
+                           pb->d_cam_cam, pb->d_cam_pt, camtab, pbpts, e_out, e_prev, pb->opt.opts[5], pc,
                            e_prev ? pp : nullptr);
     const int cnt = pb->P.nvis > 0 ? nb : 0;
     hipLaunchKernelGGL(k_reduce_sum_max, dim3(1), dim3(256), 0, pb->stream, pc, e_prev ? pp : (const double*)nullptr, cnt,
@@ -329,13 +329,13 @@ int compute_normal_blocks(bsfm_problem* pb)
         if (pb->opt.jacobian == BSFM_JAC_FD) {
             if (pb->d_known) {
                 DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_jacobian<C, true, true>), dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream,
-                                                      P.cfg, P.nvis, pb->d_cam_cam, pb->d_cam_pt, pb->d_camtab, pbpts, pb->d_Jc));
+                                                      P.cfg, P.nvis, pb->d_cam_cam, pb->d_cam_pt, pb->d_camtab, pbpts, pb->d_e, pb->d_Ac, pb->d_Bc));
             } else
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_jacobian<C, true, false>), dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream,
-                                                  P.cfg, P.nvis, pb->d_cam_cam, pb->d_cam_pt, pb->d_camtab, pbpts, pb->d_Jc));
+                                                  P.cfg, P.nvis, pb->d_cam_cam, pb->d_cam_pt, pb->d_camtab, pbpts, pb->d_e, pb->d_Ac, pb->d_Bc));
         } else {
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_jacobian<C, false, false>), dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream,
-                                                  P.cfg, P.nvis, pb->d_cam_cam, pb->d_cam_pt, pb->d_camtab, pbpts, pb->d_Jc));
+                                                  P.cfg, P.nvis, pb->d_cam_cam, pb->d_cam_pt, pb->d_camtab, pbpts, pb->d_e, pb->d_Ac, pb->d_Bc));
         }
     }
     ph_end(pb, PH_JAC);
@@ -349,7 +349,7 @@ int compute_normal_blocks(bsfm_problem* pb)
     if (P.ccon)
         hipLaunchKernelGGL(k_cam_constraints, dim3(grid_for((size_t)P.m * cnp, 256)), dim3(256), 0, pb->stream, P, pb->d_p);
     ph_begin(pb, PH_PTBLK);
-    if (P.n > 0 && !pb->mot) DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_point_blocks<C>), dim3(grid_for(P.n, 256)), dim3(256), 0, pb->stream, P, pb->d_e, pbpts));
+    if (P.n > 0 && !pb->mot) DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_point_blocks<C>), dim3(grid_for(P.n, 256)), dim3(256), 0, pb->stream, P, pbpts));
     ph_end(pb, PH_PTBLK);
     return 0;
 }
@@ -430,8 +430,10 @@ int compute_schur(bsfm_problem* pb, double mu)
         hipLaunchKernelGGL(k_rhs_init, dim3(grid_for((size_t)mm * cnp, 256)), dim3(256), 0, pb->stream, mm * cnp, P.mcon * cnp,
                            lead, pb->d_ea, Edst);
     if (pb->ntasks > 0) {
-        DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks_mfma<C>), dim3((pb->nslots + 3) / 4), dim3(256), 0, pb->stream,
-                                              P, pb->d_tasks, pb->nslots, pb->d_triples, pb->d_tri_pt, pb->d_partials, pb->d_epart));
+        // C_ij = B_ij V*_i^-1 || C_ij eb_i for this attempt's mu, then the task kernel (schur.hip.h)
+        hipLaunchKernelGGL(k_schur_prep, dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream, P.nvis, pb->d_cam_pt, pb->d_Bc, pb->d_Vinv, pb->d_eb, pb->d_Cc);
+        DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks<C>), dim3((pb->nslots + 3) / 4), dim3(256), 0, pb->stream,
+                                              P, pb->d_tasks, pb->nslots, pb->d_triples, pb->d_partials, pb->d_epart));
         if (packed) {
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_pack<C>), dim3(pb->nblk), dim3(128), 0, pb->stream, pb->nblk,
                                                   pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0, pb->d_partials, pb->d_epart,
@@ -534,7 +536,7 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     P.cfg.cnp = cnp; P.cfg.est_focal = d->est_focal_length ? 1 : 0; P.cfg.undistort = d->undistort ? 1 : 0;
     P.cfg.explicit_centers = d->explicit_camera_centers ? 1 : 0;
     P.cfg.f_scale = 0.001; P.cfg.k_scale = 5.0;                    // sfm.c:634-635
-    P.n = n; P.m = m; P.mcon = d->mcon; P.nvis = nvis; P.js = 2 * cnp + 6;
+    P.n = n; P.m = m; P.mcon = d->mcon; P.nvis = nvis;
     pb->world = d->world_size > 1 ? d->world_size : 1; pb->rank = d->world_size > 1 ? d->rank : 0;
     pb->nvis_global = d->nvis_global > 0 ? d->nvis_global : nvis;
     pb->mot = d->fix_points ? 1 : 0;
@@ -572,12 +574,13 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     DM(pb->d_p, pb->nvars_local); DM(pb->d_pdp, pb->nvars_local); DM(pb->d_dp, pb->nvars_local);
     DM(pb->d_camtab, (size_t)m * CT_STRIDE); DM(pb->d_camtab_trial, (size_t)m * CT_STRIDE);
     DM(pb->d_e, 2 * (size_t)nvis); DM(pb->d_hx, 2 * (size_t)nvis);
-    DM(pb->d_Jc, (size_t)nvis * P.js); DM(pb->d_campart, (size_t)m * CAM_SPLIT * (cnp * (cnp + 1) / 2 + cnp)); DM(pb->d_U, (size_t)m * cnp * cnp + (size_t)m * cnp); pb->d_ea = pb->d_U + (size_t)m * cnp * cnp;   /* one buffer: one exchange */
+    DM(pb->d_Ac, (size_t)nvis * 2 * cnp); DM(pb->d_Bc, (size_t)nvis * 8); if (!pb->mot) { DM(pb->d_Cc, (size_t)nvis * 8); } DM(pb->d_xc, 2 * (size_t)nvis); DM(pb->d_campart, (size_t)m * CAM_SPLIT * (cnp * (cnp + 1) / 2 + cnp)); DM(pb->d_U, (size_t)m * cnp * cnp + (size_t)m * cnp); pb->d_ea = pb->d_U + (size_t)m * cnp * cnp;   /* one buffer: one exchange */
     DM(pb->d_V, 6 * (size_t)n); DM(pb->d_Vinv, 6 * (size_t)n); DM(pb->d_eb, 3 * (size_t)n);
     DM(pb->d_S, (size_t)pb->ld * pb->ld); DM(pb->d_E, pb->ld);
     pb->red_blocks = std::max(grid_for(nvis, RES_BLOCK), std::max(grid_for(n, 256), 1024));
     DM(pb->d_red, 4 * (size_t)pb->red_blocks); DM(pb->d_scal, SC_COUNT + 16); DM(pb->d_mixed, 8 + 4 * (size_t)std::max(1, d->world_size)); DM(pb->d_flags, 4);
 #undef DM
+    if (nvis > 0) hipLaunchKernelGGL(k_permute16, dim3(grid_for(nvis, 256)), dim3(256), 0, pb->stream, nvis, pb->d_camobs, pb->d_x, pb->d_xc);   // measurements in camera-major order
     if (hipHostMalloc((void**)&pb->h_scal, (SC_COUNT + 16) * sizeof(double)) != hipSuccess) return fail("pinned");
     if (hipHostMalloc((void**)&pb->h_flags, 4 * sizeof(int)) != hipSuccess) return fail("pinned");
     (void)hipMemsetAsync(pb->d_scal, 0, (SC_COUNT + 16) * sizeof(double), pb->stream); (void)hipMemsetAsync(pb->d_flags, 0, 4 * sizeof(int), pb->stream);
@@ -632,10 +635,10 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
         P.pweight = d->point_constraint_weight;
     }
     if (!ok) return fail("upload");
-    P.x = pb->d_x; P.obs_cam = pb->d_obs_cam; P.obs_pt = pb->d_obs_pt; P.rowptr = pb->d_rowptr;
+    P.x = pb->d_x; P.xc = pb->d_xc; P.obs_cam = pb->d_obs_cam; P.obs_pt = pb->d_obs_pt; P.rowptr = pb->d_rowptr;
     P.camptr = pb->d_camptr; P.camobs = pb->d_camobs; P.campos = pb->d_campos; P.cam_pt = pb->d_cam_pt; P.cam_cam = pb->d_cam_cam; P.Rinit = pb->d_Rinit; P.finit = pb->d_finit;
     P.ccon = pb->d_ccon; P.cval = pb->d_cval; P.cw = pb->d_cw; P.pcon = pb->d_pcon; P.pval = pb->d_pval;
-    P.Jc = pb->d_Jc; P.U = pb->d_U; P.ea = pb->d_ea; P.V = pb->d_V; P.Vinv = pb->d_Vinv; P.eb = pb->d_eb;
+    P.Ac = pb->d_Ac; P.Bc = pb->d_Bc; P.Cc = pb->d_Cc; P.U = pb->d_U; P.ea = pb->d_ea; P.V = pb->d_V; P.Vinv = pb->d_Vinv; P.eb = pb->d_eb;
     if (potrf_init(pb->potrf, pb->ld, pb->opt.potrf_backend) != 0) return fail("potrf workspace");
     pb->ev_ok = true;
     for (int i = 0; i < PH_COUNT; ++i) {
@@ -1257,7 +1260,11 @@ int bsfm_eval_residuals(bsfm_problem_t* pb, double* e_out, double* cost)
                        pb->d_p + (size_t)pb->P.m * pb->cnp, 1, pb->d_scal + SC_CCOST);
     if (read_scalars(pb)) return BSFM_ERROR;
     if (cost) *cost = pb->h_scal[SC_COST] + pb->h_scal[SC_CCOST];
-    if (e_out && pb->P.nvis) HIP_OK(hipMemcpy(e_out, pb->d_e, 2 * (size_t)pb->P.nvis * sizeof(double), hipMemcpyDeviceToHost));
+    if (e_out && pb->P.nvis) {   // the device copy is camera-major: back to observation (CRS) order through the trial buffer
+        hipLaunchKernelGGL(k_permute16, dim3(grid_for(pb->P.nvis, 256)), dim3(256), 0, pb->stream, pb->P.nvis, pb->d_campos, pb->d_e, pb->d_hx);
+        HIP_OK(hipStreamSynchronize(pb->stream));
+        HIP_OK(hipMemcpy(e_out, pb->d_hx, 2 * (size_t)pb->P.nvis * sizeof(double), hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 
@@ -1291,12 +1298,19 @@ int bsfm_eval_normal_equations(bsfm_problem_t* pb, double mu, double* U, double*
         (void)hipFree(tmp);
     }
     if (eb && n) HIP_OK(hipMemcpy(eb, pb->d_eb, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-    if (J && pb->P.nvis) {   // the device copy is camera-major: back to observation order on the host (export path only)
-        const size_t nv = (size_t)pb->P.nvis, js = (size_t)pb->P.js;
-        std::vector<double> jc(nv * js); std::vector<int> pos(nv);
-        HIP_OK(hipMemcpy(jc.data(), pb->d_Jc, nv * js * sizeof(double), hipMemcpyDeviceToHost));
+    if (J && pb->P.nvis) {   // the device copies are camera-major and chunked: back to the reference's record A (2 x cnp) || B (2 x 3) in
+                             // observation order on the host (export path only)
+        const size_t nv = (size_t)pb->P.nvis, js = (size_t)(2 * cnp + 6);
+        std::vector<double> ac(nv * 2 * cnp), bc(nv * 8); std::vector<int> pos(nv);
+        HIP_OK(hipMemcpy(ac.data(), pb->d_Ac, ac.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(bc.data(), pb->d_Bc, bc.size() * sizeof(double), hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(pos.data(), pb->d_campos, nv * sizeof(int), hipMemcpyDeviceToHost));
-        for (size_t k = 0; k < nv; ++k) memcpy(J + k * js, jc.data() + (size_t)pos[k] * js, js * sizeof(double));
+        for (size_t k = 0; k < nv; ++k) {
+            const double* a = ac.data() + (size_t)pos[k] * 2 * cnp; const double* b = bc.data() + (size_t)pos[k] * 8;
+            double* o = J + k * js;
+            for (int c = 0; c < cnp; ++c) { o[c] = a[2 * c]; o[cnp + c] = a[2 * c + 1]; }
+            for (int q = 0; q < 6; ++q) o[2 * cnp + q] = b[q];
+        }
     }
     if (S && pb->Sdim) HIP_OK(hipMemcpy2D(S, (size_t)pb->Sdim * sizeof(double), pb->d_S, (size_t)pb->ld * sizeof(double),
                                           (size_t)pb->Sdim * sizeof(double), pb->Sdim, hipMemcpyDeviceToHost));
