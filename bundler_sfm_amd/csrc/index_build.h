@@ -9,7 +9,11 @@ namespace bsfm {
 // consecutive slots, which fixes the summation order; the array itself is in LAUNCH order, see index_build.hip) or -1 = padding
 struct SchurTask { int start; int count; int diag; int out; };
 
-constexpr int SCHUR_CHUNK = 168;      // co-visibility triples per task = 8 passes of 21 (schur.hip.h)
+constexpr int SCHUR_CHUNK_MAX = 192;  // upper bound of the co-visibility triples per task (LDS of the task kernel, schur.hip.h)
+// Triples per task: a multiple of the kernel's pass of 16, BSFM_SCHUR_CHUNK overrides the default.  It is also the knob for the L2
+// working set of the task kernel: the ~55 tasks of a camera clique over one point range re-read each other's records, and what
+// is in flight per XCD (tasks x triples x 2 x 272 bytes) has to stay below its 4 MB.
+int schur_chunk();
 
 // Everything the LM kernels index with, built on the device from the CRS (rowptr, colidx) the caller hands over.
 // All pointers are device memory owned by the receiver (hipFree each one that is non-null).

@@ -115,26 +115,26 @@ __global__ void k_gen_triples(int n, int mcon, int mm, const int* __restrict__ r
 
 template <typename KeyT>
 __global__ void k_blocks(int nblk, int mcon, int mm, const KeyT* __restrict__ ukeys, const int* __restrict__ counts,
-                         int* __restrict__ blk_j, int* __restrict__ blk_k, int* __restrict__ ntask)
+                         int* __restrict__ blk_j, int* __restrict__ blk_k, int* __restrict__ ntask, int chunk)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblk) return;
     const unsigned long long key = (unsigned long long)ukeys[b];
     blk_j[b] = mcon + (int)(key / (unsigned long long)mm);
     blk_k[b] = mcon + (int)(key % (unsigned long long)mm);
-    ntask[b] = (counts[b] + SCHUR_CHUNK - 1) / SCHUR_CHUNK;
+    ntask[b] = (counts[b] + chunk - 1) / chunk;
 }
 
 // tasks in block order; blk_start / blk_task0 are the exclusive scans of the triple and task counts (entry nblk = totals)
 __global__ void k_tasks(int nblk, const int* __restrict__ blk_start, const int* __restrict__ blk_task0, const int* __restrict__ blk_j,
-                        const int* __restrict__ blk_k, SchurTask* __restrict__ tasks)
+                        const int* __restrict__ blk_k, SchurTask* __restrict__ tasks, int chunk)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblk) return;
     const int s0 = blk_start[b], s1 = blk_start[b + 1], diag = blk_j[b] == blk_k[b] ? 1 : 0;
     int t = blk_task0[b];
-    for (int s = s0; s < s1; s += SCHUR_CHUNK, ++t) {
-        SchurTask tk; tk.start = s; tk.count = min(SCHUR_CHUNK, s1 - s); tk.diag = diag; tk.out = t;
+    for (int s = s0; s < s1; s += chunk, ++t) {
+        SchurTask tk; tk.start = s; tk.count = min(chunk, s1 - s); tk.diag = diag; tk.out = t;
         tasks[t] = tk;
     }
 }
@@ -266,7 +266,7 @@ int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int
     IX_OK(tmp.alloc(&ntask, (size_t)nblk + 1)); IX_OK(tmp.alloc(&blk_start, (size_t)nblk + 1));
     IX_OK(hipMemsetAsync(ntask + nblk, 0, sizeof(int), st));
     IX_OK(hipMemsetAsync(counts + nblk, 0, sizeof(int), st));          // counts has nt + 1 >= nblk + 1 entries
-    hipLaunchKernelGGL((k_blocks<KeyT>), dim3(grid_for(nblk, 256)), dim3(256), 0, st, nblk, mcon, mm, ukeys, counts, ix.blk_j, ix.blk_k, ntask);
+    hipLaunchKernelGGL((k_blocks<KeyT>), dim3(grid_for(nblk, 256)), dim3(256), 0, st, nblk, mcon, mm, ukeys, counts, ix.blk_j, ix.blk_k, ntask, schur_chunk());
     size_t sb = 0;
     IX_OK(prim::exclusive_sum(nullptr, sb, ntask, ix.blk_task0, nblk + 1, st));
     void* d_scan = nullptr;
@@ -280,7 +280,7 @@ int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int
     SchurTask* tasks = nullptr;
     if (order_by_block) IX_OK(hipMalloc((void**)&tasks, std::max<size_t>(1, (size_t)ntasks) * sizeof(SchurTask)));
     else IX_OK(tmp.alloc(&tasks, (size_t)ntasks));
-    hipLaunchKernelGGL(k_tasks, dim3(grid_for(nblk, 256)), dim3(256), 0, st, nblk, blk_start, ix.blk_task0, ix.blk_j, ix.blk_k, tasks);
+    hipLaunchKernelGGL(k_tasks, dim3(grid_for(nblk, 256)), dim3(256), 0, st, nblk, blk_start, ix.blk_task0, ix.blk_j, ix.blk_k, tasks, schur_chunk());
     hipLaunchKernelGGL(k_tri_pt, dim3(grid_for(nt, 256)), dim3(256), 0, st, (int)nt, vals_out, ix.cam_pt, ix.tri_pt);
     if (order_by_block) { ix.tasks = tasks; ix.nslots = ntasks; }
     else {
@@ -545,6 +545,17 @@ int build_index_device(int n, int m, int mcon, int nvis, const int* d_rowptr, co
     return 0;
 }
 
+int schur_chunk()
+{
+    static const int v = [] {
+        int c = 192;
+        if (const char* e = getenv("BSFM_SCHUR_CHUNK")) c = atoi(e);
+        c = (std::max(16, std::min(SCHUR_CHUNK_MAX, c)) + 15) / 16 * 16;
+        return std::min(c, SCHUR_CHUNK_MAX);
+    }();
+    return v;
+}
+
 // ---- dense visibility mask -> CRS on the device ------------------------------------------
 // The reference's contract (lib/sba-1.5/sba_levmar.c:642-663): the k-th non-zero byte of vmask in row-major order is measurement k;
 // rowptr[i] = number of non-zero bytes before row i, colidx[k] = column of the k-th one.  At 1 000 cameras / 500 000 points the mask
@@ -626,6 +637,19 @@ __global__ __launch_bounds__(256) void k_vmask_fill(const uint4* __restrict__ vm
 
 }  // namespace
 
+namespace {
+struct PlainAlloc {          // hipMalloc'ed temporaries, freed on scope exit
+    std::vector<void*> p;
+    ~PlainAlloc() { for (void* q : p) if (q) (void)hipFree(q); }
+    template <typename T> hipError_t alloc(T** out, size_t count)
+    {
+        const hipError_t e = hipMalloc(reinterpret_cast<void**>(out), std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) p.push_back(*out);
+        return e;
+    }
+};
+}  // namespace
+
 int crs_from_vmask_device(int n, int m, const char* h_vmask, int** d_rowptr_out, int** d_colidx_out, int* nvis_out, double ms_out[3],
                           hipStream_t st)
 {
@@ -638,11 +662,15 @@ int crs_from_vmask_device(int n, int m, const char* h_vmask, int** d_rowptr_out,
     if (npieces > (size_t)INT_MAX) { fprintf(stderr, "[bsfm] visibility mask too large\n"); return -1; }
     const auto t0 = std::chrono::steady_clock::now();
     auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
-    Scratch tmp(st);
+    // Plain hipMalloc for everything hipMemcpy touches here.  With stream-ordered POOL memory (Scratch) this function returned zeros for
+    // particular mask sizes when it was the first device work of a process: the uploaded mask was there for kernels but read back as
+    // zeros by a device-to-host copy and vice versa (debug dumps, round 3) -- pool blocks and the copy engines do not mix reliably on
+    // this runtime.  The three allocations cost ~0.1 ms against a 9 ms upload at the headline size.
+    PlainAlloc tmp;
     char* d_vm = nullptr; int* d_cnt = nullptr; int* d_off = nullptr;
     IX_OK(tmp.alloc(&d_vm, padded)); IX_OK(tmp.alloc(&d_cnt, npieces + 1)); IX_OK(tmp.alloc(&d_off, npieces + 1));
-    if (padded > total) IX_OK(hipMemsetAsync(d_vm + (padded - 16), 0, 16, st));
-    if (total) IX_OK(hipMemcpyAsync(d_vm, h_vmask, total, hipMemcpyHostToDevice, st));
+    if (padded > total) { IX_OK(hipMemsetAsync(d_vm + (padded - 16), 0, 16, st)); IX_OK(hipStreamSynchronize(st)); }
+    if (total) IX_OK(hipMemcpy(d_vm, h_vmask, total, hipMemcpyHostToDevice));
     IX_OK(hipStreamSynchronize(st));
     if (ms_out) ms_out[0] = ms_since(t0);                               // upload (pageable host memory: staged by the runtime)
     const auto t1 = std::chrono::steady_clock::now();
@@ -654,20 +682,19 @@ int crs_from_vmask_device(int n, int m, const char* h_vmask, int** d_rowptr_out,
     IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_scan), sb));
     IX_OK(prim::exclusive_sum(d_scan, sb, d_cnt, d_off, npieces + 1, st));
     int nvis = 0;
-    IX_OK(hipMemcpyAsync(&nvis, d_off + npieces, sizeof(int), hipMemcpyDeviceToHost, st));
     IX_OK(hipStreamSynchronize(st));
+    IX_OK(hipMemcpy(&nvis, d_off + npieces, sizeof(int), hipMemcpyDeviceToHost));
     if (nvis < 0) { fprintf(stderr, "[bsfm] visibility mask: more than 2^31-1 observations\n"); return -1; }
     int *rp = nullptr, *ci = nullptr;
     IX_OK(keep(&rp, (size_t)n + 1));
     if (keep(&ci, (size_t)nvis) != hipSuccess) { (void)hipFree(rp); return -1; }
     hipLaunchKernelGGL(k_vmask_fill, dim3((unsigned)npieces), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_vm), nwords16, total, n, m,
                        d_off, rp, ci);
-    // rows that start at or beyond the last byte (only i = n when n*m is a multiple of 16, and every row of an empty mask) point at nvis
-    if ((size_t)n * (size_t)m >= padded || total == 0) {
-        const int last = nvis;
-        if (total == 0) { std::vector<int> z((size_t)n + 1, 0); if (hipMemcpyAsync(rp, z.data(), z.size() * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(rp); (void)hipFree(ci); return -1; } }
-        else if (hipMemcpyAsync(rp + n, &last, sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) { (void)hipFree(rp); (void)hipFree(ci); return -1; }
-    }
+    // rowptr[n] = nvis: no lane covers byte n*m when the mask length is a multiple of 16 (and nothing at all is covered by an empty
+    // mask); copied device-to-device from the scan's total -- not from a host temporary, whose lifetime an asynchronous copy would
+    // outlive (round 3: a flaky rowptr[n] in the n*m = 65 536 test case)
+    if (total == 0) { if (hipMemsetAsync(rp, 0, ((size_t)n + 1) * sizeof(int), st) != hipSuccess) { (void)hipFree(rp); (void)hipFree(ci); return -1; } }
+    else if (hipMemcpyAsync(rp + n, d_off + npieces, sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess) { (void)hipFree(rp); (void)hipFree(ci); return -1; }
     if (hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(rp); (void)hipFree(ci); return -1; }
     if (ms_out) { ms_out[1] = ms_since(t1); ms_out[2] = ms_since(t0); }
     *d_rowptr_out = rp; *d_colidx_out = ci; *nvis_out = nvis;

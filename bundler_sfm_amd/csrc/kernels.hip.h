@@ -65,6 +65,15 @@ __device__ __forceinline__ double wave_sum(double v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
 }
+// value of lane Q of every quad (DPP quad_perm [Q, Q, Q, Q]): two 32-bit moves, no LDS
+template <int Q>
+__device__ __forceinline__ double quad_bcast_d(double v)
+{
+    constexpr int ctrl = Q | (Q << 2) | (Q << 4) | (Q << 6);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_max(double v)
 {
 #pragma unroll
@@ -186,17 +195,14 @@ __global__ __launch_bounds__(256) void k_jacobian(ModelCfg cfg, int nvis,
     // The 256 records of a workgroup are contiguous in both streams: they are transposed through LDS so that every store
     // instruction writes 64 x 16 consecutive bytes (a lane-per-record store touches 64 different cache lines per instruction,
     // 16 bytes of each: the kernel was bound by those write transactions, 0.43 ms for 960 MB).
-    constexpr int LA = CNP + 1 - (CNP & 1);                  // LDS row strides in chunks (odd: conflict-free column writes)
+    // The two streams go through the SAME staging area one after the other (37 KB: three workgroups per CU; both at once were 57 KB:
+    // two, and the kernel went from 0.31 to 0.41 ms).
+    constexpr int LA = CNP + 1 - (CNP & 1);                  // LDS row stride in chunks (odd: conflict-free column writes)
     constexpr int LB = 5;
-    __shared__ double2 stage[256 * (LA + LB)];
+    __shared__ double2 stage[256 * LA];
     double2* mineA = stage + threadIdx.x * LA;
-    double2* stageB = stage + 256 * LA;
-    double2* mineB = stageB + threadIdx.x * LB;
 #pragma unroll
     for (int q = 0; q < CNP; ++q) mineA[q] = make_double2(A[q], A[CNP + q]);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) mineB[q] = make_double2(B[2 * q], B[2 * q + 1]);
-    mineB[3] = et;
     __syncthreads();
     const int t0 = blockIdx.x * 256;
     const int nrec = min(256, nvis - t0);
@@ -205,8 +211,15 @@ __global__ __launch_bounds__(256) void k_jacobian(ModelCfg cfg, int nvis,
         const int rec = c / CNP, part = c - rec * CNP;
         outa[c] = stage[rec * LA + part];
     }
+    __syncthreads();
+    static_assert(LB <= LA, "the B || e records reuse the staging area of the A chunks");
+    double2* mineB = stage + threadIdx.x * LB;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) mineB[q] = make_double2(B[2 * q], B[2 * q + 1]);
+    mineB[3] = et;
+    __syncthreads();
     double2* outb = reinterpret_cast<double2*>(Bc + (size_t)t0 * 8);
-    for (int c = threadIdx.x; c < nrec * 4; c += 256) outb[c] = stageB[(c >> 2) * LB + (c & 3)];
+    for (int c = threadIdx.x; c < nrec * 4; c += 256) outb[c] = stage[(c >> 2) * LB + (c & 3)];
 }
 
 // N 16-byte loads of 2N consecutive doubles.  Jacobian records are 16-byte aligned (even length, 2*cnp even), which
@@ -363,26 +376,39 @@ __global__ __launch_bounds__(256) void k_point_invert(int n, double mu, const do
 // one 64-byte record.  With it a Schur task forms its 2 x 2 core as C_ij B_ik^T (12 FMAs) from two 48-byte operands instead of
 // gathering V*_i^-1 and doing the 3 x 3 product per co-visibility triple (a point with d cameras is in d (d + 1) / 2 triples), and
 // the reduced right-hand side needs no eb gather: e_j -= sum_i A_ij^T r_ij (sba_levmar.c:1195-1216, 1320-1339: Y_ij = W_ij V*_i^-1).
-__global__ __launch_bounds__(256) void k_schur_prep(int nvis, const int* __restrict__ cam_pt, const double* __restrict__ Bc,
-        const double* __restrict__ Vinv, const double* __restrict__ eb, double* __restrict__ Cc)
+// Walked in POINT-major (CRS) order with FOUR lanes per observation: V*_i^-1 and eb_i of consecutive observations are the same or the
+// next point (streamed; in camera-major order every camera sweeps the whole 36 MB of point data past L2: 0.28 ms), the B || e record
+// is ONE 64-byte sector fetched by the quad (lane q loads chunk q, the six B values go round by DPP), and lane q stores chunk q of the
+// C || r record: one whole 64-byte sector per quad, gathered and scattered through campos[].
+__global__ __launch_bounds__(256) void k_schur_prep(int nvis, const int* __restrict__ obs_pt, const int* __restrict__ campos,
+        const double* __restrict__ Bc, const double* __restrict__ Vinv, const double* __restrict__ eb, double* __restrict__ Cc)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= nvis) return;
-    double B[6], vi[6];
-    load_pairs<3>(Bc + (size_t)t * 8, B);
-    const int i = cam_pt[t];
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t k = min(g >> 2, (size_t)nvis - 1);               // surplus quads of the last workgroup repeat the last observation
+    const int q = (int)(g & 3);
+    const size_t t = (size_t)campos[k];
+    const int i = obs_pt[k];
+    const double2 mine = reinterpret_cast<const double2*>(Bc)[t * 4 + q];
+    double vi[6];
     load_pairs<3>(Vinv + (size_t)i * 6, vi);
-    const double e0 = eb[(size_t)i * 3], e1 = eb[(size_t)i * 3 + 1], e2 = eb[(size_t)i * 3 + 2];
+    const double b0 = quad_bcast_d<0>(mine.x), b1 = quad_bcast_d<0>(mine.y), b2 = quad_bcast_d<1>(mine.x);
+    const double b3 = quad_bcast_d<1>(mine.y), b4 = quad_bcast_d<2>(mine.x), b5 = quad_bcast_d<2>(mine.y);
     const double i00 = vi[0], i01 = vi[1], i02 = vi[2], i11 = vi[3], i12 = vi[4], i22 = vi[5];
-    const double c00 = B[0] * i00 + B[1] * i01 + B[2] * i02;
-    const double c01 = B[0] * i01 + B[1] * i11 + B[2] * i12;
-    const double c02 = B[0] * i02 + B[1] * i12 + B[2] * i22;
-    const double c10 = B[3] * i00 + B[4] * i01 + B[5] * i02;
-    const double c11 = B[3] * i01 + B[4] * i11 + B[5] * i12;
-    const double c12 = B[3] * i02 + B[4] * i12 + B[5] * i22;
-    double2* o = reinterpret_cast<double2*>(Cc + (size_t)t * 8);
-    o[0] = make_double2(c00, c01); o[1] = make_double2(c02, c10); o[2] = make_double2(c11, c12);
-    o[3] = make_double2(c00 * e0 + c01 * e1 + c02 * e2, c10 * e0 + c11 * e1 + c12 * e2);
+    const double c00 = b0 * i00 + b1 * i01 + b2 * i02;
+    const double c01 = b0 * i01 + b1 * i11 + b2 * i12;
+    const double c02 = b0 * i02 + b1 * i12 + b2 * i22;
+    const double c10 = b3 * i00 + b4 * i01 + b5 * i02;
+    const double c11 = b3 * i01 + b4 * i11 + b5 * i12;
+    const double c12 = b3 * i02 + b4 * i12 + b5 * i22;
+    double2 o;
+    if (q == 0) o = make_double2(c00, c01);
+    else if (q == 1) o = make_double2(c02, c10);
+    else if (q == 2) o = make_double2(c11, c12);
+    else {
+        const double e0 = eb[(size_t)i * 3], e1 = eb[(size_t)i * 3 + 1], e2 = eb[(size_t)i * 3 + 2];
+        o = make_double2(c00 * e0 + c01 * e1 + c02 * e2, c10 * e0 + c11 * e1 + c12 * e2);
+    }
+    if ((g >> 2) < (size_t)nvis) reinterpret_cast<double2*>(Cc)[t * 4 + q] = o;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -39,17 +39,9 @@
 
 namespace bsfm {
 
-// value of lane Q of every quad (DPP quad_perm [Q, Q, Q, Q]): two 32-bit moves, no LDS
-template <int Q>
-__device__ __forceinline__ double quad_bcast(double v)
-{
-    constexpr int ctrl = Q | (Q << 2) | (Q << 4) | (Q << 6);
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
+template <int Q> __device__ __forceinline__ double quad_bcast(double v) { return quad_bcast_d<Q>(v); }
 
-constexpr int SCH_MAXT = 168;         // triples per task (SCHUR_CHUNK in index_build.h)
+constexpr int SCH_MAXT = SCHUR_CHUNK_MAX;   // triples per task at most (index_build.h)
 
 // (k_schur_tasks_v2, the round-1 VALU kernel -- 3 lanes per triple, 224 VGPRs, 1.56 ms at config 3 -- was removed from the library in
 // round 3; its description above is kept because the staging scheme is shared.)
@@ -77,18 +69,21 @@ constexpr int SCH_MAXT = 168;         // triples per task (SCHUR_CHUNK in index_
 // epilogue are those of round 2.  v_mfma_f64_16x16x4: A[i][k] at lane i + 16 k, B[k][j] at lane j + 16 k, D[i][j]: register r of
 // lane l = row 4 r + (l >> 4), column l & 15 (scripts/probe_mfma16.hip).
 constexpr int SCM_PASS = 16;          // triples per pass (4 lanes each)
-#ifndef BSFM_SCHUR_WPS
-#define BSFM_SCHUR_WPS 3              // waves per SIMD the kernel is compiled for (workgroups per CU)
-#endif
-
-template <int CNP>
-__global__ __launch_bounds__(256, BSFM_SCHUR_WPS) void k_schur_tasks(DevProblem P, const SchurTask* __restrict__ tasks, int ntasks,
+// WPS: waves per SIMD the kernel is compiled for (= workgroups per CU); BSFM_SCHUR_WPS selects 2 / 3 / 4 at run time
+// Split timing at config 3 (variants of this kernel, not kept; profiles/r03_schur_split.txt): as shipped 1.02 ms (3 workgroups per CU,
+// 160 triples per task; 0.94 with 4 per CU and 192); no gathers after a task's first pass 0.63; no matrix instructions 0.79; gathers +
+// 2 x 2 core only (no LDS, no matrix instructions) 0.81 -- the kernel is bound by the L1-miss path of its 16-byte gathers (11.4 GB
+// per launch through L1 = 23 bytes / clock / CU, of which 1.7-3.3 GB miss L2), no longer by the LDS pipeline (SQ_LDS_IDX_ACTIVE 30 %
+// of the kernel, was 85 %) or the matrix pipe (35 % busy).
+template <int CNP, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_schur_tasks(DevProblem P, const SchurTask* __restrict__ tasks, int ntasks,
         const int2* __restrict__ triples, double* __restrict__ partials, double* __restrict__ epart)
 {
     typedef double d2_ __attribute__((ext_vector_type(2)));
     typedef double v4d_ __attribute__((ext_vector_type(4)));
     constexpr int ROWC = 16;                          // chunks per slab row (256 bytes)
     constexpr bool THIRD = CNP > 8;                   // a ninth chunk exists (lane q = 0 takes it)
+    constexpr bool ALLC = CNP >= 8;                   // chunks 0 .. 7 all exist: no per-lane column test
     __shared__ __attribute__((aligned(16))) d2_ smx[4][SCM_PASS * ROWC];
     __shared__ __attribute__((aligned(16))) d2_ smy[4][SCM_PASS * ROWC];
     __shared__ int2 sm_tri[4][SCH_MAXT];
@@ -141,8 +136,8 @@ __global__ __launch_bounds__(256, BSFM_SCHUR_WPS) void k_schur_tasks(DevProblem 
         if (!live_) { m00 = 0.0; m01 = 0.0; m10 = 0.0; m11 = 0.0; }                                                 \
         d2_* xr_ = X + p * ROWC;                                                                                    \
         d2_* yr_ = Y + p * ROWC;                                                                                    \
-        if (c0 < CNP) { xr_[c0] = aj[S_][0]; const d2_ y_ = { m00 * ak[S_][0].x + m01 * ak[S_][0].y, m10 * ak[S_][0].x + m11 * ak[S_][0].y }; yr_[c0] = y_; } \
-        if (c1 < CNP) { xr_[c1] = aj[S_][1]; const d2_ y_ = { m00 * ak[S_][1].x + m01 * ak[S_][1].y, m10 * ak[S_][1].x + m11 * ak[S_][1].y }; yr_[c1] = y_; } \
+        if (ALLC || c0 < CNP) { xr_[c0] = aj[S_][0]; const d2_ y_ = { m00 * ak[S_][0].x + m01 * ak[S_][0].y, m10 * ak[S_][0].x + m11 * ak[S_][0].y }; yr_[c0] = y_; } \
+        if (ALLC || c1 < CNP) { xr_[c1] = aj[S_][1]; const d2_ y_ = { m00 * ak[S_][1].x + m01 * ak[S_][1].y, m10 * ak[S_][1].x + m11 * ak[S_][1].y }; yr_[c1] = y_; } \
         if (THIRD && q == 0) { xr_[CNP - 1] = aj[S_][2]; const d2_ y_ = { m00 * ak[S_][2].x + m01 * ak[S_][2].y, m10 * ak[S_][2].x + m11 * ak[S_][2].y }; yr_[CNP - 1] = y_; } \
         if (diag && q == 3) { const d2_ r_ = { live_ ? cj[S_].x : 0.0, live_ ? cj[S_].y : 0.0 }; yr_[CNP] = r_; }   \
         /* same wave: LDS operations complete in order, the reads below see the stores above */                    \

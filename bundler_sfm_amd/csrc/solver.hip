@@ -144,7 +144,7 @@ int setup_components(bsfm_problem* pb, const std::vector<int>& bj, const std::ve
 
 // Takes over the arrays of the device-side index construction (index_build.hip): camera-major maps and, unless the problem is
 // camera-only, the co-visibility triples bucketed by reduced-camera block (j <= k) in (j,k) order and, inside a block, in
-// point order -- the order the reference visits them (sba_levmar.c:1218-1268) -- cut into tasks of <= SCHUR_CHUNK triples.
+// point order -- the order the reference visits them (sba_levmar.c:1218-1268) -- cut into tasks of <= schur_chunk() triples.
 int adopt_index(bsfm_problem* pb, DeviceIndex& ix)
 {
     pb->d_obs_pt = ix.obs_pt; pb->d_camptr = ix.camptr; pb->d_camobs = ix.camobs; pb->d_campos = ix.campos;
@@ -431,9 +431,12 @@ int compute_schur(bsfm_problem* pb, double mu)
                            lead, pb->d_ea, Edst);
     if (pb->ntasks > 0) {
         // C_ij = B_ij V*_i^-1 || C_ij eb_i for this attempt's mu, then the task kernel (schur.hip.h)
-        hipLaunchKernelGGL(k_schur_prep, dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream, P.nvis, pb->d_cam_pt, pb->d_Bc, pb->d_Vinv, pb->d_eb, pb->d_Cc);
-        DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks<C>), dim3((pb->nslots + 3) / 4), dim3(256), 0, pb->stream,
-                                              P, pb->d_tasks, pb->nslots, pb->d_triples, pb->d_partials, pb->d_epart));
+        hipLaunchKernelGGL(k_schur_prep, dim3(grid_for(4 * (size_t)P.nvis, 256)), dim3(256), 0, pb->stream, P.nvis, pb->d_obs_pt, pb->d_campos, pb->d_Bc, pb->d_Vinv, pb->d_eb, pb->d_Cc);
+        static const int wps = [] { const char* e = getenv("BSFM_SCHUR_WPS"); const int v = e ? atoi(e) : 4; return v < 2 ? 2 : (v > 4 ? 4 : v); }();
+        const dim3 sg((pb->nslots + 3) / 4);
+        if (wps == 2) { DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks<C, 2>), sg, dim3(256), 0, pb->stream, P, pb->d_tasks, pb->nslots, pb->d_triples, pb->d_partials, pb->d_epart)); }
+        else if (wps == 4) { DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks<C, 4>), sg, dim3(256), 0, pb->stream, P, pb->d_tasks, pb->nslots, pb->d_triples, pb->d_partials, pb->d_epart)); }
+        else { DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks<C, 3>), sg, dim3(256), 0, pb->stream, P, pb->d_tasks, pb->nslots, pb->d_triples, pb->d_partials, pb->d_epart)); }
         if (packed) {
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_pack<C>), dim3(pb->nblk), dim3(128), 0, pb->stream, pb->nblk,
                                                   pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0, pb->d_partials, pb->d_epart,
@@ -820,6 +823,7 @@ int bsfm_problem_export_schur(bsfm_problem_t* pb, int* triples, int* tri_pt, int
     return ok ? 0 : BSFM_ERROR;
 }
 
+int bsfm_schur_chunk(void) { return schur_chunk(); }
 int bsfm_problem_cnp(const bsfm_problem_t* pb) { return pb->cnp; }
 int bsfm_problem_num_cameras(const bsfm_problem_t* pb) { return pb->P.m; }
 int bsfm_problem_num_points(const bsfm_problem_t* pb) { return pb->P.n; }

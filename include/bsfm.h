@@ -248,6 +248,8 @@ int bsfm_problem_export_index(bsfm_problem_t *pb, int *rowptr, int *colidx, int 
  * block; tri_pt = point of a triple; blk_j / blk_k (nblk), blk_task0 (nblk + 1); tasks (4 ints each: start, count, diag, slot;
  * nslots entries in launch order, slot -1 = padding). */
 int bsfm_problem_schur_sizes(const bsfm_problem_t *pb, int *ntriples, int *nblk, int *ntasks, int *nslots);
+/* co-visibility triples per Schur task (a multiple of 16; default 192, BSFM_SCHUR_CHUNK overrides it before the first problem) */
+int bsfm_schur_chunk(void);
 int bsfm_problem_export_schur(bsfm_problem_t *pb, int *triples, int *tri_pt, int *blk_j, int *blk_k, int *blk_task0, int *tasks);
 /* dense vmask -> CRS exactly as run_sfm does it (host only); returns nvis, rowptr / colidx may be NULL. */
 int bsfm_crs_from_vmask(int n, int m, const char *vmask, int *rowptr, int *colidx);

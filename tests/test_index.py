@@ -135,7 +135,9 @@ def test_device_index_is_the_reference_index(gpu_bsfm, n, m, density, mcon, seed
     mm = m - mcon
     assert np.array_equal(sc["blk_j"], mcon + ukeys // mm) and np.array_equal(sc["blk_k"], mcon + ukeys % mm)
     counts = np.diff(np.append(starts, len(keys)))
-    ntask = (counts + 167) // 168
+    CH = int(B.lib.bsfm_schur_chunk())            # triples per task (index_build.hip:schur_chunk, BSFM_SCHUR_CHUNK)
+    assert CH % 16 == 0 and 16 <= CH <= 192
+    ntask = (counts + CH - 1) // CH
     assert np.array_equal(sc["blk_task0"], np.concatenate([[0], np.cumsum(ntask)]))
     tasks = sc["tasks"]; real = tasks[tasks[:, 3] >= 0]
     assert len(real) == sc["ntasks"] == int(ntask.sum())
@@ -144,8 +146,8 @@ def test_device_index_is_the_reference_index(gpu_bsfm, n, m, density, mcon, seed
     exp = []
     for b in range(len(ukeys)):
         for t in range(ntask[b]):
-            s0 = starts[b] + 168 * t
-            exp.append((s0, min(168, starts[b] + counts[b] - s0), int(sc["blk_j"][b] == sc["blk_k"][b])))
+            s0 = starts[b] + CH * t
+            exp.append((s0, min(CH, starts[b] + counts[b] - s0), int(sc["blk_j"][b] == sc["blk_k"][b])))
     assert np.array_equal(by_slot[:, :3], np.array(exp, np.int32).reshape(-1, 3))
     # launch order: sorted by the first point a task touches, one contiguous stretch per XCD (workgroup % 8)
     nwg = len(tasks) // 4
