@@ -412,6 +412,18 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
+    # how many ranks actually took part: every rank contributes 1 to a sum over the job's communicator (the driver's SCALE record can
+    # check it against --gpus; 1 on a single-GPU run)
+    ranks_seen = 1
+    if world > 1:
+        if comm:
+            one = (C.c_double * 1)(1.0)
+            B.lib.bsfm_comm_allreduce_host(comm, one, 1, 0)
+            ranks_seen = int(round(one[0]))
+        else:
+            tt = torch.tensor([1.0], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(tt)
+            ranks_seen = int(round(float(tt.item())))
     m, n, deg = args.cams, args.points, args.deg
     cnp = 9
     jac = B.JAC_FD if args.jacobian == "fd" else B.JAC_ANALYTIC
@@ -472,7 +484,7 @@ def main():
             "config": {"workload": f"synthetic BA {m} cams / {n} pts / {nvis_global} obs (BASELINE.json configs[2]), "
                                    f"cnp=9, {args.jacobian} Jacobian, point-sharded x{world}",
                        "cameras": m, "points": n, "observations": nvis_global, "jacobian": args.jacobian,
-                       "reduced_solver": args.reduced_solver, "collective": collective,
+                       "reduced_solver": args.reduced_solver, "collective": collective, "rccl_ranks_seen": ranks_seen,
                        "solve_attempts_per_step": round(r["att"] / max(done, 1), 3), "restarts_after_convergence": r["restarts"],
                        "problem_create_s": round(r["t_create"], 3),
                        "problem_create_ms": {k: round(pb.phase_ms("create_" + k), 2) for k in ("total", "upload", "index", "alloc")},

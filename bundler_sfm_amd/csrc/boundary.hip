@@ -27,6 +27,7 @@ namespace {
 
 // wall milliseconds of the phases of the last bsfm_run_sfm_ex call of this thread (bsfm_run_sfm_last_ms)
 thread_local double g_run_ms[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+thread_local int g_create_failed = 0;            // the last bsfm_run_sfm_ex could not even build its problem
 enum { RM_TOTAL = 0, RM_CRS, RM_CRS_UPLOAD, RM_CRS_KERNELS, RM_CREATE, RM_LM, RM_DOWNLOAD, RM_CRS_ON_DEVICE };
 inline double ms_since(std::chrono::steady_clock::time_point t0)
 {
@@ -112,6 +113,8 @@ struct MultiArgs {
     int optimize_for_fisheye;
 };
 
+constexpr int RUN_MULTI_NO_COMM = -1000;      // the communicator could not be created: nothing was touched
+
 int run_multi(int G, const std::vector<int>& devs, const MultiArgs& a, const bsfm_options_t& opt, double info[BSFM_INFOSZ])
 {
     const int n = a.n, m = a.m;
@@ -127,12 +130,17 @@ int run_multi(int G, const std::vector<int>& devs, const MultiArgs& a, const bsf
         for (int g = 1; g <= G; ++g) bounds[g] = std::max(bounds[g], bounds[g - 1]);
     }
     std::vector<bsfm_comm_t*> comms((size_t)G, nullptr);
-    if (bsfm_comm_create_all(G, devs.data(), comms.data()) != 0) { fprintf(stderr, "[bsfm] run_sfm: cannot set up the %d-GPU communicator\n", G); return BSFM_ERROR; }
+    if (bsfm_comm_create_all(G, devs.data(), comms.data()) != 0) return RUN_MULTI_NO_COMM;      // the caller falls back to one GPU
     std::vector<int> rcs((size_t)G, BSFM_ERROR);
     std::vector<std::vector<double>> infos((size_t)G, std::vector<double>(BSFM_INFOSZ, 0.0));
     std::vector<bsfm_camera_params_t> cam_out((size_t)m);
     auto worker = [&](int g) {
-        if (hipSetDevice(devs[g]) != hipSuccess) return;
+        if (hipSetDevice(devs[g]) != hipSuccess) {
+            // still take part in the "everybody has a problem" exchange, or the other ranks would wait for this one forever
+            double bad = 1.0;
+            (void)bsfm_comm_allreduce_host(comms[g], &bad, 1, 1);
+            return;
+        }
         const int lo = bounds[g], hi = bounds[g + 1], k0 = rp[lo];
         std::vector<int> lrp((size_t)(hi - lo) + 1);
         for (int i = lo; i <= hi; ++i) lrp[i - lo] = rp[i] - k0;
@@ -179,6 +187,9 @@ int run_multi(int G, const std::vector<int>& devs, const MultiArgs& a, const bsf
 }
 
 }  // namespace
+
+extern "C" int bsfm_last_call_infra_failure(void);
+extern "C" void bsfm_clear_infra_failure(void);
 
 extern "C" {
 
@@ -422,11 +433,16 @@ int bsfm_run_sfm_ex(int num_pts, int num_cameras, int ncons, char* vmask, double
                                 init_camera_params, reinterpret_cast<double*>(init_pts), use_constraints, use_point_constraints,
                                 reinterpret_cast<const double*>(points_constraints), point_constraint_weight, optimize_for_fisheye ? 1 : 0 };
                 const int rc = run_multi(G, devs, a, opt, info);
-                if (opt.verbose >= 1) {
-                    printf("[run_sfm] Number of iterations: %d\n", (int)info[5]);   // sfm.c:872-873
-                    printf("info[6] = %0.3f\n", info[6]);
+                if (rc != RUN_MULTI_NO_COMM) {
+                    if (opt.verbose >= 1) {
+                        printf("[run_sfm] Number of iterations: %d\n", (int)info[5]);   // sfm.c:872-873
+                        printf("info[6] = %0.3f\n", info[6]);
+                    }
+                    return rc;
                 }
-                return rc;
+                // librccl missing / ncclCommInitAll failed: the job still runs, on one GPU (it used to return an error
+                // that the void run_sfm could not report, and Bundler went on with unoptimised parameters)
+                fprintf(stderr, "[bsfm] run_sfm: the %d-GPU communicator could not be set up -- continuing on ONE GPU\n", G);
             }
         }
     }
@@ -447,7 +463,7 @@ int bsfm_run_sfm_ex(int num_pts, int num_cameras, int ncons, char* vmask, double
 
     const auto t_cr = std::chrono::steady_clock::now();
     bsfm_problem_t* pb = bsfm_problem_create(&d, &opt);
-    if (!pb) return BSFM_ERROR;
+    if (!pb) { g_create_failed = 1; return BSFM_ERROR; }
     g_run_ms[RM_CREATE] = ms_since(t_cr);
     const auto t_lm = std::chrono::steady_clock::now();
     int rc = bsfm_lm_begin(pb);
@@ -482,14 +498,20 @@ void run_sfm(int num_pts, int num_cameras, int ncons, char* vmask, double* proje
              int fix_points, int optimize_for_fisheye, double eps2,
              double* Vout, double* Sout, double* Uout, double* Wout)
 {
+    g_create_failed = 0;
+    bsfm_clear_infra_failure();
     const int rc = bsfm_run_sfm_ex(num_pts, num_cameras, ncons, vmask, projections, est_focal_length,
                                    const_focal_length, undistort, explicit_camera_centers, init_camera_params,
                                    init_pts, use_constraints, use_point_constraints, points_constraints,
                                    point_constraint_weight, fix_points, optimize_for_fisheye, eps2,
                                    Vout, Sout, Uout, Wout, nullptr, nullptr);
-    if (rc == BSFM_ERROR && bsfm_device_count() <= 0) {
-        // the reference's run_sfm cannot fail silently either (fatal paths exit(1), sba_levmar.c:72-83)
-        fprintf(stderr, "[bsfm] run_sfm: no HIP device and no CPU fallback -- aborting\n");
+    // run_sfm returns void: a failure of the machinery (no device, a HIP error, a problem that could not be built, a hand-off
+    // that timed out) must not look like a finished adjustment to the caller -- the reference's fatal paths exit(1) as well
+    // (lib/sba-1.5/sba_levmar.c:72-83).  SBA's own numerical exits (SBA_ERROR: stop 7, "almost singular", too few measurements)
+    // return to the caller as they do in the reference.
+    if (rc == BSFM_ERROR && (bsfm_device_count() <= 0 || g_create_failed || bsfm_last_call_infra_failure())) {
+        fprintf(stderr, "[bsfm] run_sfm: %s -- aborting (there is no CPU fallback)\n",
+                bsfm_device_count() <= 0 ? "no HIP device" : (g_create_failed ? "the problem could not be set up on the device" : "a device-side failure"));
         exit(1);
     }
 }

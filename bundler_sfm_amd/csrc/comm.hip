@@ -7,7 +7,12 @@
 //                                    RANK, WORLD_SIZE, LOCAL_RANK, MASTER_PORT from the environment; rank 0 draws the
 //                                    ncclUniqueId and hands it over through a file under /dev/shm (single node);
 //   * bsfm_comm_create_all           one rank per THREAD of one process (ncclCommInitAll over the visible devices): what
-//                                    run_sfm uses when it is asked for more than one GPU (boundary.hip);
+//                                    run_sfm uses when it is asked for more than one GPU (boundary.hip).  Every thread owns ONE
+//                                    communicator and ONE device and issues its all-reduces on its own stream in the same order
+//                                    as its peers: that is RCCL's "one thread per device" usage, which needs no
+//                                    ncclGroupStart / ncclGroupEnd (grouping is for ONE thread that drives SEVERAL communicators,
+//                                    where un-grouped blocking calls would deadlock); the communicators are created together
+//                                    by ncclCommInitAll before the threads start;
 //   * the loopback transport         ranks of one process that share ONE device (RCCL refuses duplicate devices in a
 //                                    communicator): a barrier + a peer-summing kernel, summed in rank order on every rank.  Only
 //                                    there so that the multi-rank control flow can be tested on a 1-GPU box.
@@ -16,7 +21,10 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <unistd.h>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <cctype>
+#include <memory>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -71,12 +79,19 @@ struct Loopback {
     std::vector<double*> scratch;       // per-rank result buffers
     std::vector<size_t> scratch_cap;
     int refs = 0;
-    void barrier()
+    bool broken = false;
+    // false when a rank never arrived (it died, or left the LM loop on an error of its own): nobody waits forever
+    bool barrier(double timeout_s = 300.0)
     {
         std::unique_lock<std::mutex> lk(mu);
+        if (broken) return false;
         const long gen = generation;
-        if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); }
-        else cv.wait(lk, [&] { return generation != gen; });
+        if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); return true; }
+        if (!cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return generation != gen || broken; }) || broken) {
+            broken = true; cv.notify_all();
+            return false;
+        }
+        return true;
     }
 };
 
@@ -155,13 +170,13 @@ int bsfm_comm_allreduce(bsfm_comm_t* c, void* buf, size_t count, int op, void* s
                 L->scratch_cap[c->rank] = count;
             }
         }
-        L->barrier();                                                        // every rank's pointer is published
+        if (!L->barrier()) { fprintf(stderr, "[bsfm] comm: a rank of the in-process group never reached the exchange (rank %d gives up)\n", c->rank); return BSFM_ERROR; }   // every rank's pointer is published
         std::vector<double*> h(L->bufs);
         if (hipMemcpyAsync(c->d_srcs, h.data(), (size_t)c->world * sizeof(double*), hipMemcpyHostToDevice, st) != hipSuccess) return BSFM_ERROR;
         hipLaunchKernelGGL(k_peer_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, c->world, count, op,
                            (double* const*)c->d_srcs, L->scratch[c->rank]);
         if (hipStreamSynchronize(st) != hipSuccess) return BSFM_ERROR;
-        L->barrier();                                                        // every rank has read every buffer
+        if (!L->barrier()) return BSFM_ERROR;                                // every rank has read every buffer
         if (hipMemcpyAsync(buf, L->scratch[c->rank], count * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return BSFM_ERROR;
         return 0;
     }
@@ -188,8 +203,54 @@ int bsfm_comm_barrier(bsfm_comm_t* c)
 }
 
 // One rank per process.  Environment (what torch.distributed.run / mpirun wrappers export): RANK, WORLD_SIZE, LOCAL_RANK,
-// MASTER_PORT.  The 128-byte ncclUniqueId travels through /dev/shm/bsfm_nccl_<MASTER_PORT>_<parent pid>.id (all ranks of a
-// launcher share the parent process; BSFM_COMM_ID_FILE overrides the path), written atomically by rank 0.
+// MASTER_ADDR, MASTER_PORT (+ TORCHELASTIC_RUN_ID when present).  The 128-byte ncclUniqueId travels through a file under /dev/shm
+// (single node) whose name is derived from what every rank of ONE job shares and two jobs do not: MASTER_ADDR, MASTER_PORT,
+// WORLD_SIZE and the launcher's run id -- not from getppid() (round 2), which differs between ranks under launchers that fork per
+// rank from different parents.  BSFM_COMM_ID_FILE overrides the path.  Rank 0 removes a stale file of an earlier, crashed job
+// before it creates its own (O_CREAT | O_EXCL | O_NOFOLLOW, mode 0600, written under a temporary name and renamed); the payload
+// carries a magic word, the world size and rank 0's creation time, and the other ranks only accept a file created after they
+// themselves started (minus a grace period for launcher skew), so an id left behind by an earlier job is never picked up.
+// ncclCommInitRank runs under a watchdog: if the ranks do not meet within BSFM_COMM_TIMEOUT_S (default 180 s) the process says so
+// and exits -- RCCL itself would wait forever.
+}  // extern "C"
+namespace {
+
+struct IdFilePayload { unsigned long long magic; int world; int reserved; long long created_ns; ncclUniqueId id; };
+constexpr unsigned long long ID_MAGIC = 0x6273666d5f6e6363ULL;      // "bsfm_ncc"
+
+long long now_ns()
+{
+    return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+}
+const long long g_process_start_ns = now_ns();                       // static initialisation = library load
+
+std::string sanitize(const char* s)
+{
+    std::string o;
+    for (const char* q = s ? s : ""; *q; ++q) o += (isalnum((unsigned char)*q) || *q == '-' || *q == '.') ? *q : '_';
+    return o.empty() ? std::string("none") : o;
+}
+
+// runs fn() on a helper thread; false when it did not finish within `seconds`
+template <typename F> bool with_timeout(double seconds, F fn)
+{
+    struct St { std::mutex mu; std::condition_variable cv; bool done = false; };
+    auto st = std::make_shared<St>();
+    std::thread([st, fn]() mutable { fn(); { std::lock_guard<std::mutex> lk(st->mu); st->done = true; } st->cv.notify_all(); }).detach();
+    std::unique_lock<std::mutex> lk(st->mu);
+    return st->cv.wait_for(lk, std::chrono::duration<double>(seconds), [&] { return st->done; });
+}
+
+double comm_timeout_s()
+{
+    const char* e = getenv("BSFM_COMM_TIMEOUT_S");
+    const double v = e ? atof(e) : 180.0;
+    return v > 1.0 ? v : 1.0;
+}
+
+}  // namespace
+extern "C" {
+
 bsfm_comm_t* bsfm_comm_create_from_env(void)
 {
     const char* er = getenv("RANK"); const char* ew = getenv("WORLD_SIZE"); const char* el = getenv("LOCAL_RANK");
@@ -204,32 +265,50 @@ bsfm_comm_t* bsfm_comm_create_from_env(void)
     if (!rccl().ok) { delete c; return nullptr; }
     std::string path;
     if (const char* e = getenv("BSFM_COMM_ID_FILE")) path = e;
-    else {
-        const char* port = getenv("MASTER_PORT");
-        char buf[256];
-        snprintf(buf, sizeof(buf), "/dev/shm/bsfm_nccl_%s_%ld.id", port ? port : "0", (long)getppid());
-        path = buf;
-    }
+    else
+        path = "/dev/shm/bsfm_nccl_" + sanitize(getenv("MASTER_ADDR")) + "_" + sanitize(getenv("MASTER_PORT")) + "_w" + std::to_string(world) + "_" +
+               sanitize(getenv("TORCHELASTIC_RUN_ID")) + ".id";
     c->id_file = path;
-    ncclUniqueId id;
+    const double tmo = comm_timeout_s();
+    IdFilePayload pl;
+    memset(&pl, 0, sizeof(pl));
     if (rank == 0) {
-        if (rccl().GetUniqueId(&id) != ncclSuccess) { fprintf(stderr, "[bsfm] comm: ncclGetUniqueId failed\n"); delete c; return nullptr; }
-        const std::string tmp = path + ".tmp";
-        FILE* f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(&id, sizeof(id), 1, f) != 1) { fprintf(stderr, "[bsfm] comm: cannot write %s\n", tmp.c_str()); if (f) fclose(f); delete c; return nullptr; }
-        fclose(f);
-        if (rename(tmp.c_str(), path.c_str()) != 0) { fprintf(stderr, "[bsfm] comm: cannot publish %s\n", path.c_str()); delete c; return nullptr; }
+        if (rccl().GetUniqueId(&pl.id) != ncclSuccess) { fprintf(stderr, "[bsfm] comm: ncclGetUniqueId failed\n"); delete c; return nullptr; }
+        pl.magic = ID_MAGIC; pl.world = world; pl.created_ns = now_ns();
+        const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+        (void)unlink(path.c_str());                               // a stale id of an earlier job with the same address / port
+        (void)unlink(tmp.c_str());
+        const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+        bool ok = fd >= 0 && write(fd, &pl, sizeof(pl)) == (ssize_t)sizeof(pl);
+        if (fd >= 0) ok = (close(fd) == 0) && ok;
+        if (!ok || rename(tmp.c_str(), path.c_str()) != 0) {
+            fprintf(stderr, "[bsfm] comm: cannot publish %s\n", path.c_str()); (void)unlink(tmp.c_str()); delete c; return nullptr;
+        }
     } else {
+        const long long grace_ns = 120LL * 1000000000LL;           // launchers start their ranks within seconds of each other
         const auto t0 = std::chrono::steady_clock::now();
         bool got = false;
-        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 120.0) {
-            FILE* f = fopen(path.c_str(), "rb");
-            if (f) { got = fread(&id, sizeof(id), 1, f) == 1; fclose(f); if (got) break; }
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < tmo) {
+            const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW);
+            if (fd >= 0) {
+                IdFilePayload q;
+                const bool rd = read(fd, &q, sizeof(q)) == (ssize_t)sizeof(q);
+                (void)close(fd);
+                if (rd && q.magic == ID_MAGIC && q.world == world && q.created_ns >= g_process_start_ns - grace_ns) { pl = q; got = true; break; }
+            }
             std::this_thread::sleep_for(std::chrono::milliseconds(20));
         }
-        if (!got) { fprintf(stderr, "[bsfm] comm: rank %d timed out waiting for %s\n", rank, path.c_str()); delete c; return nullptr; }
+        if (!got) { fprintf(stderr, "[bsfm] comm: rank %d found no fresh id at %s within %.0f s (is rank 0 running with the same MASTER_ADDR / MASTER_PORT / WORLD_SIZE?)\n", rank, path.c_str(), tmo); delete c; return nullptr; }
     }
-    const ncclResult_t r = rccl().CommInitRank(&c->nccl, world, id, rank);
+    ncclResult_t r = ncclSuccess;
+    ncclComm_t* slot = &c->nccl;
+    const int dev = c->device;
+    const ncclUniqueId id = pl.id;
+    if (!with_timeout(tmo, [&r, slot, world, id, rank, dev] { (void)hipSetDevice(dev); r = rccl().CommInitRank(slot, world, id, rank); })) {
+        fprintf(stderr, "[bsfm] FATAL: ncclCommInitRank did not complete within %.0f s on rank %d of %d (a rank is missing or holds another job's id); RCCL cannot be cancelled -- exiting\n", tmo, rank, world);
+        fflush(stderr);
+        _exit(3);
+    }
     if (r != ncclSuccess) { fprintf(stderr, "[bsfm] ncclCommInitRank failed: %s\n", rccl().GetErrorString(r)); c->nccl = nullptr; bsfm_comm_destroy(c); return nullptr; }
     if (comm_alloc_common(c)) { bsfm_comm_destroy(c); return nullptr; }
     return c;
@@ -249,7 +328,13 @@ int bsfm_comm_create_all(int ndev, const int* devs, bsfm_comm_t** comms)
         if (distinct) {
             if (!rccl().ok) return fail();
             std::vector<ncclComm_t> nc((size_t)ndev);
-            const ncclResult_t r = rccl().CommInitAll(nc.data(), ndev, devs);
+            ncclResult_t r = ncclSuccess;
+            ncclComm_t* ncp = nc.data();
+            if (!with_timeout(comm_timeout_s(), [&r, ncp, ndev, devs] { r = rccl().CommInitAll(ncp, ndev, devs); })) {
+                fprintf(stderr, "[bsfm] FATAL: ncclCommInitAll over %d devices did not complete within %.0f s -- exiting\n", ndev, comm_timeout_s());
+                fflush(stderr);
+                _exit(3);
+            }
             if (r != ncclSuccess) { fprintf(stderr, "[bsfm] ncclCommInitAll failed: %s\n", rccl().GetErrorString(r)); return fail(); }
             for (int g = 0; g < ndev; ++g) comms[g]->nccl = nc[g];
         } else {

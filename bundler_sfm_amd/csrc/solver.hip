@@ -30,12 +30,20 @@
 
 using namespace bsfm;
 
+// Infrastructure failures (a HIP call that failed, a hand-off that timed out, a collective that broke) as opposed to the numerical
+// exits SBA itself knows (stop 7, "almost singular", too few measurements): the drop-in run_sfm aborts the process on the former, as
+// the reference's fatal paths do (exit(1), lib/sba-1.5/sba_levmar.c:72-83), and carries on after the latter, as the reference does.
+static thread_local int g_infra_failure = 0;
+extern "C" int bsfm_last_call_infra_failure(void) { return g_infra_failure; }
+extern "C" void bsfm_clear_infra_failure(void) { g_infra_failure = 0; }
+
 #define HIP_OK(call)                                                                               \
     do {                                                                                           \
         hipError_t _e = (call);                                                                    \
         if (_e != hipSuccess) {                                                                    \
             fprintf(stderr, "[bsfm] HIP error %s at %s:%d: %s\n", hipGetErrorName(_e), __FILE__,   \
                     __LINE__, #call);                                                              \
+            g_infra_failure = 1;                                                                   \
             return BSFM_ERROR;                                                                     \
         }                                                                                          \
     } while (0)
@@ -260,13 +268,13 @@ int allreduce_host(bsfm_problem* pb, double* vals, int count, int op)
     double* tmp = pb->d_scal + SC_COUNT;   // spare slots
     HIP_OK(hipMemcpyAsync(tmp, vals, count * sizeof(double), hipMemcpyHostToDevice, pb->stream));
     if (pb->comm) {
-        if (bsfm_comm_allreduce(pb->comm, tmp, (size_t)count, op, pb->stream) != 0) return BSFM_ERROR;
+        if (bsfm_comm_allreduce(pb->comm, tmp, (size_t)count, op, pb->stream) != 0) { g_infra_failure = 1; return BSFM_ERROR; }
         HIP_OK(hipMemcpyAsync(vals, tmp, count * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
         HIP_OK(hipStreamSynchronize(pb->stream));
         return 0;
     }
     HIP_OK(hipStreamSynchronize(pb->stream));
-    if (pb->allreduce(tmp, (size_t)count, op, pb->allreduce_ctx) != 0) return BSFM_ERROR;
+    if (pb->allreduce(tmp, (size_t)count, op, pb->allreduce_ctx) != 0) { g_infra_failure = 1; return BSFM_ERROR; }
     HIP_OK(hipMemcpy(vals, tmp, count * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
 }
@@ -282,12 +290,12 @@ int allreduce_mixed(bsfm_problem* pb, double* sums, int ns, double* maxs, int nm
     double* tmp = pb->d_mixed;
     HIP_OK(hipMemcpyAsync(tmp, h.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice, pb->stream));
     if (pb->comm) {
-        if (bsfm_comm_allreduce(pb->comm, tmp, (size_t)count, 0, pb->stream) != 0) return BSFM_ERROR;
+        if (bsfm_comm_allreduce(pb->comm, tmp, (size_t)count, 0, pb->stream) != 0) { g_infra_failure = 1; return BSFM_ERROR; }
         HIP_OK(hipMemcpyAsync(h.data(), tmp, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
         HIP_OK(hipStreamSynchronize(pb->stream));
     } else {
         HIP_OK(hipStreamSynchronize(pb->stream));
-        if (pb->allreduce(tmp, (size_t)count, 0, pb->allreduce_ctx) != 0) return BSFM_ERROR;
+        if (pb->allreduce(tmp, (size_t)count, 0, pb->allreduce_ctx) != 0) { g_infra_failure = 1; return BSFM_ERROR; }
         HIP_OK(hipMemcpy(h.data(), tmp, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
     }
     for (int q = 0; q < ns; ++q) sums[q] = h[q];
@@ -301,9 +309,9 @@ int allreduce_mixed(bsfm_problem* pb, double* sums, int ns, double* maxs, int nm
 int allreduce_dev(bsfm_problem* pb, double* dbuf, size_t count, int op)
 {
     if (!has_collective(pb)) return 0;
-    if (pb->comm) return bsfm_comm_allreduce(pb->comm, dbuf, count, op, pb->stream);      // enqueued on the compute stream: no host hop
+    if (pb->comm) { const int rc = bsfm_comm_allreduce(pb->comm, dbuf, count, op, pb->stream); if (rc) g_infra_failure = 1; return rc; }      // enqueued on the compute stream: no host hop
     HIP_OK(hipStreamSynchronize(pb->stream));
-    if (pb->allreduce(dbuf, count, op, pb->allreduce_ctx) != 0) { fprintf(stderr, "[bsfm] allreduce hook failed\n"); return BSFM_ERROR; }
+    if (pb->allreduce(dbuf, count, op, pb->allreduce_ctx) != 0) { fprintf(stderr, "[bsfm] allreduce hook failed\n"); g_infra_failure = 1; return BSFM_ERROR; }
     return 0;
 }
 
@@ -380,10 +388,12 @@ int exchange_block_union(bsfm_problem* pb)
         seg[(size_t)pb->rank * maxcnt + b] = (double)((long long)pb->h_blk_j[b] * m + pb->h_blk_k[b] + 1);
     double* dseg = nullptr;
     HIP_OK(dmalloc(&dseg, total));
-    HIP_OK(hipMemcpy(dseg, seg.data(), total * sizeof(double), hipMemcpyHostToDevice));
+    // upload, exchange and download all ride the compute stream (one synchronisation at the end; the host needs the union to build
+    // the packed layout, once per problem)
+    HIP_OK(hipMemcpyAsync(dseg, seg.data(), total * sizeof(double), hipMemcpyHostToDevice, pb->stream));
     if (total && allreduce_dev(pb, dseg, total, 0)) { (void)hipFree(dseg); return BSFM_ERROR; }
-    HIP_OK(hipStreamSynchronize(pb->stream));        // the library-side collective is only ENQUEUED on the compute stream
-    HIP_OK(hipMemcpy(seg.data(), dseg, total * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpyAsync(seg.data(), dseg, total * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
+    HIP_OK(hipStreamSynchronize(pb->stream));
     (void)hipFree(dseg);
     std::vector<long long> keys;
     keys.reserve(total);
@@ -981,7 +991,25 @@ static int lm_iterate_mot(bsfm_problem_t* pb, int iters)
     return pb->stop;
 }
 
+static int lm_iterate_impl(bsfm_problem_t* pb, int iters);
+
 int bsfm_lm_iterate(bsfm_problem_t* pb, int iters)
+{
+    const int before = g_infra_failure;
+    const int rc = lm_iterate_impl(pb, iters);
+    if (rc == BSFM_ERROR && g_infra_failure && !before && has_collective(pb)) {
+        // This rank failed on its own (HIP error, broken collective) in the middle of an iteration: its peers are, or will shortly be,
+        // blocked inside a collective that this rank will never join, and RCCL has no time-out.  Ending the process is the only way to
+        // end the job (the launcher then takes the other ranks down); the reference's own fatal paths exit(1) as well.
+        fprintf(stderr, "[bsfm] FATAL: rank %d of %d failed inside an LM iteration; aborting the process so that its peers are not left "
+                        "waiting in a collective\n", pb->rank, pb->world);
+        fflush(stderr);
+        abort();
+    }
+    return rc;
+}
+
+static int lm_iterate_impl(bsfm_problem_t* pb, int iters)
 {
     if (!pb->began) { if (bsfm_lm_begin(pb) != 0) return BSFM_ERROR; }
     if (pb->error) return BSFM_ERROR;
@@ -1059,16 +1087,19 @@ int bsfm_lm_iterate(bsfm_problem_t* pb, int iters)
             double flagsd[1] = { (double)pb->h_flags[0] };
             double sums[4] = { pb->h_scal[SC_PT_DP], pb->h_scal[SC_PT_DL], pb->h_scal[SC_COST_TRIAL], 0.0 };
             double maxs[1] = { pb->h_scal[SC_PCT] };
+            int potrf_info = pb->h_flags[1];
             if (pb->world > 1) {
-                double mx2[2] = { flagsd[0], maxs[0] };
-                if (allreduce_mixed(pb, sums, 3, mx2, 2)) return BSFM_ERROR;
-                flagsd[0] = mx2[0]; maxs[0] = mx2[1];
+                // a hand-off time-out inside one rank's solve rides the exchange: every rank learns of it and they leave TOGETHER
+                // (a rank that left alone would strand its peers inside the next collective)
+                double mx3[3] = { flagsd[0], maxs[0], potrf_info < 0 ? 1.0 : 0.0 };
+                if (allreduce_mixed(pb, sums, 3, mx3, 3)) return BSFM_ERROR;
+                flagsd[0] = mx3[0]; maxs[0] = mx3[1];
+                if (mx3[2] != 0.0 && potrf_info >= 0) potrf_info = POTRF_INFO_TIMEOUT;
             }
             const bool singularV = flagsd[0] != 0.0;
-            const int potrf_info = pb->h_flags[1];
             if (potrf_info < 0) {         // POTRF_INFO_TIMEOUT: a hand-off inside the persistent Cholesky kernels never arrived
                 fprintf(stderr, "[bsfm] FATAL: the reduced camera solve timed out inside its persistent kernels (info %d)\n", potrf_info);
-                pb->error = 1;
+                pb->error = 1; g_infra_failure = 1;
                 return BSFM_ERROR;
             }
             bool accepted = false;
