@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libbsfm_hip.so")
 
 INFOSZ = 10
 JAC_FD, JAC_ANALYTIC = 0, 1
-SOLVER_DENSE, SOLVER_AUTO = 0, 1
+SOLVER_DENSE, SOLVER_AUTO, SOLVER_ENVELOPE = 0, 1, 2
 
 
 class CameraParams(C.Structure):

@@ -417,16 +417,19 @@ __global__ __launch_bounds__(256) void k_schur_prep(int nvis, const int* __restr
 template <int CNP>
 __global__ __launch_bounds__(128) void k_schur_assemble(int nblk, const int* __restrict__ blk_j, const int* __restrict__ blk_k,
         const int* __restrict__ blk_task0, const double* __restrict__ partials, const double* __restrict__ epart,
-        const double* __restrict__ U, double mu, int mcon, double* __restrict__ S, int ld, double* __restrict__ E)
+        const double* __restrict__ U, double mu, int mcon, double* __restrict__ S, int ld, double* __restrict__ E,
+        const int* __restrict__ spos)
 {
+    // spos (envelope solver): position of free camera c = j - mcon in the reordered system; nullptr = natural order
     const int b = blockIdx.x;
     if (b >= nblk) return;
     const int j = blk_j[b], k = blk_k[b];
+    const int pj = spos ? spos[j - mcon] : j - mcon, pk = spos ? spos[k - mcon] : k - mcon;
     if (j == k && threadIdx.x >= CNP * CNP && threadIdx.x < CNP * CNP + CNP) {   // e_j -= this block's tasks (E was set to ea by k_rhs_init)
         const int q = threadIdx.x - CNP * CNP;
         double se = 0.0;
         for (int t = blk_task0[b]; t < blk_task0[b + 1]; ++t) se += epart[(size_t)t * CNP + q];
-        E[(size_t)(j - mcon) * CNP + q] -= se;
+        E[(size_t)pj * CNP + q] -= se;
     }
     if (threadIdx.x >= CNP * CNP) return;
     const int row = threadIdx.x / CNP, col = threadIdx.x % CNP;
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(128) void k_schur_assemble(int nblk, const int* __r
     for (int t = blk_task0[b]; t < blk_task0[b + 1]; ++t) s += partials[(size_t)t * CNP * CNP + threadIdx.x];
     double v = -s;
     if (j == k) { v += U[(size_t)j * CNP * CNP + threadIdx.x]; if (row == col) v += mu; }
-    const size_t rj = (size_t)(j - mcon) * CNP + row, ck = (size_t)(k - mcon) * CNP + col;
+    const size_t rj = (size_t)pj * CNP + row, ck = (size_t)pk * CNP + col;
     S[rj * ld + ck] = v;
     if (j != k) S[ck * ld + rj] = v;
 }
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(128) void k_schur_unpack(int ngblk, const int* __re
 // camptr == nullptr: fill EVERY diagonal block (multi-GPU path: k_schur_unpack then overwrites those with a block).
 template <int CNP>
 __global__ void k_schur_diag_fill(int m, int mcon, const int* __restrict__ camptr, const double* __restrict__ U,
-                                  double mu, double* __restrict__ S, int ld)
+                                  double mu, double* __restrict__ S, int ld, const int* __restrict__ spos)
 {
     const int j = mcon + blockIdx.x;
     if (j >= m || threadIdx.x >= CNP * CNP) return;
@@ -487,7 +490,8 @@ __global__ void k_schur_diag_fill(int m, int mcon, const int* __restrict__ campt
     const int row = threadIdx.x / CNP, col = threadIdx.x % CNP;
     double v = U[(size_t)j * CNP * CNP + threadIdx.x];
     if (row == col) v += mu;
-    S[((size_t)(j - mcon) * CNP + row) * ld + (size_t)(j - mcon) * CNP + col] = v;
+    const size_t pj = spos ? spos[j - mcon] : j - mcon;
+    S[(pj * CNP + row) * ld + pj * CNP + col] = v;
 }
 
 // S is rebuilt for every solve attempt (the factorisation overwrites it and fills in its zero blocks).  Only the lower
@@ -508,10 +512,20 @@ __global__ __launch_bounds__(256) void k_zero_lower_tiles(double* __restrict__ S
 
 // Reduced right-hand side: E_j starts as ea_j (on the rank that contributes U/ea to a multi-GPU sum, else 0); the tasks of
 // the diagonal blocks subtract sum_i A_ij^T (B_ij V*_i^-1 eb_i) in k_schur_assemble / k_schur_pack (sba_levmar.c:1320-1339).
-__global__ __launch_bounds__(256) void k_rhs_init(int count, int off, int add_ea, const double* __restrict__ ea, double* __restrict__ E)
+__global__ __launch_bounds__(256) void k_rhs_init(int count, int off, int add_ea, const double* __restrict__ ea, double* __restrict__ E,
+                                                  const int* __restrict__ spos, int cnp)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < count) E[t] = add_ea ? ea[off + t] : 0.0;
+    if (t >= count) return;
+    const int dst = spos ? spos[t / cnp] * cnp + t % cnp : t;
+    E[dst] = add_ea ? ea[off + t] : 0.0;
+}
+
+// envelope solver: the solution comes back in the reordered system; dpa[c] = x[spos[c]] for the free cameras
+__global__ __launch_bounds__(256) void k_unpermute_step(int count, int cnp, const int* __restrict__ spos, const double* __restrict__ x, double* __restrict__ dpa)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < count) dpa[t] = x[(size_t)spos[t / cnp] * cnp + t % cnp];
 }
 
 // ---------------------------------------------------------------------------------------------------

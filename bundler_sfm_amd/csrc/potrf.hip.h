@@ -99,6 +99,11 @@ struct PotrfWorkspace {
     hipStream_t sd = nullptr;  // side stream: the part of panel k / first trailing column the NEXT diagonal tile does not need
     hipEvent_t* evP = nullptr; hipEvent_t* evU = nullptr;   // panel k complete (side stream) / trailing update k done
     hipEvent_t* evT = nullptr; hipEvent_t* evC = nullptr;   // first panel tile of step k ready (chain) / first trailing column done (side)
+    // Tile ENVELOPE of the matrix (opt-in, solver.hip: BSFM_SOLVER_ENVELOPE): env_rows[k] = number of tile rows below diagonal tile k
+    // that can hold a non-zero of the factor (rows k+1 .. k+env_rows[k]; Cholesky without pivoting creates no fill outside the envelope
+    // of the matrix).  Empty = dense (every step works on all rows below k).  d_last[k] = k + env_rows[k] for the backward substitution.
+    std::vector<int> env_rows;
+    int* d_last = nullptr;
     double* linv = nullptr;    // nblk tiles: inverse of each diagonal factor tile
     double* y = nullptr;       // ld
     double* xs = nullptr;      // ld
@@ -840,7 +845,7 @@ __global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int 
 // the flag; consumers poll the flag relaxed from one lane and then read x_i with agent-scope (sc1) loads, which bypass
 // the possibly stale L1.  Flags are zeroed by a memset node before every launch; epoch = 1.
 __global__ __launch_bounds__(256) void k_bwd_persistent(const double* __restrict__ S, int ld, int nblk,
-        const double* __restrict__ Linv, const double* __restrict__ y, double* x, int* flags, int* timeout)
+        const double* __restrict__ Linv, const double* __restrict__ y, double* x, int* flags, int* timeout, const int* __restrict__ last_row)
 {
     __shared__ double yk[POTRF_NB];
     __shared__ double xi[POTRF_NB];
@@ -855,7 +860,8 @@ __global__ __launch_bounds__(256) void k_bwd_persistent(const double* __restrict
     }
     if (threadIdx.x < POTRF_NB) yk[threadIdx.x] = y[(size_t)kk * POTRF_NB + threadIdx.x];
     __syncthreads();
-    for (int i = nblk - 1; i > kk; --i) {
+    const int itop = last_row ? last_row[kk] : nblk - 1;      // tile envelope: the tiles (i, kk) beyond it are structurally zero
+    for (int i = itop; i > kk; --i) {
         {   // tile (i, kk), rows of this half, column c
             const double* Lc = S + ((size_t)i * POTRF_NB + 64 * h) * ld + (size_t)kk * POTRF_NB + c;
 #pragma unroll
@@ -908,6 +914,7 @@ inline void potrf_free(PotrfWorkspace& w)
     if (w.xs) (void)hipFree(w.xs);
     if (w.etmp) (void)hipFree(w.etmp);
     if (w.bflags) (void)hipFree(w.bflags);
+    if (w.d_last) (void)hipFree(w.d_last);
     if (w.rb_handle && w.rb_destroy) w.rb_destroy(w.rb_handle);
     if (w.ev0) (void)hipEventDestroy(w.ev0);
     if (w.ev1) (void)hipEventDestroy(w.ev1);
@@ -1028,11 +1035,35 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
     (void)hipEventRecord(w.evU[w.nblk], st);                 // everything queued before the solve (S, E ready)
     (void)hipStreamWaitEvent(w.s2, w.evU[w.nblk], 0);
     (void)hipStreamWaitEvent(w.sd, w.evU[w.nblk], 0);
+    // Tile envelope (opt-in): step k only touches the env_rows[k] tile rows below k that can hold a non-zero of the factor.
+    const bool env = (int)w.env_rows.size() >= nblk && w.d_last != nullptr;
+    auto rows_below = [&](int k) { return env ? std::min(w.env_rows[k], nblk - k - 1) : nblk - k - 1; };
     hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, 0, n, w.linv, d_info, w.dbg);
     for (int k = 0; k + 1 < nblk; ++k) {
-        const int T = nblk - k - 1;                          // tile rows below the diagonal tile k
+        const int T = rows_below(k);                         // tile rows below the diagonal tile k (all of them unless an envelope is set)
+        const int Tprev = k > 0 ? rows_below(k - 1) : 0;
         double* pk = panel_of(k);
         const double* Lk = w.linv + (size_t)k * tl;
+        // what panel k-1 still owes tile (k+1, k+1): its tile 1 = row k+1 (the bulk launches leave that one tile to the chain)
+        const double* owed = (k > 0 && Tprev >= 2) ? (const double*)panel_of(k - 1) + tl : (const double*)nullptr;
+        if (T == 0) {
+            // Envelope only: column k has nothing below the diagonal tile -- rows k+1.. are decoupled from it.  y_k on the side stream
+            // (E_k is complete once the earlier column updates queued there have run), the events of this step are recorded empty,
+            // and tile (k+1, k+1) only takes what panel k-1 owes it.
+            (void)hipEventRecord(w.evT[k], st);                                   // diagonal tile k (and its inverse) are final
+            (void)hipStreamWaitEvent(w.sd, w.evT[k], 0);
+            hipLaunchKernelGGL(k_fwd_last, dim3(1), dim3(256), 0, w.sd, Lk, w.etmp + (size_t)k * POTRF_NB, w.y + (size_t)k * POTRF_NB);
+            (void)hipEventRecord(w.evP[k], w.sd);
+            (void)hipEventRecord(w.evC[k], w.sd);
+            (void)hipStreamWaitEvent(w.s2, w.evP[k], 0);
+            (void)hipEventRecord(w.evU[k], w.s2);
+            // tile (k+1, k+1) may have been touched by the bulk launches up to step k-2: they are ordered behind evC[k-1] (see below)
+            if (k > 0) (void)hipStreamWaitEvent(st, w.evC[k - 1], 0);
+            if (owed)
+                hipLaunchKernelGGL(k_chain_tile32<1>, dim3(10), dim3(256), lds32, st, S, ld, k, Lk, const_cast<double*>(owed), (const double*)nullptr, (const double*)nullptr);
+            hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, k + 1, n, w.linv, d_info, w.dbg);
+            continue;
+        }
         // chain: first panel tile (its column k was completed by the side stream of step k-1)
         if (k > 0) (void)hipStreamWaitEvent(st, w.evC[k - 1], 0);
         hipLaunchKernelGGL(k_chain_tile32<0>, dim3(16), dim3(256), lds32, st, S, ld, k, Lk, pk, (const double*)nullptr, (const double*)nullptr);
@@ -1062,7 +1093,7 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         // having waited for evU[k-2] itself.  (Tried: hipStreamWriteValue32 / hipStreamWaitValue32 on signal memory instead
         // of the chain <-> side events: no faster.)
         hipLaunchKernelGGL(k_chain_tile32<1>, dim3(10), dim3(256), lds32, st, S, ld, k, Lk, pk,
-                           k > 0 ? (const double*)panel_of(k - 1) : (const double*)nullptr, (const double*)nullptr);
+                           owed ? owed - tl : (const double*)nullptr, (const double*)nullptr);
         hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, k + 1, n, w.linv, d_info, w.dbg);
     }
     // y of the last tile: E_last is final once the side stream has drained
@@ -1071,7 +1102,8 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
                        w.etmp + (size_t)(nblk - 1) * POTRF_NB, w.y + (size_t)(nblk - 1) * POTRF_NB);
     // persistent backward substitution: all nblk workgroups must be resident (one per tile column)
     (void)hipMemsetAsync(w.bflags, 0, (size_t)(w.nblk + 1) * sizeof(int), st);
-    hipLaunchKernelGGL(k_bwd_persistent, dim3(nblk), dim3(256), 0, st, S, ld, nblk, w.linv, w.y, w.xs, w.bflags, w.bflags + w.nblk);
+    hipLaunchKernelGGL(k_bwd_persistent, dim3(nblk), dim3(256), 0, st, S, ld, nblk, w.linv, w.y, w.xs, w.bflags, w.bflags + w.nblk,
+                       (const int*)(env ? w.d_last : nullptr));
     hipLaunchKernelGGL(k_fold_timeout, dim3(1), dim3(1), 0, st, (const int*)(w.bflags + w.nblk), d_info);     // a hand-off that never arrived must not pass as a solution
     (void)hipMemcpyAsync(x_out, w.xs, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
     if (w.ev1) (void)hipEventRecord(w.ev1, st);

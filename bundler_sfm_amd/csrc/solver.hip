@@ -118,6 +118,9 @@ struct bsfm_problem {
     bsfm_comm_t* comm = nullptr;        // library-side collective (comm.hip: RCCL over xGMI); takes precedence over the hook
     PotrfWorkspace potrf;
     CompSolver comps;                   // opt-in: independent camera groups solved one workgroup each (compsolve.hip.h)
+    // opt-in envelope solver: free camera c sits at position h_spos[c] of the reordered reduced system (reverse Cuthill-McKee);
+    // the tile envelope itself lives in potrf.env_rows / potrf.d_last
+    std::vector<int> h_spos; int* d_spos = nullptr; double* d_xperm = nullptr; bool envelope = false;
     // LM state (names follow sba_levmar.c)
     int itno = 0, stop = 0, nu = 2, nfev = 0, njev = 0, nlss = 0, began = 0, error = 0;
     double mu = 0.0, p_eL2 = 0.0, init_p_eL2 = 0.0, eab_inf = 0.0, dp_L2 = DBL_MAX, p_L2 = 0.0, maxdiag = DBL_MIN;
@@ -138,7 +141,7 @@ void free_all(bsfm_problem* pb)
                      pb->d_dp, pb->d_camtab, pb->d_camtab_trial, pb->d_e, pb->d_hx, pb->d_U,
                      pb->d_V, pb->d_Vinv, pb->d_eb, pb->d_S, pb->d_E, pb->d_partials, pb->d_epart, pb->d_campart, pb->d_red, pb->d_scal, pb->d_mixed,
                      pb->d_flags, pb->d_triples, pb->d_tri_pt, pb->d_tasks, pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0,
-                     pb->d_gidx, pb->d_gblk_j, pb->d_gblk_k, pb->d_G };
+                     pb->d_gidx, pb->d_gblk_j, pb->d_gblk_k, pb->d_G, pb->d_spos, pb->d_xperm };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (pb->h_scal) (void)hipHostFree(pb->h_scal);
     if (pb->h_flags) (void)hipHostFree(pb->h_flags);
@@ -362,15 +365,97 @@ int compute_normal_blocks(bsfm_problem* pb)
     return 0;
 }
 
-// Opt-in structure-aware reduced solve (compsolve.hip.h): groups of cameras that share no point with the rest.
+// Opt-in envelope solver (BSFM_SOLVER_ENVELOPE, or BSFM_SOLVER_AUTO on a scene that does not fall into small groups).
+// The reduced camera system of a real reconstruction is sparse in 9 x 9 blocks (S_jk != 0 only when cameras j and k share a point)
+// but the reference factors it densely (sba_Axb_Chol).  Cholesky without pivoting creates no fill outside the ENVELOPE of the matrix
+// (row i: from its first non-zero column to the diagonal), so after a bandwidth-reducing renumbering of the cameras -- reverse
+// Cuthill-McKee on the co-visibility graph, the blocks list built once per problem -- whole 128 x 128 tiles of the factor are
+// structurally zero and the tiled factorisation of potrf.hip.h simply skips them: step k works on env_rows[k] tile rows instead of
+// all rows below k.  Exact; only the summation order inside the skipped (all-zero) products differs from the dense path.
+int setup_envelope(bsfm_problem* pb, const std::vector<int>& bj, const std::vector<int>& bk)
+{
+    const int mm = pb->P.m - pb->P.mcon, mcon = pb->P.mcon, cnp = pb->cnp;
+    pb->envelope = false;
+    if (mm <= 0 || pb->opt.potrf_backend != 0) return 0;
+    // ---- reverse Cuthill-McKee
+    std::vector<std::vector<int>> adj((size_t)mm);
+    for (size_t b = 0; b < bj.size(); ++b) {
+        const int a = bj[b] - mcon, c = bk[b] - mcon;
+        if (a != c) { adj[a].push_back(c); adj[c].push_back(a); }
+    }
+    std::vector<int> deg((size_t)mm);
+    for (int j = 0; j < mm; ++j) deg[j] = (int)adj[j].size();
+    for (int j = 0; j < mm; ++j) std::sort(adj[j].begin(), adj[j].end(), [&](int x, int y) { return deg[x] != deg[y] ? deg[x] < deg[y] : x < y; });
+    std::vector<int> order; order.reserve((size_t)mm);
+    std::vector<char> seen((size_t)mm, 0);
+    std::vector<int> byDeg((size_t)mm);
+    for (int j = 0; j < mm; ++j) byDeg[j] = j;
+    std::sort(byDeg.begin(), byDeg.end(), [&](int x, int y) { return deg[x] != deg[y] ? deg[x] < deg[y] : x < y; });
+    auto bfs_far = [&](int start, std::vector<int>& visited_out) {     // last node of a breadth-first sweep (pseudo-peripheral search)
+        std::vector<int> q{ start }; std::vector<char> mark((size_t)mm, 0); mark[start] = 1;
+        for (size_t h = 0; h < q.size(); ++h) for (int v : adj[q[h]]) if (!mark[v] && !seen[v]) { mark[v] = 1; q.push_back(v); }
+        visited_out = q;
+        return q.back();
+    };
+    for (int s0 : byDeg) {
+        if (seen[s0]) continue;
+        std::vector<int> comp;
+        int start = bfs_far(s0, comp);
+        start = bfs_far(start, comp);                                  // two sweeps: a node far from a node far from the seed
+        std::vector<int> q{ start }; seen[start] = 1;
+        for (size_t h = 0; h < q.size(); ++h) for (int v : adj[q[h]]) if (!seen[v]) { seen[v] = 1; q.push_back(v); }
+        order.insert(order.end(), q.begin(), q.end());
+    }
+    std::reverse(order.begin(), order.end());
+    pb->h_spos.assign((size_t)mm, 0);
+    for (int p = 0; p < mm; ++p) pb->h_spos[order[p]] = p;
+    // ---- tile envelope of the reordered matrix (lower triangle: row tile I, first non-zero column tile first[I])
+    const int nt = pb->ld / POTRF_NB;
+    std::vector<int> first((size_t)nt);
+    for (int I = 0; I < nt; ++I) first[I] = I;
+    for (size_t b = 0; b < bj.size(); ++b) {
+        const int pa = pb->h_spos[bj[b] - mcon], pc = pb->h_spos[bk[b] - mcon];
+        const int hi = std::max(pa, pc), lo = std::min(pa, pc);
+        const int c0 = lo * cnp / POTRF_NB;
+        for (int I = hi * cnp / POTRF_NB; I <= (hi * cnp + cnp - 1) / POTRF_NB; ++I) first[I] = std::min(first[I], c0);
+    }
+    std::vector<int> last((size_t)nt);
+    for (int K = 0; K < nt; ++K) last[K] = K;
+    for (int I = 0; I < nt; ++I) for (int K = first[I]; K <= I; ++K) last[K] = std::max(last[K], I);
+    pb->potrf.env_rows.assign((size_t)nt, 0);
+    long long tiles_env = 0, tiles_dense = 0;
+    for (int K = 0; K < nt; ++K) { pb->potrf.env_rows[K] = last[K] - K; tiles_env += (long long)(last[K] - K) * (last[K] - K + 1) / 2; tiles_dense += (long long)(nt - K - 1) * (nt - K) / 2; }
+    if (!pb->d_spos) HIP_OK(dmalloc(&pb->d_spos, (size_t)mm));
+    if (!pb->d_xperm) HIP_OK(dmalloc(&pb->d_xperm, (size_t)pb->ld));
+    if (!pb->potrf.d_last) HIP_OK(dmalloc(&pb->potrf.d_last, (size_t)nt));
+    HIP_OK(hipMemcpy(pb->d_spos, pb->h_spos.data(), (size_t)mm * sizeof(int), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(pb->potrf.d_last, last.data(), (size_t)nt * sizeof(int), hipMemcpyHostToDevice));
+    pb->envelope = true;
+    if (pb->opt.verbose >= 2)
+        printf("[bsfm] reduced camera system: envelope solver, %lld of %lld tile products (%.1f %%)\n", tiles_env, tiles_dense,
+               tiles_dense ? 100.0 * (double)tiles_env / (double)tiles_dense : 0.0);
+    return 0;
+}
+
+// Opt-in structure-aware reduced solves: groups of cameras that share no point with the rest (compsolve.hip.h), else / or the envelope
 int setup_components(bsfm_problem* pb, const std::vector<int>& bj, const std::vector<int>& bk)
 {
-    if (pb->opt.reduced_solver != BSFM_SOLVER_AUTO || pb->opt.potrf_backend != 0) return 0;
-    if (comp_setup(pb->comps, pb->P.m - pb->P.mcon, pb->cnp, bj, bk, pb->P.mcon)) return BSFM_ERROR;
-    if (pb->opt.verbose >= 2) {
-        if (pb->comps.active) printf("[bsfm] reduced camera system: %d independent camera groups (largest %d unknowns), solved group by group\n",
-                                     pb->comps.ncomp, pb->comps.maxdim);
-        else printf("[bsfm] reduced camera system: connected (or a group too large for LDS), dense Cholesky\n");
+    if (pb->opt.potrf_backend != 0) return 0;
+    if (pb->opt.reduced_solver == BSFM_SOLVER_AUTO) {
+        if (comp_setup(pb->comps, pb->P.m - pb->P.mcon, pb->cnp, bj, bk, pb->P.mcon)) return BSFM_ERROR;
+        if (pb->opt.verbose >= 2) {
+            if (pb->comps.active) printf("[bsfm] reduced camera system: %d independent camera groups (largest %d unknowns), solved group by group\n",
+                                         pb->comps.ncomp, pb->comps.maxdim);
+            else printf("[bsfm] reduced camera system: connected (or a group too large for LDS): envelope solver\n");
+        }
+        if (pb->comps.active) return 0;
+    }
+    if (pb->opt.reduced_solver == BSFM_SOLVER_AUTO || pb->opt.reduced_solver == BSFM_SOLVER_ENVELOPE) {
+        if (pb->world > 1) {      // the packed exchange assembles S in the natural order on every rank
+            if (pb->opt.verbose >= 2) printf("[bsfm] envelope solver: single-rank problems only, using the dense solve\n");
+            return 0;
+        }
+        return setup_envelope(pb, bj, bk);
     }
     return 0;
 }
@@ -430,6 +515,8 @@ int compute_schur(bsfm_problem* pb, double mu)
     const int mm = P.m - P.mcon;
     const int lead = pb->rank == 0 ? 1 : 0;
     const bool packed = has_collective(pb);
+    // envelope solver: S, E are assembled in the reordered camera numbering (exports always use the natural one)
+    const int* spos = (pb->envelope && !pb->export_full_s) ? pb->d_spos : nullptr;
     if (packed && pb->ngblk < 0 && exchange_block_union(pb)) return BSFM_ERROR;
     if (pb->export_full_s) (void)hipMemsetAsync(pb->d_S, 0, (size_t)pb->ld * pb->ld * sizeof(double), pb->stream);
     else if (!pb->comps.active) {   // (the group-by-group solve never writes S: blocks that are structurally empty stay zero)
@@ -438,7 +525,7 @@ int compute_schur(bsfm_problem* pb, double mu)
     double* Edst = packed ? pb->d_G + (size_t)pb->ngblk * cnp * cnp : pb->d_E;     // packed: E rides behind the blocks
     if (mm > 0)
         hipLaunchKernelGGL(k_rhs_init, dim3(grid_for((size_t)mm * cnp, 256)), dim3(256), 0, pb->stream, mm * cnp, P.mcon * cnp,
-                           lead, pb->d_ea, Edst);
+                           lead, pb->d_ea, Edst, spos, cnp);
     if (pb->ntasks > 0) {
         // C_ij = B_ij V*_i^-1 || C_ij eb_i for this attempt's mu, then the task kernel (schur.hip.h)
         hipLaunchKernelGGL(k_schur_prep, dim3(grid_for(4 * (size_t)P.nvis, 256)), dim3(256), 0, pb->stream, P.nvis, pb->d_obs_pt, pb->d_campos, pb->d_Bc, pb->d_Vinv, pb->d_eb, pb->d_Cc);
@@ -454,7 +541,7 @@ int compute_schur(bsfm_problem* pb, double mu)
         } else {
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_assemble<C>), dim3(pb->nblk), dim3(128), 0, pb->stream, pb->nblk,
                                                   pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0, pb->d_partials, pb->d_epart,
-                                                  pb->d_U, mu, P.mcon, pb->d_S, pb->ld, Edst));
+                                                  pb->d_U, mu, P.mcon, pb->d_S, pb->ld, Edst, spos));
         }
     }
     if (packed) {
@@ -464,13 +551,13 @@ int compute_schur(bsfm_problem* pb, double mu)
         (void)hipMemcpyAsync(pb->d_E, Edst, (size_t)pb->Sdim * sizeof(double), hipMemcpyDeviceToDevice, pb->stream);
         if (mm > 0)
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_diag_fill<C>), dim3(mm), dim3(128), 0, pb->stream, P.m, P.mcon,
-                                                  (const int*)nullptr, pb->d_U, mu, pb->d_S, pb->ld));
+                                                  (const int*)nullptr, pb->d_U, mu, pb->d_S, pb->ld, (const int*)nullptr));
         if (pb->ngblk > 0)
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_unpack<C>), dim3(pb->ngblk), dim3(128), 0, pb->stream, pb->ngblk,
                                                   pb->d_gblk_j, pb->d_gblk_k, pb->d_G, pb->d_U, mu, P.mcon, pb->d_S, pb->ld));
     } else if (mm > 0) {
         DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_diag_fill<C>), dim3(mm), dim3(128), 0, pb->stream, P.m, P.mcon,
-                                              pb->d_camptr, pb->d_U, mu, pb->d_S, pb->ld));
+                                              pb->d_camptr, pb->d_U, mu, pb->d_S, pb->ld, spos));
     }
     return 0;
 }
@@ -495,7 +582,10 @@ void bsfm_default_options(bsfm_options_t* opt)
     opt->potrf_backend = 0;
     if (const char* e = getenv("BSFM_POTRF")) if (!strcmp(e, "rocsolver")) opt->potrf_backend = 1;
     opt->reduced_solver = BSFM_SOLVER_DENSE;
-    if (const char* e = getenv("BSFM_REDUCED_SOLVER")) if (!strcmp(e, "auto")) opt->reduced_solver = BSFM_SOLVER_AUTO;
+    if (const char* e = getenv("BSFM_REDUCED_SOLVER")) {
+        if (!strcmp(e, "auto")) opt->reduced_solver = BSFM_SOLVER_AUTO;
+        else if (!strcmp(e, "envelope")) opt->reduced_solver = BSFM_SOLVER_ENVELOPE;
+    }
     opt->num_gpus = 0;
     if (const char* e = getenv("BSFM_NUM_GPUS")) opt->num_gpus = atoi(e);
 }
@@ -1069,6 +1159,10 @@ static int lm_iterate_impl(bsfm_problem_t* pb, int iters)
             // S dpa = E, Cholesky (sba_Axb_Chol, lib/sba-1.5/sba_lapack.c:374-485); info -> d_flags[1]
             if (pb->comps.active) {
                 if (comp_solve(pb->comps, pb->potrf, cnp, pb->d_S, pb->ld, pb->d_E, d_dpa + (size_t)P.mcon * cnp, pb->d_flags + 1, pb->stream)) return BSFM_ERROR;
+            } else if (pb->envelope) {
+                if (potrf_solve(pb->potrf, pb->d_S, pb->ld, pb->Sdim, pb->d_E, pb->d_xperm, pb->d_flags + 1, pb->stream)) return BSFM_ERROR;
+                hipLaunchKernelGGL(k_unpermute_step, dim3(grid_for((size_t)pb->Sdim, 256)), dim3(256), 0, pb->stream, pb->Sdim, cnp,
+                                   (const int*)pb->d_spos, (const double*)pb->d_xperm, d_dpa + (size_t)P.mcon * cnp);
             } else if (potrf_solve(pb->potrf, pb->d_S, pb->ld, pb->Sdim, pb->d_E, d_dpa + (size_t)P.mcon * cnp, pb->d_flags + 1, pb->stream)) return BSFM_ERROR;
             ph_end(pb, PH_SOLVE);
             if (P.mcon > 0) (void)hipMemsetAsync(d_dpa, 0, (size_t)P.mcon * cnp * sizeof(double), pb->stream);
@@ -1358,6 +1452,8 @@ int bsfm_dense_chol_solve(int n, const double* A, const double* b, double* x, in
     if (bsfm_device_count() <= 0) { fprintf(stderr, "[bsfm] FATAL: no usable HIP device\n"); return BSFM_ERROR; }
     if (n <= 0) return BSFM_ERROR;
     const int ld = std::max(POTRF_NB, (n + POTRF_NB - 1) / POTRF_NB * POTRF_NB);
+    const bool envelope = backend == 2;          // 2: the tiled factorisation restricted to the tile envelope of A (test entry)
+    if (envelope) backend = 0;
     PotrfWorkspace ws;
     if (potrf_init(ws, ld, backend)) return BSFM_ERROR;
     double *dS = nullptr, *dE = nullptr, *dx = nullptr; int* dinfo = nullptr;
@@ -1369,6 +1465,19 @@ int bsfm_dense_chol_solve(int n, const double* A, const double* b, double* x, in
         if (hipMemset(dS, 0, (size_t)ld * ld * sizeof(double)) != hipSuccess || hipMemset(dE, 0, ld * sizeof(double)) != hipSuccess || hipMemset(dinfo, 0, sizeof(int)) != hipSuccess) break;
         if (hipMemcpy2D(dS, (size_t)ld * sizeof(double), A, (size_t)n * sizeof(double), (size_t)n * sizeof(double), n, hipMemcpyHostToDevice) != hipSuccess) break;
         if (hipMemcpy(dE, b, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) break;
+        if (envelope) {      // tile envelope of A's own zero pattern (lower triangle), no reordering: the test entry of the envelope solver
+            const int nt = ld / POTRF_NB;
+            std::vector<int> first((size_t)nt), last((size_t)nt);
+            for (int I = 0; I < nt; ++I) { first[I] = I; last[I] = I; }
+            for (int r = 0; r < n; ++r)
+                for (int c = 0; c <= r; ++c)
+                    if (A[(size_t)r * n + c] != 0.0) { first[r / POTRF_NB] = std::min(first[r / POTRF_NB], c / POTRF_NB); break; }
+            for (int I = 0; I < nt; ++I) for (int K = first[I]; K <= I; ++K) last[K] = std::max(last[K], I);
+            ws.env_rows.assign((size_t)nt, 0);
+            for (int K = 0; K < nt; ++K) ws.env_rows[K] = last[K] - K;
+            if (hipMalloc((void**)&ws.d_last, (size_t)nt * sizeof(int)) != hipSuccess) break;
+            if (hipMemcpy(ws.d_last, last.data(), (size_t)nt * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) break;
+        }
         if (potrf_solve(ws, dS, ld, n, dE, dx, dinfo, st)) break;
         if (hipStreamSynchronize(st) != hipSuccess) break;
         if (hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) break;

@@ -65,7 +65,7 @@ enum {
                               which passes projac=NULL, sfm.c:820-828) */
 };
 
-enum { BSFM_SOLVER_DENSE = 0, BSFM_SOLVER_AUTO = 1 };
+enum { BSFM_SOLVER_DENSE = 0, BSFM_SOLVER_AUTO = 1, BSFM_SOLVER_ENVELOPE = 2 };
 
 typedef struct {
     int jacobian;        /* BSFM_JAC_FD (default for run_sfm) or BSFM_JAC_ANALYTIC */
@@ -77,7 +77,11 @@ typedef struct {
     int reduced_solver;  /* BSFM_SOLVER_DENSE (default): Cholesky of the whole dense S, the reference's algorithm
                             (sba_Axb_Chol); BSFM_SOLVER_AUTO: when the cameras fall into groups that share no point
                             (S block diagonal up to a permutation, every group <= 128 unknowns) solve group by group,
-                            otherwise dense.  Same solution up to rounding.  Env: BSFM_REDUCED_SOLVER=auto|dense. */
+                            otherwise the envelope solver.  BSFM_SOLVER_ENVELOPE: the cameras are renumbered (reverse
+                            Cuthill-McKee on the co-visibility graph) and the tiled Cholesky skips the 128 x 128 tiles outside
+                            the envelope of the reordered S -- exact (Cholesky without pivoting fills nothing outside the
+                            envelope), dpotrf's info then counts in the reordered system.  Same solution up to rounding.
+                            Env: BSFM_REDUCED_SOLVER=auto|dense|envelope. */
     int num_gpus;        /* run_sfm / bsfm_run_sfm_ex only: 0 or 1 = one GPU (default; env BSFM_NUM_GPUS overrides), n > 1 = shard the
                             points over the first n visible devices inside this one process (one host thread per GPU, RCCL
                             all-reduce of the camera system over xGMI, comm.hip), -1 = all visible devices */

@@ -129,3 +129,34 @@ def test_backward_substitution_timeout_word_reaches_info(gpu_bsfm):
         if n > 200:
             A[150, 150] = -1.0
             assert gpu_bsfm.dense_chol_solve(A, b)[0] == 151
+
+
+@pytest.mark.parametrize("n,half_band,seed", [(700, 90, 1), (2500, 300, 2), (1500, 64, 3), (900, 1000, 4), (2000, 1, 5), (1536, 40, 6), (1300, 200, 7)])
+def test_envelope_factorisation_of_a_banded_system(gpu_bsfm, n, half_band, seed):
+    """The opt-in envelope solver's factorisation (potrf.hip.h with PotrfWorkspace::env_rows: every step of the tiled schedule only
+    touches the tile rows inside the envelope of the matrix; Cholesky without pivoting creates no fill outside it) on banded SPD
+    systems -- narrow bands (steps with ONE or NO tile row below the diagonal tile: the decoupled-column path), a band wider than the
+    matrix (= dense), a ragged envelope -- against LAPACK and against the dense schedule on the same matrix; dpotrf's failure code
+    is kept.  Test entry: bsfm_dense_chol_solve(..., backend = 2) derives the tile envelope from the zero pattern of A."""
+    import scipy.linalg as sl
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((n, n))
+    i, j = np.indices((n, n))
+    A[np.abs(i - j) > half_band] = 0.0
+    if seed == 3:                                                        # ragged: a few long rows far from the diagonal
+        A[1200:1210, 100:140] = rng.standard_normal((10, 40))
+    if seed in (6, 7):                                                   # block diagonal: tile columns with NOTHING below the diagonal tile
+        blk = 512 if seed == 6 else 384                                  # (6: blocks end on tile boundaries; 7: they do not)
+        A[(i // blk) != (j // blk)] = 0.0
+    A = np.tril(A); A = A + A.T
+    A[np.arange(n), np.arange(n)] = np.abs(A).sum(axis=1) + 1.0          # diagonally dominant => SPD, same pattern
+    b = rng.standard_normal(n)
+    rc2, x2 = gpu_bsfm.dense_chol_solve(A, b, backend=2)
+    rc0, x0 = gpu_bsfm.dense_chol_solve(A, b, backend=0)
+    assert rc2 == 0 and rc0 == 0
+    ref = sl.cho_solve(sl.cho_factor(A, lower=True), b)
+    assert np.abs(x2 - ref).max() <= 1e-11 * np.abs(ref).max()
+    assert np.abs(x2 - x0).max() <= 1e-12 * np.abs(ref).max()
+    if n > 400:
+        A[333, 333] = -1.0
+        assert gpu_bsfm.dense_chol_solve(A, b, backend=2)[0] == 334
