@@ -122,6 +122,7 @@ struct PotrfWorkspace {
     double syrk_ms = 0.0; long long syrk_cnt = 0;
     double* sy_flops = nullptr; double syrk_flops = 0.0;     // flops of each timed launch / running sum
     int syrk_events = 1;        // HIP-event timing of every n-th bulk launch (BSFM_SYRK_EVENTS=n; 0 = none)
+    int timing = 1;             // 0: no timing events at all (small problems: solver.hip turns it off below 100 000 observations)
     int syrk_nt = 0;            // non-temporal C traffic in the bulk kernel (BSFM_SYRK_NT=1; measured neutral: 8.44 vs 8.52 ms per solve)
     long long* dbg = nullptr;   // optional device buffer: cycle stamps of k_potrf_diag phases (BSFM_DEBUG_DIAG=1)
 };
@@ -836,6 +837,41 @@ __global__ __launch_bounds__(512) void k_potrf_diag(double* __restrict__ S, int 
     diag_tile_body(dlds, S, ld, k, n_total, Linv, info, dbg);
 }
 
+// Systems of ONE tile (<= 128 unknowns: up to 14 cameras at cnp = 9, the first rounds of every incremental reconstruction): factor,
+// inverse and both substitutions in the one workgroup that holds the tile -- one launch instead of nine stream operations
+// (rhs copy, diagonal tile, forward tile, flag memset, persistent backward kernel, time-out fold, solution copy ...).
+// x = inv(L)^T (inv(L) E): the inverse factor has just been written by this workgroup (and was never read before in this launch).
+__global__ __launch_bounds__(512) void k_potrf_solve_one(double* __restrict__ S, int ld, int n_total, double* __restrict__ Linv,
+        int* __restrict__ info, const double* __restrict__ E, double* __restrict__ x)
+{
+    extern __shared__ __attribute__((aligned(16))) double dlds[];
+    diag_tile_body(dlds, S, ld, 0, n_total, Linv, info, nullptr);
+    __threadfence_block();
+    __syncthreads();
+    double* vec = dlds; double* red = dlds + POTRF_NB; double* yv = dlds + 5 * POTRF_NB;     // the tile in LDS is no longer needed
+    const int r = threadIdx.x & 127, h = threadIdx.x >> 7;                                  // 4 quarter-sums per row
+    if (threadIdx.x < POTRF_NB) vec[threadIdx.x] = threadIdx.x < n_total ? E[threadIdx.x] : 0.0;
+    __syncthreads();
+    {
+        const double* Li = Linv + (size_t)r * POTRF_NB + 32 * h;
+        double s = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < 32; ++c) s += Li[c] * vec[32 * h + c];
+        red[h * POTRF_NB + r] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < POTRF_NB) yv[r] = (red[r] + red[POTRF_NB + r]) + (red[2 * POTRF_NB + r] + red[3 * POTRF_NB + r]);
+    __syncthreads();
+    {
+        double s = 0.0;                                                                      // x[r] = sum_q inv(L)[q][r] y[q]
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) s += Linv[(size_t)(32 * h + q) * POTRF_NB + r] * yv[32 * h + q];
+        red[h * POTRF_NB + r] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < POTRF_NB && threadIdx.x < n_total) x[r] = (red[r] + red[POTRF_NB + r]) + (red[2 * POTRF_NB + r] + red[3 * POTRF_NB + r]);
+}
+
 // Backward substitution x = L^-T y as ONE persistent launch (replaces nblk dependent launches).
 // Workgroup kk owns tile column kk, all nblk workgroups are resident at once (nblk <= #CUs, 256 threads, no big LDS):
 //   for i = nblk-1 .. kk+1 :  wait for x_i  ->  y_kk -= L_{i,kk}^T x_i        (tile (i,kk) prefetched into registers
@@ -971,6 +1007,8 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
     (void)hipEventCreate(&w.ev0); (void)hipEventCreate(&w.ev1);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(DG_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_solve_one), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(DG_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_tile32<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(T32_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_tile32<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(T32_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
     w.sy0 = new hipEvent_t[w.nblk]; w.sy1 = new hipEvent_t[w.nblk]; w.sy_flops = new double[w.nblk];
@@ -998,7 +1036,7 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
 inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double* E, double* x_out, int* d_info, hipStream_t st)
 {
     if (n <= 0) return 0;
-    if (w.ev0) (void)hipEventRecord(w.ev0, st);
+    if (w.ev0 && w.timing) (void)hipEventRecord(w.ev0, st);
     if (w.backend == 1) {
         w.rb_set_stream(w.rb_handle, st);
         (void)hipMemcpyAsync(x_out, E, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
@@ -1015,6 +1053,11 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         return -1;
     }
     w.sy_used = 0;
+    if (nblk == 1) {         // one tile: everything in one launch
+        hipLaunchKernelGGL(k_potrf_solve_one, dim3(1), dim3(512), DG_LDS_DOUBLES * sizeof(double), st, S, ld, n, w.linv, d_info, E, x_out);
+        if (w.ev1 && w.timing) (void)hipEventRecord(w.ev1, st);
+        return 0;
+    }
     const size_t lds_bytes = 2 * 128 * GEMM_LDS_STRIDE * sizeof(double);
     (void)hipMemsetAsync(w.etmp, 0, (size_t)ld * sizeof(double), st);
     (void)hipMemcpyAsync(w.etmp, E, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
@@ -1079,7 +1122,7 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         (void)hipStreamWaitEvent(w.s2, w.evP[k], 0);
         if (T > 2) {
             const double* pprev = nullptr;
-            const bool timed = w.syrk_events > 0 && (k % w.syrk_events) == 0;
+            const bool timed = w.timing && w.syrk_events > 0 && (k % w.syrk_events) == 0;
             if (timed) (void)hipEventRecord(w.sy0[w.sy_used], w.s2);
             const dim3 bg(T * (T - 1) / 2 - 1);
             if (w.syrk_nt) hipLaunchKernelGGL(k_syrk_update<true>, bg, dim3(512), lds_bytes, w.s2, S, ld, k, pk, 2, pprev);
@@ -1106,7 +1149,7 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
                        (const int*)(env ? w.d_last : nullptr));
     hipLaunchKernelGGL(k_fold_timeout, dim3(1), dim3(1), 0, st, (const int*)(w.bflags + w.nblk), d_info);     // a hand-off that never arrived must not pass as a solution
     (void)hipMemcpyAsync(x_out, w.xs, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
-    if (w.ev1) (void)hipEventRecord(w.ev1, st);
+    if (w.ev1 && w.timing) (void)hipEventRecord(w.ev1, st);
     if (w.dbg) {
         long long h[8]; (void)hipStreamSynchronize(st); (void)hipMemcpy(h, w.dbg, sizeof(h), hipMemcpyDeviceToHost);
         fprintf(stderr, "[bsfm] diag tile stamps (100 MHz ticks): load %lld, phaseA %lld (A1 %lld A2 %lld A3 %lld), store %lld, phaseB %lld\n", h[0], h[1], h[4], h[5], h[6], h[2], h[3]);
@@ -1117,6 +1160,7 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
 inline void potrf_collect_time(PotrfWorkspace& w)
 {
     float ms = 0.f;
+    if (!w.timing) { w.sy_used = 0; return; }
     if (w.ev0 && w.ev1 && hipEventElapsedTime(&ms, w.ev0, w.ev1) == hipSuccess && ms >= 0.f) { w.ms += ms; w.cnt++; }
     for (int i = 0; i < w.sy_used; ++i)
         if (hipEventElapsedTime(&ms, w.sy0[i], w.sy1[i]) == hipSuccess && ms >= 0.f) { w.syrk_ms += ms; w.syrk_cnt++; w.syrk_flops += w.sy_flops[i]; }
