@@ -458,11 +458,15 @@ def main():
                                             "frac": round(sdim ** 3 / 3.0 / (phases["solve"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if phases["solve"] > 0 else None}}
         # HBM-bound streaming kernels against the 8 TB/s roof: algorithmic bytes / HIP-event time
         rp = r["rp"]
-        nv_loc, np_loc, js = float(r["k1"] - r["k0"]), float(r["hi"] - r["lo"]), 2 * cnp + 6
+        nv_loc, np_loc = float(r["k1"] - r["k0"]), float(r["hi"] - r["lo"])
         deg2 = float(np.sum(np.diff(rp).astype(np.float64) * (np.diff(rp) + 1) / 2))        # co-visibility triples
-        alg = {"jacobian": nv_loc * (8 * js + 8 + 24), "cam_blocks": nv_loc * (16 * cnp + 16 + 4),
-               "point_blocks": nv_loc * (48 + 16 + 4) + np_loc * 72, "backsub": nv_loc * (8 * js + 8) + np_loc * 120,
-               "residual": nv_loc * 56}
+        # algorithmic bytes per observation with the round-3 layout: Ac 16 cnp B, Bc 64 B (B || e), Cc 64 B, e 16 B, xc 16 B
+        a_b = 16.0 * cnp
+        alg = {"jacobian": nv_loc * (8 + 24 + 16 + a_b + 64),                 # index pair, point, e in; Ac, Bc out
+               "cam_blocks": nv_loc * (a_b + 16),                             # Ac, e streamed
+               "point_blocks": nv_loc * (64 + 4) + np_loc * 72,               # one Bc record per observation, V / eb out
+               "backsub": nv_loc * (a_b + 48 + 8) + np_loc * 120,             # Ac + B gathered, index pair
+               "residual": nv_loc * (16 + 8 + 24 + 16)}                       # xc, index pair, point in; e out
         hbm = {}
         for ph, nbytes in alg.items():
             ms = phases.get(ph, 0.0)
@@ -474,7 +478,7 @@ def main():
         schur = {"ms": phases["schur"], "triples": deg2, "useful_flop": schur_flop,
                  "TFLOPs": round(schur_flop / (phases["schur"] * 1e-3) / 1e12, 2) if phases["schur"] > 0 else None,
                  "frac_of_fp64_peak": round(schur_flop / (phases["schur"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if phases["schur"] > 0 else None,
-                 "unique_footprint_GB": round((nv_loc * 8 * js + np_loc * 72) / 1e9, 3),
+                 "unique_footprint_GB": round(nv_loc * (16.0 * cnp + 64 + 64) / 1e9, 3),
                  "note": "record gathers of the triples are served by L2 / Infinity Cache; against HBM only the unique footprint counts"}
         out = {
             "metric": "BA LM iterations/sec", "value": round(done / elapsed, 4), "unit": "iterations/s",
