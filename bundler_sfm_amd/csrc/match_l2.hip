@@ -428,7 +428,7 @@ static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_rad
         ok = ok && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreate(&s.k0) == hipSuccess && hipEventCreate(&s.k1) == hipSuccess;
     }
-    if (!ok) { fprintf(stderr, "[bsfm] matcher: allocation failed\n"); release(); fclose(f); return BSFM_ERROR; }
+    if (!ok) { fprintf(stderr, "[bsfm] matcher: allocation failed\n"); release(); if (f) fclose(f); return BSFM_ERROR; }
     int total_pairs_written = 0;
     std::vector<char> text;
     auto put_int = [&](int v, char sep) {

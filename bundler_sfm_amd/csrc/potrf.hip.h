@@ -71,6 +71,7 @@ struct StreamPool {
 inline StreamPool& stream_pool() { static StreamPool* p = new StreamPool(); return *p; }   // leaked on purpose: no teardown order issues at exit
 
 constexpr int POTRF_NB = 128;
+constexpr int POTRF_NARROW = 8;      // upper bound of BSFM_NARROW (steps with at most that many tile rows run single-stream, k_narrow_tiles)
 constexpr int POTRF_MAX_TILES = 240;   // k_bwd_persistent needs one resident workgroup per tile column (256 CUs)
 #ifndef BSFM_SYRK_WPS
 #define BSFM_SYRK_WPS 4      // waves per SIMD the bulk tile kernel is compiled for (4 = two workgroups per CU)
@@ -122,6 +123,11 @@ struct PotrfWorkspace {
     double syrk_ms = 0.0; long long syrk_cnt = 0;
     double* sy_flops = nullptr; double syrk_flops = 0.0;     // flops of each timed launch / running sum
     int syrk_events = 1;        // HIP-event timing of every n-th bulk launch (BSFM_SYRK_EVENTS=n; 0 = none)
+    int narrow = 3;             // steps with at most this many tile rows run single-stream (k_narrow_tiles); BSFM_NARROW = 0 .. 8.  Measured
+                                // (profiles/r03_narrow_steps.txt): 8 vs 0: 50 / 100 / 200 / 400 cameras 0.603 / 0.891 / 1.641 / 3.139 vs 0.620 / 0.939 / 1.694 /
+                                // 3.205 ms per iteration, but the envelope solve of the banded scene (4-5 rows per step) 5.36 vs 5.22 ms: the three-stream
+                                // step hides its panel / column work behind the next diagonal tile, the single-stream step does not -- so only the very
+                                // narrow steps (where there is next to nothing to hide) take this path by default
     int timing = 1;             // 0: no timing events at all (small problems: solver.hip turns it off below 100 000 observations)
     int syrk_nt = 0;            // non-temporal C traffic in the bulk kernel (BSFM_SYRK_NT=1; measured neutral: 8.44 vs 8.52 ms per solve)
     long long* dbg = nullptr;   // optional device buffer: cycle stamps of k_potrf_diag phases (BSFM_DEBUG_DIAG=1)
@@ -483,6 +489,105 @@ __global__ __launch_bounds__(256, 2) void k_chain_tile32(   // (2: a 256-registe
         } else {
             Ct[(size_t)rw * ld + col] = cin[t] - acc[t];
         }
+    }
+}
+
+// ---- NARROW STEPS (round 3) ------------------------------------------------------------------------------------------------
+// A step with few tile rows below its diagonal tile (<= POTRF_NARROW: every step of a small problem or of the envelope solver on a
+// banded scene, and the last steps of the dense factorisation) has no bulk worth a stream of its own; what it pays in the three-stream
+// schedule is the plumbing -- two launch boundaries and two cross-stream event hops (~16 us) next to 58 us of kernels.  Such a step runs
+// on the chain stream ALONE as three launches, no events, no owed-tile bookkeeping:
+//   k_narrow_tiles<0>  every panel tile P_a = S_{k+1+a,k} inv(L_kk)^T in 32 x 32 blocks (T x 16 workgroups) -> compact panel; + y_k
+//   k_narrow_tiles<1>  every trailing tile S_{k+1+a,k+1+b} -= P_a P_b^T, b <= a, in 32 x 32 blocks; + the panel copies -> S, + E -= P y_k
+//   k_potrf_diag       the next diagonal tile
+// Same 32 x 32-block products as k_chain_tile32 (whole K range of both operands to LDS in one step, 16x16x4 on two accumulator chains).
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_narrow_tiles(double* __restrict__ S, int ld, int k, int T, const double* __restrict__ Linv,
+        double* __restrict__ panel, double* __restrict__ E, double* __restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr size_t TL = (size_t)POTRF_NB * POTRF_NB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int a = 0, b = 0, blk;
+    if (MODE == 0) {
+        if ((int)blockIdx.x == T * 16) { fwd_tile_solve(Linv, E + (size_t)k * POTRF_NB, y + (size_t)k * POTRF_NB, lds); return; }   // y_k = inv(L_kk) E_k
+        a = blockIdx.x >> 4; blk = blockIdx.x & 15;
+    } else {
+        const int ntri = T * (T + 1) / 2;
+        int w = (int)blockIdx.x - ntri * 16;
+        if (w >= 0) {
+            if (w < T) {                 // panel tile w -> S (the factor itself lives in S: backward substitution, exports)
+                double* dst = S + ((size_t)(k + 1 + w) * POTRF_NB) * ld + (size_t)k * POTRF_NB;
+                const double* src = panel + (size_t)w * TL;
+                for (int idx = tid; idx < POTRF_NB * POTRF_NB / 2; idx += 256) {
+                    const int r = idx >> 6, c2 = (idx & 63) * 2;
+                    *reinterpret_cast<double2*>(dst + (size_t)r * ld + c2) = *reinterpret_cast<const double2*>(src + (size_t)r * POTRF_NB + c2);
+                }
+                return;
+            }
+            w -= T;                      // forward substitution: E_{k+1+w} -= P_w y_k, 2 lanes per row
+            const int row = tid >> 1, part = tid & 1;
+            const double* Pr = panel + (size_t)w * TL + (size_t)row * POTRF_NB + 64 * part;
+            const double* yk = y + (size_t)k * POTRF_NB + 64 * part;
+            double sacc = 0.0;
+#pragma unroll 16
+            for (int c = 0; c < 64; ++c) sacc += Pr[c] * yk[c];
+            sacc += __shfl_xor(sacc, 1, 64);
+            if (part == 0) E[(size_t)(k + 1 + w) * POTRF_NB + row] -= sacc;
+            return;
+        }
+        const int t = blockIdx.x >> 4; blk = blockIdx.x & 15;
+        a = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+        while ((a + 1) * (a + 2) / 2 <= t) ++a;
+        while (a * (a + 1) / 2 > t) --a;
+        b = t - a * (a + 1) / 2;
+    }
+    const int br = blk >> 2, bc = blk & 3;
+    if (MODE == 1 && a == b && bc > br) return;              // diagonal tiles: the lower-triangle blocks are all the next kernels read
+    const int wr = (wave >> 1) * 16, wc = (wave & 1) * 16;
+    const int K0 = MODE == 0 ? 32 * (bc + 1) : POTRF_NB;     // inv(L_kk) is lower triangular: column block bc only needs k < 32 (bc + 1)
+    double* As = lds; double* Bs = lds + 32 * T32_STRIDE;
+    const double* A_; const double* B_; int lda_;
+    if (MODE == 0) { A_ = S + ((size_t)(k + 1 + a) * POTRF_NB + 32 * br) * ld + (size_t)k * POTRF_NB; lda_ = ld; B_ = Linv + (size_t)(32 * bc) * POTRF_NB; }
+    else { A_ = panel + (size_t)a * TL + (size_t)(32 * br) * POTRF_NB; lda_ = POTRF_NB; B_ = panel + (size_t)b * TL + (size_t)(32 * bc) * POTRF_NB; }
+    double* Ct = S + ((size_t)(k + 1 + a) * POTRF_NB + 32 * br) * ld + (size_t)(k + 1 + b) * POTRF_NB + 32 * bc;     // MODE 1 only
+    double cin[4] = { 0.0, 0.0, 0.0, 0.0 };
+    if (MODE == 1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) cin[t] = Ct[(size_t)(wr + 4 * t + (lane >> 4)) * ld + wc + (lane & 15)];
+    }
+    const int row = tid >> 3, c2 = (tid & 7) * 2;
+    double pa[8][2], pb[8][2];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if (16 * q < K0) {
+            const double2 ta = *reinterpret_cast<const double2*>(A_ + (size_t)row * lda_ + 16 * q + c2);
+            const double2 tb = *reinterpret_cast<const double2*>(B_ + (size_t)row * POTRF_NB + 16 * q + c2);
+            pa[q][0] = ta.x; pa[q][1] = ta.y; pb[q][0] = tb.x; pb[q][1] = tb.y;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if (16 * q < K0) {
+            *reinterpret_cast<double2*>(As + row * T32_STRIDE + 16 * q + c2) = make_double2(pa[q][0], pa[q][1]);
+            *reinterpret_cast<double2*>(Bs + row * T32_STRIDE + 16 * q + c2) = make_double2(pb[q][0], pb[q][1]);
+        }
+    }
+    __syncthreads();
+    typedef double v4d_ __attribute__((ext_vector_type(4)));
+    const double* ap16 = As + (wr + (lane & 15)) * T32_STRIDE + (lane >> 4);
+    const double* bp = Bs + (wc + (lane & 15)) * T32_STRIDE + (lane >> 4);
+    v4d_ c = { 0.0, 0.0, 0.0, 0.0 }, cc = { 0.0, 0.0, 0.0, 0.0 };
+    for (int kk = 0; kk < K0; kk += 8) {
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap16[kk], bp[kk], c, 0, 0, 0);
+        cc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap16[kk + 4], bp[kk + 4], cc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int rw = wr + 4 * t + (lane >> 4), col = wc + (lane & 15);
+        const double v = c[t] + cc[t];
+        if (MODE == 0) panel[(size_t)a * TL + (size_t)(32 * br + rw) * POTRF_NB + 32 * bc + col] = v;
+        else Ct[(size_t)rw * ld + col] = cin[t] - v;
     }
 }
 
@@ -1011,6 +1116,9 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
                             (int)(DG_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_tile32<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(T32_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain_tile32<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(T32_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_narrow_tiles<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(T32_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_narrow_tiles<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(T32_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    if (const char* e = getenv("BSFM_NARROW")) w.narrow = std::max(0, std::min(POTRF_NARROW, atoi(e)));
     w.sy0 = new hipEvent_t[w.nblk]; w.sy1 = new hipEvent_t[w.nblk]; w.sy_flops = new double[w.nblk];
     for (int i = 0; i < w.nblk; ++i) { (void)hipEventCreate(&w.sy0[i]); (void)hipEventCreate(&w.sy1[i]); }
     if (const char* e = getenv("BSFM_SYRK_NT")) w.syrk_nt = atoi(e) != 0;
@@ -1089,24 +1197,25 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         const double* Lk = w.linv + (size_t)k * tl;
         // what panel k-1 still owes tile (k+1, k+1): its tile 1 = row k+1 (the bulk launches leave that one tile to the chain)
         const double* owed = (k > 0 && Tprev >= 2) ? (const double*)panel_of(k - 1) + tl : (const double*)nullptr;
-        if (T == 0) {
-            // Envelope only: column k has nothing below the diagonal tile -- rows k+1.. are decoupled from it.  y_k on the side stream
-            // (E_k is complete once the earlier column updates queued there have run), the events of this step are recorded empty,
-            // and tile (k+1, k+1) only takes what panel k-1 owes it.
-            (void)hipEventRecord(w.evT[k], st);                                   // diagonal tile k (and its inverse) are final
-            (void)hipStreamWaitEvent(w.sd, w.evT[k], 0);
-            hipLaunchKernelGGL(k_fwd_last, dim3(1), dim3(256), 0, w.sd, Lk, w.etmp + (size_t)k * POTRF_NB, w.y + (size_t)k * POTRF_NB);
-            (void)hipEventRecord(w.evP[k], w.sd);
-            (void)hipEventRecord(w.evC[k], w.sd);
-            (void)hipStreamWaitEvent(w.s2, w.evP[k], 0);
-            (void)hipEventRecord(w.evU[k], w.s2);
-            // tile (k+1, k+1) may have been touched by the bulk launches up to step k-2: they are ordered behind evC[k-1] (see below)
-            if (k > 0) (void)hipStreamWaitEvent(st, w.evC[k - 1], 0);
-            if (owed)
-                hipLaunchKernelGGL(k_chain_tile32<1>, dim3(10), dim3(256), lds32, st, S, ld, k, Lk, const_cast<double*>(owed), (const double*)nullptr, (const double*)nullptr);
+        const bool prev_narrow = k > 0 && Tprev <= w.narrow;
+        if (prev_narrow) owed = nullptr;                     // a narrow step applies its panel to EVERY trailing tile: nothing is owed
+        if (T <= w.narrow) {
+            // ---- narrow step: chain stream only.  Whatever the previous (wide) step left on the other streams must have landed first.
+            if (k > 0 && !prev_narrow) { (void)hipStreamWaitEvent(st, w.evC[k - 1], 0); (void)hipStreamWaitEvent(st, w.evU[k - 1], 0); }
+            if (owed)      // (the wide step before launched its bulk over ALL its tiles when it knew this step to be narrow: see below)
+                owed = nullptr;
+            hipLaunchKernelGGL(k_narrow_tiles<0>, dim3(T * 16 + 1), dim3(256), lds32, st, S, ld, k, T, Lk, pk, w.etmp, w.y);
+            if (T > 0)
+                hipLaunchKernelGGL(k_narrow_tiles<1>, dim3(T * (T + 1) / 2 * 16 + 2 * T), dim3(256), lds32, st, S, ld, k, T, Lk, pk, w.etmp, w.y);
+            const bool next_wide = k + 2 < nblk && rows_below(k + 1) > w.narrow;
+            if (next_wide || k + 2 >= nblk) {                // only a following wide step (or the tail of the solve) looks at this step's events
+                (void)hipEventRecord(w.evT[k], st); (void)hipEventRecord(w.evP[k], st);
+                (void)hipEventRecord(w.evC[k], st); (void)hipEventRecord(w.evU[k], st);
+            }
             hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), diag_lds, st, S, ld, k + 1, n, w.linv, d_info, w.dbg);
             continue;
         }
+        const bool next_narrow = k + 2 < nblk && rows_below(k + 1) <= w.narrow;
         // chain: first panel tile (its column k was completed by the side stream of step k-1)
         if (k > 0) (void)hipStreamWaitEvent(st, w.evC[k - 1], 0);
         hipLaunchKernelGGL(k_chain_tile32<0>, dim3(16), dim3(256), lds32, st, S, ld, k, Lk, pk, (const double*)nullptr, (const double*)nullptr);
@@ -1120,14 +1229,16 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         (void)hipEventRecord(w.evC[k], w.sd);
         // bulk
         (void)hipStreamWaitEvent(w.s2, w.evP[k], 0);
-        if (T > 2) {
+        if (T > 2 || (next_narrow && T == 2)) {
             const double* pprev = nullptr;
             const bool timed = w.timing && w.syrk_events > 0 && (k % w.syrk_events) == 0;
             if (timed) (void)hipEventRecord(w.sy0[w.sy_used], w.s2);
-            const dim3 bg(T * (T - 1) / 2 - 1);
-            if (w.syrk_nt) hipLaunchKernelGGL(k_syrk_update<true>, bg, dim3(512), lds_bytes, w.s2, S, ld, k, pk, 2, pprev);
-            else hipLaunchKernelGGL(k_syrk_update<false>, bg, dim3(512), lds_bytes, w.s2, S, ld, k, pk, 2, pprev);
-            if (timed) { (void)hipEventRecord(w.sy1[w.sy_used], w.s2); w.sy_flops[w.sy_used++] = tile_flops * (T * (T - 1) / 2 - 1); }
+            // part 2 leaves tile (k+2, k+2) to the chain's k_chain_tile32<1> of the next step; a NARROW next step has no such kernel: part 3
+            const int ntile = T * (T - 1) / 2 - (next_narrow ? 0 : 1);
+            const dim3 bg(ntile);
+            if (w.syrk_nt) hipLaunchKernelGGL(k_syrk_update<true>, bg, dim3(512), lds_bytes, w.s2, S, ld, k, pk, next_narrow ? 3 : 2, pprev);
+            else hipLaunchKernelGGL(k_syrk_update<false>, bg, dim3(512), lds_bytes, w.s2, S, ld, k, pk, next_narrow ? 3 : 2, pprev);
+            if (timed) { (void)hipEventRecord(w.sy1[w.sy_used], w.s2); w.sy_flops[w.sy_used++] = tile_flops * ntile; }
         }
         (void)hipEventRecord(w.evU[k], w.s2);
         // chain: next diagonal tile

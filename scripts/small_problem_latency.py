@@ -26,7 +26,7 @@ def run(tag, n, m, vm, proj, cams, pts, s):
     pb.close()
     line = (f"{tag}: GPU run_sfm {1e3 * min(ts):8.2f} ms, {int(info[5])} iterations (resident API: create {1e3 * t_create:.2f} ms {split}, "
             f"LM {1e3 * t_solve:.2f} ms = {1e3 * t_solve / max(info[5], 1):.3f} ms/iter)")
-    if O.have_ref():
+    if O.have_ref() and not os.environ.get("SMALL_NO_REF"):
         t = time.perf_counter(); O.ref_run_sfm(n, m, vm, proj, cams, pts); tr = time.perf_counter() - t
         line += f" | reference run_sfm (1 core) {1e3 * tr:9.1f} ms"
     print(line, flush=True)
