@@ -465,7 +465,8 @@ __global__ __launch_bounds__(128) void k_schur_pack(int nblk, const int* __restr
 // ... and after the exchange every rank assembles the same S from the summed blocks.
 template <int CNP>
 __global__ __launch_bounds__(128) void k_schur_unpack(int ngblk, const int* __restrict__ gj, const int* __restrict__ gk,
-        const double* __restrict__ G, const double* __restrict__ U, double mu, int mcon, double* __restrict__ S, int ld)
+        const double* __restrict__ G, const double* __restrict__ U, double mu, int mcon, double* __restrict__ S, int ld,
+        const int* __restrict__ spos)
 {
     const int g = blockIdx.x;
     if (g >= ngblk || threadIdx.x >= CNP * CNP) return;
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(128) void k_schur_unpack(int ngblk, const int* __re
     const int row = threadIdx.x / CNP, col = threadIdx.x % CNP;
     double v = -G[(size_t)g * CNP * CNP + threadIdx.x];
     if (j == k) { v += U[(size_t)j * CNP * CNP + threadIdx.x]; if (row == col) v += mu; }
-    const size_t rj = (size_t)(j - mcon) * CNP + row, ck = (size_t)(k - mcon) * CNP + col;
+    const size_t rj = (size_t)(spos ? spos[j - mcon] : j - mcon) * CNP + row, ck = (size_t)(spos ? spos[k - mcon] : k - mcon) * CNP + col;
     S[rj * ld + ck] = v;
     if (j != k) S[ck * ld + rj] = v;
 }

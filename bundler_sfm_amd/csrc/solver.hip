@@ -450,10 +450,8 @@ int setup_components(bsfm_problem* pb, const std::vector<int>& bj, const std::ve
         if (pb->comps.active) return 0;
     }
     if (pb->opt.reduced_solver == BSFM_SOLVER_AUTO || pb->opt.reduced_solver == BSFM_SOLVER_ENVELOPE) {
-        if (pb->world > 1) {      // the packed exchange assembles S in the natural order on every rank
-            if (pb->opt.verbose >= 2) printf("[bsfm] envelope solver: single-rank problems only, using the dense solve\n");
-            return 0;
-        }
+        // multi-rank jobs come here with the job-wide UNION of the block lists (exchange_block_union): every rank derives the same
+        // numbering and the same envelope, the exchange buffer itself stays in the natural numbering
         return setup_envelope(pb, bj, bk);
     }
     return 0;
@@ -514,9 +512,9 @@ int compute_schur(bsfm_problem* pb, double mu)
     const int mm = P.m - P.mcon;
     const int lead = pb->rank == 0 ? 1 : 0;
     const bool packed = has_collective(pb);
+    if (packed && pb->ngblk < 0 && exchange_block_union(pb)) return BSFM_ERROR;      // (first attempt of a multi-rank job: also decides on the envelope)
     // envelope solver: S, E are assembled in the reordered camera numbering (exports always use the natural one)
     const int* spos = (pb->envelope && !pb->export_full_s) ? pb->d_spos : nullptr;
-    if (packed && pb->ngblk < 0 && exchange_block_union(pb)) return BSFM_ERROR;
     if (pb->export_full_s) (void)hipMemsetAsync(pb->d_S, 0, (size_t)pb->ld * pb->ld * sizeof(double), pb->stream);
     else if (!pb->comps.active) {   // (the group-by-group solve never writes S: blocks that are structurally empty stay zero)
         const int nt = pb->ld / POTRF_NB; hipLaunchKernelGGL(k_zero_lower_tiles, dim3(nt * (nt + 1) / 2), dim3(256), 0, pb->stream, pb->d_S, pb->ld); }
@@ -524,7 +522,7 @@ int compute_schur(bsfm_problem* pb, double mu)
     double* Edst = packed ? pb->d_G + (size_t)pb->ngblk * cnp * cnp : pb->d_E;     // packed: E rides behind the blocks
     if (mm > 0)
         hipLaunchKernelGGL(k_rhs_init, dim3(grid_for((size_t)mm * cnp, 256)), dim3(256), 0, pb->stream, mm * cnp, P.mcon * cnp,
-                           lead, pb->d_ea, Edst, spos, cnp);
+                           lead, pb->d_ea, Edst, packed ? (const int*)nullptr : spos, cnp);     // (packed: E travels in the natural numbering)
     if (pb->ntasks > 0) {
         // C_ij = B_ij V*_i^-1 || C_ij eb_i for this attempt's mu, then the task kernel (schur.hip.h)
         hipLaunchKernelGGL(k_schur_prep, dim3(grid_for(4 * (size_t)P.nvis, 256)), dim3(256), 0, pb->stream, P.nvis, pb->d_obs_pt, pb->d_campos, pb->d_Bc, pb->d_Vinv, pb->d_eb, pb->d_Cc);
@@ -547,13 +545,15 @@ int compute_schur(bsfm_problem* pb, double mu)
         // exchange step 2: the block sums of the union structure and E in ONE buffer; U was already summed over
         // ranks, so every rank then assembles the SAME S = [j==k](U_j + mu I) - G_jk and solves it redundantly
         if (allreduce_dev(pb, pb->d_G, (size_t)pb->ngblk * cnp * cnp + (size_t)pb->Sdim, 0)) return BSFM_ERROR;
-        (void)hipMemcpyAsync(pb->d_E, Edst, (size_t)pb->Sdim * sizeof(double), hipMemcpyDeviceToDevice, pb->stream);
+        if (spos && mm > 0)      // envelope solver: into the reordered numbering on the way out of the exchange buffer
+            hipLaunchKernelGGL(k_rhs_init, dim3(grid_for((size_t)mm * cnp, 256)), dim3(256), 0, pb->stream, mm * cnp, 0, 1, (const double*)Edst, pb->d_E, spos, cnp);
+        else (void)hipMemcpyAsync(pb->d_E, Edst, (size_t)pb->Sdim * sizeof(double), hipMemcpyDeviceToDevice, pb->stream);
         if (mm > 0)
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_diag_fill<C>), dim3(mm), dim3(128), 0, pb->stream, P.m, P.mcon,
-                                                  (const int*)nullptr, pb->d_U, mu, pb->d_S, pb->ld, (const int*)nullptr));
+                                                  (const int*)nullptr, pb->d_U, mu, pb->d_S, pb->ld, spos));
         if (pb->ngblk > 0)
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_unpack<C>), dim3(pb->ngblk), dim3(128), 0, pb->stream, pb->ngblk,
-                                                  pb->d_gblk_j, pb->d_gblk_k, pb->d_G, pb->d_U, mu, P.mcon, pb->d_S, pb->ld));
+                                                  pb->d_gblk_j, pb->d_gblk_k, pb->d_G, pb->d_U, mu, P.mcon, pb->d_S, pb->ld, spos));
     } else if (mm > 0) {
         DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_diag_fill<C>), dim3(mm), dim3(128), 0, pb->stream, P.m, P.mcon,
                                               pb->d_camptr, pb->d_U, mu, pb->d_S, pb->ld, spos));

@@ -125,9 +125,11 @@ def test_run_sfm_over_two_in_process_ranks_matches_one_gpu(monkeypatch):
     s = B.synth_ba(m, n, 6, banded=True)
     vm = B.dense_vmask(n, m, s["rowptr"], s["colidx"])
     outs = []
-    for g in (1, 2, 3):
+    for g, solver in ((1, B.SOLVER_DENSE), (2, B.SOLVER_DENSE), (3, B.SOLVER_DENSE), (2, B.SOLVER_ENVELOPE), (3, B.SOLVER_AUTO)):
+        # (the last two: the envelope solver on a multi-rank job -- every rank derives the same camera numbering from the job-wide
+        #  union of the reduced-camera blocks; the exchange buffer stays in the natural numbering)
         cams = B.copy_cameras(s["cams"]); pts = s["pts"].copy()
-        opt = B.default_options(jacobian=B.JAC_ANALYTIC, verbose=0, itmax=8, num_gpus=g)
+        opt = B.default_options(jacobian=B.JAC_ANALYTIC, verbose=0, itmax=8, num_gpus=g, reduced_solver=solver)
         rc, info = B.run_sfm(n, m, 0, vm, s["proj"], 1, 0, 1, 1, cams, pts, eps2=1e-12, options=opt)
         assert rc >= 0
         outs.append((info, np.array([list(c.R) + list(c.t) + [c.f] + list(c.k) for c in cams]), pts))
