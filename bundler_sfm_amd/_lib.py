@@ -76,7 +76,7 @@ SYMBOLS = [
     "bsfm_problem_cnp", "bsfm_problem_num_cameras", "bsfm_problem_num_points", "bsfm_problem_nvis", "bsfm_eval_residuals", "bsfm_problem_outlier_stats", "bsfm_problem_ray_angles", "bsfm_triangulate_batch", "bsfm_rand_seed", "bsfm_rand_next", "bsfm_fmatrix_ransac_batch",
     "bsfm_estimate_fmatrix_batch", "bsfm_compute_tracks",
     "bsfm_eval_normal_equations", "bsfm_dense_chol_solve", "bsfm_match_keys_l2", "bsfm_key_match_full",
-    "bsfm_key_match_full_sharded", "bsfm_merge_match_files", "bsfm_match_set_create", "bsfm_match_set_run", "bsfm_match_set_run_table", "bsfm_free", "bsfm_match_set_stats",
+    "bsfm_key_match_full_sharded", "bsfm_merge_match_files", "bsfm_match_set_create", "bsfm_match_set_run", "bsfm_match_set_run_table", "bsfm_free", "bsfm_match_set_stats", "bsfm_match_kernel", "bsfm_match_set_rescan_launches",
     "bsfm_match_set_destroy",
     "bsfm_device_count", "bsfm_version", "bsfm_device_synchronize", "bsfm_synth_ba", "bsfm_synth_keys",
 ]
@@ -177,6 +177,10 @@ def _load():
     lib.bsfm_free.restype = None
     lib.bsfm_match_set_stats.argtypes = [vp, dp, dp, C.POINTER(C.c_longlong), ip]
     lib.bsfm_match_set_stats.restype = C.c_int
+    lib.bsfm_match_kernel.argtypes = [C.c_int]
+    lib.bsfm_match_kernel.restype = C.c_int
+    lib.bsfm_match_set_rescan_launches.argtypes = [vp]
+    lib.bsfm_match_set_rescan_launches.restype = C.c_int
     lib.bsfm_match_set_destroy.argtypes = [vp]
     lib.bsfm_match_set_destroy.restype = None
     lib.bsfm_comm_create_from_env.argtypes = []

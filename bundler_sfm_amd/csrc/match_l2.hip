@@ -33,7 +33,6 @@ namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-constexpr int QB = 128;            // queries per workgroup
 constexpr int BIG = 0x3fffffff;
 constexpr size_t KEY_SLACK = 64;        // keys of slack behind the last image: the scan prefetches whole tiles (k_match_l2)
 
@@ -85,13 +84,29 @@ __device__ __forceinline__ v4i flip(const uint4 v)          // the loaded words 
     return r;
 }
 
+#ifndef BSFM_MATCH_RESCAN_WGS
+#define BSFM_MATCH_RESCAN_WGS 3      // workgroups per CU of the minimum-only variant (its exchange buffer is half the size)
+#endif
 // nn_out[out_off + query] = index of the accepted nearest neighbour in the database image, or -1.
-__global__ __launch_bounds__(256, 2) void k_match_l2(const unsigned char* __restrict__ keys, const int* __restrict__ qstat,
+// RESCAN = false: exact running top-2 per slot (3 VALU instructions per distance).  RESCAN = true (round 3): a slot keeps only its
+// running MINIMUM (2 VALU per distance).  The second smallest of the slot minima is then an upper bound of the true second-nearest
+// distance -- only the other columns of the WINNING slot can lie below it -- so a row whose nearest fails the ratio test against
+// that bound fails it for good, and the rows that pass get the winning slot's other columns (<= 127 keys) measured exactly
+// (v_dot4_i32_i8) by the whole workgroup before the final test.  Without the second-best registers a workgroup holds QBT = 256
+// query rows (16 row groups of A fragments per wave), which halves the database fragments fetched per MAC -- what the scan is
+// bound by: with the loads taken out (timing experiment) the 128-row kernels run at 3.23 (top-2) / 2.72 us (minimum only) per
+// 5000 x 5000 pair instead of 3.83 / 3.84.  DEPTH = 2: the hand-pipelined loop (see there).
+template <bool RESCAN, int DEPTH, int QBT>
+__global__ __launch_bounds__(256, RESCAN && QBT == 128 ? BSFM_MATCH_RESCAN_WGS : 2) void k_match_l2(const unsigned char* __restrict__ keys, const int* __restrict__ qstat,
         const PairDesc* __restrict__ pairs, int npairs, int db_off, int db_n, double ratio_sq, int* __restrict__ nn_out, int one)
 {
-    constexpr int NG = QB / 16;                       // row groups of 16 queries held by every wave
+    constexpr int NG = QBT / 16;                      // row groups of 16 queries held by every wave
+    constexpr int TPR = 256 / QBT;                    // threads that merge one query row after a segment (2 at 128 queries, 1 at 256)
+    static_assert(QBT == 128 || (QBT == 256 && RESCAN), "256 queries per workgroup only fit without the second-best registers");
     constexpr int XS = 65;                            // row stride (uint2) of the exchange buffer: 64 column classes + 1 pad
-    __shared__ uint2 xch[QB * XS];                    // per segment: every (query row, column class) slot's packed (best, second)
+    // per segment: every (query row, column class) slot's packed (best, second); the minimum-only variant exchanges the best alone
+    __shared__ unsigned xch_raw[QBT * XS * (RESCAN ? 1 : 2)];
+    uint2* xch = reinterpret_cast<uint2*>(xch_raw);
     // Locate the pair this block belongs to: a binary search on the pairs' first-block numbers that every thread runs on
     // uniform addresses (scalar loads, no barrier; one thread searching + a barrier kept 255 threads idle for 9 round trips).
     int s_pair = 0;
@@ -101,23 +116,31 @@ __global__ __launch_bounds__(256, 2) void k_match_l2(const unsigned char* __rest
         s_pair = lo;
     }
     const PairDesc pd = pairs[s_pair];
-    const int qbase = (blockIdx.x - pd.blk0) * QB;
+    const int qbase = (blockIdx.x - pd.blk0) * QBT;
     // running (nearest, second nearest, column) of query row threadIdx.x / 2, kept by the two threads that merge that row
-    const int row_qa = qstat[pd.q_off + min(qbase + (int)(threadIdx.x >> 1), pd.q_n - 1)] - 2 * 128 * 128 * 128;
+    const int my_row = (int)threadIdx.x / TPR;
+    const int row_qa = qstat[pd.q_off + min(qbase + my_row, pd.q_n - 1)] - 2 * 128 * 128 * 128;
     int row_d0 = BIG, row_d1 = BIG, row_idx = -1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned char* qkeys = keys + (size_t)pd.q_off * 128;
     const unsigned char* dkeys = keys + (size_t)db_off * 128;
 
-    // A fragments: NG row groups x 2 k-steps stay in registers for the whole scan.  QB = 128 queries per workgroup: every
-    // database fragment a wave fetches from L2 is used for 8 MFMA pairs -- the scan is bound by that L2 -> CU traffic
-    // (128 MAC per byte at QB = 128), it was 8.0 us per 5000 x 5000 pair with 64 queries per workgroup.
+    // A fragments: NG row groups x 2 k-steps stay in registers for the whole scan.  QBT queries per workgroup: every
+    // database fragment a wave fetches from L2 is used for QBT / 16 MFMA pairs -- the scan is bound by that L2 -> CU traffic
+    // (QBT MAC per byte): 8.0 us per 5000 x 5000 pair with 64 queries per workgroup, 3.6-3.8 with 128, 3.3 with 256.
     v4i afrag[NG][2];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const int row = min(qbase + 16 * g + (lane & 15), pd.q_n - 1);
         afrag[g][0] = load_frag(qkeys, row, lane, 0);
         afrag[g][1] = load_frag(qkeys, row, lane, 1);
+    }
+    if (DEPTH != 0) {
+        // the hand-counted waits of the scan loop below assume that nothing of the compiler's own is in flight: make it wait for
+        // the A fragments HERE (its bookkeeping does not see the loop's inline-asm loads, and a late compiler wait for a fragment
+        // inside the loop would become a wait for the prefetches as well)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) asm volatile("" : "+v"(afrag[g][0]), "+v"(afrag[g][1]));
     }
     // Running top-2 per slot on PACKED keys.  Ranking needs only e = qb - 2 dot (the query term qa is the same for every
     // candidate of a row), so the per-distance work is ONE 24-bit multiply-add that builds the key (below), one v_min_u32
@@ -151,19 +174,8 @@ __global__ __launch_bounds__(256, 2) void k_match_l2(const unsigned char* __rest
         // (running pointers, no clamp: the key and statistic arrays carry one tile of slack behind the last image, and what
         //  is loaded past the database image only ever meets DEADQ)
         const int colf = seg + 16 * wave + (lane & 15);
-        const unsigned char* kp = dkeys + (size_t)colf * 128 + 16 * (lane >> 4);
-        const int* qp = qstat + db_off + colf;
-        uint4 rf0 = *reinterpret_cast<const uint4*>(kp), rf1 = *reinterpret_cast<const uint4*>(kp + 64);
-        int rqb = *qp;
-        int coln = colf;
-        for (int tile = seg; tile < seg_end; tile += 64) {
-            const v4i bf0 = flip(rf0), bf1 = flip(rf1);
-            const int qbb = coln < db_n ? rqb + EBIAS : DEADQ;
-            if (tile + 64 < seg_end) {
-                kp += 64 * 128; qp += 64; coln += 64;
-                rf0 = *reinterpret_cast<const uint4*>(kp); rf1 = *reinterpret_cast<const uint4*>(kp + 64);
-                rqb = *qp;
-            }
+        // multiply and rank one tile whose fragments are (bf0, bf1) and whose statistic term is qbb
+        auto rank_tile = [&](const v4i bf0, const v4i bf1, const int qbb, const int tile) __attribute__((always_inline)) {
             // key = ((qb + BIAS - 2 dot) << TB) | tile = K - (dot << (TB + 1)) with K = ((qb + BIAS) << TB) | tile: the low TB
             // bits are untouched by the subtraction, so ONE 24-bit multiply-add per distance builds the packed key
             const int K = (int)(((unsigned)qbb << TB) | (unsigned)((tile - seg) >> 6));
@@ -176,9 +188,11 @@ __global__ __launch_bounds__(256, 2) void k_match_l2(const unsigned char* __rest
 #define BSFM_RANK(R)                                                                                                      \
                 {   /* (no inline asm on the accumulator itself: the compiler must see the MFMA -> VALU dependency) */     \
                     const unsigned key = (unsigned)(__mul24(acc[R], mscale) + K);        /* v_mad_i32_i24 */              \
-                    unsigned m;                                                                                           \
-                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(b0[g][R]), "v"(b1[g][R]), "v"(key));                  \
-                    b1[g][R] = m;                                                                                         \
+                    if (!RESCAN) {                                                                                        \
+                        unsigned m;                                                                                       \
+                        asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(b0[g][R]), "v"(b1[g][R]), "v"(key));              \
+                        b1[g][R] = m;                                                                                     \
+                    }                                                                                                     \
                     b0[g][R] = min(b0[g][R], key);                                                                        \
                 }
 #pragma unroll
@@ -195,6 +209,57 @@ __global__ __launch_bounds__(256, 2) void k_match_l2(const unsigned char* __rest
                 acc = nacc;
             }
 #undef BSFM_RANK
+        };
+        if (DEPTH == 0) {
+            const unsigned char* kp = dkeys + (size_t)colf * 128 + 16 * (lane >> 4);
+            const int* qp = qstat + db_off + colf;
+            uint4 rf0 = *reinterpret_cast<const uint4*>(kp), rf1 = *reinterpret_cast<const uint4*>(kp + 64);
+            int rqb = *qp;
+            int coln = colf;
+            for (int tile = seg; tile < seg_end; tile += 64) {
+                const v4i bf0 = flip(rf0), bf1 = flip(rf1);
+                const int qbb = coln < db_n ? rqb + EBIAS : DEADQ;
+                if (tile + 64 < seg_end) {
+                    kp += 64 * 128; qp += 64; coln += 64;
+                    rf0 = *reinterpret_cast<const uint4*>(kp); rf1 = *reinterpret_cast<const uint4*>(kp + 64);
+                    rqb = *qp;
+                }
+                rank_tile(bf0, bf1, qbb, tile);
+            }
+        } else {
+            // TWO tiles in flight, loads and waits written by hand (the compiler hoists, clusters or copies what it manages itself:
+            // with its own loads every attempt at a distance of two tiles ended in a vmcnt(0) or in a copy of a register that was
+            // still being loaded).  Three register sets rotate -- tile t is multiplied out of one while the loads of tile t + 2 go
+            // into the set tile t - 1 has finished with -- and the loop is unrolled three times so that no set ever changes registers.
+            // Every tile issues exactly three loads (the last ones reload the segment's last tile), so "all but the newest three"
+            // is the wait for the set about to be used; the counter is drained before the registers are reused.
+            const unsigned koff = (unsigned)((16 * wave + (lane & 15)) * 128 + 16 * (lane >> 4));
+            const unsigned qoff = (unsigned)(4 * (16 * wave + (lane & 15)));
+            const int seg_last = seg + ((seg_end - seg - 1) & ~63);          // first column of the segment's last tile
+            v4i x0, x1, y0, y1, z0, z1; int xq, yq, zq;
+#define BSFM_ISSUE(S0, S1, SQ, T)                                                                                          \
+            {   const int tn = min((T), seg_last);                                                                        \
+                const unsigned char* sp = dkeys + (size_t)tn * 128;                                                       \
+                const int* sq = qstat + db_off + tn;                                                                      \
+                asm volatile("global_load_dwordx4 %0, %3, %4\n\tglobal_load_dwordx4 %1, %3, %4 offset:64\n\t"            \
+                             "global_load_dword %2, %5, %6"                                                               \
+                             : "=&v"(S0), "=&v"(S1), "=&v"(SQ) : "v"(koff), "s"(sp), "v"(qoff), "s"(sq) : "memory"); }
+#define BSFM_USE(S0, S1, SQ, L0, L1, LQ, T)                                                                                \
+            {   asm volatile("s_waitcnt vmcnt(3)" : "+v"(S0), "+v"(S1), "+v"(SQ));                                        \
+                const v4i bf0 = S0, bf1 = S1;                                                                             \
+                const int qbb = colf + ((T) - seg) < db_n ? SQ + EBIAS : DEADQ;                                           \
+                BSFM_ISSUE(L0, L1, LQ, (T) + 128)                                                                         \
+                rank_tile(bf0, bf1, qbb, (T)); }
+            BSFM_ISSUE(x0, x1, xq, seg)
+            BSFM_ISSUE(y0, y1, yq, seg + 64)
+            for (int tile = seg;;) {
+                BSFM_USE(x0, x1, xq, z0, z1, zq, tile) tile += 64; if (tile >= seg_end) break;
+                BSFM_USE(y0, y1, yq, x0, x1, xq, tile) tile += 64; if (tile >= seg_end) break;
+                BSFM_USE(z0, z1, zq, y0, y1, yq, tile) tile += 64; if (tile >= seg_end) break;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(xq), "+v"(y0), "+v"(y1), "+v"(yq), "+v"(z0), "+v"(z1), "+v"(zq));
+#undef BSFM_USE
+#undef BSFM_ISSUE
         }
         // Segment merge through LDS: slot (row, column class 16 wave + lane % 16) goes to xch[row][class]; then two threads per
         // query row scan 32 classes each (6 VALU per class), combine with one DPP swap, and the even thread folds the segment's
@@ -205,20 +270,23 @@ __global__ __launch_bounds__(256, 2) void k_match_l2(const unsigned char* __rest
         for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                xch[(16 * g + 4 * (lane >> 4) + r) * XS + 16 * wave + (lane & 15)] = make_uint2(b0[g][r], b1[g][r]);
+                if (RESCAN) xch_raw[(16 * g + 4 * (lane >> 4) + r) * XS + 16 * wave + (lane & 15)] = b0[g][r];
+                else xch[(16 * g + 4 * (lane >> 4) + r) * XS + 16 * wave + (lane & 15)] = make_uint2(b0[g][r], b1[g][r]);
         __syncthreads();
         {
-            const int half = threadIdx.x & 1;
-            const uint2* src = xch + (threadIdx.x >> 1) * XS + 32 * half;
+            constexpr int CPT = 64 / TPR;              // column classes per merging thread
+            const int half = TPR == 2 ? (threadIdx.x & 1) : 0;
+            const uint2* src = xch + my_row * XS + CPT * half;
+            const unsigned* src1 = xch_raw + my_row * XS + CPT * half;
             unsigned k0 = 0xffffffffu, k1 = 0xffffffffu; int cls = 0;
 #pragma unroll 8
-            for (int e = 0; e < 32; ++e) {
-                const uint2 o = src[e];
+            for (int e = 0; e < CPT; ++e) {
+                const uint2 o = RESCAN ? make_uint2(src1[e], 0xffffffffu) : src[e];
                 k1 = min(max(k0, o.x), min(k1, o.y));
-                cls = o.x < k0 ? 32 * half + e : cls;
+                cls = o.x < k0 ? CPT * half + e : cls;
                 k0 = min(k0, o.x);
             }
-            {   // the other half of the row sits in the neighbouring lane
+            if (TPR == 2) {   // the other half of the row sits in the neighbouring lane
                 const unsigned o0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k0, 0xB1, 0xf, 0xf, false);
                 const unsigned o1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k1, 0xB1, 0xf, 0xf, false);
                 const int oc = __builtin_amdgcn_update_dpp(0, cls, 0xB1, 0xf, 0xf, false);
@@ -234,8 +302,44 @@ __global__ __launch_bounds__(256, 2) void k_match_l2(const unsigned char* __rest
             else row_d1 = min(row_d1, c0);
         }
     }
-    if ((threadIdx.x & 1) == 0) {
-        const int q = qbase + (threadIdx.x >> 1);
+    if (RESCAN) {
+        // rows whose nearest passes the test against the BOUND: measure the other columns of the winning slot exactly
+        __shared__ int s_cnt, s_row[QBT], s_idx[QBT], s_d1[QBT];
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        bool need = false;
+        int slot = 0;
+        if ((threadIdx.x & (TPR - 1)) == 0 && qbase + my_row < pd.q_n && row_idx >= 0) {
+#pragma clang fp contract(off)
+            need = ((double)row_d0) < ratio_sq * ((double)row_d1);
+        }
+        if (need) { slot = atomicAdd(&s_cnt, 1); s_row[slot] = my_row; s_idx[slot] = row_idx; s_d1[slot] = row_d1; }
+        __syncthreads();
+        const int items = s_cnt * (SEG / 64);
+        for (int it = threadIdx.x; it < items; it += 256) {
+            const int p = it / (SEG / 64), t = it % (SEG / 64);
+            const int ridx = s_idx[p];
+            const int col = (ridx / SEG) * SEG + 64 * t + (ridx & 63);
+            if (col < db_n && col != ridx) {
+                const int q = qbase + s_row[p];
+                const uint4* a = reinterpret_cast<const uint4*>(qkeys + (size_t)q * 128);
+                const uint4* b = reinterpret_cast<const uint4*>(dkeys + (size_t)col * 128);
+                int dot = 0;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) {
+                    const uint4 x = a[w], y = b[w];
+                    dot = __builtin_amdgcn_sdot4((int)x.x, (int)y.x, dot, false); dot = __builtin_amdgcn_sdot4((int)x.y, (int)y.y, dot, false);
+                    dot = __builtin_amdgcn_sdot4((int)x.z, (int)y.z, dot, false); dot = __builtin_amdgcn_sdot4((int)x.w, (int)y.w, dot, false);
+                }
+                const int d = qstat[pd.q_off + q] - 2 * 128 * 128 * 128 + qstat[db_off + col] - 2 * dot;
+                atomicMin(&s_d1[p], d);
+            }
+        }
+        __syncthreads();
+        if (need) row_d1 = s_d1[slot];
+    }
+    if ((threadIdx.x & (TPR - 1)) == 0) {
+        const int q = qbase + my_row;
         if (q < pd.q_n) {
             bool ok;
             {
@@ -245,6 +349,35 @@ __global__ __launch_bounds__(256, 2) void k_match_l2(const unsigned char* __rest
             nn_out[pd.out_off + q] = ok ? row_idx : -1;
         }
     }
+}
+
+// Which scan kernel a launch uses.  Both are exact and give the same table; they differ in what they cost:
+//   top-2   (k_match_l2<false, 0, 128>): 3 VALU per distance, 128 queries per workgroup, indifferent to the data;
+//   rescan  (k_match_l2<true, 2, 256>):  2 VALU per distance, 256 queries per workgroup (half the L2 -> CU fragment traffic per MAC),
+//           + 128 exact distances for every query row that passes the ratio test against the bound: 14-17 % faster when few rows
+//           pass (unordered photo collections: 3.29 vs 3.82 us per 5000 x 5000 pair), 28 % slower when a quarter of them do.
+// auto (the default) starts with rescan and switches per launch on the share of accepted matches in the last launch whose
+// results the host has seen.  BSFM_MATCH_KERNEL=top2|rescan|auto or bsfm_match_kernel() pin it.
+enum { MATCH_AUTO = 0, MATCH_TOP2 = 1, MATCH_RESCAN = 2 };
+constexpr double MATCH_RESCAN_MAX_ACCEPT = 0.05;      // accepted matches per query above which the top-2 kernel is the cheaper one
+int& match_mode()
+{
+    static int mode = [] {
+        const char* e = getenv("BSFM_MATCH_KERNEL");
+        if (e && !strcmp(e, "top2")) return (int)MATCH_TOP2;
+        if (e && !strcmp(e, "rescan")) return (int)MATCH_RESCAN;
+        return (int)MATCH_AUTO;
+    }();
+    return mode;
+}
+constexpr int match_qb(bool rescan) { return rescan ? 256 : 128; }     // queries per workgroup of the two kernels
+
+void launch_match(bool rescan, int blocks, hipStream_t st, const unsigned char* keys, const int* qstat, const PairDesc* pairs, int npairs,
+                  int db_off, int db_n, double ratio_sq, int* nn_out)
+{
+    // (the hand-pipelined loop exists for the minimum-only scan alone: with the top-2 registers on top the unrolled loop spills)
+    if (rescan) hipLaunchKernelGGL((k_match_l2<true, 2, 256>), dim3(blocks), dim3(256), 0, st, keys, qstat, pairs, npairs, db_off, db_n, ratio_sq, nn_out, 1);
+    else hipLaunchKernelGGL((k_match_l2<false, 0, 128>), dim3(blocks), dim3(256), 0, st, keys, qstat, pairs, npairs, db_off, db_n, ratio_sq, nn_out, 1);
 }
 
 struct DevKeys {
@@ -282,8 +415,10 @@ extern "C" int bsfm_match_keys_l2(int n1, const unsigned char* k1, int n2, const
     hipLaunchKernelGGL(k_key_stats, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, d.keys, (int)tot, d.qstat);
     const PairDesc pd = { 0, n1, 0, 0 };
     HIPM(hipMemcpy(d.pairs, &pd, sizeof(pd), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_match_l2, dim3((n1 + QB - 1) / QB), dim3(256), 0, 0, d.keys, d.qstat, d.pairs, 1, n1, n2,
-                       ratio * ratio, d.nn, 1);
+    {   // one pair on its own is a pair the caller expects to match: the data-independent kernel unless pinned otherwise
+        const bool rescan = match_mode() == MATCH_RESCAN;
+        launch_match(rescan, (n1 + match_qb(rescan) - 1) / match_qb(rescan), 0, d.keys, d.qstat, d.pairs, 1, n1, n2, ratio * ratio, d.nn);
+    }
     std::vector<int> nn(n1);
     HIPM(hipDeviceSynchronize());
     HIPM(hipMemcpy(nn.data(), d.nn, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost));
@@ -343,7 +478,7 @@ struct bsfm_match_set {
     size_t tot = 0;
     DevKeys d;
     // measurement of the last run: HIP-event time of the k_match_l2 launches, their distance count, pairs searched
-    double kernel_ms = 0.0; double distances = 0.0; long long pairs = 0; int launches = 0;
+    double kernel_ms = 0.0; double distances = 0.0; long long pairs = 0; int launches = 0, launches_rescan = 0;
 };
 
 extern "C" bsfm_match_set_t* bsfm_match_set_create(int num_images, const int* num_keys, const unsigned char* const* keys)
@@ -369,6 +504,15 @@ extern "C" bsfm_match_set_t* bsfm_match_set_create(int num_images, const int* nu
 }
 
 extern "C" void bsfm_match_set_destroy(bsfm_match_set_t* ms) { delete ms; }
+
+extern "C" int bsfm_match_kernel(int mode)
+{
+    const int old = match_mode();
+    if (mode >= MATCH_AUTO && mode <= MATCH_RESCAN) match_mode() = mode;
+    return old;
+}
+
+extern "C" int bsfm_match_set_rescan_launches(const bsfm_match_set_t* ms) { return ms ? ms->launches_rescan : BSFM_ERROR; }
 
 extern "C" int bsfm_match_set_stats(const bsfm_match_set_t* ms, double* kernel_ms, double* distances, long long* pairs, int* launches)
 {
@@ -397,7 +541,7 @@ static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_rad
     const std::vector<size_t>& off = ms->off;
     const size_t tot = ms->tot;
     DevKeys& d = ms->d;
-    ms->kernel_ms = 0.0; ms->distances = 0.0; ms->pairs = 0; ms->launches = 0;
+    ms->kernel_ms = 0.0; ms->distances = 0.0; ms->pairs = 0; ms->launches = 0; ms->launches_rescan = 0;
     if (tot == 0) { if (f) fclose(f); return 0; }
     // Two-slot pipeline on one stream: while the GPU scans database image k, the host turns the nearest-neighbour table of
     // image k-1 into text (own integer formatter: the text, not the search, was the larger part of the wall time).
@@ -406,6 +550,7 @@ static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_rad
         hipEvent_t done = nullptr, k0 = nullptr, k1 = nullptr; int image = -1; size_t npairs = 0; std::vector<int> js; bool busy = false;
         double dist = 0.0;
     } slots[2];
+    double accept_rate = 0.0;       // accepted matches per query in the last drained launch (auto mode's signal)
     hipStream_t st = nullptr;
     auto release = [&] {
         for (Slot& s : slots) {
@@ -443,11 +588,13 @@ static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_rad
         if (hipEventSynchronize(s.done) != hipSuccess) return false;
         { float kms = 0.f; if (hipEventElapsedTime(&kms, s.k0, s.k1) == hipSuccess && kms >= 0.f) { ms->kernel_ms += kms; ms->distances += s.dist; ms->pairs += (long long)s.npairs; ms->launches++; } }
         text.clear();
+        size_t seen_q = 0, seen_m = 0;
         for (size_t p = 0; p < s.npairs; ++p) {
             const int* row = s.h_nn + s.h_pairs[p].out_off;
             const int qn = s.h_pairs[p].q_n;
             int cnt = 0;
             for (int q = 0; q < qn; ++q) cnt += row[q] >= 0;
+            seen_q += (size_t)qn; seen_m += (size_t)cnt;
             if (cnt >= 16) {   // KeyMatchFull.cpp:131-142: "j i\n", count, "idx_j idx_i" lines
                 if (f) {
                     put_int(s.js[p], ' '); put_int(s.image, '\n'); put_int(cnt, '\n');
@@ -463,6 +610,7 @@ static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_rad
             }
         }
         if (f && !text.empty()) fwrite(text.data(), 1, text.size(), f);
+        if (seen_q) accept_rate = (double)seen_m / (double)seen_q;
         s.busy = false;
         return true;
     };
@@ -475,12 +623,14 @@ static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_rad
         ok = drain(s);
         if (!ok) break;
         s.js.clear(); s.npairs = 0; s.image = i;
+        const bool rescan = match_mode() == MATCH_RESCAN || (match_mode() == MATCH_AUTO && accept_rate <= MATCH_RESCAN_MAX_ACCEPT);
+        const int qb = match_qb(rescan);
         int blk = 0; size_t out = 0;
         for (int j = start; j < i; ++j) {
             if (num_keys[j] == 0) continue;
             s.h_pairs[s.npairs++] = { (int)off[j], num_keys[j], (int)out, blk };
             s.js.push_back(j);
-            blk += (num_keys[j] + QB - 1) / QB; out += (size_t)num_keys[j];
+            blk += (num_keys[j] + qb - 1) / qb; out += (size_t)num_keys[j];
         }
         if (s.npairs == 0) continue;
         if (num_keys[i] < 2) {
@@ -489,8 +639,8 @@ static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_rad
         }
         ok = ok && hipMemcpyAsync(s.d_pairs, s.h_pairs, s.npairs * sizeof(PairDesc), hipMemcpyHostToDevice, st) == hipSuccess;
         ok = ok && hipEventRecord(s.k0, st) == hipSuccess;
-        hipLaunchKernelGGL(k_match_l2, dim3(blk), dim3(256), 0, st, d.keys, d.qstat, s.d_pairs, (int)s.npairs,
-                           (int)off[i], num_keys[i], ratio * ratio, s.d_nn, 1);
+        launch_match(rescan, blk, st, d.keys, d.qstat, s.d_pairs, (int)s.npairs, (int)off[i], num_keys[i], ratio * ratio, s.d_nn);
+        ms->launches_rescan += rescan;
         ok = ok && hipEventRecord(s.k1, st) == hipSuccess;
         s.dist = (double)out * (double)num_keys[i];        // query keys of all pairs x database keys
         ok = ok && hipMemcpyAsync(s.h_nn, s.d_nn, out * sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess;

@@ -384,6 +384,13 @@ typedef struct bsfm_match_set bsfm_match_set_t;
 bsfm_match_set_t *bsfm_match_set_create(int num_images, const int *num_keys, const unsigned char *const *keys);
 int bsfm_match_set_run(bsfm_match_set_t *ms, double ratio, int window_radius, const char *out_path, int rank, int world_size);
 int bsfm_match_set_stats(const bsfm_match_set_t *ms, double *kernel_ms, double *distances, long long *pairs, int *launches);
+/* Scan kernel of the matcher: 0 = auto (default; per launch, from the share of accepted matches the last finished launch had),
+ * 1 = exact running top-2 (cost independent of the data), 2 = running minimum + exact rescan of the winning slot (faster when
+ * few queries pass the ratio test, slower when many do).  All three give the same matches (keys2a.cpp:347-372).  Returns the
+ * previous setting; an out-of-range value only queries.  Environment: BSFM_MATCH_KERNEL=auto|top2|rescan. */
+int bsfm_match_kernel(int mode);
+/* launches of the last bsfm_match_set_run* that used the rescan kernel (of bsfm_match_set_stats' `launches`) */
+int bsfm_match_set_rescan_launches(const bsfm_match_set_t *ms);
 /* The same search with the match table in memory instead of text: pair p = images pair_i[p] < pair_j[p] in the
  * order of the text file, its matches matches[2q] (key of pair_i) / matches[2q+1] (key of pair_j) for q in match_ptr[p] ..
  * match_ptr[p+1]-1 -- the layout bsfm_compute_tracks and BaseApp::LoadMatchTable (src/BundleIO.cpp:112-166) use.  Only pairs

@@ -22,10 +22,20 @@ def synth_keys(B, n, seed, dup=None):
 
 
 def gpu_match(B, k1, k2, ratio=0.6):
-    out = np.zeros((len(k1), 2), np.int32)
-    cnt = B.lib.bsfm_match_keys_l2(len(k1), k1.ctypes.data_as(U), len(k2), k2.ctypes.data_as(U), ratio,
-                                   out.ctypes.data_as(C.POINTER(C.c_int)), len(k1))
-    return cnt, out[:max(cnt, 0)]
+    """Runs BOTH scan kernels of the matcher (exact running top-2; running minimum + exact rescan of the winning slot, match_l2.hip)
+    and insists that they agree, so every parity test below covers both."""
+    res = []
+    for mode in (1, 2):
+        old = B.lib.bsfm_match_kernel(mode)
+        try:
+            out = np.zeros((len(k1), 2), np.int32)
+            cnt = B.lib.bsfm_match_keys_l2(len(k1), k1.ctypes.data_as(U), len(k2), k2.ctypes.data_as(U), ratio,
+                                           out.ctypes.data_as(C.POINTER(C.c_int)), len(k1))
+        finally:
+            B.lib.bsfm_match_kernel(old)
+        res.append((cnt, out[:max(cnt, 0)]))
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]), "top-2 and rescan kernels disagree"
+    return res[0]
 
 
 @pytest.mark.parametrize("name", ["a", "b", "tiny"])
@@ -295,6 +305,74 @@ def test_gpu_best_and_second_best_in_different_segments(gpu_bsfm):
     cnt, got = gpu_match(B, k1, k2)
     ref = O.port_match(k1, k2)
     assert cnt == len(ref) and np.array_equal(got, ref)
+
+
+@pytest.mark.gpu
+def test_gpu_runner_up_inside_the_winning_slot(gpu_bsfm):
+    """The rescan kernel keeps one running minimum per (query row, column class mod 64) slot and measures the winning slot's other
+    columns exactly only for rows that pass the ratio test against the bound: plant nearest and runner-up in the SAME slot (columns
+    64 t apart, same 8 192-key segment), at distances on both sides of the ratio test, also in the last partial tile."""
+    B = gpu_bsfm
+    n2 = 9000 + 37
+    k2 = synth_keys(B, n2, 81)
+    k1 = synth_keys(B, 300, 82)
+    rng = np.random.default_rng(7)
+    for q in range(300):
+        cls = int(rng.integers(0, 64))
+        seg = int(rng.integers(0, 2))
+        lo, hi = (0, 8192) if seg == 0 else (8192, n2)
+        cols = np.arange(lo + (cls - lo) % 64, hi, 64)
+        a, b = rng.choice(cols, 2, replace=False)
+        if q % 7 == 0:
+            a = cols[-1]                                   # the last (partial) tile of the segment
+            b = cols[0] if b == a else b
+        near = k1[q].astype(np.int32)
+        k2[a] = np.clip(near + rng.integers(-2, 3, 128), 0, 255).astype(np.uint8)
+        w = 3 + q % 6                                      # runner-up from "fails the test" to "passes it clearly"
+        k2[b] = np.clip(near + rng.integers(-w, w + 1, 128), 0, 255).astype(np.uint8)
+    cnt, got = gpu_match(B, k1, k2)
+    ref = O.port_match(k1, k2)
+    assert cnt == len(ref) and np.array_equal(got, ref)
+    assert 30 < cnt < 290                                  # both outcomes of the test occur
+
+
+@pytest.mark.gpu
+def test_auto_kernel_choice_follows_the_acceptance_rate(gpu_bsfm, tmp_path):
+    """auto starts with the rescan kernel and moves to the top-2 kernel once the launches it has seen accept more than 5 % of their
+    queries; whatever it picks, matches.init.txt is the same bytes."""
+    B = gpu_bsfm
+    images, nk = 14, 700
+    base = synth_keys(B, nk, 90)
+    rng = np.random.default_rng(3)
+    keys = []
+    for i in range(images):
+        k = synth_keys(B, nk, 91 + i)
+        if i >= 4:                                         # the first images share nothing, the later ones half of their keys
+            sel = rng.permutation(nk)[: nk // 2]
+            k[sel] = np.clip(base[sel].astype(np.int32) + rng.integers(-6, 7, (len(sel), 128)), 0, 255).astype(np.uint8)
+        keys.append(k)
+    arr = (U * images)(*[k.ctypes.data_as(U) for k in keys])
+    nks = np.full(images, nk, np.int32)
+    ms = B.lib.bsfm_match_set_create(images, nks.ctypes.data_as(C.POINTER(C.c_int)), arr)
+    assert ms
+    texts, mix = {}, {}
+    try:
+        for mode, name in ((1, "top2"), (2, "rescan"), (0, "auto")):
+            old = B.lib.bsfm_match_kernel(mode)
+            try:
+                path = str(tmp_path / f"m_{name}.txt").encode()
+                assert B.lib.bsfm_match_set_run(ms, 0.6, -1, path, 0, 1) >= 0
+            finally:
+                B.lib.bsfm_match_kernel(old)
+            texts[name] = open(path, "rb").read()
+            kms, dist, npairs, nl = C.c_double(), C.c_double(), C.c_longlong(), C.c_int()
+            B.lib.bsfm_match_set_stats(ms, C.byref(kms), C.byref(dist), C.byref(npairs), C.byref(nl))
+            mix[name] = (B.lib.bsfm_match_set_rescan_launches(ms), nl.value)
+    finally:
+        B.lib.bsfm_match_set_destroy(ms)
+    assert texts["top2"] == texts["rescan"] == texts["auto"] and len(texts["auto"]) > 1000
+    assert mix["top2"][0] == 0 and mix["rescan"][0] == mix["rescan"][1] == images - 1
+    assert 0 < mix["auto"][0] < mix["auto"][1], mix       # it began with rescan and switched
 
 
 @pytest.mark.gpu
