@@ -33,6 +33,7 @@ namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
+constexpr int QB = 128;            // queries per workgroup
 constexpr int BIG = 0x3fffffff;
 constexpr size_t KEY_SLACK = 64;        // keys of slack behind the last image: the scan prefetches whole tiles (k_match_l2)
 
@@ -84,29 +85,13 @@ __device__ __forceinline__ v4i flip(const uint4 v)          // the loaded words 
     return r;
 }
 
-#ifndef BSFM_MATCH_RESCAN_WGS
-#define BSFM_MATCH_RESCAN_WGS 3      // workgroups per CU of the minimum-only variant (its exchange buffer is half the size)
-#endif
 // nn_out[out_off + query] = index of the accepted nearest neighbour in the database image, or -1.
-// RESCAN = false: exact running top-2 per slot (3 VALU instructions per distance).  RESCAN = true (round 3): a slot keeps only its
-// running MINIMUM (2 VALU per distance).  The second smallest of the slot minima is then an upper bound of the true second-nearest
-// distance -- only the other columns of the WINNING slot can lie below it -- so a row whose nearest fails the ratio test against
-// that bound fails it for good, and the rows that pass get the winning slot's other columns (<= 127 keys) measured exactly
-// (v_dot4_i32_i8) by the whole workgroup before the final test.  Without the second-best registers a workgroup holds QBT = 256
-// query rows (16 row groups of A fragments per wave), which halves the database fragments fetched per MAC -- what the scan is
-// bound by: with the loads taken out (timing experiment) the 128-row kernels run at 3.23 (top-2) / 2.72 us (minimum only) per
-// 5000 x 5000 pair instead of 3.83 / 3.84.  DEPTH = 2: the hand-pipelined loop (see there).
-template <bool RESCAN, int DEPTH, int QBT>
-__global__ __launch_bounds__(256, RESCAN && QBT == 128 ? BSFM_MATCH_RESCAN_WGS : 2) void k_match_l2(const unsigned char* __restrict__ keys, const int* __restrict__ qstat,
+__global__ __launch_bounds__(256, 2) void k_match_l2(const unsigned char* __restrict__ keys, const int* __restrict__ qstat,
         const PairDesc* __restrict__ pairs, int npairs, int db_off, int db_n, double ratio_sq, int* __restrict__ nn_out, int one)
 {
-    constexpr int NG = QBT / 16;                      // row groups of 16 queries held by every wave
-    constexpr int TPR = 256 / QBT;                    // threads that merge one query row after a segment (2 at 128 queries, 1 at 256)
-    static_assert(QBT == 128 || (QBT == 256 && RESCAN), "256 queries per workgroup only fit without the second-best registers");
+    constexpr int NG = QB / 16;                       // row groups of 16 queries held by every wave
     constexpr int XS = 65;                            // row stride (uint2) of the exchange buffer: 64 column classes + 1 pad
-    // per segment: every (query row, column class) slot's packed (best, second); the minimum-only variant exchanges the best alone
-    __shared__ unsigned xch_raw[QBT * XS * (RESCAN ? 1 : 2)];
-    uint2* xch = reinterpret_cast<uint2*>(xch_raw);
+    __shared__ uint2 xch[QB * XS];                    // per segment: every (query row, column class) slot's packed (best, second)
     // Locate the pair this block belongs to: a binary search on the pairs' first-block numbers that every thread runs on
     // uniform addresses (scalar loads, no barrier; one thread searching + a barrier kept 255 threads idle for 9 round trips).
     int s_pair = 0;
@@ -116,31 +101,23 @@ __global__ __launch_bounds__(256, RESCAN && QBT == 128 ? BSFM_MATCH_RESCAN_WGS :
         s_pair = lo;
     }
     const PairDesc pd = pairs[s_pair];
-    const int qbase = (blockIdx.x - pd.blk0) * QBT;
+    const int qbase = (blockIdx.x - pd.blk0) * QB;
     // running (nearest, second nearest, column) of query row threadIdx.x / 2, kept by the two threads that merge that row
-    const int my_row = (int)threadIdx.x / TPR;
-    const int row_qa = qstat[pd.q_off + min(qbase + my_row, pd.q_n - 1)] - 2 * 128 * 128 * 128;
+    const int row_qa = qstat[pd.q_off + min(qbase + (int)(threadIdx.x >> 1), pd.q_n - 1)] - 2 * 128 * 128 * 128;
     int row_d0 = BIG, row_d1 = BIG, row_idx = -1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned char* qkeys = keys + (size_t)pd.q_off * 128;
     const unsigned char* dkeys = keys + (size_t)db_off * 128;
 
-    // A fragments: NG row groups x 2 k-steps stay in registers for the whole scan.  QBT queries per workgroup: every
-    // database fragment a wave fetches from L2 is used for QBT / 16 MFMA pairs -- the scan is bound by that L2 -> CU traffic
-    // (QBT MAC per byte): 8.0 us per 5000 x 5000 pair with 64 queries per workgroup, 3.6-3.8 with 128, 3.3 with 256.
+    // A fragments: NG row groups x 2 k-steps stay in registers for the whole scan.  QB = 128 queries per workgroup: every
+    // database fragment a wave fetches from L2 is used for 8 MFMA pairs -- the scan is bound by that L2 -> CU traffic
+    // (128 MAC per byte at QB = 128), it was 8.0 us per 5000 x 5000 pair with 64 queries per workgroup.
     v4i afrag[NG][2];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const int row = min(qbase + 16 * g + (lane & 15), pd.q_n - 1);
         afrag[g][0] = load_frag(qkeys, row, lane, 0);
         afrag[g][1] = load_frag(qkeys, row, lane, 1);
-    }
-    if (DEPTH != 0) {
-        // the hand-counted waits of the scan loop below assume that nothing of the compiler's own is in flight: make it wait for
-        // the A fragments HERE (its bookkeeping does not see the loop's inline-asm loads, and a late compiler wait for a fragment
-        // inside the loop would become a wait for the prefetches as well)
-#pragma unroll
-        for (int g = 0; g < NG; ++g) asm volatile("" : "+v"(afrag[g][0]), "+v"(afrag[g][1]));
     }
     // Running top-2 per slot on PACKED keys.  Ranking needs only e = qb - 2 dot (the query term qa is the same for every
     // candidate of a row), so the per-distance work is ONE 24-bit multiply-add that builds the key (below), one v_min_u32
@@ -174,8 +151,19 @@ __global__ __launch_bounds__(256, RESCAN && QBT == 128 ? BSFM_MATCH_RESCAN_WGS :
         // (running pointers, no clamp: the key and statistic arrays carry one tile of slack behind the last image, and what
         //  is loaded past the database image only ever meets DEADQ)
         const int colf = seg + 16 * wave + (lane & 15);
-        // multiply and rank one tile whose fragments are (bf0, bf1) and whose statistic term is qbb
-        auto rank_tile = [&](const v4i bf0, const v4i bf1, const int qbb, const int tile) __attribute__((always_inline)) {
+        const unsigned char* kp = dkeys + (size_t)colf * 128 + 16 * (lane >> 4);
+        const int* qp = qstat + db_off + colf;
+        uint4 rf0 = *reinterpret_cast<const uint4*>(kp), rf1 = *reinterpret_cast<const uint4*>(kp + 64);
+        int rqb = *qp;
+        int coln = colf;
+        for (int tile = seg; tile < seg_end; tile += 64) {
+            const v4i bf0 = flip(rf0), bf1 = flip(rf1);
+            const int qbb = coln < db_n ? rqb + EBIAS : DEADQ;
+            if (tile + 64 < seg_end) {
+                kp += 64 * 128; qp += 64; coln += 64;
+                rf0 = *reinterpret_cast<const uint4*>(kp); rf1 = *reinterpret_cast<const uint4*>(kp + 64);
+                rqb = *qp;
+            }
             // key = ((qb + BIAS - 2 dot) << TB) | tile = K - (dot << (TB + 1)) with K = ((qb + BIAS) << TB) | tile: the low TB
             // bits are untouched by the subtraction, so ONE 24-bit multiply-add per distance builds the packed key
             const int K = (int)(((unsigned)qbb << TB) | (unsigned)((tile - seg) >> 6));
@@ -188,11 +176,9 @@ __global__ __launch_bounds__(256, RESCAN && QBT == 128 ? BSFM_MATCH_RESCAN_WGS :
 #define BSFM_RANK(R)                                                                                                      \
                 {   /* (no inline asm on the accumulator itself: the compiler must see the MFMA -> VALU dependency) */     \
                     const unsigned key = (unsigned)(__mul24(acc[R], mscale) + K);        /* v_mad_i32_i24 */              \
-                    if (!RESCAN) {                                                                                        \
-                        unsigned m;                                                                                       \
-                        asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(b0[g][R]), "v"(b1[g][R]), "v"(key));              \
-                        b1[g][R] = m;                                                                                     \
-                    }                                                                                                     \
+                    unsigned m;                                                                                           \
+                    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(b0[g][R]), "v"(b1[g][R]), "v"(key));                  \
+                    b1[g][R] = m;                                                                                         \
                     b0[g][R] = min(b0[g][R], key);                                                                        \
                 }
 #pragma unroll
@@ -209,57 +195,6 @@ __global__ __launch_bounds__(256, RESCAN && QBT == 128 ? BSFM_MATCH_RESCAN_WGS :
                 acc = nacc;
             }
 #undef BSFM_RANK
-        };
-        if (DEPTH == 0) {
-            const unsigned char* kp = dkeys + (size_t)colf * 128 + 16 * (lane >> 4);
-            const int* qp = qstat + db_off + colf;
-            uint4 rf0 = *reinterpret_cast<const uint4*>(kp), rf1 = *reinterpret_cast<const uint4*>(kp + 64);
-            int rqb = *qp;
-            int coln = colf;
-            for (int tile = seg; tile < seg_end; tile += 64) {
-                const v4i bf0 = flip(rf0), bf1 = flip(rf1);
-                const int qbb = coln < db_n ? rqb + EBIAS : DEADQ;
-                if (tile + 64 < seg_end) {
-                    kp += 64 * 128; qp += 64; coln += 64;
-                    rf0 = *reinterpret_cast<const uint4*>(kp); rf1 = *reinterpret_cast<const uint4*>(kp + 64);
-                    rqb = *qp;
-                }
-                rank_tile(bf0, bf1, qbb, tile);
-            }
-        } else {
-            // TWO tiles in flight, loads and waits written by hand (the compiler hoists, clusters or copies what it manages itself:
-            // with its own loads every attempt at a distance of two tiles ended in a vmcnt(0) or in a copy of a register that was
-            // still being loaded).  Three register sets rotate -- tile t is multiplied out of one while the loads of tile t + 2 go
-            // into the set tile t - 1 has finished with -- and the loop is unrolled three times so that no set ever changes registers.
-            // Every tile issues exactly three loads (the last ones reload the segment's last tile), so "all but the newest three"
-            // is the wait for the set about to be used; the counter is drained before the registers are reused.
-            const unsigned koff = (unsigned)((16 * wave + (lane & 15)) * 128 + 16 * (lane >> 4));
-            const unsigned qoff = (unsigned)(4 * (16 * wave + (lane & 15)));
-            const int seg_last = seg + ((seg_end - seg - 1) & ~63);          // first column of the segment's last tile
-            v4i x0, x1, y0, y1, z0, z1; int xq, yq, zq;
-#define BSFM_ISSUE(S0, S1, SQ, T)                                                                                          \
-            {   const int tn = min((T), seg_last);                                                                        \
-                const unsigned char* sp = dkeys + (size_t)tn * 128;                                                       \
-                const int* sq = qstat + db_off + tn;                                                                      \
-                asm volatile("global_load_dwordx4 %0, %3, %4\n\tglobal_load_dwordx4 %1, %3, %4 offset:64\n\t"            \
-                             "global_load_dword %2, %5, %6"                                                               \
-                             : "=&v"(S0), "=&v"(S1), "=&v"(SQ) : "v"(koff), "s"(sp), "v"(qoff), "s"(sq) : "memory"); }
-#define BSFM_USE(S0, S1, SQ, L0, L1, LQ, T)                                                                                \
-            {   asm volatile("s_waitcnt vmcnt(3)" : "+v"(S0), "+v"(S1), "+v"(SQ));                                        \
-                const v4i bf0 = S0, bf1 = S1;                                                                             \
-                const int qbb = colf + ((T) - seg) < db_n ? SQ + EBIAS : DEADQ;                                           \
-                BSFM_ISSUE(L0, L1, LQ, (T) + 128)                                                                         \
-                rank_tile(bf0, bf1, qbb, (T)); }
-            BSFM_ISSUE(x0, x1, xq, seg)
-            BSFM_ISSUE(y0, y1, yq, seg + 64)
-            for (int tile = seg;;) {
-                BSFM_USE(x0, x1, xq, z0, z1, zq, tile) tile += 64; if (tile >= seg_end) break;
-                BSFM_USE(y0, y1, yq, x0, x1, xq, tile) tile += 64; if (tile >= seg_end) break;
-                BSFM_USE(z0, z1, zq, y0, y1, yq, tile) tile += 64; if (tile >= seg_end) break;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(xq), "+v"(y0), "+v"(y1), "+v"(yq), "+v"(z0), "+v"(z1), "+v"(zq));
-#undef BSFM_USE
-#undef BSFM_ISSUE
         }
         // Segment merge through LDS: slot (row, column class 16 wave + lane % 16) goes to xch[row][class]; then two threads per
         // query row scan 32 classes each (6 VALU per class), combine with one DPP swap, and the even thread folds the segment's
@@ -270,23 +205,20 @@ __global__ __launch_bounds__(256, RESCAN && QBT == 128 ? BSFM_MATCH_RESCAN_WGS :
         for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (RESCAN) xch_raw[(16 * g + 4 * (lane >> 4) + r) * XS + 16 * wave + (lane & 15)] = b0[g][r];
-                else xch[(16 * g + 4 * (lane >> 4) + r) * XS + 16 * wave + (lane & 15)] = make_uint2(b0[g][r], b1[g][r]);
+                xch[(16 * g + 4 * (lane >> 4) + r) * XS + 16 * wave + (lane & 15)] = make_uint2(b0[g][r], b1[g][r]);
         __syncthreads();
         {
-            constexpr int CPT = 64 / TPR;              // column classes per merging thread
-            const int half = TPR == 2 ? (threadIdx.x & 1) : 0;
-            const uint2* src = xch + my_row * XS + CPT * half;
-            const unsigned* src1 = xch_raw + my_row * XS + CPT * half;
+            const int half = threadIdx.x & 1;
+            const uint2* src = xch + (threadIdx.x >> 1) * XS + 32 * half;
             unsigned k0 = 0xffffffffu, k1 = 0xffffffffu; int cls = 0;
 #pragma unroll 8
-            for (int e = 0; e < CPT; ++e) {
-                const uint2 o = RESCAN ? make_uint2(src1[e], 0xffffffffu) : src[e];
+            for (int e = 0; e < 32; ++e) {
+                const uint2 o = src[e];
                 k1 = min(max(k0, o.x), min(k1, o.y));
-                cls = o.x < k0 ? CPT * half + e : cls;
+                cls = o.x < k0 ? 32 * half + e : cls;
                 k0 = min(k0, o.x);
             }
-            if (TPR == 2) {   // the other half of the row sits in the neighbouring lane
+            {   // the other half of the row sits in the neighbouring lane
                 const unsigned o0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k0, 0xB1, 0xf, 0xf, false);
                 const unsigned o1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)k1, 0xB1, 0xf, 0xf, false);
                 const int oc = __builtin_amdgcn_update_dpp(0, cls, 0xB1, 0xf, 0xf, false);
@@ -302,44 +234,8 @@ __global__ __launch_bounds__(256, RESCAN && QBT == 128 ? BSFM_MATCH_RESCAN_WGS :
             else row_d1 = min(row_d1, c0);
         }
     }
-    if (RESCAN) {
-        // rows whose nearest passes the test against the BOUND: measure the other columns of the winning slot exactly
-        __shared__ int s_cnt, s_row[QBT], s_idx[QBT], s_d1[QBT];
-        if (threadIdx.x == 0) s_cnt = 0;
-        __syncthreads();
-        bool need = false;
-        int slot = 0;
-        if ((threadIdx.x & (TPR - 1)) == 0 && qbase + my_row < pd.q_n && row_idx >= 0) {
-#pragma clang fp contract(off)
-            need = ((double)row_d0) < ratio_sq * ((double)row_d1);
-        }
-        if (need) { slot = atomicAdd(&s_cnt, 1); s_row[slot] = my_row; s_idx[slot] = row_idx; s_d1[slot] = row_d1; }
-        __syncthreads();
-        const int items = s_cnt * (SEG / 64);
-        for (int it = threadIdx.x; it < items; it += 256) {
-            const int p = it / (SEG / 64), t = it % (SEG / 64);
-            const int ridx = s_idx[p];
-            const int col = (ridx / SEG) * SEG + 64 * t + (ridx & 63);
-            if (col < db_n && col != ridx) {
-                const int q = qbase + s_row[p];
-                const uint4* a = reinterpret_cast<const uint4*>(qkeys + (size_t)q * 128);
-                const uint4* b = reinterpret_cast<const uint4*>(dkeys + (size_t)col * 128);
-                int dot = 0;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) {
-                    const uint4 x = a[w], y = b[w];
-                    dot = __builtin_amdgcn_sdot4((int)x.x, (int)y.x, dot, false); dot = __builtin_amdgcn_sdot4((int)x.y, (int)y.y, dot, false);
-                    dot = __builtin_amdgcn_sdot4((int)x.z, (int)y.z, dot, false); dot = __builtin_amdgcn_sdot4((int)x.w, (int)y.w, dot, false);
-                }
-                const int d = qstat[pd.q_off + q] - 2 * 128 * 128 * 128 + qstat[db_off + col] - 2 * dot;
-                atomicMin(&s_d1[p], d);
-            }
-        }
-        __syncthreads();
-        if (need) row_d1 = s_d1[slot];
-    }
-    if ((threadIdx.x & (TPR - 1)) == 0) {
-        const int q = qbase + my_row;
+    if ((threadIdx.x & 1) == 0) {
+        const int q = qbase + (threadIdx.x >> 1);
         if (q < pd.q_n) {
             bool ok;
             {
@@ -351,11 +247,245 @@ __global__ __launch_bounds__(256, RESCAN && QBT == 128 ? BSFM_MATCH_RESCAN_WGS :
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_match_bound (round 3): the same exact search at ONE VALU instruction per distance and 256 query rows per workgroup.
+//
+// d = qa + qb - 2 dot.  With c = ceil(qb / 2) and p = qb & 1:  -(qb - 2 dot) = 2 (dot - c) + p, so t = dot - c is the distance up
+// to the parity bit: d = qa - 2 t - p.  -c rides in as the C operand of the first matrix instruction (one register quad per tile),
+// the accumulator IS t, and a slot (query row, column class mod 64, 8 192-key segment) keeps max t with one v_max_i32: no key
+// packing, no tile number, no second best -- which also frees the registers for 16 row groups of A fragments per wave (half the
+// database fragments per MAC, what the scan is bound by).  What the scan leaves per row is therefore a BOUND, made exact afterwards:
+//   * T0 = the largest slot maximum, T1 = the second largest (equal to T0 when two slots tie).  The nearest distance lies in
+//     [qa - 2 T0 - 1, qa - 2 T0] and the second nearest is at most qa - 2 T1.  A row whose lower bound fails the ratio test against
+//     that upper bound fails it for good (most rows): -1.
+//   * The others get the <= 128 columns of the winning slot measured exactly (v_dot4_i32_i8): nearest E0, its column, second E1 in
+//     the slot.  With T1 < T0 every other slot is at least qa - 2 T1 - 1 > E0, so E0 is THE nearest, and the second nearest is
+//     min(E1, best of the second slot), the latter known to within one unit: if the ratio test gives the same answer at both ends
+//     of that unit it is decided;
+//   * the rest (T1 == T0, or a test that hinges on the parity bit of the second slot: ~1e-5 of the rows) are measured against the
+//     whole database image exactly, one row at a time by the whole workgroup.
+// The fragment loads are written by hand two tiles ahead (three rotating register sets, loop unrolled three times, hand-counted
+// vmcnt): the compiler hoists, clusters or copies loads it manages itself, and every such attempt ended in a vmcnt(0) or in a copy
+// of a register that was still being loaded.
+constexpr int QBB = 256;                 // query rows per workgroup
+constexpr int BSEG = 8192;               // database keys per segment = 128 tiles: bounds a slot (and a rescan) at 128 columns
+constexpr int DEADC = -(1 << 29);        // C operand of padding columns: below every real t (|dot| <= 2^21, |c| <= 2^23)
+constexpr int TMIN = -(1 << 30);
+
+__global__ __launch_bounds__(256, 2) void k_match_bound(const unsigned char* __restrict__ keys, const int* __restrict__ qstat,
+        const PairDesc* __restrict__ pairs, int npairs, int db_off, int db_n, double ratio_sq, int* __restrict__ nn_out)
+{
+    constexpr int NG = QBB / 16;                      // row groups of 16 queries held by every wave
+    constexpr int XS = 65;                            // row stride of the exchange buffer: 64 column classes + 1 pad
+    constexpr int ITEM_CAP = 128;                     // rescans per pass: 128 x 128 distances fit the exchange buffer
+    __shared__ int xch[QBB * XS];                     // per segment: every (query row, column class) slot's max t; later the rescan's distances
+    __shared__ int s_cnt, s_full, s_row[QBB], s_slot[QBB], s_res[QBB][3], s_frow[QBB];
+    __shared__ unsigned long long s_best;
+    __shared__ int s_second;
+    int s_pair = 0;
+    {   // block -> pair: binary search on uniform addresses (scalar loads)
+        int lo = 0, hi = npairs - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pairs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+        s_pair = lo;
+    }
+    const PairDesc pd = pairs[s_pair];
+    const int qbase = (blockIdx.x - pd.blk0) * QBB;
+    const int my_row = (int)threadIdx.x;              // the query row whose slots this thread merges after every segment
+    const bool my_valid = qbase + my_row < pd.q_n;
+    const int row_qa = qstat[pd.q_off + min(qbase + my_row, pd.q_n - 1)] - 2 * 128 * 128 * 128;
+    int R0 = TMIN, R1 = TMIN, Rslot = 0;              // largest / second largest slot maximum of the row, first column of the winning slot
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned char* qkeys = keys + (size_t)pd.q_off * 128;
+    const unsigned char* dkeys = keys + (size_t)db_off * 128;
+
+    v4i afrag[NG][2];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int row = min(qbase + 16 * g + (lane & 15), pd.q_n - 1);
+        afrag[g][0] = load_frag(qkeys, row, lane, 0);
+        afrag[g][1] = load_frag(qkeys, row, lane, 1);
+    }
+    // the hand-counted waits below assume that nothing of the compiler's own is in flight: make it wait for the A fragments HERE
+    // (its bookkeeping does not see the inline-asm loads, and a late compiler wait inside the loop would wait for the prefetches too)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) asm volatile("" : "+v"(afrag[g][0]), "+v"(afrag[g][1]));
+
+    const unsigned koff = (unsigned)((16 * wave + (lane & 15)) * 128 + 16 * (lane >> 4));
+    const unsigned qoff = (unsigned)(4 * (16 * wave + (lane & 15)));
+    for (int seg = 0; seg < db_n; seg += BSEG) {
+        int b0[NG][4];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b0[g][r] = TMIN;
+        const int seg_end = min(db_n, seg + BSEG);
+        const int seg_last = seg + ((seg_end - seg - 1) & ~63);          // first column of the segment's last tile
+        const int colf = seg + 16 * wave + (lane & 15);
+        // one tile: groups g + 1 and g + 2 are in the matrix pipe while group g is ranked (three accumulators; order pinned with
+        // sched_barrier).  With two, the two VALU instructions between a group's second matrix instruction and its ranking did not
+        // cover the instruction's latency any more (s_nop 4-5 after every one of them).
+        auto rank_tile = [&](const v4i bf0, const v4i bf1, const int cq) __attribute__((always_inline)) {
+            const v4i cvec = { cq, cq, cq, cq };
+            v4i acc[3];
+            acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[0][0], bf0, cvec, 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[0][1], bf1, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[1][0], bf0, cvec, 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[1][1], bf1, acc[1], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int cur = g % 3, nxt = (g + 2) % 3;
+                if (g + 2 < NG) acc[nxt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[g + 2][0], bf0, cvec, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                b0[g][0] = max(b0[g][0], acc[cur][0]); b0[g][1] = max(b0[g][1], acc[cur][1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 2 < NG) acc[nxt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[g + 2][1], bf1, acc[nxt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                b0[g][2] = max(b0[g][2], acc[cur][2]); b0[g][3] = max(b0[g][3], acc[cur][3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        v4i x0, x1, y0, y1, z0, z1; int xq, yq, zq;
+        // every tile issues exactly three loads (the last ones reload the segment's last tile), so "all but the newest three" is the
+        // wait for the set about to be used; the counter is drained before the registers are reused
+#define BSFM_ISSUE(S0, S1, SQ, T)                                                                                          \
+        {   const int tn = min((T), seg_last);                                                                            \
+            const unsigned char* sp = dkeys + (size_t)tn * 128;                                                           \
+            const int* sq = qstat + db_off + tn;                                                                          \
+            asm volatile("global_load_dwordx4 %0, %3, %4\n\tglobal_load_dwordx4 %1, %3, %4 offset:64\n\t"                \
+                         "global_load_dword %2, %5, %6"                                                                   \
+                         : "=&v"(S0), "=&v"(S1), "=&v"(SQ) : "v"(koff), "s"(sp), "v"(qoff), "s"(sq) : "memory"); }
+#define BSFM_USE(S0, S1, SQ, L0, L1, LQ, T)                                                                                \
+        {   asm volatile("s_waitcnt vmcnt(3)" : "+v"(S0), "+v"(S1), "+v"(SQ));                                            \
+            const v4i bf0 = S0, bf1 = S1;                                                                                 \
+            const int cq = colf + ((T) - seg) < db_n ? -((SQ + 1) >> 1) : DEADC;                                          \
+            BSFM_ISSUE(L0, L1, LQ, (T) + 128)                                                                             \
+            rank_tile(bf0, bf1, cq); }
+        BSFM_ISSUE(x0, x1, xq, seg)
+        BSFM_ISSUE(y0, y1, yq, seg + 64)
+        for (int tile = seg;;) {
+            BSFM_USE(x0, x1, xq, z0, z1, zq, tile) tile += 64; if (tile >= seg_end) break;
+            BSFM_USE(y0, y1, yq, x0, x1, xq, tile) tile += 64; if (tile >= seg_end) break;
+            BSFM_USE(z0, z1, zq, y0, y1, yq, tile) tile += 64; if (tile >= seg_end) break;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x0), "+v"(x1), "+v"(xq), "+v"(y0), "+v"(y1), "+v"(yq), "+v"(z0), "+v"(z1), "+v"(zq));
+#undef BSFM_USE
+#undef BSFM_ISSUE
+        // segment merge through LDS: slot (row, class 16 wave + lane % 16) -> xch[row][class]; one thread per query row then scans
+        // the 64 classes and folds (largest, second largest, class of the largest) into the row's running state
+        __syncthreads();                               // the previous segment's readers are done
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                xch[(16 * g + 4 * (lane >> 4) + r) * XS + 16 * wave + (lane & 15)] = b0[g][r];
+        __syncthreads();
+        {
+            const int* src = xch + my_row * XS;
+            int k0 = TMIN, k1 = TMIN, cls = 0;
+#pragma unroll 8
+            for (int e = 0; e < 64; ++e) {
+                const int o = src[e];
+                k1 = max(min(k0, o), k1);
+                cls = o > k0 ? e : cls;
+                k0 = max(k0, o);
+            }
+            if (k0 > R0) { R1 = max(R0, k1); R0 = k0; Rslot = seg + cls; }
+            else R1 = max(R1, k0);
+        }
+    }
+
+    // ---- from the bounds to the exact answer
+    auto exact_dist = [&](const int q, const int col) {
+        const uint4* a = reinterpret_cast<const uint4*>(qkeys + (size_t)q * 128);
+        const uint4* b = reinterpret_cast<const uint4*>(dkeys + (size_t)col * 128);
+        int dot = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const uint4 x = a[w], y = b[w];
+            dot = __builtin_amdgcn_sdot4((int)x.x, (int)y.x, dot, false); dot = __builtin_amdgcn_sdot4((int)x.y, (int)y.y, dot, false);
+            dot = __builtin_amdgcn_sdot4((int)x.z, (int)y.z, dot, false); dot = __builtin_amdgcn_sdot4((int)x.w, (int)y.w, dot, false);
+        }
+        return qstat[pd.q_off + q] - 2 * 128 * 128 * 128 + qstat[db_off + col] - 2 * dot;
+    };
+    auto passes = [&](const int d0, const int d1) {
+        bool ok;
+        {
+#pragma clang fp contract(off)
+            ok = ((double)d0) < ratio_sq * ((double)d1);          // src/keys2a.cpp:362
+        }
+        return ok;
+    };
+    if (threadIdx.x == 0) { s_cnt = 0; s_full = 0; }
+    __syncthreads();                                   // (also: the last segment's readers of xch are done)
+    int result = -1;
+    // 1 = may pass: the nearest's lower bound against the second nearest's upper bound (a true pass always lands here)
+    const bool maybe = my_valid && passes(row_qa - 2 * R0 - 1, row_qa - 2 * R1);
+    int slot = -1;
+    if (maybe) { slot = atomicAdd(&s_cnt, 1); s_row[slot] = my_row; s_slot[slot] = Rslot; }
+    __syncthreads();
+    const int cnt = s_cnt;
+    bool need_full = false;
+    for (int p0 = 0; p0 < cnt; p0 += ITEM_CAP) {
+        const int np = min(cnt - p0, ITEM_CAP);
+        // every (item, column of its slot) pair: the exact distance into xch[item][column index]
+        for (int it = threadIdx.x; it < np * 128; it += 256) {
+            const int p = p0 + (it >> 7), t = it & 127;
+            const int s0 = s_slot[p];
+            const int col = s0 + 64 * t;
+            const int send = min(db_n, (s0 / BSEG) * BSEG + BSEG);
+            xch[it] = col < send ? exact_dist(qbase + s_row[p], col) : BIG;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < np) {                   // one thread per item: nearest, its column index, second nearest of the slot
+            const int* dv = xch + 128 * threadIdx.x;
+            int e0 = BIG, e1 = BIG, c0 = 0;
+            for (int t = 0; t < 128; ++t) {
+                const int d = dv[t];
+                e1 = min(max(e0, d), e1);
+                c0 = d < e0 ? t : c0;
+                e0 = min(e0, d);
+            }
+            s_res[p0 + threadIdx.x][0] = e0; s_res[p0 + threadIdx.x][1] = c0; s_res[p0 + threadIdx.x][2] = e1;
+        }
+        __syncthreads();
+    }
+    if (maybe) {
+        const int e0 = s_res[slot][0], e1 = s_res[slot][2];
+        const int others_hi = row_qa - 2 * R1;         // the best of every other slot lies in [others_hi - 1, others_hi]
+        const bool hi = passes(e0, min(e1, others_hi)), lo = passes(e0, min(e1, others_hi - 1));
+        if (R1 < R0 && hi == lo) result = hi ? Rslot + 64 * s_res[slot][1] : -1;
+        else need_full = true;                         // two slots tie for the nearest, or the test hinges on a parity bit
+    }
+    if (need_full) s_frow[atomicAdd(&s_full, 1)] = my_row;
+    __syncthreads();
+    const int nfull = s_full;
+    for (int f = 0; f < nfull; ++f) {                  // rare: the whole database image against one row, exactly
+        const int row = s_frow[f];
+        if (threadIdx.x == 0) { s_best = ~0ull; s_second = BIG; }
+        __syncthreads();
+        int m0 = BIG, m1 = BIG, c0 = 0;
+        for (int col = threadIdx.x; col < db_n; col += 256) {
+            const int d = exact_dist(qbase + row, col);
+            m1 = min(max(m0, d), m1);
+            c0 = d < m0 ? col : c0;
+            m0 = min(m0, d);
+        }
+        atomicMin(&s_best, ((unsigned long long)(unsigned)m0 << 32) | (unsigned)c0);
+        __syncthreads();
+        const int bcol = (int)(unsigned)(s_best & 0xffffffffull);
+        atomicMin(&s_second, m0 < BIG && c0 == bcol ? m1 : m0);
+        __syncthreads();
+        if (my_row == row) result = passes((int)(s_best >> 32), s_second) ? bcol : -1;
+        __syncthreads();
+    }
+    if (my_valid) nn_out[pd.out_off + qbase + my_row] = result;
+}
+
 // Which scan kernel a launch uses.  Both are exact and give the same table; they differ in what they cost:
-//   top-2   (k_match_l2<false, 0, 128>): 3 VALU per distance, 128 queries per workgroup, indifferent to the data;
-//   rescan  (k_match_l2<true, 2, 256>):  2 VALU per distance, 256 queries per workgroup (half the L2 -> CU fragment traffic per MAC),
-//           + 128 exact distances for every query row that passes the ratio test against the bound: 14-17 % faster when few rows
-//           pass (unordered photo collections: 3.29 vs 3.82 us per 5000 x 5000 pair), 28 % slower when a quarter of them do.
+//   top-2   (k_match_l2):    3 VALU per distance, 128 queries per workgroup, indifferent to the data;
+//   rescan  (k_match_bound): 1 VALU per distance, 256 queries per workgroup (half the L2 -> CU fragment traffic per MAC), + 128 exact
+//           distances for every query row that may pass the ratio test: faster while few rows pass (unordered photo collections),
+//           slower when a quarter of them do (video-like sets), see DESIGN section 10 / profiles/r03_match_kernels_ab.txt.
 // auto (the default) starts with rescan and switches per launch on the share of accepted matches in the last launch whose
 // results the host has seen.  BSFM_MATCH_KERNEL=top2|rescan|auto or bsfm_match_kernel() pin it.
 enum { MATCH_AUTO = 0, MATCH_TOP2 = 1, MATCH_RESCAN = 2 };
@@ -370,14 +500,13 @@ int& match_mode()
     }();
     return mode;
 }
-constexpr int match_qb(bool rescan) { return rescan ? 256 : 128; }     // queries per workgroup of the two kernels
+constexpr int match_qb(bool rescan) { return rescan ? QBB : QB; }       // queries per workgroup of the two kernels
 
 void launch_match(bool rescan, int blocks, hipStream_t st, const unsigned char* keys, const int* qstat, const PairDesc* pairs, int npairs,
                   int db_off, int db_n, double ratio_sq, int* nn_out)
 {
-    // (the hand-pipelined loop exists for the minimum-only scan alone: with the top-2 registers on top the unrolled loop spills)
-    if (rescan) hipLaunchKernelGGL((k_match_l2<true, 2, 256>), dim3(blocks), dim3(256), 0, st, keys, qstat, pairs, npairs, db_off, db_n, ratio_sq, nn_out, 1);
-    else hipLaunchKernelGGL((k_match_l2<false, 0, 128>), dim3(blocks), dim3(256), 0, st, keys, qstat, pairs, npairs, db_off, db_n, ratio_sq, nn_out, 1);
+    if (rescan) hipLaunchKernelGGL(k_match_bound, dim3(blocks), dim3(256), 0, st, keys, qstat, pairs, npairs, db_off, db_n, ratio_sq, nn_out);
+    else hipLaunchKernelGGL(k_match_l2, dim3(blocks), dim3(256), 0, st, keys, qstat, pairs, npairs, db_off, db_n, ratio_sq, nn_out, 1);
 }
 
 struct DevKeys {

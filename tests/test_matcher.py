@@ -22,8 +22,8 @@ def synth_keys(B, n, seed, dup=None):
 
 
 def gpu_match(B, k1, k2, ratio=0.6):
-    """Runs BOTH scan kernels of the matcher (exact running top-2; running minimum + exact rescan of the winning slot, match_l2.hip)
-    and insists that they agree, so every parity test below covers both."""
+    """Runs BOTH scan kernels of the matcher (k_match_l2: exact running top-2; k_match_bound: one running maximum per slot, bounds,
+    exact rescan of the winning slot -- match_l2.hip) and insists that they agree, so every parity test below covers both."""
     res = []
     for mode in (1, 2):
         old = B.lib.bsfm_match_kernel(mode)
@@ -334,6 +334,58 @@ def test_gpu_runner_up_inside_the_winning_slot(gpu_bsfm):
     ref = O.port_match(k1, k2)
     assert cnt == len(ref) and np.array_equal(got, ref)
     assert 30 < cnt < 290                                  # both outcomes of the test occur
+
+
+def _with_sq_dist(base, rng, sq):
+    """a copy of `base` (values kept inside 40..200) whose squared distance to it is exactly `sq` (sum of 25s, then 9 / 4 / 1 steps)"""
+    k = base.astype(np.int32).copy()
+    pos = list(rng.permutation(128))
+    for step in (5, 3, 2, 1):
+        while sq >= step * step and pos:
+            i = pos.pop()
+            k[i] += step if k[i] < 128 else -step
+            sq -= step * step
+    assert sq == 0
+    return k.astype(np.uint8)
+
+
+@pytest.mark.gpu
+def test_gpu_ratio_test_on_the_parity_bit_and_ties(gpu_bsfm):
+    """k_match_bound knows every slot's best distance only to within one unit (the parity bit of the column term): plant nearest /
+    second-nearest pairs in DIFFERENT slots whose ratio test is decided by that unit (25 d0 vs 9 d1 one apart on either side, for
+    d1 of both parities), exact duplicates (two slots tie at distance 0) and equal nearest distances in two slots -- the rows the
+    kernel has to measure against the whole image.  Reference semantics: src/keys2a.cpp:362, strict inequality in double."""
+    B = gpu_bsfm
+    n2 = 3000
+    rng = np.random.default_rng(11)
+    k2 = synth_keys(B, n2, 83)
+    k1 = np.clip(synth_keys(B, 120, 84), 40, 200)
+    cols = rng.permutation(n2)
+    expect_pass = {}
+    for q in range(120):
+        a, b = int(cols[2 * q]), int(cols[2 * q + 1])
+        if (a - b) % 64 == 0:
+            b = (b + 1) % n2
+        m = 4 + q % 20
+        kind = q % 6
+        if kind < 4:             # d0 = 9 m; 25 d0 = 225 m against 9 d1 with d1 = 25 m + delta: passes iff delta >= 1
+            delta = (-1, 0, 1, 2)[kind]
+            d0, d1 = 9 * m, 25 * m + delta
+            expect_pass[q] = 25 * d0 < 9 * d1
+        elif kind == 4:          # exact duplicates in two slots: 0 < 0.36 * 0 is false
+            d0, d1 = 0, 0
+            expect_pass[q] = False
+        else:                    # the same non-zero nearest distance in two slots
+            d0 = d1 = 9 * m + 1
+            expect_pass[q] = False
+        k2[a] = _with_sq_dist(k1[q], rng, d0)
+        k2[b] = _with_sq_dist(k1[q], rng, d1)
+    cnt, got = gpu_match(B, k1, k2)
+    ref = O.port_match(k1, k2)
+    assert cnt == len(ref) and np.array_equal(got, ref)
+    accepted = set(got[:, 0].tolist())
+    for q, ok in expect_pass.items():
+        assert (q in accepted) == ok, (q, ok)
 
 
 @pytest.mark.gpu
