@@ -20,6 +20,9 @@
 //     slots; the 16 column classes of a row are merged with wave shuffles, the four waves through LDS, then the ratio
 //     test runs in FP64 exactly as the reference writes it.
 //   * KeyMatchFull: all pairs (j < i) of one database image i go into ONE launch (grid = sum of query blocks).
+// Two scan kernels give that same table: k_match_l2 (above: exact running top-2, 3 VALU per distance, 128 queries per workgroup)
+// and k_match_bound (round 3: 1 VALU per distance, 256 queries per workgroup, bounds from the scan + exact rescan of the winning
+// slot); match_set_run picks one per launch, k_pair_counts / k_pair_write hand the accepted matches to the host compacted.
 #include <hip/hip_runtime.h>
 #include <climits>
 #include <cstdio>
@@ -481,6 +484,53 @@ __global__ __launch_bounds__(256, 2) void k_match_bound(const unsigned char* __r
     if (my_valid) nn_out[pd.out_off + qbase + my_row] = result;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The accepted matches of a launch, compacted on the device (round 3): the host used to copy the whole nearest-neighbour table
+// back (one int per query and pair: 2.5 GB per pass at config 5, serialised with the kernels on the one stream) and scan it.
+// k_pair_counts: accepted matches per pair.  k_pair_write: every pair's (query, neighbour) list in query order -- the order of
+// the reference's loop, keys2a.cpp:356-369 -- at the exclusive prefix of the counts, written straight into pinned host memory
+// together with the counts (a few hundred bytes per pair instead of 4 bytes per query).
+__global__ __launch_bounds__(256) void k_pair_counts(const PairDesc* __restrict__ pairs, const int* __restrict__ nn, int* __restrict__ cnt)
+{
+    __shared__ int sm[4];
+    const PairDesc pd = pairs[blockIdx.x];
+    int c = 0;
+    for (int q = threadIdx.x; q < pd.q_n; q += 256) c += nn[pd.out_off + q] >= 0;
+    for (int o = 32; o; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ __launch_bounds__(256) void k_pair_write(const PairDesc* __restrict__ pairs, const int* __restrict__ nn, const int* __restrict__ cnt,
+                                                    int* __restrict__ h_cnt, int2* __restrict__ h_matches)
+{
+    __shared__ int sm[4], s_base;
+    const int p = blockIdx.x;
+    const PairDesc pd = pairs[p];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int before = 0;
+    for (int i = threadIdx.x; i < p; i += 256) before += cnt[i];
+    for (int o = 32; o; o >>= 1) before += __shfl_xor(before, o);
+    if (lane == 0) sm[wave] = before;
+    __syncthreads();
+    if (threadIdx.x == 0) { s_base = sm[0] + sm[1] + sm[2] + sm[3]; h_cnt[p] = cnt[p]; }
+    __syncthreads();
+    int base = s_base;
+    for (int q0 = 0; q0 < pd.q_n; q0 += 256) {
+        const int q = q0 + (int)threadIdx.x;
+        const int v = q < pd.q_n ? nn[pd.out_off + q] : -1;
+        const unsigned long long m = __ballot(v >= 0);
+        __syncthreads();                              // sm is reused
+        if (lane == 0) sm[wave] = __popcll(m);
+        __syncthreads();
+        int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) pos += sm[w];
+        if (v >= 0) h_matches[pos] = make_int2(q, v);
+        base += sm[0] + sm[1] + sm[2] + sm[3];
+    }
+}
+
 // Which scan kernel a launch uses.  Both are exact and give the same table; they differ in what they cost:
 //   top-2   (k_match_l2):    3 VALU per distance, 128 queries per workgroup, indifferent to the data;
 //   rescan  (k_match_bound): 1 VALU per distance, 256 queries per workgroup (half the L2 -> CU fragment traffic per MAC), + 128 exact
@@ -672,10 +722,11 @@ static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_rad
     DevKeys& d = ms->d;
     ms->kernel_ms = 0.0; ms->distances = 0.0; ms->pairs = 0; ms->launches = 0; ms->launches_rescan = 0;
     if (tot == 0) { if (f) fclose(f); return 0; }
-    // Two-slot pipeline on one stream: while the GPU scans database image k, the host turns the nearest-neighbour table of
-    // image k-1 into text (own integer formatter: the text, not the search, was the larger part of the wall time).
+    // Two-slot pipeline on one stream: while the GPU scans database image k, the host turns the accepted matches of image k-1
+    // (compacted on the device, written by k_pair_write straight into the slot's pinned buffers) into text (own integer formatter).
     struct Slot {
-        PairDesc* h_pairs = nullptr; PairDesc* d_pairs = nullptr; int* h_nn = nullptr; int* d_nn = nullptr;
+        PairDesc* h_pairs = nullptr; PairDesc* d_pairs = nullptr; int* d_nn = nullptr; int* d_cnt = nullptr;
+        int* h_cnt = nullptr; int2* h_m = nullptr;           // pinned: accepted matches per pair / the pairs' (query, neighbour) lists back to back
         hipEvent_t done = nullptr, k0 = nullptr, k1 = nullptr; int image = -1; size_t npairs = 0; std::vector<int> js; bool busy = false;
         double dist = 0.0;
     } slots[2];
@@ -684,7 +735,9 @@ static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_rad
     auto release = [&] {
         for (Slot& s : slots) {
             if (s.h_pairs) (void)hipHostFree(s.h_pairs);
-            if (s.h_nn) (void)hipHostFree(s.h_nn);
+            if (s.h_cnt) (void)hipHostFree(s.h_cnt);
+            if (s.h_m) (void)hipHostFree(s.h_m);
+            if (s.d_cnt) (void)hipFree(s.d_cnt);
             if (s.d_pairs) (void)hipFree(s.d_pairs);
             if (s.d_nn) (void)hipFree(s.d_nn);
             if (s.done) (void)hipEventDestroy(s.done);
@@ -696,7 +749,9 @@ static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_rad
     bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
     for (Slot& s : slots) {
         ok = ok && hipHostMalloc((void**)&s.h_pairs, (size_t)num_images * sizeof(PairDesc)) == hipSuccess;
-        ok = ok && hipHostMalloc((void**)&s.h_nn, tot * sizeof(int)) == hipSuccess;
+        ok = ok && hipHostMalloc((void**)&s.h_cnt, (size_t)num_images * sizeof(int)) == hipSuccess;
+        ok = ok && hipHostMalloc((void**)&s.h_m, tot * sizeof(int2)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&s.d_cnt, (size_t)num_images * sizeof(int)) == hipSuccess;
         ok = ok && hipMalloc((void**)&s.d_pairs, (size_t)num_images * sizeof(PairDesc)) == hipSuccess;
         ok = ok && hipMalloc((void**)&s.d_nn, tot * sizeof(int)) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
@@ -718,25 +773,24 @@ static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_rad
         { float kms = 0.f; if (hipEventElapsedTime(&kms, s.k0, s.k1) == hipSuccess && kms >= 0.f) { ms->kernel_ms += kms; ms->distances += s.dist; ms->pairs += (long long)s.npairs; ms->launches++; } }
         text.clear();
         size_t seen_q = 0, seen_m = 0;
+        const int2* mlist = s.h_m;                     // the pairs' lists follow one another in pair order (k_pair_write)
         for (size_t p = 0; p < s.npairs; ++p) {
-            const int* row = s.h_nn + s.h_pairs[p].out_off;
-            const int qn = s.h_pairs[p].q_n;
-            int cnt = 0;
-            for (int q = 0; q < qn; ++q) cnt += row[q] >= 0;
-            seen_q += (size_t)qn; seen_m += (size_t)cnt;
+            const int cnt = s.h_cnt[p];
+            seen_q += (size_t)s.h_pairs[p].q_n; seen_m += (size_t)cnt;
             if (cnt >= 16) {   // KeyMatchFull.cpp:131-142: "j i\n", count, "idx_j idx_i" lines
                 if (f) {
                     put_int(s.js[p], ' '); put_int(s.image, '\n'); put_int(cnt, '\n');
-                    for (int q = 0; q < qn; ++q) if (row[q] >= 0) { put_int(q, ' '); put_int(row[q], '\n'); }
+                    for (int t = 0; t < cnt; ++t) { put_int(mlist[t].x, ' '); put_int(mlist[t].y, '\n'); }
                 }
                 if (tab) {
                     tab->pi.push_back(s.js[p]); tab->pj.push_back(s.image);
-                    for (int q = 0; q < qn; ++q) if (row[q] >= 0) { tab->m.push_back(q); tab->m.push_back(row[q]); }
+                    for (int t = 0; t < cnt; ++t) { tab->m.push_back(mlist[t].x); tab->m.push_back(mlist[t].y); }
                     if (tab->m.size() / 2 > (size_t)INT_MAX) tab->overflow = true;
                     tab->ptr.push_back((int)(tab->m.size() / 2));
                 }
                 ++total_pairs_written;
             }
+            mlist += cnt;
         }
         if (f && !text.empty()) fwrite(text.data(), 1, text.size(), f);
         if (seen_q) accept_rate = (double)seen_m / (double)seen_q;
@@ -772,7 +826,8 @@ static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_rad
         ms->launches_rescan += rescan;
         ok = ok && hipEventRecord(s.k1, st) == hipSuccess;
         s.dist = (double)out * (double)num_keys[i];        // query keys of all pairs x database keys
-        ok = ok && hipMemcpyAsync(s.h_nn, s.d_nn, out * sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess;
+        hipLaunchKernelGGL(k_pair_counts, dim3((unsigned)s.npairs), dim3(256), 0, st, s.d_pairs, s.d_nn, s.d_cnt);
+        hipLaunchKernelGGL(k_pair_write, dim3((unsigned)s.npairs), dim3(256), 0, st, s.d_pairs, s.d_nn, s.d_cnt, s.h_cnt, s.h_m);
         ok = ok && hipEventRecord(s.done, st) == hipSuccess;
         s.busy = true;
         ++turn;
