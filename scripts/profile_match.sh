@@ -1,6 +1,6 @@
 #!/bin/bash
 # Matcher evidence (ON THE GPU BOX through gpurun): bench line of config 5, rocprofv3 kernel stats of the same command, SQ counters
-# of k_match_l2 in their own passes (120 images).   usage: bash scripts/profile_match.sh <tag>   -> gpurun_out/prof/<tag>_*
+# of the scan kernels (k_match_bound / k_match_l2) in their own passes (120 images).   usage: bash scripts/profile_match.sh <tag>   -> gpurun_out/prof/<tag>_*
 set -u
 TAG=${1:-match}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
@@ -18,13 +18,14 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   timeout 300 rocprofv3 --pmc $set -d /tmp/p_mc_$tag -o c --output-format csv -- python $ROOT/bench.py --workload match --steps 4 --match-images 120 --no-cpu-baseline > /dev/null 2> /tmp/mc_$tag.err
   f=$(find /tmp/p_mc_$tag -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python - "$f" >> $OUT/${TAG}_pmc_counters.txt <<'PY'
-import csv, sys, collections
+import csv, sys, collections, re
 acc = collections.defaultdict(lambda: [set(), 0.0])
 for r in csv.DictReader(open(sys.argv[1])):
-    if "k_match_l2" not in r["Kernel_Name"]: continue
-    a = acc[r["Counter_Name"]]; a[0].add(r["Dispatch_Id"]); a[1] += float(r["Counter_Value"])
+    m = re.search(r"k_match_\w+", r["Kernel_Name"])
+    if not m: continue
+    a = acc[m.group(0) + " " + r["Counter_Name"]]; a[0].add(r["Dispatch_Id"]); a[1] += float(r["Counter_Value"])
 for k, (ids, tot) in acc.items():
     print(k, "launches", len(ids), "mean_per_launch", tot / max(len(ids), 1))
 PY
 done
-head -c 400 $OUT/${TAG}_bench.json; echo; cat $OUT/${TAG}_pmc_counters.txt; grep k_match_l2 $OUT/${TAG}_kernel_stats.csv | cut -c1-200
+head -c 400 $OUT/${TAG}_bench.json; echo; cat $OUT/${TAG}_pmc_counters.txt; grep -E "k_match_|k_pair_" $OUT/${TAG}_kernel_stats.csv | cut -c1-200
