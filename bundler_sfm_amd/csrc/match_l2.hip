@@ -730,8 +730,10 @@ static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_rad
         hipEvent_t done = nullptr, k0 = nullptr, k1 = nullptr; int image = -1; size_t npairs = 0; std::vector<int> js; bool busy = false;
         double dist = 0.0;
     } slots[2];
+    hipEvent_t base_ev = nullptr;   // time zero of the pass on the device clock
+    double cover_end = 0.0;         // end of the union of scan intervals so far (ms after base_ev)
     double accept_rate = 0.0;       // accepted matches per query in the last drained launch (auto mode's signal)
-    hipStream_t st = nullptr;
+    hipStream_t sts[2] = { nullptr, nullptr };    // one stream per slot: the tail of a launch (its last workgroups) overlaps the head of the next
     auto release = [&] {
         for (Slot& s : slots) {
             if (s.h_pairs) (void)hipHostFree(s.h_pairs);
@@ -744,9 +746,11 @@ static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_rad
             if (s.k0) (void)hipEventDestroy(s.k0);
             if (s.k1) (void)hipEventDestroy(s.k1);
         }
-        if (st) (void)hipStreamDestroy(st);
+        for (hipStream_t q : sts) if (q) (void)hipStreamDestroy(q);
+        if (base_ev) (void)hipEventDestroy(base_ev);
     };
-    bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&sts[0], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&sts[1], hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreate(&base_ev) == hipSuccess && hipEventRecord(base_ev, sts[0]) == hipSuccess;
     for (Slot& s : slots) {
         ok = ok && hipHostMalloc((void**)&s.h_pairs, (size_t)num_images * sizeof(PairDesc)) == hipSuccess;
         ok = ok && hipHostMalloc((void**)&s.h_cnt, (size_t)num_images * sizeof(int)) == hipSuccess;
@@ -770,7 +774,16 @@ static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_rad
     auto drain = [&](Slot& s) -> bool {
         if (!s.busy) return true;
         if (hipEventSynchronize(s.done) != hipSuccess) return false;
-        { float kms = 0.f; if (hipEventElapsedTime(&kms, s.k0, s.k1) == hipSuccess && kms >= 0.f) { ms->kernel_ms += kms; ms->distances += s.dist; ms->pairs += (long long)s.npairs; ms->launches++; } }
+        {   // scan-kernel time of the pass = the UNION of the launches' [start, end] intervals on the common clock (the two streams'
+            // launches overlap by design; summing their durations would count the shared stretch twice)
+            float t0 = 0.f, t1 = 0.f;
+            if (hipEventElapsedTime(&t0, base_ev, s.k0) == hipSuccess && hipEventElapsedTime(&t1, base_ev, s.k1) == hipSuccess && t1 >= t0) {
+                const double from = std::max((double)t0, cover_end);
+                if ((double)t1 > from) ms->kernel_ms += (double)t1 - from;
+                cover_end = std::max(cover_end, (double)t1);
+                ms->distances += s.dist; ms->pairs += (long long)s.npairs; ms->launches++;
+            }
+        }
         text.clear();
         size_t seen_q = 0, seen_m = 0;
         const int2* mlist = s.h_m;                     // the pairs' lists follow one another in pair order (k_pair_write)
@@ -803,6 +816,7 @@ static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_rad
         int start = 0;
         if (window_radius > 0) start = std::max(i - window_radius, 0);   // KeyMatchFull.cpp:117-119
         Slot& s = slots[turn & 1];
+        hipStream_t st = sts[turn & 1];
         ok = drain(s);
         if (!ok) break;
         s.js.clear(); s.npairs = 0; s.image = i;

@@ -378,15 +378,16 @@ int bsfm_merge_match_files(int count, const char *const *paths, const char *out_
 /* Resident key set: the descriptors of all images (and their per-key statistics) stay in HBM across runs, so that repeated
  * matching passes (different window radius / ratio, or a timed benchmark pass) do not re-upload 128 bytes per key.
  * bsfm_key_match_full_sharded == create + run + destroy.  After a run, bsfm_match_set_stats reports the HIP-event time of the
- * brute-force kernel's launches, the number of descriptor distances they evaluated (x 128 MAC each), the image pairs searched
- * and the launch count. */
+ * brute-force kernels' launches (the union of their [start, end] intervals: consecutive launches run on two streams so that the
+ * tail of one overlaps the head of the next), the number of descriptor distances they evaluated (x 128 MAC each), the image
+ * pairs searched and the launch count. */
 typedef struct bsfm_match_set bsfm_match_set_t;
 bsfm_match_set_t *bsfm_match_set_create(int num_images, const int *num_keys, const unsigned char *const *keys);
 int bsfm_match_set_run(bsfm_match_set_t *ms, double ratio, int window_radius, const char *out_path, int rank, int world_size);
 int bsfm_match_set_stats(const bsfm_match_set_t *ms, double *kernel_ms, double *distances, long long *pairs, int *launches);
 /* Scan kernel of the matcher: 0 = auto (default; per launch, from the share of accepted matches the last finished launch had),
- * 1 = exact running top-2 (cost independent of the data), 2 = running minimum + exact rescan of the winning slot (faster when
- * few queries pass the ratio test, slower when many do).  All three give the same matches (keys2a.cpp:347-372).  Returns the
+ * 1 = k_match_l2, exact running top-2 (cost independent of the data), 2 = k_match_bound, one running maximum per slot + bounds +
+ * exact rescan of the winning slot (faster when few queries pass the ratio test, slower when many do).  All three give the same matches (keys2a.cpp:347-372).  Returns the
  * previous setting; an out-of-range value only queries.  Environment: BSFM_MATCH_KERNEL=auto|top2|rescan. */
 int bsfm_match_kernel(int mode);
 /* launches of the last bsfm_match_set_run* that used the rescan kernel (of bsfm_match_set_stats' `launches`) */
