@@ -262,6 +262,8 @@ def matcher_leg(args, passes=1):
                "alg_ops_per_launch": ops / max(nl.value, 1), "launches": nl.value, "avg_launch_ms": round(kms.value / max(nl.value, 1), 4),
                "kernel_ms_per_pass": round(kms.value, 2), "us_per_image_pair": round(1e3 * kms.value / max(npairs.value, 1), 3),
                "note": "achieved = 2 x 128 int8 ops per descriptor distance x distances of the launches / HIP-event time of the launches "
+                       "(the UNION of their intervals: consecutive launches alternate between two streams so that one's tail overlaps the next one's "
+                       "head; BSFM_MATCH_STREAMS=1 serialises them, which is what profiles/*_match_kernel_stats.csv was taken with) "
                        "(match_l2.hip); peak = measured v_mfma_i32_16x16x64_i8 ceiling; compulsory HBM traffic is the 320 MB key set "
                        "(L2 / Infinity Cache resident), so the kernel is compute-bound"}}
     # CPU baseline: the reference's own matcher (ANN kd-tree priority search, 200 visits, src/keys2a.cpp:347-372) on a bounded

@@ -734,6 +734,8 @@ static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_rad
     double cover_end = 0.0;         // end of the union of scan intervals so far (ms after base_ev)
     double accept_rate = 0.0;       // accepted matches per query in the last drained launch (auto mode's signal)
     hipStream_t sts[2] = { nullptr, nullptr };    // one stream per slot: the tail of a launch (its last workgroups) overlaps the head of the next
+    // BSFM_MATCH_STREAMS=1: everything on one stream (launches strictly one after the other: what a profiler's per-launch durations need)
+    static const bool one_stream = [] { const char* e = getenv("BSFM_MATCH_STREAMS"); return e && atoi(e) == 1; }();
     auto release = [&] {
         for (Slot& s : slots) {
             if (s.h_pairs) (void)hipHostFree(s.h_pairs);
@@ -816,7 +818,7 @@ static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_rad
         int start = 0;
         if (window_radius > 0) start = std::max(i - window_radius, 0);   // KeyMatchFull.cpp:117-119
         Slot& s = slots[turn & 1];
-        hipStream_t st = sts[turn & 1];
+        hipStream_t st = sts[one_stream ? 0 : (turn & 1)];
         ok = drain(s);
         if (!ok) break;
         s.js.clear(); s.npairs = 0; s.image = i;

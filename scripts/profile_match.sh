@@ -9,13 +9,15 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 timeout 600 python $ROOT/bench.py --workload match > $OUT/${TAG}_bench.json 2> /tmp/mb.err
-timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_m -o st --output-format csv -- python $ROOT/bench.py --workload match --steps 4 --no-cpu-baseline > $OUT/${TAG}_bench_under_profiler.json 2> /tmp/stm.err
+# per-launch durations: ONE stream (BSFM_MATCH_STREAMS=1), otherwise consecutive launches overlap and every one of them looks twice as long
+BSFM_MATCH_STREAMS=1 timeout 600 python $ROOT/bench.py --workload match > $OUT/${TAG}_bench_one_stream.json 2> /tmp/mb1.err
+BSFM_MATCH_STREAMS=1 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/p_m -o st --output-format csv -- python $ROOT/bench.py --workload match --steps 4 --no-cpu-baseline > $OUT/${TAG}_bench_under_profiler.json 2> /tmp/stm.err
 cp $(find /tmp/p_m -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
 : > $OUT/${TAG}_pmc_counters.txt
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM"; do
   tag=$(echo $set | cut -d' ' -f1)
-  timeout 300 rocprofv3 --pmc $set -d /tmp/p_mc_$tag -o c --output-format csv -- python $ROOT/bench.py --workload match --steps 4 --match-images 120 --no-cpu-baseline > /dev/null 2> /tmp/mc_$tag.err
+  BSFM_MATCH_STREAMS=1 timeout 300 rocprofv3 --pmc $set -d /tmp/p_mc_$tag -o c --output-format csv -- python $ROOT/bench.py --workload match --steps 4 --match-images 120 --no-cpu-baseline > /dev/null 2> /tmp/mc_$tag.err
   f=$(find /tmp/p_mc_$tag -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python - "$f" >> $OUT/${TAG}_pmc_counters.txt <<'PY'
 import csv, sys, collections, re
