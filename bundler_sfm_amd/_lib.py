@@ -72,7 +72,7 @@ SYMBOLS = [
     "bsfm_comm_allreduce", "bsfm_comm_allreduce_host", "bsfm_comm_barrier", "bsfm_problem_set_comm",
     "bsfm_problem_set_allreduce", "bsfm_problem_set_stream", "bsfm_problem_reset_params", "bsfm_problem_append", "bsfm_problem_remove_points", "bsfm_lm_begin",
     "bsfm_lm_iterate", "bsfm_lm_finish", "bsfm_lm_solve_attempts", "bsfm_lm_last_kernel_ms",
-    "bsfm_problem_download", "bsfm_problem_export_index", "bsfm_problem_schur_sizes", "bsfm_problem_export_schur", "bsfm_crs_from_vmask", "bsfm_crs_from_vmask_device", "bsfm_run_sfm_last_ms", "bsfm_schur_chunk",
+    "bsfm_problem_download", "bsfm_problem_export_index", "bsfm_problem_schur_sizes", "bsfm_problem_export_schur", "bsfm_crs_from_vmask", "bsfm_crs_from_vmask_device", "bsfm_run_sfm_last_ms", "bsfm_schur_chunk", "bsfm_device_cache_trim",
     "bsfm_problem_cnp", "bsfm_problem_num_cameras", "bsfm_problem_num_points", "bsfm_problem_nvis", "bsfm_eval_residuals", "bsfm_problem_outlier_stats", "bsfm_problem_ray_angles", "bsfm_triangulate_batch", "bsfm_rand_seed", "bsfm_rand_next", "bsfm_fmatrix_ransac_batch",
     "bsfm_estimate_fmatrix_batch", "bsfm_compute_tracks",
     "bsfm_eval_normal_equations", "bsfm_dense_chol_solve", "bsfm_match_keys_l2", "bsfm_key_match_full",
@@ -222,6 +222,8 @@ def _load():
     lib.bsfm_crs_from_vmask_device.restype = C.c_int
     lib.bsfm_schur_chunk.argtypes = []
     lib.bsfm_schur_chunk.restype = C.c_int
+    lib.bsfm_device_cache_trim.argtypes = []
+    lib.bsfm_device_cache_trim.restype = None
     lib.bsfm_run_sfm_last_ms.argtypes = [C.c_char_p]
     lib.bsfm_run_sfm_last_ms.restype = C.c_double
     lib.bsfm_device_count.argtypes = []

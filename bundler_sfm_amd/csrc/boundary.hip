@@ -22,6 +22,7 @@
 #include <hip/hip_runtime_api.h>
 #include "../../include/bsfm.h"
 #include "index_build.h"
+#include "devcache.h"
 
 namespace {
 
@@ -216,7 +217,7 @@ int bsfm_crs_from_vmask_device(int n, int m, const char* vmask, int* rowptr, int
     bool ok = true;
     if (rowptr) ok = hipMemcpy(rowptr, d_rp, ((size_t)n + 1) * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
     if (ok && colidx && nvis) ok = hipMemcpy(colidx, d_ci, (size_t)nvis * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
-    (void)hipFree(d_rp); (void)hipFree(d_ci);
+    bsfm::dev_free(d_rp); bsfm::dev_free(d_ci);
     return ok ? nvis : BSFM_ERROR;
 }
 
@@ -389,7 +390,7 @@ int bsfm_run_sfm_ex(int num_pts, int num_cameras, int ncons, char* vmask, double
     for (double& v : g_run_ms) v = 0.0;
     std::vector<int> rowptr, colidx;
     int *d_rp = nullptr, *d_ci = nullptr;                     // device CRS (owned here)
-    struct DevCrsGuard { int*& a; int*& b; ~DevCrsGuard() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } crs_guard{ d_rp, d_ci };
+    struct DevCrsGuard { int*& a; int*& b; ~DevCrsGuard() { bsfm::dev_free(a); bsfm::dev_free(b); } } crs_guard{ d_rp, d_ci };
     bool host_crs = true;
     {
         const auto t0 = std::chrono::steady_clock::now();

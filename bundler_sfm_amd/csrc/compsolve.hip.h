@@ -79,8 +79,8 @@ struct CompSolver {
 
 inline void comp_free(CompSolver& cs)
 {
-    if (cs.d_ptr) (void)hipFree(cs.d_ptr);
-    if (cs.d_cams) (void)hipFree(cs.d_cams);
+    bsfm::dev_free(cs.d_ptr, true);
+    bsfm::dev_free(cs.d_cams, true);
     cs = CompSolver();
 }
 
@@ -112,7 +112,7 @@ inline int comp_setup(CompSolver& cs, int mm, int cnp, const std::vector<int>& b
     for (int c = 0; c < nc; ++c) ptr[c + 1] = ptr[c] + count[c];
     std::vector<int> cur(ptr.begin(), ptr.end() - 1);
     for (int j = 0; j < mm; ++j) cams[cur[label[find(j)]]++] = j;
-    if (hipMalloc(&cs.d_ptr, (size_t)(nc + 1) * sizeof(int)) != hipSuccess || hipMalloc(&cs.d_cams, (size_t)mm * sizeof(int)) != hipSuccess) return -1;
+    if (bsfm::dev_alloc((void**)&cs.d_ptr, (size_t)(nc + 1) * sizeof(int)) != hipSuccess || bsfm::dev_alloc((void**)&cs.d_cams, (size_t)mm * sizeof(int)) != hipSuccess) return -1;
     if (hipMemcpy(cs.d_ptr, ptr.data(), (size_t)(nc + 1) * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(cs.d_cams, cams.data(), (size_t)mm * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return -1;
     cs.ncomp = nc; cs.maxdim = maxc * cnp; cs.stride = cs.maxdim | 1;

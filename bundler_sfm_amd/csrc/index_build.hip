@@ -23,6 +23,7 @@
 #include <mutex>
 #include <chrono>
 #include "index_build.h"
+#include "devcache.h"
 
 namespace bsfm {
 namespace {
@@ -219,7 +220,8 @@ struct EventPair {
     ~EventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
 };
 
-template <typename T> hipError_t keep(T** p, size_t count) { return hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T)); }
+// what a build hands to its caller comes from the problems' block cache (devcache.h): the caller releases it with dev_free
+template <typename T> hipError_t keep(T** p, size_t count) { return bsfm::dev_alloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T)); }
 
 template <typename KeyT>
 int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int* d_colidx, const long long* d_toff, long long total,
@@ -278,7 +280,7 @@ int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int
     IX_OK(hipStreamSynchronize(st));
     ix.ntasks = ntasks;
     SchurTask* tasks = nullptr;
-    if (order_by_block) IX_OK(hipMalloc((void**)&tasks, std::max<size_t>(1, (size_t)ntasks) * sizeof(SchurTask)));
+    if (order_by_block) IX_OK(bsfm::dev_alloc((void**)&tasks, std::max<size_t>(1, (size_t)ntasks) * sizeof(SchurTask)));
     else IX_OK(tmp.alloc(&tasks, (size_t)ntasks));
     hipLaunchKernelGGL(k_tasks, dim3(grid_for(nblk, 256)), dim3(256), 0, st, nblk, blk_start, ix.blk_task0, ix.blk_j, ix.blk_k, tasks, schur_chunk());
     hipLaunchKernelGGL(k_tri_pt, dim3(grid_for(nt, 256)), dim3(256), 0, st, (int)nt, vals_out, ix.cam_pt, ix.tri_pt);
@@ -384,7 +386,7 @@ int merge_observations_device(int n_new, int m_new, int nvis, const int* d_obs_p
     IX_OK(hipStreamSynchronize(st));
     if (hflag) {
         fprintf(stderr, "[bsfm] append:%s%s\n", (hflag & 1) ? " point / camera index out of range" : "", (hflag & 2) ? " an observation (point, camera) is given twice" : "");
-        (void)hipFree(*rowptr_out); (void)hipFree(*colidx_out); (void)hipFree(*x_out);
+        bsfm::dev_free(*rowptr_out); bsfm::dev_free(*colidx_out); bsfm::dev_free(*x_out);
         *rowptr_out = nullptr; *colidx_out = nullptr; *x_out = nullptr;
         return -1;
     }
@@ -474,7 +476,8 @@ void free_index_device(DeviceIndex& ix)
 {
     void* ptrs[] = { ix.obs_pt, ix.camptr, ix.camobs, ix.campos, ix.cam_pt, ix.cam_cam, ix.triples, ix.tri_pt, ix.tasks,
                      ix.blk_j, ix.blk_k, ix.blk_task0 };
-    for (void* p : ptrs) if (p) (void)hipFree(p);
+    (void)hipDeviceSynchronize();
+    for (void* p : ptrs) bsfm::dev_free(p, true);
     ix = DeviceIndex();
 }
 
@@ -687,15 +690,15 @@ int crs_from_vmask_device(int n, int m, const char* h_vmask, int** d_rowptr_out,
     if (nvis < 0) { fprintf(stderr, "[bsfm] visibility mask: more than 2^31-1 observations\n"); return -1; }
     int *rp = nullptr, *ci = nullptr;
     IX_OK(keep(&rp, (size_t)n + 1));
-    if (keep(&ci, (size_t)nvis) != hipSuccess) { (void)hipFree(rp); return -1; }
+    if (keep(&ci, (size_t)nvis) != hipSuccess) { bsfm::dev_free(rp); return -1; }
     hipLaunchKernelGGL(k_vmask_fill, dim3((unsigned)npieces), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_vm), nwords16, total, n, m,
                        d_off, rp, ci);
     // rowptr[n] = nvis: no lane covers byte n*m when the mask length is a multiple of 16 (and nothing at all is covered by an empty
     // mask); copied device-to-device from the scan's total -- not from a host temporary, whose lifetime an asynchronous copy would
     // outlive (round 3: a flaky rowptr[n] in the n*m = 65 536 test case)
-    if (total == 0) { if (hipMemsetAsync(rp, 0, ((size_t)n + 1) * sizeof(int), st) != hipSuccess) { (void)hipFree(rp); (void)hipFree(ci); return -1; } }
-    else if (hipMemcpyAsync(rp + n, d_off + npieces, sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess) { (void)hipFree(rp); (void)hipFree(ci); return -1; }
-    if (hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(rp); (void)hipFree(ci); return -1; }
+    if (total == 0) { if (hipMemsetAsync(rp, 0, ((size_t)n + 1) * sizeof(int), st) != hipSuccess) { bsfm::dev_free(rp); bsfm::dev_free(ci); return -1; } }
+    else if (hipMemcpyAsync(rp + n, d_off + npieces, sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess) { bsfm::dev_free(rp); bsfm::dev_free(ci); return -1; }
+    if (hipStreamSynchronize(st) != hipSuccess) { bsfm::dev_free(rp); bsfm::dev_free(ci); return -1; }
     if (ms_out) { ms_out[1] = ms_since(t1); ms_out[2] = ms_since(t0); }
     *d_rowptr_out = rp; *d_colidx_out = ci; *nvis_out = nvis;
     return 0;

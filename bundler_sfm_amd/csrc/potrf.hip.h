@@ -38,6 +38,7 @@
 #include <cstring>
 #include <algorithm>
 #include <mutex>
+#include "devcache.h"
 
 namespace bsfm {
 
@@ -1049,13 +1050,13 @@ __global__ void k_fold_timeout(const int* __restrict__ timeout, int* __restrict_
 // ------------------------------------------------------------------------------------------------
 inline void potrf_free(PotrfWorkspace& w)
 {
-    if (w.panel) (void)hipFree(w.panel);
-    if (w.linv) (void)hipFree(w.linv);
-    if (w.y) (void)hipFree(w.y);
-    if (w.xs) (void)hipFree(w.xs);
-    if (w.etmp) (void)hipFree(w.etmp);
-    if (w.bflags) (void)hipFree(w.bflags);
-    if (w.d_last) (void)hipFree(w.d_last);
+    bsfm::dev_free(w.panel, true);
+    bsfm::dev_free(w.linv, true);
+    bsfm::dev_free(w.y, true);
+    bsfm::dev_free(w.xs, true);
+    bsfm::dev_free(w.etmp, true);
+    bsfm::dev_free(w.bflags, true);
+    bsfm::dev_free(w.d_last, true);
     if (w.rb_handle && w.rb_destroy) w.rb_destroy(w.rb_handle);
     if (w.ev0) (void)hipEventDestroy(w.ev0);
     if (w.ev1) (void)hipEventDestroy(w.ev1);
@@ -1074,7 +1075,7 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
 {
     w.ld = ld; w.nblk = ld / POTRF_NB; w.backend = backend;
     const size_t tile = (size_t)POTRF_NB * POTRF_NB;
-    if (hipMalloc((void**)&w.panel, 4 * std::max<size_t>(1, (size_t)(w.nblk - 1)) * tile * sizeof(double)) != hipSuccess) return -1;
+    if (bsfm::dev_alloc((void**)&w.panel, 4 * std::max<size_t>(1, (size_t)(w.nblk - 1)) * tile * sizeof(double)) != hipSuccess) return -1;
     {   // Optional CU reservation (BSFM_PANEL_CUS=n masks n CUs out of the bulk stream, hipExtStreamCreateWithCUMask).
         // It was essential for the two-stream schedule (the 150 KB-LDS diagonal-tile workgroup could never be placed
         // while 2 400 bulk workgroups were queued: 12.4 vs 13.9 ms).  With the three-stream schedule the chain only
@@ -1103,11 +1104,11 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
         if (hipEventCreateWithFlags(&w.evT[i], hipEventDisableTiming) != hipSuccess) return -1;
         if (hipEventCreateWithFlags(&w.evC[i], hipEventDisableTiming) != hipSuccess) return -1;
     }
-    if (hipMalloc((void**)&w.linv, (size_t)w.nblk * tile * sizeof(double)) != hipSuccess) return -1;
-    if (hipMalloc((void**)&w.y, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
-    if (hipMalloc((void**)&w.xs, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
-    if (hipMalloc((void**)&w.etmp, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
-    if (hipMalloc((void**)&w.bflags, (size_t)(w.nblk + 1) * sizeof(int)) != hipSuccess) return -1;
+    if (bsfm::dev_alloc((void**)&w.linv, (size_t)w.nblk * tile * sizeof(double)) != hipSuccess) return -1;
+    if (bsfm::dev_alloc((void**)&w.y, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
+    if (bsfm::dev_alloc((void**)&w.xs, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
+    if (bsfm::dev_alloc((void**)&w.etmp, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
+    if (bsfm::dev_alloc((void**)&w.bflags, (size_t)(w.nblk + 1) * sizeof(int)) != hipSuccess) return -1;
     if (const char* e = getenv("BSFM_SYRK_EVENTS")) w.syrk_events = std::max(0, atoi(e));
     (void)hipEventCreate(&w.ev0); (void)hipEventCreate(&w.ev1);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_diag), hipFuncAttributeMaxDynamicSharedMemorySize,

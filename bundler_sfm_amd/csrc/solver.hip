@@ -18,11 +18,13 @@
 #include <algorithm>
 #include <string>
 #include <mutex>
+#include <unordered_map>
 #include <utility>
 #include <dlfcn.h>
 #include <chrono>
 
 #include "../../include/bsfm.h"
+#include "devcache.h"
 #include "kernels.hip.h"
 #include "schur.hip.h"
 #include "potrf.hip.h"
@@ -63,10 +65,91 @@ enum Scal { SC_COST = 0, SC_COST_TRIAL, SC_PCT, SC_CAM3 /*3*/, SC_PT_DP = 6, SC_
 
 template <typename T> hipError_t dmalloc(T** p, size_t count)
 {
-    return hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T));
+    return bsfm::dev_alloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T));
 }
 
 }  // namespace
+
+// ---- device block cache (devcache.h) --------------------------------------------------------------------------------------
+namespace bsfm {
+namespace {
+struct DevCache {
+    struct Blk { void* p; size_t bytes; int dev; };
+    std::mutex mu;
+    std::vector<Blk> idle;
+    std::unordered_map<void*, size_t> live;      // class size of every block handed out
+    size_t idle_bytes = 0, cap = 0;
+    DevCache()
+    {
+        long mb = 6144;
+        if (const char* e = getenv("BSFM_DEVCACHE_MB")) mb = atol(e);
+        cap = mb > 0 ? (size_t)mb << 20 : 0;
+    }
+    static size_t size_class(size_t bytes)
+    {
+        if (bytes <= 4096) return 4096;
+        int lg = 63 - __builtin_clzll((unsigned long long)bytes);
+        const size_t step = (size_t)1 << (lg - 3);               // eight classes per octave
+        return (bytes + step - 1) / step * step;
+    }
+    void trim_locked()
+    {
+        for (const Blk& b : idle) (void)hipFree(b.p);
+        idle.clear(); idle_bytes = 0;
+    }
+};
+DevCache& dev_cache() { static DevCache* c = new DevCache(); return *c; }   // leaked on purpose (no teardown order issues at exit)
+}  // namespace
+
+hipError_t dev_alloc(void** p, size_t bytes)
+{
+    DevCache& c = dev_cache();
+    const size_t cls = DevCache::size_class(bytes);
+    int dev = 0; (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(c.mu);
+    for (size_t i = c.idle.size(); i-- > 0;)
+        if (c.idle[i].bytes == cls && c.idle[i].dev == dev) {
+            *p = c.idle[i].p; c.idle_bytes -= cls; c.idle.erase(c.idle.begin() + (long)i);
+            c.live[*p] = cls;
+            return hipSuccess;
+        }
+    hipError_t e = hipMalloc(p, cls);
+    if (e != hipSuccess && !c.idle.empty()) {        // the free list may be what is in the way: give it back and try again
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+        c.trim_locked();
+        e = hipMalloc(p, cls);
+    }
+    if (e == hipSuccess) c.live[*p] = cls;
+    return e;
+}
+
+void dev_free(void* p, bool synced)
+{
+    if (!p) return;
+    DevCache& c = dev_cache();
+    std::unique_lock<std::mutex> lk(c.mu);
+    auto it = c.live.find(p);
+    if (it == c.live.end()) { lk.unlock(); (void)hipFree(p); return; }     // not one of ours
+    const size_t cls = it->second;
+    c.live.erase(it);
+    if (c.cap == 0 || cls > c.cap) { lk.unlock(); (void)hipFree(p); return; }
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (!synced) { lk.unlock(); (void)hipDeviceSynchronize(); lk.lock(); }
+    while (c.idle_bytes + cls > c.cap && !c.idle.empty()) {               // oldest blocks make room
+        (void)hipFree(c.idle.front().p); c.idle_bytes -= c.idle.front().bytes; c.idle.erase(c.idle.begin());
+    }
+    c.idle.push_back({ p, cls, dev }); c.idle_bytes += cls;
+}
+}  // namespace bsfm
+
+extern "C" void bsfm_device_cache_trim(void)
+{
+    (void)hipDeviceSynchronize();
+    bsfm::DevCache& c = bsfm::dev_cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.trim_locked();
+}
 
 struct bsfm_problem {
     bsfm_options_t opt;
@@ -136,13 +219,14 @@ namespace {
 
 void free_all(bsfm_problem* pb)
 {
+    (void)hipDeviceSynchronize();          // nothing may still be using the blocks that go back to the cache
     void* ptrs[] = { pb->d_x, pb->d_xc, pb->d_Rinit, pb->d_finit, pb->d_known, pb->d_obs_cam, pb->d_obs_pt, pb->d_rowptr, pb->d_camptr,
                      pb->d_camobs, pb->d_campos, pb->d_cam_pt, pb->d_cam_cam, pb->d_Ac, pb->d_Bc, pb->d_Cc, pb->d_ccon, pb->d_pcon, pb->d_cval, pb->d_cw, pb->d_pval, pb->d_p, pb->d_pdp,
                      pb->d_dp, pb->d_camtab, pb->d_camtab_trial, pb->d_e, pb->d_hx, pb->d_U,
                      pb->d_V, pb->d_Vinv, pb->d_eb, pb->d_S, pb->d_E, pb->d_partials, pb->d_epart, pb->d_campart, pb->d_red, pb->d_scal, pb->d_mixed,
                      pb->d_triples, pb->d_tri_pt, pb->d_tasks, pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0,
                      pb->d_gidx, pb->d_gblk_j, pb->d_gblk_k, pb->d_G, pb->d_spos, pb->d_xperm };
-    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (void* p : ptrs) bsfm::dev_free(p, true);          // bsfm_problem_destroy has synchronised the device
     if (pb->h_scal) (void)hipHostFree(pb->h_scal);
     potrf_free(pb->potrf);
     comp_free(pb->comps);
@@ -473,10 +557,10 @@ int exchange_block_union(bsfm_problem* pb)
     // upload, exchange and download all ride the compute stream (one synchronisation at the end; the host needs the union to build
     // the packed layout, once per problem)
     HIP_OK(hipMemcpyAsync(dseg, seg.data(), total * sizeof(double), hipMemcpyHostToDevice, pb->stream));
-    if (total && allreduce_dev(pb, dseg, total, 0)) { (void)hipFree(dseg); return BSFM_ERROR; }
+    if (total && allreduce_dev(pb, dseg, total, 0)) { bsfm::dev_free(dseg); return BSFM_ERROR; }
     HIP_OK(hipMemcpyAsync(seg.data(), dseg, total * sizeof(double), hipMemcpyDeviceToHost, pb->stream));
     HIP_OK(hipStreamSynchronize(pb->stream));
-    (void)hipFree(dseg);
+    bsfm::dev_free(dseg);
     std::vector<long long> keys;
     keys.reserve(total);
     for (size_t q = 0; q < total; ++q) if (seg[q] > 0.5) keys.push_back((long long)(seg[q] + 0.5) - 1);
@@ -795,7 +879,7 @@ int bsfm_problem_append(bsfm_problem_t* pb, int num_new_cameras, const bsfm_came
     for (int j = 0; j < num_new_cameras; ++j) cams[(size_t)m0 + j] = new_cameras[j];
     // new observations / points to the device; merge with the resident ones there
     int *d_apt = nullptr, *d_acam = nullptr, *d_rp = nullptr, *d_ci = nullptr; double *d_axy = nullptr, *d_x = nullptr, *d_pts = nullptr;
-    auto cleanup = [&] { for (void* q : { (void*)d_apt, (void*)d_acam, (void*)d_axy, (void*)d_rp, (void*)d_ci, (void*)d_x, (void*)d_pts }) if (q) (void)hipFree(q); };
+    auto cleanup = [&] { for (void* q : { (void*)d_apt, (void*)d_acam, (void*)d_axy, (void*)d_rp, (void*)d_ci, (void*)d_x, (void*)d_pts }) bsfm::dev_free(q); };
     bool ok = dmalloc(&d_apt, (size_t)nadd) == hipSuccess && dmalloc(&d_acam, (size_t)nadd) == hipSuccess && dmalloc(&d_axy, 2 * (size_t)nadd) == hipSuccess &&
               dmalloc(&d_pts, 3 * (size_t)n1) == hipSuccess;
     if (ok && nadd) ok = hipMemcpy(d_apt, add_pt, (size_t)nadd * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
@@ -841,7 +925,7 @@ int bsfm_problem_remove_points(bsfm_problem_t* pb, const unsigned char* remove, 
     std::vector<bsfm_camera_params_t> cams(pb->h_cams);
     if (bsfm_problem_download(pb, nullptr, cams.data(), nullptr) != 0) return BSFM_ERROR;
     unsigned char* d_rm = nullptr; int *d_rp = nullptr, *d_ci = nullptr, *d_remap = nullptr; double *d_x = nullptr, *d_pts = nullptr;
-    auto cleanup = [&] { for (void* q : { (void*)d_rm, (void*)d_rp, (void*)d_ci, (void*)d_remap, (void*)d_x, (void*)d_pts }) if (q) (void)hipFree(q); };
+    auto cleanup = [&] { for (void* q : { (void*)d_rm, (void*)d_rp, (void*)d_ci, (void*)d_remap, (void*)d_x, (void*)d_pts }) bsfm::dev_free(q); };
     if (dmalloc(&d_rm, (size_t)n0) != hipSuccess || hipMemcpy(d_rm, remove, (size_t)n0, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return BSFM_ERROR; }
     int n1 = 0, nvis1 = 0;
     if (compact_points_device(n0, nvis0, pb->d_rowptr, pb->d_obs_pt, pb->d_obs_cam, pb->d_x, d_rm, &d_rp, &d_ci, &d_x, &d_remap, &n1, &nvis1, pb->stream) != 0) { cleanup(); return BSFM_ERROR; }
@@ -1327,7 +1411,7 @@ int bsfm_problem_outlier_stats(bsfm_problem_t* pb, double min_thr, double max_th
     launch_cam_table(pb, pb->d_p, pb->d_camtab);
     launch_residual(pb, pb->d_camtab, pb->d_p, pb->d_e, nullptr, SC_COST);
     double *dist = nullptr, *dist_cm = nullptr, *stats = nullptr, *perr = nullptr; int* cnt = nullptr; unsigned char* pflag = nullptr;
-    auto cleanup = [&] { for (void* q : { (void*)dist, (void*)dist_cm, (void*)stats, (void*)perr, (void*)cnt, (void*)pflag }) if (q) (void)hipFree(q); };
+    auto cleanup = [&] { for (void* q : { (void*)dist, (void*)dist_cm, (void*)stats, (void*)perr, (void*)cnt, (void*)pflag }) bsfm::dev_free(q); };
     if (dmalloc(&dist, (size_t)nvis) != hipSuccess || dmalloc(&dist_cm, (size_t)nvis) != hipSuccess ||
         dmalloc(&stats, (size_t)4 * m) != hipSuccess || dmalloc(&perr, (size_t)n) != hipSuccess ||
         dmalloc(&cnt, (size_t)m) != hipSuccess || dmalloc(&pflag, (size_t)n) != hipSuccess) { cleanup(); return BSFM_ERROR; }
@@ -1368,7 +1452,7 @@ int bsfm_problem_ray_angles(bsfm_problem_t* pb, double ray_angle_threshold, doub
     const int m = pb->P.m, n = pb->P.n, nvis = pb->P.nvis;
     if (pb->mot) { fprintf(stderr, "[bsfm] ray angles: the camera-only problem does not hold the points on the device\n"); return BSFM_ERROR; }
     double *rays = nullptr, *deg = nullptr; unsigned char* flag = nullptr;
-    auto cleanup = [&] { for (void* q : { (void*)rays, (void*)deg, (void*)flag }) if (q) (void)hipFree(q); };
+    auto cleanup = [&] { for (void* q : { (void*)rays, (void*)deg, (void*)flag }) bsfm::dev_free(q); };
     if (dmalloc(&rays, (size_t)3 * nvis + 1) != hipSuccess || dmalloc(&deg, (size_t)n + 1) != hipSuccess ||
         dmalloc(&flag, (size_t)n + 1) != hipSuccess) { cleanup(); return BSFM_ERROR; }
     if (nvis > 0)
@@ -1430,7 +1514,7 @@ int bsfm_eval_normal_equations(bsfm_problem_t* pb, double mu, double* U, double*
         hipLaunchKernelGGL(k_expand_v, dim3(grid_for(n, 256)), dim3(256), 0, pb->stream, n, mu, pb->d_V, tmp);
         HIP_OK(hipStreamSynchronize(pb->stream));
         HIP_OK(hipMemcpy(V, tmp, 9 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
-        (void)hipFree(tmp);
+        bsfm::dev_free(tmp);
     }
     if (eb && n) HIP_OK(hipMemcpy(eb, pb->d_eb, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     if (J && pb->P.nvis) {   // the device copies are camera-major and chunked: back to the reference's record A (2 x cnp) || B (2 x 3) in
@@ -1481,7 +1565,7 @@ int bsfm_dense_chol_solve(int n, const double* A, const double* b, double* x, in
             for (int I = 0; I < nt; ++I) for (int K = first[I]; K <= I; ++K) last[K] = std::max(last[K], I);
             ws.env_rows.assign((size_t)nt, 0);
             for (int K = 0; K < nt; ++K) ws.env_rows[K] = last[K] - K;
-            if (hipMalloc((void**)&ws.d_last, (size_t)nt * sizeof(int)) != hipSuccess) break;
+            if (bsfm::dev_alloc((void**)&ws.d_last, (size_t)nt * sizeof(int)) != hipSuccess) break;
             if (hipMemcpy(ws.d_last, last.data(), (size_t)nt * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) break;
         }
         if (potrf_solve(ws, dS, ld, n, dE, dx, dinfo, st)) break;
@@ -1490,7 +1574,8 @@ int bsfm_dense_chol_solve(int n, const double* A, const double* b, double* x, in
         if (hipMemcpy(x, dx, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) break;
         rc = info;
     } while (0);
-    if (dS) (void)hipFree(dS); if (dE) (void)hipFree(dE); if (dx) (void)hipFree(dx); if (dinfo) (void)hipFree(dinfo);
+    (void)hipDeviceSynchronize();
+    bsfm::dev_free(dS, true); bsfm::dev_free(dE, true); bsfm::dev_free(dx, true); bsfm::dev_free(dinfo, true);
     if (st) (void)hipStreamDestroy(st);
     potrf_free(ws);
     return rc;

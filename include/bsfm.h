@@ -254,6 +254,11 @@ int bsfm_problem_export_index(bsfm_problem_t *pb, int *rowptr, int *colidx, int 
 int bsfm_problem_schur_sizes(const bsfm_problem_t *pb, int *ntriples, int *nblk, int *ntasks, int *nslots);
 /* co-visibility triples per Schur task (a multiple of 16; default 192, BSFM_SCHUR_CHUNK overrides it before the first problem) */
 int bsfm_schur_chunk(void);
+/* Resident problems take their device buffers from a process-wide cache of blocks and give them back to it when they are destroyed
+ * (hipFree synchronises the device and costs 40-60 us per buffer: a fifth of a 14-camera run_sfm call).  The cache is bounded
+ * (BSFM_DEVCACHE_MB, default 6144; 0 = no cache) and empties itself when an allocation fails; this call empties it on request,
+ * e.g. before another library needs the memory. */
+void bsfm_device_cache_trim(void);
 int bsfm_problem_export_schur(bsfm_problem_t *pb, int *triples, int *tri_pt, int *blk_j, int *blk_k, int *blk_task0, int *tasks);
 /* dense vmask -> CRS exactly as run_sfm does it (host only); returns nvis, rowptr / colidx may be NULL. */
 int bsfm_crs_from_vmask(int n, int m, const char *vmask, int *rowptr, int *colidx);

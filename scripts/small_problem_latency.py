@@ -18,13 +18,14 @@ def run(tag, n, m, vm, proj, cams, pts, s):
         t = time.perf_counter()
         rc, info = B.run_sfm(n, m, 0, vm, proj, 1, 0, 1, 1, c2, p2, eps2=1e-12, options=opt)
         ts.append(time.perf_counter() - t)
+    ph = {k: round(B.lib.bsfm_run_sfm_last_ms(k.encode()), 2) for k in ("total", "crs", "create", "lm", "download")}
     t = time.perf_counter()
     pb = B.Problem(n, m, s["rowptr"], s["colidx"], proj, cams, pts, options=opt)
     t_create = time.perf_counter() - t
     t = time.perf_counter(); pb.solve(); t_solve = time.perf_counter() - t
     split = {k: round(pb.phase_ms("create_" + k), 2) for k in ("total", "upload", "index", "alloc")}
     pb.close()
-    line = (f"{tag}: GPU run_sfm {1e3 * min(ts):8.2f} ms, {int(info[5])} iterations (resident API: create {1e3 * t_create:.2f} ms {split}, "
+    line = (f"{tag}: GPU run_sfm {1e3 * min(ts):8.2f} ms {ph}, {int(info[5])} iterations (resident API: create {1e3 * t_create:.2f} ms {split}, "
             f"LM {1e3 * t_solve:.2f} ms = {1e3 * t_solve / max(info[5], 1):.3f} ms/iter)")
     if O.have_ref() and not os.environ.get("SMALL_NO_REF"):
         t = time.perf_counter(); O.ref_run_sfm(n, m, vm, proj, cams, pts); tr = time.perf_counter() - t
