@@ -197,6 +197,7 @@ struct bsfm_problem {
     std::vector<bsfm_camera_params_t> h_cams;      // the caller's camera structs (constraints, known intrinsics ...): template for bsfm_problem_append
     bsfm_problem_desc_t desc0{};                  // scalar fields of the description the problem was created from
     hipStream_t stream = nullptr; bool own_stream = false;
+    bool speculate = false;            // launch the first damping attempt of an iteration before its gradient test is read (small problems; BSFM_SPECULATE=0|1)
     bsfm_allreduce_fn allreduce = nullptr; void* allreduce_ctx = nullptr;
     bsfm_comm_t* comm = nullptr;        // library-side collective (comm.hip: RCCL over xGMI); takes precedence over the hook
     PotrfWorkspace potrf;
@@ -832,6 +833,9 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     // were a tenth of an iteration; BSFM_PHASE_TIMING=1 / 0 forces it.
     pb->ev_ok = nvis >= 100000;
     if (const char* e = getenv("BSFM_PHASE_TIMING")) pb->ev_ok = atoi(e) != 0;
+    // measured (profiles/r03_small_problem_latency_speculate.txt): 10 % of an iteration at 14 cameras, nothing from 50 cameras on
+    pb->speculate = pb->nvis_global <= 30000;
+    if (const char* e = getenv("BSFM_SPECULATE")) pb->speculate = atoi(e) != 0;
     pb->potrf.timing = pb->ev_ok ? 1 : 0;
     for (int i = 0; pb->ev_ok && i < PH_COUNT; ++i) {
         pb->ev_created = true;
@@ -1214,10 +1218,14 @@ static int lm_iterate_impl(bsfm_problem_t* pb, int iters)
         hipLaunchKernelGGL(k_iter_final, dim3(1), dim3(256), 0, pb->stream, P, d_pa, d_pb, pb->d_red, 1,
                            pb->world > 1 ? SC_COUNT + 8 : -1, (int)SC_EABINF_A, (int)SC_EABINF_B, (int)SC_MAXDIAG_U, (int)SC_MAXDIAG_V,
                            (int)SC_PL2_A, (int)SC_PL2_B, (int)SC_CCOST, pb->d_scal);
-        if (read_scalars(pb)) return BSFM_ERROR;
-        const double vmaxdiag = pb->h_scal[SC_MAXDIAG_V];   // diagonals are sums of squares (>= 0): a 0-based max is exact
-        double ccost = pb->h_scal[SC_CCOST];
-        {
+        // The gradient norm / parameter norm / largest diagonal of this iteration (sba_levmar.c:1085-1130).  They cost a round trip to the
+        // host, and on a 14-camera problem a round trip is a tenth of the iteration -- so from the second iteration on (mu is known
+        // then) the first damping attempt is launched BEFORE they are read and they come back with the attempt's own scalars.  If the
+        // gradient test says stop, the attempt is dropped: it has only written trial buffers and no counter has moved.
+        double ccost = 0.0;
+        auto take_iteration_scalars = [&]() -> int {
+            const double vmaxdiag = pb->h_scal[SC_MAXDIAG_V];   // diagonals are sums of squares (>= 0): a 0-based max is exact
+            ccost = pb->h_scal[SC_CCOST];
             double mx[2] = { pb->h_scal[SC_EABINF_B], vmaxdiag };
             double sm[2] = { pb->h_scal[SC_PL2_B], 0.0 };
             if (pb->world > 1) {
@@ -1232,9 +1240,16 @@ static int lm_iterate_impl(bsfm_problem_t* pb, int iters)
             if (pb->h_scal[SC_MAXDIAG_U] > md) md = pb->h_scal[SC_MAXDIAG_U];
             if (mx[1] > md) md = mx[1];
             pb->maxdiag = md;
+            return 0;
+        };
+        bool deferred = pb->itno > 0 && pb->world == 1 && pb->speculate;
+        bool grad_stop = false;        // the deferred gradient test fired: leave the iteration loop exactly where the reference does (sba_levmar.c:1125)
+        if (!deferred) {
+            if (read_scalars(pb)) return BSFM_ERROR;
+            if (take_iteration_scalars()) return BSFM_ERROR;
+            if (pb->eab_inf <= eps1) { pb->dp_L2 = 0.0; pb->stop = 1; break; }
+            if (pb->itno == 0) pb->mu = tau * pb->maxdiag;
         }
-        if (pb->eab_inf <= eps1) { pb->dp_L2 = 0.0; pb->stop = 1; break; }
-        if (pb->itno == 0) pb->mu = tau * pb->maxdiag;
 
         while (1) {   // determine increment using adaptive damping (sba_levmar.c:1131)
             const double mu = pb->mu;
@@ -1267,6 +1282,11 @@ static int lm_iterate_impl(bsfm_problem_t* pb, int iters)
             ph_end(pb, PH_RESID);
             if (read_scalars(pb)) return BSFM_ERROR;
             collect_phase_times(pb);
+            if (deferred) {      // the iteration's own scalars arrived with this attempt's
+                deferred = false;
+                if (take_iteration_scalars()) return BSFM_ERROR;
+                if (pb->eab_inf <= eps1) { pb->dp_L2 = 0.0; pb->stop = 1; grad_stop = true; break; }      // the attempt is dropped unseen
+            }
 
             double flagsd[1] = { (double)pb->h_flags[0] };
             double sums[4] = { pb->h_scal[SC_PT_DP], pb->h_scal[SC_PT_DL], pb->h_scal[SC_COST_TRIAL], 0.0 };
@@ -1344,6 +1364,7 @@ static int lm_iterate_impl(bsfm_problem_t* pb, int iters)
             }
             pb->nu = nu2;
         }
+        if (grad_stop) break;
         if (pb->p_eL2 <= eps3_sq) pb->stop = 5;
     }
     if (pb->itno >= itmax) pb->stop = 3;
