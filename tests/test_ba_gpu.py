@@ -836,3 +836,30 @@ def test_group_solver_with_a_camera_that_sees_nothing(gpu_bsfm):
     assert out[0][4] == 0 and out[1][4] == 4         # three camera groups + the lonely camera
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
     assert abs(out[0][2] - out[1][2]) <= 1e-12 * out[0][2] and np.abs(out[0][3] - out[1][3]).max() <= 1e-12
+
+
+@pytest.mark.gpu
+def test_block_cache_reuse_and_trim_leave_results_bit_identical(gpu_bsfm):
+    """Resident problems take their device buffers from a process-wide block cache and hand them back dirty (devcache.h: hipFree
+    synchronises the device ~60 times per tear-down).  The same run_sfm call must give the same bits whether its blocks are fresh
+    (after bsfm_device_cache_trim), reused from an identical problem, or reused from DIFFERENT problems (other sizes, other data)."""
+    B = gpu_bsfm
+    opt = B.default_options(verbose=0)
+
+    def run(m, n, deg):
+        s = B.synth_ba(m, n, deg)
+        vm = B.dense_vmask(n, m, s["rowptr"], s["colidx"])
+        cams = B.copy_cameras(s["cams"]); pts = s["pts"].copy()
+        rc, info = B.run_sfm(n, m, 0, vm, s["proj"], 1, 0, 1, 1, cams, pts, eps2=1e-12, options=opt)
+        return rc, np.array(info), np.array([[c.f, c.k[0], c.k[1], *list(c.t), *list(c.R)] for c in cams]), pts
+
+    B.lib.bsfm_device_cache_trim()
+    ref = run(20, 900, 6)                         # fresh blocks
+    again = run(20, 900, 6)                       # every block comes back out of the cache
+    run(33, 2000, 5); run(9, 300, 4)              # other shapes leave their own dirt in the size classes around
+    third = run(20, 900, 6)
+    B.lib.bsfm_device_cache_trim()
+    fourth = run(20, 900, 6)                      # fresh again
+    for other in (again, third, fourth):
+        assert other[0] == ref[0] and np.array_equal(other[1], ref[1])
+        assert np.array_equal(other[2], ref[2]) and np.array_equal(other[3], ref[3])
