@@ -19,6 +19,7 @@
 #include <string>
 #include <mutex>
 #include <unordered_map>
+#include <deque>
 #include <utility>
 #include <dlfcn.h>
 #include <chrono>
@@ -74,10 +75,13 @@ template <typename T> hipError_t dmalloc(T** p, size_t count)
 namespace bsfm {
 namespace {
 struct DevCache {
-    struct Blk { void* p; size_t bytes; int dev; };
+    // idle blocks by (device, size class) -- constant-time hand-out however many classes an incremental reconstruction leaves
+    // behind -- plus their order of arrival for the eviction (entries of blocks that went out again are skipped lazily)
     std::mutex mu;
-    std::vector<Blk> idle;
-    std::unordered_map<void*, size_t> live;      // class size of every block handed out
+    std::unordered_map<unsigned long long, std::vector<void*>> bins;
+    std::deque<std::pair<unsigned long long, void*>> fifo;
+    std::unordered_map<void*, unsigned long long> idle_key;     // idle block -> its bin
+    std::unordered_map<void*, size_t> live;                      // class size of every block handed out
     size_t idle_bytes = 0, cap = 0;
     DevCache()
     {
@@ -92,10 +96,20 @@ struct DevCache {
         const size_t step = (size_t)1 << (lg - 3);               // eight classes per octave
         return (bytes + step - 1) / step * step;
     }
+    static unsigned long long key_of(int dev, size_t cls) { return ((unsigned long long)(unsigned)dev << 48) ^ (unsigned long long)cls; }
+    static size_t class_of(unsigned long long key) { return (size_t)(key & ((1ull << 48) - 1)); }
+    void drop_locked(unsigned long long key, void* p)             // an idle block back to the driver
+    {
+        std::vector<void*>& v = bins[key];
+        for (size_t i = 0; i < v.size(); ++i) if (v[i] == p) { v[i] = v.back(); v.pop_back(); break; }
+        idle_key.erase(p);
+        idle_bytes -= class_of(key);
+        (void)hipFree(p);
+    }
     void trim_locked()
     {
-        for (const Blk& b : idle) (void)hipFree(b.p);
-        idle.clear(); idle_bytes = 0;
+        for (auto& kv : bins) for (void* p : kv.second) (void)hipFree(p);
+        bins.clear(); fifo.clear(); idle_key.clear(); idle_bytes = 0;
     }
 };
 DevCache& dev_cache() { static DevCache* c = new DevCache(); return *c; }   // leaked on purpose (no teardown order issues at exit)
@@ -107,14 +121,15 @@ hipError_t dev_alloc(void** p, size_t bytes)
     const size_t cls = DevCache::size_class(bytes);
     int dev = 0; (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(c.mu);
-    for (size_t i = c.idle.size(); i-- > 0;)
-        if (c.idle[i].bytes == cls && c.idle[i].dev == dev) {
-            *p = c.idle[i].p; c.idle_bytes -= cls; c.idle.erase(c.idle.begin() + (long)i);
-            c.live[*p] = cls;
-            return hipSuccess;
-        }
+    auto it = c.bins.find(DevCache::key_of(dev, cls));
+    if (it != c.bins.end() && !it->second.empty()) {
+        *p = it->second.back(); it->second.pop_back();
+        c.idle_key.erase(*p); c.idle_bytes -= cls;
+        c.live[*p] = cls;
+        return hipSuccess;
+    }
     hipError_t e = hipMalloc(p, cls);
-    if (e != hipSuccess && !c.idle.empty()) {        // the free list may be what is in the way: give it back and try again
+    if (e != hipSuccess && c.idle_bytes) {           // the free list may be what is in the way: give it back and try again
         (void)hipGetLastError();
         (void)hipDeviceSynchronize();
         c.trim_locked();
@@ -136,10 +151,25 @@ void dev_free(void* p, bool synced)
     if (c.cap == 0 || cls > c.cap) { lk.unlock(); (void)hipFree(p); return; }
     int dev = 0; (void)hipGetDevice(&dev);
     if (!synced) { lk.unlock(); (void)hipDeviceSynchronize(); lk.lock(); }
-    while (c.idle_bytes + cls > c.cap && !c.idle.empty()) {               // oldest blocks make room
-        (void)hipFree(c.idle.front().p); c.idle_bytes -= c.idle.front().bytes; c.idle.erase(c.idle.begin());
+    const unsigned long long key = DevCache::key_of(dev, cls);
+    c.bins[key].push_back(p); c.idle_key[p] = key; c.fifo.emplace_back(key, p); c.idle_bytes += cls;
+    size_t guard = c.fifo.size();
+    while (c.idle_bytes > c.cap && guard-- > 0) {                           // the oldest idle blocks make room
+        const auto old = c.fifo.front(); c.fifo.pop_front();
+        auto ik = c.idle_key.find(old.second);
+        if (ik == c.idle_key.end() || ik->second != old.first) continue;    // stale: that block went out again since
+        if (old.second == p) { c.fifo.push_back(old); continue; }           // the newcomer stays (its turn comes later)
+        c.drop_locked(old.first, old.second);
     }
-    c.idle.push_back({ p, cls, dev }); c.idle_bytes += cls;
+    if (c.fifo.size() > 4 * (c.idle_key.size() + 16)) {                     // compact the arrival list: one entry per idle block
+        std::deque<std::pair<unsigned long long, void*>> keep;
+        std::unordered_map<void*, int> seen;
+        for (auto e = c.fifo.rbegin(); e != c.fifo.rend(); ++e) {           // (the newest entry of a block is the one that counts)
+            auto ik = c.idle_key.find(e->second);
+            if (ik != c.idle_key.end() && ik->second == e->first && !seen[e->second]++) keep.push_front(*e);
+        }
+        c.fifo.swap(keep);
+    }
 }
 }  // namespace bsfm
 
