@@ -1,4 +1,5 @@
-"""Block cache under an incremental-reconstruction pattern: run_sfm on growing problems (8 .. 59 cameras, every size twice).\nRun with BSFM_DEVCACHE_MB=8 / 64 to exercise the eviction path."""
+"""Block cache under an incremental-reconstruction pattern: run_sfm on growing problems (8 .. 59 cameras, every size twice).
+Run with BSFM_DEVCACHE_MB=8 / 64 to exercise the eviction path."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, bundler_sfm_amd as B
