@@ -1,0 +1,777 @@
+// chol_flow.hip.h -- the tile-dataflow Cholesky solve of the reduced camera system on gfx950 (round 4).
+//
+// Replaces sba_Axb_Chol = dpotrf("U") + dpotrs (lib/sba-1.5/sba_lapack.c:374-485, called from lib/sba-1.5/sba_levmar.c:1368):
+// S = L L^T on the row-major lower triangle, y = L^-1 E fused into the factorisation, x = L^-T y behind it; info = k on the
+// first non-positive pivot, as dpotrf reports it.
+//
+// ONE kernel, k_chol_flow, runs the whole factorisation: resident 512-thread workgroups (two per CU) draw tasks from the static
+// order of chol_flow_sched.h with an atomic ticket, wait on per-tile counters for the tasks they depend on, do the tile
+// operation, and signal.  No stream events, no launch boundaries inside the factorisation (rounds 1-3: ~350 launches and ~280 events
+// per solve; the events, 7-18 us each, and the starvation of the chain's big-LDS / big-VGPR kernels between bulk launches were
+// what bounded the solve).  Every role fits the footprint of a bulk workgroup -- 128 VGPRs, 77 KB of LDS -- so
+// the chain never waits for an empty CU:
+//   POTRF   the diagonal tile in REGISTERS (wave w owns tile rows 16w..16w+15 as MFMA accumulators), only the finished
+//           16 x 16 blocks of the factor in LDS (swizzled, conflict-free for every access pattern used); factor AND inverse;
+//   TRSM    P_ik = S_ik inv(L_kk)^T as a product with the explicit inverse (a GEMM, no triangular solve), 64-row halves, or
+//           sixteen 32 x 32 blocks for the one tile the chain waits for;
+//   UPD     S_ij -= sum_p P_ip P_jp^T, np panels per pass over C: 128 x 128 (bulk), 64-row halves (the column the chain needs
+//           next), ten 32 x 32 blocks (the next diagonal tile);
+//   right-hand side: y_k = W_k E_k and E_j -= sum_p P_jp y_p as tile row T of the same task graph.
+//
+// Visibility between workgroups (MI355X_MICROARCH.md, "inter-workgroup visibility"; cdna_hip_programming.md guideline 16, R1):
+//   * data that is REWRITTEN during the launch (tiles of S, E) is only ever accessed with agent-scope (sc1) loads and stores: sc1
+//     loads bypass the CU's L1, sc1 stores write through and drop the line from the XCD's L2, and every reader of such data is
+//     also its next writer -- so no cache ever holds a copy that a later task could read stale;
+//   * data that is written ONCE per launch (the compact panel tiles Pc, the inverse diagonal factors W, y) is stored sc1 and
+//     read with plain (cached) loads after the producer's counter has been seen: no address of it is read before it is written;
+//   * a producer drains its stores (every wave: s_waitcnt vmcnt(0)), the workgroup synchronises, one lane increments the counter
+//     (agent-scope atomic); a consumer polls with relaxed agent-scope loads from one lane, then synchronises.
+// Spins are bounded (wall clock): an expired wait sets the time-out word, every workgroup leaves, and the solve reports
+// POTRF_INFO_TIMEOUT through dpotrf's info word instead of a silently wrong solution.
+#pragma once
+#include "potrf.hip.h"
+#include "chol_flow_sched.h"
+#include <map>
+#include <memory>
+
+namespace bsfm {
+
+struct FlowArgs {
+    double* S; int ld; int n_total; int T;
+    double* Pc;            // compact panel tiles: tile (i, k), i > k, at tri(i, k) * 128 * 128 (row stride 128)
+    double* Linv;          // W_k = inv(L_kk), tile k (upper triangle stays zero: cleared once at allocation)
+    double* E;             // right-hand side (working copy, ld)
+    double* y;             // y = L^-1 E
+    const FlowTask* tasks;
+    unsigned t_end;        // tickets >= t_end end the workgroup (chunked launches: the ticket counter carries over)
+    unsigned* ticket;      // [0] ticket counter, [1] time-out word
+    unsigned* flags;       // per-tile counters
+    int* info;
+    long long* trace;      // optional: 4 stamps per task
+};
+
+constexpr size_t FLOW_TL = (size_t)POTRF_NB * POTRF_NB;
+__host__ __device__ inline size_t flow_tri(int i, int k) { return (size_t)i * (size_t)(i - 1) / 2 + (size_t)k; }
+
+__device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ---- LDS budget (doubles).  The POTRF role needs 28 + 8 + 2 blocks of 16 x 16 and the pivot vector; the GEMM roles 2 x 128 x 18.
+constexpr int FLOW_LB = 0, FLOW_DI = 28 * 256, FLOW_LS = 36 * 256, FLOW_SV = 38 * 256;
+constexpr int FLOW_LDS_DOUBLES = 38 * 256 + 128;            // 78 848 bytes: two workgroups per CU (160 KB)
+static_assert(FLOW_LDS_DOUBLES >= 2 * 128 * GEMM_LDS_STRIDE, "GEMM staging must fit");
+static_assert(FLOW_LDS_DOUBLES >= T32_LDS_DOUBLES, "32 x 32 block staging must fit");
+
+// 16 x 16 block in LDS, stride 16, column index XOR-swizzled by the row pair: conflict-free for (a) MFMA operand reads
+// (row = lane & 15, column = 4 q + (lane >> 4)), (b) accumulator-layout writes (row = 4 q + (lane >> 4), column = lane & 15)
+// and (c) one-lane-per-row reads of a fixed column.
+__device__ __forceinline__ int swz16(int r, int c) { return r * 16 + (c ^ ((r >> 1) << 1)); }
+
+// C(MR x 128) += A(MR x K, row-major lda) * B(128 x K, row-major ldb)^T on v_mfma_f64_16x16x4 (accumulators in VGPRs: the
+// full-rate form), 8 waves as 4 (rows) x 2 (columns): a wave owns (MR / 4) x 64.  K in chunks of 16 through
+// LDS (row stride 18), the next chunk prefetched into registers while the matrix instructions of the current one issue.
+// acc[4 bi + r][u]: row wr + 16 bi + 4 r + (lane >> 4), column wc + 16 u + (lane & 15).
+template <int MR, bool NEG_A, bool A_SC1>
+__device__ __forceinline__ void flow_gemm_nt(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
+                                             int K, double* __restrict__ lds, double (&acc)[MR / 16][4])
+{
+    constexpr int NBI = MR / 64;                  // 16-row blocks per wave
+    constexpr int NPA = MR / 64;                  // staging passes of 64 rows for A (B: 2)
+    double* As = lds;
+    double* Bs = lds + MR * GEMM_LDS_STRIDE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = (wave >> 1) * (MR / 4), wc = (wave & 1) * 64;
+    const int srow = tid >> 3, sc2 = (tid & 7) * 2;
+    const double* Ag = A + (size_t)srow * lda + sc2;
+    const double* Bg = B + (size_t)srow * ldb + sc2;
+    double* Asw = As + srow * GEMM_LDS_STRIDE + sc2;
+    double* Bsw = Bs + srow * GEMM_LDS_STRIDE + sc2;
+    double pa[NPA][2], pb[2][2];
+#define BSFM_FLOW_GLOAD(kc)                                                                                    \
+    _Pragma("unroll") for (int q = 0; q < NPA; ++q) {                                                           \
+        const double* ap_ = Ag + (size_t)(64 * q) * lda + (kc);                                                 \
+        if (A_SC1) { pa[q][0] = ld_sc1(ap_); pa[q][1] = ld_sc1(ap_ + 1); }                                      \
+        else { const double2 ta = *reinterpret_cast<const double2*>(ap_); pa[q][0] = ta.x; pa[q][1] = ta.y; }   \
+    }                                                                                                           \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                             \
+        const double2 tb = *reinterpret_cast<const double2*>(Bg + (size_t)(64 * q) * ldb + (kc));               \
+        pb[q][0] = tb.x; pb[q][1] = tb.y;                                                                       \
+    }
+    BSFM_FLOW_GLOAD(0)
+    for (int kc = 0; kc < K; kc += GEMM_KC) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NPA; ++q)
+            *reinterpret_cast<double2*>(Asw + 64 * q * GEMM_LDS_STRIDE) = NEG_A ? make_double2(-pa[q][0], -pa[q][1]) : make_double2(pa[q][0], pa[q][1]);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            *reinterpret_cast<double2*>(Bsw + 64 * q * GEMM_LDS_STRIDE) = make_double2(pb[q][0], pb[q][1]);
+        __syncthreads();
+        if (kc + GEMM_KC < K) { BSFM_FLOW_GLOAD(kc + GEMM_KC) }
+#pragma unroll
+        for (int kk = 0; kk < GEMM_KC; kk += 4) {
+            double b[4], a2[NBI];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b[u] = Bs[(wc + 16 * u + (lane & 15)) * GEMM_LDS_STRIDE + kk + (lane >> 4)];
+#pragma unroll
+            for (int bi = 0; bi < NBI; ++bi) a2[bi] = As[(wr + 16 * bi + (lane & 15)) * GEMM_LDS_STRIDE + kk + (lane >> 4)];
+#pragma unroll
+            for (int bi = 0; bi < NBI; ++bi)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v4d c = { acc[4 * bi][u], acc[4 * bi + 1][u], acc[4 * bi + 2][u], acc[4 * bi + 3][u] };
+                    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[bi], b[u], c, 0, 0, 0);
+                    acc[4 * bi][u] = c[0]; acc[4 * bi + 1][u] = c[1]; acc[4 * bi + 2][u] = c[2]; acc[4 * bi + 3][u] = c[3];
+                }
+        }
+    }
+#undef BSFM_FLOW_GLOAD
+}
+
+// ---- UPD128 / UPD64: rows [r0, r0 + MR) of tile (i, j) -= sum_p P_ip P_jp^T.  The accumulators start as the C tile and the A operand
+// is negated while it is staged, so the matrix cores produce S_ij - P P^T directly (store-only epilogue).
+template <int MR>
+__device__ __attribute__((noinline)) void flow_upd(const FlowArgs& a, int i, int j, int p0, int np, int r0, double* lds)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = (wave >> 1) * (MR / 4), wc = (wave & 1) * 64;
+    double* Sij = a.S + ((size_t)i * POTRF_NB + r0) * a.ld + (size_t)j * POTRF_NB;
+    double acc[MR / 16][4];
+    {
+        const double* cp = Sij + (size_t)(wr + (lane >> 4)) * a.ld + wc + (lane & 15);
+#pragma unroll
+        for (int q = 0; q < MR / 16; ++q) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[q][u] = ld_sc1(cp + 16 * u);
+            cp += 4 * (size_t)a.ld;
+        }
+    }
+#pragma unroll 1
+    for (int p = p0; p < p0 + np; ++p)
+        flow_gemm_nt<MR, true, false>(a.Pc + flow_tri(i, p) * FLOW_TL + (size_t)r0 * POTRF_NB, POTRF_NB,
+                                      a.Pc + flow_tri(j, p) * FLOW_TL, POTRF_NB, POTRF_NB, lds, acc);
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));          // recompute the store address (keeping the load addresses alive costs registers)
+    const int wave2 = tid2 >> 6, lane2 = tid2 & 63;
+    double* Sl = Sij + (size_t)((wave2 >> 1) * (MR / 4) + (lane2 >> 4)) * a.ld + (wave2 & 1) * 64 + (lane2 & 15);
+#pragma unroll
+    for (int q = 0; q < MR / 16; ++q) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) st_sc1(Sl + 16 * u, acc[q][u]);
+        Sl += 4 * (size_t)a.ld;
+    }
+}
+
+// ---- TRSM64: rows [r0, r0 + 64) of P_ik = S_ik W_k^T -> compact panel tile.
+__device__ __attribute__((noinline)) void flow_trsm64(const FlowArgs& a, int i, int k, int r0, double* lds)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = (wave >> 1) * 16, wc = (wave & 1) * 64;
+    double acc[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[q][u] = 0.0;
+    flow_gemm_nt<64, false, true>(a.S + ((size_t)i * POTRF_NB + r0) * a.ld + (size_t)k * POTRF_NB, a.ld,
+                                  a.Linv + (size_t)k * FLOW_TL, POTRF_NB, POTRF_NB, lds, acc);
+    double* Pt = a.Pc + flow_tri(i, k) * FLOW_TL + (size_t)(r0 + wr + (lane >> 4)) * POTRF_NB + wc + (lane & 15);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) st_sc1(Pt + 16 * u, acc[q][u]);
+        Pt += 4 * POTRF_NB;
+    }
+}
+
+// ---- the chain's 32 x 32 block products (whole K range of both operands to LDS in one step, row stride 132, waves 0..3 compute a
+// 16 x 16 block each on two accumulator chains -- bounded by one global-load round trip):
+//   TRSM32, part = 4 br + bc:  block (br, bc) of P_ik = S_ik W_k^T, K = 32 (bc + 1) (W is lower triangular)
+//   UPD32,  part -> (br, bc), bc <= br:  block of S_jj -= sum_p P_jp P_jp^T
+template <bool IS_UPD>
+__device__ __attribute__((noinline)) void flow_tile32(const FlowArgs& a, int i, int k, int p0, int np, int part, double* lds)
+{
+    int br, bc;
+    if (!IS_UPD) { br = part >> 2; bc = part & 3; }
+    else { br = part < 1 ? 0 : part < 3 ? 1 : part < 6 ? 2 : 3; bc = part - br * (br + 1) / 2; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = ((wave >> 1) & 1) * 16, wc = (wave & 1) * 16;
+    const int K0 = IS_UPD ? POTRF_NB : 32 * (bc + 1);
+    double* As = lds; double* Bs = lds + 32 * T32_STRIDE;
+    // IS_UPD: i == k (diagonal tile j = i); C block in S
+    double* Ct = a.S + ((size_t)i * POTRF_NB + 32 * br) * a.ld + (size_t)k * POTRF_NB + 32 * bc;
+    double cin[4] = { 0.0, 0.0, 0.0, 0.0 };
+    if (IS_UPD && wave < 4) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) cin[t] = ld_sc1(Ct + (size_t)(wr + 4 * t + (lane >> 4)) * a.ld + wc + (lane & 15));
+    }
+    // staging: threads 0..255 fetch the A rows, 256..511 the B rows: row = (tid & 255) >> 3, 16-byte columns (tid & 7) + 8 q
+    const int half = tid >> 8, t2 = tid & 255, row = t2 >> 3, c2 = (t2 & 7) * 2;
+    v4d c = { 0.0, 0.0, 0.0, 0.0 }, cc = { 0.0, 0.0, 0.0, 0.0 };
+    const int nseg = IS_UPD ? np : 1;
+#pragma unroll 1
+    for (int sg = 0; sg < nseg; ++sg) {
+        double pv[8][2];
+        if (!IS_UPD) {
+            if (half == 0) {
+                const double* A_ = a.S + ((size_t)i * POTRF_NB + 32 * br + row) * a.ld + (size_t)k * POTRF_NB;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (16 * q < K0) { pv[q][0] = ld_sc1(A_ + 16 * q + c2); pv[q][1] = ld_sc1(A_ + 16 * q + c2 + 1); }
+            } else {
+                const double* B_ = a.Linv + (size_t)k * FLOW_TL + (size_t)(32 * bc + row) * POTRF_NB;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (16 * q < K0) { const double2 t = *reinterpret_cast<const double2*>(B_ + 16 * q + c2); pv[q][0] = t.x; pv[q][1] = t.y; }
+            }
+        } else {
+            const double* base_ = a.Pc + flow_tri(i, p0 + sg) * FLOW_TL;
+            const double* src = base_ + (size_t)(32 * (half ? bc : br) + row) * POTRF_NB;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const double2 t = *reinterpret_cast<const double2*>(src + 16 * q + c2); pv[q][0] = t.x; pv[q][1] = t.y; }
+        }
+        if (sg > 0) __syncthreads();          // the previous segment has been consumed
+        double* dst = (half ? Bs : As) + row * T32_STRIDE + c2;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (16 * q < K0) *reinterpret_cast<double2*>(dst + 16 * q) = make_double2(pv[q][0], pv[q][1]);
+        __syncthreads();
+        if (wave < 4) {
+            const double* ap16 = As + (wr + (lane & 15)) * T32_STRIDE + (lane >> 4);
+            const double* bp = Bs + (wc + (lane & 15)) * T32_STRIDE + (lane >> 4);
+            for (int kk = 0; kk < K0; kk += 8) {
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(ap16[kk], bp[kk], c, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap16[kk + 4], bp[kk + 4], cc, 0, 0, 0);
+            }
+        }
+    }
+    if (wave < 4) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int rw = wr + 4 * t + (lane >> 4), col = wc + (lane & 15);
+            const double v = c[t] + cc[t];
+            if (!IS_UPD) st_sc1(a.Pc + flow_tri(i, k) * FLOW_TL + (size_t)(32 * br + rw) * POTRF_NB + 32 * bc + col, v);
+            else st_sc1(Ct + (size_t)rw * a.ld + col, cin[t] - v);
+        }
+    }
+}
+
+// ---- right-hand side row.  FTRSM: y_k = W_k E_k.  FUPD: E_j -= sum_p P_jp y_p (4 lanes per row, panels in order).
+__device__ __forceinline__ void flow_ftrsm(const FlowArgs& a, int k, double* lds)
+{
+    double* vec = lds; double* red = lds + POTRF_NB;
+    const int tid = threadIdx.x, r = tid & 127, h = tid >> 7;          // 4 quarter-sums per row
+    if (tid < POTRF_NB) vec[tid] = ld_sc1(a.E + (size_t)k * POTRF_NB + tid);
+    __syncthreads();
+    const double* Wi = a.Linv + (size_t)k * FLOW_TL + (size_t)r * POTRF_NB + 32 * h;
+    double s = 0.0;
+#pragma unroll 8
+    for (int c = 0; c < 32; ++c) s += Wi[c] * vec[32 * h + c];
+    red[h * POTRF_NB + r] = s;
+    __syncthreads();
+    if (tid < POTRF_NB) st_sc1(a.y + (size_t)k * POTRF_NB + r, (red[r] + red[POTRF_NB + r]) + (red[2 * POTRF_NB + r] + red[3 * POTRF_NB + r]));
+}
+
+__device__ __forceinline__ void flow_fupd(const FlowArgs& a, int j, int p0, int np)
+{
+    const int tid = threadIdx.x, row = tid >> 2, part = tid & 3;
+    double e = 0.0;
+    if (part == 0) e = ld_sc1(a.E + (size_t)j * POTRF_NB + row);
+#pragma unroll 1
+    for (int p = p0; p < p0 + np; ++p) {
+        const double* Pr = a.Pc + flow_tri(j, p) * FLOW_TL + (size_t)row * POTRF_NB + 32 * part;
+        const double* yp = a.y + (size_t)p * POTRF_NB + 32 * part;
+        double s = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < 32; ++c) s += Pr[c] * yp[c];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        e -= s;
+    }
+    if (part == 0) st_sc1(a.E + (size_t)j * POTRF_NB + row, e);
+}
+
+// ---- POTRF: the diagonal tile, factor and inverse, in the footprint of a bulk workgroup.
+// Wave w holds tile rows 16 w .. 16 w + 15 as eight 16 x 16 blocks in the accumulator layout of v_mfma_f64_16x16x4 (register q of lane
+// l = row 4 q + (l >> 4), column l & 15), so the trailing updates accumulate straight into the tile.  Per block column s:
+//   A1  wave s turns its diagonal block into one-lane-per-row form (through LDS) and factors it: v_readlane broadcasts, 1 / pivot by
+//       v_rcp_f64 + two Newton steps, square roots deferred (the round-1 routine);
+//   A2  every wave below solves its block (I, s) against L_ss, one lane per row, and leaves the finished block of L in LDS;
+//       wave s meanwhile derives inv(L_ss) by the same substitution on the identity;
+//   A3  wave I: block (I, J) -= L_Is L_Js^T for s < J <= I, operands from LDS, result in registers.  Wave s + 1 has ONE product
+//       to do and goes straight on to factor block (s + 1, s + 1) while the others still update.
+// Then the inverse by block forward substitution, wave J = block column J: X_IJ = -inv(L_II) sum_K L_IK X_KJ; the accumulator
+// layout of X_KJ IS the B-operand layout of the next product, so X never leaves the registers.
+__device__ __attribute__((noinline)) void flow_potrf(const FlowArgs& a, int k, double* lds)
+{
+    double* Lb = lds + FLOW_LB; double* Di = lds + FLOW_DI; double* Ls = lds + FLOW_LS; double* sv = lds + FLOW_SV;
+    const int tid = threadIdx.x, lane0 = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int base = k * POTRF_NB, n_total = a.n_total;
+    const double* G = a.S + (size_t)base * a.ld + base;
+    const int lr0 = lane0 >> 4, lc0 = lane0 & 15;
+    // t[m]: block (w, s + m) at step s (the blocks are shifted down one place per step, so that the step's code exists once
+    // and every register index is static)
+    double t[8][4];
+    const int lr = lr0, lc = lc0;
+    // The whole tile lies inside the padded allocation of S, so every lane loads unconditionally (32 loads in flight, no divergent
+    // control flow) and the triangle / padding rules are applied with selects: lower triangle of S, identity beyond n_total.
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 16 * w + 4 * q + lr;
+        const double* rowp = G + (size_t)r * a.ld + lc;          // one address per row, the block columns are immediate offsets
+#pragma unroll
+        for (int J = 0; J < 8; ++J) t[J][q] = ld_sc1(rowp + 16 * J);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 16 * w + 4 * q + lr;
+#pragma unroll
+        for (int J = 0; J < 8; ++J) {
+            const int c = 16 * J + lc;
+            const bool inside = base + r < n_total && base + c < n_total;
+            const double pad = (r == c) ? 1.0 : 0.0;
+            t[J][q] = inside ? (c <= r ? t[J][q] : 0.0) : pad;
+        }
+    }
+#define BSFM_RDLANE(v, l) __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), (l)), __builtin_amdgcn_readlane(__double2loint(v), (l)))
+#define BSFM_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#pragma unroll 1
+    for (int s = 0; s < 8; ++s) {
+        double* Lss = Ls + (s & 1) * 256;
+        // opaque copies of the lane coordinates: the swizzled LDS addresses below are loop-invariant, and the compiler would otherwise
+        // hoist several dozen of them out of the loop and spill them (404 bytes of scratch per lane); one XOR per access is cheaper
+        int lr = lr0, lc = lc0, lane = lane0;
+        asm volatile("" : "+v"(lr), "+v"(lc), "+v"(lane));
+        if (w == s) {
+            // ---- A1
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Lss[swz16(4 * q + lr, lc)] = t[0][q];
+            BSFM_LDS_FENCE();
+            const int r = lc;
+            double d[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) d[c] = Lss[swz16(r, c)];
+            double myp = 1.0;
+            int bad = -1;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double piv = BSFM_RDLANE(d[j], j);
+                if (!(piv > 0.0) && bad < 0) bad = j;              // (wave-uniform) first non-positive pivot = dpotrf's info
+                myp = (r == j) ? piv : myp;
+                double inv = __builtin_amdgcn_rcp(piv);
+                inv = fma(fma(-piv, inv, 1.0), inv, inv);
+                inv = fma(fma(-piv, inv, 1.0), inv, inv);
+                const double lrj = d[j] * inv;
+#pragma unroll
+                for (int c = j + 1; c < 16; ++c) { const double sc = BSFM_RDLANE(d[j], c); d[c] -= lrj * sc; }
+            }
+            if (lane == 0 && bad >= 0 && base + 16 * s + bad < n_total) atomicCAS(a.info, 0, base + 16 * s + bad + 1);
+            const double myrs = rsqrt_f64(myp);                       // 1 / L[r][r]
+            BSFM_LDS_FENCE();                                          // (every lane has read its row before lanes 0..15 overwrite the block)
+            if (lane < 16) {
+                sv[16 * s + r] = myrs;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const double rs_c = BSFM_RDLANE(myrs, c);
+                    Lss[swz16(r, c)] = (c <= r) ? d[c] * rs_c : 0.0;
+                }
+            }
+        }
+        __syncthreads();
+        if (w > s) {
+            // ---- A2: block (w, s) -> one lane per row, x <- x inv(L_ss)^T by forward substitution, finished block of L -> LDS
+            double* dst = Lb + (w * (w - 1) / 2 + s) * 256;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[swz16(4 * q + lr, lc)] = t[0][q];
+            BSFM_LDS_FENCE();
+            if (lane < 16) {
+                double x[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) x[c] = dst[swz16(lane, c)];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const double xc = x[c] * sv[16 * s + c];
+                    x[c] = xc;
+#pragma unroll
+                    for (int kq = c + 1; kq < 16; ++kq) x[kq] -= xc * Lss[swz16(kq, c)];
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c) dst[swz16(lane, c)] = x[c];
+            }
+        } else if (w == s) {
+            // inv(L_ss): the same substitution on the rows of the identity; lane c ends up with column c of the inverse
+            if (lane < 16) {
+                double x[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) x[c] = (c == lane) ? 1.0 : 0.0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const double xc = x[c] * sv[16 * s + c];
+                    x[c] = xc;
+#pragma unroll
+                    for (int kq = c + 1; kq < 16; ++kq) x[kq] -= xc * Lss[swz16(kq, c)];
+                }
+                double* Dd = Di + s * 256;
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) Dd[swz16(rr, lane)] = x[rr];
+            }
+        }
+        __syncthreads();
+        if (w > s) {
+            // ---- A3: t[m] = block (w, s + m) -= L_ws L_(s+m)s^T for 1 <= m <= w - s
+            const double* Aw = Lb + (w * (w - 1) / 2 + s) * 256;
+            double av[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[q] = -Aw[swz16(lc, 4 * q + lr)];
+#pragma unroll
+            for (int m = 1; m < 8; ++m) {
+                const int J = s + m;
+                if (J <= w) {
+                    const double* Bj = (J == w) ? Aw : Lb + (J * (J - 1) / 2 + s) * 256;
+                    double bv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bv[q] = Bj[swz16(lc, 4 * q + lr)];
+                    v4d c = { t[m][0], t[m][1], t[m][2], t[m][3] };
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], c, 0, 0, 0);
+                    t[m][0] = c[0]; t[m][1] = c[1]; t[m][2] = c[2]; t[m][3] = c[3];
+                }
+            }
+        }
+        // shift: block (w, s + 1 + m) moves to place m
+#pragma unroll
+        for (int m = 0; m < 7; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[m][q] = t[m + 1][q];
+    }
+    __syncthreads();
+    // ---- inverse: wave w = block column J of X = inv(L); t[I] = X_IJ in the accumulator layout (re-uses the tile's registers)
+    {
+        const int J = w;
+        const double* DJ = Di + J * 256;
+#pragma unroll
+        for (int I = 0; I < 8; ++I)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[I][q] = 0.0;
+#pragma unroll
+        for (int I = 0; I < 8; ++I) {
+            if (I == J) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t[I][q] = DJ[swz16(4 * q + lr, lc)];
+            } else if (I > J) {
+                v4d acc = { 0.0, 0.0, 0.0, 0.0 }, acc2 = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                for (int K = 0; K < I; ++K) {
+                    if (K >= J) {
+                        const double* Lik = Lb + (I * (I - 1) / 2 + K) * 256;
+                        double av[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) av[q] = Lik[swz16(lc, 4 * q + lr)];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], t[K][0], acc, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], t[K][1], acc2, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], t[K][2], acc, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], t[K][3], acc2, 0, 0, 0);
+                    }
+                }
+                double sacc[4] = { acc[0] + acc2[0], acc[1] + acc2[1], acc[2] + acc2[2], acc[3] + acc2[3] };
+                const double* DI = Di + I * 256;
+                v4d res = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                for (int q = 0; q < 4; ++q) res = __builtin_amdgcn_mfma_f64_16x16x4f64(DI[swz16(lc, 4 * q + lr)], sacc[q], res, 0, 0, 0);
+                t[I][0] = -res[0]; t[I][1] = -res[1]; t[I][2] = -res[2]; t[I][3] = -res[3];
+            }
+        }
+        double* Wk = a.Linv + (size_t)k * FLOW_TL;
+#pragma unroll
+        for (int I = 0; I < 8; ++I) {
+            if (I >= J) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) st_sc1(Wk + (size_t)(16 * I + 4 * q + lr) * POTRF_NB + 16 * J + lc, t[I][q]);
+            }
+        }
+    }
+#undef BSFM_RDLANE
+#undef BSFM_LDS_FENCE
+}
+
+constexpr long long FLOW_SPIN_LIMIT_TICKS = 40LL * 1000 * 1000;      // 0.4 s of the 100 MHz wall clock: far beyond any solve this library accepts
+
+__global__ __launch_bounds__(512, 4) void k_chol_flow(FlowArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ unsigned s_ticket;
+    __shared__ int s_abort;
+    const int tid = threadIdx.x;
+    for (;;) {
+        long long st0 = 0;
+        if (tid == 0) {
+            s_ticket = atomicAdd(a.ticket, 1u);
+            s_abort = 0;
+            if (a.trace) st0 = wall_clock64();
+        }
+        __syncthreads();
+        const unsigned tk = __builtin_amdgcn_readfirstlane(s_ticket);
+        if (tk >= a.t_end) {
+            // give the ticket back for the next chunk's launch: the counter must end at exactly t_end
+            if (tid == 0) atomicSub(a.ticket, 1u);
+            return;
+        }
+        const FlowTask* tp = a.tasks + tk;
+        const uint32_t w0 = *reinterpret_cast<const uint32_t*>(tp);               // type | np << 8 | part << 16 | nwait << 24
+        const uint32_t w1 = *(reinterpret_cast<const uint32_t*>(tp) + 1);         // i | j << 16
+        const uint32_t w2 = *(reinterpret_cast<const uint32_t*>(tp) + 2);         // p0 | pad << 16
+        const int type = __builtin_amdgcn_readfirstlane((int)(w0 & 255u)), np = __builtin_amdgcn_readfirstlane((int)((w0 >> 8) & 255u));
+        const int part = __builtin_amdgcn_readfirstlane((int)((w0 >> 16) & 255u)), nwait = __builtin_amdgcn_readfirstlane((int)(w0 >> 24));
+        const int ti = __builtin_amdgcn_readfirstlane((int)(w1 & 0xffffu)), tj = __builtin_amdgcn_readfirstlane((int)(w1 >> 16));
+        const int p0 = __builtin_amdgcn_readfirstlane((int)(w2 & 0xffffu));
+        if (tid == 0) {
+            const long long t_begin = wall_clock64();
+            for (int q = 0; q < nwait; ++q) {
+                const unsigned idx = tp->w[q].idx, thr = tp->w[q].thr;
+                unsigned spins = 0;
+                while (__hip_atomic_load(a.flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < thr) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 63u) == 0u) {
+                        if (__hip_atomic_load(a.ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                            wall_clock64() - t_begin > FLOW_SPIN_LIMIT_TICKS) {
+                            __hip_atomic_store(a.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            s_abort = 1;
+                            break;
+                        }
+                    }
+                }
+                if (s_abort) break;
+            }
+            if (a.trace) { a.trace[4 * (size_t)tk + 0] = st0; a.trace[4 * (size_t)tk + 1] = wall_clock64(); }
+        }
+        __syncthreads();
+        if (s_abort) return;
+        switch (type) {
+        case FT_POTRF:  flow_potrf(a, tj, lds); break;
+        case FT_TRSM32: flow_tile32<false>(a, ti, tj, 0, 0, part, lds); break;
+        case FT_TRSM64: flow_trsm64(a, ti, tj, 64 * part, lds); break;
+        case FT_UPD32:  flow_tile32<true>(a, ti, tj, p0, np, part, lds); break;
+        case FT_UPD64:  flow_upd<64>(a, ti, tj, p0, np, 64 * part, lds); break;
+        case FT_UPD128: flow_upd<128>(a, ti, tj, p0, np, 0, lds); break;
+        case FT_FTRSM:  flow_ftrsm(a, tj, lds); break;
+        case FT_FUPD:   flow_fupd(a, tj, p0, np); break;
+        default: break;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave drains its write-through stores
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(a.flags + tp->sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.trace) {
+                a.trace[4 * (size_t)tk + 2] = wall_clock64();
+                unsigned xcc = 0;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                a.trace[4 * (size_t)tk + 3] = (long long)(xcc & 15u) | ((long long)blockIdx.x << 8);
+            }
+        }
+    }
+}
+
+// Backward substitution x = L^-T y, one persistent launch (k_bwd_persistent of potrf.hip.h reading the compact panel tiles).
+__global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc, int nblk, const double* __restrict__ Linv,
+        const double* __restrict__ y, double* x, int* flags, int* timeout, const int* __restrict__ last_row)
+{
+    __shared__ double yk[POTRF_NB];
+    __shared__ double xi[POTRF_NB];
+    __shared__ double red[POTRF_NB];
+    const int kk = nblk - 1 - (int)blockIdx.x;
+    const int c = threadIdx.x & 127, h = threadIdx.x >> 7;
+    double lreg[64], tcur[64];
+    {
+        const double* Li = Linv + (size_t)kk * FLOW_TL + (size_t)(64 * h) * POTRF_NB + c;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) lreg[r] = Li[(size_t)r * POTRF_NB];
+    }
+    if (threadIdx.x < POTRF_NB) yk[threadIdx.x] = y[(size_t)kk * POTRF_NB + threadIdx.x];
+    __syncthreads();
+    const int itop = last_row ? last_row[kk] : nblk - 1;
+    for (int i = itop; i > kk; --i) {
+        {
+            const double* Lc = Pc + flow_tri(i, kk) * FLOW_TL + (size_t)(64 * h) * POTRF_NB + c;
+#pragma unroll
+            for (int r = 0; r < 64; ++r) tcur[r] = Lc[(size_t)r * POTRF_NB];
+        }
+        if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(&flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 26)) { atomicExch(timeout, 1); break; }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < POTRF_NB)
+            xi[threadIdx.x] = __hip_atomic_load(&x[(size_t)i * POTRF_NB + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        double sacc = 0.0;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) sacc += tcur[r] * xi[64 * h + r];
+        if (h == 1) red[c] = sacc;
+        __syncthreads();
+        if (h == 0) yk[c] -= sacc + red[c];
+        __syncthreads();
+    }
+    double sacc = 0.0;
+#pragma unroll
+    for (int r = 0; r < 64; ++r) sacc += lreg[r] * yk[64 * h + r];
+    if (h == 1) red[c] = sacc;
+    __syncthreads();
+    if (h == 0) __hip_atomic_store(&x[(size_t)kk * POTRF_NB + c], sacc + red[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&flags[kk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void k_flow_fold_timeout(const unsigned* __restrict__ ticket, const int* __restrict__ bwd_timeout, int* __restrict__ info)
+{
+    if (ticket[1] != 0u || *bwd_timeout != 0) *info = POTRF_INFO_TIMEOUT;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct FlowWorkspace {
+    int nblk = 0;                          // tiles the buffers were sized for
+    std::vector<int> env_key;              // envelope the schedule was built for
+    FlowSchedule sched;
+    FlowTask* d_tasks = nullptr;
+    unsigned* d_sync = nullptr;            // [ticket, time-out, 2 spare] + counters
+    double* pc = nullptr;                  // compact panel tiles
+    long long* d_trace = nullptr;
+    int chunk_cols = 0;                    // 0: one launch; n: a launch per n tile columns (BSFM_FLOW_CHUNK)
+    int wgs = 512;                         // resident workgroups (BSFM_FLOW_WGS)
+    bool trace = false;                    // BSFM_FLOW_TRACE=1: per-task stamps, dumped to BSFM_FLOW_TRACE_FILE after every solve
+    double flops = 0.0;                    // flops of one factorisation as scheduled (UPD + TRSM tile products, 2 * 128^3 each)
+    hipEvent_t k0 = nullptr, k1 = nullptr; // around the k_chol_flow launch(es): the roofline kernel's duration
+    double kern_ms = 0.0; long long kern_cnt = 0; bool kern_pending = false;
+};
+
+inline void flow_free(FlowWorkspace& f)
+{
+    bsfm::dev_free(f.d_tasks, true); bsfm::dev_free(f.d_sync, true); bsfm::dev_free(f.pc, true);
+    if (f.d_trace) (void)hipFree(f.d_trace);
+    if (f.k0) (void)hipEventDestroy(f.k0);
+    if (f.k1) (void)hipEventDestroy(f.k1);
+    f = FlowWorkspace();
+}
+
+inline FlowParams flow_params_from_env()
+{
+    FlowParams p;
+    if (const char* e = getenv("BSFM_FLOW_NPMAX")) p.np_max = std::max(1, std::min(8, atoi(e)));
+    if (const char* e = getenv("BSFM_FLOW_SLOTS")) p.slots = std::max(32, atoi(e));
+    if (const char* e = getenv("BSFM_FLOW_URGENT")) p.urgent_cols = std::max(0, atoi(e));
+    return p;
+}
+
+// (Re)builds the schedule for nblk tile columns and the given envelope (empty = dense) and uploads it.
+inline int flow_prepare(FlowWorkspace& f, int nblk, const std::vector<int>& env_rows)
+{
+    std::vector<int> key;
+    if ((int)env_rows.size() >= nblk) { key.resize((size_t)nblk); for (int k = 0; k < nblk; ++k) key[k] = k + env_rows[k]; }
+    if (f.d_tasks && f.nblk == nblk && f.env_key == key) return 0;
+    bsfm::dev_free(f.d_tasks, true); f.d_tasks = nullptr;
+    bsfm::dev_free(f.d_sync, true); f.d_sync = nullptr;
+    if (f.nblk != nblk) { bsfm::dev_free(f.pc, true); f.pc = nullptr; }
+    if (const char* e = getenv("BSFM_FLOW_CHUNK")) f.chunk_cols = std::max(0, atoi(e));
+    if (const char* e = getenv("BSFM_FLOW_WGS")) f.wgs = std::max(1, atoi(e));
+    if (const char* e = getenv("BSFM_FLOW_TRACE")) f.trace = atoi(e) != 0;
+    if (flow_build_schedule(nblk, key, flow_params_from_env(), f.sched) != 0) return -1;
+    if (flow_check_schedule(f.sched) != 0) { fprintf(stderr, "[bsfm] flow schedule failed its dependency check\n"); return -1; }
+    f.nblk = nblk; f.env_key = key;
+    const size_t nt = f.sched.tasks.size();
+    if (bsfm::dev_alloc((void**)&f.d_tasks, nt * sizeof(FlowTask)) != hipSuccess) return -1;
+    if (hipMemcpy(f.d_tasks, f.sched.tasks.data(), nt * sizeof(FlowTask), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (bsfm::dev_alloc((void**)&f.d_sync, (4 + (size_t)f.sched.nflags) * sizeof(unsigned)) != hipSuccess) return -1;
+    if (!f.pc) {
+        const size_t ntile = std::max<size_t>(1, (size_t)nblk * (size_t)(nblk - 1) / 2);
+        if (bsfm::dev_alloc((void**)&f.pc, ntile * FLOW_TL * sizeof(double)) != hipSuccess) return -1;
+    }
+    if (f.trace) {
+        if (f.d_trace) (void)hipFree(f.d_trace);
+        if (hipMalloc((void**)&f.d_trace, nt * 4 * sizeof(long long)) != hipSuccess) return -1;
+    }
+    f.flops = (f.sched.upd_tiles + f.sched.trsm_tiles) * 2.0 * POTRF_NB * POTRF_NB * POTRF_NB;
+    if (!f.k0) { (void)hipEventCreate(&f.k0); (void)hipEventCreate(&f.k1); }
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_flow), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(FLOW_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    return 0;
+}
+
+inline void flow_dump_trace(FlowWorkspace& f, hipStream_t st)
+{
+    const char* path = getenv("BSFM_FLOW_TRACE_FILE");
+    if (!f.trace || !f.d_trace || !path) return;
+    (void)hipStreamSynchronize(st);
+    const size_t nt = f.sched.tasks.size();
+    std::vector<long long> h(nt * 4);
+    if (hipMemcpy(h.data(), f.d_trace, nt * 4 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return;
+    FILE* fp = fopen(path, "w");
+    if (!fp) return;
+    long long t0 = h[0];
+    for (size_t q = 0; q < nt; ++q) t0 = std::min(t0, h[4 * q]);
+    fprintf(fp, "# ticket type i j p0 np part  t_ticket t_ready t_done (us since the first ticket)  xcc wg\n");
+    for (size_t q = 0; q < nt; ++q) {
+        const FlowTask& t = f.sched.tasks[q];
+        fprintf(fp, "%zu %d %d %d %d %d %d %.2f %.2f %.2f %lld %lld\n", q, t.type, t.i, t.j, t.p0, t.np, t.part,
+                (h[4 * q] - t0) * 0.01, (h[4 * q + 1] - t0) * 0.01, (h[4 * q + 2] - t0) * 0.01, h[4 * q + 3] & 15, h[4 * q + 3] >> 8);
+    }
+    fclose(fp);
+}
+
+// Solves S x = E (n valid rows, S padded to ld); S is destroyed, E is preserved.  info: 0, dpotrf's k, or POTRF_INFO_TIMEOUT.
+inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, int n, const double* E, double* x_out, int* d_info, hipStream_t st)
+{
+    const int nblk = (n + POTRF_NB - 1) / POTRF_NB;
+    if (flow_prepare(f, nblk, w.env_rows) != 0) return -1;
+    const size_t nt = f.sched.tasks.size();
+    (void)hipMemsetAsync(f.d_sync, 0, (4 + (size_t)f.sched.nflags) * sizeof(unsigned), st);
+    (void)hipMemsetAsync(w.etmp, 0, (size_t)ld * sizeof(double), st);
+    (void)hipMemcpyAsync(w.etmp, E, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
+    FlowArgs a;
+    a.S = S; a.ld = ld; a.n_total = n; a.T = nblk; a.Pc = f.pc; a.Linv = w.linv; a.E = w.etmp; a.y = w.y;
+    a.tasks = f.d_tasks; a.ticket = f.d_sync; a.flags = f.d_sync + 4; a.info = d_info; a.trace = f.trace ? f.d_trace : nullptr;
+    const size_t lds_bytes = FLOW_LDS_DOUBLES * sizeof(double);
+    const bool timed = w.timing && f.k0;
+    if (timed) {
+        if (f.kern_pending) { float ms = 0.f; if (hipEventElapsedTime(&ms, f.k0, f.k1) == hipSuccess && ms >= 0.f) { f.kern_ms += ms; f.kern_cnt++; } f.kern_pending = false; }
+        (void)hipEventRecord(f.k0, st);
+    }
+    if (f.chunk_cols <= 0) {
+        a.t_end = (unsigned)nt;
+        hipLaunchKernelGGL(k_chol_flow, dim3((unsigned)std::min<size_t>((size_t)f.wgs, nt)), dim3(512), lds_bytes, st, a);
+    } else {
+        for (int k0 = 0; k0 < nblk; k0 += f.chunk_cols) {
+            const int k1 = k0 + f.chunk_cols;
+            const size_t t0 = (size_t)f.sched.stage_start[(size_t)k0];
+            const size_t t1 = k1 < nblk ? (size_t)f.sched.stage_start[(size_t)k1] : nt;
+            a.t_end = (unsigned)t1;
+            if (t1 > t0) hipLaunchKernelGGL(k_chol_flow, dim3((unsigned)std::min<size_t>((size_t)f.wgs, t1 - t0)), dim3(512), lds_bytes, st, a);
+        }
+    }
+    if (timed) { (void)hipEventRecord(f.k1, st); f.kern_pending = true; }
+    // backward substitution
+    const bool env = (int)w.env_rows.size() >= nblk && w.d_last != nullptr;
+    (void)hipMemsetAsync(w.bflags, 0, (size_t)(w.nblk + 1) * sizeof(int), st);
+    hipLaunchKernelGGL(k_bwd_flow, dim3(nblk), dim3(256), 0, st, (const double*)f.pc, nblk, (const double*)w.linv, (const double*)w.y, w.xs,
+                       w.bflags, w.bflags + w.nblk, (const int*)(env ? w.d_last : nullptr));
+    hipLaunchKernelGGL(k_flow_fold_timeout, dim3(1), dim3(1), 0, st, (const unsigned*)f.d_sync, (const int*)(w.bflags + w.nblk), d_info);
+    (void)hipMemcpyAsync(x_out, w.xs, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
+    if (f.trace) flow_dump_trace(f, st);
+    return 0;
+}
+
+inline int flow_solve_dispatch(PotrfWorkspace& w, double* S, int ld, int n, const double* E, double* x_out, int* d_info, hipStream_t st)
+{
+    if (!w.flow) w.flow = new FlowWorkspace();
+    return flow_solve(w, *w.flow, S, ld, n, E, x_out, d_info, st);
+}
+inline void flow_release(PotrfWorkspace& w)
+{
+    if (w.flow) { flow_free(*w.flow); delete w.flow; w.flow = nullptr; }
+}
+
+inline void flow_collect_time(FlowWorkspace& f)
+{
+    if (f.kern_pending) { float ms = 0.f; if (hipEventElapsedTime(&ms, f.k0, f.k1) == hipSuccess && ms >= 0.f) { f.kern_ms += ms; f.kern_cnt++; } f.kern_pending = false; }
+}
+
+}  // namespace bsfm

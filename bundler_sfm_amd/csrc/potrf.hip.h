@@ -93,7 +93,14 @@ constexpr int G64_STRIDE = G64_KC + 2;
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+struct FlowWorkspace;          // chol_flow.hip.h: the tile-dataflow factorisation (round 4, the default for systems of two or more tiles)
+struct PotrfWorkspace;
+inline int flow_solve_dispatch(PotrfWorkspace& w, double* S, int ld, int n, const double* E, double* x_out, int* d_info, hipStream_t st);
+inline void flow_release(PotrfWorkspace& w);
+
 struct PotrfWorkspace {
+    FlowWorkspace* flow = nullptr;
+    int use_flow = 1;           // BSFM_CHOL=streams selects the three-stream schedule of rounds 1-3 below (kept as the A/B reference)
     int ld = 0, nblk = 0, backend = 0;
     double* panel = nullptr;   // 4 x (nblk-1) tiles of NB x NB: compact copies of the last panels (ring, k & 3)
     hipStream_t s2 = nullptr;  // bulk-update stream of the lookahead schedule
@@ -1050,6 +1057,7 @@ __global__ void k_fold_timeout(const int* __restrict__ timeout, int* __restrict_
 // ------------------------------------------------------------------------------------------------
 inline void potrf_free(PotrfWorkspace& w)
 {
+    flow_release(w);
     bsfm::dev_free(w.panel, true);
     bsfm::dev_free(w.linv, true);
     bsfm::dev_free(w.y, true);
@@ -1105,6 +1113,8 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
         if (hipEventCreateWithFlags(&w.evC[i], hipEventDisableTiming) != hipSuccess) return -1;
     }
     if (bsfm::dev_alloc((void**)&w.linv, (size_t)w.nblk * tile * sizeof(double)) != hipSuccess) return -1;
+    if (hipMemset(w.linv, 0, (size_t)w.nblk * tile * sizeof(double)) != hipSuccess) return -1;      // the dataflow POTRF never writes the (zero) upper triangle of an inverse factor
+    if (const char* e = getenv("BSFM_CHOL")) w.use_flow = strcmp(e, "streams") != 0;
     if (bsfm::dev_alloc((void**)&w.y, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
     if (bsfm::dev_alloc((void**)&w.xs, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
     if (bsfm::dev_alloc((void**)&w.etmp, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
@@ -1166,6 +1176,11 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         hipLaunchKernelGGL(k_potrf_solve_one, dim3(1), dim3(512), DG_LDS_DOUBLES * sizeof(double), st, S, ld, n, w.linv, d_info, E, x_out);
         if (w.ev1 && w.timing) (void)hipEventRecord(w.ev1, st);
         return 0;
+    }
+    if (w.use_flow) {
+        const int rc = flow_solve_dispatch(w, S, ld, n, E, x_out, d_info, st);
+        if (w.ev1 && w.timing) (void)hipEventRecord(w.ev1, st);
+        return rc;
     }
     const size_t lds_bytes = 2 * 128 * GEMM_LDS_STRIDE * sizeof(double);
     (void)hipMemsetAsync(w.etmp, 0, (size_t)ld * sizeof(double), st);

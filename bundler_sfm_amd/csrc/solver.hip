@@ -29,6 +29,7 @@
 #include "kernels.hip.h"
 #include "schur.hip.h"
 #include "potrf.hip.h"
+#include "chol_flow.hip.h"
 #include "compsolve.hip.h"
 
 using namespace bsfm;
@@ -1586,6 +1587,22 @@ int bsfm_eval_normal_equations(bsfm_problem_t* pb, double mu, double* U, double*
                                           (size_t)pb->Sdim * sizeof(double), pb->Sdim, hipMemcpyDeviceToHost));
     if (E && pb->Sdim) HIP_OK(hipMemcpy(E, pb->d_E, (size_t)pb->Sdim * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
+}
+
+int bsfm_chol_flow_schedule(int nblk, const int* last, int np_max, int slots, void* tasks_out, int capacity, double* sim_us)
+{
+    if (nblk <= 0) return -1;
+    FlowParams prm = flow_params_from_env();
+    if (np_max > 0) prm.np_max = std::min(8, np_max);
+    if (slots > 0) prm.slots = slots;
+    std::vector<int> lv;
+    if (last) lv.assign(last, last + nblk);
+    FlowSchedule sc;
+    if (flow_build_schedule(nblk, lv, prm, sc) != 0 || flow_check_schedule(sc) != 0) return -1;
+    if (sim_us) *sim_us = sc.sim_us;
+    const int nt = (int)sc.tasks.size();
+    if (tasks_out) memcpy(tasks_out, sc.tasks.data(), (size_t)std::min(nt, std::max(0, capacity)) * sizeof(FlowTask));
+    return nt;
 }
 
 int bsfm_dense_chol_solve(int n, const double* A, const double* b, double* x, int backend)

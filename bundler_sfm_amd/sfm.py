@@ -366,6 +366,27 @@ class Problem:
         return out
 
 
+FLOW_TASK_DTYPE = np.dtype([("type", "u1"), ("np", "u1"), ("part", "u1"), ("nwait", "u1"), ("i", "<u2"), ("j", "<u2"), ("p0", "<u2"),
+                            ("pad", "<u2"), ("sig", "<u4"), ("w", "<u4", (3, 2))])
+
+
+def chol_flow_schedule(nblk, last=None, np_max=0, slots=0):
+    """Static task order of the tile-dataflow Cholesky (csrc/chol_flow_sched.h); host only.  Returns (tasks, simulated microseconds)."""
+    lastp = None
+    if last is not None:
+        last = np.ascontiguousarray(last, np.int32)
+        lastp = last.ctypes.data_as(C.POINTER(C.c_int))
+    sim = C.c_double(0.0)
+    n = lib.bsfm_chol_flow_schedule(nblk, lastp, np_max, slots, None, 0, C.byref(sim))
+    if n < 0:
+        raise RuntimeError("bsfm_chol_flow_schedule failed its dependency check")
+    tasks = np.zeros(n, FLOW_TASK_DTYPE)
+    assert tasks.itemsize == 40
+    n2 = lib.bsfm_chol_flow_schedule(nblk, lastp, np_max, slots, tasks.ctypes.data_as(C.c_void_p), n, C.byref(sim))
+    assert n2 == n
+    return tasks, sim.value
+
+
 def dense_chol_solve(A, b, backend=0):
     A = np.ascontiguousarray(A, np.float64)
     b = np.ascontiguousarray(b, np.float64)

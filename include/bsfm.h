@@ -309,6 +309,14 @@ int bsfm_eval_normal_equations(bsfm_problem_t *pb, double mu, double *U, double 
 /* Dense SPD solve on the device with the production Cholesky: A (n x n, symmetric, row-major, host),
  * b (n) -> x (n). Returns 0, or k>0 if the leading minor k is not positive definite (dpotrf's info). */
 int bsfm_dense_chol_solve(int n, const double *A, const double *b, double *x, int backend);
+/* Test / diagnostic hook (no device needed): the static task order of the tile-dataflow Cholesky (csrc/chol_flow_sched.h) for a
+ * system of nblk tile columns.  last[k] (NULL = dense) = last tile row of column k's envelope.  tasks_out (NULL to query the
+ * count) receives 40-byte records { u8 type, np, part, nwait; u16 i, j, p0, pad; u32 sig; { u32 idx, thr } w[3] }: task types
+ * 0 POTRF, 1 TRSM32 (16 parts), 2 TRSM64 (2), 3 UPD32 (10), 4 UPD64 (2), 5 UPD128, 6 FTRSM, 7 FUPD; a task waits until counter
+ * w[q].idx >= w[q].thr for its nwait conditions and increments counter sig when done; counter of tile (i, j) = i * nblk + j, row
+ * nblk = the right-hand side.  np_max / slots <= 0 select the defaults.  Returns the number of tasks, or -1 when the builder
+ * fails its own dependency check (every wait must be satisfiable by tasks that come EARLIER in the order). */
+int bsfm_chol_flow_schedule(int nblk, const int *last, int np_max, int slots, void *tasks_out, int capacity, double *sim_us);
 
 /* ---- 3b. batched multi-view triangulation -------------------------------------------- */
 /* npoints independent points; point i owns views view_ptr[i] .. view_ptr[i+1]-1.  View v observes the normalised image

@@ -1,0 +1,195 @@
+"""Static task order of the tile-dataflow Cholesky (bundler_sfm_amd/csrc/chol_flow_sched.h), checked on the CPU.
+
+The product hands the tasks of this order to workgroups by an atomic ticket; each task spins until the counters it names have
+reached its thresholds.  Two properties make that scheme correct, and both are tested here without a GPU:
+  * structure: every wait is satisfiable by tasks EARLIER in the order (=> ticket order cannot deadlock);
+  * semantics: executing the tasks -- in ticket order, or in ANY interleaving that respects only the waits, with any number of
+    workers -- yields the Cholesky factor, y = L^-1 E and nothing else: a numpy replay with a small tile size against
+    numpy.linalg (the reference's dpotrf("U") + dpotrs, lib/sba-1.5/sba_lapack.c:374-485, is the same factorisation).
+"""
+import numpy as np
+import pytest
+
+import bundler_sfm_amd.sfm as B
+
+POTRF, TRSM32, TRSM64, UPD32, UPD64, UPD128, FTRSM, FUPD = range(8)
+
+
+def lower_blocks32():
+    out = []
+    for br in range(4):
+        for bc in range(br + 1):
+            out.append((br, bc))
+    return out
+
+
+class Replay:
+    """numpy semantics of every task type on an nb x nb tiling (nb divisible by 4)."""
+
+    def __init__(self, T, nb, A, b):
+        self.T, self.nb = T, nb
+        self.S = np.tril(A).copy()          # only the lower triangle is ever read
+        self.E = b.copy()
+        self.P = {}                         # (i, k) -> panel tile, filled block by block
+        self.W = {}
+        self.y = np.zeros_like(b)
+        self.flags = np.zeros((T + 1) * T, np.int64)
+
+    def tile(self, i, j):
+        nb = self.nb
+        return self.S[i * nb:(i + 1) * nb, j * nb:(j + 1) * nb]
+
+    def ready(self, t):
+        return all(self.flags[t["w"][q][0]] >= t["w"][q][1] for q in range(t["nwait"]))
+
+    def run(self, t):
+        nb, T = self.nb, self.T
+        ty, i, j, p0, npn, part = int(t["type"]), int(t["i"]), int(t["j"]), int(t["p0"]), int(t["np"]), int(t["part"])
+        h, q4 = nb // 2, nb // 4
+        if ty == POTRF:
+            Sjj = self.tile(j, j)
+            L = np.linalg.cholesky(np.tril(Sjj) + np.tril(Sjj, -1).T)
+            self.W[j] = np.linalg.inv(L)
+        elif ty in (TRSM32, TRSM64):
+            P = self.P.setdefault((i, j), np.full((nb, nb), np.nan))
+            full = self.tile(i, j) @ self.W[j].T
+            if ty == TRSM64:
+                P[part * h:(part + 1) * h] = full[part * h:(part + 1) * h]
+            else:
+                br, bc = part >> 2, part & 3
+                P[br * q4:(br + 1) * q4, bc * q4:(bc + 1) * q4] = full[br * q4:(br + 1) * q4, bc * q4:(bc + 1) * q4]
+        elif ty in (UPD32, UPD64, UPD128):
+            C = self.tile(i, j)
+            upd = np.zeros((nb, nb))
+            for p in range(p0, p0 + npn):
+                Pi, Pj = self.P[(i, p)], self.P[(j, p)]
+                assert not np.isnan(Pi).any() and not np.isnan(Pj).any(), "panel tile read before it was complete"
+                upd += Pi @ Pj.T
+            if ty == UPD128:
+                C -= upd
+            elif ty == UPD64:
+                C[part * h:(part + 1) * h] -= upd[part * h:(part + 1) * h]
+            else:
+                assert i == j
+                br, bc = lower_blocks32()[part]
+                C[br * q4:(br + 1) * q4, bc * q4:(bc + 1) * q4] -= upd[br * q4:(br + 1) * q4, bc * q4:(bc + 1) * q4]
+        elif ty == FTRSM:
+            self.y[j * nb:(j + 1) * nb] = self.W[j] @ self.E[j * nb:(j + 1) * nb]
+        elif ty == FUPD:
+            for p in range(p0, p0 + npn):
+                Pj = self.P[(j, p)]
+                assert not np.isnan(Pj).any()
+                self.E[j * nb:(j + 1) * nb] -= Pj @ self.y[p * nb:(p + 1) * nb]
+        else:
+            raise AssertionError(ty)
+        self.flags[t["sig"]] += 1
+
+
+def spd_with_envelope(T, nb, last, seed):
+    """SPD matrix whose tile (i, j) is non-zero only for i <= last[j] (banded / ragged envelopes), diagonally dominant."""
+    rng = np.random.default_rng(seed)
+    n = T * nb
+    A = np.zeros((n, n))
+    for j in range(T):
+        for i in range(j, last[j] + 1):
+            blk = rng.standard_normal((nb, nb))
+            A[i * nb:(i + 1) * nb, j * nb:(j + 1) * nb] = blk
+    A = np.tril(A)
+    A = A + A.T
+    A[np.diag_indices(n)] = np.abs(A).sum(axis=1) + 1.0
+    return A, rng.standard_normal(n)
+
+
+def check_result(rp, A, b, last):
+    T, nb = rp.T, rp.nb
+    L = np.linalg.cholesky(A)
+    for (i, k), P in rp.P.items():
+        assert np.abs(P - L[i * nb:(i + 1) * nb, k * nb:(k + 1) * nb]).max() <= 1e-9 * np.abs(L).max(), (i, k)
+    for k in range(T):
+        assert np.abs(rp.W[k] - np.linalg.inv(L[k * nb:(k + 1) * nb, k * nb:(k + 1) * nb])).max() <= 1e-9
+        for i in range(k + 1, T):
+            if i <= last[k]:
+                assert (i, k) in rp.P
+            else:
+                assert np.abs(L[i * nb:(i + 1) * nb, k * nb:(k + 1) * nb]).max() <= 1e-12      # outside the envelope the factor is zero
+    yref = np.linalg.solve(L, b)
+    assert np.abs(rp.y - yref).max() <= 1e-9 * np.abs(yref).max()
+
+
+def closed(last):
+    last = list(last)
+    T = len(last)
+    for p in range(T):
+        for j in range(p + 1, last[p] + 1):
+            last[j] = max(last[j], last[p])
+    return last
+
+
+CASES = [
+    ("dense2", 2, None), ("dense3", 3, None), ("dense7", 7, None), ("dense12", 12, None),
+    ("band2", 10, [min(9, k + 2) for k in range(10)]),
+    ("band1", 9, [min(8, k + 1) for k in range(9)]),
+    ("blockdiag", 8, [1, 1, 3, 3, 5, 5, 7, 7]),
+    ("ragged", 11, [3, 1, 6, 3, 4, 9, 6, 10, 8, 10, 10]),
+    ("diagonal", 5, [0, 1, 2, 3, 4]),
+]
+
+
+@pytest.mark.parametrize("name,T,last", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("np_max", [1, 4])
+def test_schedule_replays_to_the_cholesky_factor(name, T, last, np_max):
+    tasks, sim = B.chol_flow_schedule(T, last, np_max=np_max)
+    lastc = closed(last) if last is not None else [T - 1] * T
+    nb = 8
+    A, b = spd_with_envelope(T, nb, lastc, seed=T * 131 + np_max)
+    # (1) ticket order, one worker
+    rp = Replay(T, nb, A, b)
+    for t in tasks:
+        assert rp.ready(t), "a task's wait is not satisfied by the tasks before it"
+        rp.run(t)
+    check_result(rp, A, b, lastc)
+    # every tile of the envelope was finalised exactly once, every counter ends where its last waiter expects it
+    types = tasks["type"]
+    assert (types == POTRF).sum() == T and (types == FTRSM).sum() == T
+    assert len(rp.P) == sum(lastc[k] - k for k in range(T))
+    # (2) random interleavings that respect ONLY the waits (tickets are drawn in order, execution is not)
+    rng = np.random.default_rng(7)
+    for workers in (2, 5, 64, 600):
+        rp = Replay(T, nb, A, b)
+        held, nxt, done = [], 0, 0
+        while done < len(tasks):
+            while len(held) < workers and nxt < len(tasks):
+                held.append(nxt); nxt += 1
+            runnable = [k for k in held if rp.ready(tasks[k])]
+            assert runnable, "deadlock: every worker holds a task whose waits cannot be met"
+            k = runnable[rng.integers(len(runnable))]
+            rp.run(tasks[k]); held.remove(k); done += 1
+        check_result(rp, A, b, lastc)
+
+
+def test_schedule_is_deterministic_and_merges_panels():
+    a, sa = B.chol_flow_schedule(24, None, np_max=4)
+    b, sb = B.chol_flow_schedule(24, None, np_max=4)
+    assert sa == sb and a.tobytes() == b.tobytes()
+    # the bulk falls behind the chain on a system this size: some visits apply several panels in one pass over the tile
+    bulk = a[a["type"] == UPD128]
+    assert len(bulk) > 0
+    # work conservation: every tile (i, j) receives each of its j panels exactly once
+    T = 24
+    seen = {}
+    for t in a[np.isin(a["type"], [UPD32, UPD64, UPD128])]:
+        if t["part"] != 0:
+            continue
+        for p in range(t["p0"], t["p0"] + t["np"]):
+            key = (int(t["i"]), int(t["j"]), p)
+            assert key not in seen
+            seen[key] = 1
+    assert len(seen) == sum(j for j in range(T) for i in range(j, T))
+
+
+def test_headline_size_schedule_builds_quickly():
+    import time
+    t0 = time.time()
+    tasks, sim = B.chol_flow_schedule(71)
+    assert time.time() - t0 < 2.0
+    assert 20000 < len(tasks) < 200000 and 3000.0 < sim < 12000.0
