@@ -42,13 +42,26 @@ struct FlowArgs {
     double* Linv;          // W_k = inv(L_kk), tile k (upper triangle stays zero: cleared once at allocation)
     double* E;             // right-hand side (working copy, ld)
     double* y;             // y = L^-1 E
-    const FlowTask* tasks;
-    unsigned t_end;        // tickets >= t_end end the workgroup (chunked launches: the ticket counter carries over)
-    unsigned* ticket;      // [0] ticket counter, [1] time-out word
-    unsigned* flags;       // per-tile counters
+    const FlowTask* tasks;        // bulk queue
+    const FlowTask* chain_tasks;  // chain queue
+    unsigned n_bulk, n_chain;
+    unsigned n_chain_wgs;  // workgroups that serve the chain queue, each alone on its CU (0: one queue order is not split -- n_chain must be 0 then)
+    unsigned* sync;        // [0] bulk ticket, [1] time-out word, [2] chain ticket, [3] chain claims, [4 .. 4 + nflags) per-tile counters,
+                           // then FLOW_CU_KEYS arrivals per CU and FLOW_CU_KEYS verdicts per CU
+    unsigned nflags;
     int* info;
-    long long* trace;      // optional: 4 stamps per task
+    long long* trace;      // optional: 4 stamps per task (bulk tasks first, then chain tasks), then (from ptrace_ofs) 40 phase stamps per POTRF column
+    unsigned ptrace_ofs;
 };
+constexpr unsigned FLOW_CU_KEYS = 4096;      // XCC (4 bits) | SE (3) | SH (1) | CU (4)
+
+// The heavy roles are separate functions: inlined into one kernel body they share a register allocation and spill (508 bytes of
+// scratch per lane against 24-236 on their own).  BSFM_FLOW_INLINE_ROLES is a bring-up switch of scripts/r4/flow_dbg.hip.
+#ifdef BSFM_FLOW_INLINE_ROLES
+#define BSFM_FLOW_ROLE __forceinline__
+#else
+#define BSFM_FLOW_ROLE __attribute__((noinline))
+#endif
 
 constexpr size_t FLOW_TL = (size_t)POTRF_NB * POTRF_NB;
 __host__ __device__ inline size_t flow_tri(int i, int k) { return (size_t)i * (size_t)(i - 1) / 2 + (size_t)k; }
@@ -56,9 +69,9 @@ __host__ __device__ inline size_t flow_tri(int i, int k) { return (size_t)i * (s
 __device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// ---- LDS budget (doubles).  The POTRF role needs 28 + 8 + 2 blocks of 16 x 16 and the pivot vector; the GEMM roles 2 x 128 x 18.
-constexpr int FLOW_LB = 0, FLOW_DI = 28 * 256, FLOW_LS = 36 * 256, FLOW_SV = 38 * 256;
-constexpr int FLOW_LDS_DOUBLES = 38 * 256 + 128;            // 78 848 bytes: two workgroups per CU (160 KB)
+// ---- LDS budget (doubles).  The POTRF role needs 28 + 8 blocks of 16 x 16; the GEMM roles 2 x 128 x 18.
+constexpr int FLOW_LB = 0, FLOW_DI = 28 * 256;
+constexpr int FLOW_LDS_DOUBLES = 36 * 256;                  // 73 728 bytes: two workgroups per CU (160 KB)
 static_assert(FLOW_LDS_DOUBLES >= 2 * 128 * GEMM_LDS_STRIDE, "GEMM staging must fit");
 static_assert(FLOW_LDS_DOUBLES >= T32_LDS_DOUBLES, "32 x 32 block staging must fit");
 
@@ -130,9 +143,25 @@ __device__ __forceinline__ void flow_gemm_nt(const double* __restrict__ A, int l
 
 // ---- UPD128 / UPD64: rows [r0, r0 + MR) of tile (i, j) -= sum_p P_ip P_jp^T.  The accumulators start as the C tile and the A operand
 // is negated while it is staged, so the matrix cores produce S_ij - P P^T directly (store-only epilogue).
-template <int MR>
-__device__ __attribute__((noinline)) void flow_upd(const FlowArgs& a, int i, int j, int p0, int np, int r0, double* lds)
+// Role arguments are made wave-uniform on entry (v_readfirstlane): arguments of a non-inlined function arrive in VGPRs, and loops /
+// branches on values the compiler takes for lane-divergent are linearised lane by lane -- around barriers that is not a
+// performance matter but a correctness one (see the note at k_chol_flow).
+#define BSFM_UNIFORM_INT(x) x = __builtin_amdgcn_readfirstlane(x)
+__device__ __forceinline__ FlowArgs flow_uniform_args(const FlowArgs& a)
 {
+    FlowArgs u = a;
+    auto up = [](const void* p) { const unsigned long long v = (unsigned long long)p;
+        return (void*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v)); };
+    u.S = (double*)up(a.S); u.Pc = (double*)up(a.Pc); u.Linv = (double*)up(a.Linv); u.E = (double*)up(a.E); u.y = (double*)up(a.y);
+    u.info = (int*)up(a.info); u.trace = (long long*)up(a.trace); u.ptrace_ofs = (unsigned)__builtin_amdgcn_readfirstlane((int)a.ptrace_ofs);
+    u.ld = __builtin_amdgcn_readfirstlane(a.ld); u.n_total = __builtin_amdgcn_readfirstlane(a.n_total); u.T = __builtin_amdgcn_readfirstlane(a.T);
+    return u;
+}
+
+template <int MR>
+__device__ BSFM_FLOW_ROLE void flow_upd(const FlowArgs& a_in, int i, int j, int p0, int np, int r0, double* lds)
+{
+    const FlowArgs a = flow_uniform_args(a_in); BSFM_UNIFORM_INT(i); BSFM_UNIFORM_INT(j); BSFM_UNIFORM_INT(p0); BSFM_UNIFORM_INT(np); BSFM_UNIFORM_INT(r0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = (wave >> 1) * (MR / 4), wc = (wave & 1) * 64;
     double* Sij = a.S + ((size_t)i * POTRF_NB + r0) * a.ld + (size_t)j * POTRF_NB;
@@ -163,8 +192,9 @@ __device__ __attribute__((noinline)) void flow_upd(const FlowArgs& a, int i, int
 }
 
 // ---- TRSM64: rows [r0, r0 + 64) of P_ik = S_ik W_k^T -> compact panel tile.
-__device__ __attribute__((noinline)) void flow_trsm64(const FlowArgs& a, int i, int k, int r0, double* lds)
+__device__ BSFM_FLOW_ROLE void flow_trsm64(const FlowArgs& a_in, int i, int k, int r0, double* lds)
 {
+    const FlowArgs a = flow_uniform_args(a_in); BSFM_UNIFORM_INT(i); BSFM_UNIFORM_INT(k); BSFM_UNIFORM_INT(r0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = (wave >> 1) * 16, wc = (wave & 1) * 64;
     double acc[4][4];
@@ -188,8 +218,9 @@ __device__ __attribute__((noinline)) void flow_trsm64(const FlowArgs& a, int i, 
 //   TRSM32, part = 4 br + bc:  block (br, bc) of P_ik = S_ik W_k^T, K = 32 (bc + 1) (W is lower triangular)
 //   UPD32,  part -> (br, bc), bc <= br:  block of S_jj -= sum_p P_jp P_jp^T
 template <bool IS_UPD>
-__device__ __attribute__((noinline)) void flow_tile32(const FlowArgs& a, int i, int k, int p0, int np, int part, double* lds)
+__device__ BSFM_FLOW_ROLE void flow_tile32(const FlowArgs& a_in, int i, int k, int p0, int np, int part, double* lds)
 {
+    const FlowArgs a = flow_uniform_args(a_in); BSFM_UNIFORM_INT(i); BSFM_UNIFORM_INT(k); BSFM_UNIFORM_INT(p0); BSFM_UNIFORM_INT(np); BSFM_UNIFORM_INT(part);
     int br, bc;
     if (!IS_UPD) { br = part >> 2; bc = part & 3; }
     else { br = part < 1 ? 0 : part < 3 ? 1 : part < 6 ? 2 : 3; bc = part - br * (br + 1) / 2; }
@@ -288,66 +319,147 @@ __device__ __forceinline__ void flow_fupd(const FlowArgs& a, int j, int p0, int 
 }
 
 // ---- POTRF: the diagonal tile, factor and inverse, in the footprint of a bulk workgroup.
-// Wave w holds tile rows 16 w .. 16 w + 15 as eight 16 x 16 blocks in the accumulator layout of v_mfma_f64_16x16x4 (register q of lane
-// l = row 4 q + (l >> 4), column l & 15), so the trailing updates accumulate straight into the tile.  Per block column s:
-//   A1  wave s turns its diagonal block into one-lane-per-row form (through LDS) and factors it: v_readlane broadcasts, 1 / pivot by
-//       v_rcp_f64 + two Newton steps, square roots deferred (the round-1 routine);
-//   A2  every wave below solves its block (I, s) against L_ss, one lane per row, and leaves the finished block of L in LDS;
-//       wave s meanwhile derives inv(L_ss) by the same substitution on the identity;
-//   A3  wave I: block (I, J) -= L_Is L_Js^T for s < J <= I, operands from LDS, result in registers.  Wave s + 1 has ONE product
-//       to do and goes straight on to factor block (s + 1, s + 1) while the others still update.
-// Then the inverse by block forward substitution, wave J = block column J: X_IJ = -inv(L_II) sum_K L_IK X_KJ; the accumulator
-// layout of X_KJ IS the B-operand layout of the next product, so X never leaves the registers.
-__device__ __attribute__((noinline)) void flow_potrf(const FlowArgs& a, int k, double* lds)
+// The lower triangle of the tile is 36 blocks of 16 x 16.  Every block has ONE owner wave that holds it in registers in the
+// accumulator layout of v_mfma_f64_16x16x4 (register q of lane l = row 4 q + (l >> 4), column l & 15), so the trailing updates
+// accumulate straight into it; the operands of every product come from LDS, where the FINISHED blocks of L (28 below the diagonal)
+// and the inverses of the 8 diagonal blocks live (swizzled, 72 KB).  owner(I, J) = (I - J + J (J + 1) / 2) mod 8: the blocks of one
+// column have eight different owners (its panel solves run in parallel), every wave owns 4 or 5 blocks (40 VGPRs), and the owner
+// of the next diagonal block has at most 2 other live blocks.  Per block column s:
+//   A1  the owner of (s, s) turns it into one-lane-per-row form (through LDS) and factors it -- v_readlane broadcasts, 1 / pivot by
+//       v_rcp_f64 + two Newton steps, no square root inside the loop -- and carries the inverse along in the same loop: lane c
+//       builds column c of inv(R) (R = the unscaled factor, L = R diag(1 / sqrt(pivot))) from the very broadcasts the
+//       elimination uses, one more FMA per broadcast; inv(L_ss) = diag(sqrt(pivot)) inv(R) goes to LDS;
+//   A2  the owner of (I, s): X = B inv(L_ss)^T as ONE 16 x 16 x 16 matrix product (all 64 lanes; the round-4 bring-up version
+//       solved it by substitution on 16 lanes: 3.4 us per step against 0.4), finished block of L -> LDS;
+//   A3  block (I, J) -= L_Is L_Js^T for every live block, the next diagonal block first: its owner goes straight on to A1 of the
+//       next column while the others are still updating.
+// Then the inverse of the whole factor by block forward substitution, wave J = block column J: X_IJ = -inv(L_II) sum_K L_IK X_KJ;
+// the accumulator layout of X_KJ IS the B-operand layout of the next product, so X never leaves the registers.
+__device__ const unsigned long long kFlowPotrfSlots[8] = {      // 5 slots per wave, 8 bits each: I << 4 | J, 0xff = empty; sorted by (J, I)
+    0xff65537200ull, 0xff75631110ull, 0xff44732120ull, 0xff54223130ull, 0x7764324140ull, 0x6674425150ull, 0x7633526160ull, 0x5543627170ull };
+
+__device__ BSFM_FLOW_ROLE void flow_potrf(const FlowArgs& a_in, int k, double* lds)
 {
-    double* Lb = lds + FLOW_LB; double* Di = lds + FLOW_DI; double* Ls = lds + FLOW_LS; double* sv = lds + FLOW_SV;
+    const FlowArgs a = flow_uniform_args(a_in); BSFM_UNIFORM_INT(k);
+    double* Lb = lds + FLOW_LB; double* Di = lds + FLOW_DI;
     const int tid = threadIdx.x, lane0 = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int base = k * POTRF_NB, n_total = a.n_total;
     const double* G = a.S + (size_t)base * a.ld + base;
     const int lr0 = lane0 >> 4, lc0 = lane0 & 15;
-    // t[m]: block (w, s + m) at step s (the blocks are shifted down one place per step, so that the step's code exists once
-    // and every register index is static)
-    double t[8][4];
-    const int lr = lr0, lc = lc0;
-    // The whole tile lies inside the padded allocation of S, so every lane loads unconditionally (32 loads in flight, no divergent
-    // control flow) and the triangle / padding rules are applied with selects: lower triangle of S, identity beyond n_total.
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = 16 * w + 4 * q + lr;
-        const double* rowp = G + (size_t)r * a.ld + lc;          // one address per row, the block columns are immediate offsets
-#pragma unroll
-        for (int J = 0; J < 8; ++J) t[J][q] = ld_sc1(rowp + 16 * J);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = 16 * w + 4 * q + lr;
-#pragma unroll
-        for (int J = 0; J < 8; ++J) {
-            const int c = 16 * J + lc;
-            const bool inside = base + r < n_total && base + c < n_total;
-            const double pad = (r == c) ? 1.0 : 0.0;
-            t[J][q] = inside ? (c <= r ? t[J][q] : 0.0) : pad;
-        }
-    }
+#define BSFM_FLOW_MARK(code) do { if (a.trace && lane0 == 0 && w == 0) a.trace[a.ptrace_ofs + 40 * (size_t)k + (code)] = wall_clock64(); } while (0)
 #define BSFM_RDLANE(v, l) __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), (l)), __builtin_amdgcn_readlane(__double2loint(v), (l)))
 #define BSFM_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+    BSFM_FLOW_MARK(1);
+    int sI[5], sJ[5];
+    {
+        const unsigned long long packed = kFlowPotrfSlots[w];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            const int b = __builtin_amdgcn_readfirstlane((int)((packed >> (8 * m)) & 0xffull));
+            sI[m] = b == 0xff ? -1 : b >> 4; sJ[m] = b == 0xff ? -1 : b & 15;
+        }
+    }
+    double t[5][4];
+    {
+        // The whole tile lies inside the padded allocation of S, so every lane loads unconditionally (20 loads in flight, no divergent
+        // control flow) and the triangle / padding rules are applied with selects: lower triangle of S, identity beyond n_total.
+        const int lr = lr0, lc = lc0;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            const int I = sI[m] < 0 ? 0 : sI[m], J = sJ[m] < 0 ? 0 : sJ[m];
+            const double* bp = G + (size_t)(16 * I + lr) * a.ld + 16 * J + lc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t[m][q] = ld_sc1(bp + (size_t)(4 * q) * a.ld);
+        }
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+            const int I = sI[m] < 0 ? 0 : sI[m], J = sJ[m] < 0 ? 0 : sJ[m];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 16 * I + 4 * q + lr, c = 16 * J + lc;
+                const bool inside = base + r < n_total && base + c < n_total;
+                const double pad = (r == c) ? 1.0 : 0.0;
+                t[m][q] = inside ? (c <= r ? t[m][q] : 0.0) : pad;
+            }
+        }
+    }
+    BSFM_FLOW_MARK(2);
+    // cur: the block a phase works on, picked out of the wave's slots with scalar tests (one instantiation of A1 / A2 instead of five)
+    double cur[4];
+    bool have = false;
+    // ---- A1 of block column 0 (its owner: wave 0, slot 0), then per column: barrier, A2, barrier, A3 (+ A1 of the next column)
 #pragma unroll 1
-    for (int s = 0; s < 8; ++s) {
-        double* Lss = Ls + (s & 1) * 256;
+    for (int s = -1; s < 8; ++s) {
         // opaque copies of the lane coordinates: the swizzled LDS addresses below are loop-invariant, and the compiler would otherwise
-        // hoist several dozen of them out of the loop and spill them (404 bytes of scratch per lane); one XOR per access is cheaper
+        // hoist several dozen of them out of the loop and spill them; one XOR per access is cheaper
         int lr = lr0, lc = lc0, lane = lane0;
         asm volatile("" : "+v"(lr), "+v"(lc), "+v"(lane));
-        if (w == s) {
-            // ---- A1
+        if (s >= 0) {
+            __syncthreads();                                   // inv(L_ss) is in LDS
+            BSFM_FLOW_MARK(4 + 4 * s + 1);
+            // ---- A2
+            int Isel = -1;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) Lss[swz16(4 * q + lr, lc)] = t[0][q];
+            for (int m = 0; m < 5; ++m)
+                if (sJ[m] == s && sI[m] > s) {
+                    Isel = sI[m];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cur[q] = t[m][q];
+                }
+            if (Isel >= 0) {
+                double* dst = Lb + (Isel * (Isel - 1) / 2 + s) * 256;
+                const double* Dd = Di + s * 256;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[swz16(4 * q + lr, lc)] = cur[q];
+                BSFM_LDS_FENCE();
+                double av[4], bv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { av[q] = dst[swz16(lc, 4 * q + lr)]; bv[q] = Dd[swz16(lc, 4 * q + lr)]; }
+                v4d x = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], x, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[swz16(4 * q + lr, lc)] = x[q];
+            }
+            __syncthreads();                                   // block column s of L is in LDS
+            BSFM_FLOW_MARK(4 + 4 * s + 2);
+            if (s == 7) break;
+            // ---- A3, the next diagonal block first
+            have = false;
+#pragma unroll
+            for (int m = 0; m < 5; ++m)
+                if (sI[m] == s + 1 && sJ[m] == s + 1) {
+                    have = true;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cur[q] = t[m][q];
+                }
+            if (have) {
+                const double* Ap = Lb + ((s + 1) * s / 2 + s) * 256;
+                double av[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) av[q] = Ap[swz16(lc, 4 * q + lr)];
+                v4d c = { cur[0], cur[1], cur[2], cur[3] };
+#pragma unroll
+                for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[q], av[q], c, 0, 0, 0);
+                cur[0] = c[0]; cur[1] = c[1]; cur[2] = c[2]; cur[3] = c[3];
+            }
+        } else {
+            have = (w == 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cur[q] = t[0][q];
+        }
+        const int sn = s + 1;                                  // the block column whose diagonal block is factored now
+        if (have) {
+            // ---- A1: factor + inverse of block (sn, sn)
+            double* blk = Di + sn * 256;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) blk[swz16(4 * q + lr, lc)] = cur[q];
             BSFM_LDS_FENCE();
             const int r = lc;
-            double d[16];
+            double d[16], x[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) d[c] = Lss[swz16(r, c)];
+            for (int c = 0; c < 16; ++c) { d[c] = blk[swz16(r, c)]; x[c] = (c == r) ? 1.0 : 0.0; }
             double myp = 1.0;
             int bad = -1;
 #pragma unroll
@@ -358,103 +470,62 @@ __device__ __attribute__((noinline)) void flow_potrf(const FlowArgs& a, int k, d
                 double inv = __builtin_amdgcn_rcp(piv);
                 inv = fma(fma(-piv, inv, 1.0), inv, inv);
                 inv = fma(fma(-piv, inv, 1.0), inv, inv);
-                const double lrj = d[j] * inv;
+                const double lrj = d[j] * inv;                    // R[r][j] / pivot_j
+                const double xj = x[j] * inv;                     // row j of inv(R), column r
+                x[j] = xj;
 #pragma unroll
-                for (int c = j + 1; c < 16; ++c) { const double sc = BSFM_RDLANE(d[j], c); d[c] -= lrj * sc; }
+                for (int c = j + 1; c < 16; ++c) {
+                    const double sc = BSFM_RDLANE(d[j], c);       // R[c][j]
+                    d[c] -= lrj * sc;
+                    x[c] -= xj * sc;
+                }
             }
-            if (lane == 0 && bad >= 0 && base + 16 * s + bad < n_total) atomicCAS(a.info, 0, base + 16 * s + bad + 1);
-            const double myrs = rsqrt_f64(myp);                       // 1 / L[r][r]
-            BSFM_LDS_FENCE();                                          // (every lane has read its row before lanes 0..15 overwrite the block)
+            if (lane == 0 && bad >= 0 && base + 16 * sn + bad < n_total) atomicCAS(a.info, 0, base + 16 * sn + bad + 1);
+            const double mysq = myp * rsqrt_f64(myp);              // L[r][r] = sqrt(pivot_r)
+            BSFM_LDS_FENCE();                                      // (every lane has read its row before lanes 0..15 overwrite the block)
             if (lane < 16) {
-                sv[16 * s + r] = myrs;
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const double rs_c = BSFM_RDLANE(myrs, c);
-                    Lss[swz16(r, c)] = (c <= r) ? d[c] * rs_c : 0.0;
+                for (int i = 0; i < 16; ++i) {
+                    const double sq_i = BSFM_RDLANE(mysq, i);
+                    blk[swz16(i, r)] = x[i] * sq_i;               // inv(L)[i][r] = sqrt(pivot_i) inv(R)[i][r]
                 }
             }
         }
-        __syncthreads();
-        if (w > s) {
-            // ---- A2: block (w, s) -> one lane per row, x <- x inv(L_ss)^T by forward substitution, finished block of L -> LDS
-            double* dst = Lb + (w * (w - 1) / 2 + s) * 256;
+        if (s >= 0) {
+            // ---- A3, the other live blocks
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dst[swz16(4 * q + lr, lc)] = t[0][q];
-            BSFM_LDS_FENCE();
-            if (lane < 16) {
-                double x[16];
+            for (int m = 0; m < 5; ++m)
+                if (sJ[m] > s && !(sI[m] == s + 1 && sJ[m] == s + 1)) {
+                    const int I = sI[m], J = sJ[m];
+                    const double* Ap = Lb + (I * (I - 1) / 2 + s) * 256;
+                    const double* Bp = I == J ? Ap : Lb + (J * (J - 1) / 2 + s) * 256;
+                    double av[4], bv[4];
 #pragma unroll
-                for (int c = 0; c < 16; ++c) x[c] = dst[swz16(lane, c)];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const double xc = x[c] * sv[16 * s + c];
-                    x[c] = xc;
-#pragma unroll
-                    for (int kq = c + 1; kq < 16; ++kq) x[kq] -= xc * Lss[swz16(kq, c)];
-                }
-#pragma unroll
-                for (int c = 0; c < 16; ++c) dst[swz16(lane, c)] = x[c];
-            }
-        } else if (w == s) {
-            // inv(L_ss): the same substitution on the rows of the identity; lane c ends up with column c of the inverse
-            if (lane < 16) {
-                double x[16];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) x[c] = (c == lane) ? 1.0 : 0.0;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const double xc = x[c] * sv[16 * s + c];
-                    x[c] = xc;
-#pragma unroll
-                    for (int kq = c + 1; kq < 16; ++kq) x[kq] -= xc * Lss[swz16(kq, c)];
-                }
-                double* Dd = Di + s * 256;
-#pragma unroll
-                for (int rr = 0; rr < 16; ++rr) Dd[swz16(rr, lane)] = x[rr];
-            }
-        }
-        __syncthreads();
-        if (w > s) {
-            // ---- A3: t[m] = block (w, s + m) -= L_ws L_(s+m)s^T for 1 <= m <= w - s
-            const double* Aw = Lb + (w * (w - 1) / 2 + s) * 256;
-            double av[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) av[q] = -Aw[swz16(lc, 4 * q + lr)];
-#pragma unroll
-            for (int m = 1; m < 8; ++m) {
-                const int J = s + m;
-                if (J <= w) {
-                    const double* Bj = (J == w) ? Aw : Lb + (J * (J - 1) / 2 + s) * 256;
-                    double bv[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) bv[q] = Bj[swz16(lc, 4 * q + lr)];
+                    for (int q = 0; q < 4; ++q) { av[q] = -Ap[swz16(lc, 4 * q + lr)]; bv[q] = Bp[swz16(lc, 4 * q + lr)]; }
                     v4d c = { t[m][0], t[m][1], t[m][2], t[m][3] };
 #pragma unroll
                     for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], c, 0, 0, 0);
                     t[m][0] = c[0]; t[m][1] = c[1]; t[m][2] = c[2]; t[m][3] = c[3];
                 }
-            }
+            BSFM_FLOW_MARK(4 + 4 * s + 3);
         }
-        // shift: block (w, s + 1 + m) moves to place m
-#pragma unroll
-        for (int m = 0; m < 7; ++m)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) t[m][q] = t[m + 1][q];
     }
-    __syncthreads();
-    // ---- inverse: wave w = block column J of X = inv(L); t[I] = X_IJ in the accumulator layout (re-uses the tile's registers)
+    BSFM_FLOW_MARK(36);
+    // ---- inverse: wave w = block column J of X = inv(L); xb[I] = X_IJ in the accumulator layout
     {
+        const int lr = lr0, lc = lc0;
         const int J = w;
         const double* DJ = Di + J * 256;
+        double xb[8][4];
 #pragma unroll
         for (int I = 0; I < 8; ++I)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) t[I][q] = 0.0;
+            for (int q = 0; q < 4; ++q) xb[I][q] = 0.0;
 #pragma unroll
         for (int I = 0; I < 8; ++I) {
             if (I == J) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) t[I][q] = DJ[swz16(4 * q + lr, lc)];
+                for (int q = 0; q < 4; ++q) xb[I][q] = DJ[swz16(4 * q + lr, lc)];
             } else if (I > J) {
                 v4d acc = { 0.0, 0.0, 0.0, 0.0 }, acc2 = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
@@ -464,10 +535,10 @@ __device__ __attribute__((noinline)) void flow_potrf(const FlowArgs& a, int k, d
                         double av[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) av[q] = Lik[swz16(lc, 4 * q + lr)];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], t[K][0], acc, 0, 0, 0);
-                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], t[K][1], acc2, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], t[K][2], acc, 0, 0, 0);
-                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], t[K][3], acc2, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], xb[K][0], acc, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], xb[K][1], acc2, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], xb[K][2], acc, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], xb[K][3], acc2, 0, 0, 0);
                     }
                 }
                 double sacc[4] = { acc[0] + acc2[0], acc[1] + acc2[1], acc[2] + acc2[2], acc[3] + acc2[3] };
@@ -475,7 +546,7 @@ __device__ __attribute__((noinline)) void flow_potrf(const FlowArgs& a, int k, d
                 v4d res = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
                 for (int q = 0; q < 4; ++q) res = __builtin_amdgcn_mfma_f64_16x16x4f64(DI[swz16(lc, 4 * q + lr)], sacc[q], res, 0, 0, 0);
-                t[I][0] = -res[0]; t[I][1] = -res[1]; t[I][2] = -res[2]; t[I][3] = -res[3];
+                xb[I][0] = -res[0]; xb[I][1] = -res[1]; xb[I][2] = -res[2]; xb[I][3] = -res[3];
             }
         }
         double* Wk = a.Linv + (size_t)k * FLOW_TL;
@@ -483,66 +554,126 @@ __device__ __attribute__((noinline)) void flow_potrf(const FlowArgs& a, int k, d
         for (int I = 0; I < 8; ++I) {
             if (I >= J) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) st_sc1(Wk + (size_t)(16 * I + 4 * q + lr) * POTRF_NB + 16 * J + lc, t[I][q]);
+                for (int q = 0; q < 4; ++q) st_sc1(Wk + (size_t)(16 * I + 4 * q + lr) * POTRF_NB + 16 * J + lc, xb[I][q]);
             }
         }
     }
+    BSFM_FLOW_MARK(37);
+#undef BSFM_FLOW_MARK
 #undef BSFM_RDLANE
 #undef BSFM_LDS_FENCE
 }
 
 constexpr long long FLOW_SPIN_LIMIT_TICKS = 40LL * 1000 * 1000;      // 0.4 s of the 100 MHz wall clock: far beyond any solve this library accepts
 
-__global__ __launch_bounds__(512, 4) void k_chol_flow(FlowArgs a)
+#ifndef BSFM_FLOW_WPS
+#define BSFM_FLOW_WPS 4          // waves per SIMD the kernel is compiled for: 4 = two 512-thread workgroups per CU (128 VGPRs)
+#endif
+// NOTE on control flow.  Ticket, waits and signal are single-thread jobs between workgroup barriers.  Written as `if (tid == 0) { ...
+// loops, exits ... }` they are NOT sound: a lane-divergent region with loops inside gives the compiler no obligation to reconverge
+// wave 0 before the next barrier -- on the first bring-up lanes 1..63 of wave 0 ran on (through the barrier and the whole POTRF role,
+// barriers included) while lane 0 still owed its block, the barrier released on a stale ticket, wave 0 executed every barrier twice
+// and the launch never ended (profiles/r04_flow_bringup_notes.txt).  So: everything that steers the loop is a SCALAR value
+// (v_readfirstlane), the single-thread jobs are done by WAVE 0 under a scalar branch with all of its lanes executing the same
+// loads and loops, and only the side effects (atomic, store) sit under a one-instruction `lane == 0` predicate.
+//
+// Roles.  The chain's tasks (POTRF and the two single-tile products behind it) are latency: next to a bulk workgroup on the same CU
+// a POTRF takes 80-250 us instead of 55 (profiles/r04_flow_task_durations.txt).  The first n_chain_wgs workgroups that find themselves
+// FIRST on their CU therefore serve the chain queue, and the workgroup that arrives second on such a CU leaves at once, so a chain
+// workgroup has its CU to itself.  A CU is identified by XCC_ID and the SE / SH / CU fields of HW_ID; if that reading were ever
+// wrong (another part, another partition mode) the only consequence is a shared CU or a few idle slots -- nothing waits on it.
+__global__ __launch_bounds__(512, BSFM_FLOW_WPS) void k_chol_flow(FlowArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ unsigned s_ticket;
     __shared__ int s_abort;
-    const int tid = threadIdx.x;
+    __shared__ int s_role;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned* const flags = a.sync + 4;
+    // ---- role: 0 = bulk queue, 1 = chain queue, 2 = leave (second workgroup on a chain CU)
+    if (wave == 0) {
+        int role = 0;
+        const unsigned n_cw = (unsigned)__builtin_amdgcn_readfirstlane((int)a.n_chain_wgs);
+        if (n_cw > 0u) {
+            unsigned hw = 0, xcc = 0;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            const unsigned key = ((xcc & 15u) << 8) | (((hw >> 13) & 7u) << 5) | (((hw >> 12) & 1u) << 4) | ((hw >> 8) & 15u);
+            unsigned* cu_count = flags + a.nflags + key;
+            unsigned* cu_state = flags + a.nflags + FLOW_CU_KEYS + key;
+            unsigned slot = 0;
+            if (lane == 0) slot = atomicAdd(cu_count, 1u);
+            slot = (unsigned)__builtin_amdgcn_readfirstlane((int)slot);
+            if (slot == 0u) {
+                unsigned r = 0;
+                if (lane == 0) r = atomicAdd(a.sync + 3, 1u);
+                r = (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+                role = r < n_cw ? 1 : 0;
+                if (lane == 0) __hip_atomic_store(cu_state, role ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (slot == 1u) {
+                // the first workgroup on this CU decides within a microsecond; an unanswered wait just means "bulk"
+                unsigned st = 0;
+                for (int it = 0; it < 4096 && st == 0u; ++it) {
+                    st = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cu_state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (st == 0u) __builtin_amdgcn_s_sleep(1);
+                }
+                role = st == 2u ? 2 : 0;
+            }
+        }
+        if (lane == 0) s_role = role;
+    }
+    __syncthreads();
+    const int role = __builtin_amdgcn_readfirstlane(s_role);
+    if (role == 2) return;
+    const FlowTask* const queue = role == 1 ? a.chain_tasks : a.tasks;
+    const unsigned t_end = (unsigned)__builtin_amdgcn_readfirstlane((int)(role == 1 ? a.n_chain : a.n_bulk));
+    unsigned* const ticket = a.sync + (role == 1 ? 2 : 0);
+    const size_t trace_base = role == 1 ? (size_t)a.n_bulk : 0;
     for (;;) {
         long long st0 = 0;
-        if (tid == 0) {
-            s_ticket = atomicAdd(a.ticket, 1u);
-            s_abort = 0;
+        if (wave == 0) {
+            unsigned t = 0;
+            if (lane == 0) t = atomicAdd(ticket, 1u);
+            t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+            if (lane == 0) { s_ticket = t; s_abort = 0; }
             if (a.trace) st0 = wall_clock64();
         }
         __syncthreads();
-        const unsigned tk = __builtin_amdgcn_readfirstlane(s_ticket);
-        if (tk >= a.t_end) {
-            // give the ticket back for the next chunk's launch: the counter must end at exactly t_end
-            if (tid == 0) atomicSub(a.ticket, 1u);
-            return;
-        }
-        const FlowTask* tp = a.tasks + tk;
+        const unsigned tk = (unsigned)__builtin_amdgcn_readfirstlane((int)s_ticket);
+        if (tk >= t_end) return;
+        const FlowTask* tp = queue + tk;
         const uint32_t w0 = *reinterpret_cast<const uint32_t*>(tp);               // type | np << 8 | part << 16 | nwait << 24
         const uint32_t w1 = *(reinterpret_cast<const uint32_t*>(tp) + 1);         // i | j << 16
-        const uint32_t w2 = *(reinterpret_cast<const uint32_t*>(tp) + 2);         // p0 | pad << 16
+        const uint32_t w2 = *(reinterpret_cast<const uint32_t*>(tp) + 2);         // p0 | queue << 16
         const int type = __builtin_amdgcn_readfirstlane((int)(w0 & 255u)), np = __builtin_amdgcn_readfirstlane((int)((w0 >> 8) & 255u));
         const int part = __builtin_amdgcn_readfirstlane((int)((w0 >> 16) & 255u)), nwait = __builtin_amdgcn_readfirstlane((int)(w0 >> 24));
         const int ti = __builtin_amdgcn_readfirstlane((int)(w1 & 0xffffu)), tj = __builtin_amdgcn_readfirstlane((int)(w1 >> 16));
         const int p0 = __builtin_amdgcn_readfirstlane((int)(w2 & 0xffffu));
-        if (tid == 0) {
+        if (wave == 0) {
+            // every lane of wave 0 polls the same word: one request, a scalar verdict
             const long long t_begin = wall_clock64();
-            for (int q = 0; q < nwait; ++q) {
-                const unsigned idx = tp->w[q].idx, thr = tp->w[q].thr;
+            int ab = 0;
+            for (int q = 0; q < nwait && !ab; ++q) {
+                const unsigned idx = (unsigned)__builtin_amdgcn_readfirstlane((int)tp->w[q].idx);
+                const unsigned thr = (unsigned)__builtin_amdgcn_readfirstlane((int)tp->w[q].thr);
                 unsigned spins = 0;
-                while (__hip_atomic_load(a.flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < thr) {
+                for (;;) {
+                    const unsigned seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (seen >= thr) break;
                     __builtin_amdgcn_s_sleep(1);
                     if ((++spins & 63u) == 0u) {
-                        if (__hip_atomic_load(a.ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
-                            wall_clock64() - t_begin > FLOW_SPIN_LIMIT_TICKS) {
-                            __hip_atomic_store(a.ticket + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            s_abort = 1;
-                            break;
-                        }
+                        const unsigned tmo = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        const int late = __builtin_amdgcn_readfirstlane((int)(wall_clock64() - t_begin > FLOW_SPIN_LIMIT_TICKS));
+                        if (tmo != 0u || late) { ab = 1; break; }
                     }
                 }
-                if (s_abort) break;
             }
-            if (a.trace) { a.trace[4 * (size_t)tk + 0] = st0; a.trace[4 * (size_t)tk + 1] = wall_clock64(); }
+            if (ab && lane == 0) { __hip_atomic_store(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_abort = 1; }
+            if (a.trace && lane == 0) { a.trace[4 * (trace_base + tk) + 0] = st0; a.trace[4 * (trace_base + tk) + 1] = wall_clock64(); }
         }
         __syncthreads();
-        if (s_abort) return;
+        if (__builtin_amdgcn_readfirstlane(s_abort)) return;
         switch (type) {
         case FT_POTRF:  flow_potrf(a, tj, lds); break;
         case FT_TRSM32: flow_tile32<false>(a, ti, tj, 0, 0, part, lds); break;
@@ -557,12 +688,12 @@ __global__ __launch_bounds__(512, 4) void k_chol_flow(FlowArgs a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave drains its write-through stores
         __syncthreads();
         if (tid == 0) {
-            __hip_atomic_fetch_add(a.flags + tp->sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(flags + tp->sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a.trace) {
-                a.trace[4 * (size_t)tk + 2] = wall_clock64();
+                a.trace[4 * (trace_base + tk) + 2] = wall_clock64();
                 unsigned xcc = 0;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                a.trace[4 * (size_t)tk + 3] = (long long)(xcc & 15u) | ((long long)blockIdx.x << 8);
+                a.trace[4 * (trace_base + tk) + 3] = (long long)(xcc & 15u) | ((long long)blockIdx.x << 8) | ((long long)role << 32);
             }
         }
     }
@@ -631,16 +762,18 @@ __global__ void k_flow_fold_timeout(const unsigned* __restrict__ ticket, const i
 struct FlowWorkspace {
     int nblk = 0;                          // tiles the buffers were sized for
     std::vector<int> env_key;              // envelope the schedule was built for
-    FlowSchedule sched;
-    FlowTask* d_tasks = nullptr;
-    unsigned* d_sync = nullptr;            // [ticket, time-out, 2 spare] + counters
+    FlowSchedule sched;                    // tasks in the simulated order (both queues)
+    std::vector<FlowTask> bulk, chain;     // the two queues, as uploaded
+    FlowTask* d_tasks = nullptr;           // bulk queue, then chain queue
+    unsigned* d_sync = nullptr;            // tickets, time-out, claims, per-tile counters, per-CU words
+    size_t sync_words = 0;
     double* pc = nullptr;                  // compact panel tiles
     long long* d_trace = nullptr;
-    int chunk_cols = 0;                    // 0: one launch; n: a launch per n tile columns (BSFM_FLOW_CHUNK)
-    int wgs = 512;                         // resident workgroups (BSFM_FLOW_WGS)
+    int wgs = 512;                         // workgroups launched (BSFM_FLOW_WGS)
+    int chain_wgs = 16;                    // of them: serve the chain queue, alone on their CU (BSFM_FLOW_CHAIN_WGS; 0 = one queue)
     bool trace = false;                    // BSFM_FLOW_TRACE=1: per-task stamps, dumped to BSFM_FLOW_TRACE_FILE after every solve
     double flops = 0.0;                    // flops of one factorisation as scheduled (UPD + TRSM tile products, 2 * 128^3 each)
-    hipEvent_t k0 = nullptr, k1 = nullptr; // around the k_chol_flow launch(es): the roofline kernel's duration
+    hipEvent_t k0 = nullptr, k1 = nullptr; // around the k_chol_flow launch: the roofline kernel's duration
     double kern_ms = 0.0; long long kern_cnt = 0; bool kern_pending = false;
 };
 
@@ -659,6 +792,8 @@ inline FlowParams flow_params_from_env()
     if (const char* e = getenv("BSFM_FLOW_NPMAX")) p.np_max = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("BSFM_FLOW_SLOTS")) p.slots = std::max(32, atoi(e));
     if (const char* e = getenv("BSFM_FLOW_URGENT")) p.urgent_cols = std::max(0, atoi(e));
+    if (const char* e = getenv("BSFM_FLOW_TPOTRF")) p.t_potrf = atof(e);
+    if (const char* e = getenv("BSFM_FLOW_TUPD128")) { double a0 = 0, a1 = 0; if (sscanf(e, "%lf,%lf", &a0, &a1) == 2) { p.t_upd128_0 = a0; p.t_upd128_per = a1; } }
     return p;
 }
 
@@ -671,23 +806,29 @@ inline int flow_prepare(FlowWorkspace& f, int nblk, const std::vector<int>& env_
     bsfm::dev_free(f.d_tasks, true); f.d_tasks = nullptr;
     bsfm::dev_free(f.d_sync, true); f.d_sync = nullptr;
     if (f.nblk != nblk) { bsfm::dev_free(f.pc, true); f.pc = nullptr; }
-    if (const char* e = getenv("BSFM_FLOW_CHUNK")) f.chunk_cols = std::max(0, atoi(e));
-    if (const char* e = getenv("BSFM_FLOW_WGS")) f.wgs = std::max(1, atoi(e));
+    if (const char* e = getenv("BSFM_FLOW_WGS")) f.wgs = std::max(2, atoi(e));
+    if (const char* e = getenv("BSFM_FLOW_CHAIN_WGS")) f.chain_wgs = std::max(0, atoi(e));
     if (const char* e = getenv("BSFM_FLOW_TRACE")) f.trace = atoi(e) != 0;
+    f.chain_wgs = std::min(f.chain_wgs, f.wgs / 4);
     if (flow_build_schedule(nblk, key, flow_params_from_env(), f.sched) != 0) return -1;
     if (flow_check_schedule(f.sched) != 0) { fprintf(stderr, "[bsfm] flow schedule failed its dependency check\n"); return -1; }
     f.nblk = nblk; f.env_key = key;
+    f.bulk.clear(); f.chain.clear();
+    for (const FlowTask& t : f.sched.tasks) (f.chain_wgs > 0 && t.pad == 1 ? f.chain : f.bulk).push_back(t);
     const size_t nt = f.sched.tasks.size();
     if (bsfm::dev_alloc((void**)&f.d_tasks, nt * sizeof(FlowTask)) != hipSuccess) return -1;
-    if (hipMemcpy(f.d_tasks, f.sched.tasks.data(), nt * sizeof(FlowTask), hipMemcpyHostToDevice) != hipSuccess) return -1;
-    if (bsfm::dev_alloc((void**)&f.d_sync, (4 + (size_t)f.sched.nflags) * sizeof(unsigned)) != hipSuccess) return -1;
+    if (!f.bulk.empty() && hipMemcpy(f.d_tasks, f.bulk.data(), f.bulk.size() * sizeof(FlowTask), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (!f.chain.empty() && hipMemcpy(f.d_tasks + f.bulk.size(), f.chain.data(), f.chain.size() * sizeof(FlowTask), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    f.sync_words = 4 + (size_t)f.sched.nflags + 2 * (size_t)FLOW_CU_KEYS;
+    if (bsfm::dev_alloc((void**)&f.d_sync, f.sync_words * sizeof(unsigned)) != hipSuccess) return -1;
     if (!f.pc) {
         const size_t ntile = std::max<size_t>(1, (size_t)nblk * (size_t)(nblk - 1) / 2);
         if (bsfm::dev_alloc((void**)&f.pc, ntile * FLOW_TL * sizeof(double)) != hipSuccess) return -1;
     }
     if (f.trace) {
         if (f.d_trace) (void)hipFree(f.d_trace);
-        if (hipMalloc((void**)&f.d_trace, nt * 4 * sizeof(long long)) != hipSuccess) return -1;
+        if (hipMalloc((void**)&f.d_trace, (nt * 4 + 40 * (size_t)nblk) * sizeof(long long)) != hipSuccess) return -1;
+        (void)hipMemset(f.d_trace, 0, (nt * 4 + 40 * (size_t)nblk) * sizeof(long long));
     }
     f.flops = (f.sched.upd_tiles + f.sched.trsm_tiles) * 2.0 * POTRF_NB * POTRF_NB * POTRF_NB;
     if (!f.k0) { (void)hipEventCreate(&f.k0); (void)hipEventCreate(&f.k1); }
@@ -708,11 +849,21 @@ inline void flow_dump_trace(FlowWorkspace& f, hipStream_t st)
     if (!fp) return;
     long long t0 = h[0];
     for (size_t q = 0; q < nt; ++q) t0 = std::min(t0, h[4 * q]);
-    fprintf(fp, "# ticket type i j p0 np part  t_ticket t_ready t_done (us since the first ticket)  xcc wg\n");
+    fprintf(fp, "# ticket type i j p0 np part  t_ticket t_ready t_done (us since the first ticket)  xcc wg queue\n");
     for (size_t q = 0; q < nt; ++q) {
-        const FlowTask& t = f.sched.tasks[q];
-        fprintf(fp, "%zu %d %d %d %d %d %d %.2f %.2f %.2f %lld %lld\n", q, t.type, t.i, t.j, t.p0, t.np, t.part,
-                (h[4 * q] - t0) * 0.01, (h[4 * q + 1] - t0) * 0.01, (h[4 * q + 2] - t0) * 0.01, h[4 * q + 3] & 15, h[4 * q + 3] >> 8);
+        const FlowTask& t = q < f.bulk.size() ? f.bulk[q] : f.chain[q - f.bulk.size()];
+        fprintf(fp, "%zu %d %d %d %d %d %d %.2f %.2f %.2f %lld %lld %lld\n", q, t.type, t.i, t.j, t.p0, t.np, t.part,
+                (h[4 * q] - t0) * 0.01, (h[4 * q + 1] - t0) * 0.01, (h[4 * q + 2] - t0) * 0.01, h[4 * q + 3] & 15, (h[4 * q + 3] >> 8) & 0xffffff, h[4 * q + 3] >> 32);
+    }
+    std::vector<long long> ph(40 * (size_t)f.nblk);
+    if (hipMemcpy(ph.data(), f.d_trace + 4 * nt, ph.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
+        fprintf(fp, "# POTRF phases per column (us since entry): loaded | per block column: inverse diagonal block visible, block column visible, updates issued | loop done, end\n");
+        for (int k = 0; k < f.nblk; ++k) {
+            const long long* q = ph.data() + 40 * (size_t)k;
+            fprintf(fp, "#P %d: %.2f |", k, (q[2] - q[1]) * 0.01);
+            for (int s2 = 0; s2 < 8; ++s2) fprintf(fp, " %.2f %.2f %.2f |", (q[5 + 4 * s2] - q[1]) * 0.01, (q[6 + 4 * s2] - q[1]) * 0.01, s2 < 7 ? (q[7 + 4 * s2] - q[1]) * 0.01 : 0.0);
+            fprintf(fp, " %.2f %.2f\n", (q[36] - q[1]) * 0.01, (q[37] - q[1]) * 0.01);
+        }
     }
     fclose(fp);
 }
@@ -723,30 +874,23 @@ inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, in
     const int nblk = (n + POTRF_NB - 1) / POTRF_NB;
     if (flow_prepare(f, nblk, w.env_rows) != 0) return -1;
     const size_t nt = f.sched.tasks.size();
-    (void)hipMemsetAsync(f.d_sync, 0, (4 + (size_t)f.sched.nflags) * sizeof(unsigned), st);
+    (void)hipMemsetAsync(f.d_sync, 0, f.sync_words * sizeof(unsigned), st);
     (void)hipMemsetAsync(w.etmp, 0, (size_t)ld * sizeof(double), st);
     (void)hipMemcpyAsync(w.etmp, E, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
     FlowArgs a;
     a.S = S; a.ld = ld; a.n_total = n; a.T = nblk; a.Pc = f.pc; a.Linv = w.linv; a.E = w.etmp; a.y = w.y;
-    a.tasks = f.d_tasks; a.ticket = f.d_sync; a.flags = f.d_sync + 4; a.info = d_info; a.trace = f.trace ? f.d_trace : nullptr;
+    a.tasks = f.d_tasks; a.chain_tasks = f.d_tasks + f.bulk.size(); a.n_bulk = (unsigned)f.bulk.size(); a.n_chain = (unsigned)f.chain.size();
+    a.n_chain_wgs = (unsigned)f.chain_wgs; a.sync = f.d_sync; a.nflags = (unsigned)f.sched.nflags; a.info = d_info;
+    a.trace = f.trace ? f.d_trace : nullptr; a.ptrace_ofs = (unsigned)(4 * nt);
     const size_t lds_bytes = FLOW_LDS_DOUBLES * sizeof(double);
     const bool timed = w.timing && f.k0;
     if (timed) {
         if (f.kern_pending) { float ms = 0.f; if (hipEventElapsedTime(&ms, f.k0, f.k1) == hipSuccess && ms >= 0.f) { f.kern_ms += ms; f.kern_cnt++; } f.kern_pending = false; }
         (void)hipEventRecord(f.k0, st);
     }
-    if (f.chunk_cols <= 0) {
-        a.t_end = (unsigned)nt;
-        hipLaunchKernelGGL(k_chol_flow, dim3((unsigned)std::min<size_t>((size_t)f.wgs, nt)), dim3(512), lds_bytes, st, a);
-    } else {
-        for (int k0 = 0; k0 < nblk; k0 += f.chunk_cols) {
-            const int k1 = k0 + f.chunk_cols;
-            const size_t t0 = (size_t)f.sched.stage_start[(size_t)k0];
-            const size_t t1 = k1 < nblk ? (size_t)f.sched.stage_start[(size_t)k1] : nt;
-            a.t_end = (unsigned)t1;
-            if (t1 > t0) hipLaunchKernelGGL(k_chol_flow, dim3((unsigned)std::min<size_t>((size_t)f.wgs, t1 - t0)), dim3(512), lds_bytes, st, a);
-        }
-    }
+    // every workgroup of the grid is resident at once (two per CU); small systems do not need them all
+    const unsigned grid = (unsigned)std::min<size_t>((size_t)f.wgs, nt + 2 * (size_t)f.chain_wgs);
+    hipLaunchKernelGGL(k_chol_flow, dim3(grid), dim3(512), lds_bytes, st, a);
     if (timed) { (void)hipEventRecord(f.k1, st); f.kern_pending = true; }
     // backward substitution
     const bool env = (int)w.env_rows.size() >= nblk && w.d_last != nullptr;

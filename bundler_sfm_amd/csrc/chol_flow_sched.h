@@ -9,10 +9,12 @@
 //      TRSM(i,k)             P_ik = S_ik W_k^T                                               (i > k; row T = the right-hand side: y_k)
 //      UPD(i,j,p0,np)        S_ij -= sum_{p = p0}^{p0+np-1} P_ip P_jp^T                      (i >= j > p; np panels in ONE pass over the tile)
 //
-// tasks are handed to resident workgroups in ONE fixed order by an atomic ticket, and each task waits on monotonic per-tile
+// tasks are handed to resident workgroups in a fixed order by an atomic ticket, and each task waits on monotonic per-tile
 // counters for exactly the tasks it depends on (flag >= threshold), then signals its own tile's counter.  Because every task's
-// dependencies hold EARLIER tickets, the order is a topological order of the task graph and the scheme cannot deadlock however many
-// workgroups are resident.
+// dependencies come EARLIER in the order, it is a topological order of the task graph and the scheme cannot deadlock however many
+// workgroups are resident.  The order is served as TWO queues, each a subsequence of it: the chain (POTRF, first panel tile, next
+// diagonal tile) by a few workgroups that have a CU to themselves, everything else by the rest -- the earliest unfinished task of
+// the whole order is always at the head of its queue with all of its dependencies done, so the argument carries over.
 //
 // This file builds that order: an event-driven simulation of greedy list scheduling on `slots` workgroup slots with estimated task
 // durations.  Priorities: the chain (POTRF, the first panel tile, the next diagonal tile) first; then the panel rows and the column
@@ -51,7 +53,7 @@ struct FlowWait { uint32_t idx, thr; };
 
 struct FlowTask {          // 40 bytes, read with scalar loads by the device
     uint8_t type, np, part, nwait;
-    uint16_t i, j, p0, pad;
+    uint16_t i, j, p0, pad;      // pad: queue (1 = chain, 0 = bulk)
     uint32_t sig;          // counter this task increments when it is done
     FlowWait w[3];
 };
@@ -61,11 +63,11 @@ struct FlowParams {
     int slots = 512;          // resident workgroups assumed by the simulation (2 per CU x 256)
     int np_max = 4;           // panels per bulk visit
     int np_max_rhs = 8;       // ... for the right-hand-side row
-    // estimated durations, microseconds (calibrated from the per-task trace, profiles/r04_flow_task_durations.txt)
-    double t_potrf = 42.0, t_trsm32 = 6.6, t_trsm64 = 28.0, t_upd32 = 7.3, t_upd32_per = 3.0;
-    double t_upd64_0 = 10.0, t_upd64_per = 20.0, t_upd128_0 = 14.0, t_upd128_per = 35.0;
-    double t_ftrsm = 3.0, t_fupd_0 = 3.0, t_fupd_per = 1.5;
-    double t_hand = 1.5;      // completion -> visible to a dependent
+    // estimated durations, microseconds: medians of the per-task trace of the n = 9 000 solve on MI355X (profiles/r04_flow_task_durations.txt)
+    double t_potrf = 56.0, t_trsm32 = 6.0, t_trsm64 = 17.0, t_upd32 = 7.5, t_upd32_per = 3.5;
+    double t_upd64_0 = 7.0, t_upd64_per = 12.5, t_upd128_0 = 12.0, t_upd128_per = 27.0;
+    double t_ftrsm = 10.0, t_fupd_0 = 5.0, t_fupd_per = 8.0;
+    double t_hand = 0.5;      // completion -> visible to a dependent (measured 0.3-0.5)
     int urgent_cols = 1;      // columns up to (chain front + urgent_cols) are served in halves / blocks
 };
 
@@ -174,7 +176,8 @@ inline int flow_build_schedule(int T, const std::vector<int>& last_in, const Flo
     auto emit = [&](uint8_t type, int i, int j, int p0, int np, int part, uint32_t sig, const FlowWait* w, int nw) {
         FlowTask k{};
         k.type = type; k.np = (uint8_t)np; k.part = (uint8_t)part; k.nwait = (uint8_t)nw;
-        k.i = (uint16_t)i; k.j = (uint16_t)j; k.p0 = (uint16_t)p0; k.pad = 0; k.sig = sig;
+        k.i = (uint16_t)i; k.j = (uint16_t)j; k.p0 = (uint16_t)p0; k.sig = sig;
+        k.pad = (type == FT_POTRF || type == FT_TRSM32 || type == FT_UPD32) ? 1 : 0;      // queue: 1 = the chain's own workgroups, 0 = bulk
         for (int q = 0; q < 3; ++q) k.w[q] = q < nw ? w[q] : FlowWait{ 0u, 0u };
         out.tasks.push_back(k);
         out.count[type]++;

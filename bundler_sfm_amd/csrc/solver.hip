@@ -1636,8 +1636,27 @@ int bsfm_dense_chol_solve(int n, const double* A, const double* b, double* x, in
             if (bsfm::dev_alloc((void**)&ws.d_last, (size_t)nt * sizeof(int)) != hipSuccess) break;
             if (hipMemcpy(ws.d_last, last.data(), (size_t)nt * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) break;
         }
-        if (potrf_solve(ws, dS, ld, n, dE, dx, dinfo, st)) break;
-        if (hipStreamSynchronize(st) != hipSuccess) break;
+        // BSFM_CHOL_REPS=n (diagnostics): solve n times (S is destroyed by a solve and uploaded again) and print the device time of each
+        int reps = 1;
+        if (const char* e = getenv("BSFM_CHOL_REPS")) reps = std::max(1, atoi(e));
+        bool failed = false;
+        for (int rep = 0; rep < reps && !failed; ++rep) {
+            if (rep > 0) {
+                if (hipMemset(dinfo, 0, sizeof(int)) != hipSuccess) { failed = true; break; }
+                if (hipMemcpy2D(dS, (size_t)ld * sizeof(double), A, (size_t)n * sizeof(double), (size_t)n * sizeof(double), n, hipMemcpyHostToDevice) != hipSuccess) { failed = true; break; }
+            }
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (reps > 1) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
+            if (potrf_solve(ws, dS, ld, n, dE, dx, dinfo, st)) { failed = true; break; }
+            if (reps > 1) (void)hipEventRecord(e1, st);
+            if (hipStreamSynchronize(st) != hipSuccess) { failed = true; break; }
+            if (reps > 1) {
+                float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+                fprintf(stderr, "[bsfm] dense_chol_solve n = %d rep %d: %.3f ms\n", n, rep, ms);
+                (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+            }
+        }
+        if (failed) break;
         if (hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) break;
         if (hipMemcpy(x, dx, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) break;
         rc = info;

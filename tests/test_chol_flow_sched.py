@@ -152,18 +152,24 @@ def test_schedule_replays_to_the_cholesky_factor(name, T, last, np_max):
     types = tasks["type"]
     assert (types == POTRF).sum() == T and (types == FTRSM).sum() == T
     assert len(rp.P) == sum(lastc[k] - k for k in range(T))
-    # (2) random interleavings that respect ONLY the waits (tickets are drawn in order, execution is not)
+    # (2) random interleavings that respect ONLY the waits.  The product serves the order as two queues -- the chain's tasks
+    # (queue 1) by their own workgroups, the rest (queue 0) by the others -- each drawn in order, executed in any order.
     rng = np.random.default_rng(7)
-    for workers in (2, 5, 64, 600):
+    queues = [np.flatnonzero(tasks["pad"] == 0), np.flatnonzero(tasks["pad"] == 1)]
+    assert set(tasks["type"][queues[1]].tolist()) <= {POTRF, TRSM32, UPD32} and len(queues[1]) > 0
+    for workers in ((1, 1), (2, 1), (5, 3), (64, 16), (600, 16), (1, 16)):
         rp = Replay(T, nb, A, b)
-        held, nxt, done = [], 0, 0
+        held = [[], []]
+        nxt = [0, 0]
+        done = 0
         while done < len(tasks):
-            while len(held) < workers and nxt < len(tasks):
-                held.append(nxt); nxt += 1
-            runnable = [k for k in held if rp.ready(tasks[k])]
+            for q in (0, 1):
+                while len(held[q]) < workers[q] and nxt[q] < len(queues[q]):
+                    held[q].append(int(queues[q][nxt[q]])); nxt[q] += 1
+            runnable = [(q, k) for q in (0, 1) for k in held[q] if rp.ready(tasks[k])]
             assert runnable, "deadlock: every worker holds a task whose waits cannot be met"
-            k = runnable[rng.integers(len(runnable))]
-            rp.run(tasks[k]); held.remove(k); done += 1
+            q, k = runnable[rng.integers(len(runnable))]
+            rp.run(tasks[k]); held[q].remove(k); done += 1
         check_result(rp, A, b, lastc)
 
 
