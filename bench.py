@@ -444,7 +444,26 @@ def main():
         phases = {ph: round(pb.phase_ms(ph), 4) for ph in
                   ("jacobian", "cam_blocks", "point_blocks", "point_invert", "schur", "solve", "backsub", "residual")}
         roof = None
-        if syrk_ms and syrk_ms > 0:
+        flow_ms = pb.phase_ms("flow_kernel")
+        whole = {"flop": sdim ** 3 / 3.0, "solve_ms": phases["solve"],
+                 "TFLOPs": round(sdim ** 3 / 3.0 / (phases["solve"] * 1e-3) / 1e12, 2) if phases["solve"] > 0 else None,
+                 "frac": round(sdim ** 3 / 3.0 / (phases["solve"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if phases["solve"] > 0 else None}
+        if flow_ms and flow_ms > 0:
+            # round 4: the whole factorisation (and the forward substitution) is ONE launch of k_chol_flow (csrc/chol_flow.hip.h);
+            # achieved = the flops of the tasks the library scheduled for that launch / its HIP-event duration on the launch stream
+            lib_flops = pb.phase_ms("flow_gflop") * 1e9
+            ach = lib_flops / (flow_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "k_chol_flow", "achieved": round(ach, 3), "peak": FP64_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic("k_chol_flow"),
+                    "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                    "this command (scripts/profile_round.sh -> profiles/*_pmc_traffic.json; 2 x FETCH_SIZE "
+                                    "per the gfx950 correction), NOT measured in this run; algorithmic traffic: every tile task reads and "
+                                    "writes its 128 KB C tile once per visit (1 to 4 panels per visit)",
+                    "mfma_counters": pmc_mfma("k_chol_flow"), "launches_per_solve": 1, "avg_launch_ms": round(flow_ms, 4),
+                    "alg_flop_per_launch": lib_flops, "tasks_per_launch": int(pb.phase_ms("flow_tasks")),
+                    "scheduler_estimate_ms": round(pb.phase_ms("flow_sim_us") * 1e-3, 3),
+                    "whole_factorisation": whole}
+        elif syrk_ms and syrk_ms > 0:
             lib_gflop = pb.phase_ms("syrk_gflop")       # the library's own count of what it launched
             lib_flops = lib_gflop * 1e9
             ach = lib_flops / (syrk_ms * 1e-3) / 1e12
@@ -455,9 +474,7 @@ def main():
                                     "per the gfx950 correction), NOT measured in this run; algorithmic C traffic is 2 x 128 KB per tile",
                     "mfma_counters": pmc_mfma("k_syrk_update"), "launches_per_solve": pb.phase_ms("syrk_launches"), "avg_launch_ms": round(syrk_ms, 4),
                     "alg_flop_per_launch": lib_flops,
-                    "whole_factorisation": {"flop": sdim ** 3 / 3.0, "solve_ms": phases["solve"],
-                                            "TFLOPs": round(sdim ** 3 / 3.0 / (phases["solve"] * 1e-3) / 1e12, 2) if phases["solve"] > 0 else None,
-                                            "frac": round(sdim ** 3 / 3.0 / (phases["solve"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if phases["solve"] > 0 else None}}
+                    "whole_factorisation": whole}
         # HBM-bound streaming kernels against the 8 TB/s roof: algorithmic bytes / HIP-event time
         rp = r["rp"]
         nv_loc, np_loc = float(r["k1"] - r["k0"]), float(r["hi"] - r["lo"])

@@ -441,6 +441,7 @@ void collect_phase_times(bsfm_problem* pb)
         if (hipEventElapsedTime(&ms, pb->ev[i][0], pb->ev[i][1]) == hipSuccess && ms >= 0.f) { pb->ph_ms[i] += ms; pb->ph_cnt[i]++; }
     }
     potrf_collect_time(pb->potrf);
+    if (pb->potrf.flow) flow_collect_time(*pb->potrf.flow);
     (void)hipGetLastError();      // phases that did not run this iteration leave hipErrorInvalidHandle behind: do not let it stick
 }
 
@@ -1064,6 +1065,12 @@ double bsfm_lm_last_kernel_ms(const bsfm_problem_t* pb, const char* phase)
     if (!strcmp(phase, "syrk")) return pb->potrf.syrk_cnt ? pb->potrf.syrk_ms / (double)pb->potrf.syrk_cnt : -1.0;
     if (!strcmp(phase, "syrk_gflop")) return pb->potrf.syrk_cnt ? pb->potrf.syrk_flops * 1e-9 / (double)pb->potrf.syrk_cnt : -1.0;
     if (!strcmp(phase, "syrk_launches")) return pb->potrf.cnt ? (double)pb->potrf.syrk_cnt / (double)pb->potrf.cnt : -1.0;
+    // the tile-dataflow factorisation (chol_flow.hip.h): HIP-event time of a k_chol_flow launch, the flops it was scheduled to do
+    // (UPD + TRSM tile products at 2 * 128^3, POTRF + inverse at 128^3 per diagonal tile), tasks per launch
+    if (!strcmp(phase, "flow_kernel")) return pb->potrf.flow && pb->potrf.flow->kern_cnt ? pb->potrf.flow->kern_ms / (double)pb->potrf.flow->kern_cnt : -1.0;
+    if (!strcmp(phase, "flow_gflop")) return pb->potrf.flow && pb->potrf.flow->kern_cnt ? (pb->potrf.flow->flops + (double)pb->potrf.flow->nblk * POTRF_NB * POTRF_NB * POTRF_NB) * 1e-9 : -1.0;
+    if (!strcmp(phase, "flow_tasks")) return pb->potrf.flow && pb->potrf.flow->kern_cnt ? (double)pb->potrf.flow->sched.tasks.size() : -1.0;
+    if (!strcmp(phase, "flow_sim_us")) return pb->potrf.flow && pb->potrf.flow->kern_cnt ? pb->potrf.flow->sched.sim_us : -1.0;
     // bsfm_problem_create: host wall time (total / upload of the visibility index / index construction / allocation) and the
     // device time of the index construction alone
     if (!strcmp(phase, "create_total")) return pb->create_ms[0];
@@ -1081,6 +1088,7 @@ int bsfm_lm_begin(bsfm_problem_t* pb)
     pb->mu = 0.0; pb->eab_inf = 0.0; pb->dp_L2 = DBL_MAX; pb->p_L2 = 0.0; pb->maxdiag = DBL_MIN;
     for (int i = 0; i < PH_COUNT; ++i) { pb->ph_ms[i] = 0.0; pb->ph_cnt[i] = 0; }
     pb->potrf.ms = 0.0; pb->potrf.cnt = 0; pb->potrf.syrk_ms = 0.0; pb->potrf.syrk_cnt = 0; pb->potrf.syrk_flops = 0.0;
+    if (pb->potrf.flow) { pb->potrf.flow->kern_ms = 0.0; pb->potrf.flow->kern_cnt = 0; pb->potrf.flow->kern_pending = false; }
     if (nobs < pb->nvars_global) {   // sba_levmar.c:647-650
         fprintf(stderr, "SBA: sba_motstr_levmar_x() cannot solve a problem with fewer measurements [%lld] than unknowns [%lld]\n",
                 nobs, pb->nvars_global);
