@@ -456,39 +456,41 @@ __device__ BSFM_FLOW_ROLE void flow_potrf(const FlowArgs& a_in, int k, double* l
 #pragma unroll
             for (int q = 0; q < 4; ++q) blk[swz16(4 * q + lr, lc)] = cur[q];
             BSFM_LDS_FENCE();
+            // lanes 0..15 hold the rows of the block (lane r: row r), lanes 16..31 the columns of inv(R) under construction (lane 16 + r:
+            // column r); both halves run the SAME instruction stream -- v[c] -= (v[j] / pivot_j) * R[c][j] is the elimination step for
+            // a row of the block and the substitution step for a column of the inverse -- so every broadcast R[c][j] is used by exactly
+            // one FMA.  (Two FMAs per broadcast, d and x in the same lanes, made the compiler park all 136 broadcasts in a VGPR
+            // through v_writelane / v_readlane: 1 774 instructions instead of ~700.)
             const int r = lc;
-            double d[16], x[16];
+            const bool is_x = lr == 1;
+            double v[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) { d[c] = blk[swz16(r, c)]; x[c] = (c == r) ? 1.0 : 0.0; }
+            for (int c = 0; c < 16; ++c) { const double e = blk[swz16(r, c)]; v[c] = is_x ? ((c == r) ? 1.0 : 0.0) : e; }
             double myp = 1.0;
             int bad = -1;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const double piv = BSFM_RDLANE(d[j], j);
+                const double piv = BSFM_RDLANE(v[j], j);           // lane j < 16: R[j][j]
                 if (!(piv > 0.0) && bad < 0) bad = j;              // (wave-uniform) first non-positive pivot = dpotrf's info
                 myp = (r == j) ? piv : myp;
                 double inv = __builtin_amdgcn_rcp(piv);
                 inv = fma(fma(-piv, inv, 1.0), inv, inv);
                 inv = fma(fma(-piv, inv, 1.0), inv, inv);
-                const double lrj = d[j] * inv;                    // R[r][j] / pivot_j
-                const double xj = x[j] * inv;                     // row j of inv(R), column r
-                x[j] = xj;
+                const double f = v[j] * inv;                      // rows: R[r][j] / pivot_j;  inverse: entry (j, r) of inv(R)
 #pragma unroll
                 for (int c = j + 1; c < 16; ++c) {
-                    const double sc = BSFM_RDLANE(d[j], c);       // R[c][j]
-                    d[c] -= lrj * sc;
-                    x[c] -= xj * sc;
+                    const double sc = BSFM_RDLANE(v[j], c);       // lane c < 16: R[c][j]
+                    v[c] -= f * sc;
                 }
+                v[j] = is_x ? f : v[j];
             }
             if (lane == 0 && bad >= 0 && base + 16 * sn + bad < n_total) atomicCAS(a.info, 0, base + 16 * sn + bad + 1);
             const double mysq = myp * rsqrt_f64(myp);              // L[r][r] = sqrt(pivot_r)
-            BSFM_LDS_FENCE();                                      // (every lane has read its row before lanes 0..15 overwrite the block)
-            if (lane < 16) {
+            BSFM_LDS_FENCE();                                      // (every lane has read its row before lanes 16..31 overwrite the block)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const double sq_i = BSFM_RDLANE(mysq, i);
-                    blk[swz16(i, r)] = x[i] * sq_i;               // inv(L)[i][r] = sqrt(pivot_i) inv(R)[i][r]
-                }
+            for (int i = 0; i < 16; ++i) {
+                const double sq_i = BSFM_RDLANE(mysq, i);
+                if (is_x) blk[swz16(i, r)] = v[i] * sq_i;         // inv(L)[i][r] = sqrt(pivot_i) inv(R)[i][r]
             }
         }
         if (s >= 0) {
