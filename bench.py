@@ -19,8 +19,8 @@ RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT, all-reduces enqueued on the comput
 torch.distributed hook of round 1 remains only as a fallback when the communicator cannot be created (`collective` in the
 line says which one ran).
 
-Also in the line (N = 1): `cpu_baseline` (the reference's own SBA at the headline config from the committed
-profiles/*_cpu_baseline_cfg3.json measured on the GPU box's host, plus a small live sample of this run), `connected_scene`
+Also in the line (N = 1): `cpu_baseline` (the reference's own SBA at the headline config, ONE iteration timed live in this run on one host
+core, with the committed profiles/*_cpu_baseline_cfg3.json of an earlier round beside it), `connected_scene`
 (the same size with banded visibility: a connected camera graph), `matcher` (BASELINE.json configs[4]: KeyMatchFull all-pairs,
 500 images x 5 000 keys, with its own roofline and CPU baseline).  `--workload match` prints the matcher line alone.
 
@@ -53,9 +53,9 @@ def parse():
     ap.add_argument("--jacobian", choices=["fd", "analytic"], default="fd",
                     help="fd = the reference's forward differences (run_sfm default), analytic = closed form")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline", choices=["cached", "live"], default="cached",
-                    help="cached (default): the reference's headline-size run measured on the GPU box's host and committed under profiles/ "
-                         "+ a small live sample; live: run the reference at the headline size in THIS run (one iteration, ~1.5 min of one core)")
+    ap.add_argument("--cpu-baseline", choices=["cached", "live"], default="live",
+                    help="live (default): run the reference at the headline size in THIS run (one LM iteration, ~1.5 min of one host core), the "
+                         "committed figure of an earlier round beside it; cached: only the committed profiles/*_cpu_baseline_cfg3.json + a small live sample")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the end_to_end_run_sfm object (dense vmask in, cameras / points out)")
     ap.add_argument("--reduced-solver", choices=["dense", "auto"], default="dense",
                     help="dense (default, the reference's algorithm: Cholesky of the whole reduced camera system) or auto "
@@ -245,6 +245,7 @@ def matcher_leg(args, passes=1):
     el = (time.perf_counter() - t0) / passes
     kms, dist, npairs, nl = C.c_double(), C.c_double(), C.c_longlong(), C.c_int()
     B.lib.bsfm_match_set_stats(ms, C.byref(kms), C.byref(dist), C.byref(npairs), C.byref(nl))
+    n_rescan = int(B.lib.bsfm_match_set_rescan_launches(ms))
     B.lib.bsfm_match_set_destroy(ms)
     size = os.path.getsize(out_path)
     os.unlink(out_path)
@@ -257,11 +258,15 @@ def matcher_leg(args, passes=1):
                       "image_pairs": pairs_total, "pair_blocks_written": blocks, "output_bytes": size,
                       "key_generation_s": round(t_gen, 2), "upload_and_stats_s": round(t_up, 3)},
            "roofline": None if ach is None else {
-               "bound": "mfma", "kernel": "k_match_l2", "achieved": round(ach, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
+               "bound": "mfma", "kernel": "k_match_bound" if 2 * n_rescan >= nl.value else "k_match_l2",
+               "launches_by_kernel": {"k_match_bound": n_rescan, "k_match_l2": int(nl.value) - n_rescan},
+               "achieved": round(ach, 1), "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s",
                "frac": round(ach / I8_MFMA_PEAK_TOPS, 4), "traffic": None,
+               "frac_wall_clock": round(ops / el / 1e12 / I8_MFMA_PEAK_TOPS, 4),
                "alg_ops_per_launch": ops / max(nl.value, 1), "launches": nl.value, "avg_launch_ms": round(kms.value / max(nl.value, 1), 4),
                "kernel_ms_per_pass": round(kms.value, 2), "us_per_image_pair": round(1e3 * kms.value / max(npairs.value, 1), 3),
-               "note": "achieved = 2 x 128 int8 ops per descriptor distance x distances of the launches / HIP-event time of the launches "
+               "note": "frac_wall_clock = the same ops / the wall time of the pass (pair write-out included); "
+                       "achieved = 2 x 128 int8 ops per descriptor distance x distances of the launches / HIP-event time of the launches "
                        "(the UNION of their intervals: consecutive launches alternate between two streams so that one's tail overlaps the next one's "
                        "head; BSFM_MATCH_STREAMS=1 serialises them, which is what profiles/*_match_kernel_stats.csv was taken with) "
                        "(match_l2.hip); peak = measured v_mfma_i32_16x16x64_i8 ceiling; compulsory HBM traffic is the 320 MB key set "

@@ -69,7 +69,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 SYMBOLS = [
     "bsfm_default_options", "run_sfm", "bsfm_run_sfm_ex", "bsfm_sba_motstr_levmar", "bsfm_sba_mot_levmar", "bsfm_problem_create", "bsfm_problem_destroy",
     "bsfm_comm_create_from_env", "bsfm_comm_create_all", "bsfm_comm_destroy", "bsfm_comm_rank", "bsfm_comm_world", "bsfm_comm_transport",
-    "bsfm_comm_allreduce", "bsfm_comm_allreduce_host", "bsfm_comm_barrier", "bsfm_problem_set_comm",
+    "bsfm_comm_allreduce", "bsfm_comm_allreduce_host", "bsfm_comm_barrier", "bsfm_comm_idfile_exchange", "bsfm_problem_set_comm",
     "bsfm_problem_set_allreduce", "bsfm_problem_set_stream", "bsfm_problem_reset_params", "bsfm_problem_append", "bsfm_problem_remove_points", "bsfm_lm_begin",
     "bsfm_lm_iterate", "bsfm_lm_finish", "bsfm_lm_solve_attempts", "bsfm_lm_last_kernel_ms",
     "bsfm_problem_download", "bsfm_problem_export_index", "bsfm_problem_schur_sizes", "bsfm_problem_export_schur", "bsfm_crs_from_vmask", "bsfm_crs_from_vmask_device", "bsfm_run_sfm_last_ms", "bsfm_schur_chunk", "bsfm_device_cache_trim",
@@ -157,6 +157,8 @@ def _load():
     lib.bsfm_eval_normal_equations.restype = C.c_int
     lib.bsfm_dense_chol_solve.argtypes = [C.c_int, dp, dp, dp, C.c_int]
     lib.bsfm_dense_chol_solve.restype = C.c_int
+    lib.bsfm_comm_idfile_exchange.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_ubyte)]
+    lib.bsfm_comm_idfile_exchange.restype = C.c_int
     lib.bsfm_chol_flow_schedule.argtypes = [C.c_int, ip, C.c_int, C.c_int, vp, C.c_int, dp]
     lib.bsfm_chol_flow_schedule.restype = C.c_int
     ucp = C.POINTER(C.c_ubyte)

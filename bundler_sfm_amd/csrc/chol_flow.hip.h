@@ -702,13 +702,16 @@ __global__ __launch_bounds__(512, BSFM_FLOW_WPS) void k_chol_flow(FlowArgs a)
 }
 
 // Backward substitution x = L^-T y, one persistent launch (k_bwd_persistent of potrf.hip.h reading the compact panel tiles).
-__global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc, int nblk, const double* __restrict__ Linv,
+// Every workgroup of a launch must be resident (it waits for the tile columns to its right), so systems of more than POTRF_MAX_TILES
+// tile columns run it in WAVES of that many columns, rightmost first (`first` = columns already done): a later wave finds the flags
+// of the earlier ones set.
+__global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc, int nblk, int first, const double* __restrict__ Linv,
         const double* __restrict__ y, double* x, int* flags, int* timeout, const int* __restrict__ last_row)
 {
     __shared__ double yk[POTRF_NB];
     __shared__ double xi[POTRF_NB];
     __shared__ double red[POTRF_NB];
-    const int kk = nblk - 1 - (int)blockIdx.x;
+    const int kk = nblk - 1 - first - (int)blockIdx.x;
     const int c = threadIdx.x & 127, h = threadIdx.x >> 7;
     double lreg[64], tcur[64];
     {
@@ -897,8 +900,9 @@ inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, in
     // backward substitution
     const bool env = (int)w.env_rows.size() >= nblk && w.d_last != nullptr;
     (void)hipMemsetAsync(w.bflags, 0, (size_t)(w.nblk + 1) * sizeof(int), st);
-    hipLaunchKernelGGL(k_bwd_flow, dim3(nblk), dim3(256), 0, st, (const double*)f.pc, nblk, (const double*)w.linv, (const double*)w.y, w.xs,
-                       w.bflags, w.bflags + w.nblk, (const int*)(env ? w.d_last : nullptr));
+    for (int first = 0; first < nblk; first += POTRF_MAX_TILES)
+        hipLaunchKernelGGL(k_bwd_flow, dim3(std::min(POTRF_MAX_TILES, nblk - first)), dim3(256), 0, st, (const double*)f.pc, nblk, first,
+                           (const double*)w.linv, (const double*)w.y, w.xs, w.bflags, w.bflags + w.nblk, (const int*)(env ? w.d_last : nullptr));
     hipLaunchKernelGGL(k_flow_fold_timeout, dim3(1), dim3(1), 0, st, (const unsigned*)f.d_sync, (const int*)(w.bflags + w.nblk), d_info);
     (void)hipMemcpyAsync(x_out, w.xs, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
     if (f.trace) flow_dump_trace(f, st);

@@ -35,6 +35,7 @@
 #include <chrono>
 #include <thread>
 #include "../../include/bsfm.h"
+#include "idfile.h"
 
 namespace {
 
@@ -215,14 +216,8 @@ int bsfm_comm_barrier(bsfm_comm_t* c)
 }  // extern "C"
 namespace {
 
-struct IdFilePayload { unsigned long long magic; int world; int reserved; long long created_ns; ncclUniqueId id; };
-constexpr unsigned long long ID_MAGIC = 0x6273666d5f6e6363ULL;      // "bsfm_ncc"
-
-long long now_ns()
-{
-    return (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
-}
-const long long g_process_start_ns = now_ns();                       // static initialisation = library load
+static_assert(sizeof(ncclUniqueId) == bsfm::IDFILE_PAYLOAD, "the id file carries exactly one ncclUniqueId");
+const long long g_process_start_ns = bsfm::idfile_now_ns();          // static initialisation = library load
 
 std::string sanitize(const char* s)
 {
@@ -270,40 +265,19 @@ bsfm_comm_t* bsfm_comm_create_from_env(void)
                sanitize(getenv("TORCHELASTIC_RUN_ID")) + ".id";
     c->id_file = path;
     const double tmo = comm_timeout_s();
-    IdFilePayload pl;
-    memset(&pl, 0, sizeof(pl));
+    ncclUniqueId uid;
+    memset(&uid, 0, sizeof(uid));
     if (rank == 0) {
-        if (rccl().GetUniqueId(&pl.id) != ncclSuccess) { fprintf(stderr, "[bsfm] comm: ncclGetUniqueId failed\n"); delete c; return nullptr; }
-        pl.magic = ID_MAGIC; pl.world = world; pl.created_ns = now_ns();
-        const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
-        (void)unlink(path.c_str());                               // a stale id of an earlier job with the same address / port
-        (void)unlink(tmp.c_str());
-        const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
-        bool ok = fd >= 0 && write(fd, &pl, sizeof(pl)) == (ssize_t)sizeof(pl);
-        if (fd >= 0) ok = (close(fd) == 0) && ok;
-        if (!ok || rename(tmp.c_str(), path.c_str()) != 0) {
-            fprintf(stderr, "[bsfm] comm: cannot publish %s\n", path.c_str()); (void)unlink(tmp.c_str()); delete c; return nullptr;
-        }
+        if (rccl().GetUniqueId(&uid) != ncclSuccess) { fprintf(stderr, "[bsfm] comm: ncclGetUniqueId failed\n"); delete c; return nullptr; }
+        if (bsfm::idfile_publish(path, world, reinterpret_cast<const unsigned char*>(&uid)) != 0) { delete c; return nullptr; }
     } else {
-        const long long grace_ns = 120LL * 1000000000LL;           // launchers start their ranks within seconds of each other
-        const auto t0 = std::chrono::steady_clock::now();
-        bool got = false;
-        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < tmo) {
-            const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW);
-            if (fd >= 0) {
-                IdFilePayload q;
-                const bool rd = read(fd, &q, sizeof(q)) == (ssize_t)sizeof(q);
-                (void)close(fd);
-                if (rd && q.magic == ID_MAGIC && q.world == world && q.created_ns >= g_process_start_ns - grace_ns) { pl = q; got = true; break; }
-            }
-            std::this_thread::sleep_for(std::chrono::milliseconds(20));
-        }
-        if (!got) { fprintf(stderr, "[bsfm] comm: rank %d found no fresh id at %s within %.0f s (is rank 0 running with the same MASTER_ADDR / MASTER_PORT / WORLD_SIZE?)\n", rank, path.c_str(), tmo); delete c; return nullptr; }
+        // launchers start their ranks within seconds of each other: 120 s of grace
+        if (bsfm::idfile_wait(path, world, rank, tmo, g_process_start_ns, 120.0, reinterpret_cast<unsigned char*>(&uid)) != 0) { delete c; return nullptr; }
     }
     ncclResult_t r = ncclSuccess;
     ncclComm_t* slot = &c->nccl;
     const int dev = c->device;
-    const ncclUniqueId id = pl.id;
+    const ncclUniqueId id = uid;
     if (!with_timeout(tmo, [&r, slot, world, id, rank, dev] { (void)hipSetDevice(dev); r = rccl().CommInitRank(slot, world, id, rank); })) {
         fprintf(stderr, "[bsfm] FATAL: ncclCommInitRank did not complete within %.0f s on rank %d of %d (a rank is missing or holds another job's id); RCCL cannot be cancelled -- exiting\n", tmo, rank, world);
         fflush(stderr);
@@ -312,6 +286,16 @@ bsfm_comm_t* bsfm_comm_create_from_env(void)
     if (r != ncclSuccess) { fprintf(stderr, "[bsfm] ncclCommInitRank failed: %s\n", rccl().GetErrorString(r)); c->nccl = nullptr; bsfm_comm_destroy(c); return nullptr; }
     if (comm_alloc_common(c)) { bsfm_comm_destroy(c); return nullptr; }
     return c;
+}
+
+// Test hook (no device, no RCCL): the id hand-over of bsfm_comm_create_from_env on its own.  rank 0 publishes id[128] at `path`, any
+// other rank waits up to timeout_s for a record that passes every check of idfile.h and receives it in id[128].  grace_s = how much
+// older than this process a record may be (120 in production).  Returns 0, or BSFM_ERROR (message on stderr).
+int bsfm_comm_idfile_exchange(const char* path, int rank, int world, double timeout_s, double grace_s, unsigned char* id)
+{
+    if (!path || !id || world < 1 || rank < 0 || rank >= world) return BSFM_ERROR;
+    if (rank == 0) return bsfm::idfile_publish(path, world, id) == 0 ? 0 : BSFM_ERROR;
+    return bsfm::idfile_wait(path, world, rank, timeout_s, g_process_start_ns, grace_s, id) == 0 ? 0 : BSFM_ERROR;
 }
 
 // One rank per thread of THIS process: fills comms[0 .. ndev-1] for the devices devs[.] (the caller's threads then each take one

@@ -16,7 +16,8 @@ constexpr int SCHUR_CHUNK_MAX = 192;  // upper bound of the co-visibility triple
 int schur_chunk();
 
 // Everything the LM kernels index with, built on the device from the CRS (rowptr, colidx) the caller hands over.
-// All pointers are device memory owned by the receiver (hipFree each one that is non-null).
+// All pointers are device memory owned by the receiver; they come from bsfm::dev_alloc (devcache.h): release each non-null one with
+// bsfm::dev_free, NOT hipFree (the block cache keeps a record of every block it hands out).
 struct DeviceIndex {
     int* obs_pt = nullptr;        // nvis: point of observation k
     int* camptr = nullptr;        // m + 1
@@ -42,7 +43,7 @@ void free_index_device(DeviceIndex& ix);
 
 // Growing a resident problem: merges `nadd` new observations (point, camera, x, y -- device arrays, any order) into
 // an existing CRS (rowptr / obs_pt / colidx / x of nvis observations) for n_new points and m_new cameras.  Outputs (device, owned by
-// the caller, hipFree): rowptr_out (n_new + 1), colidx_out and x_out (nvis + nadd; 2 doubles per observation), ordered by
+// the caller, bsfm::dev_free): rowptr_out (n_new + 1), colidx_out and x_out (nvis + nadd; 2 doubles per observation), ordered by
 // (point, camera) = the reference's measurement order.  Returns 0, or -1 (index out of range, an observation given twice).
 int merge_observations_device(int n_new, int m_new, int nvis, const int* d_obs_pt, const int* d_colidx, const double* d_x,
                               int nadd, const int* d_add_pt, const int* d_add_cam, const double* d_add_xy,
@@ -50,7 +51,7 @@ int merge_observations_device(int n_new, int m_new, int nvis, const int* d_obs_p
 
 // Shrinking a resident problem (the outlier loop of RunSFM_SBA, src/Bundle.cpp:784-913): drops the points with
 // d_remove[i] != 0 (device, n bytes) and all their observations; the others keep their order.  Outputs (device, owned by the caller,
-// hipFree): the CRS of the kept points, remap_out (n: new index or -1); *n_keep / *nvis_keep.  Returns 0 or -1.
+// bsfm::dev_free): the CRS of the kept points, remap_out (n: new index or -1); *n_keep / *nvis_keep.  Returns 0 or -1.
 int compact_points_device(int n, int nvis, const int* d_rowptr, const int* d_obs_pt, const int* d_colidx, const double* d_x,
                           const unsigned char* d_remove, int** rowptr_out, int** colidx_out, double** x_out, int** remap_out,
                           int* n_keep, int* nvis_keep, hipStream_t st);
@@ -58,9 +59,11 @@ int compact_points_device(int n, int nvis, const int* d_rowptr, const int* d_obs
 int gather_kept_device(int n, const int* d_remap, int width_bytes, const void* src, void* dst, hipStream_t st);
 
 // Dense visibility mask (host, n*m bytes, row-major, the reference's vmask) -> CRS ON THE DEVICE: uploads the mask and builds
-// rowptr (n + 1) / colidx (nvis) there (device arrays owned by the caller, hipFree).  Bit-identical to the reference's fill loop
+// rowptr (n + 1) / colidx (nvis) there (device arrays owned by the caller, bsfm::dev_free).  Bit-identical to the reference's fill loop
 // (lib/sba-1.5/sba_levmar.c:642-663).  ms_out (optional): upload / kernels / total wall milliseconds.  Returns 0 or -1.
 int crs_from_vmask_device(int n, int m, const char* h_vmask, int** d_rowptr_out, int** d_colidx_out, int* nvis_out, double ms_out[3],
                           hipStream_t st);
 
+// Gives the pages of the private stream-ordered scratch pools back to the driver (bsfm_device_cache_trim).
+void index_pool_trim();
 }  // namespace bsfm

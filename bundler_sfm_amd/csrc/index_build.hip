@@ -175,9 +175,9 @@ __global__ void k_launch_order(int ntasks, int nwg, const SchurTask* __restrict_
 // Temporaries come from a PRIVATE stream-ordered pool per device (release threshold unlimited, so the ~0.9 GB of sort buffers of one
 // problem_create are still there for the next run_sfm call).  Round 2 raised the threshold of the process-wide DEFAULT pool instead,
 // which changed the host application's own allocation behaviour; the default pool is no longer touched.
+static hipMemPool_t g_scratch_pools[64] = {};
 inline hipMemPool_t scratch_pool()
 {
-    static hipMemPool_t pools[64] = {};
     static std::once_flag once[64];
     int dev = 0; (void)hipGetDevice(&dev);
     const int slot = dev & 63;
@@ -192,10 +192,10 @@ inline hipMemPool_t scratch_pool()
         if (hipMemPoolCreate(&pool, &props) == hipSuccess && pool) {
             unsigned long long thr = ~0ULL;
             (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
-            pools[slot] = pool;
+            g_scratch_pools[slot] = pool;
         } else (void)hipGetLastError();          // no private pool: plain hipMallocAsync on the default pool, untouched
     });
-    return pools[slot];
+    return g_scratch_pools[slot];
 }
 
 struct Scratch {
@@ -280,12 +280,13 @@ int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int
     IX_OK(hipStreamSynchronize(st));
     ix.ntasks = ntasks;
     SchurTask* tasks = nullptr;
-    if (order_by_block) IX_OK(bsfm::dev_alloc((void**)&tasks, std::max<size_t>(1, (size_t)ntasks) * sizeof(SchurTask)));
-    else IX_OK(tmp.alloc(&tasks, (size_t)ntasks));
+    if (order_by_block) {
+        IX_OK(bsfm::dev_alloc((void**)&tasks, std::max<size_t>(1, (size_t)ntasks) * sizeof(SchurTask)));
+        ix.tasks = tasks; ix.nslots = ntasks;          // owned by ix from here on: free_index_device releases it on every error path
+    } else IX_OK(tmp.alloc(&tasks, (size_t)ntasks));
     hipLaunchKernelGGL(k_tasks, dim3(grid_for(nblk, 256)), dim3(256), 0, st, nblk, blk_start, ix.blk_task0, ix.blk_j, ix.blk_k, tasks, schur_chunk());
     hipLaunchKernelGGL(k_tri_pt, dim3(grid_for(nt, 256)), dim3(256), 0, st, (int)nt, vals_out, ix.cam_pt, ix.tri_pt);
-    if (order_by_block) { ix.tasks = tasks; ix.nslots = ntasks; }
-    else {
+    if (!order_by_block) {
         int *tk_in = nullptr, *tk_out = nullptr, *id_in = nullptr, *ord = nullptr;
         IX_OK(tmp.alloc(&tk_in, (size_t)ntasks)); IX_OK(tmp.alloc(&tk_out, (size_t)ntasks));
         IX_OK(tmp.alloc(&id_in, (size_t)ntasks)); IX_OK(tmp.alloc(&ord, (size_t)ntasks));
@@ -312,6 +313,12 @@ int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int
 }
 
 }  // namespace
+
+// bsfm_device_cache_trim: the private scratch pools give their pages back too (every device that built an index)
+void index_pool_trim()
+{
+    for (hipMemPool_t pool : g_scratch_pools) if (pool) (void)hipMemPoolTrimTo(pool, 0);
+}
 
 namespace {
 

@@ -1166,7 +1166,7 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         return 0;
     }
     const int nblk = (n + POTRF_NB - 1) / POTRF_NB;
-    if (nblk > POTRF_MAX_TILES) {
+    if (nblk > POTRF_MAX_TILES && !w.use_flow) {      // (the dataflow path runs its backward substitution in waves of POTRF_MAX_TILES columns)
         fprintf(stderr, "[bsfm] reduced camera system of order %d exceeds the %d-tile residency limit of the persistent "
                         "backward substitution\n", n, POTRF_MAX_TILES);
         return -1;

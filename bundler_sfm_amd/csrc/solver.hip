@@ -82,7 +82,8 @@ struct DevCache {
     std::unordered_map<unsigned long long, std::vector<void*>> bins;
     std::deque<std::pair<unsigned long long, void*>> fifo;
     std::unordered_map<void*, unsigned long long> idle_key;     // idle block -> its bin
-    std::unordered_map<void*, size_t> live;                      // class size of every block handed out
+    struct Live { size_t cls; int dev; };
+    std::unordered_map<void*, Live> live;                        // class size and ALLOCATING device of every block handed out
     size_t idle_bytes = 0, cap = 0;
     DevCache()
     {
@@ -126,7 +127,7 @@ hipError_t dev_alloc(void** p, size_t bytes)
     if (it != c.bins.end() && !it->second.empty()) {
         *p = it->second.back(); it->second.pop_back();
         c.idle_key.erase(*p); c.idle_bytes -= cls;
-        c.live[*p] = cls;
+        c.live[*p] = DevCache::Live{ cls, dev };
         return hipSuccess;
     }
     hipError_t e = hipMalloc(p, cls);
@@ -136,7 +137,7 @@ hipError_t dev_alloc(void** p, size_t bytes)
         c.trim_locked();
         e = hipMalloc(p, cls);
     }
-    if (e == hipSuccess) c.live[*p] = cls;
+    if (e == hipSuccess) c.live[*p] = DevCache::Live{ cls, dev };
     return e;
 }
 
@@ -147,11 +148,19 @@ void dev_free(void* p, bool synced)
     std::unique_lock<std::mutex> lk(c.mu);
     auto it = c.live.find(p);
     if (it == c.live.end()) { lk.unlock(); (void)hipFree(p); return; }     // not one of ours
-    const size_t cls = it->second;
-    c.live.erase(it);
+    const size_t cls = it->second.cls;
+    const int dev = it->second.dev;              // the device the block lives on, NOT the one that happens to be current (ADVICE r3:
+    c.live.erase(it);                            // a problem created on GPU 1 and destroyed with GPU 0 current used to land in GPU 0's bins)
     if (c.cap == 0 || cls > c.cap) { lk.unlock(); (void)hipFree(p); return; }
-    int dev = 0; (void)hipGetDevice(&dev);
-    if (!synced) { lk.unlock(); (void)hipDeviceSynchronize(); lk.lock(); }
+    if (!synced) {
+        // nothing may still be using the block: synchronise ITS device
+        lk.unlock();
+        int cur = 0; (void)hipGetDevice(&cur);
+        if (cur != dev) (void)hipSetDevice(dev);
+        (void)hipDeviceSynchronize();
+        if (cur != dev) (void)hipSetDevice(cur);
+        lk.lock();
+    }
     const unsigned long long key = DevCache::key_of(dev, cls);
     c.bins[key].push_back(p); c.idle_key[p] = key; c.fifo.emplace_back(key, p); c.idle_bytes += cls;
     size_t guard = c.fifo.size();
@@ -177,9 +186,17 @@ void dev_free(void* p, bool synced)
 extern "C" void bsfm_device_cache_trim(void)
 {
     (void)hipDeviceSynchronize();
-    bsfm::DevCache& c = bsfm::dev_cache();
-    std::lock_guard<std::mutex> lk(c.mu);
-    c.trim_locked();
+    {
+        bsfm::DevCache& c = bsfm::dev_cache();
+        std::lock_guard<std::mutex> lk(c.mu);
+        c.trim_locked();
+    }
+    // the stream-ordered pools the index construction draws its sort scratch from keep their pages too
+    int dev = 0;
+    hipMemPool_t pool = nullptr;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) (void)hipMemPoolTrimTo(pool, 0);
+    bsfm::index_pool_trim();
+    (void)hipGetLastError();
 }
 
 struct bsfm_problem {

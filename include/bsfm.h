@@ -205,6 +205,11 @@ const char *bsfm_comm_transport(const bsfm_comm_t *c);      /* "rccl", "loopback
 int bsfm_comm_allreduce(bsfm_comm_t *c, void *device_buf, size_t count, int op, void *stream);
 int bsfm_comm_allreduce_host(bsfm_comm_t *c, double *vals, int count, int op);     /* count <= 256, synchronous */
 int bsfm_comm_barrier(bsfm_comm_t *c);
+/* Test hook (no device, no RCCL): the id hand-over of bsfm_comm_create_from_env on its own (csrc/idfile.h).  rank 0 publishes
+ * id[128] at `path`; any other rank waits up to timeout_s for a record that was written by THIS user with mode 0600, is no symbolic
+ * link, carries this world size and is not older than the calling process by more than grace_s (120 in production), and receives it
+ * in id[128].  Returns 0 or BSFM_ERROR (message on stderr). */
+int bsfm_comm_idfile_exchange(const char *path, int rank, int world, double timeout_s, double grace_s, unsigned char *id);
 
 bsfm_problem_t *bsfm_problem_create(const bsfm_problem_desc_t *desc, const bsfm_options_t *opt);
 void bsfm_problem_destroy(bsfm_problem_t *pb);

@@ -60,8 +60,8 @@ def test_cross_check_backend_agrees(gpu_bsfm):
 
 @pytest.mark.timeout(900)
 def test_solve_at_the_headline_order_9000(gpu_bsfm):
-    """n = 9 000 = 71 tile columns: the size of the reduced camera system of BASELINE.json configs[2] -- three-stream
-    lookahead schedule, ring of 4 panel buffers, 68 bulk launches, persistent backward substitution over 71 workgroups."""
+    """n = 9 000 = 71 tile columns: the size of the reduced camera system of BASELINE.json configs[2] -- one k_chol_flow launch
+    of ~42 000 tile tasks (csrc/chol_flow.hip.h), persistent backward substitution over 71 workgroups."""
     n = 9000
     rng = np.random.default_rng(9000)
     # low-rank-plus-diagonal SPD matrix with a wide spectrum (building A A^T at this order on the host would take minutes)
@@ -78,6 +78,27 @@ def test_solve_at_the_headline_order_9000(gpu_bsfm):
     G = F * np.sqrt(np.linspace(0.5, 2.0, 64))
     Dib = b / d; DiG = G / d[:, None]
     xw = Dib - DiG @ np.linalg.solve(np.eye(64) + G.T @ DiG, G.T @ Dib)
+    assert np.abs(x - xw).max() <= 1e-9 * np.abs(xw).max()
+
+
+@pytest.mark.skipif(os.environ.get("BSFM_TEST_HUGE") != "1", reason="31 232 unknowns = 244 tile columns: 7.8 GB on the host, minutes; set BSFM_TEST_HUGE=1")
+@pytest.mark.timeout(1800)
+def test_more_than_240_tile_columns(gpu_bsfm):
+    """Rounds 1-3 refused systems of more than 240 tile columns (3 413 cameras): the persistent backward substitution needs one
+    resident workgroup per tile column.  The dataflow path (round 4) runs it in waves of 240 columns."""
+    n = 244 * 128
+    rng = np.random.default_rng(31232)
+    F = rng.standard_normal((n, 32))
+    d = np.exp(rng.uniform(np.log(1e-1), np.log(1e1), n))
+    w = np.linspace(0.5, 2.0, 32)
+    A = (F * w) @ F.T
+    A[np.diag_indices(n)] += d
+    b = rng.standard_normal(n)
+    rc, x = gpu_bsfm.dense_chol_solve(A, b)
+    assert rc == 0
+    G = F * np.sqrt(w)
+    Dib = b / d; DiG = G / d[:, None]
+    xw = Dib - DiG @ np.linalg.solve(np.eye(32) + G.T @ DiG, G.T @ Dib)       # Woodbury
     assert np.abs(x - xw).max() <= 1e-9 * np.abs(xw).max()
 
 
