@@ -797,6 +797,7 @@ inline FlowParams flow_params_from_env()
     if (const char* e = getenv("BSFM_FLOW_NPMAX")) p.np_max = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("BSFM_FLOW_SLOTS")) p.slots = std::max(32, atoi(e));
     if (const char* e = getenv("BSFM_FLOW_URGENT")) p.urgent_cols = std::max(0, atoi(e));
+    if (const char* e = getenv("BSFM_FLOW_LAZY")) p.lazy_cols = std::max(0, atoi(e));
     if (const char* e = getenv("BSFM_FLOW_TPOTRF")) p.t_potrf = atof(e);
     if (const char* e = getenv("BSFM_FLOW_TUPD128")) { double a0 = 0, a1 = 0; if (sscanf(e, "%lf,%lf", &a0, &a1) == 2) { p.t_upd128_0 = a0; p.t_upd128_per = a1; } }
     return p;

@@ -69,6 +69,8 @@ struct FlowParams {
     double t_ftrsm = 10.0, t_fupd_0 = 5.0, t_fupd_per = 8.0;
     double t_hand = 0.5;      // completion -> visible to a dependent (measured 0.3-0.5)
     int urgent_cols = 1;      // columns up to (chain front + urgent_cols) are served in halves / blocks
+    int lazy_cols = 0;        // > 0: a bulk tile further than this many columns ahead of the chain is only visited once TWO panels are ready
+                              // for it (or its last one): a one-panel visit moves 393 KB for 4.2 Mflop and is HBM-bound
 };
 
 struct FlowSchedule {
@@ -163,7 +165,9 @@ inline int flow_build_schedule(int T, const std::vector<int>& last_in, const Flo
         if (t.busy || t.fin || t.started_final) return;
         if (t.t_ready > now) return;
         if (t.ver < j) {
-            if (panels_ready(i, j, t.ver) > 0) ready.push({ classify_upd(i, j), j, i, 1 });
+            const int nr = panels_ready(i, j, t.ver);
+            const int need = (prm.lazy_cols > 0 && i != T && j > front + prm.lazy_cols) ? std::min(2, j - t.ver) : 1;
+            if (nr >= need) ready.push({ classify_upd(i, j), j, i, 1 });
         } else {
             // final: POTRF (diagonal) or TRSM
             if (i == j) ready.push({ 0, j, i, 0 });
@@ -196,7 +200,14 @@ inline int flow_build_schedule(int T, const std::vector<int>& last_in, const Flo
             // re-validate
             bool ok = !t.busy && !t.fin && !t.started_final && t.t_ready <= now;
             int n = 0;
-            if (ok && c.kind == 1) { ok = t.ver < j; if (ok) { n = panels_ready(i, j, t.ver); ok = n > 0; } }
+            if (ok && c.kind == 1) {
+                ok = t.ver < j;
+                if (ok) {
+                    n = panels_ready(i, j, t.ver);
+                    const int need = (prm.lazy_cols > 0 && i != T && j > front + prm.lazy_cols) ? std::min(2, j - t.ver) : 1;
+                    ok = n >= need;
+                }
+            }
             if (ok && c.kind == 0) {
                 ok = t.ver >= j;
                 if (ok && i != j) { const Tile& d = tl(j, j); ok = d.p_ready >= 0.0 && d.p_ready <= now; }
@@ -266,7 +277,7 @@ inline int flow_build_schedule(int T, const std::vector<int>& last_in, const Flo
                     potrf_done[(size_t)j] = 1;
                     while (front < T && potrf_done[(size_t)front]) ++front;
                     for (int r = j + 1; r < R; ++r) consider(r, j);                      // TRSMs of column j
-                    for (int c2 = j + 1; c2 <= std::min(T - 1, front + prm.urgent_cols); ++c2)     // urgency may have changed
+                    for (int c2 = j + 1; c2 <= std::min(T - 1, front + std::max(prm.urgent_cols, prm.lazy_cols)); ++c2)     // urgency may have changed
                         for (int r = c2; r < R; ++r) consider(r, c2);
                 } else {
                     // P_ij ready: row operand of tiles (i, c), j < c <= i; column operand of tiles (r, i), r >= i

@@ -13,7 +13,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 250 rocprofv3 --kernel-trace --stats -d /tmp/p_stats -o st --output-format csv -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-matcher --no-connected --no-structure-aware --no-end-to-end > $OUT/${TAG}_bench_under_profiler.json 2> /tmp/st.err
 cp $(find /tmp/p_stats -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
-python $ROOT/scripts/trace_chain.py $(find /tmp/p_stats -name "*kernel_trace.csv" | head -1) 40 41 > $OUT/${TAG}_chain_timeline.txt 2>&1
+BSFM_FLOW_TRACE=1 BSFM_FLOW_TRACE_FILE=/tmp/flow_trace.txt timeout 200 python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-matcher --no-connected --no-structure-aware --no-end-to-end > /dev/null 2>&1; python $ROOT/scripts/r4/trace_stats.py /tmp/flow_trace.txt > $OUT/${TAG}_chain_timeline.txt 2>&1
 timeout 250 rocprofv3 --pmc FETCH_SIZE -d /tmp/p_f -o f --output-format csv -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-matcher --no-connected --no-structure-aware --no-end-to-end > /dev/null 2> /tmp/f.err
 timeout 250 rocprofv3 --pmc WRITE_SIZE -d /tmp/p_w -o w --output-format csv -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-matcher --no-connected --no-structure-aware --no-end-to-end > /dev/null 2> /tmp/w.err
 timeout 250 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d /tmp/p_m -o m --output-format csv -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-matcher --no-connected --no-structure-aware --no-end-to-end > /dev/null 2> /tmp/m.err
