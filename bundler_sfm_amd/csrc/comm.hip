@@ -23,6 +23,8 @@
 #include <unistd.h>
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <sys/mman.h>
+#include <atomic>
 #include <cctype>
 #include <memory>
 #include <cstdio>
@@ -38,6 +40,8 @@
 #include "idfile.h"
 
 namespace {
+
+double comm_timeout_s();
 
 struct Rccl {
     void* lib = nullptr;
@@ -105,11 +109,43 @@ __global__ void k_peer_reduce(int world, size_t count, int op, double* const* __
     dst[i] = v;
 }
 
+// ---- ipc transport: ranks in DIFFERENT processes that share a device (or a node): tests of the multi-process control flow on a
+// 1-GPU box, where RCCL refuses two ranks on one device.  Rank 0 creates a control block in POSIX shared memory
+// whose name derives from a random nonce that travels through the same id file as the ncclUniqueId (idfile.h); every rank
+// publishes the hipIpcMemHandle of a fixed-capacity exchange buffer there; an all-reduce copies the contribution into the own
+// exchange buffer, meets the others at a barrier in the control block (generation counter, bounded wait), sums all ranks' buffers
+// in RANK ORDER (the same bits on every rank) straight into the caller's buffer, and meets them again before the exchange buffers
+// are reused.  Larger messages go in pieces of the buffer's capacity.
+constexpr int IPC_MAX_WORLD = 16;
+struct IpcShared {
+    unsigned long long magic; int world; int reserved;
+    std::atomic<int> arrived; std::atomic<long> generation; std::atomic<int> broken; std::atomic<int> published;
+    unsigned long long capacity;                   // doubles per exchange buffer
+    hipIpcMemHandle_t handles[IPC_MAX_WORLD];
+};
+struct IpcPeer {
+    IpcShared* sh = nullptr; size_t map_bytes = 0; std::string shm_path;
+    double* mine = nullptr; double* peers[IPC_MAX_WORLD] = {}; size_t cap = 0;
+    bool barrier(int world, double timeout_s)
+    {
+        if (sh->broken.load()) return false;
+        const long gen = sh->generation.load();
+        if (sh->arrived.fetch_add(1) + 1 == world) { sh->arrived.store(0); sh->generation.fetch_add(1); return true; }
+        const auto t0 = std::chrono::steady_clock::now();
+        while (sh->generation.load() == gen) {
+            if (sh->broken.load() || std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) { sh->broken.store(1); return false; }
+            std::this_thread::yield();
+        }
+        return !sh->broken.load();
+    }
+};
+
 }  // namespace
 
 struct bsfm_comm {
     int rank = 0, world = 1, device = 0;
     ncclComm_t nccl = nullptr;          // RCCL transport
+    IpcPeer* ipc = nullptr;             // ipc transport (processes sharing a device / node)
     Loopback* loop = nullptr;           // loopback transport (shared by the ranks of one process)
     double** d_srcs = nullptr;          // loopback: device array of the ranks' buffer pointers
     double* d_small = nullptr;          // staging for host-scalar reductions
@@ -121,7 +157,7 @@ namespace {
 int comm_alloc_common(bsfm_comm* c)
 {
     if (hipMalloc((void**)&c->d_small, 256 * sizeof(double)) != hipSuccess) return -1;
-    if (c->loop && hipMalloc((void**)&c->d_srcs, (size_t)c->world * sizeof(double*)) != hipSuccess) return -1;
+    if ((c->loop || c->ipc) && hipMalloc((void**)&c->d_srcs, (size_t)c->world * sizeof(double*)) != hipSuccess) return -1;
     return 0;
 }
 
@@ -131,7 +167,7 @@ extern "C" {
 
 int bsfm_comm_rank(const bsfm_comm_t* c) { return c ? c->rank : 0; }
 int bsfm_comm_world(const bsfm_comm_t* c) { return c ? c->world : 1; }
-const char* bsfm_comm_transport(const bsfm_comm_t* c) { return !c ? "none" : (c->nccl ? "rccl" : (c->loop ? "loopback" : "none")); }
+const char* bsfm_comm_transport(const bsfm_comm_t* c) { return !c ? "none" : (c->nccl ? "rccl" : (c->ipc ? "ipc" : (c->loop ? "loopback" : "none"))); }
 
 void bsfm_comm_destroy(bsfm_comm_t* c)
 {
@@ -140,6 +176,14 @@ void bsfm_comm_destroy(bsfm_comm_t* c)
     if (c->nccl && rccl().ok) (void)rccl().CommDestroy(c->nccl);
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->d_srcs) (void)hipFree(c->d_srcs);
+    if (c->ipc) {
+        (void)hipDeviceSynchronize();
+        for (int r = 0; r < c->world; ++r) if (r != c->rank && c->ipc->peers[r]) (void)hipIpcCloseMemHandle(c->ipc->peers[r]);
+        if (c->ipc->mine) (void)hipFree(c->ipc->mine);
+        if (c->ipc->sh) (void)munmap(c->ipc->sh, c->ipc->map_bytes);
+        if (c->rank == 0 && !c->ipc->shm_path.empty()) (void)unlink(c->ipc->shm_path.c_str());
+        delete c->ipc;
+    }
     if (c->loop) {
         bool last;
         { std::lock_guard<std::mutex> lk(c->loop->mu); last = --c->loop->refs == 0; }
@@ -157,6 +201,21 @@ int bsfm_comm_allreduce(bsfm_comm_t* c, void* buf, size_t count, int op, void* s
     if (c->nccl) {
         const ncclResult_t r = rccl().AllReduce(buf, buf, count, ncclDouble, op == 0 ? ncclSum : ncclMax, c->nccl, st);
         if (r != ncclSuccess) { fprintf(stderr, "[bsfm] ncclAllReduce failed: %s\n", rccl().GetErrorString(r)); return BSFM_ERROR; }
+        return 0;
+    }
+    if (c->ipc) {
+        IpcPeer* I = c->ipc;
+        const double tmo = comm_timeout_s();
+        for (size_t off = 0; off < count; off += I->cap) {
+            const size_t n = std::min(I->cap, count - off);
+            double* part = (double*)buf + off;
+            if (hipMemcpyAsync(I->mine, part, n * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return BSFM_ERROR;
+            if (hipStreamSynchronize(st) != hipSuccess) return BSFM_ERROR;              // this rank's contribution is in its exchange buffer
+            if (!I->barrier(c->world, tmo)) { fprintf(stderr, "[bsfm] comm: a rank of the ipc group never reached the exchange (rank %d gives up)\n", c->rank); return BSFM_ERROR; }
+            hipLaunchKernelGGL(k_peer_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->world, n, op, (double* const*)c->d_srcs, part);
+            if (hipStreamSynchronize(st) != hipSuccess) return BSFM_ERROR;
+            if (!I->barrier(c->world, tmo)) return BSFM_ERROR;                           // every rank has read every exchange buffer
+        }
         return 0;
     }
     if (c->loop) {
@@ -257,7 +316,10 @@ bsfm_comm_t* bsfm_comm_create_from_env(void)
     c->rank = rank; c->world = world; c->device = local % ndev;
     if (hipSetDevice(c->device) != hipSuccess) { delete c; return nullptr; }
     if (world == 1 && !getenv("BSFM_COMM_FORCE_RCCL")) { if (comm_alloc_common(c)) { bsfm_comm_destroy(c); return nullptr; } return c; }
-    if (!rccl().ok) { delete c; return nullptr; }
+    const char* tr = getenv("BSFM_COMM_TRANSPORT");
+    const bool want_ipc = tr && !strcmp(tr, "ipc");
+    if (!want_ipc && !rccl().ok) { delete c; return nullptr; }
+    if (want_ipc && world > IPC_MAX_WORLD) { fprintf(stderr, "[bsfm] comm: the ipc transport takes at most %d ranks\n", IPC_MAX_WORLD); delete c; return nullptr; }
     std::string path;
     if (const char* e = getenv("BSFM_COMM_ID_FILE")) path = e;
     else
@@ -265,6 +327,65 @@ bsfm_comm_t* bsfm_comm_create_from_env(void)
                sanitize(getenv("TORCHELASTIC_RUN_ID")) + ".id";
     c->id_file = path;
     const double tmo = comm_timeout_s();
+    if (want_ipc) {
+        // ---- ipc transport: nonce through the id file -> control block in shared memory -> exchange-buffer handles
+        unsigned char nonce[bsfm::IDFILE_PAYLOAD];
+        memset(nonce, 0, sizeof(nonce));
+        if (rank == 0) {
+            const int rfd = open("/dev/urandom", O_RDONLY);
+            const bool ok = rfd >= 0 && read(rfd, nonce, 16) == 16;
+            if (rfd >= 0) (void)close(rfd);
+            if (!ok) { fprintf(stderr, "[bsfm] comm: no random nonce\n"); delete c; return nullptr; }
+        }
+        char hex[33];
+        auto shm_name = [&] { for (int q = 0; q < 16; ++q) snprintf(hex + 2 * q, 3, "%02x", nonce[q]); return std::string("/dev/shm/bsfm_ipc_") + hex; };
+        IpcPeer* I = new IpcPeer();
+        c->ipc = I;
+        I->map_bytes = sizeof(IpcShared);
+        size_t cap_mb = 64;
+        if (const char* e = getenv("BSFM_COMM_IPC_MB")) cap_mb = (size_t)std::max(1, atoi(e));
+        I->cap = cap_mb * (1u << 20) / sizeof(double);
+        int fd = -1;
+        if (rank == 0) {
+            I->shm_path = shm_name();
+            fd = open(I->shm_path.c_str(), O_RDWR | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+            if (fd < 0 || ftruncate(fd, (off_t)I->map_bytes) != 0) { fprintf(stderr, "[bsfm] comm: cannot create %s\n", I->shm_path.c_str()); if (fd >= 0) (void)close(fd); bsfm_comm_destroy(c); return nullptr; }
+        } else {
+            if (bsfm::idfile_wait(path, world, rank, tmo, g_process_start_ns, 120.0, nonce) != 0) { bsfm_comm_destroy(c); return nullptr; }
+            I->shm_path = shm_name();
+            fd = open(I->shm_path.c_str(), O_RDWR | O_NOFOLLOW);
+            if (fd < 0) { fprintf(stderr, "[bsfm] comm: rank %d cannot open %s\n", rank, I->shm_path.c_str()); bsfm_comm_destroy(c); return nullptr; }
+        }
+        void* mp = mmap(nullptr, I->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        (void)close(fd);
+        if (mp == MAP_FAILED) { fprintf(stderr, "[bsfm] comm: mmap of %s failed\n", I->shm_path.c_str()); bsfm_comm_destroy(c); return nullptr; }
+        I->sh = (IpcShared*)mp;
+        if (rank == 0) {
+            // (a fresh file is zero-filled: counters start at 0); the block exists BEFORE the nonce is published
+            I->sh->world = world; I->sh->capacity = I->cap; I->sh->magic = bsfm::IDFILE_MAGIC;
+            if (bsfm::idfile_publish(path, world, nonce) != 0) { bsfm_comm_destroy(c); return nullptr; }
+        }
+        if (hipMalloc((void**)&I->mine, I->cap * sizeof(double)) != hipSuccess ||
+            hipIpcGetMemHandle(&I->sh->handles[rank], I->mine) != hipSuccess) { fprintf(stderr, "[bsfm] comm: cannot export the exchange buffer of rank %d\n", rank); bsfm_comm_destroy(c); return nullptr; }
+        I->sh->published.fetch_add(1);
+        const auto t0 = std::chrono::steady_clock::now();
+        while (I->sh->published.load() < world) {
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > tmo) {
+                fprintf(stderr, "[bsfm] comm: only %d of %d ranks reached the ipc group within %.0f s\n", I->sh->published.load(), world, tmo);
+                bsfm_comm_destroy(c); return nullptr;
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+        for (int r = 0; r < world; ++r) {
+            if (r == rank) { I->peers[r] = I->mine; continue; }
+            if (hipIpcOpenMemHandle((void**)&I->peers[r], I->sh->handles[r], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+                fprintf(stderr, "[bsfm] comm: rank %d cannot open the exchange buffer of rank %d\n", rank, r); I->peers[r] = nullptr; bsfm_comm_destroy(c); return nullptr;
+            }
+        }
+        if (comm_alloc_common(c)) { bsfm_comm_destroy(c); return nullptr; }
+        if (hipMemcpy(c->d_srcs, I->peers, (size_t)world * sizeof(double*), hipMemcpyHostToDevice) != hipSuccess) { bsfm_comm_destroy(c); return nullptr; }
+        return c;
+    }
     ncclUniqueId uid;
     memset(&uid, 0, sizeof(uid));
     if (rank == 0) {

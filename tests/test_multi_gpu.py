@@ -188,3 +188,97 @@ def test_rccl_communicator_from_env_world_size_one(tmp_path):
     assert res["exists_before_destroy"] and not res["exists_after_destroy"]
     c_two, c_one, rc2, rc3 = res["ba"]
     assert rc2 == rc3 and abs(c_two - c_one) <= 1e-12 * c_one
+
+
+# ---- two PROCESSES on one GPU through the library's own communicator (ipc transport of comm.hip) -----------------------------
+def _ipc_worker(out):
+    import ctypes as C
+    import json
+    import torch
+    import bundler_sfm_amd as B
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    B.lib.bsfm_comm_create_from_env.restype = C.c_void_p
+    B.lib.bsfm_comm_transport.restype = C.c_char_p
+    c = B.lib.bsfm_comm_create_from_env()
+    res = dict(ok=bool(c), rank=rank)
+    if c:
+        c = C.c_void_p(c)
+        res["transport"] = B.lib.bsfm_comm_transport(c).decode()
+        v = (C.c_double * 2)(rank + 1.0, 10.0 * (rank + 1))
+        res["rc_host"] = B.lib.bsfm_comm_allreduce_host(c, v, 2, 0)
+        res["host_sum"] = [v[0], v[1]]
+        # a message larger than the exchange buffer (BSFM_COMM_IPC_MB = 1 -> 131 072 doubles): three pieces; max as the operation
+        n = 300001
+        t = (torch.arange(n, dtype=torch.float64, device="cuda:0") % 1000) * (1.0 if rank == 0 else -0.5)
+        B.lib.bsfm_comm_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        res["rc_big"] = B.lib.bsfm_comm_allreduce(c, C.c_void_p(t.data_ptr()), n, 0, None)
+        torch.cuda.synchronize()
+        exp = (torch.arange(n, dtype=torch.float64) % 1000) * 0.5
+        res["big_err"] = float((t.cpu() - exp).abs().max())
+        # the BA problem sharded over the two processes, reduced through this communicator
+        sc = _scene(B)
+        lo, hi = shard_points(sc["rowptr"], world, rank)
+        rp = (sc["rowptr"][lo:hi + 1] - sc["rowptr"][lo]).astype(np.int32)
+        k0, k1 = int(sc["rowptr"][lo]), int(sc["rowptr"][hi])
+        opt = B.default_options(jacobian=B.JAC_ANALYTIC, verbose=0, itmax=ITERS, opts=[1e-3, 0.0, 0.0, 0.0, 0.0, -1.0])
+        pb = B.Problem(hi - lo, sc["m"], rp, sc["colidx"][k0:k1], sc["proj"][2 * k0:2 * k1], sc["cams"], sc["pts"][3 * lo:3 * hi],
+                       options=opt, world_size=world, rank=rank, nvis_global=int(sc["rowptr"][-1]), nvars_global=sc["m"] * 9 + 3 * sc["n"])
+        B.lib.bsfm_problem_set_comm(pb.h, c)
+        assert pb.lm_begin() == 0
+        pb.lm_iterate(ITERS)
+        rc, info = pb.lm_finish()
+        p = pb.download(want_cams=False)[0]
+        pb.close()
+        np.save(out + f".p{rank}.npy", p)
+        res["info"] = [float(x) for x in info]
+        res["lo"], res["hi"] = int(lo), int(hi)
+        B.lib.bsfm_comm_destroy(c)
+    json.dump(res, open(out + f".{rank}.json", "w"))
+
+
+def test_two_processes_one_gpu_through_the_native_ipc_transport(tmp_path):
+    """bsfm_comm_create_from_env with WORLD_SIZE = 2 between two PROCESSES that share cuda:0 -- the id-file
+    hand-over (csrc/idfile.h), the control block in shared memory, the exchange buffers opened through hipIpc, chunked all-reduces in
+    rank order and the whole multi-rank LM control flow of solver.hip, without torch.distributed in the loop.  (RCCL refuses two
+    ranks on one device; with one GPU per rank the same entry point takes the RCCL branch.)"""
+    import json
+    import subprocess
+    import bundler_sfm_amd as B
+    sc = _scene(B)
+    p1, info1 = _solve(B, sc, 0, sc["n"], 1, 0)
+    out = str(tmp_path / "ipc")
+    port = str(_free_port())
+    procs = []
+    for rank in (1, 0):                     # the waiting rank starts first
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   BSFM_COMM_TRANSPORT="ipc", BSFM_COMM_IPC_MB="1", BSFM_COMM_ID_FILE=str(tmp_path / "job.id"),
+                   BSFM_COMM_TIMEOUT_S="60", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        code = f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {HERE!r}); import test_multi_gpu as t; t._ipc_worker({out!r})"
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    errs = [p.communicate(timeout=170) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [e[1][-1500:] for e in errs]
+    m = sc["m"]
+    res = [json.load(open(out + f".{k}.json")) for k in (0, 1)]
+    ps = [np.load(out + f".p{k}.npy") for k in (0, 1)]
+    for k in (0, 1):
+        r = res[k]
+        assert r["ok"] and r["transport"] == "ipc"
+        assert r["rc_host"] == 0 and r["host_sum"] == [3.0, 30.0]
+        assert r["rc_big"] == 0 and r["big_err"] == 0.0
+        assert abs(r["info"][1] - info1[1]) <= 1e-9 * info1[1] and r["info"][5] == info1[5]
+        assert np.abs(ps[k][:9 * m] - p1[:9 * m]).max() <= 1e-8 * np.abs(p1[:9 * m]).max()
+        assert np.abs(ps[k][9 * m:] - p1[9 * m + 3 * r["lo"]:9 * m + 3 * r["hi"]]).max() <= 1e-8
+    assert np.array_equal(ps[0][:9 * m], ps[1][:9 * m])               # bitwise identical replicas
+    assert not os.path.exists(str(tmp_path / "job.id"))                # rank 0 removed the id file on destroy
+
+
+def test_ipc_transport_times_out_when_a_rank_is_missing(tmp_path):
+    """One rank of a world of two never shows up: the other gives up after BSFM_COMM_TIMEOUT_S with a message, no hang."""
+    import subprocess
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               BSFM_COMM_TRANSPORT="ipc", BSFM_COMM_ID_FILE=str(tmp_path / "job.id"), BSFM_COMM_TIMEOUT_S="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); import bundler_sfm_amd as B; import ctypes as C; "
+            "B.lib.bsfm_comm_create_from_env.restype = C.c_void_p; c = B.lib.bsfm_comm_create_from_env(); print('COMM', bool(c))")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "COMM False" in r.stdout
+    assert "only 1 of 2 ranks reached the ipc group" in r.stderr
