@@ -318,6 +318,77 @@ __device__ __forceinline__ void flow_fupd(const FlowArgs& a, int j, int p0, int 
     if (part == 0) st_sc1(a.E + (size_t)j * POTRF_NB + row, e);
 }
 
+// ---- 16 x 16 diagonal block: factorisation + inverse, one lane per row (all four 16-lane rows of the wave mirror each other).
+// The broadcasts R[c][j] -> every lane go through DPP row_newbcast (gfx90a+: lane c of each 16-lane row to the whole row): two
+// v_mov_b32_dpp per value, no SGPRs.  (The v_readlane form of rounds 1-3 needs an SGPR pair per value plus wait states before its
+// use; with the inverse carried along -- two FMAs per broadcast -- the compiler parked all 136 pairs in a VGPR through v_writelane:
+// 1 774 instructions per block; rows and inverse columns in separate lane halves: 1 059; this form: ~700.)
+template <int C> __device__ __forceinline__ double flow_bcast16(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + C, 0xf, 0xf, true);       // every lane is written: no "old" value to keep
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + C, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int J, int C> struct FlowA1Upd {
+    static __device__ __forceinline__ void run(double (&d)[16], double (&x)[16], double lrj, double xj)
+    {
+        const double b = flow_bcast16<C>(d[J]);       // R[c][j]
+        d[C] -= lrj * b;
+        x[C] -= xj * b;
+        // keep the two uses of a broadcast together: left alone, the compiler defers the whole inverse (an independent chain) to the end of
+        // the block factorisation and parks all 120 broadcast values in scratch meanwhile.  Volatile asms keep their order, and both
+        // values pass through this one.
+        asm volatile("" : "+v"(d[C]), "+v"(x[C]));
+        FlowA1Upd<J, C + 1>::run(d, x, lrj, xj);
+    }
+};
+template <int J> struct FlowA1Upd<J, 16> { static __device__ __forceinline__ void run(double (&)[16], double (&)[16], double, double) {} };
+template <int J> struct FlowA1Col {
+    static __device__ __forceinline__ void run(double (&d)[16], double (&x)[16], double& myp, int& bad, int r)
+    {
+        const double piv = flow_bcast16<J>(d[J]);      // R[j][j]
+        bad = (bad < 0 && !(piv > 0.0)) ? J : bad;      // first non-positive pivot = dpotrf's info (the same in every lane)
+        myp = (r == J) ? piv : myp;
+        double inv = __builtin_amdgcn_rcp(piv);
+        inv = fma(fma(-piv, inv, 1.0), inv, inv);
+        inv = fma(fma(-piv, inv, 1.0), inv, inv);
+        const double lrj = d[J] * inv;                  // R[r][j] / pivot_j
+        const double xj = x[J] * inv;                   // entry (j, r) of inv(R)
+        x[J] = xj;
+        FlowA1Upd<J, J + 1>::run(d, x, lrj, xj);
+        FlowA1Col<J + 1>::run(d, x, myp, bad, r);
+    }
+};
+template <> struct FlowA1Col<16> { static __device__ __forceinline__ void run(double (&)[16], double (&)[16], double&, int&, int) {} };
+template <int I> struct FlowA1Out {
+    static __device__ __forceinline__ void run(double* blk, const double (&x)[16], double mysq, int r, bool w)
+    {
+        const double sq_i = flow_bcast16<I>(mysq);
+        if (w) blk[swz16(I, r)] = x[I] * sq_i;          // inv(L)[i][r] = sqrt(pivot_i) inv(R)[i][r]
+        FlowA1Out<I + 1>::run(blk, x, mysq, r, w);
+    }
+};
+template <> struct FlowA1Out<16> { static __device__ __forceinline__ void run(double*, const double (&)[16], double, int, bool) {} };
+
+// A1 as a function of its own (its 64 live doubles + the calling wave's tile blocks do not fit 128 VGPRs in one body): reads the block
+// from LDS (one lane per row), leaves inv(L_ss) there; returns the index of the first non-positive pivot or -1.
+__device__ __attribute__((noinline)) int flow_factor16(double* blk, int lane_in)
+{
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int r = lane & 15;
+    double d[16], x[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { d[c] = blk[swz16(r, c)]; x[c] = (c == r) ? 1.0 : 0.0; }
+    double myp = 1.0;
+    int bad = -1;
+    FlowA1Col<0>::run(d, x, myp, bad, r);
+    const double mysq = myp * rsqrt_f64(myp);              // L[r][r] = sqrt(pivot_r)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (every lane has read its row before lanes 0..15 overwrite the block)
+    FlowA1Out<0>::run(blk, x, mysq, r, lane < 16);
+    return bad;
+}
+
 // ---- POTRF: the diagonal tile, factor and inverse, in the footprint of a bulk workgroup.
 // The lower triangle of the tile is 36 blocks of 16 x 16.  Every block has ONE owner wave that holds it in registers in the
 // accumulator layout of v_mfma_f64_16x16x4 (register q of lane l = row 4 q + (l >> 4), column l & 15), so the trailing updates
@@ -456,42 +527,8 @@ __device__ BSFM_FLOW_ROLE void flow_potrf(const FlowArgs& a_in, int k, double* l
 #pragma unroll
             for (int q = 0; q < 4; ++q) blk[swz16(4 * q + lr, lc)] = cur[q];
             BSFM_LDS_FENCE();
-            // lanes 0..15 hold the rows of the block (lane r: row r), lanes 16..31 the columns of inv(R) under construction (lane 16 + r:
-            // column r); both halves run the SAME instruction stream -- v[c] -= (v[j] / pivot_j) * R[c][j] is the elimination step for
-            // a row of the block and the substitution step for a column of the inverse -- so every broadcast R[c][j] is used by exactly
-            // one FMA.  (Two FMAs per broadcast, d and x in the same lanes, made the compiler park all 136 broadcasts in a VGPR
-            // through v_writelane / v_readlane: 1 774 instructions instead of ~700.)
-            const int r = lc;
-            const bool is_x = lr == 1;
-            double v[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) { const double e = blk[swz16(r, c)]; v[c] = is_x ? ((c == r) ? 1.0 : 0.0) : e; }
-            double myp = 1.0;
-            int bad = -1;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const double piv = BSFM_RDLANE(v[j], j);           // lane j < 16: R[j][j]
-                if (!(piv > 0.0) && bad < 0) bad = j;              // (wave-uniform) first non-positive pivot = dpotrf's info
-                myp = (r == j) ? piv : myp;
-                double inv = __builtin_amdgcn_rcp(piv);
-                inv = fma(fma(-piv, inv, 1.0), inv, inv);
-                inv = fma(fma(-piv, inv, 1.0), inv, inv);
-                const double f = v[j] * inv;                      // rows: R[r][j] / pivot_j;  inverse: entry (j, r) of inv(R)
-#pragma unroll
-                for (int c = j + 1; c < 16; ++c) {
-                    const double sc = BSFM_RDLANE(v[j], c);       // lane c < 16: R[c][j]
-                    v[c] -= f * sc;
-                }
-                v[j] = is_x ? f : v[j];
-            }
+            const int bad = flow_factor16(blk, lane);
             if (lane == 0 && bad >= 0 && base + 16 * sn + bad < n_total) atomicCAS(a.info, 0, base + 16 * sn + bad + 1);
-            const double mysq = myp * rsqrt_f64(myp);              // L[r][r] = sqrt(pivot_r)
-            BSFM_LDS_FENCE();                                      // (every lane has read its row before lanes 16..31 overwrite the block)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const double sq_i = BSFM_RDLANE(mysq, i);
-                if (is_x) blk[swz16(i, r)] = v[i] * sq_i;         // inv(L)[i][r] = sqrt(pivot_i) inv(R)[i][r]
-            }
         }
         if (s >= 0) {
             // ---- A3, the other live blocks
