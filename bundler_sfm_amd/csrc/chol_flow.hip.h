@@ -459,6 +459,15 @@ __device__ BSFM_FLOW_ROLE void flow_potrf(const FlowArgs& a_in, int k, double* l
     // cur: the block a phase works on, picked out of the wave's slots with scalar tests (one instantiation of A1 / A2 instead of five)
     double cur[4];
     bool have = false;
+    // The INVERSE of the tile, X = inv(L), is built row by row IN THE SHADOW of the block factorisations: row s of X needs row s of L
+    // (final after step s - 1), the rows above it and inv(L_ss) -- all there once A1(s) is done -- and while one wave factors block
+    // (s + 1, s + 1) the others have nothing else to do.  X_sJ = -inv(L_ss) sum_{K = J}^{s-1} L_sK X_KJ, one block per wave; the
+    // accumulator layout of a product IS the B-operand layout of the next, so only finished blocks go to LDS, where X_sJ takes the
+    // place of L_sJ (row s of L is dead by then: it was only an operand of the updates of the steps before s).  What used to be a
+    // separate 8 us phase after the loop (35 dependent products on wave 0) is now the last row: at most 8 products.
+    double xr[4] = { 0.0, 0.0, 0.0, 0.0 };            // this wave's block of the previous row of X, written out after the next barrier
+    int xJ = -1;                                      // ... its column (-1: none)
+    double* Wk = a.Linv + (size_t)k * FLOW_TL;
     // ---- A1 of block column 0 (its owner: wave 0, slot 0), then per column: barrier, A2, barrier, A3 (+ A1 of the next column)
 #pragma unroll 1
     for (int s = -1; s < 8; ++s) {
@@ -467,8 +476,18 @@ __device__ BSFM_FLOW_ROLE void flow_potrf(const FlowArgs& a_in, int k, double* l
         int lr = lr0, lc = lc0, lane = lane0;
         asm volatile("" : "+v"(lr), "+v"(lc), "+v"(lane));
         if (s >= 0) {
-            __syncthreads();                                   // inv(L_ss) is in LDS
+            __syncthreads();                                   // inv(L_ss) is in LDS; every wave is done with row s - 1 of L
             BSFM_FLOW_MARK(4 + 4 * s + 1);
+            if (xJ >= 0) {
+                // row s - 1 of X: into the slot of L_(s-1)J and out to W
+                double* slot = Lb + ((s - 1) * (s - 2) / 2 + xJ) * 256;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    slot[swz16(4 * q + lr, lc)] = xr[q];
+                    st_sc1(Wk + (size_t)(16 * (s - 1) + 4 * q + lr) * POTRF_NB + 16 * xJ + lc, xr[q]);
+                }
+                xJ = -1;
+            }
             // ---- A2
             int Isel = -1;
 #pragma unroll
@@ -493,7 +512,7 @@ __device__ BSFM_FLOW_ROLE void flow_potrf(const FlowArgs& a_in, int k, double* l
 #pragma unroll
                 for (int q = 0; q < 4; ++q) dst[swz16(4 * q + lr, lc)] = x[q];
             }
-            __syncthreads();                                   // block column s of L is in LDS
+            __syncthreads();                                   // block column s of L and row s - 1 of X are in LDS
             BSFM_FLOW_MARK(4 + 4 * s + 2);
             if (s == 7) break;
             // ---- A3, the next diagonal block first
@@ -547,55 +566,61 @@ __device__ BSFM_FLOW_ROLE void flow_potrf(const FlowArgs& a_in, int k, double* l
                     t[m][0] = c[0]; t[m][1] = c[1]; t[m][2] = c[2]; t[m][3] = c[3];
                 }
             BSFM_FLOW_MARK(4 + 4 * s + 3);
+            // ---- row s of X (s >= 1): block (s, J) by the J-th wave that is not factoring
+            if (s >= 1 && !have) {
+                const int own = ((s + 1) * (s + 2) / 2) & 7;          // the wave that owns block (s + 1, s + 1)
+                const int J = w < own ? w : w - 1;
+                if (J < s) {
+                    // (rolled on purpose: unrolled over K with scalar tests and two accumulator chains the role spills and a tile takes 46-52 us
+                    //  instead of 39-41)
+                    v4d acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll 1
+                    for (int K = J; K < s; ++K) {
+                        const double* Ap = Lb + (s * (s - 1) / 2 + K) * 256;                                   // L_sK
+                        const double* Bp = K == J ? Di + J * 256 : Lb + (K * (K - 1) / 2 + J) * 256;            // X_KJ (X_JJ = inv(L_JJ))
+                        double av[4], bv[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { av[q] = Ap[swz16(lc, 4 * q + lr)]; bv[q] = Bp[swz16(4 * q + lr, lc)]; }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+                    }
+                    const double* Ds = Di + s * 256;
+                    v4d res = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) res = __builtin_amdgcn_mfma_f64_16x16x4f64(Ds[swz16(lc, 4 * q + lr)], acc[q], res, 0, 0, 0);
+                    xr[0] = -res[0]; xr[1] = -res[1]; xr[2] = -res[2]; xr[3] = -res[3];
+                    xJ = J;
+                }
+            }
         }
     }
     BSFM_FLOW_MARK(36);
-    // ---- inverse: wave w = block column J of X = inv(L); xb[I] = X_IJ in the accumulator layout
+    // ---- the last row of X (block (7, J) by wave J) and the diagonal blocks X_II = inv(L_II) (wave I); row 6 was written out above
     {
         const int lr = lr0, lc = lc0;
-        const int J = w;
-        const double* DJ = Di + J * 256;
-        double xb[8][4];
+        if (w < 7) {
+            const int J = w;
+            v4d acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll 1
+            for (int K = J; K < 7; ++K) {
+                const double* Ap = Lb + (21 + K) * 256;
+                const double* Bp = K == J ? Di + J * 256 : Lb + (K * (K - 1) / 2 + J) * 256;
+                double av[4], bv[4];
 #pragma unroll
-        for (int I = 0; I < 8; ++I)
+                for (int q = 0; q < 4; ++q) { av[q] = Ap[swz16(lc, 4 * q + lr)]; bv[q] = Bp[swz16(4 * q + lr, lc)]; }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) xb[I][q] = 0.0;
-#pragma unroll
-        for (int I = 0; I < 8; ++I) {
-            if (I == J) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) xb[I][q] = DJ[swz16(4 * q + lr, lc)];
-            } else if (I > J) {
-                v4d acc = { 0.0, 0.0, 0.0, 0.0 }, acc2 = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-                for (int K = 0; K < I; ++K) {
-                    if (K >= J) {
-                        const double* Lik = Lb + (I * (I - 1) / 2 + K) * 256;
-                        double av[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) av[q] = Lik[swz16(lc, 4 * q + lr)];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], xb[K][0], acc, 0, 0, 0);
-                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], xb[K][1], acc2, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], xb[K][2], acc, 0, 0, 0);
-                        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], xb[K][3], acc2, 0, 0, 0);
-                    }
-                }
-                double sacc[4] = { acc[0] + acc2[0], acc[1] + acc2[1], acc[2] + acc2[2], acc[3] + acc2[3] };
-                const double* DI = Di + I * 256;
-                v4d res = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-                for (int q = 0; q < 4; ++q) res = __builtin_amdgcn_mfma_f64_16x16x4f64(DI[swz16(lc, 4 * q + lr)], sacc[q], res, 0, 0, 0);
-                xb[I][0] = -res[0]; xb[I][1] = -res[1]; xb[I][2] = -res[2]; xb[I][3] = -res[3];
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
             }
-        }
-        double* Wk = a.Linv + (size_t)k * FLOW_TL;
+            const double* Ds = Di + 7 * 256;
+            v4d res = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
-        for (int I = 0; I < 8; ++I) {
-            if (I >= J) {
+            for (int q = 0; q < 4; ++q) res = __builtin_amdgcn_mfma_f64_16x16x4f64(Ds[swz16(lc, 4 * q + lr)], acc[q], res, 0, 0, 0);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) st_sc1(Wk + (size_t)(16 * I + 4 * q + lr) * POTRF_NB + 16 * J + lc, xb[I][q]);
-            }
+            for (int q = 0; q < 4; ++q) st_sc1(Wk + (size_t)(112 + 4 * q + lr) * POTRF_NB + 16 * J + lc, -res[q]);
         }
+        const double* Dw = Di + w * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) st_sc1(Wk + (size_t)(16 * w + 4 * q + lr) * POTRF_NB + 16 * w + lc, Dw[swz16(4 * q + lr, lc)]);
     }
     BSFM_FLOW_MARK(37);
 #undef BSFM_FLOW_MARK

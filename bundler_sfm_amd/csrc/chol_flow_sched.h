@@ -64,7 +64,7 @@ struct FlowParams {
     int np_max = 4;           // panels per bulk visit
     int np_max_rhs = 8;       // ... for the right-hand-side row
     // estimated durations, microseconds: medians of the per-task trace of the n = 9 000 solve on MI355X (profiles/r04_flow_task_durations.txt)
-    double t_potrf = 56.0, t_trsm32 = 6.0, t_trsm64 = 17.0, t_upd32 = 7.5, t_upd32_per = 3.5;
+    double t_potrf = 42.0, t_trsm32 = 4.5, t_trsm64 = 17.0, t_upd32 = 5.0, t_upd32_per = 2.5;
     double t_upd64_0 = 7.0, t_upd64_per = 12.5, t_upd128_0 = 12.0, t_upd128_per = 27.0;
     double t_ftrsm = 10.0, t_fupd_0 = 5.0, t_fupd_per = 8.0;
     double t_hand = 0.5;      // completion -> visible to a dependent (measured 0.3-0.5)
