@@ -820,9 +820,23 @@ __global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc,
     if (threadIdx.x == 0) __hip_atomic_store(&flags[kk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ void k_flow_fold_timeout(const unsigned* __restrict__ ticket, const int* __restrict__ bwd_timeout, int* __restrict__ info)
+// The small jobs around the two kernels, one launch each instead of three memsets and two copies (at 50 cameras a solve is 0.2 ms and
+// every stream operation costs 5-8 us of it).  Begin: counters / tickets / per-CU words and the backward flags to zero, the right-hand
+// side into its padded working copy.  End: a time-out of either kernel becomes the solve's info, the solution leaves the padded vector.
+__global__ __launch_bounds__(256) void k_flow_begin(unsigned* __restrict__ sync, unsigned sync_words, int* __restrict__ bflags, int nbflags,
+                                                    double* __restrict__ etmp, const double* __restrict__ E, int n, int ld)
 {
-    if (ticket[1] != 0u || *bwd_timeout != 0) *info = POTRF_INFO_TIMEOUT;
+    const unsigned stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    for (unsigned q = t0; q < sync_words; q += stride) sync[q] = 0u;
+    for (unsigned q = t0; q < (unsigned)nbflags; q += stride) bflags[q] = 0;
+    for (unsigned q = t0; q < (unsigned)ld; q += stride) etmp[q] = q < (unsigned)n ? E[q] : 0.0;
+}
+__global__ __launch_bounds__(256) void k_flow_end(const unsigned* __restrict__ ticket, const int* __restrict__ bwd_timeout, int* __restrict__ info,
+                                                  const double* __restrict__ xs, double* __restrict__ x_out, int n)
+{
+    const unsigned stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t0 == 0 && (ticket[1] != 0u || *bwd_timeout != 0)) *info = POTRF_INFO_TIMEOUT;
+    for (unsigned q = t0; q < (unsigned)n; q += stride) x_out[q] = xs[q];
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -942,9 +956,8 @@ inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, in
     const int nblk = (n + POTRF_NB - 1) / POTRF_NB;
     if (flow_prepare(f, nblk, w.env_rows) != 0) return -1;
     const size_t nt = f.sched.tasks.size();
-    (void)hipMemsetAsync(f.d_sync, 0, f.sync_words * sizeof(unsigned), st);
-    (void)hipMemsetAsync(w.etmp, 0, (size_t)ld * sizeof(double), st);
-    (void)hipMemcpyAsync(w.etmp, E, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(k_flow_begin, dim3((unsigned)std::min<size_t>(64, (std::max<size_t>(f.sync_words, (size_t)ld) + 255) / 256)), dim3(256), 0, st,
+                       f.d_sync, (unsigned)f.sync_words, w.bflags, w.nblk + 1, w.etmp, E, n, ld);
     FlowArgs a;
     a.S = S; a.ld = ld; a.n_total = n; a.T = nblk; a.Pc = f.pc; a.Linv = w.linv; a.E = w.etmp; a.y = w.y;
     a.tasks = f.d_tasks; a.chain_tasks = f.d_tasks + f.bulk.size(); a.n_bulk = (unsigned)f.bulk.size(); a.n_chain = (unsigned)f.chain.size();
@@ -962,12 +975,11 @@ inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, in
     if (timed) { (void)hipEventRecord(f.k1, st); f.kern_pending = true; }
     // backward substitution
     const bool env = (int)w.env_rows.size() >= nblk && w.d_last != nullptr;
-    (void)hipMemsetAsync(w.bflags, 0, (size_t)(w.nblk + 1) * sizeof(int), st);
     for (int first = 0; first < nblk; first += POTRF_MAX_TILES)
         hipLaunchKernelGGL(k_bwd_flow, dim3(std::min(POTRF_MAX_TILES, nblk - first)), dim3(256), 0, st, (const double*)f.pc, nblk, first,
                            (const double*)w.linv, (const double*)w.y, w.xs, w.bflags, w.bflags + w.nblk, (const int*)(env ? w.d_last : nullptr));
-    hipLaunchKernelGGL(k_flow_fold_timeout, dim3(1), dim3(1), 0, st, (const unsigned*)f.d_sync, (const int*)(w.bflags + w.nblk), d_info);
-    (void)hipMemcpyAsync(x_out, w.xs, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(k_flow_end, dim3((unsigned)std::min(64, (n + 255) / 256)), dim3(256), 0, st, (const unsigned*)f.d_sync, (const int*)(w.bflags + w.nblk),
+                       d_info, (const double*)w.xs, x_out, n);
     if (f.trace) flow_dump_trace(f, st);
     return 0;
 }

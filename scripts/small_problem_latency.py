@@ -33,7 +33,10 @@ def run(tag, n, m, vm, proj, cams, pts, s):
     print(line, flush=True)
 
 
+ONLY = [int(v) for v in os.environ.get("SMALL_ONLY", "").split(",") if v]        # e.g. SMALL_ONLY=50 under the profiler
 for m, n in ((14, 1500), (50, 10000), (100, 20000), (200, 50000), (400, 100000)):
+    if ONLY and m not in ONLY:
+        continue
     s = B.synth_ba(m, n, 10)
     vm = B.dense_vmask(n, m, s["rowptr"], s["colidx"])
     run(f"{m:4d} cams / {n:6d} pts / {10 * n:7d} obs", n, m, vm, s["proj"], s["cams"], s["pts"], s)

@@ -39,7 +39,22 @@ def test_matches_oracle_restatement(gpu_bsfm):
     assert rc == 0 and np.abs(x - x0).max() <= 1e-11 * np.abs(x0).max()
 
 
-@pytest.mark.parametrize("n,bad", [(50, 10), (300, 200), (300, 0)])
+def test_solution_is_bit_identical_from_run_to_run(gpu_bsfm):
+    """The tile-dataflow factorisation hands its tasks to whichever workgroup is free, but the ORDER of the floating-point
+    operations on every tile is fixed by the schedule (csrc/chol_flow_sched.h): repeated solves must agree to the last bit.  (A stale
+    read of a panel tile -- the failure the agent-scope loads / stores of chol_flow.hip.h exist to prevent -- would show up here as an
+    occasional difference.)"""
+    A, b = spd(2900, 11)
+    ref = None
+    for _ in range(6):
+        rc, x = gpu_bsfm.dense_chol_solve(A, b)
+        assert rc == 0
+        if ref is None:
+            ref = x.copy()
+        assert np.array_equal(x, ref)
+
+
+@pytest.mark.parametrize("n,bad", [(50, 10), (300, 200), (300, 0), (1000, 700), (1000, 128), (1000, 999)])
 def test_not_positive_definite_reports_leading_minor(gpu_bsfm, n, bad):
     """dpotrf's info = order of the first non-positive-definite leading minor (sba_lapack.c:436-439)."""
     A, b = spd(n, 9)
