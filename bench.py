@@ -536,55 +536,68 @@ def main():
             out["cpu_baseline"] = None
     pb.close()
 
-    if world == 1 and rank == 0:
-        if not args.no_structure_aware and args.reduced_solver == "dense":
-            # NOT the headline: the same problem with the opt-in group-by-group reduced solve (compsolve.hip.h).  This
-            # generator's cameras fall into m/deg groups that share no point, so S is block diagonal up to a permutation;
-            # `value` above is measured with the reference's algorithm (dense Cholesky of the whole S).
-            try:
-                r2 = run_ba(B, args, s, 1, 0, None, None, lambda: B.lib.bsfm_device_synchronize(), B.SOLVER_AUTO, jac, "structure_aware")
-                pb2, info2, d2 = r2["pb"], r2["info"], r2["done"]
-                out["structure_aware"] = {"reduced_solver": "auto (independent camera groups, one workgroup each)",
-                                          "iterations_per_s": round(d2 / r2["elapsed"], 3), "ms_per_step": round(1e3 * r2["elapsed"] / max(d2, 1), 4),
-                                          "solve_ms": round(pb2.phase_ms("solve"), 4), "schur_ms": round(pb2.phase_ms("schur"), 4),
-                                          "final_cost": info2[1],
-                                          "cost_after_3_iterations": r2["cost3"],
-                                          "final_cost_rel_diff_vs_dense": abs(r2["cost3"] - r["cost3"]) / r["cost3"],
-                                          "final_cost_rel_diff_vs_dense_note": "relative difference of the cost after THREE iterations from the initial parameters "
-                                                                               "(fixed iteration index, before any restart of either run)",
-                                          "problem_create_s_warm_process": round(r2["t_create"], 3)}
-                pb2.close()
-            except Exception as exc:
-                out["structure_aware"] = {"error": repr(exc)}
-        if not args.no_connected:
-            # Second scene of the same size whose camera graph is CONNECTED (banded visibility: every point is seen from a window of
-            # 50 neighbouring cameras), so the reduced camera system is a band and not 100 independent cliques: different Schur
-            # task mix (more, smaller blocks), nothing for a structure-aware solver to exploit.  Dense reduced solve.
-            try:
-                sb = B.synth_ba(m, n, deg, banded=True)
-                r3 = run_ba(B, args, sb, 1, 0, None, None, lambda: B.lib.bsfm_device_synchronize(), B.SOLVER_DENSE, jac, "connected")
-                pb3, info3, d3 = r3["pb"], r3["info"], r3["done"]
+    # ---- the non-headline legs.  On N > 1 ranks the two structure-aware solvers are run as well (every rank takes part, the time is the
+    # maximum over the ranks), so that a SCALE record shows the curve of the replicated dense solve AND the curves of the solvers whose
+    # replicated term is small; the single-GPU-only objects (CPU baseline, end-to-end run_sfm, matcher) stay with N = 1.
+    if rank != 0:
+        out = {}
+
+    def leg(scene, solver, label):
+        r_ = run_ba(B, args, scene, world, rank, comm, hook_setup, sync, solver, jac, label)
+        r_["elapsed"] = max_over_ranks(r_["elapsed"])
+        return r_
+
+    if not args.no_structure_aware and args.reduced_solver == "dense":
+        # NOT the headline: the same problem with the opt-in group-by-group reduced solve (compsolve.hip.h).  This
+        # generator's cameras fall into m/deg groups that share no point, so S is block diagonal up to a permutation;
+        # `value` above is measured with the reference's algorithm (dense Cholesky of the whole S).
+        try:
+            r2 = leg(s, B.SOLVER_AUTO, "structure_aware")
+            pb2, info2, d2 = r2["pb"], r2["info"], r2["done"]
+            out["structure_aware"] = {"reduced_solver": "auto (independent camera groups, one workgroup each)", "n_gpus": world,
+                                      "iterations_per_s": round(d2 / r2["elapsed"], 3), "ms_per_step": round(1e3 * r2["elapsed"] / max(d2, 1), 4),
+                                      "solve_ms": round(pb2.phase_ms("solve"), 4), "schur_ms": round(pb2.phase_ms("schur"), 4),
+                                      "final_cost": info2[1],
+                                      "cost_after_3_iterations": r2["cost3"],
+                                      "final_cost_rel_diff_vs_dense": abs(r2["cost3"] - r["cost3"]) / r["cost3"],
+                                      "final_cost_rel_diff_vs_dense_note": "relative difference of the cost after THREE iterations from the initial parameters "
+                                                                           "(fixed iteration index, before any restart of either run)",
+                                      "problem_create_s_warm_process": round(r2["t_create"], 3)}
+            pb2.close()
+        except Exception as exc:
+            out["structure_aware"] = {"error": repr(exc)}
+    if not args.no_connected:
+        # Second scene of the same size whose camera graph is CONNECTED (banded visibility: every point is seen from a window of
+        # 50 neighbouring cameras), so the reduced camera system is a band and not 100 independent cliques: different Schur
+        # task mix (more, smaller blocks), nothing for a structure-aware solver to exploit.  Dense reduced solve.
+        try:
+            sb = B.synth_ba(m, n, deg, banded=True)
+            r3 = leg(sb, B.SOLVER_DENSE, "connected")
+            pb3, info3, d3 = r3["pb"], r3["info"], r3["done"]
+            out["connected_scene"] = {"workload": f"banded visibility (window of 50 cameras), {m} cams / {n} pts / {int(sb['rowptr'][-1])} obs, dense reduced solve",
+                                      "n_gpus": world,
+                                      "iterations_per_s": round(d3 / r3["elapsed"], 3), "ms_per_step": round(1e3 * r3["elapsed"] / max(d3, 1), 4),
+                                      "steps": d3, "solve_attempts_per_step": round(r3["att"] / max(d3, 1), 3),
+                                      "phases_ms": {ph: round(pb3.phase_ms(ph), 4) for ph in ("jacobian", "cam_blocks", "point_blocks", "schur", "solve", "backsub", "residual")},
+                                      "initial_cost": info3[0], "final_cost": info3[1], "cost_after_3_iterations": r3["cost3"],
+                                      "problem_create_s": round(r3["t_create"], 3)}
+            if world == 1:
                 sc = pb3.export_schur()
-                out["connected_scene"] = {"workload": f"banded visibility (window of 50 cameras), {m} cams / {n} pts / {int(sb['rowptr'][-1])} obs, dense reduced solve",
-                                          "iterations_per_s": round(d3 / r3["elapsed"], 3), "ms_per_step": round(1e3 * r3["elapsed"] / max(d3, 1), 4),
-                                          "steps": d3, "solve_attempts_per_step": round(r3["att"] / max(d3, 1), 3),
-                                          "phases_ms": {ph: round(pb3.phase_ms(ph), 4) for ph in ("jacobian", "cam_blocks", "point_blocks", "schur", "solve", "backsub", "residual")},
-                                          "reduced_camera_blocks": int(len(sc["blk_j"])), "schur_tasks": int(sc["ntasks"]),
-                                          "initial_cost": info3[0], "final_cost": info3[1], "cost_after_3_iterations": r3["cost3"],
-                                          "problem_create_s": round(r3["t_create"], 3)}
-                pb3.close()
-                # the same connected scene with the opt-in ENVELOPE solver: cameras renumbered by reverse Cuthill-McKee, the tiled Cholesky
-                # skips the tiles outside the envelope of the reordered S (exact; NOT the headline: `value` is the dense solve)
-                r4 = run_ba(B, args, sb, 1, 0, None, None, lambda: B.lib.bsfm_device_synchronize(), B.SOLVER_ENVELOPE, jac, "connected_envelope")
-                pb4, info4, d4 = r4["pb"], r4["info"], r4["done"]
-                out["connected_scene"]["envelope_solver"] = {
-                    "iterations_per_s": round(d4 / r4["elapsed"], 3), "ms_per_step": round(1e3 * r4["elapsed"] / max(d4, 1), 4),
-                    "solve_ms": round(pb4.phase_ms("solve"), 4), "schur_ms": round(pb4.phase_ms("schur"), 4),
-                    "cost_after_3_iterations": r4["cost3"], "cost_rel_diff_vs_dense_after_3_iterations": abs(r4["cost3"] - r3["cost3"]) / r3["cost3"],
-                    "syrk_launches_per_solve": pb4.phase_ms("syrk_launches")}
-                pb4.close()
-            except Exception as exc:
-                out["connected_scene"] = {"error": repr(exc)}
+                out["connected_scene"]["reduced_camera_blocks"] = int(len(sc["blk_j"])); out["connected_scene"]["schur_tasks"] = int(sc["ntasks"])
+            pb3.close()
+            # the same connected scene with the opt-in ENVELOPE solver: cameras renumbered by reverse Cuthill-McKee, the tiled Cholesky
+            # skips the tiles outside the envelope of the reordered S (exact; NOT the headline: `value` is the dense solve)
+            r4 = leg(sb, B.SOLVER_ENVELOPE, "connected_envelope")
+            pb4, info4, d4 = r4["pb"], r4["info"], r4["done"]
+            out["connected_scene"]["envelope_solver"] = {
+                "iterations_per_s": round(d4 / r4["elapsed"], 3), "ms_per_step": round(1e3 * r4["elapsed"] / max(d4, 1), 4),
+                "solve_ms": round(pb4.phase_ms("solve"), 4), "schur_ms": round(pb4.phase_ms("schur"), 4),
+                "cost_after_3_iterations": r4["cost3"], "cost_rel_diff_vs_dense_after_3_iterations": abs(r4["cost3"] - r3["cost3"]) / r3["cost3"],
+                "syrk_launches_per_solve": pb4.phase_ms("syrk_launches")}
+            pb4.close()
+        except Exception as exc:
+            out["connected_scene"] = {"error": repr(exc)}
+    if world == 1 and rank == 0:
         if not args.no_end_to_end:
             # The drop-in boundary itself at the headline size: dense vmask (n*m bytes) and host arrays in, cameras / points out,
             # run_sfm's own options (itmax 150, all stop rules on): vmask -> CRS (on the device), uploads, index construction,

@@ -282,3 +282,42 @@ def test_ipc_transport_times_out_when_a_rank_is_missing(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "COMM False" in r.stdout
     assert "only 1 of 2 ranks reached the ipc group" in r.stderr
+
+
+def test_bench_runs_as_two_ranks_on_one_gpu(tmp_path):
+    """bench.py itself on N > 1 ranks -- the command the driver launches for its SCALE record -- as two processes sharing cuda:0
+    over the ipc transport (one GPU per rank takes the RCCL branch of the same entry point): one JSON line from rank 0, both ranks
+    counted, the headline run plus the structure-aware legs (independent groups, connected scene dense / envelope) on a small scene,
+    every cost at the fixed iteration index equal to the single-process run's."""
+    import json
+    import subprocess
+    common = ["--steps", "3", "--warmup", "1", "--cams", "120", "--points", "12000", "--no-cpu-baseline", "--no-matcher", "--no-end-to-end"]
+    env1 = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env1.pop(k, None)
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, env=env1, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-1500:]
+    ref = json.loads(one.stdout.strip().splitlines()[-1])
+    port = str(_free_port())
+    procs = []
+    for rank in (1, 0):
+        env = dict(env1, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   BSFM_COMM_TRANSPORT="ipc", BSFM_COMM_ID_FILE=str(tmp_path / "bench.id"), BSFM_COMM_TIMEOUT_S="60")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=280) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    assert outs[0][0].strip() == ""                                    # rank 1 prints nothing
+    lines = [ln for ln in outs[1][0].strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                             # ONE JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks_seen"] == 2 and "ipc" in d["config"]["collective"]
+    assert d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "strong" and d["cpu_baseline"] is None
+    close = lambda a, b: abs(a - b) <= 1e-9 * abs(b)
+    assert close(d["cost_after_3_iterations"], ref["cost_after_3_iterations"])
+    sa, cs = d["structure_aware"], d["connected_scene"]
+    assert "error" not in sa and "error" not in cs and sa["n_gpus"] == 2 and cs["n_gpus"] == 2
+    assert close(sa["cost_after_3_iterations"], ref["structure_aware"]["cost_after_3_iterations"])
+    assert close(cs["cost_after_3_iterations"], ref["connected_scene"]["cost_after_3_iterations"])
+    assert close(cs["envelope_solver"]["cost_after_3_iterations"], ref["connected_scene"]["envelope_solver"]["cost_after_3_iterations"])
+    assert "matcher" not in d and "end_to_end_run_sfm" not in d
