@@ -31,6 +31,9 @@
 #pragma once
 #include "potrf.hip.h"
 #include "chol_flow_sched.h"
+#include <list>
+#include <memory>
+#include <mutex>
 #include <map>
 #include <memory>
 
@@ -879,6 +882,48 @@ inline FlowParams flow_params_from_env()
     return p;
 }
 
+// The order depends only on (tile columns, envelope, parameters), and building it costs 56 ms at 71 tile columns (0.7 s at 141) -- a
+// quarter of a whole run_sfm call at config 3.  Bundler calls run_sfm again and again with the same or a slowly growing camera count
+// (outlier rounds, src/Bundle.cpp:784-913; incremental steps, src/BundleFast.cpp:263-438), each call with a problem of its own, so the
+// built orders are kept process-wide: the most recently used FLOW_SCHED_CACHE_ENTRIES of them, at most FLOW_SCHED_CACHE_TASKS tasks.
+constexpr size_t FLOW_SCHED_CACHE_ENTRIES = 8;
+constexpr size_t FLOW_SCHED_CACHE_TASKS = 1500000;      // 60 MB of host memory
+struct FlowSchedCacheEntry { int nblk; std::vector<int> key; std::vector<double> prm; std::shared_ptr<const FlowSchedule> sched; };
+inline std::mutex& flow_sched_cache_mutex() { static std::mutex m; return m; }
+inline std::list<FlowSchedCacheEntry>& flow_sched_cache() { static std::list<FlowSchedCacheEntry> c; return c; }
+inline int flow_cached_schedule(int nblk, const std::vector<int>& key, const FlowParams& p, FlowSchedule& out)
+{
+    const std::vector<double> pv = { (double)p.slots, (double)p.np_max, (double)p.np_max_rhs, p.t_potrf, p.t_trsm32, p.t_trsm64, p.t_upd32, p.t_upd32_per,
+                                     p.t_upd64_0, p.t_upd64_per, p.t_upd128_0, p.t_upd128_per, p.t_ftrsm, p.t_fupd_0, p.t_fupd_per, p.t_hand,
+                                     (double)p.urgent_cols, (double)p.lazy_cols };
+    {
+        std::lock_guard<std::mutex> lock(flow_sched_cache_mutex());
+        auto& c = flow_sched_cache();
+        for (auto it = c.begin(); it != c.end(); ++it)
+            if (it->nblk == nblk && it->key == key && it->prm == pv) {
+                out = *it->sched;
+                c.splice(c.begin(), c, it);                // most recently used first
+                return 0;
+            }
+    }
+    auto built = std::make_shared<FlowSchedule>();
+    if (flow_build_schedule(nblk, key, p, *built) != 0) return -1;
+    if (flow_check_schedule(*built) != 0) { fprintf(stderr, "[bsfm] flow schedule failed its dependency check\n"); return -1; }
+    out = *built;
+    if (built->tasks.size() <= FLOW_SCHED_CACHE_TASKS) {
+        std::lock_guard<std::mutex> lock(flow_sched_cache_mutex());
+        auto& c = flow_sched_cache();
+        c.push_front(FlowSchedCacheEntry{ nblk, key, pv, built });
+        size_t total = 0, kept = 0;
+        for (auto it = c.begin(); it != c.end();) {      // newest first: drop from the old end what no longer fits
+            const size_t nt = it->sched->tasks.size();
+            if (kept >= 1 && (kept + 1 > FLOW_SCHED_CACHE_ENTRIES || total + nt > FLOW_SCHED_CACHE_TASKS)) it = c.erase(it);
+            else { total += nt; ++kept; ++it; }
+        }
+    }
+    return 0;
+}
+
 // (Re)builds the schedule for nblk tile columns and the given envelope (empty = dense) and uploads it.
 inline int flow_prepare(FlowWorkspace& f, int nblk, const std::vector<int>& env_rows)
 {
@@ -892,8 +937,7 @@ inline int flow_prepare(FlowWorkspace& f, int nblk, const std::vector<int>& env_
     if (const char* e = getenv("BSFM_FLOW_CHAIN_WGS")) f.chain_wgs = std::max(0, atoi(e));
     if (const char* e = getenv("BSFM_FLOW_TRACE")) f.trace = atoi(e) != 0;
     f.chain_wgs = std::min(f.chain_wgs, f.wgs / 4);
-    if (flow_build_schedule(nblk, key, flow_params_from_env(), f.sched) != 0) return -1;
-    if (flow_check_schedule(f.sched) != 0) { fprintf(stderr, "[bsfm] flow schedule failed its dependency check\n"); return -1; }
+    if (flow_cached_schedule(nblk, key, flow_params_from_env(), f.sched) != 0) return -1;
     f.nblk = nblk; f.env_key = key;
     f.bulk.clear(); f.chain.clear();
     for (const FlowTask& t : f.sched.tasks) (f.chain_wgs > 0 && t.pad == 1 ? f.chain : f.bulk).push_back(t);

@@ -1623,7 +1623,7 @@ int bsfm_chol_flow_schedule(int nblk, const int* last, int np_max, int slots, vo
     std::vector<int> lv;
     if (last) lv.assign(last, last + nblk);
     FlowSchedule sc;
-    if (flow_build_schedule(nblk, lv, prm, sc) != 0 || flow_check_schedule(sc) != 0) return -1;
+    if (flow_cached_schedule(nblk, lv, prm, sc) != 0) return -1;        // the product's path: built and checked once per process and shape
     if (sim_us) *sim_us = sc.sim_us;
     const int nt = (int)sc.tasks.size();
     if (tasks_out) memcpy(tasks_out, sc.tasks.data(), (size_t)std::min(nt, std::max(0, capacity)) * sizeof(FlowTask));

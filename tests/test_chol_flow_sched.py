@@ -199,3 +199,24 @@ def test_headline_size_schedule_builds_quickly():
     tasks, sim = B.chol_flow_schedule(71)
     assert time.time() - t0 < 2.0
     assert 20000 < len(tasks) < 200000 and 3000.0 < sim < 12000.0
+
+
+def test_schedules_are_kept_process_wide():
+    """run_sfm builds a problem per call, Bundler calls it again and again at the same camera count: the order of a shape is built
+    (56 ms at 71 tile columns) and checked once per process, later requests copy it (chol_flow.hip.h: flow_cached_schedule); the
+    cache keeps the 8 most recently used shapes and what it hands out is what a fresh build gives."""
+    import time
+    t0 = time.perf_counter(); a, sa = B.chol_flow_schedule(67); first = time.perf_counter() - t0
+    t0 = time.perf_counter(); b, sb = B.chol_flow_schedule(67); again = time.perf_counter() - t0
+    assert sa == sb and a.tobytes() == b.tobytes()
+    assert again < 0.5 * first
+    # a different envelope or different parameters are different entries
+    band = [min(66, k + 3) for k in range(67)]
+    c, _ = B.chol_flow_schedule(67, band)
+    d, _ = B.chol_flow_schedule(67, None, np_max=2)
+    assert len(c) < len(a) and d.tobytes() != a.tobytes()
+    # push the first shape out (more shapes than entries), ask again: rebuilt, identical
+    for T in range(20, 32):
+        B.chol_flow_schedule(T)
+    e, se = B.chol_flow_schedule(67)
+    assert se == sa and e.tobytes() == a.tobytes()
