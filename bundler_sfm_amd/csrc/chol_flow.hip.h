@@ -649,6 +649,9 @@ constexpr long long FLOW_SPIN_LIMIT_TICKS = 40LL * 1000 * 1000;      // 0.4 s of
 // FIRST on their CU therefore serve the chain queue, and the workgroup that arrives second on such a CU leaves at once, so a chain
 // workgroup has its CU to itself.  A CU is identified by XCC_ID and the SE / SH / CU fields of HW_ID; if that reading were ever
 // wrong (another part, another partition mode) the only consequence is a shared CU or a few idle slots -- nothing waits on it.
+// (Measured and dropped, round 4: drawing the NEXT ticket in the shadow of the store drain -- neutral; polling a task's three counters
+// together instead of one after the other -- 1.3 % slower, both together 3.5 % slower.  The 4.8 us a ready task spends between ticket and
+// work are not what limits the launch.)
 __global__ __launch_bounds__(512, BSFM_FLOW_WPS) void k_chol_flow(FlowArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -877,6 +880,7 @@ inline FlowParams flow_params_from_env()
     if (const char* e = getenv("BSFM_FLOW_SLOTS")) p.slots = std::max(32, atoi(e));
     if (const char* e = getenv("BSFM_FLOW_URGENT")) p.urgent_cols = std::max(0, atoi(e));
     if (const char* e = getenv("BSFM_FLOW_LAZY")) p.lazy_cols = std::max(0, atoi(e));
+    if (const char* e = getenv("BSFM_FLOW_ADAPT")) p.adaptive_halves = std::max(0, atoi(e));
     if (const char* e = getenv("BSFM_FLOW_TPOTRF")) p.t_potrf = atof(e);
     if (const char* e = getenv("BSFM_FLOW_TUPD128")) { double a0 = 0, a1 = 0; if (sscanf(e, "%lf,%lf", &a0, &a1) == 2) { p.t_upd128_0 = a0; p.t_upd128_per = a1; } }
     return p;
@@ -895,7 +899,7 @@ inline int flow_cached_schedule(int nblk, const std::vector<int>& key, const Flo
 {
     const std::vector<double> pv = { (double)p.slots, (double)p.np_max, (double)p.np_max_rhs, p.t_potrf, p.t_trsm32, p.t_trsm64, p.t_upd32, p.t_upd32_per,
                                      p.t_upd64_0, p.t_upd64_per, p.t_upd128_0, p.t_upd128_per, p.t_ftrsm, p.t_fupd_0, p.t_fupd_per, p.t_hand,
-                                     (double)p.urgent_cols, (double)p.lazy_cols };
+                                     (double)p.urgent_cols, (double)p.lazy_cols, (double)p.adaptive_halves };
     {
         std::lock_guard<std::mutex> lock(flow_sched_cache_mutex());
         auto& c = flow_sched_cache();

@@ -69,6 +69,9 @@ struct FlowParams {
     double t_ftrsm = 10.0, t_fupd_0 = 5.0, t_fupd_per = 8.0;
     double t_hand = 0.5;      // completion -> visible to a dependent (measured 0.3-0.5)
     int urgent_cols = 1;      // columns up to (chain front + urgent_cols) are served in halves / blocks
+    int adaptive_halves = 128; // > 0: the column the chain needs next is served in 64-row halves only while the bulk has no backlog (fewer than this many
+                              // ready tasks beyond the free slots): a half runs at 50 TFLOP/s-equivalent against 53-73 for a whole tile, and latency only
+                              // matters when the chain is the bound.  6.47 -> 6.40 ms at 71 tile columns; 0 = always halves
     int lazy_cols = 0;        // > 0: a bulk tile further than this many columns ahead of the chain is only visited once TWO panels are ready
                               // for it (or its last one): a one-panel visit moves 393 KB for 4.2 Mflop and is HBM-bound
 };
@@ -225,7 +228,9 @@ inline int flow_build_schedule(int T, const std::vector<int>& last_in, const Flo
                 const int cls = classify_upd(i, j);
                 if (i == T) { type = FT_FUPD; parts = 1; dur = prm.t_fupd_0 + prm.t_fupd_per * n; }
                 else if (cls == 1) { n = std::min(n, 3); type = FT_UPD32; parts = 10; dur = prm.t_upd32 + prm.t_upd32_per * (n - 1); }
-                else if (cls == 2) { n = std::min(n, 2); type = FT_UPD64; parts = 2; dur = prm.t_upd64_0 + prm.t_upd64_per * n; }
+                else if (cls == 2 && !(prm.adaptive_halves && (long long)ready.size() > (long long)free_slots + prm.adaptive_halves)) {
+                    n = std::min(n, 2); type = FT_UPD64; parts = 2; dur = prm.t_upd64_0 + prm.t_upd64_per * n;
+                }
                 else { type = FT_UPD128; parts = 1; dur = prm.t_upd128_0 + prm.t_upd128_per * n; }
             }
             if (parts > free_slots) break;            // the head of the queue waits for room (it has the highest priority)
