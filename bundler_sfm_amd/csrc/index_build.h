@@ -36,9 +36,12 @@ struct DeviceIndex {
 };
 
 // rowptr (n+1) / colidx (nvis) are DEVICE arrays.  Returns 0, or -1 with a message on stderr (bad CRS, allocation failure,
-// more than 2^31-1 co-visibility triples).  order_by_block != 0 keeps the tasks in block order (BSFM_SCHUR_ORDER=block).
+// more than 2^31-1 co-visibility triples).  order_mode: launch order of the Schur tasks (results do not depend on it: the partial sums
+// keep their block order) -- clustered (default: point slice, then the cameras in breadth-first numbering), block order
+// (BSFM_SCHUR_ORDER=block) or by first point (BSFM_SCHUR_ORDER=point, the order of rounds 1-3).
+enum { SCHUR_ORDER_CLUSTERED = 0, SCHUR_ORDER_BLOCK = 1, SCHUR_ORDER_POINT = 2 };
 int build_index_device(int n, int m, int mcon, int nvis, const int* d_rowptr, const int* d_colidx, bool want_schur,
-                       int order_by_block, DeviceIndex& out, hipStream_t st);
+                       int order_mode, DeviceIndex& out, hipStream_t st);
 void free_index_device(DeviceIndex& ix);
 
 // Growing a resident problem: merges `nadd` new observations (point, camera, x, y -- device arrays, any order) into

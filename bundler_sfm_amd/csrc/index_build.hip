@@ -152,6 +152,21 @@ __global__ void k_task_keys(int ntasks, const SchurTask* __restrict__ tasks, con
     if (t < ntasks) keys[t] = tri_pt[tasks[t].start];
 }
 
+// Key of the clustered launch order: (slice of the point range the task starts in, the two cameras in breadth-first numbering).
+__global__ void k_task_keys_clustered(int nblk, int mcon, const int* __restrict__ blk_task0, const int* __restrict__ blk_j, const int* __restrict__ blk_k,
+                                      const int* __restrict__ rank, const SchurTask* __restrict__ tasks, const int* __restrict__ tri_pt,
+                                      int n, int slices, unsigned long long* __restrict__ keys)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk) return;
+    const unsigned ra = (unsigned)rank[blk_j[b] - mcon], rb = (unsigned)rank[blk_k[b] - mcon];
+    const unsigned long long cams = ((unsigned long long)min(ra, rb) << 24) | (unsigned long long)max(ra, rb);
+    for (int t = blk_task0[b]; t < blk_task0[b + 1]; ++t) {
+        const unsigned long long slice = (unsigned long long)((long long)tri_pt[tasks[t].start] * slices / max(n, 1));
+        keys[t] = (slice << 48) | cams;
+    }
+}
+
 // Launch order (schur.hip.h): tasks sorted by the first point they touch (`ord`), then every XCD (workgroup index % 8, four
 // tasks per workgroup) gets ONE contiguous stretch of that order: the workgroups wg = x, x + 8, x + 16 ... take consecutive
 // four-task pieces.  Slots past the end are padding (out = -1).
@@ -225,7 +240,7 @@ template <typename T> hipError_t keep(T** p, size_t count) { return bsfm::dev_al
 
 template <typename KeyT>
 int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int* d_colidx, const long long* d_toff, long long total,
-                int order_by_block, DeviceIndex& ix, hipStream_t st)
+                int order_mode, DeviceIndex& ix, hipStream_t st)
 {
     const int mm = m - mcon;
     Scratch tmp(st);
@@ -280,33 +295,82 @@ int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int
     IX_OK(hipStreamSynchronize(st));
     ix.ntasks = ntasks;
     SchurTask* tasks = nullptr;
-    if (order_by_block) {
+    if (order_mode == SCHUR_ORDER_BLOCK) {
         IX_OK(bsfm::dev_alloc((void**)&tasks, std::max<size_t>(1, (size_t)ntasks) * sizeof(SchurTask)));
         ix.tasks = tasks; ix.nslots = ntasks;          // owned by ix from here on: free_index_device releases it on every error path
     } else IX_OK(tmp.alloc(&tasks, (size_t)ntasks));
     hipLaunchKernelGGL(k_tasks, dim3(grid_for(nblk, 256)), dim3(256), 0, st, nblk, blk_start, ix.blk_task0, ix.blk_j, ix.blk_k, tasks, schur_chunk());
     hipLaunchKernelGGL(k_tri_pt, dim3(grid_for(nt, 256)), dim3(256), 0, st, (int)nt, vals_out, ix.cam_pt, ix.tri_pt);
-    if (!order_by_block) {
-        int *tk_in = nullptr, *tk_out = nullptr, *id_in = nullptr, *ord = nullptr;
-        IX_OK(tmp.alloc(&tk_in, (size_t)ntasks)); IX_OK(tmp.alloc(&tk_out, (size_t)ntasks));
+    ix.h_blk_j.resize((size_t)nblk); ix.h_blk_k.resize((size_t)nblk);
+    std::vector<int> h_ntask((size_t)nblk);
+    if (nblk) {
+        IX_OK(hipMemcpyAsync(ix.h_blk_j.data(), ix.blk_j, (size_t)nblk * sizeof(int), hipMemcpyDeviceToHost, st));
+        IX_OK(hipMemcpyAsync(ix.h_blk_k.data(), ix.blk_k, (size_t)nblk * sizeof(int), hipMemcpyDeviceToHost, st));
+        if (order_mode == SCHUR_ORDER_CLUSTERED) IX_OK(hipMemcpyAsync(h_ntask.data(), ntask, (size_t)nblk * sizeof(int), hipMemcpyDeviceToHost, st));
+    }
+    if (order_mode != SCHUR_ORDER_BLOCK) {
+        int *id_in = nullptr, *ord = nullptr;
         IX_OK(tmp.alloc(&id_in, (size_t)ntasks)); IX_OK(tmp.alloc(&ord, (size_t)ntasks));
-        hipLaunchKernelGGL(k_task_keys, dim3(grid_for(ntasks, 256)), dim3(256), 0, st, ntasks, tasks, ix.tri_pt, tk_in);
         hipLaunchKernelGGL(k_iota, dim3(grid_for(ntasks, 256)), dim3(256), 0, st, ntasks, id_in);
-        size_t ob = 0;
-        const int pbits = bits_for((unsigned long long)std::max(n, 1) - 1ULL);
-        IX_OK(prim::sort_pairs(nullptr, ob, tk_in, tk_out, id_in, ord, ntasks, 0, pbits, st));
-        void* d_ob = nullptr;
-        IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_ob), ob));
-        IX_OK(prim::sort_pairs(d_ob, ob, tk_in, tk_out, id_in, ord, ntasks, 0, pbits, st));
+        if (order_mode == SCHUR_ORDER_POINT) {
+            int *tk_in = nullptr, *tk_out = nullptr;
+            IX_OK(tmp.alloc(&tk_in, (size_t)ntasks)); IX_OK(tmp.alloc(&tk_out, (size_t)ntasks));
+            hipLaunchKernelGGL(k_task_keys, dim3(grid_for(ntasks, 256)), dim3(256), 0, st, ntasks, tasks, ix.tri_pt, tk_in);
+            size_t ob = 0;
+            const int pbits = bits_for((unsigned long long)std::max(n, 1) - 1ULL);
+            IX_OK(prim::sort_pairs(nullptr, ob, tk_in, tk_out, id_in, ord, ntasks, 0, pbits, st));
+            void* d_ob = nullptr;
+            IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_ob), ob));
+            IX_OK(prim::sort_pairs(d_ob, ob, tk_in, tk_out, id_in, ord, ntasks, 0, pbits, st));
+        } else {
+            // Clustered order.  Two tasks read the same Jacobian records iff they share a camera AND their point ranges overlap, and what
+            // is in flight on one XCD (~500 tasks, ~100 KB of records each) has to overlap enough to fit its 4 MB of L2.  Sorting by the
+            // first point alone does that only when all blocks of a camera group cut their point lists at the same places (the generator's
+            // cliques); on a connected scene the first point of a chunk is noise, neighbours in the order are unrelated blocks, the L2
+            // hit rate is 9 % and the kernel fetches 17 GB per launch (profiles/r04_schur_connected_counters.txt).  So: the point range
+            // in as many SLICES as the largest block has tasks; within a slice the cameras in breadth-first numbering of the
+            // co-visibility graph (components contiguous, neighbours close) -- (slice, lower camera, higher camera).
+            IX_OK(hipStreamSynchronize(st));
+            const int mm2 = m - mcon;
+            std::vector<int> rank((size_t)mm2, 0);
+            {
+                std::vector<int> adj_ptr((size_t)mm2 + 1, 0);
+                for (int b = 0; b < nblk; ++b) { const int a = ix.h_blk_j[b] - mcon, c = ix.h_blk_k[b] - mcon; if (a != c) { ++adj_ptr[a + 1]; ++adj_ptr[c + 1]; } }
+                for (int j = 0; j < mm2; ++j) adj_ptr[j + 1] += adj_ptr[j];
+                std::vector<int> adj((size_t)adj_ptr[mm2]), fill(adj_ptr.begin(), adj_ptr.end() - 1);
+                for (int b = 0; b < nblk; ++b) { const int a = ix.h_blk_j[b] - mcon, c = ix.h_blk_k[b] - mcon; if (a != c) { adj[fill[a]++] = c; adj[fill[c]++] = a; } }
+                std::vector<char> seen((size_t)mm2, 0);
+                std::vector<int> q; q.reserve((size_t)mm2);
+                for (int s0 = 0; s0 < mm2; ++s0) {
+                    if (seen[s0]) continue;
+                    seen[s0] = 1; q.push_back(s0);
+                    for (size_t h = q.size() - 1; h < q.size(); ++h)
+                        for (int e = adj_ptr[q[h]]; e < adj_ptr[q[h] + 1]; ++e) if (!seen[adj[e]]) { seen[adj[e]] = 1; q.push_back(adj[e]); }
+                }
+                for (int p = 0; p < mm2; ++p) rank[q[p]] = p;
+            }
+            int slices = 1;
+            for (int b = 0; b < nblk; ++b) slices = std::max(slices, h_ntask[b]);
+            slices = std::min(slices, 4096);
+            int* d_rank = nullptr;
+            IX_OK(tmp.alloc(&d_rank, (size_t)mm2));
+            IX_OK(hipMemcpyAsync(d_rank, rank.data(), (size_t)mm2 * sizeof(int), hipMemcpyHostToDevice, st));
+            unsigned long long *ck_in = nullptr, *ck_out = nullptr;
+            IX_OK(tmp.alloc(&ck_in, (size_t)ntasks)); IX_OK(tmp.alloc(&ck_out, (size_t)ntasks));
+            hipLaunchKernelGGL(k_task_keys_clustered, dim3(grid_for(nblk, 256)), dim3(256), 0, st, nblk, mcon, ix.blk_task0, ix.blk_j, ix.blk_k, d_rank,
+                               tasks, ix.tri_pt, n, slices, ck_in);
+            size_t ob = 0;
+            const int kb2 = 48 + bits_for((unsigned long long)slices);
+            IX_OK(prim::sort_pairs(nullptr, ob, ck_in, ck_out, id_in, ord, ntasks, 0, kb2, st));
+            void* d_ob = nullptr;
+            IX_OK(tmp.alloc(reinterpret_cast<char**>(&d_ob), ob));
+            IX_OK(prim::sort_pairs(d_ob, ob, ck_in, ck_out, id_in, ord, ntasks, 0, kb2, st));
+            IX_OK(hipStreamSynchronize(st));          // `rank` (host) was the source of an asynchronous copy
+        }
         const int nwg = (ntasks + 3) / 4;
         ix.nslots = nwg * 4;
         IX_OK(keep(&ix.tasks, (size_t)ix.nslots));
         hipLaunchKernelGGL(k_launch_order, dim3(grid_for((size_t)ix.nslots, 256)), dim3(256), 0, st, ntasks, nwg, tasks, ord, ix.tasks);
-    }
-    ix.h_blk_j.resize((size_t)nblk); ix.h_blk_k.resize((size_t)nblk);
-    if (nblk) {
-        IX_OK(hipMemcpyAsync(ix.h_blk_j.data(), ix.blk_j, (size_t)nblk * sizeof(int), hipMemcpyDeviceToHost, st));
-        IX_OK(hipMemcpyAsync(ix.h_blk_k.data(), ix.blk_k, (size_t)nblk * sizeof(int), hipMemcpyDeviceToHost, st));
     }
     IX_OK(hipStreamSynchronize(st));          // temporaries are freed when `tmp` goes out of scope
     return 0;
@@ -489,7 +553,7 @@ void free_index_device(DeviceIndex& ix)
 }
 
 int build_index_device(int n, int m, int mcon, int nvis, const int* d_rowptr, const int* d_colidx, bool want_schur,
-                       int order_by_block, DeviceIndex& ix, hipStream_t st)
+                       int order_mode, DeviceIndex& ix, hipStream_t st)
 {
     // rocPRIM checks hipGetLastError() after its launches: a stale error of an EARLIER, unrelated call in this thread (e.g.
     // hipEventElapsedTime on a never-recorded phase event -> hipErrorInvalidHandle) would be reported as a sort failure
@@ -541,8 +605,8 @@ int build_index_device(int n, int m, int mcon, int nvis, const int* d_rowptr, co
         if (total > (long long)INT_MAX) { fprintf(stderr, "[bsfm] too many co-visibility triples (%lld)\n", total); return -1; }
         const unsigned long long maxkey = (unsigned long long)(m - mcon) * (unsigned long long)(m - mcon);
         const int rc = maxkey <= 0xffffffffULL
-            ? build_schur<unsigned int>(n, m, mcon, nvis, d_rowptr, d_colidx, toff, total, order_by_block, ix, st)
-            : build_schur<unsigned long long>(n, m, mcon, nvis, d_rowptr, d_colidx, toff, total, order_by_block, ix, st);
+            ? build_schur<unsigned int>(n, m, mcon, nvis, d_rowptr, d_colidx, toff, total, order_mode, ix, st)
+            : build_schur<unsigned long long>(n, m, mcon, nvis, d_rowptr, d_colidx, toff, total, order_mode, ix, st);
         if (rc) return rc;
     }
     if (getenv("BSFM_DEBUG_INDEX")) fprintf(stderr, "[bsfm] index build: n %d m %d nvis %d triples %d blocks %d tasks %d\n", n, m, nvis, ix.ntriples, ix.nblk, ix.ntasks);

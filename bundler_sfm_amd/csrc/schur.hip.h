@@ -23,6 +23,10 @@
 // different XCDs.  Tasks are therefore launched sorted by the first point they touch (tasks over the same points become
 // neighbours) and each XCD (blockIdx % 8) is handed one contiguous stretch of that order, so a record is fetched into ONE L2
 // and found there by the other tasks that need it.  Output slots stay in block order: sums are bit-identical.
+// Round 4: that order only works when the blocks of a camera group cut their point lists at the same places (the generator's
+// cliques).  On a connected scene it left 9 % L2 hits and 17 GB fetched per launch; the launch order is now (slice of the point
+// range, lower camera, higher camera) with the cameras in breadth-first numbering of the co-visibility graph
+// (index_build.hip: SCHUR_ORDER_CLUSTERED; profiles/r04_schur_connected_counters.txt): same on the cliques, 3.2 -> 2.5 ms connected.
 // Then the instruction stream: the disassembly showed ~50 exec-mask blocks per pass (predicated staging, lane-dependent row tests
 // the compiler could not fold) and mul + fma + add per accumulator; clamped staging slots, __builtin_assume on the lane's
 // column index and explicit FMAs brought the pass to ~235 instructions (96 FP64) and the kernel from 1.86 to 1.67 ms.  L2 read

@@ -798,7 +798,7 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
         const auto t_ix0 = std::chrono::steady_clock::now();
         const char* eo = getenv("BSFM_SCHUR_ORDER");
         DeviceIndex ix;
-        if (build_index_device(n, m, d->mcon, nvis, pb->d_rowptr, pb->d_obs_cam, !pb->mot, (eo && !strcmp(eo, "block")) ? 1 : 0, ix, pb->stream) != 0) {
+        if (build_index_device(n, m, d->mcon, nvis, pb->d_rowptr, pb->d_obs_cam, !pb->mot, (eo && !strcmp(eo, "block")) ? SCHUR_ORDER_BLOCK : (eo && !strcmp(eo, "point")) ? SCHUR_ORDER_POINT : SCHUR_ORDER_CLUSTERED, ix, pb->stream) != 0) {
             free_index_device(ix);
             return fail("index construction");
         }
