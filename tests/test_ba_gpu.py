@@ -863,3 +863,39 @@ def test_block_cache_reuse_and_trim_leave_results_bit_identical(gpu_bsfm):
     for other in (again, third, fourth):
         assert other[0] == ref[0] and np.array_equal(other[1], ref[1])
         assert np.array_equal(other[2], ref[2]) and np.array_equal(other[3], ref[3])
+
+
+@pytest.mark.parametrize("banded", [False, True], ids=["cliques", "connected"])
+def test_schur_launch_order_does_not_change_a_bit(gpu_bsfm, monkeypatch, banded):
+    """The Schur tasks are LAUNCHED in an order chosen for the L2s -- clustered (default: point slice, then the two cameras in
+    breadth-first numbering of the co-visibility graph, index_build.hip), by block, or by first point (rounds 1-3) -- while their
+    partial sums keep the block order the reference visits them in (sba_levmar.c:1218-1268).  So S and E must be the same BITS under
+    all three, every order must be a permutation of the same task list, and the LM run must not notice."""
+    B = gpu_bsfm
+    m, n = 130, 30000          # 16 groups of 8 cameras with 10 tasks per block / ~3 200 blocks of ~2 tasks
+    s = B.synth_ba(m, n, 8, banded=banded)
+    res = {}
+    for order in ("", "block", "point"):
+        if order:
+            monkeypatch.setenv("BSFM_SCHUR_ORDER", order)
+        else:
+            monkeypatch.delenv("BSFM_SCHUR_ORDER", raising=False)
+        pb = B.Problem(n, m, s["rowptr"], s["colidx"], s["proj"], s["cams"], s["pts"],
+                       options=B.default_options(jacobian=B.JAC_ANALYTIC, verbose=0, itmax=4))
+        ne = pb.normal_equations(mu=0.37)
+        sc = pb.export_schur()
+        rc, info = pb.solve()
+        p, _, _ = pb.download()
+        pb.close()
+        live = sc["tasks"][sc["tasks"][:, 3] >= 0]
+        res[order] = dict(S=ne["S"], E=ne["E"], tasks=live, info=np.array(info), p=p, ntasks=sc["ntasks"])
+    ref = res[""]
+    for order in ("block", "point"):
+        r = res[order]
+        assert r["S"].tobytes() == ref["S"].tobytes() and r["E"].tobytes() == ref["E"].tobytes(), order
+        assert r["info"].tobytes() == ref["info"].tobytes() and r["p"].tobytes() == ref["p"].tobytes(), order
+        assert r["ntasks"] == ref["ntasks"] == len(r["tasks"]) == len(ref["tasks"])
+        key = lambda t: t[np.lexsort((t[:, 0], t[:, 3]))]
+        assert np.array_equal(key(r["tasks"]), key(ref["tasks"])), order          # the same tasks, another order
+    assert np.array_equal(np.sort(ref["tasks"][:, 3]), np.arange(ref["ntasks"]))     # every output slot exactly once
+    assert not np.array_equal(ref["tasks"][:, 3], res["block"]["tasks"][:, 3])      # ... and the orders do differ
