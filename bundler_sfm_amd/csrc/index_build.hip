@@ -243,6 +243,8 @@ int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int
                 int order_mode, DeviceIndex& ix, hipStream_t st)
 {
     const int mm = m - mcon;
+    // a problem whose Jacobian records (272 bytes per observation) fit one XCD's L2 needs no launch order at all: block order, no task sort
+    if (order_mode == SCHUR_ORDER_CLUSTERED && (size_t)nvis * 272u <= (size_t)(4u << 20)) order_mode = SCHUR_ORDER_BLOCK;
     Scratch tmp(st);
     const size_t nt = (size_t)total;
     ix.ntriples = (int)total;
