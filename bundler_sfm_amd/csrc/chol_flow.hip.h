@@ -34,8 +34,6 @@
 #include <list>
 #include <memory>
 #include <mutex>
-#include <map>
-#include <memory>
 
 namespace bsfm {
 
@@ -422,7 +420,6 @@ __device__ BSFM_FLOW_ROLE void flow_potrf(const FlowArgs& a_in, int k, double* l
     const double* G = a.S + (size_t)base * a.ld + base;
     const int lr0 = lane0 >> 4, lc0 = lane0 & 15;
 #define BSFM_FLOW_MARK(code) do { if (a.trace && lane0 == 0 && w == 0) a.trace[a.ptrace_ofs + 40 * (size_t)k + (code)] = wall_clock64(); } while (0)
-#define BSFM_RDLANE(v, l) __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), (l)), __builtin_amdgcn_readlane(__double2loint(v), (l)))
 #define BSFM_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
     BSFM_FLOW_MARK(1);
     int sI[5], sJ[5];
@@ -627,7 +624,6 @@ __device__ BSFM_FLOW_ROLE void flow_potrf(const FlowArgs& a_in, int k, double* l
     }
     BSFM_FLOW_MARK(37);
 #undef BSFM_FLOW_MARK
-#undef BSFM_RDLANE
 #undef BSFM_LDS_FENCE
 }
 
