@@ -106,9 +106,50 @@ def schur_restatement(rowptr, colidx, campos, mcon, m):
     return keys[order], np.array(vals, np.int32).reshape(-1, 2)[order], np.array(pts, np.int32)[order]
 
 
+def expected_launch(by_slot, sc, pts, n, m, mcon, nvis):
+    """numpy restatement of the launch order of the Schur tasks (index_build.hip: build_schur, k_task_keys_clustered, k_launch_order)."""
+    ntasks = len(by_slot)
+    if nvis * 272 <= (4 << 20):
+        return by_slot                                     # block order, no padding slots
+    mm = m - mcon
+    adj = [[] for _ in range(mm)]
+    for a, c in zip(sc["blk_j"] - mcon, sc["blk_k"] - mcon):
+        if a != c:
+            adj[a].append(c); adj[c].append(a)
+    seen = np.zeros(mm, bool); q = []
+    for s0 in range(mm):                                   # breadth-first numbering, components one after the other
+        if seen[s0]:
+            continue
+        seen[s0] = True; q.append(s0); h = len(q) - 1
+        while h < len(q):
+            for v in adj[q[h]]:
+                if not seen[v]:
+                    seen[v] = True; q.append(v)
+            h += 1
+    rank = np.zeros(mm, np.int64); rank[np.array(q)] = np.arange(mm)
+    ntask = np.diff(sc["blk_task0"])
+    slices = min(max(1, int(ntask.max())), 4096)
+    blk_of = np.repeat(np.arange(len(ntask)), ntask)
+    ra, rb = rank[sc["blk_j"][blk_of] - mcon], rank[sc["blk_k"][blk_of] - mcon]
+    first = pts[by_slot[:, 0]].astype(np.int64)
+    key = ((first * slices // max(n, 1)) << 48) | (np.minimum(ra, rb) << 24) | np.maximum(ra, rb)
+    order = np.argsort(key, kind="stable")
+    nwg = (ntasks + 3) // 4
+    out = np.zeros((4 * nwg, 4), np.int32); out[:, 3] = -1
+    for wg in range(nwg):
+        x = wg & 7
+        nxt = (wg >> 3) + sum((nwg - r + 7) // 8 for r in range(x) if nwg > r)
+        for w in range(4):
+            src = 4 * nxt + w
+            if src < ntasks:
+                out[4 * wg + w] = by_slot[order[src]]
+    return out
+
+
 @pytest.mark.gpu
 @needs_ref
-@pytest.mark.parametrize("n,m,density,mcon,seed", [(300, 40, 0.2, 0, 1), (57, 9, 0.6, 2, 2), (400, 64, 0.1, 0, 5), (2000, 130, 0.03, 3, 4)])
+@pytest.mark.parametrize("n,m,density,mcon,seed", [(300, 40, 0.2, 0, 1), (57, 9, 0.6, 2, 2), (400, 64, 0.1, 0, 5), (2000, 130, 0.03, 3, 4),
+                                                   (2600, 70, 0.1, 1, 7), (6000, 12, 0.5, 0, 8)])   # the last two are past the block-order limit (one / eight tasks per block)
 def test_device_index_is_the_reference_index(gpu_bsfm, n, m, density, mcon, seed):
     B = gpu_bsfm
     rng = np.random.default_rng(seed)
@@ -149,13 +190,9 @@ def test_device_index_is_the_reference_index(gpu_bsfm, n, m, density, mcon, seed
             s0 = starts[b] + CH * t
             exp.append((s0, min(CH, starts[b] + counts[b] - s0), int(sc["blk_j"][b] == sc["blk_k"][b])))
     assert np.array_equal(by_slot[:, :3], np.array(exp, np.int32).reshape(-1, 3))
-    # launch order: sorted by the first point a task touches, one contiguous stretch per XCD (workgroup % 8)
-    nwg = len(tasks) // 4
-    first_pt = np.where(tasks[:, 3] >= 0, pts[np.clip(tasks[:, 0], 0, max(len(pts) - 1, 0))] if len(pts) else 0, 1 << 30)
-    for x in range(8):
-        seq = np.concatenate([first_pt[4 * wg:4 * wg + 4] for wg in range(x, nwg, 8)]) if nwg > x else np.zeros(0)
-        seq = seq[seq < (1 << 30)]
-        assert (np.diff(seq) >= 0).all()
+    # launch order (index_build.hip): block order when the records fit one L2, else (point slice, cameras in breadth-first numbering),
+    # one contiguous stretch of that order per XCD (workgroup % 8)
+    assert np.array_equal(tasks, expected_launch(by_slot, sc, pts, n, m, mcon, nvis))
     pb.close()
 
 
