@@ -899,3 +899,39 @@ def test_schur_launch_order_does_not_change_a_bit(gpu_bsfm, monkeypatch, banded)
         assert np.array_equal(key(r["tasks"]), key(ref["tasks"])), order          # the same tasks, another order
     assert np.array_equal(np.sort(ref["tasks"][:, 3]), np.arange(ref["ntasks"]))     # every output slot exactly once
     assert not np.array_equal(ref["tasks"][:, 3], res["block"]["tasks"][:, 3])      # ... and the orders do differ
+
+
+@pytest.mark.parametrize("est,und,ncons,banded", [(1, 1, 0, True), (1, 1, 3, False), (1, 0, 0, True), (0, 0, 2, True)],
+                         ids=["cnp9-connected", "cnp9-3fixed-cliques", "cnp7-connected", "cnp6-2fixed-connected"])
+def test_midsize_run_sfm_matches_the_reference_live(gpu_bsfm, est, und, ncons, banded):
+    """The drop-in boundary at the sizes incremental Bundler spends its time at (72 cameras: 4-5 tile columns of the tile-dataflow
+    Cholesky, chol_flow.hip.h), every camera model (cnp 9 / 7 / 6) and fixed cameras in front of the reduced system, against the
+    reference's own run_sfm called LIVE on the same inputs (oracle/_ref, lib/sfm-driver/sfm.c:592-1003): per-camera focal length,
+    distortion, centre and rotation, and every point, after both runs stopped by their own rules."""
+    import oracle_util as O
+    if not O.have_ref():
+        pytest.skip("oracle/_ref not built")
+    B = gpu_bsfm
+    m, n = 72, 6000
+    s = B.synth_ba(m, n, 8, banded=banded)
+    vm = B.dense_vmask(n, m, s["rowptr"], s["colidx"])
+    if not und:
+        for cm in s["cams"]:
+            cm.k[0] = 0.0; cm.k[1] = 0.0
+        # (the generator projected WITH its small distortion: both implementations fit the same slightly wrong model to the same data)
+    cams = B.copy_cameras(s["cams"]); pts = s["pts"].copy()
+    rc, info = B.run_sfm(n, m, ncons, vm, s["proj"], est, 0, und, 1, cams, pts, eps2=1e-12, options=B.default_options(verbose=0))
+    assert rc >= 0
+    rcams, rpts = O.ref_run_sfm(n, m, vm, s["proj"], s["cams"], s["pts"], ncons=ncons, est_focal=est, undistort=und, explicit=1, eps2=1e-12)
+    f = np.array([c.f for c in cams]); rf = np.array([c.f for c in rcams])
+    k = np.array([list(c.k) for c in cams]); rk = np.array([list(c.k) for c in rcams])
+    t = np.array([list(c.t) for c in cams]); rt = np.array([list(c.t) for c in rcams])
+    R = np.array([list(c.R) for c in cams]); rR = np.array([list(c.R) for c in rcams])
+    d = dict(f=np.abs(f - rf).max() / np.abs(rf).max(), k=np.abs(k - rk).max() / max(np.abs(rk).max(), 1e-3), t=np.abs(t - rt).max() / np.abs(rt).max(),
+             R=np.abs(R - rR).max(), pts=np.abs(pts - rpts).max() / np.abs(rpts).max())
+    print("\n[midsize vs live reference]", {q: f"{v:.1e}" for q, v in d.items()}, "iterations", int(info[5]), "stop", int(info[6]))
+    # measured: 0 .. 2e-11 (cnp 6 / 7), 4e-7 (cnp 9, connected), 3e-5 at most on the clique scene with fixed cameras (the second distortion coefficient of the clique scene is barely determined: values up to 2, Snavely's
+    # 4 % rule stops both runs on the way there); the bounds are those of the fixture tests above
+    assert d["f"] <= 1e-5 and d["k"] <= 1e-4 and d["t"] <= 1e-5 and d["R"] <= 1e-5 and d["pts"] <= 1e-5, d
+    if ncons:
+        assert np.array_equal(f[:ncons], np.array([c.f for c in s["cams"]][:ncons])) and np.array_equal(t[:ncons], np.array([list(c.t) for c in s["cams"]][:ncons]))
