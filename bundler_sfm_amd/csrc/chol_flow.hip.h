@@ -853,7 +853,7 @@ struct FlowWorkspace {
     double* pc = nullptr;                  // compact panel tiles
     long long* d_trace = nullptr;
     int wgs = 512;                         // workgroups launched (BSFM_FLOW_WGS)
-    int chain_wgs = 16;                    // of them: serve the chain queue, alone on their CU (BSFM_FLOW_CHAIN_WGS; 0 = one queue)
+    int chain_wgs = 16;                    // of them: serve the chain queue, alone on their CU (16 or 26, see flow_prepare; BSFM_FLOW_CHAIN_WGS; 0 = one queue)
     bool trace = false;                    // BSFM_FLOW_TRACE=1: per-task stamps, dumped to BSFM_FLOW_TRACE_FILE after every solve
     double flops = 0.0;                    // flops of one factorisation as scheduled (UPD + TRSM tile products, 2 * 128^3 each)
     hipEvent_t k0 = nullptr, k1 = nullptr; // around the k_chol_flow launch: the roofline kernel's duration
@@ -934,10 +934,14 @@ inline int flow_prepare(FlowWorkspace& f, int nblk, const std::vector<int>& env_
     bsfm::dev_free(f.d_sync, true); f.d_sync = nullptr;
     if (f.nblk != nblk) { bsfm::dev_free(f.pc, true); f.pc = nullptr; }
     if (const char* e = getenv("BSFM_FLOW_WGS")) f.wgs = std::max(2, atoi(e));
-    if (const char* e = getenv("BSFM_FLOW_CHAIN_WGS")) f.chain_wgs = std::max(0, atoi(e));
     if (const char* e = getenv("BSFM_FLOW_TRACE")) f.trace = atoi(e) != 0;
-    f.chain_wgs = std::min(f.chain_wgs, f.wgs / 4);
     if (flow_cached_schedule(nblk, key, flow_params_from_env(), f.sched) != 0) return -1;
+    // Chain workgroups: 16 serve the sixteen blocks of the first panel tile at once, but the one that has just finished POTRF joins late;
+    // a chain-bound factorisation (few tile products per column: up to ~45 dense tile columns, any envelope) gains 1-3 % from 26, a
+    // bulk-bound one loses 2 % (every chain workgroup takes a CU away from the bulk): n = 3 600: 1.62 -> 1.58 ms, n = 9 000: 6.40 -> 6.55.
+    f.chain_wgs = (f.sched.upd_tiles + f.sched.trsm_tiles) < 400.0 * nblk ? 26 : 16;
+    if (const char* e = getenv("BSFM_FLOW_CHAIN_WGS")) f.chain_wgs = std::max(0, atoi(e));
+    f.chain_wgs = std::min(f.chain_wgs, f.wgs / 4);
     f.nblk = nblk; f.env_key = key;
     f.bulk.clear(); f.chain.clear();
     for (const FlowTask& t : f.sched.tasks) (f.chain_wgs > 0 && t.pad == 1 ? f.chain : f.bulk).push_back(t);
