@@ -178,6 +178,8 @@ __global__ __launch_bounds__(256) void k_permute16(int nvis, const int* __restri
 // broadcast), gather their point (24 bytes, the point array is L2-resident) and write consecutive records of the two streams
 // Ac (cnp chunks (A[0][c], A[1][c])) and Bc (B || e, 64 bytes; e is copied from the residual array so that the per-point kernels
 // find it in the same sector as B).
+// (The forward-difference variant takes 164 VGPRs = three waves per SIMD.  Capped at 128 -- __launch_bounds__(256, 4) -- it spills 32
+// registers and the phase goes from 0.38 to 0.51 ms at config 3: measured in round 4, not kept.)
 template <int CNP, bool FD, bool KNOWN>
 __global__ __launch_bounds__(256) void k_jacobian(ModelCfg cfg, int nvis,
         const int* __restrict__ cam_cam, const int* __restrict__ cam_pt,
