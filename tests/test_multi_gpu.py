@@ -321,3 +321,36 @@ def test_bench_runs_as_two_ranks_on_one_gpu(tmp_path):
     assert close(cs["cost_after_3_iterations"], ref["connected_scene"]["cost_after_3_iterations"])
     assert close(cs["envelope_solver"]["cost_after_3_iterations"], ref["connected_scene"]["envelope_solver"]["cost_after_3_iterations"])
     assert "matcher" not in d and "end_to_end_run_sfm" not in d
+
+
+def test_bench_line_has_the_contract_fields(tmp_path):
+    """One JSON line with the fields the driver parses (metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better /
+    scaling / vs_baseline / dtype / data / config.workload) and the two objects of this tier: `roofline` (bound, achieved <= peak, unit,
+    frac = achieved / peak, traffic) for the dominant kernel and `cpu_baseline` (value, unit, cores, kind, sample) -- on a small scene,
+    both timed windows."""
+    import json
+    import subprocess
+    env1 = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env1.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--cams", "150", "--points", "15000",
+           "--cpu-baseline", "cached", "--cpu-sample", "20,1500", "--no-matcher", "--no-end-to-end", "--no-connected", "--no-structure-aware"]
+    one = subprocess.run(cmd, env=env1, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-1500:]
+    lines = [ln for ln in one.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["metric"] == "BA LM iterations/sec" and d["unit"] == "iterations/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["scaling"] in ("strong", "weak") and d["vs_baseline"] is None and isinstance(d["config"]["workload"], str)
+    assert abs(d["value"] * d["ms_per_step"] - 1e3) <= 1.0                           # iterations/s and ms per step describe the same run
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["kernel"] == "k_chol_flow" and 0 < r["achieved"] <= r["peak"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-3 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] == "reference" and c["cores"] == 1 and c["value"] > 0 and isinstance(c["sample"], str) and "unit" in c
+    assert "run_sfm" in d["config"]["timed_window"] and d["continued_past_convergence"]["iterations_per_s"] > 0
+    two = subprocess.run(cmd + ["--window", "continue"], env=env1, capture_output=True, text=True, timeout=300)
+    assert two.returncode == 0, two.stderr[-1500:]
+    d2 = json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][0])
+    assert d2["continued_past_convergence"] is None and "rounds 1-3" in d2["config"]["timed_window"]
