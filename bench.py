@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--workload", choices=["ba", "match"], default="ba", help="ba (default, the headline metric) or match (KeyMatchFull, configs[4])")
     ap.add_argument("--no-matcher", action="store_true", help="skip the matcher object of the BA line")
     ap.add_argument("--no-connected", action="store_true", help="skip the connected-scene object of the BA line")
+    ap.add_argument("--no-dense-valued", action="store_true", help="skip the dense_valued_S object (the headline's Cholesky task list on a fully dense matrix)")
     ap.add_argument("--match-images", type=int, default=500)
     ap.add_argument("--match-keys", type=int, default=5000)
     ap.add_argument("--match-cpu-pairs", type=int, default=60, help="image pairs of the bounded CPU (reference ANN) sample")
@@ -100,10 +101,17 @@ def syrk_flops_per_launch(sdim):
 
 
 def pmc_summary():
-    """Newest committed PMC summary (counters need their own profiler passes, so they cannot be collected inside this run)."""
+    """The committed PMC summary this line quotes (counters need their own profiler passes, so they cannot be collected inside this
+    run).  Which file: the one profiles/LATEST names (written by scripts/profile_round.sh next to the summary it produced), else the
+    most recently modified *_pmc_traffic.json -- NOT the lexicographically last name (round 4 quoted a superseded file that way)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     try:
+        ptr = os.path.join(ROOT, "profiles", "LATEST")
+        if os.path.exists(ptr):
+            name = json.load(open(ptr)).get("pmc_traffic")
+            if name and os.path.exists(os.path.join(ROOT, "profiles", name)):
+                return json.load(open(os.path.join(ROOT, "profiles", name))), name
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=os.path.getmtime)
         return (json.load(open(files[-1])), os.path.basename(files[-1])) if files else (None, None)
     except Exception:
         return None, None
@@ -469,7 +477,8 @@ def main():
         flops_launch, nlaunch = syrk_flops_per_launch(sdim)
         syrk_ms = pb.phase_ms("syrk")
         phases = {ph: round(pb.phase_ms(ph), 4) for ph in
-                  ("jacobian", "cam_blocks", "point_blocks", "point_invert", "schur", "solve", "backsub", "residual")}
+                  ("jacobian", "cam_blocks", "point_blocks", "point_invert", "schur", "schur_prep", "schur_rows", "schur_tasks",
+                   "solve", "backsub", "residual")}
         roof = None
         flow_ms = pb.phase_ms("flow_kernel")
         whole = {"flop": sdim ** 3 / 3.0, "solve_ms": phases["solve"],
@@ -481,7 +490,11 @@ def main():
             lib_flops = pb.phase_ms("flow_gflop") * 1e9
             ach = lib_flops / (flow_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "k_chol_flow", "achieved": round(ach, 3), "peak": FP64_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic("k_chol_flow"),
+                    "unit": "TFLOP/s", "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4),
+                    "frac_useful": round(sdim ** 3 / 3.0 / (flow_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+                    "frac_note": "frac counts the tile products the launch EXECUTES (full diagonal tiles, panel solves as products with the explicit "
+                                 "inverse); frac_useful counts SURVEY 8(d)'s algorithmic n^3/3 over the same launch time",
+                    "traffic": pmc_traffic("k_chol_flow"), "traffic_source": (pmc_summary()[1] and "profiles/" + pmc_summary()[1]),
                     "traffic_note": "HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                     "this command (scripts/profile_round.sh -> profiles/*_pmc_traffic.json; 2 x FETCH_SIZE "
                                     "per the gfx950 correction), NOT measured in this run; algorithmic traffic: every tile task reads and "
@@ -514,20 +527,31 @@ def main():
                "backsub": nv_loc * (a_b + 48 + 8) + np_loc * 120,             # Ac + B gathered, index pair
                "residual": nv_loc * (16 + 8 + 24 + 16)}                       # xc, index pair, point in; e out
         hbm = {}
+        kern_of = {"jacobian": "k_jacobian", "cam_blocks": "k_cam_blocks", "point_blocks": "k_point_blocks", "backsub": "k_backsub", "residual": "k_residual"}
         for ph, nbytes in alg.items():
             ms = phases.get(ph, 0.0)
             if ms and ms > 0:
                 gbs = nbytes / (ms * 1e-3) / 1e9
                 hbm[ph] = {"alg_GB": round(nbytes / 1e9, 3), "ms": ms, "GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / 8000.0, 3)}
-        hbm["note"] = "algorithmic bytes per phase (DESIGN.md section 4) over its HIP-event time"
+                ctr = pmc_traffic(kern_of[ph]) if world == 1 else None       # the committed counters are of the single-GPU command
+                if ctr:
+                    hbm[ph]["counter_GB"] = round(ctr / 1e9, 3); hbm[ph]["counter_over_algorithmic"] = round(ctr / nbytes, 3)
+        hbm["note"] = ("algorithmic bytes per phase (DESIGN.md section 4) over its HIP-event time; counter_GB = 2 x FETCH_SIZE + WRITE_SIZE per launch "
+                       "from " + (pmc_summary()[1] and "profiles/" + pmc_summary()[1] or "no committed PMC summary"))
         schur_flop = deg2 * 486.0                       # 486 flop per co-visibility pair with the symmetry used
-        schur = {"ms": phases["schur"], "triples": deg2, "useful_flop": schur_flop,
+        schur = {"ms": phases["schur"], "prep_ms": phases["schur_prep"], "rows_kernel_ms": phases["schur_rows"], "tasks_kernel_ms": phases["schur_tasks"],
+                 "row_kernel": {"workgroups": int(pb.phase_ms("row_wgs")), "pieces": int(pb.phase_ms("row_pieces")), "dense_blocks": int(pb.phase_ms("row_blocks")),
+                                "triples": int(pb.phase_ms("row_triples")), "segment_records": int(pb.phase_ms("row_L"))},
+                 "kernels_frac_of_fp64_peak": (round(schur_flop / ((phases["schur_rows"] + phases["schur_tasks"]) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)
+                                               if phases["schur_rows"] + phases["schur_tasks"] > 0 else None),
+                 "triples": deg2, "useful_flop": schur_flop,
                  "TFLOPs": round(schur_flop / (phases["schur"] * 1e-3) / 1e12, 2) if phases["schur"] > 0 else None,
                  "frac_of_fp64_peak": round(schur_flop / (phases["schur"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if phases["schur"] > 0 else None,
                  "unique_footprint_GB": round(nv_loc * (16.0 * cnp + 64 + 64) / 1e9, 3),
                  "note": "record gathers of the triples are served by L2 / Infinity Cache; against HBM only the unique footprint counts"}
         out = {
             "metric": "BA LM iterations/sec", "value": round(done / elapsed, 4), "unit": "iterations/s",
+            "protocol": "window=" + args.window + (" (since round 4; BENCH_r01..r03 used window=continue: see continued_past_convergence)" if args.window == "run" else ""),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / max(done, 1), 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -569,8 +593,25 @@ def main():
     if rank != 0:
         out = {}
 
+    legs_ok = [True]
+
     def leg(scene, solver, label):
-        r_ = run_ba(B, args, scene, world, rank, comm, hook_setup, sync, solver, jac, label)
+        """A non-headline leg.  On N > 1 ranks a failure must be COLLECTIVE: a rank that fails before its first exchange (problem
+        construction, allocation) would otherwise leave the others waiting inside the next all-reduce.  So: once any leg failed on
+        any rank, every rank skips the remaining legs; and after a leg every rank learns whether all ranks finished it."""
+        if not legs_ok[0]:
+            raise RuntimeError("skipped: an earlier leg failed on some rank")
+        err = None
+        try:
+            r_ = run_ba(B, args, scene, world, rank, comm, hook_setup, sync, solver, jac, label)
+        except BaseException as exc:       # noqa: BLE001 -- the flag exchange below must happen on every rank
+            err, r_ = exc, None
+        failed_somewhere = max_over_ranks(1.0 if err is not None else 0.0) > 0.5
+        if failed_somewhere:
+            legs_ok[0] = False
+            if r_ is not None:
+                r_["pb"].close()
+            raise RuntimeError(f"leg {label}: failed on {'this' if err is not None else 'another'} rank: {err!r}")
         r_["elapsed"] = max_over_ranks(r_["elapsed"])
         return r_
 
@@ -624,6 +665,29 @@ def main():
             pb4.close()
         except Exception as exc:
             out["connected_scene"] = {"error": repr(exc)}
+    if world == 1 and rank == 0 and not args.no_dense_valued:
+        # The headline's dense task list on a matrix whose 128 x 128 tiles ALL hold numbers (both synthetic scenes give an S that is
+        # 1-5 % non-empty blocks; the part sustains a higher clock when most FP64 matrix operands are zeros): a random SPD matrix of the
+        # headline's order through bsfm_dense_chol_solve (factorisation + both substitutions).  NOT `value`.
+        try:
+            nn = m * cnp
+            rng = np.random.default_rng(5)
+            Gm = rng.standard_normal((nn, nn + 64))
+            Am = Gm @ Gm.T + nn * np.eye(nn); del Gm
+            bm = rng.standard_normal(nn)
+            rc_d, x_d, ms_d, fms, fgf = B.sfm.dense_chol_solve_timed(Am, bm, reps=4)
+            resid = float(np.abs(Am @ x_d - bm).max() / (np.abs(Am).max() * np.abs(x_d).max()))
+            del Am
+            best = float(np.min(ms_d[1:])) if len(ms_d) > 1 else float(ms_d[0])
+            out["dense_valued_S"] = {"workload": f"random fully dense SPD matrix, n = {nn} ({(nn + NB - 1) // NB} tile columns), the headline's task list",
+                                     "rc": rc_d, "solve_ms_per_rep": [round(float(v), 3) for v in ms_d], "solve_ms": round(best, 3),
+                                     "k_chol_flow_ms": round(fms, 4), "scaled_residual": resid,
+                                     "frac": round(fgf * 1e9 / (fms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if fms > 0 else None,
+                                     "frac_useful": round(nn ** 3 / 3.0 / (fms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if fms > 0 else None,
+                                     "whole_solve_frac_useful": round(nn ** 3 / 3.0 / (best * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+                                     "headline_scene_solve_ms": phases["solve"]}
+        except Exception as exc:
+            out["dense_valued_S"] = {"error": repr(exc)}
     if world == 1 and rank == 0:
         if not args.no_end_to_end:
             # The drop-in boundary itself at the headline size: dense vmask (n*m bytes) and host arrays in, cameras / points out,

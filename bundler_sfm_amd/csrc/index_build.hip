@@ -184,6 +184,47 @@ __global__ void k_launch_order(int ntasks, int nwg, const SchurTask* __restrict_
     launch[slot] = tk;
 }
 
+// ---- row-wise Schur kernel (round 5; schur_rows.h has the plan, schur.hip.h the kernel) --------------------------------------------
+// stage B: one thread per candidate visit (dense block b, segment s of camera j): the triples of b whose j-side record is in s
+__global__ void k_row_visits(int nvisits, int nblk, int L, const int* __restrict__ visbase, const int* __restrict__ blk_start,
+                             const int* __restrict__ blk_j, const int* __restrict__ camptr, const int2* __restrict__ triples,
+                             int* __restrict__ vis_lo, int* __restrict__ vis_cnt)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nvisits) return;
+    int lo = 0, hi = nblk;                           // block of visit v: last b with visbase[b] <= v (sparse blocks have empty ranges)
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (visbase[mid + 1] <= v) lo = mid + 1; else hi = mid; }
+    const int b = lo, s = v - visbase[b];
+    const int r0 = camptr[blk_j[b]] + s * L;
+    int first = 0, cnt = 0;
+    row_visit_range(blk_start[b], blk_start[b + 1], r0, r0 + L, [&](int t) { return triples[t].x; }, first, cnt);
+    vis_lo[v] = first; vis_cnt[v] = cnt;
+}
+
+// slots k_schur_assemble / k_schur_pack add for block b: the row pieces of a dense block, the tasks of a sparse one
+__global__ void k_blk_ranges(int nblk, int ntasks, const int* __restrict__ blk_task0, const int* __restrict__ blk_row0, int2* __restrict__ range)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk) return;
+    if (blk_row0 && blk_row0[b + 1] > blk_row0[b]) range[b] = make_int2(ntasks + blk_row0[b], ntasks + blk_row0[b + 1]);
+    else range[b] = make_int2(blk_task0[b], blk_task0[b + 1]);
+}
+
+// launch list of the task kernel when some blocks went to the row kernel: their tasks become padding
+__global__ void k_mask_tasks(int nslots, int nblk, const SchurTask* __restrict__ tasks, const int* __restrict__ blk_task0,
+                             const int* __restrict__ blk_row0, SchurTask* __restrict__ out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nslots) return;
+    SchurTask tk = tasks[t];
+    if (tk.out >= 0) {
+        int lo = 0, hi = nblk;                       // block of slot tk.out: last b with blk_task0[b] <= out (every block has >= 1 task)
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (blk_task0[mid + 1] <= tk.out) lo = mid + 1; else hi = mid; }
+        if (blk_row0[lo + 1] > blk_row0[lo]) { tk.start = 0; tk.count = 0; tk.diag = 0; tk.out = -1; }
+    }
+    out[t] = tk;
+}
+
 // Temporaries of one build come from the device's stream-ordered memory pool (hipMallocAsync): the pool keeps what it is given
 // back (release threshold = unlimited, set once), so the ~0.9 GB of sort buffers cost an allocation only on the FIRST run_sfm
 // call of a process -- an incremental reconstruction calls run_sfm hundreds of times.  Freed on every exit path.
@@ -238,11 +279,33 @@ struct EventPair {
 // what a build hands to its caller comes from the problems' block cache (devcache.h): the caller releases it with dev_free
 template <typename T> hipError_t keep(T** p, size_t count) { return bsfm::dev_alloc(reinterpret_cast<void**>(p), std::max<size_t>(count, 1) * sizeof(T)); }
 
+// breadth-first numbering of the free cameras in the co-visibility graph (components contiguous, neighbours close)
+void bfs_rank(int mm2, int mcon, const std::vector<int>& bj, const std::vector<int>& bk, std::vector<int>& rank)
+{
+    const int nblk = (int)bj.size();
+    rank.assign((size_t)mm2, 0);
+    std::vector<int> adj_ptr((size_t)mm2 + 1, 0);
+    for (int b = 0; b < nblk; ++b) { const int a = bj[b] - mcon, c = bk[b] - mcon; if (a != c) { ++adj_ptr[a + 1]; ++adj_ptr[c + 1]; } }
+    for (int j = 0; j < mm2; ++j) adj_ptr[j + 1] += adj_ptr[j];
+    std::vector<int> adj((size_t)adj_ptr[mm2]), fill(adj_ptr.begin(), adj_ptr.end() - 1);
+    for (int b = 0; b < nblk; ++b) { const int a = bj[b] - mcon, c = bk[b] - mcon; if (a != c) { adj[fill[a]++] = c; adj[fill[c]++] = a; } }
+    std::vector<char> seen((size_t)mm2, 0);
+    std::vector<int> q; q.reserve((size_t)mm2);
+    for (int s0 = 0; s0 < mm2; ++s0) {
+        if (seen[s0]) continue;
+        seen[s0] = 1; q.push_back(s0);
+        for (size_t h = q.size() - 1; h < q.size(); ++h)
+            for (int e = adj_ptr[q[h]]; e < adj_ptr[q[h] + 1]; ++e) if (!seen[adj[e]]) { seen[adj[e]] = 1; q.push_back(adj[e]); }
+    }
+    for (int p = 0; p < mm2; ++p) rank[q[p]] = p;
+}
+
 template <typename KeyT>
 int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int* d_colidx, const long long* d_toff, long long total,
                 int order_mode, DeviceIndex& ix, hipStream_t st)
 {
     const int mm = m - mcon;
+    std::vector<int> rank;                  // breadth-first numbering of the free cameras (clustered launch order, row plan)
     // a problem whose Jacobian records (272 bytes per observation) fit one XCD's L2 needs no launch order at all: block order, no task sort
     if (order_mode == SCHUR_ORDER_CLUSTERED && (size_t)nvis * 272u <= (size_t)(4u << 20)) order_mode = SCHUR_ORDER_BLOCK;
     Scratch tmp(st);
@@ -252,7 +315,9 @@ int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int
     if (total == 0) {
         ix.ntasks = ix.nblk = ix.nslots = 0;
         IX_OK(keep(&ix.tasks, 1)); IX_OK(keep(&ix.blk_j, 1)); IX_OK(keep(&ix.blk_k, 1)); IX_OK(keep(&ix.blk_task0, 1));
+        IX_OK(keep(&ix.blk_range, 1));
         IX_OK(hipMemsetAsync(ix.blk_task0, 0, sizeof(int), st));
+        ix.tasks_launch = ix.tasks;
         return 0;
     }
     KeyT *keys_in = nullptr, *keys_out = nullptr; unsigned long long* vals_in = nullptr;
@@ -334,23 +399,7 @@ int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int
             // co-visibility graph (components contiguous, neighbours close) -- (slice, lower camera, higher camera).
             IX_OK(hipStreamSynchronize(st));
             const int mm2 = m - mcon;
-            std::vector<int> rank((size_t)mm2, 0);
-            {
-                std::vector<int> adj_ptr((size_t)mm2 + 1, 0);
-                for (int b = 0; b < nblk; ++b) { const int a = ix.h_blk_j[b] - mcon, c = ix.h_blk_k[b] - mcon; if (a != c) { ++adj_ptr[a + 1]; ++adj_ptr[c + 1]; } }
-                for (int j = 0; j < mm2; ++j) adj_ptr[j + 1] += adj_ptr[j];
-                std::vector<int> adj((size_t)adj_ptr[mm2]), fill(adj_ptr.begin(), adj_ptr.end() - 1);
-                for (int b = 0; b < nblk; ++b) { const int a = ix.h_blk_j[b] - mcon, c = ix.h_blk_k[b] - mcon; if (a != c) { adj[fill[a]++] = c; adj[fill[c]++] = a; } }
-                std::vector<char> seen((size_t)mm2, 0);
-                std::vector<int> q; q.reserve((size_t)mm2);
-                for (int s0 = 0; s0 < mm2; ++s0) {
-                    if (seen[s0]) continue;
-                    seen[s0] = 1; q.push_back(s0);
-                    for (size_t h = q.size() - 1; h < q.size(); ++h)
-                        for (int e = adj_ptr[q[h]]; e < adj_ptr[q[h] + 1]; ++e) if (!seen[adj[e]]) { seen[adj[e]] = 1; q.push_back(adj[e]); }
-                }
-                for (int p = 0; p < mm2; ++p) rank[q[p]] = p;
-            }
+            bfs_rank(mm2, mcon, ix.h_blk_j, ix.h_blk_k, rank);
             int slices = 1;
             for (int b = 0; b < nblk; ++b) slices = std::max(slices, h_ntask[b]);
             slices = std::min(slices, 4096);
@@ -374,6 +423,53 @@ int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int
         IX_OK(keep(&ix.tasks, (size_t)ix.nslots));
         hipLaunchKernelGGL(k_launch_order, dim3(grid_for((size_t)ix.nslots, 256)), dim3(256), 0, st, ntasks, nwg, tasks, ord, ix.tasks);
     }
+    IX_OK(hipStreamSynchronize(st));
+    // ---- round 5: plan of the row kernel for the dense blocks (schur_rows.h), slot ranges per block, launch list of the task kernel
+    ix.tasks_launch = ix.tasks;
+    int dense_min = 0;
+    const int L = schur_row_config(nvis, &dense_min);
+    if (L > 0 && nblk > 0) {
+        RowPlanParams prm; prm.L = L; prm.dense_min = dense_min;
+        std::vector<int> h_counts((size_t)nblk), h_camptr((size_t)m + 1);
+        IX_OK(hipMemcpyAsync(h_counts.data(), counts, (size_t)nblk * sizeof(int), hipMemcpyDeviceToHost, st));
+        IX_OK(hipMemcpyAsync(h_camptr.data(), ix.camptr, ((size_t)m + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+        IX_OK(hipStreamSynchronize(st));
+        RowPlanA pa;
+        row_plan_stage_a(m, mcon, ix.h_blk_j, h_counts, h_camptr, prm, pa);
+        if (pa.nvisits > 0) {
+            int *d_visbase = nullptr, *d_lo = nullptr, *d_cnt = nullptr;
+            IX_OK(tmp.alloc(&d_visbase, (size_t)nblk + 1)); IX_OK(tmp.alloc(&d_lo, (size_t)pa.nvisits)); IX_OK(tmp.alloc(&d_cnt, (size_t)pa.nvisits));
+            IX_OK(hipMemcpyAsync(d_visbase, pa.visbase.data(), ((size_t)nblk + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_row_visits, dim3(grid_for((size_t)pa.nvisits, 256)), dim3(256), 0, st, pa.nvisits, nblk, L, d_visbase, blk_start,
+                               ix.blk_j, ix.camptr, ix.triples, d_lo, d_cnt);
+            std::vector<int> h_lo((size_t)pa.nvisits), h_cnt((size_t)pa.nvisits);
+            IX_OK(hipMemcpyAsync(h_lo.data(), d_lo, (size_t)pa.nvisits * sizeof(int), hipMemcpyDeviceToHost, st));
+            IX_OK(hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)pa.nvisits * sizeof(int), hipMemcpyDeviceToHost, st));
+            IX_OK(hipStreamSynchronize(st));
+            if (rank.empty()) bfs_rank(mm, mcon, ix.h_blk_j, ix.h_blk_k, rank);
+            RowPlan plan;
+            row_plan_stage_c(m, mcon, ix.h_blk_j, ix.h_blk_k, h_camptr, prm, pa, h_lo, h_cnt, rank, ntasks, plan);
+            if (!plan.wgs.empty()) {
+                ix.n_row_wgs = (int)plan.wgs.size(); ix.n_row_pieces = (int)plan.pieces.size(); ix.n_row_slots = plan.nslots;
+                ix.row_L = L; ix.n_row_blocks = pa.ndense; ix.row_triples = plan.triples;
+                IX_OK(keep(&ix.row_wgs, plan.wgs.size())); IX_OK(keep(&ix.row_pieces, plan.pieces.size())); IX_OK(keep(&ix.blk_row0, (size_t)nblk + 1));
+                IX_OK(hipMemcpyAsync(ix.row_wgs, plan.wgs.data(), plan.wgs.size() * sizeof(RowWG), hipMemcpyHostToDevice, st));
+                IX_OK(hipMemcpyAsync(ix.row_pieces, plan.pieces.data(), plan.pieces.size() * sizeof(RowPiece), hipMemcpyHostToDevice, st));
+                IX_OK(hipMemcpyAsync(ix.blk_row0, plan.blk_row0.data(), ((size_t)nblk + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+                if (plan.triples == total) ix.tasks_launch = nullptr;            // every block is dense: the task kernel has nothing to do
+                else {
+                    SchurTask* masked = nullptr;
+                    IX_OK(keep(&masked, (size_t)ix.nslots));
+                    ix.tasks_launch = masked;
+                    hipLaunchKernelGGL(k_mask_tasks, dim3(grid_for((size_t)ix.nslots, 256)), dim3(256), 0, st, ix.nslots, nblk, ix.tasks, ix.blk_task0,
+                                       ix.blk_row0, masked);
+                }
+                IX_OK(hipStreamSynchronize(st));          // the plan's host vectors were sources of asynchronous copies
+            }
+        }
+    }
+    IX_OK(keep(&ix.blk_range, (size_t)nblk));
+    hipLaunchKernelGGL(k_blk_ranges, dim3(grid_for((size_t)nblk, 256)), dim3(256), 0, st, nblk, ntasks, ix.blk_task0, ix.blk_row0, ix.blk_range);
     IX_OK(hipStreamSynchronize(st));          // temporaries are freed when `tmp` goes out of scope
     return 0;
 }
@@ -548,7 +644,8 @@ int gather_kept_device(int n, const int* d_remap, int width_bytes, const void* s
 void free_index_device(DeviceIndex& ix)
 {
     void* ptrs[] = { ix.obs_pt, ix.camptr, ix.camobs, ix.campos, ix.cam_pt, ix.cam_cam, ix.triples, ix.tri_pt, ix.tasks,
-                     ix.blk_j, ix.blk_k, ix.blk_task0 };
+                     ix.blk_j, ix.blk_k, ix.blk_task0, ix.row_wgs, ix.row_pieces, ix.blk_row0, ix.blk_range,
+                     ix.tasks_launch != ix.tasks ? (void*)ix.tasks_launch : nullptr };
     (void)hipDeviceSynchronize();
     for (void* p : ptrs) bsfm::dev_free(p, true);
     ix = DeviceIndex();
@@ -619,6 +716,22 @@ int build_index_device(int n, int m, int mcon, int nvis, const int* d_rowptr, co
         if (e0 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ix.build_ms = ms;
     } else IX_OK(hipStreamSynchronize(st));
     return 0;
+}
+
+int schur_row_config(int nvis, int* dense_min_out)
+{
+    // read at every problem_create (not cached: the tests switch the row kernel on and off inside one process)
+    const char* e = getenv("BSFM_SCHUR_ROWS");
+    const int mode = !e ? 2 : (!strcmp(e, "0") ? 0 : (!strcmp(e, "1") ? 1 : 2));
+    e = getenv("BSFM_SCHUR_ROW_L");
+    int L = e ? atoi(e) : 128;
+    L = std::min(ROW_LMAX, (std::max(16, std::min(ROW_LMAX, L)) + 15) / 16 * 16);
+    e = getenv("BSFM_SCHUR_ROW_MIN");
+    if (dense_min_out) *dense_min_out = std::max(1, e ? atoi(e) : 24);
+    // auto: the row kernel pays once the Jacobian records no longer fit one XCD's L2 (below that the task kernel's gathers are L2 hits
+    // and a problem is a handful of launches whose fixed costs matter more)
+    if (mode == 0 || (mode == 2 && (size_t)nvis * 272u <= (size_t)(4u << 20))) return -1;
+    return L;
 }
 
 int schur_chunk()

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void k_schur_prep(int nvis, const int* __restr
 // S_jk = [j==k](U_j + mu I) - sum_tasks partial ; mirrored into S_kj (sba_levmar.c:1274-1316).
 template <int CNP>
 __global__ __launch_bounds__(128) void k_schur_assemble(int nblk, const int* __restrict__ blk_j, const int* __restrict__ blk_k,
-        const int* __restrict__ blk_task0, const double* __restrict__ partials, const double* __restrict__ epart,
+        const int2* __restrict__ blk_range, const double* __restrict__ partials, const double* __restrict__ epart,
         const double* __restrict__ U, double mu, int mcon, double* __restrict__ S, int ld, double* __restrict__ E,
         const int* __restrict__ spos)
 {
@@ -427,16 +427,17 @@ __global__ __launch_bounds__(128) void k_schur_assemble(int nblk, const int* __r
     if (b >= nblk) return;
     const int j = blk_j[b], k = blk_k[b];
     const int pj = spos ? spos[j - mcon] : j - mcon, pk = spos ? spos[k - mcon] : k - mcon;
+    const int2 sl = blk_range[b];               // the block's slots: tasks of k_schur_tasks or pieces of k_schur_rows (index_build.hip)
     if (j == k && threadIdx.x >= CNP * CNP && threadIdx.x < CNP * CNP + CNP) {   // e_j -= this block's tasks (E was set to ea by k_rhs_init)
         const int q = threadIdx.x - CNP * CNP;
         double se = 0.0;
-        for (int t = blk_task0[b]; t < blk_task0[b + 1]; ++t) se += epart[(size_t)t * CNP + q];
+        for (int t = sl.x; t < sl.y; ++t) se += epart[(size_t)t * CNP + q];
         E[(size_t)pj * CNP + q] -= se;
     }
     if (threadIdx.x >= CNP * CNP) return;
     const int row = threadIdx.x / CNP, col = threadIdx.x % CNP;
     double s = 0.0;
-    for (int t = blk_task0[b]; t < blk_task0[b + 1]; ++t) s += partials[(size_t)t * CNP * CNP + threadIdx.x];
+    for (int t = sl.x; t < sl.y; ++t) s += partials[(size_t)t * CNP * CNP + threadIdx.x];
     double v = -s;
     if (j == k) { v += U[(size_t)j * CNP * CNP + threadIdx.x]; if (row == col) v += mu; }
     const size_t rj = (size_t)pj * CNP + row, ck = (size_t)pk * CNP + col;
@@ -447,20 +448,21 @@ __global__ __launch_bounds__(128) void k_schur_assemble(int nblk, const int* __r
 // Multi-GPU job: this rank's block sums go to their slot of the union structure (the buffer that is all-reduced) ...
 template <int CNP>
 __global__ __launch_bounds__(128) void k_schur_pack(int nblk, const int* __restrict__ blk_j, const int* __restrict__ blk_k,
-        const int* __restrict__ blk_task0, const double* __restrict__ partials, const double* __restrict__ epart,
+        const int2* __restrict__ blk_range, const double* __restrict__ partials, const double* __restrict__ epart,
         const int* __restrict__ gidx, double* __restrict__ G, int mcon, double* __restrict__ E)
 {
     const int b = blockIdx.x;
     if (b >= nblk) return;
+    const int2 sl = blk_range[b];
     if (blk_j[b] == blk_k[b] && threadIdx.x >= CNP * CNP && threadIdx.x < CNP * CNP + CNP) {
         const int q = threadIdx.x - CNP * CNP;
         double se = 0.0;
-        for (int t = blk_task0[b]; t < blk_task0[b + 1]; ++t) se += epart[(size_t)t * CNP + q];
+        for (int t = sl.x; t < sl.y; ++t) se += epart[(size_t)t * CNP + q];
         E[(size_t)(blk_j[b] - mcon) * CNP + q] -= se;
     }
     if (threadIdx.x >= CNP * CNP) return;
     double s = 0.0;
-    for (int t = blk_task0[b]; t < blk_task0[b + 1]; ++t) s += partials[(size_t)t * CNP * CNP + threadIdx.x];
+    for (int t = sl.x; t < sl.y; ++t) s += partials[(size_t)t * CNP * CNP + threadIdx.x];
     G[(size_t)gidx[b] * CNP * CNP + threadIdx.x] = s;
 }
 

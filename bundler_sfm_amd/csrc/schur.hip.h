@@ -183,4 +183,139 @@ __global__ __launch_bounds__(256, WPS) void k_schur_tasks(DevProblem P, const Sc
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Round 5: k_schur_rows -- the j side of every triple comes out of LDS, only the k side is gathered (plan: schur_rows.h).
+// k_schur_tasks fetches 400 bytes per triple in 16-byte chunks (25 chunks: A_ij, A_ik, C_ij || r_ij, B_ik) and is bound by the L1 path
+// of those gathers (11.4 GB per launch at 1 000 cameras / 5 M observations, 8.4 x the footprint).  208 of the 400 bytes
+// are the j side, and a point seen by d cameras has its record (i, j) gathered again for every partner k >= j.  Here a workgroup owns
+// (camera j, a segment of <= L consecutive records of j) and
+//   * streams the segment's A_ij chunks and C_ij || r_ij records ONCE into an LDS slab (contiguous in both camera-major streams:
+//     fully coalesced, no gather), row stride CNP + 4 chunks;
+//   * each of its four waves then walks its pieces -- contiguous runs of passes of the partner blocks (j, k), dealt out by the host
+//     so that the waves carry equal numbers of passes -- exactly like a task of k_schur_tasks, except that
+//       - only A_ik (CNP chunks) and B_ik (3 chunks) are gathered into registers: 12 chunks per triple instead of 25;
+//       - C_ij comes from the slab (one 16-byte LDS read per lane);
+//       - the X operand of the matrix instructions is read straight from the slab row of the triple's j-side record (the slab IS the
+//         operand layout: chunk c of a row = (A[0][c], A[1][c])), so the pass writes only the Y slab (16 rows x 256 bytes per wave).
+//     Lanes whose output row / column does not exist read a clamped chunk: D[a][b] = sum_k X[k][a] Y[k][b], so a junk operand
+//     column only reaches output entries that are never stored.
+// Partial sums go to the piece's slot; k_schur_assemble adds a block's slots in slot order (segment after segment): deterministic.
+template <int CNP>
+__global__ __launch_bounds__(256, 4) void k_schur_rows(DevProblem P, const RowWG* __restrict__ wgs, const RowPiece* __restrict__ pieces,
+        const int2* __restrict__ triples, double* __restrict__ partials, double* __restrict__ epart)
+{
+    typedef double d2_ __attribute__((ext_vector_type(2)));
+    typedef double v4d_ __attribute__((ext_vector_type(4)));
+    constexpr int ROWC = 16;                          // chunks per Y row (256 bytes)
+    constexpr int RS = CNP + 4;                       // chunks per slab row: A_ij (CNP), C_ij || r_ij (4)
+    constexpr bool THIRD = CNP > 8;
+    constexpr bool ALLC = CNP >= 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char row_dyn[];      // the slab: L x RS chunks
+    __shared__ __attribute__((aligned(16))) d2_ smy[ROW_NW][SCM_PASS * ROWC];
+    __shared__ int2 sm_tri[ROW_NW][ROW_LMAX];
+    d2_* Xs = reinterpret_cast<d2_*>(row_dyn);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    struct { int rec0, nrec, piece0; } wg;          // (the header is read field by field: indexing np[] of a by-value copy with the wave number puts it in scratch)
+    const int* hdr = reinterpret_cast<const int*>(wgs + blockIdx.x);
+    wg.rec0 = hdr[0]; wg.nrec = hdr[1]; wg.piece0 = hdr[2];
+    const d2_* Ac2 = reinterpret_cast<const d2_*>(P.Ac);
+    const d2_* Bc2 = reinterpret_cast<const d2_*>(P.Bc);
+    {   // the segment's records, both streams contiguous
+        const d2_* srcA = Ac2 + (size_t)wg.rec0 * CNP;
+        for (int c = threadIdx.x; c < wg.nrec * CNP; c += 256) { const int r = c / CNP, part = c - r * CNP; Xs[r * RS + part] = srcA[c]; }
+        const d2_* srcC = reinterpret_cast<const d2_*>(P.Cc) + (size_t)wg.rec0 * 4;
+        for (int c = threadIdx.x; c < wg.nrec * 4; c += 256) Xs[(c >> 2) * RS + CNP + (c & 3)] = srcC[c];
+    }
+    d2_* Y = smy[wave];
+    int2* tq = sm_tri[wave];
+    for (int t = lane; t < SCM_PASS * ROWC; t += 64) { const d2_ z = { 0.0, 0.0 }; Y[t] = z; }
+    __syncthreads();
+    int pc0 = wg.piece0;
+#pragma unroll
+    for (int w = 0; w < ROW_NW - 1; ++w) { const int c = hdr[3 + w]; if (w < wave) pc0 += c; }
+    const int npc = hdr[3 + wave];
+
+    const int p = lane >> 2, q = lane & 3;            // triple of the pass, lane of its quad
+    const int c0 = q + 4 * (p & 1), c1 = c0 ^ 4;      // this lane's chunks of A_ik
+    const int l0 = c0 < CNP ? c0 : CNP - 1, l1 = c1 < CNP ? c1 : CNP - 1;
+    const int kk = lane >> 4, oi = lane & 15;         // matrix-operand role: reduction slot, output row / column
+    const int xo = oi < CNP ? oi : CNP - 1;           // clamped operand chunk of the slab row
+
+    for (int pi = 0; pi < npc; ++pi) {
+        const RowPiece tk = pieces[pc0 + pi];
+        const bool diag = tk.diag != 0;
+        // the piece's triples: .x becomes the slab row of the j-side record
+        for (int t = lane; t < tk.count; t += 64) { int2 ab = triples[tk.start + t]; ab.x -= wg.rec0; tq[t] = ab; }
+        v4d_ acc0 = { 0.0, 0.0, 0.0, 0.0 }, acc1 = { 0.0, 0.0, 0.0, 0.0 };
+        d2_ ak[2][3], bk[2];
+        int lj[2];
+#define BSFM_ROW_ISSUE(p0_, S_)                                                                                     \
+        {                                                                                                           \
+            const int tr_ = min((p0_) + p, tk.count - 1);                                                           \
+            const int2 ab_ = tq[tr_];                                                                               \
+            const d2_* rb_ = Ac2 + (size_t)ab_.y * CNP;                                                             \
+            ak[S_][0] = rb_[l0]; ak[S_][1] = rb_[l1];                                                               \
+            if (THIRD) ak[S_][2] = rb_[CNP - 1];                                                                    \
+            bk[S_] = Bc2[(size_t)ab_.y * 4 + min(q, 2)];                                                            \
+            lj[S_] = ab_.x;                                                                                         \
+        }
+#define BSFM_ROW_COMPUTE(p0_, S_)                                                                                   \
+        {                                                                                                           \
+            const bool live_ = (p0_) + p < tk.count;                                                                \
+            const d2_ cj_ = Xs[lj[S_] * RS + CNP + q];                  /* chunk q of C_ij || r_ij */                 \
+            int lx_[SCM_PASS / 4];                                                                                  \
+            _Pragma("unroll") for (int u = 0; u < SCM_PASS / 4; ++u) lx_[u] = tq[min((p0_) + 4 * u + kk, tk.count - 1)].x; \
+            const double C00 = quad_bcast<0>(cj_.x), C01 = quad_bcast<0>(cj_.y), C02 = quad_bcast<1>(cj_.x);        \
+            const double C10 = quad_bcast<1>(cj_.y), C11 = quad_bcast<2>(cj_.x), C12 = quad_bcast<2>(cj_.y);        \
+            const double B00 = quad_bcast<0>(bk[S_].x), B01 = quad_bcast<0>(bk[S_].y), B02 = quad_bcast<1>(bk[S_].x); \
+            const double B10 = quad_bcast<1>(bk[S_].y), B11 = quad_bcast<2>(bk[S_].x), B12 = quad_bcast<2>(bk[S_].y); \
+            double m00 = C00 * B00 + C01 * B01 + C02 * B02, m01 = C00 * B10 + C01 * B11 + C02 * B12;                \
+            double m10 = C10 * B00 + C11 * B01 + C12 * B02, m11 = C10 * B10 + C11 * B11 + C12 * B12;                \
+            if (!live_) { m00 = 0.0; m01 = 0.0; m10 = 0.0; m11 = 0.0; }                                             \
+            d2_* yr_ = Y + p * ROWC;                                                                                \
+            if (ALLC || c0 < CNP) { const d2_ y_ = { m00 * ak[S_][0].x + m01 * ak[S_][0].y, m10 * ak[S_][0].x + m11 * ak[S_][0].y }; yr_[c0] = y_; } \
+            if (ALLC || c1 < CNP) { const d2_ y_ = { m00 * ak[S_][1].x + m01 * ak[S_][1].y, m10 * ak[S_][1].x + m11 * ak[S_][1].y }; yr_[c1] = y_; } \
+            if (THIRD && q == 0) { const d2_ y_ = { m00 * ak[S_][2].x + m01 * ak[S_][2].y, m10 * ak[S_][2].x + m11 * ak[S_][2].y }; yr_[CNP - 1] = y_; } \
+            if (diag && q == 3) { const d2_ r_ = { live_ ? cj_.x : 0.0, live_ ? cj_.y : 0.0 }; yr_[CNP] = r_; }     \
+            /* same wave: LDS operations complete in order, the reads below see the stores above */                \
+            d2_ xa_[SCM_PASS / 4], yb_[SCM_PASS / 4];                                                               \
+            _Pragma("unroll") for (int u = 0; u < SCM_PASS / 4; ++u) { xa_[u] = Xs[lx_[u] * RS + xo]; yb_[u] = Y[(4 * u + kk) * ROWC + oi]; } \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+            _Pragma("unroll") for (int u = 0; u < SCM_PASS / 4; ++u) {                                              \
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa_[u].x, yb_[u].x, acc0, 0, 0, 0);                     \
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa_[u].y, yb_[u].y, acc1, 0, 0, 0);                     \
+            }                                                                                                       \
+            asm volatile("" ::: "memory");                       /* the next pass's stores must not move above these reads */ \
+        }
+
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the triple list is in LDS
+        BSFM_ROW_ISSUE(0, 0)
+        for (int p0 = 0; p0 < tk.count; p0 += 2 * SCM_PASS) {
+            if (p0 + SCM_PASS < tk.count) BSFM_ROW_ISSUE(p0 + SCM_PASS, 1)
+            BSFM_ROW_COMPUTE(p0, 0)
+            if (p0 + SCM_PASS < tk.count) {
+                if (p0 + 2 * SCM_PASS < tk.count) BSFM_ROW_ISSUE(p0 + 2 * SCM_PASS, 0)
+                BSFM_ROW_COMPUTE(p0 + SCM_PASS, 1)
+            }
+        }
+#undef BSFM_ROW_ISSUE
+#undef BSFM_ROW_COMPUTE
+        // D[a][b]: register r of lane l holds row a = 4 r + (l >> 4), column b = l & 15
+        {
+            double* out = partials + (size_t)tk.out * CNP * CNP;
+            const int b = lane & 15;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int a = 4 * rr + (lane >> 4);
+                const double v = acc0[rr] + acc1[rr];
+                if (a < CNP) {
+                    if (b < CNP) out[a * CNP + b] = v;
+                    else if (b == CNP && diag) epart[(size_t)tk.out * CNP + a] = v;
+                }
+            }
+        }
+        asm volatile("" ::: "memory");                                   // the next piece's triple list must not overtake this piece's reads
+    }
+}
+
 }  // namespace bsfm

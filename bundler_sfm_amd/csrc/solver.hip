@@ -57,9 +57,9 @@ namespace {
 constexpr double SBA_EPSILON_SQ = 1E-12 * 1E-12;   // lib/sba-1.5/sba_levmar.c:35-36
 constexpr double SBA_ONE_THIRD = 0.3333333334;     // lib/sba-1.5/sba_levmar.c:38
 
-enum Phase { PH_JAC = 0, PH_CAMBLK, PH_PTBLK, PH_INVERT, PH_SCHUR, PH_SOLVE, PH_BACKSUB, PH_RESID, PH_COUNT };
+enum Phase { PH_JAC = 0, PH_CAMBLK, PH_PTBLK, PH_INVERT, PH_SCHUR, PH_SOLVE, PH_BACKSUB, PH_RESID, PH_SCHUR_PREP, PH_SCHUR_ROWS, PH_SCHUR_TASKS, PH_COUNT };
 const char* kPhaseNames[PH_COUNT] = { "jacobian", "cam_blocks", "point_blocks", "point_invert", "schur",
-                                      "solve", "backsub", "residual" };
+                                      "solve", "backsub", "residual", "schur_prep", "schur_rows", "schur_tasks" };
 
 // scalar block layout (device doubles)
 enum Scal { SC_COST = 0, SC_COST_TRIAL, SC_PCT, SC_CAM3 /*3*/, SC_PT_DP = 6, SC_PT_P, SC_PT_DL,
@@ -233,6 +233,11 @@ struct bsfm_problem {
     int2* d_triples = nullptr; SchurTask* d_tasks = nullptr; int* d_tri_pt = nullptr;
     int nslots = 0;                     // entries of d_tasks (launch order, padded to whole workgroups)
     int *d_blk_j = nullptr, *d_blk_k = nullptr, *d_blk_task0 = nullptr;
+    // round 5: dense blocks go through the row kernel (schur_rows.h / k_schur_rows); d_tasks_launch is the task kernel's list
+    // (== d_tasks when no block is dense, a masked copy when some are, nullptr when all are); d_blk_range = slots per block
+    RowWG* d_row_wgs = nullptr; RowPiece* d_row_pieces = nullptr; int* d_blk_row0 = nullptr; int2* d_blk_range = nullptr;
+    SchurTask* d_tasks_launch = nullptr;
+    int n_row_wgs = 0, n_row_pieces = 0, n_row_slots = 0, row_L = 0, n_row_blocks = 0; long long row_triples = 0;
     // multi-GPU exchange of the reduced camera system: the UNION over ranks of the non-empty blocks S_jk (j <= k),
     // one cnp x cnp sum per block, is what crosses xGMI -- not the dense (9m)^2 matrix
     std::vector<int> h_blk_j, h_blk_k;
@@ -274,6 +279,7 @@ void free_all(bsfm_problem* pb)
                      pb->d_dp, pb->d_camtab, pb->d_camtab_trial, pb->d_e, pb->d_hx, pb->d_U,
                      pb->d_V, pb->d_Vinv, pb->d_eb, pb->d_S, pb->d_E, pb->d_partials, pb->d_epart, pb->d_campart, pb->d_red, pb->d_scal, pb->d_mixed,
                      pb->d_triples, pb->d_tri_pt, pb->d_tasks, pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0,
+                     pb->d_row_wgs, pb->d_row_pieces, pb->d_blk_row0, pb->d_blk_range, pb->d_tasks_launch != pb->d_tasks ? (void*)pb->d_tasks_launch : nullptr,
                      pb->d_gidx, pb->d_gblk_j, pb->d_gblk_k, pb->d_G, pb->d_spos, pb->d_xperm };
     for (void* p : ptrs) bsfm::dev_free(p, true);          // bsfm_problem_destroy has synchronised the device
     if (pb->h_scal) (void)hipHostFree(pb->h_scal);
@@ -295,13 +301,20 @@ int adopt_index(bsfm_problem* pb, DeviceIndex& ix)
     pb->d_triples = ix.triples; pb->d_tri_pt = ix.tri_pt; pb->d_tasks = ix.tasks;
     pb->d_blk_j = ix.blk_j; pb->d_blk_k = ix.blk_k; pb->d_blk_task0 = ix.blk_task0;
     pb->ntriples = ix.ntriples; pb->ntasks = ix.ntasks; pb->nblk = ix.nblk; pb->nslots = ix.nslots;
+    pb->d_row_wgs = ix.row_wgs; pb->d_row_pieces = ix.row_pieces; pb->d_blk_row0 = ix.blk_row0; pb->d_blk_range = ix.blk_range;
+    pb->d_tasks_launch = ix.tasks_launch;
+    pb->n_row_wgs = ix.n_row_wgs; pb->n_row_pieces = ix.n_row_pieces; pb->n_row_slots = ix.n_row_slots; pb->row_L = ix.row_L;
+    pb->n_row_blocks = ix.n_row_blocks; pb->row_triples = ix.row_triples;
     pb->h_blk_j.swap(ix.h_blk_j); pb->h_blk_k.swap(ix.h_blk_k);
     pb->index_build_ms = ix.build_ms;
     ix = DeviceIndex();                                  // ownership moved: free_all releases the arrays
     if (pb->mot) return 0;
     if (pb->world == 1 && setup_components(pb, pb->h_blk_j, pb->h_blk_k)) return BSFM_ERROR;   // world > 1: after the block-union exchange
-    HIP_OK(dmalloc(&pb->d_partials, (size_t)pb->ntasks * pb->cnp * pb->cnp));
-    HIP_OK(dmalloc(&pb->d_epart, (size_t)pb->ntasks * pb->cnp));
+    HIP_OK(dmalloc(&pb->d_partials, ((size_t)pb->ntasks + pb->n_row_slots) * pb->cnp * pb->cnp));      // task slots, then row-piece slots
+    HIP_OK(dmalloc(&pb->d_epart, ((size_t)pb->ntasks + pb->n_row_slots) * pb->cnp));
+    if (pb->opt.verbose >= 2 && pb->n_row_wgs > 0)
+        printf("[bsfm] Schur complement: %d of %d blocks (%lld of %d triples) through the row kernel: %d workgroups, %d pieces, segments of %d records\n",
+               pb->n_row_blocks, pb->nblk, pb->row_triples, pb->ntriples, pb->n_row_wgs, pb->n_row_pieces, pb->row_L);
     return 0;
 }
 
@@ -659,19 +672,33 @@ int compute_schur(bsfm_problem* pb, double mu)
                            lead, pb->d_ea, Edst, packed ? (const int*)nullptr : spos, cnp);     // (packed: E travels in the natural numbering)
     if (pb->ntasks > 0) {
         // C_ij = B_ij V*_i^-1 || C_ij eb_i for this attempt's mu, then the task kernel (schur.hip.h)
+        ph_begin(pb, PH_SCHUR_PREP);
         hipLaunchKernelGGL(k_schur_prep, dim3(grid_for(4 * (size_t)P.nvis, 256)), dim3(256), 0, pb->stream, P.nvis, pb->d_obs_pt, pb->d_campos, pb->d_Bc, pb->d_Vinv, pb->d_eb, pb->d_Cc);
+        ph_end(pb, PH_SCHUR_PREP);
         static const int wps = [] { const char* e = getenv("BSFM_SCHUR_WPS"); const int v = e ? atoi(e) : 4; return v < 2 ? 2 : (v > 4 ? 4 : v); }();
-        const dim3 sg((pb->nslots + 3) / 4);
-        if (wps == 2) { DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks<C, 2>), sg, dim3(256), 0, pb->stream, P, pb->d_tasks, pb->nslots, pb->d_triples, pb->d_partials, pb->d_epart)); }
-        else if (wps == 4) { DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks<C, 4>), sg, dim3(256), 0, pb->stream, P, pb->d_tasks, pb->nslots, pb->d_triples, pb->d_partials, pb->d_epart)); }
-        else { DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks<C, 3>), sg, dim3(256), 0, pb->stream, P, pb->d_tasks, pb->nslots, pb->d_triples, pb->d_partials, pb->d_epart)); }
+        ph_begin(pb, PH_SCHUR_ROWS);
+        if (pb->n_row_wgs > 0) {      // dense blocks: the j side from an LDS slab, one workgroup per (camera, segment of its records)
+            const size_t slab = (size_t)pb->row_L * (cnp + 4) * 16;
+            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_rows<C>), dim3(pb->n_row_wgs), dim3(256), slab, pb->stream, P, pb->d_row_wgs,
+                                                  pb->d_row_pieces, pb->d_triples, pb->d_partials, pb->d_epart));
+        }
+        ph_end(pb, PH_SCHUR_ROWS);
+        ph_begin(pb, PH_SCHUR_TASKS);
+        if (pb->d_tasks_launch) {     // sparse blocks (all blocks when the row kernel is off): one wave per task, both sides gathered
+            const SchurTask* tl = pb->d_tasks_launch;
+            const dim3 sg((pb->nslots + 3) / 4);
+            if (wps == 2) { DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks<C, 2>), sg, dim3(256), 0, pb->stream, P, tl, pb->nslots, pb->d_triples, pb->d_partials, pb->d_epart)); }
+            else if (wps == 4) { DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks<C, 4>), sg, dim3(256), 0, pb->stream, P, tl, pb->nslots, pb->d_triples, pb->d_partials, pb->d_epart)); }
+            else { DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks<C, 3>), sg, dim3(256), 0, pb->stream, P, tl, pb->nslots, pb->d_triples, pb->d_partials, pb->d_epart)); }
+        }
+        ph_end(pb, PH_SCHUR_TASKS);
         if (packed) {
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_pack<C>), dim3(pb->nblk), dim3(128), 0, pb->stream, pb->nblk,
-                                                  pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0, pb->d_partials, pb->d_epart,
+                                                  pb->d_blk_j, pb->d_blk_k, pb->d_blk_range, pb->d_partials, pb->d_epart,
                                                   pb->d_gidx, pb->d_G, P.mcon, Edst));
         } else {
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_assemble<C>), dim3(pb->nblk), dim3(128), 0, pb->stream, pb->nblk,
-                                                  pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0, pb->d_partials, pb->d_epart,
+                                                  pb->d_blk_j, pb->d_blk_k, pb->d_blk_range, pb->d_partials, pb->d_epart,
                                                   pb->d_U, mu, P.mcon, pb->d_S, pb->ld, Edst, spos));
         }
     }
@@ -1066,6 +1093,63 @@ int bsfm_problem_export_schur(bsfm_problem_t* pb, int* triples, int* tri_pt, int
     return ok ? 0 : BSFM_ERROR;
 }
 
+// round 5: the plan of the row kernel as the problem holds it (tests/test_index.py compares it with the host restatement)
+int bsfm_problem_row_sizes(const bsfm_problem_t* pb, int* nwg, int* npieces, int* nslots, int* L)
+{
+    if (nwg) *nwg = pb->n_row_wgs;
+    if (npieces) *npieces = pb->n_row_pieces;
+    if (nslots) *nslots = pb->n_row_slots;
+    if (L) *L = pb->row_L;
+    return 0;
+}
+
+// wgs: 8 ints per workgroup (RowWG); pieces: 4 ints (RowPiece); blk_row0: nblk + 1 (zeros when the row kernel is off); blk_range: 2 ints
+// per block; tasks_launch: 4 ints per task slot (what k_schur_tasks is given; out = -1 everywhere when it is not launched at all)
+int bsfm_problem_export_rows(bsfm_problem_t* pb, int* wgs, int* pieces, int* blk_row0, int* blk_range, int* tasks_launch)
+{
+    if (pb->mot) return BSFM_ERROR;
+    HIP_OK(hipStreamSynchronize(pb->stream));
+    auto down = [](void* dst, const void* src, size_t bytes) { return !dst || bytes == 0 || !src || hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess; };
+    if (blk_row0 && !pb->d_blk_row0) memset(blk_row0, 0, ((size_t)pb->nblk + 1) * sizeof(int));
+    if (tasks_launch && !pb->d_tasks_launch) for (int t = 0; t < pb->nslots; ++t) { tasks_launch[4 * t] = 0; tasks_launch[4 * t + 1] = 0; tasks_launch[4 * t + 2] = 0; tasks_launch[4 * t + 3] = -1; }
+    const bool ok = down(wgs, pb->d_row_wgs, (size_t)pb->n_row_wgs * sizeof(RowWG)) && down(pieces, pb->d_row_pieces, (size_t)pb->n_row_pieces * sizeof(RowPiece)) &&
+                    down(blk_row0, pb->d_blk_row0, ((size_t)pb->nblk + 1) * sizeof(int)) && down(blk_range, pb->d_blk_range, (size_t)pb->nblk * sizeof(int2)) &&
+                    down(tasks_launch, pb->d_tasks_launch, (size_t)pb->nslots * sizeof(SchurTask));
+    return ok ? 0 : BSFM_ERROR;
+}
+
+// Host only (no device needed): the plan of the row kernel (schur_rows.h) for a block list -- stage B replayed with the same search
+// routine the device kernel uses.  tri_x: j-side record of every triple, block after block (blk_start: nblk + 1); rank: breadth-first
+// numbers of the free cameras or null.  Call with null outputs for the sizes; returns 0 or -1 (capacity too small).
+int bsfm_schur_row_plan(int m, int mcon, int nblk, const int* blk_j, const int* blk_k, const int* blk_start, const int* tri_x, const int* camptr,
+                        const int* rank, int L, int dense_min, int slot_base, int* nwg, int* npieces, int* nslots,
+                        int* wgs_out, int cap_wgs, int* pieces_out, int cap_pieces, int* blk_row0_out)
+{
+    if (m <= 0 || nblk < 0 || L < 16 || L > ROW_LMAX || (L & 15)) return -1;
+    RowPlanParams prm; prm.L = L; prm.dense_min = std::max(1, dense_min);
+    std::vector<int> bj(blk_j, blk_j + nblk), bk(blk_k, blk_k + nblk), cp(camptr, camptr + m + 1), counts((size_t)nblk);
+    for (int b = 0; b < nblk; ++b) counts[b] = blk_start[b + 1] - blk_start[b];
+    RowPlanA pa;
+    row_plan_stage_a(m, mcon, bj, counts, cp, prm, pa);
+    std::vector<int> lo((size_t)pa.nvisits), cnt((size_t)pa.nvisits);
+    for (int b = 0; b < nblk; ++b)
+        for (int v = pa.visbase[b]; v < pa.visbase[b + 1]; ++v) {
+            const int r0 = cp[bj[b]] + (v - pa.visbase[b]) * L;
+            row_visit_range(blk_start[b], blk_start[b + 1], r0, r0 + L, [&](int t) { return tri_x[t]; }, lo[v], cnt[v]);
+        }
+    std::vector<int> rk;
+    if (rank) rk.assign(rank, rank + (m - mcon));
+    RowPlan plan;
+    row_plan_stage_c(m, mcon, bj, bk, cp, prm, pa, lo, cnt, rk, slot_base, plan);
+    if (nwg) *nwg = (int)plan.wgs.size();
+    if (npieces) *npieces = (int)plan.pieces.size();
+    if (nslots) *nslots = plan.nslots;
+    if (wgs_out) { if ((int)plan.wgs.size() > cap_wgs) return -1; memcpy(wgs_out, plan.wgs.data(), plan.wgs.size() * sizeof(RowWG)); }
+    if (pieces_out) { if ((int)plan.pieces.size() > cap_pieces) return -1; memcpy(pieces_out, plan.pieces.data(), plan.pieces.size() * sizeof(RowPiece)); }
+    if (blk_row0_out) memcpy(blk_row0_out, plan.blk_row0.data(), ((size_t)nblk + 1) * sizeof(int));
+    return 0;
+}
+
 int bsfm_schur_chunk(void) { return schur_chunk(); }
 int bsfm_problem_cnp(const bsfm_problem_t* pb) { return pb->cnp; }
 int bsfm_problem_num_cameras(const bsfm_problem_t* pb) { return pb->P.m; }
@@ -1077,6 +1161,12 @@ double bsfm_lm_last_kernel_ms(const bsfm_problem_t* pb, const char* phase)
 {
     for (int i = 0; i < PH_COUNT; ++i)
         if (!strcmp(phase, kPhaseNames[i])) return pb->ph_cnt[i] ? pb->ph_ms[i] / pb->ph_cnt[i] : -1.0;
+    // row kernel of the Schur complement (schur_rows.h): workgroups, pieces, dense blocks, triples it covers, segment length
+    if (!strcmp(phase, "row_wgs")) return (double)pb->n_row_wgs;
+    if (!strcmp(phase, "row_pieces")) return (double)pb->n_row_pieces;
+    if (!strcmp(phase, "row_blocks")) return (double)pb->n_row_blocks;
+    if (!strcmp(phase, "row_triples")) return (double)pb->row_triples;
+    if (!strcmp(phase, "row_L")) return (double)pb->row_L;
     if (!strcmp(phase, "groups")) return pb->comps.active ? (double)pb->comps.ncomp : 0.0;   // group-by-group reduced solve in use?
     if (!strcmp(phase, "potrf")) return pb->potrf.cnt ? pb->potrf.ms / pb->potrf.cnt : -1.0;
     if (!strcmp(phase, "syrk")) return pb->potrf.syrk_cnt ? pb->potrf.syrk_ms / (double)pb->potrf.syrk_cnt : -1.0;
@@ -1619,7 +1709,7 @@ int bsfm_chol_flow_schedule(int nblk, const int* last, int np_max, int slots, vo
     if (nblk <= 0) return -1;
     FlowParams prm = flow_params_from_env();
     if (np_max > 0) prm.np_max = std::min(8, np_max);
-    if (slots > 0) prm.slots = slots;
+    if (slots > 0) prm.slots = std::max(32, slots);      // fewer than 16 can never hold the 16 parts of TRSM32
     std::vector<int> lv;
     if (last) lv.assign(last, last + nblk);
     FlowSchedule sc;
@@ -1630,7 +1720,23 @@ int bsfm_chol_flow_schedule(int nblk, const int* last, int np_max, int slots, vo
     return nt;
 }
 
+static int dense_chol_solve_impl(int n, const double* A, const double* b, double* x, int backend, int reps_in, double* ms_out, double* flow_ms_out, double* flow_gflop_out);
+
 int bsfm_dense_chol_solve(int n, const double* A, const double* b, double* x, int backend)
+{
+    return dense_chol_solve_impl(n, A, b, x, backend, 0, nullptr, nullptr, nullptr);
+}
+
+// The same solve `reps` times with the device time of every repetition (ms_out[reps]: factorisation + both substitutions, HIP events
+// on the solve's stream), the mean HIP-event time of the k_chol_flow launches and the flops the library scheduled for one launch --
+// bench.py's `dense_valued_S` leg: the headline task list on a matrix whose tiles all hold numbers (missing #5).
+int bsfm_dense_chol_solve_timed(int n, const double* A, const double* b, double* x, int backend, int reps, double* ms_out, double* flow_ms_out,
+                                double* flow_gflop_out)
+{
+    return dense_chol_solve_impl(n, A, b, x, backend, std::max(1, reps), ms_out, flow_ms_out, flow_gflop_out);
+}
+
+static int dense_chol_solve_impl(int n, const double* A, const double* b, double* x, int backend, int reps_in, double* ms_out, double* flow_ms_out, double* flow_gflop_out)
 {
     if (bsfm_device_count() <= 0) { fprintf(stderr, "[bsfm] FATAL: no usable HIP device\n"); return BSFM_ERROR; }
     if (n <= 0) return BSFM_ERROR;
@@ -1664,6 +1770,8 @@ int bsfm_dense_chol_solve(int n, const double* A, const double* b, double* x, in
         // BSFM_CHOL_REPS=n (diagnostics): solve n times (S is destroyed by a solve and uploaded again) and print the device time of each
         int reps = 1;
         if (const char* e = getenv("BSFM_CHOL_REPS")) reps = std::max(1, atoi(e));
+        if (reps_in > 0) reps = reps_in;
+        const bool timed_api = reps_in > 0;
         bool failed = false;
         for (int rep = 0; rep < reps && !failed; ++rep) {
             if (rep > 0) {
@@ -1671,17 +1779,24 @@ int bsfm_dense_chol_solve(int n, const double* A, const double* b, double* x, in
                 if (hipMemcpy2D(dS, (size_t)ld * sizeof(double), A, (size_t)n * sizeof(double), (size_t)n * sizeof(double), n, hipMemcpyHostToDevice) != hipSuccess) { failed = true; break; }
             }
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (reps > 1) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
+            if (reps > 1 || timed_api) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
             if (potrf_solve(ws, dS, ld, n, dE, dx, dinfo, st)) { failed = true; break; }
-            if (reps > 1) (void)hipEventRecord(e1, st);
+            if (e1) (void)hipEventRecord(e1, st);
             if (hipStreamSynchronize(st) != hipSuccess) { failed = true; break; }
-            if (reps > 1) {
+            if (e0 && e1) {
                 float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
-                fprintf(stderr, "[bsfm] dense_chol_solve n = %d rep %d: %.3f ms\n", n, rep, ms);
+                if (timed_api) { if (ms_out) ms_out[rep] = ms; }
+                else fprintf(stderr, "[bsfm] dense_chol_solve n = %d rep %d: %.3f ms\n", n, rep, ms);
                 (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
             }
         }
         if (failed) break;
+        if (timed_api) {
+            potrf_collect_time(ws);
+            if (ws.flow) flow_collect_time(*ws.flow);
+            if (flow_ms_out) *flow_ms_out = ws.flow && ws.flow->kern_cnt ? ws.flow->kern_ms / (double)ws.flow->kern_cnt : -1.0;
+            if (flow_gflop_out) *flow_gflop_out = ws.flow && ws.flow->kern_cnt ? (ws.flow->flops + (double)ws.flow->nblk * POTRF_NB * POTRF_NB * POTRF_NB) * 1e-9 : -1.0;
+        }
         if (hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) break;
         if (hipMemcpy(x, dx, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) break;
         rc = info;

@@ -265,6 +265,21 @@ int bsfm_schur_chunk(void);
  * e.g. before another library needs the memory. */
 void bsfm_device_cache_trim(void);
 int bsfm_problem_export_schur(bsfm_problem_t *pb, int *triples, int *tri_pt, int *blk_j, int *blk_k, int *blk_task0, int *tasks);
+/* Round 5 -- the row-wise Schur kernel (csrc/schur_rows.h; reference loop lib/sba-1.5/sba_levmar.c:1195-1302).  Blocks (j,k) with
+ * enough co-visibility triples per segment of camera j's records ("dense") are accumulated by workgroups that own (camera j, a
+ * segment of <= L consecutive camera-major records): the j side of every triple is streamed once into LDS, only the k side is
+ * gathered.  The plan as the problem holds it: wgs (8 ints each: rec0, nrec, piece0, pieces of wave 0..3, pad; launch order),
+ * pieces (4 ints each: first triple, count, diag, slot), blk_row0 (nblk + 1: row slots per block before the offset ntasks),
+ * blk_range (2 ints per block: the slots k_schur_assemble adds, in that order), tasks_launch (4 ints per task slot: what the task
+ * kernel of the sparse blocks is given).  Any pointer may be NULL. */
+int bsfm_problem_row_sizes(const bsfm_problem_t *pb, int *nwg, int *npieces, int *nslots, int *L);
+int bsfm_problem_export_rows(bsfm_problem_t *pb, int *wgs, int *pieces, int *blk_row0, int *blk_range, int *tasks_launch);
+/* The same plan computed on the HOST from a block list (no device needed; tests): tri_x = j-side record of every triple, block after
+ * block (blk_start: nblk + 1), camptr (m + 1), rank = breadth-first numbers of the free cameras or NULL.  Call with NULL outputs
+ * for the sizes.  Returns 0, or -1 (bad arguments / capacity too small). */
+int bsfm_schur_row_plan(int m, int mcon, int nblk, const int *blk_j, const int *blk_k, const int *blk_start, const int *tri_x,
+                        const int *camptr, const int *rank, int L, int dense_min, int slot_base, int *nwg, int *npieces, int *nslots,
+                        int *wgs_out, int cap_wgs, int *pieces_out, int cap_pieces, int *blk_row0_out);
 /* dense vmask -> CRS exactly as run_sfm does it (host only); returns nvis, rowptr / colidx may be NULL. */
 int bsfm_crs_from_vmask(int n, int m, const char *vmask, int *rowptr, int *colidx);
 /* The same CRS built ON THE DEVICE (what run_sfm does for masks of at least 1 MB, BSFM_VMASK_DEVICE_MIN: upload, count / scan /
@@ -314,6 +329,12 @@ int bsfm_eval_normal_equations(bsfm_problem_t *pb, double mu, double *U, double 
 /* Dense SPD solve on the device with the production Cholesky: A (n x n, symmetric, row-major, host),
  * b (n) -> x (n). Returns 0, or k>0 if the leading minor k is not positive definite (dpotrf's info). */
 int bsfm_dense_chol_solve(int n, const double *A, const double *b, double *x, int backend);
+/* The same solve `reps` times (A is uploaded again before each): ms_out[reps] = device time of every repetition (factorisation +
+ * both substitutions, HIP events on the solve's stream), *flow_ms_out = mean HIP-event time of the k_chol_flow launches,
+ * *flow_gflop_out = the flops (1e9) the library scheduled for one launch.  bench.py's `dense_valued_S` leg: the reference's
+ * dpotrf + dpotrs (lib/sba-1.5/sba_lapack.c:374-485) on a matrix whose tiles all hold numbers.  Outputs may be NULL. */
+int bsfm_dense_chol_solve_timed(int n, const double *A, const double *b, double *x, int backend, int reps, double *ms_out,
+                                double *flow_ms_out, double *flow_gflop_out);
 /* Test / diagnostic hook (no device needed): the static task order of the tile-dataflow Cholesky (csrc/chol_flow_sched.h) for a
  * system of nblk tile columns.  last[k] (NULL = dense) = last tile row of column k's envelope.  tasks_out (NULL to query the
  * count) receives 40-byte records { u8 type, np, part, nwait; u16 i, j, p0, pad; u32 sig; { u32 idx, thr } w[3] }: task types
