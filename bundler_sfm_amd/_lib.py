@@ -221,12 +221,12 @@ def _load():
     lib.bsfm_problem_schur_sizes.restype = C.c_int
     lib.bsfm_problem_export_schur.argtypes = [vp, ip, ip, ip, ip, ip, ip]
     lib.bsfm_problem_export_schur.restype = C.c_int
-    lib.bsfm_problem_row_sizes.argtypes = [vp, ip, ip, ip, ip]
+    lib.bsfm_problem_row_sizes.argtypes = [vp, ip, ip, ip, ip, ip]
     lib.bsfm_problem_row_sizes.restype = C.c_int
-    lib.bsfm_problem_export_rows.argtypes = [vp, ip, ip, ip, ip, ip]
+    lib.bsfm_problem_export_rows.argtypes = [vp, ip, ip, ip, ip, ip, ip]
     lib.bsfm_problem_export_rows.restype = C.c_int
-    lib.bsfm_schur_row_plan.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, ip, ip, ip, ip, C.c_int, C.c_int, C.c_int, ip, ip, ip,
-                                        ip, C.c_int, ip, C.c_int, ip]
+    lib.bsfm_schur_row_plan.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, ip, ip, ip, ip, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, ip, ip,
+                                        ip, C.c_int, ip, ip, C.c_int, ip]
     lib.bsfm_schur_row_plan.restype = C.c_int
     lib.bsfm_dense_chol_solve_timed.argtypes = [C.c_int, dp, dp, dp, C.c_int, C.c_int, dp, dp, dp]
     lib.bsfm_dense_chol_solve_timed.restype = C.c_int

@@ -38,6 +38,9 @@ struct DeviceIndex {
     // tests/test_index.py); tasks_launch is what the task kernel is given: the same array when no block is dense, a copy with the
     // dense blocks' tasks turned into padding (out = -1) when some are, nullptr when all are.
     RowWG* row_wgs = nullptr; RowPiece* row_pieces = nullptr; int* blk_row0 = nullptr;      // blk_row0: nblk + 1 (row slots per block, without the offset)
+    int2* row_tri = nullptr;            // the row kernel's own triple array: (slab row of the j side | ROW_DEAD on padding, record of the k side),
+                                        // workgroup after workgroup, every piece padded to whole passes; row_ntri entries
+    long long row_ntri = 0; int row_tri_max = 0;
     int2* blk_range = nullptr;          // nblk
     SchurTask* tasks_launch = nullptr;  // see above (owned unless == tasks)
     int n_row_wgs = 0, n_row_pieces = 0, n_row_slots = 0, row_L = 0, n_row_blocks = 0;
@@ -53,9 +56,9 @@ struct DeviceIndex {
 enum { SCHUR_ORDER_CLUSTERED = 0, SCHUR_ORDER_BLOCK = 1, SCHUR_ORDER_POINT = 2 };
 int build_index_device(int n, int m, int mcon, int nvis, const int* d_rowptr, const int* d_colidx, bool want_schur,
                        int order_mode, DeviceIndex& out, hipStream_t st);
-// Row-kernel switches (BSFM_SCHUR_ROWS = 0 | 1 | auto, BSFM_SCHUR_ROW_L, BSFM_SCHUR_ROW_MIN): -1 = rows off for a problem of nvis
-// observations, else the segment length L; dense_min_out = triples per segment that make a block dense.
-int schur_row_config(int nvis, int* dense_min_out);
+// Row-kernel switches (BSFM_SCHUR_ROWS = 0 | 1 | auto, BSFM_SCHUR_ROW_L, BSFM_SCHUR_ROW_MIN, BSFM_SCHUR_ROW_WGMIN, BSFM_SCHUR_ROW_TRIMAX):
+// false = rows off for a problem of nvis observations, else prm holds the plan's parameters.
+bool schur_row_config(int nvis, RowPlanParams& prm);
 void free_index_device(DeviceIndex& ix);
 
 // Growing a resident problem: merges `nadd` new observations (point, camera, x, y -- device arrays, any order) into

@@ -201,6 +201,19 @@ __global__ void k_row_visits(int nvisits, int nblk, int L, const int* __restrict
     vis_lo[v] = first; vis_cnt[v] = cnt;
 }
 
+// the row kernel's own triple array: one 64-thread block per piece copies its slice, j side as slab row, padded to whole passes
+__global__ __launch_bounds__(64) void k_row_fill(int nfill, const RowFill* __restrict__ fills, const int2* __restrict__ triples, int2* __restrict__ rtri)
+{
+    if ((int)blockIdx.x >= nfill) return;
+    const RowFill f = fills[blockIdx.x];
+    const int padded = (f.count + ROW_PASS - 1) / ROW_PASS * ROW_PASS;
+    for (int t = threadIdx.x; t < padded; t += 64) {
+        int2 e = triples[f.src + min(t, f.count - 1)];
+        e.x = (e.x - f.rec0) | (t < f.count ? 0 : ROW_DEAD);
+        rtri[(size_t)f.dst + t] = e;
+    }
+}
+
 // slots k_schur_assemble / k_schur_pack add for block b: the row pieces of a dense block, the tasks of a sparse one
 __global__ void k_blk_ranges(int nblk, int ntasks, const int* __restrict__ blk_task0, const int* __restrict__ blk_row0, int2* __restrict__ range)
 {
@@ -426,10 +439,9 @@ int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int
     IX_OK(hipStreamSynchronize(st));
     // ---- round 5: plan of the row kernel for the dense blocks (schur_rows.h), slot ranges per block, launch list of the task kernel
     ix.tasks_launch = ix.tasks;
-    int dense_min = 0;
-    const int L = schur_row_config(nvis, &dense_min);
-    if (L > 0 && nblk > 0) {
-        RowPlanParams prm; prm.L = L; prm.dense_min = dense_min;
+    RowPlanParams prm;
+    if (schur_row_config(nvis, prm) && nblk > 0) {
+        const int L = prm.L;
         std::vector<int> h_counts((size_t)nblk), h_camptr((size_t)m + 1);
         IX_OK(hipMemcpyAsync(h_counts.data(), counts, (size_t)nblk * sizeof(int), hipMemcpyDeviceToHost, st));
         IX_OK(hipMemcpyAsync(h_camptr.data(), ix.camptr, ((size_t)m + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -448,14 +460,18 @@ int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int
             IX_OK(hipStreamSynchronize(st));
             if (rank.empty()) bfs_rank(mm, mcon, ix.h_blk_j, ix.h_blk_k, rank);
             RowPlan plan;
-            row_plan_stage_c(m, mcon, ix.h_blk_j, ix.h_blk_k, h_camptr, prm, pa, h_lo, h_cnt, rank, ntasks, plan);
-            if (!plan.wgs.empty()) {
+            if (row_plan_stage_c(m, mcon, ix.h_blk_j, ix.h_blk_k, h_camptr, prm, pa, h_lo, h_cnt, rank, ntasks, plan) == 0 && !plan.wgs.empty()) {
                 ix.n_row_wgs = (int)plan.wgs.size(); ix.n_row_pieces = (int)plan.pieces.size(); ix.n_row_slots = plan.nslots;
-                ix.row_L = L; ix.n_row_blocks = pa.ndense; ix.row_triples = plan.triples;
+                ix.row_L = L; ix.n_row_blocks = pa.ndense; ix.row_triples = plan.triples; ix.row_ntri = plan.ntri; ix.row_tri_max = row_tri_max(prm);
                 IX_OK(keep(&ix.row_wgs, plan.wgs.size())); IX_OK(keep(&ix.row_pieces, plan.pieces.size())); IX_OK(keep(&ix.blk_row0, (size_t)nblk + 1));
+                IX_OK(keep(&ix.row_tri, (size_t)plan.ntri));
+                RowFill* d_fills = nullptr;
+                IX_OK(tmp.alloc(&d_fills, plan.fills.size()));
                 IX_OK(hipMemcpyAsync(ix.row_wgs, plan.wgs.data(), plan.wgs.size() * sizeof(RowWG), hipMemcpyHostToDevice, st));
                 IX_OK(hipMemcpyAsync(ix.row_pieces, plan.pieces.data(), plan.pieces.size() * sizeof(RowPiece), hipMemcpyHostToDevice, st));
                 IX_OK(hipMemcpyAsync(ix.blk_row0, plan.blk_row0.data(), ((size_t)nblk + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+                IX_OK(hipMemcpyAsync(d_fills, plan.fills.data(), plan.fills.size() * sizeof(RowFill), hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(k_row_fill, dim3((unsigned)plan.fills.size()), dim3(64), 0, st, (int)plan.fills.size(), d_fills, ix.triples, ix.row_tri);
                 if (plan.triples == total) ix.tasks_launch = nullptr;            // every block is dense: the task kernel has nothing to do
                 else {
                     SchurTask* masked = nullptr;
@@ -644,7 +660,7 @@ int gather_kept_device(int n, const int* d_remap, int width_bytes, const void* s
 void free_index_device(DeviceIndex& ix)
 {
     void* ptrs[] = { ix.obs_pt, ix.camptr, ix.camobs, ix.campos, ix.cam_pt, ix.cam_cam, ix.triples, ix.tri_pt, ix.tasks,
-                     ix.blk_j, ix.blk_k, ix.blk_task0, ix.row_wgs, ix.row_pieces, ix.blk_row0, ix.blk_range,
+                     ix.blk_j, ix.blk_k, ix.blk_task0, ix.row_wgs, ix.row_pieces, ix.blk_row0, ix.blk_range, ix.row_tri,
                      ix.tasks_launch != ix.tasks ? (void*)ix.tasks_launch : nullptr };
     (void)hipDeviceSynchronize();
     for (void* p : ptrs) bsfm::dev_free(p, true);
@@ -718,20 +734,26 @@ int build_index_device(int n, int m, int mcon, int nvis, const int* d_rowptr, co
     return 0;
 }
 
-int schur_row_config(int nvis, int* dense_min_out)
+bool schur_row_config(int nvis, RowPlanParams& prm)
 {
     // read at every problem_create (not cached: the tests switch the row kernel on and off inside one process)
     const char* e = getenv("BSFM_SCHUR_ROWS");
+    const char* const e0 = e;
     const int mode = !e ? 2 : (!strcmp(e, "0") ? 0 : (!strcmp(e, "1") ? 1 : 2));
-    e = getenv("BSFM_SCHUR_ROW_L");
-    int L = e ? atoi(e) : 128;
-    L = std::min(ROW_LMAX, (std::max(16, std::min(ROW_LMAX, L)) + 15) / 16 * 16);
-    e = getenv("BSFM_SCHUR_ROW_MIN");
-    if (dense_min_out) *dense_min_out = std::max(1, e ? atoi(e) : 24);
-    // auto: the row kernel pays once the Jacobian records no longer fit one XCD's L2 (below that the task kernel's gathers are L2 hits
-    // and a problem is a handful of launches whose fixed costs matter more)
-    if (mode == 0 || (mode == 2 && (size_t)nvis * 272u <= (size_t)(4u << 20))) return -1;
-    return L;
+    prm = RowPlanParams();
+    if ((e = getenv("BSFM_SCHUR_ROW_L"))) prm.L = atoi(e);
+    prm.L = std::min(ROW_LMAX, (std::max(16, std::min(ROW_LMAX, prm.L)) + 15) / 16 * 16);
+    if ((e = getenv("BSFM_SCHUR_ROW_MIN"))) prm.dense_min = std::max(1, atoi(e));
+    if ((e = getenv("BSFM_SCHUR_ROW_WGMIN"))) prm.wg_min = std::max(1, atoi(e));
+    if ((e = getenv("BSFM_SCHUR_ROW_TRIMAX"))) prm.tri_max = std::max(ROW_LMAX, std::min(4096, atoi(e))) / ROW_PASS * ROW_PASS;
+    // OFF unless asked for (BSFM_SCHUR_ROWS=1, or =auto: on once the Jacobian records no longer fit one XCD's L2).  Measured in round 5
+    // at 1 000 cameras / 5 M observations (profiles/r05_schur_kernels.txt): 0.95-1.05 ms for the row kernel against 0.85 ms for the
+    // task kernel -- the gathers it saves were never the bound (served from L1 AND without matrix instructions the pass loop still
+    // takes 0.63 ms: both kernels sit on a chain of LDS round trips and on VALU work that FP64 matrix instructions do not overlap
+    // with on gfx950), and its segment fill adds 0.2 ms.  Kept as a tested alternative, not as the default.
+    if (mode == 0 || !e0) return false;
+    if (mode == 2 && (size_t)nvis * 272u <= (size_t)(4u << 20)) return false;
+    return true;
 }
 
 int schur_chunk()

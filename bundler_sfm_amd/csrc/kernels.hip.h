@@ -70,8 +70,10 @@ template <int Q>
 __device__ __forceinline__ double quad_bcast_d(double v)
 {
     constexpr int ctrl = Q | (Q << 2) | (Q << 4) | (Q << 6);
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);
+    // mov_dpp with bound_ctrl: every lane of a quad permutation has a valid source, so there is no "old" value to keep -- the
+    // update_dpp(0, ...) form cost one extra v_mov_b32 per half (24 per pass of the Schur kernels)
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_max(double v)

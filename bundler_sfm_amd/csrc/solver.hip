@@ -236,6 +236,7 @@ struct bsfm_problem {
     // round 5: dense blocks go through the row kernel (schur_rows.h / k_schur_rows); d_tasks_launch is the task kernel's list
     // (== d_tasks when no block is dense, a masked copy when some are, nullptr when all are); d_blk_range = slots per block
     RowWG* d_row_wgs = nullptr; RowPiece* d_row_pieces = nullptr; int* d_blk_row0 = nullptr; int2* d_blk_range = nullptr;
+    int2* d_row_tri = nullptr; long long row_ntri = 0; int row_tri_max = 0;
     SchurTask* d_tasks_launch = nullptr;
     int n_row_wgs = 0, n_row_pieces = 0, n_row_slots = 0, row_L = 0, n_row_blocks = 0; long long row_triples = 0;
     // multi-GPU exchange of the reduced camera system: the UNION over ranks of the non-empty blocks S_jk (j <= k),
@@ -279,7 +280,7 @@ void free_all(bsfm_problem* pb)
                      pb->d_dp, pb->d_camtab, pb->d_camtab_trial, pb->d_e, pb->d_hx, pb->d_U,
                      pb->d_V, pb->d_Vinv, pb->d_eb, pb->d_S, pb->d_E, pb->d_partials, pb->d_epart, pb->d_campart, pb->d_red, pb->d_scal, pb->d_mixed,
                      pb->d_triples, pb->d_tri_pt, pb->d_tasks, pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0,
-                     pb->d_row_wgs, pb->d_row_pieces, pb->d_blk_row0, pb->d_blk_range, pb->d_tasks_launch != pb->d_tasks ? (void*)pb->d_tasks_launch : nullptr,
+                     pb->d_row_wgs, pb->d_row_pieces, pb->d_blk_row0, pb->d_blk_range, pb->d_row_tri, pb->d_tasks_launch != pb->d_tasks ? (void*)pb->d_tasks_launch : nullptr,
                      pb->d_gidx, pb->d_gblk_j, pb->d_gblk_k, pb->d_G, pb->d_spos, pb->d_xperm };
     for (void* p : ptrs) bsfm::dev_free(p, true);          // bsfm_problem_destroy has synchronised the device
     if (pb->h_scal) (void)hipHostFree(pb->h_scal);
@@ -303,6 +304,7 @@ int adopt_index(bsfm_problem* pb, DeviceIndex& ix)
     pb->ntriples = ix.ntriples; pb->ntasks = ix.ntasks; pb->nblk = ix.nblk; pb->nslots = ix.nslots;
     pb->d_row_wgs = ix.row_wgs; pb->d_row_pieces = ix.row_pieces; pb->d_blk_row0 = ix.blk_row0; pb->d_blk_range = ix.blk_range;
     pb->d_tasks_launch = ix.tasks_launch;
+    pb->d_row_tri = ix.row_tri; pb->row_ntri = ix.row_ntri; pb->row_tri_max = ix.row_tri_max;
     pb->n_row_wgs = ix.n_row_wgs; pb->n_row_pieces = ix.n_row_pieces; pb->n_row_slots = ix.n_row_slots; pb->row_L = ix.row_L;
     pb->n_row_blocks = ix.n_row_blocks; pb->row_triples = ix.row_triples;
     pb->h_blk_j.swap(ix.h_blk_j); pb->h_blk_k.swap(ix.h_blk_k);
@@ -675,21 +677,26 @@ int compute_schur(bsfm_problem* pb, double mu)
         ph_begin(pb, PH_SCHUR_PREP);
         hipLaunchKernelGGL(k_schur_prep, dim3(grid_for(4 * (size_t)P.nvis, 256)), dim3(256), 0, pb->stream, P.nvis, pb->d_obs_pt, pb->d_campos, pb->d_Bc, pb->d_Vinv, pb->d_eb, pb->d_Cc);
         ph_end(pb, PH_SCHUR_PREP);
-        static const int wps = [] { const char* e = getenv("BSFM_SCHUR_WPS"); const int v = e ? atoi(e) : 4; return v < 2 ? 2 : (v > 4 ? 4 : v); }();
+        static const int wps = [] { const char* e = getenv("BSFM_SCHUR_WPS"); const int v = e ? atoi(e) : 3; return v < 2 ? 2 : (v > 4 ? 4 : v); }();
         ph_begin(pb, PH_SCHUR_ROWS);
         if (pb->n_row_wgs > 0) {      // dense blocks: the j side from an LDS slab, one workgroup per (camera, segment of its records)
-            const size_t slab = (size_t)pb->row_L * (cnp + 4) * 16;
-            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_rows<C>), dim3(pb->n_row_wgs), dim3(256), slab, pb->stream, P, pb->d_row_wgs,
-                                                  pb->d_row_pieces, pb->d_triples, pb->d_partials, pb->d_epart));
+            const int slab_chunks = pb->row_L * (cnp + 4);                      // then the workgroup's triple entries (8 bytes each)
+            const size_t dyn = (size_t)slab_chunks * 16 + (size_t)pb->row_tri_max * sizeof(int2);
+            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_rows<C>), dim3(pb->n_row_wgs), dim3(256), dyn, pb->stream, P, pb->d_row_wgs,
+                                                  pb->d_row_pieces, pb->d_row_tri, pb->d_partials, pb->d_epart, slab_chunks));
         }
         ph_end(pb, PH_SCHUR_ROWS);
         ph_begin(pb, PH_SCHUR_TASKS);
         if (pb->d_tasks_launch) {     // sparse blocks (all blocks when the row kernel is off): one wave per task, both sides gathered
             const SchurTask* tl = pb->d_tasks_launch;
             const dim3 sg((pb->nslots + 3) / 4);
-            if (wps == 2) { DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks<C, 2>), sg, dim3(256), 0, pb->stream, P, tl, pb->nslots, pb->d_triples, pb->d_partials, pb->d_epart)); }
-            else if (wps == 4) { DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks<C, 4>), sg, dim3(256), 0, pb->stream, P, tl, pb->nslots, pb->d_triples, pb->d_partials, pb->d_epart)); }
-            else { DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks<C, 3>), sg, dim3(256), 0, pb->stream, P, tl, pb->nslots, pb->d_triples, pb->d_partials, pb->d_epart)); }
+            // block sums on v_mfma_f64_4x4x4_4b (round 5: 0.847 against 0.875 ms at the headline size, three workgroups per CU);
+            // BSFM_SCHUR_MFMA=16 = the 16 x 16 x 4 tiles of rounds 3-4 (A/B)
+            static const bool m4 = [] { const char* e = getenv("BSFM_SCHUR_MFMA"); return !(e && atoi(e) == 16); }();
+#define BSFM_LAUNCH_TASKS(W_, M_) DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_tasks<C, W_, M_>), sg, dim3(256), 0, pb->stream, P, tl, pb->nslots, pb->d_triples, pb->d_partials, pb->d_epart))
+            if (m4) { if (wps == 2) { BSFM_LAUNCH_TASKS(2, true); } else if (wps == 4) { BSFM_LAUNCH_TASKS(4, true); } else { BSFM_LAUNCH_TASKS(3, true); } }
+            else { if (wps == 2) { BSFM_LAUNCH_TASKS(2, false); } else if (wps == 4) { BSFM_LAUNCH_TASKS(4, false); } else { BSFM_LAUNCH_TASKS(3, false); } }
+#undef BSFM_LAUNCH_TASKS
         }
         ph_end(pb, PH_SCHUR_TASKS);
         if (packed) {
@@ -1094,18 +1101,19 @@ int bsfm_problem_export_schur(bsfm_problem_t* pb, int* triples, int* tri_pt, int
 }
 
 // round 5: the plan of the row kernel as the problem holds it (tests/test_index.py compares it with the host restatement)
-int bsfm_problem_row_sizes(const bsfm_problem_t* pb, int* nwg, int* npieces, int* nslots, int* L)
+int bsfm_problem_row_sizes(const bsfm_problem_t* pb, int* nwg, int* npieces, int* nslots, int* L, int* ntri)
 {
     if (nwg) *nwg = pb->n_row_wgs;
     if (npieces) *npieces = pb->n_row_pieces;
     if (nslots) *nslots = pb->n_row_slots;
     if (L) *L = pb->row_L;
+    if (ntri) *ntri = (int)pb->row_ntri;
     return 0;
 }
 
-// wgs: 8 ints per workgroup (RowWG); pieces: 4 ints (RowPiece); blk_row0: nblk + 1 (zeros when the row kernel is off); blk_range: 2 ints
+// wgs: 16 ints per workgroup (RowWG); pieces: 4 ints (RowPiece); row_tri: 2 ints per entry of the kernel's own triple array; blk_row0: nblk + 1 (zeros when the row kernel is off); blk_range: 2 ints
 // per block; tasks_launch: 4 ints per task slot (what k_schur_tasks is given; out = -1 everywhere when it is not launched at all)
-int bsfm_problem_export_rows(bsfm_problem_t* pb, int* wgs, int* pieces, int* blk_row0, int* blk_range, int* tasks_launch)
+int bsfm_problem_export_rows(bsfm_problem_t* pb, int* wgs, int* pieces, int* blk_row0, int* blk_range, int* tasks_launch, int* row_tri)
 {
     if (pb->mot) return BSFM_ERROR;
     HIP_OK(hipStreamSynchronize(pb->stream));
@@ -1114,7 +1122,8 @@ int bsfm_problem_export_rows(bsfm_problem_t* pb, int* wgs, int* pieces, int* blk
     if (tasks_launch && !pb->d_tasks_launch) for (int t = 0; t < pb->nslots; ++t) { tasks_launch[4 * t] = 0; tasks_launch[4 * t + 1] = 0; tasks_launch[4 * t + 2] = 0; tasks_launch[4 * t + 3] = -1; }
     const bool ok = down(wgs, pb->d_row_wgs, (size_t)pb->n_row_wgs * sizeof(RowWG)) && down(pieces, pb->d_row_pieces, (size_t)pb->n_row_pieces * sizeof(RowPiece)) &&
                     down(blk_row0, pb->d_blk_row0, ((size_t)pb->nblk + 1) * sizeof(int)) && down(blk_range, pb->d_blk_range, (size_t)pb->nblk * sizeof(int2)) &&
-                    down(tasks_launch, pb->d_tasks_launch, (size_t)pb->nslots * sizeof(SchurTask));
+                    down(tasks_launch, pb->d_tasks_launch, (size_t)pb->nslots * sizeof(SchurTask)) &&
+                    down(row_tri, pb->d_row_tri, (size_t)pb->row_ntri * sizeof(int2));
     return ok ? 0 : BSFM_ERROR;
 }
 
@@ -1122,11 +1131,11 @@ int bsfm_problem_export_rows(bsfm_problem_t* pb, int* wgs, int* pieces, int* blk
 // routine the device kernel uses.  tri_x: j-side record of every triple, block after block (blk_start: nblk + 1); rank: breadth-first
 // numbers of the free cameras or null.  Call with null outputs for the sizes; returns 0 or -1 (capacity too small).
 int bsfm_schur_row_plan(int m, int mcon, int nblk, const int* blk_j, const int* blk_k, const int* blk_start, const int* tri_x, const int* camptr,
-                        const int* rank, int L, int dense_min, int slot_base, int* nwg, int* npieces, int* nslots,
-                        int* wgs_out, int cap_wgs, int* pieces_out, int cap_pieces, int* blk_row0_out)
+                        const int* rank, int L, int dense_min, int wg_min, int tri_max, int slot_base, int* nwg, int* npieces, int* nslots, int* ntri,
+                        int* wgs_out, int cap_wgs, int* pieces_out, int* fills_out, int cap_pieces, int* blk_row0_out)
 {
     if (m <= 0 || nblk < 0 || L < 16 || L > ROW_LMAX || (L & 15)) return -1;
-    RowPlanParams prm; prm.L = L; prm.dense_min = std::max(1, dense_min);
+    RowPlanParams prm; prm.L = L; prm.dense_min = std::max(1, dense_min); prm.wg_min = wg_min; prm.tri_max = tri_max;
     std::vector<int> bj(blk_j, blk_j + nblk), bk(blk_k, blk_k + nblk), cp(camptr, camptr + m + 1), counts((size_t)nblk);
     for (int b = 0; b < nblk; ++b) counts[b] = blk_start[b + 1] - blk_start[b];
     RowPlanA pa;
@@ -1140,12 +1149,14 @@ int bsfm_schur_row_plan(int m, int mcon, int nblk, const int* blk_j, const int* 
     std::vector<int> rk;
     if (rank) rk.assign(rank, rank + (m - mcon));
     RowPlan plan;
-    row_plan_stage_c(m, mcon, bj, bk, cp, prm, pa, lo, cnt, rk, slot_base, plan);
+    if (row_plan_stage_c(m, mcon, bj, bk, cp, prm, pa, lo, cnt, rk, slot_base, plan) != 0) return -1;
     if (nwg) *nwg = (int)plan.wgs.size();
     if (npieces) *npieces = (int)plan.pieces.size();
     if (nslots) *nslots = plan.nslots;
+    if (ntri) *ntri = (int)plan.ntri;
     if (wgs_out) { if ((int)plan.wgs.size() > cap_wgs) return -1; memcpy(wgs_out, plan.wgs.data(), plan.wgs.size() * sizeof(RowWG)); }
     if (pieces_out) { if ((int)plan.pieces.size() > cap_pieces) return -1; memcpy(pieces_out, plan.pieces.data(), plan.pieces.size() * sizeof(RowPiece)); }
+    if (fills_out) { if ((int)plan.fills.size() > cap_pieces) return -1; memcpy(fills_out, plan.fills.data(), plan.fills.size() * sizeof(RowFill)); }
     if (blk_row0_out) memcpy(blk_row0_out, plan.blk_row0.data(), ((size_t)nblk + 1) * sizeof(int));
     return 0;
 }

@@ -268,18 +268,22 @@ int bsfm_problem_export_schur(bsfm_problem_t *pb, int *triples, int *tri_pt, int
 /* Round 5 -- the row-wise Schur kernel (csrc/schur_rows.h; reference loop lib/sba-1.5/sba_levmar.c:1195-1302).  Blocks (j,k) with
  * enough co-visibility triples per segment of camera j's records ("dense") are accumulated by workgroups that own (camera j, a
  * segment of <= L consecutive camera-major records): the j side of every triple is streamed once into LDS, only the k side is
- * gathered.  The plan as the problem holds it: wgs (8 ints each: rec0, nrec, piece0, pieces of wave 0..3, pad; launch order),
- * pieces (4 ints each: first triple, count, diag, slot), blk_row0 (nblk + 1: row slots per block before the offset ntasks),
- * blk_range (2 ints per block: the slots k_schur_assemble adds, in that order), tasks_launch (4 ints per task slot: what the task
- * kernel of the sparse blocks is given).  Any pointer may be NULL. */
-int bsfm_problem_row_sizes(const bsfm_problem_t *pb, int *nwg, int *npieces, int *nslots, int *L);
-int bsfm_problem_export_rows(bsfm_problem_t *pb, int *wgs, int *pieces, int *blk_row0, int *blk_range, int *tasks_launch);
+ * gathered.  The plan as the problem holds it: wgs (16 ints each: rec0, nrec, first entry of the row triple array, passes, first
+ * piece, pieces, first pass of wave 0..3, first piece of wave 0..3, 2 x pad; launch order), pieces (4 ints each: passes, diag, slot,
+ * pad), blk_row0 (nblk + 1: row slots per block before the offset ntasks), blk_range (2 ints per block: the slots k_schur_assemble
+ * adds, in that order), tasks_launch (4 ints per task slot: what the task kernel of the sparse blocks is given), row_tri (2 ints per
+ * entry: slab row of the j side -- bit 16 set on padding --, camera-major record of the k side).  Any pointer may be NULL. */
+int bsfm_problem_row_sizes(const bsfm_problem_t *pb, int *nwg, int *npieces, int *nslots, int *L, int *ntri);
+int bsfm_problem_export_rows(bsfm_problem_t *pb, int *wgs, int *pieces, int *blk_row0, int *blk_range, int *tasks_launch, int *row_tri);
 /* The same plan computed on the HOST from a block list (no device needed; tests): tri_x = j-side record of every triple, block after
- * block (blk_start: nblk + 1), camptr (m + 1), rank = breadth-first numbers of the free cameras or NULL.  Call with NULL outputs
- * for the sizes.  Returns 0, or -1 (bad arguments / capacity too small). */
+ * block (blk_start: nblk + 1), camptr (m + 1), rank = breadth-first numbers of the free cameras or NULL; wg_min / tri_max: 0 = the
+ * defaults (2.5 L triples per segment to take a camera's row at all, 12 L padded triples per workgroup).  fills_out: 4 ints per piece
+ * (first triple, count, first entry of the row triple array, rec0).  Call with NULL outputs for the sizes.  Returns 0, or -1 (bad
+ * arguments / capacity too small). */
 int bsfm_schur_row_plan(int m, int mcon, int nblk, const int *blk_j, const int *blk_k, const int *blk_start, const int *tri_x,
-                        const int *camptr, const int *rank, int L, int dense_min, int slot_base, int *nwg, int *npieces, int *nslots,
-                        int *wgs_out, int cap_wgs, int *pieces_out, int cap_pieces, int *blk_row0_out);
+                        const int *camptr, const int *rank, int L, int dense_min, int wg_min, int tri_max, int slot_base, int *nwg,
+                        int *npieces, int *nslots, int *ntri, int *wgs_out, int cap_wgs, int *pieces_out, int *fills_out, int cap_pieces,
+                        int *blk_row0_out);
 /* dense vmask -> CRS exactly as run_sfm does it (host only); returns nvis, rowptr / colidx may be NULL. */
 int bsfm_crs_from_vmask(int n, int m, const char *vmask, int *rowptr, int *colidx);
 /* The same CRS built ON THE DEVICE (what run_sfm does for masks of at least 1 MB, BSFM_VMASK_DEVICE_MIN: upload, count / scan /

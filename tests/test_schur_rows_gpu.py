@@ -17,9 +17,9 @@ from test_oracle import CASES, load_case
 pytestmark = pytest.mark.gpu
 
 
-def rows_env(monkeypatch, on, L=None, dense_min=None):
+def rows_env(monkeypatch, on, L=None, dense_min=None, wg_min=1, tri_max=None):
     monkeypatch.setenv("BSFM_SCHUR_ROWS", "1" if on else "0")
-    for key, v in (("BSFM_SCHUR_ROW_L", L), ("BSFM_SCHUR_ROW_MIN", dense_min)):
+    for key, v in (("BSFM_SCHUR_ROW_L", L), ("BSFM_SCHUR_ROW_MIN", dense_min), ("BSFM_SCHUR_ROW_WGMIN", wg_min), ("BSFM_SCHUR_ROW_TRIMAX", tri_max)):
         if v is None:
             monkeypatch.delenv(key, raising=False)
         else:
@@ -77,15 +77,16 @@ def bfs_rank(blk_j, blk_k, mm, mcon):
     return rank
 
 
-@pytest.mark.parametrize("banded,L,dense_min,mcon", [(False, 128, 24, 0), (False, 32, 8, 2), (True, 16, 2, 0), (True, 64, 6, 1)],
-                         ids=["cliques-default", "cliques-L32-2fixed", "connected-L16", "connected-L64-mixed"])
-def test_rows_midsize_plan_bits_and_lm(gpu_bsfm, monkeypatch, banded, L, dense_min, mcon):
+@pytest.mark.parametrize("banded,L,dense_min,mcon,wg_min,tri_max", [(False, 96, 24, 0, None, None), (False, 32, 8, 2, 1, 128), (True, 16, 2, 0, 1, None),
+                                                                     (True, 64, 6, 1, 1, None), (False, 128, 24, 0, None, 512)],
+                         ids=["cliques-default", "cliques-L32-2fixed-split", "connected-L16", "connected-L64-mixed", "cliques-L128-split"])
+def test_rows_midsize_plan_bits_and_lm(gpu_bsfm, monkeypatch, banded, L, dense_min, mcon, wg_min, tri_max):
     B = gpu_bsfm
     m, n = 130, 30000
     s = B.synth_ba(m, n, 8, banded=banded)
 
     def run(on):
-        rows_env(monkeypatch, on, L, dense_min)
+        rows_env(monkeypatch, on, L, dense_min, wg_min, tri_max)
         pb = B.Problem(n, m, s["rowptr"], s["colidx"], s["proj"], s["cams"], s["pts"], mcon=mcon,
                        options=B.default_options(jacobian=B.JAC_ANALYTIC, verbose=0, itmax=4))
         ne = pb.normal_equations(mu=0.37)
@@ -115,9 +116,20 @@ def test_rows_midsize_plan_bits_and_lm(gpu_bsfm, monkeypatch, banded, L, dense_m
     starts = np.flatnonzero(np.concatenate([[True], np.diff(key) != 0]))
     blk_start[:-1] = starts; blk_start[-1] = len(key)
     rank = bfs_rank(sc["blk_j"], sc["blk_k"], m - mcon, mcon)
-    host = B.sfm.schur_row_plan(m, mcon, sc["blk_j"], sc["blk_k"], blk_start, sc["triples"][:, 0], ix["camptr"], rank, L, dense_min, sc["ntasks"])
+    host = B.sfm.schur_row_plan(m, mcon, sc["blk_j"], sc["blk_k"], blk_start, sc["triples"][:, 0], ix["camptr"], rank, L, dense_min,
+                                wg_min or 0, tri_max or 0, sc["ntasks"])
     assert np.array_equal(host["wgs"], rw["wgs"]) and np.array_equal(host["pieces"], rw["pieces"]) and np.array_equal(host["blk_row0"], rw["blk_row0"])
-    assert host["nslots"] == rw["nslots"]
+    assert host["nslots"] == rw["nslots"] and host["ntri"] == len(rw["row_tri"])
+    # the kernel's own triple array = the plan's copy list applied to the resident triples (k_row_fill)
+    exp = np.zeros((host["ntri"], 2), np.int32)
+    for src, cnt, dst, rec0 in host["fills"]:
+        padded = (cnt + 15) // 16 * 16
+        t = np.minimum(np.arange(padded), cnt - 1)
+        exp[dst:dst + padded, 0] = (sc["triples"][src + t, 0] - rec0) | np.where(np.arange(padded) < cnt, 0, B.sfm.ROW_DEAD)
+        exp[dst:dst + padded, 1] = sc["triples"][src + t, 1]
+    assert np.array_equal(exp, rw["row_tri"])
+    if tri_max:
+        assert (16 * rw["wgs"][:, 3] <= max(tri_max, 128)).all() and len(np.unique(rw["wgs"][:, 0])) < len(rw["wgs"]), "meant to split workgroups"
     dense = np.diff(rw["blk_row0"]) > 0
     exp_range = np.stack([sc["blk_task0"][:-1], sc["blk_task0"][1:]], axis=1)
     exp_range[dense] = sc["ntasks"] + np.stack([rw["blk_row0"][:-1], rw["blk_row0"][1:]], axis=1)[dense]
