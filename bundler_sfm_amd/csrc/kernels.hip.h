@@ -132,8 +132,8 @@ __global__ void k_cam_table(ModelCfg cfg, int m, const double* __restrict__ pa, 
 constexpr int RES_BLOCK = 256;
 template <bool KNOWN>
 __global__ __launch_bounds__(RES_BLOCK) void k_residual(ModelCfg cfg, int nvis,
-        const double* __restrict__ xc, const int* __restrict__ cam_cam, const int* __restrict__ cam_pt,
-        const double* __restrict__ camtab, const double* __restrict__ pb,
+        const double* __restrict__ xc, const int* __restrict__ cam_cam, const double* __restrict__ ptc,
+        const double* __restrict__ camtab,
         double* __restrict__ e_out, const double* __restrict__ e_prev, double eps5,
         double* __restrict__ part_cost, double* __restrict__ part_pct)
 {
@@ -142,7 +142,10 @@ __global__ __launch_bounds__(RES_BLOCK) void k_residual(ModelCfg cfg, int nvis,
     double c = 0.0, pct = 0.0;
     if (k < nvis) {
         const double* ct = camtab + (size_t)cam_cam[k] * CT_STRIDE;
-        const double* b = pb + (size_t)cam_pt[k] * 3;
+        // the point of observation k from the CAMERA-major mirror of the point array (round 5: streamed, 32 bytes; the gather of 24 bytes
+        // out of the 12 MB point array fetched a 128-byte line per observation: 2.6 x the algorithmic traffic of this kernel)
+        const double2 b01 = reinterpret_cast<const double2*>(ptc)[2 * (size_t)k], b2_ = reinterpret_cast<const double2*>(ptc)[2 * (size_t)k + 1];
+        const double b[3] = { b01.x, b01.y, b2_.x };
         double h0, h1;
         project_row<KNOWN>(cfg, ct, b[0], b[1], b[2], h0, h1);
         const double2 xx = reinterpret_cast<const double2*>(xc)[k];
@@ -175,6 +178,18 @@ __global__ __launch_bounds__(256) void k_permute16(int nvis, const int* __restri
     if (t < nvis) reinterpret_cast<double2*>(dst)[t] = reinterpret_cast<const double2*>(src)[src_of[t]];
 }
 
+// Camera-major mirror of the point part of a parameter vector: 32 bytes (x, y, z, 0) per observation.  Built by this gather when a
+// parameter vector comes from outside (lm_begin, reset), kept up to date by k_backsub, which scatters every new trial point to the
+// positions of its observations -- the projection kernels (residual, Jacobian) then STREAM their points.
+__global__ __launch_bounds__(256) void k_point_mirror(int nvis, const int* __restrict__ cam_pt, const double* __restrict__ pb, double* __restrict__ ptc)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nvis) return;
+    const double* b = pb + (size_t)cam_pt[t] * 3;
+    reinterpret_cast<double2*>(ptc)[2 * (size_t)t] = make_double2(b[0], b[1]);
+    reinterpret_cast<double2*>(ptc)[2 * (size_t)t + 1] = make_double2(b[2], 0.0);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Jacobian: one thread per CAMERA-major position t.  Neighbouring threads share the camera (its 72-double table row is one
 // broadcast), gather their point (24 bytes, the point array is L2-resident) and write consecutive records of the two streams
@@ -184,14 +199,15 @@ __global__ __launch_bounds__(256) void k_permute16(int nvis, const int* __restri
 // registers and the phase goes from 0.38 to 0.51 ms at config 3: measured in round 4, not kept.)
 template <int CNP, bool FD, bool KNOWN>
 __global__ __launch_bounds__(256) void k_jacobian(ModelCfg cfg, int nvis,
-        const int* __restrict__ cam_cam, const int* __restrict__ cam_pt,
-        const double* __restrict__ camtab, const double* __restrict__ pb, const double* __restrict__ e,
+        const int* __restrict__ cam_cam, const double* __restrict__ ptc,
+        const double* __restrict__ camtab, const double* __restrict__ e,
         double* __restrict__ Ac, double* __restrict__ Bc)
 {
     const int tt = blockIdx.x * 256 + threadIdx.x;
     const int t = min(tt, nvis - 1);                         // the last workgroup's surplus threads repeat the last record (never stored)
     const double* ct = camtab + (size_t)cam_cam[t] * CT_STRIDE;
-    const double* b = pb + (size_t)cam_pt[t] * 3;
+    const double2 b01 = reinterpret_cast<const double2*>(ptc)[2 * (size_t)t], b2_ = reinterpret_cast<const double2*>(ptc)[2 * (size_t)t + 1];
+    const double b[3] = { b01.x, b01.y, b2_.x };             // the point from the camera-major mirror (streamed; was a 24-byte gather)
     const double2 et = reinterpret_cast<const double2*>(e)[t];
     double A[2 * CNP], B[6], x0, x1;
     if (FD) jac_fd<CNP, KNOWN>(cfg, ct, b[0], b[1], b[2], A, B, x0, x1);
@@ -541,7 +557,7 @@ __global__ __launch_bounds__(256) void k_unpermute_step(int count, int cnp, cons
 template <int CNP>
 __global__ __launch_bounds__(256) void k_backsub(DevProblem P, double mu, const double* __restrict__ dpa,
         const double* __restrict__ pb, double* __restrict__ dpb, double* __restrict__ pdpb,
-        double* __restrict__ part /* [3][gridDim.x] */)
+        double* __restrict__ part /* [3][gridDim.x] */, double* __restrict__ ptc_out /* camera-major mirror of pdpb, or null */)
 {
     __shared__ double sm[3][4];
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -571,6 +587,13 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem P, double mu, const 
         dpb[3 * (size_t)i] = d0; dpb[3 * (size_t)i + 1] = d1; dpb[3 * (size_t)i + 2] = d2;
         const double p0 = pb[3 * (size_t)i], p1 = pb[3 * (size_t)i + 1], p2 = pb[3 * (size_t)i + 2];
         pdpb[3 * (size_t)i] = p0 + d0; pdpb[3 * (size_t)i + 1] = p1 + d1; pdpb[3 * (size_t)i + 2] = p2 + d2;
+        if (ptc_out) {      // the trial point to the camera-major positions of its observations (32-byte records; campos[] is L1 / L2 warm)
+            const double2 v01 = make_double2(p0 + d0, p1 + d1), v2 = make_double2(p2 + d2, 0.0);
+            for (int k = P.rowptr[i]; k < k1; ++k) {
+                double2* dst = reinterpret_cast<double2*>(ptc_out) + 2 * (size_t)P.campos[k];
+                dst[0] = v01; dst[1] = v2;
+            }
+        }
         s_dp = d0 * d0 + d1 * d1 + d2 * d2;
         s_p = p0 * p0 + p1 * p1 + p2 * p2;
         s_dl = d0 * (mu * d0 + g[0]) + d1 * (mu * d1 + g[1]) + d2 * (mu * d2 + g[2]);

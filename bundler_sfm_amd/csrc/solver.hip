@@ -218,6 +218,9 @@ struct bsfm_problem {
     double *d_p = nullptr, *d_pdp = nullptr, *d_dp = nullptr;
     double *d_camtab = nullptr, *d_camtab_trial = nullptr;
     double *d_e = nullptr, *d_hx = nullptr;
+    // camera-major mirrors of the point part of parameter vectors (32 bytes per observation; kernels.hip.h: k_point_mirror): slot s mirrors
+    // the vector ptc_tag[s] points at (d_p or d_pdp -- the tags follow the pointers through the accept swap), null = stale
+    double* d_ptc[2] = { nullptr, nullptr }; const double* ptc_tag[2] = { nullptr, nullptr };
     double *d_Ac = nullptr, *d_Bc = nullptr, *d_Cc = nullptr, *d_U = nullptr, *d_ea = nullptr, *d_V = nullptr, *d_Vinv = nullptr, *d_eb = nullptr;
     double *d_S = nullptr, *d_E = nullptr;
     int export_full_s = 0;              // bsfm_eval_normal_equations hands S out as a full symmetric matrix: clear all of it
@@ -277,7 +280,7 @@ void free_all(bsfm_problem* pb)
     (void)hipDeviceSynchronize();          // nothing may still be using the blocks that go back to the cache
     void* ptrs[] = { pb->d_x, pb->d_xc, pb->d_Rinit, pb->d_finit, pb->d_known, pb->d_obs_cam, pb->d_obs_pt, pb->d_rowptr, pb->d_camptr,
                      pb->d_camobs, pb->d_campos, pb->d_cam_pt, pb->d_cam_cam, pb->d_Ac, pb->d_Bc, pb->d_Cc, pb->d_ccon, pb->d_pcon, pb->d_cval, pb->d_cw, pb->d_pval, pb->d_p, pb->d_pdp,
-                     pb->d_dp, pb->d_camtab, pb->d_camtab_trial, pb->d_e, pb->d_hx, pb->d_U,
+                     pb->d_dp, pb->d_camtab, pb->d_camtab_trial, pb->d_e, pb->d_hx, pb->d_ptc[0], pb->d_ptc[1], pb->d_U,
                      pb->d_V, pb->d_Vinv, pb->d_eb, pb->d_S, pb->d_E, pb->d_partials, pb->d_epart, pb->d_campart, pb->d_red, pb->d_scal, pb->d_mixed,
                      pb->d_triples, pb->d_tri_pt, pb->d_tasks, pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0,
                      pb->d_row_wgs, pb->d_row_pieces, pb->d_blk_row0, pb->d_blk_range, pb->d_row_tri, pb->d_tasks_launch != pb->d_tasks ? (void*)pb->d_tasks_launch : nullptr,
@@ -381,20 +384,38 @@ void launch_cam_table(bsfm_problem* pb, const double* p, double* camtab)
                        pb->d_Rinit, pb->d_finit, pb->d_known, pb->opt.jacobian == BSFM_JAC_FD ? 1 : 0, camtab);
 }
 
-// e_out = x - proj(p) (camera-major order); SC slot gets sum e^2 ; optional pct-change vs e_prev into SC_PCT
-void launch_residual(bsfm_problem* pb, const double* camtab, const double* p, double* e_out,
+// The camera-major mirror of the points of parameter vector `p` (d_p or d_pdp): the slot tagged with it, else built now by a gather
+// into the slot that does not hold the mirror of the accepted parameters.  k_backsub writes the mirror of every trial vector itself
+// (lm_iterate), so inside the LM loop this only ever finds a tag.
+void invalidate_point_mirrors(bsfm_problem* pb) { pb->ptc_tag[0] = pb->ptc_tag[1] = nullptr; }
+int trial_mirror_slot(const bsfm_problem* pb) { return pb->ptc_tag[0] == pb->d_p ? 1 : 0; }
+const double* points_mirror(bsfm_problem* pb, const double* p)
+{
+    for (int s = 0; s < 2; ++s) if (pb->ptc_tag[s] == p) return pb->d_ptc[s];
+    const int s = trial_mirror_slot(pb);
+    if (pb->P.nvis > 0)
+        hipLaunchKernelGGL(k_point_mirror, dim3(grid_for(pb->P.nvis, 256)), dim3(256), 0, pb->stream, pb->P.nvis, pb->d_cam_pt,
+                           p + (size_t)pb->P.m * pb->cnp, pb->d_ptc[s]);
+    pb->ptc_tag[s] = p;
+    return pb->d_ptc[s];
+}
+
+// e_out = x - proj(p) (camera-major order); SC slot gets sum e^2 ; optional pct-change vs e_prev into SC_PCT.
+// p_points: the parameter vector whose POINTS are projected (the cameras come through camtab) -- the camera-only refinement evaluates
+// trial cameras against the points of the accepted vector.
+void launch_residual(bsfm_problem* pb, const double* camtab, const double* p_points, double* e_out,
                      const double* e_prev, int cost_slot)
 {
     const int nb = grid_for(pb->P.nvis, RES_BLOCK);
     double* pc = pb->d_red, *pp = pb->d_red + pb->red_blocks;
-    const double* pbpts = p + (size_t)pb->P.m * pb->cnp;
+    const double* ptc = points_mirror(pb, p_points);
     if (pb->P.nvis > 0 && pb->d_known)
         hipLaunchKernelGGL(k_residual<true>, dim3(nb), dim3(RES_BLOCK), 0, pb->stream, pb->P.cfg, pb->P.nvis, pb->d_xc,
-                           pb->d_cam_cam, pb->d_cam_pt, camtab, pbpts, e_out, e_prev, pb->opt.opts[5], pc,
+                           pb->d_cam_cam, ptc, camtab, e_out, e_prev, pb->opt.opts[5], pc,
                            e_prev ? pp : nullptr);
     if (pb->P.nvis > 0 && !pb->d_known)
         hipLaunchKernelGGL(k_residual<false>, dim3(nb), dim3(RES_BLOCK), 0, pb->stream, pb->P.cfg, pb->P.nvis, pb->d_xc,
-                           pb->d_cam_cam, pb->d_cam_pt, camtab, pbpts, e_out, e_prev, pb->opt.opts[5], pc,
+                           pb->d_cam_cam, ptc, camtab, e_out, e_prev, pb->opt.opts[5], pc,
                            e_prev ? pp : nullptr);
     const int cnt = pb->P.nvis > 0 ? nb : 0;
     hipLaunchKernelGGL(k_reduce_sum_max, dim3(1), dim3(256), 0, pb->stream, pc, e_prev ? pp : (const double*)nullptr, cnt,
@@ -483,18 +504,19 @@ int compute_normal_blocks(bsfm_problem* pb)
     const int cnp = pb->cnp;
     DevProblem& P = pb->P;
     const double* pbpts = pb->d_p + (size_t)P.m * cnp;
+    const double* ptc = points_mirror(pb, pb->d_p);          // (a tag hit inside the LM loop: lm_begin / the accepted trial wrote it)
     ph_begin(pb, PH_JAC);
     if (P.nvis > 0) {
         if (pb->opt.jacobian == BSFM_JAC_FD) {
             if (pb->d_known) {
                 DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_jacobian<C, true, true>), dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream,
-                                                      P.cfg, P.nvis, pb->d_cam_cam, pb->d_cam_pt, pb->d_camtab, pbpts, pb->d_e, pb->d_Ac, pb->d_Bc));
+                                                      P.cfg, P.nvis, pb->d_cam_cam, ptc, pb->d_camtab, pb->d_e, pb->d_Ac, pb->d_Bc));
             } else
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_jacobian<C, true, false>), dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream,
-                                                  P.cfg, P.nvis, pb->d_cam_cam, pb->d_cam_pt, pb->d_camtab, pbpts, pb->d_e, pb->d_Ac, pb->d_Bc));
+                                                  P.cfg, P.nvis, pb->d_cam_cam, ptc, pb->d_camtab, pb->d_e, pb->d_Ac, pb->d_Bc));
         } else {
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_jacobian<C, false, false>), dim3(grid_for(P.nvis, 256)), dim3(256), 0, pb->stream,
-                                                  P.cfg, P.nvis, pb->d_cam_cam, pb->d_cam_pt, pb->d_camtab, pbpts, pb->d_e, pb->d_Ac, pb->d_Bc));
+                                                  P.cfg, P.nvis, pb->d_cam_cam, ptc, pb->d_camtab, pb->d_e, pb->d_Ac, pb->d_Bc));
         }
     }
     ph_end(pb, PH_JAC);
@@ -844,6 +866,7 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     DM(pb->d_p, pb->nvars_local); DM(pb->d_pdp, pb->nvars_local); DM(pb->d_dp, pb->nvars_local);
     DM(pb->d_camtab, (size_t)m * CT_STRIDE); DM(pb->d_camtab_trial, (size_t)m * CT_STRIDE);
     DM(pb->d_e, 2 * (size_t)nvis); DM(pb->d_hx, 2 * (size_t)nvis);
+    DM(pb->d_ptc[0], 4 * (size_t)nvis); DM(pb->d_ptc[1], 4 * (size_t)nvis);
     DM(pb->d_Ac, (size_t)nvis * 2 * cnp); DM(pb->d_Bc, (size_t)nvis * 8); if (!pb->mot) { DM(pb->d_Cc, (size_t)nvis * 8); } DM(pb->d_xc, 2 * (size_t)nvis); DM(pb->d_campart, (size_t)m * CAM_SPLIT * (cnp * (cnp + 1) / 2 + cnp)); DM(pb->d_U, (size_t)m * cnp * cnp + (size_t)m * cnp); pb->d_ea = pb->d_U + (size_t)m * cnp * cnp;   /* one buffer: one exchange */
     DM(pb->d_V, 6 * (size_t)n); DM(pb->d_Vinv, 6 * (size_t)n); DM(pb->d_eb, 3 * (size_t)n);
     DM(pb->d_S, (size_t)pb->ld * pb->ld); DM(pb->d_E, pb->ld);
@@ -1051,6 +1074,7 @@ int bsfm_problem_reset_params(bsfm_problem_t* pb, const bsfm_camera_params_t* ca
     std::vector<double> finit(pb->P.m);
     for (int j = 0; j < pb->P.m; ++j) { memcpy(&pb->h_Rinit[9 * (size_t)j], cams[j].R, 9 * sizeof(double)); finit[j] = cams[j].f; }
     HIP_OK(hipMemcpy(pb->d_p, p.data(), p.size() * sizeof(double), hipMemcpyHostToDevice));
+    invalidate_point_mirrors(pb);
     HIP_OK(hipMemcpy(pb->d_Rinit, pb->h_Rinit.data(), pb->h_Rinit.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(pb->d_finit, finit.data(), finit.size() * sizeof(double), hipMemcpyHostToDevice));
     pb->h_cams.assign(cams, cams + pb->P.m);
@@ -1213,6 +1237,7 @@ int bsfm_lm_begin(bsfm_problem_t* pb)
         pb->error = 1; pb->began = 1;
         return BSFM_ERROR;
     }
+    invalidate_point_mirrors(pb);                       // whatever happened to the parameters since the last run: gather once
     launch_cam_table(pb, pb->d_p, pb->d_camtab);
     launch_residual(pb, pb->d_camtab, pb->d_p, pb->d_e, nullptr, SC_COST);
     hipLaunchKernelGGL(k_constraint_cost, dim3(1), dim3(256), 0, pb->stream, pb->P, pb->d_p,
@@ -1278,7 +1303,7 @@ static int lm_iterate_mot(bsfm_problem_t* pb, int iters)
             if (npts3) (void)hipMemcpyAsync(pb->d_pdp + (size_t)P.m * cnp, pb->d_p + (size_t)P.m * cnp, npts3 * sizeof(double), hipMemcpyDeviceToDevice, pb->stream);
             ph_begin(pb, PH_RESID);
             launch_cam_table(pb, pb->d_pdp, pb->d_camtab_trial);
-            launch_residual(pb, pb->d_camtab_trial, pb->d_pdp, pb->d_hx, pb->d_e, SC_COST_TRIAL);
+            launch_residual(pb, pb->d_camtab_trial, pb->d_p, pb->d_hx, pb->d_e, SC_COST_TRIAL);      // (the points do not move: those of d_p)
             ph_end(pb, PH_RESID);
             if (read_scalars(pb)) return BSFM_ERROR;
             collect_phase_times(pb);
@@ -1310,6 +1335,7 @@ static int lm_iterate_mot(bsfm_problem_t* pb, int iters)
                     pb->nu = 2;
                     if (pdp_eL2 - 2.0 * sqrt(pb->p_eL2 * pdp_eL2) < (eps4_sq - 1.0) * pb->p_eL2) pb->stop = 4;
                     std::swap(pb->d_p, pb->d_pdp);
+                    for (int ms = 0; ms < 2; ++ms) if (pb->ptc_tag[ms] == pb->d_pdp) pb->ptc_tag[ms] = pb->d_p;      // the points did not move: the mirror of the old vector is the mirror of the new one
                     std::swap(pb->d_e, pb->d_hx);
                     std::swap(pb->d_camtab, pb->d_camtab_trial);
                     pb->p_eL2 = pdp_eL2;
@@ -1429,7 +1455,11 @@ static int lm_iterate_impl(bsfm_problem_t* pb, int iters)
             ph_end(pb, PH_SOLVE);
             if (P.mcon > 0) (void)hipMemsetAsync(d_dpa, 0, (size_t)P.mcon * cnp * sizeof(double), pb->stream);
             ph_begin(pb, PH_BACKSUB);
-            if (P.n > 0) DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_backsub<C>), dim3(nbp), dim3(256), 0, pb->stream, P, mu, d_dpa, d_pb, d_dpb, d_pdpb, pb->d_red));
+            if (P.n > 0) {
+                const int ms = trial_mirror_slot(pb);            // the trial points also go to the camera-major mirror the residual kernel streams
+                DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_backsub<C>), dim3(nbp), dim3(256), 0, pb->stream, P, mu, d_dpa, d_pb, d_dpb, d_pdpb, pb->d_red, pb->d_ptc[ms]));
+                pb->ptc_tag[ms] = pb->d_pdp;
+            }
             hipLaunchKernelGGL(k_step_sums, dim3(1), dim3(256), 0, pb->stream, P.m * cnp, P.mcon * cnp, mu, d_pa, d_dpa, pb->d_ea, d_pdpa,
                                pb->d_scal + SC_CAM3, pb->d_red, P.n > 0 ? nbp : 0, pb->d_scal + SC_PT_DP);
             ph_end(pb, PH_BACKSUB);
