@@ -53,6 +53,8 @@ struct FlowArgs {
     int* info;
     long long* trace;      // optional: 4 stamps per task (bulk tasks first, then chain tasks), then (from ptrace_ofs) 40 phase stamps per POTRF column
     unsigned ptrace_ofs;
+    long long spin_limit;  // wall-clock ticks (100 MHz) a task may wait for its dependencies before the launch gives up
+    int stall_ticket;      // TEST HOOK (BSFM_FLOW_TEST_STALL=k): the bulk task with ticket k never signals -- what a starved launch looks like; -1 = none
 };
 constexpr unsigned FLOW_CU_KEYS = 4096;      // XCC (4 bits) | SE (3) | SH (1) | CU (4)
 
@@ -64,7 +66,21 @@ constexpr unsigned FLOW_CU_KEYS = 4096;      // XCC (4 bits) | SE (3) | SH (1) |
 #define BSFM_FLOW_ROLE __attribute__((noinline))
 #endif
 
+// INVARIANT the hand-offs rest on (formally a data race, safe under exactly these conditions -- keep them true when a role,
+// a tile size or a layout changes):
+//   (1) every 128-byte line of the write-once buffers -- Pc (compact panel tiles), Linv (inverse diagonal factors), y -- is written by
+//       exactly ONE task part, in full, before that part's counter is incremented, and is never written again in the launch: a tile of
+//       Pc is 128 x 128 doubles at a 128 KB-aligned offset (flow_tri * FLOW_TL), a part owns whole rows of it (64 rows = TRSM64) or
+//       32 x 32 blocks whose rows are 256-byte segments (TRSM32); Linv tile k is written by POTRF(k) alone; y_k by FTRSM(k) alone;
+//   (2) no address of those buffers is READ in a launch before its producer's counter has been observed (the static order puts every
+//       producer before its consumers, tests/test_chol_flow_sched.py), so no L1 / L2 holds a line of them from before it was written;
+//       between launches the kernel boundary invalidates the caches;
+//   (3) everything that is REWRITTEN during a launch (tiles of S, E) is only touched with agent-scope (sc1) loads and stores.
+// The static_asserts below pin the geometry (1) depends on; scripts/r4/flow_stress.py (random envelopes, many launches, bit-identity)
+// is the dynamic check and runs in the GPU suite (tests/test_chol_gpu.py::test_flow_stress_bit_identity).
 constexpr size_t FLOW_TL = (size_t)POTRF_NB * POTRF_NB;
+static_assert(POTRF_NB == 128 && FLOW_TL * sizeof(double) % 128 == 0, "a panel tile is a whole number of 128-byte lines");
+static_assert((32 * sizeof(double)) % 128 == 0 && (POTRF_NB * sizeof(double)) % 128 == 0, "a 32-column block row and a tile row are whole lines: no line has two writers");
 __host__ __device__ inline size_t flow_tri(int i, int k) { return (size_t)i * (size_t)(i - 1) / 2 + (size_t)k; }
 
 __device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -156,6 +172,7 @@ __device__ __forceinline__ FlowArgs flow_uniform_args(const FlowArgs& a)
     u.S = (double*)up(a.S); u.Pc = (double*)up(a.Pc); u.Linv = (double*)up(a.Linv); u.E = (double*)up(a.E); u.y = (double*)up(a.y);
     u.info = (int*)up(a.info); u.trace = (long long*)up(a.trace); u.ptrace_ofs = (unsigned)__builtin_amdgcn_readfirstlane((int)a.ptrace_ofs);
     u.ld = __builtin_amdgcn_readfirstlane(a.ld); u.n_total = __builtin_amdgcn_readfirstlane(a.n_total); u.T = __builtin_amdgcn_readfirstlane(a.T);
+    u.stall_ticket = __builtin_amdgcn_readfirstlane(a.stall_ticket);
     return u;
 }
 
@@ -547,7 +564,18 @@ __device__ BSFM_FLOW_ROLE void flow_potrf(const FlowArgs& a_in, int k, double* l
             for (int q = 0; q < 4; ++q) blk[swz16(4 * q + lr, lc)] = cur[q];
             BSFM_LDS_FENCE();
             const int bad = flow_factor16(blk, lane);
-            if (lane == 0 && bad >= 0 && base + 16 * sn + bad < n_total) atomicCAS(a.info, 0, base + 16 * sn + bad + 1);
+            if (lane == 0 && bad >= 0 && base + 16 * sn + bad < n_total) {
+                // dpotrf's info is the FIRST failing leading minor.  With an envelope whose diagonal tiles are independent (block-diagonal S)
+                // POTRFs of different columns run concurrently, so "first in time" is not "first in the matrix": keep the minimum
+                // (0 = unset).  One lane, no barrier inside: the loop is an ordinary structured region.
+                const int val = base + 16 * sn + bad + 1;
+                int old = __hip_atomic_load(a.info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int tries = 0; tries < 64 && (old == 0 || old > val); ++tries) {
+                    const int prev = atomicCAS(a.info, old, val);
+                    if (prev == old) break;
+                    old = prev;
+                }
+            }
         }
         if (s >= 0) {
             // ---- A3, the other live blocks
@@ -627,7 +655,7 @@ __device__ BSFM_FLOW_ROLE void flow_potrf(const FlowArgs& a_in, int k, double* l
 #undef BSFM_LDS_FENCE
 }
 
-constexpr long long FLOW_SPIN_LIMIT_TICKS = 40LL * 1000 * 1000;      // 0.4 s of the 100 MHz wall clock: far beyond any solve this library accepts
+constexpr long long FLOW_SPIN_LIMIT_TICKS = 40LL * 1000 * 1000;      // 0.4 s of the 100 MHz wall clock: far beyond any solve this library accepts (BSFM_FLOW_SPIN_MS overrides it)
 
 #ifndef BSFM_FLOW_WPS
 #define BSFM_FLOW_WPS 4          // waves per SIMD the kernel is compiled for: 4 = two 512-thread workgroups per CU (128 VGPRs)
@@ -730,7 +758,7 @@ __global__ __launch_bounds__(512, BSFM_FLOW_WPS) void k_chol_flow(FlowArgs a)
                     __builtin_amdgcn_s_sleep(1);
                     if ((++spins & 63u) == 0u) {
                         const unsigned tmo = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                        const int late = __builtin_amdgcn_readfirstlane((int)(wall_clock64() - t_begin > FLOW_SPIN_LIMIT_TICKS));
+                        const int late = __builtin_amdgcn_readfirstlane((int)(wall_clock64() - t_begin > a.spin_limit));
                         if (tmo != 0u || late) { ab = 1; break; }
                     }
                 }
@@ -754,7 +782,8 @@ __global__ __launch_bounds__(512, BSFM_FLOW_WPS) void k_chol_flow(FlowArgs a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave drains its write-through stores
         __syncthreads();
         if (tid == 0) {
-            __hip_atomic_fetch_add(flags + tp->sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(role == 0 && (int)tk == a.stall_ticket))        // (test hook: a task that never signals)
+                __hip_atomic_fetch_add(flags + tp->sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a.trace) {
                 a.trace[4 * (trace_base + tk) + 2] = wall_clock64();
                 unsigned xcc = 0;
@@ -770,7 +799,7 @@ __global__ __launch_bounds__(512, BSFM_FLOW_WPS) void k_chol_flow(FlowArgs a)
 // tile columns run it in WAVES of that many columns, rightmost first (`first` = columns already done): a later wave finds the flags
 // of the earlier ones set.
 __global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc, int nblk, int first, const double* __restrict__ Linv,
-        const double* __restrict__ y, double* x, int* flags, int* timeout, const int* __restrict__ last_row)
+        const double* __restrict__ y, double* x, int* flags, int* timeout, const int* __restrict__ last_row, long long spin_limit, int stall_col)
 {
     __shared__ double yk[POTRF_NB];
     __shared__ double xi[POTRF_NB];
@@ -794,9 +823,12 @@ __global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc,
         }
         if (threadIdx.x == 0) {
             unsigned spins = 0;
+            const long long t_begin = wall_clock64();
             while (__hip_atomic_load(&flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 26)) { atomicExch(timeout, 1); break; }
+                if ((++spins & 63u) == 0u && (wall_clock64() - t_begin > spin_limit || __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    atomicExch(timeout, 1); break;              // a bounded wait: the solve reports POTRF_INFO_TIMEOUT instead of hanging
+                }
             }
         }
         __syncthreads();
@@ -819,7 +851,7 @@ __global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc,
     if (h == 0) __hip_atomic_store(&x[(size_t)kk * POTRF_NB + c], sacc + red[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&flags[kk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && kk != stall_col) __hip_atomic_store(&flags[kk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (stall_col: test hook, -1 = none)
 }
 
 // The small jobs around the two kernels, one launch each instead of three memsets and two copies (at 50 cameras a solve is 0.2 ms and
@@ -852,6 +884,8 @@ struct FlowWorkspace {
     size_t sync_words = 0;
     double* pc = nullptr;                  // compact panel tiles
     long long* d_trace = nullptr;
+    long long spin_limit = FLOW_SPIN_LIMIT_TICKS;      // BSFM_FLOW_SPIN_MS
+    int stall_ticket = -1, stall_bwd_col = -1;         // test hooks: BSFM_FLOW_TEST_STALL (bulk ticket that never signals), BSFM_FLOW_TEST_STALL_BWD (column)
     int wgs = 512;                         // workgroups launched (BSFM_FLOW_WGS)
     int chain_wgs = 16;                    // of them: serve the chain queue, alone on their CU (16 or 26, see flow_prepare; BSFM_FLOW_CHAIN_WGS; 0 = one queue)
     bool trace = false;                    // BSFM_FLOW_TRACE=1: per-task stamps, dumped to BSFM_FLOW_TRACE_FILE after every solve
@@ -935,6 +969,10 @@ inline int flow_prepare(FlowWorkspace& f, int nblk, const std::vector<int>& env_
     if (f.nblk != nblk) { bsfm::dev_free(f.pc, true); f.pc = nullptr; }
     if (const char* e = getenv("BSFM_FLOW_WGS")) f.wgs = std::max(2, atoi(e));
     if (const char* e = getenv("BSFM_FLOW_TRACE")) f.trace = atoi(e) != 0;
+    f.spin_limit = FLOW_SPIN_LIMIT_TICKS; f.stall_ticket = -1; f.stall_bwd_col = -1;
+    if (const char* e = getenv("BSFM_FLOW_SPIN_MS")) f.spin_limit = std::max(1LL, (long long)atoll(e)) * 100000LL;
+    if (const char* e = getenv("BSFM_FLOW_TEST_STALL")) f.stall_ticket = atoi(e);
+    if (const char* e = getenv("BSFM_FLOW_TEST_STALL_BWD")) f.stall_bwd_col = atoi(e);
     if (flow_cached_schedule(nblk, key, flow_params_from_env(), f.sched) != 0) return -1;
     // Chain workgroups: 16 serve the sixteen blocks of the first panel tile at once, but the one that has just finished POTRF joins late;
     // a chain-bound factorisation (few tile products per column: up to ~45 dense tile columns, any envelope) gains 1-3 % from 26, a
@@ -1011,6 +1049,7 @@ inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, in
     a.tasks = f.d_tasks; a.chain_tasks = f.d_tasks + f.bulk.size(); a.n_bulk = (unsigned)f.bulk.size(); a.n_chain = (unsigned)f.chain.size();
     a.n_chain_wgs = (unsigned)f.chain_wgs; a.sync = f.d_sync; a.nflags = (unsigned)f.sched.nflags; a.info = d_info;
     a.trace = f.trace ? f.d_trace : nullptr; a.ptrace_ofs = (unsigned)(4 * nt);
+    a.spin_limit = f.spin_limit; a.stall_ticket = f.stall_ticket;
     const size_t lds_bytes = FLOW_LDS_DOUBLES * sizeof(double);
     const bool timed = w.timing && f.k0;
     if (timed) {
@@ -1025,7 +1064,8 @@ inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, in
     const bool env = (int)w.env_rows.size() >= nblk && w.d_last != nullptr;
     for (int first = 0; first < nblk; first += POTRF_MAX_TILES)
         hipLaunchKernelGGL(k_bwd_flow, dim3(std::min(POTRF_MAX_TILES, nblk - first)), dim3(256), 0, st, (const double*)f.pc, nblk, first,
-                           (const double*)w.linv, (const double*)w.y, w.xs, w.bflags, w.bflags + w.nblk, (const int*)(env ? w.d_last : nullptr));
+                           (const double*)w.linv, (const double*)w.y, w.xs, w.bflags, w.bflags + w.nblk, (const int*)(env ? w.d_last : nullptr),
+                           f.spin_limit, f.stall_bwd_col);
     hipLaunchKernelGGL(k_flow_end, dim3((unsigned)std::min(64, (n + 255) / 256)), dim3(256), 0, st, (const unsigned*)f.d_sync, (const int*)(w.bflags + w.nblk),
                        d_info, (const double*)w.xs, x_out, n);
     if (f.trace) flow_dump_trace(f, st);

@@ -254,6 +254,7 @@ struct bsfm_problem {
     std::vector<bsfm_camera_params_t> h_cams;      // the caller's camera structs (constraints, known intrinsics ...): template for bsfm_problem_append
     bsfm_problem_desc_t desc0{};                  // scalar fields of the description the problem was created from
     hipStream_t stream = nullptr; bool own_stream = false;
+    int flow_fallbacks = 0;             // solves repeated on the stream-ordered Cholesky schedule after a hand-off time-out of the dataflow launch
     bool speculate = false;            // launch the first damping attempt of an iteration before its gradient test is read (small problems; BSFM_SPECULATE=0|1)
     bsfm_allreduce_fn allreduce = nullptr; void* allreduce_ctx = nullptr;
     bsfm_comm_t* comm = nullptr;        // library-side collective (comm.hip: RCCL over xGMI); takes precedence over the hook
@@ -1197,6 +1198,7 @@ double bsfm_lm_last_kernel_ms(const bsfm_problem_t* pb, const char* phase)
     for (int i = 0; i < PH_COUNT; ++i)
         if (!strcmp(phase, kPhaseNames[i])) return pb->ph_cnt[i] ? pb->ph_ms[i] / pb->ph_cnt[i] : -1.0;
     // row kernel of the Schur complement (schur_rows.h): workgroups, pieces, dense blocks, triples it covers, segment length
+    if (!strcmp(phase, "flow_fallbacks")) return (double)pb->flow_fallbacks;
     if (!strcmp(phase, "row_wgs")) return (double)pb->n_row_wgs;
     if (!strcmp(phase, "row_pieces")) return (double)pb->n_row_pieces;
     if (!strcmp(phase, "row_blocks")) return (double)pb->n_row_blocks;
@@ -1489,6 +1491,21 @@ static int lm_iterate_impl(bsfm_problem_t* pb, int iters)
             }
             const bool singularV = flagsd[0] != 0.0;
             if (potrf_info < 0) {         // POTRF_INFO_TIMEOUT: a hand-off inside the persistent Cholesky kernels never arrived
+                // The tile-dataflow launch needs its workgroups co-resident to make progress at full speed; a GPU shared with another
+                // process can starve it beyond the spin limit.  The three-stream schedule of rounds 1-3 (same binary, same arithmetic,
+                // ordinary launches that wait for nothing but stream order) does not: this problem switches to it, warns once, and the
+                // attempt is repeated from the point inversion on -- S is rebuilt from the block sums, no LM counter has moved yet.
+                // Every rank of a multi-GPU job sees the same verdict (it rode the exchange above), so they switch together.
+                const int nblk_s = (pb->Sdim + POTRF_NB - 1) / POTRF_NB;
+                if (pb->potrf.use_flow && !pb->comps.active && nblk_s <= POTRF_MAX_TILES) {
+                    static bool warned = false;
+                    if (!warned) { warned = true;
+                        fprintf(stderr, "[bsfm] WARNING: the tile-dataflow Cholesky launch timed out waiting for its own workgroups (GPU shared with another "
+                                        "job?); falling back to the stream-ordered schedule for this problem\n"); }
+                    pb->potrf.use_flow = 0;
+                    ++pb->flow_fallbacks;
+                    continue;
+                }
                 fprintf(stderr, "[bsfm] FATAL: the reduced camera solve timed out inside its persistent kernels (info %d)\n", potrf_info);
                 pb->error = 1; g_infra_failure = 1;
                 return BSFM_ERROR;
@@ -1832,6 +1849,17 @@ static int dense_chol_solve_impl(int n, const double* A, const double* b, double
             }
         }
         if (failed) break;
+        if (hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) break;
+        if (info == POTRF_INFO_TIMEOUT && ws.use_flow && backend == 0 && ld / POTRF_NB <= POTRF_MAX_TILES) {
+            // starved dataflow launch: the same system once more on the stream-ordered schedule (see bsfm_lm_iterate)
+            fprintf(stderr, "[bsfm] WARNING: the tile-dataflow Cholesky launch timed out waiting for its own workgroups; repeating the solve on the "
+                            "stream-ordered schedule\n");
+            ws.use_flow = 0;
+            if (hipMemset(dinfo, 0, sizeof(int)) != hipSuccess) break;
+            if (hipMemcpy2D(dS, (size_t)ld * sizeof(double), A, (size_t)n * sizeof(double), (size_t)n * sizeof(double), n, hipMemcpyHostToDevice) != hipSuccess) break;
+            if (potrf_solve(ws, dS, ld, n, dE, dx, dinfo, st)) break;
+            if (hipStreamSynchronize(st) != hipSuccess) break;
+        }
         if (timed_api) {
             potrf_collect_time(ws);
             if (ws.flow) flow_collect_time(*ws.flow);

@@ -152,10 +152,9 @@ def test_ill_conditioned_reduced_camera_system(gpu_bsfm):
     assert np.abs(x - ref).max() <= 20 * cond * np.finfo(float).eps * np.abs(ref).max()
 
 
-def test_backward_substitution_timeout_word_reaches_info(gpu_bsfm):
-    """(Round 3: the opt-in variants of round 2 -- persistent panel engine, split chain, two-level blocking -- were measured slower and
-    removed from the library, scripts/archive/ keeps their source and DESIGN.md section 10 their timelines.)  What is left to pin
-    here: a normal solve reports info = 0 through the same word the persistent backward substitution's timeout is folded into."""
+def test_info_word_of_a_normal_and_of_an_indefinite_solve(gpu_bsfm):
+    """dpotrf's info through the word the persistent kernels' time-outs are folded into (sba_lapack.c:374-485: info = k for the first
+    non-positive leading minor): 0 for SPD systems of one to twenty tile columns, k for a planted negative pivot."""
     for n in (1, 129, 1000, 2500):
         A, b = spd(n, 40 + n)
         rc0, x0 = gpu_bsfm.dense_chol_solve(A, b)
@@ -165,6 +164,106 @@ def test_backward_substitution_timeout_word_reaches_info(gpu_bsfm):
         if n > 200:
             A[150, 150] = -1.0
             assert gpu_bsfm.dense_chol_solve(A, b)[0] == 151
+
+
+def test_flow_stress_bit_identity(gpu_bsfm):
+    """Random sizes and random tile envelopes through the dataflow launch (the dynamic check of the hand-off invariant stated at flow_tri,
+    chol_flow.hip.h: write-once lines have one writer, rewritten data is only touched with agent-scope accesses): every solution
+    against its scaled residual, and every system solved twice -- the same bits both times.  scripts/r4/flow_stress.py is the long
+    form (150 cases)."""
+    rng = np.random.default_rng(23)
+    for c in range(24):
+        n = int(rng.choice([rng.integers(129, 400), rng.integers(400, 1400), rng.integers(1400, 3000)], p=[0.4, 0.4, 0.2]))
+        T = (n + 127) // 128
+        env = c % 2 == 1
+        if env:
+            A = np.zeros((n, n))
+            first = [max(0, I - int(rng.integers(0, max(1, min(T, 8))))) for I in range(T)]
+            for I in range(T):
+                r0, r1 = 128 * I, min(n, 128 * (I + 1))
+                A[r0:r1, 128 * first[I]:r1] = rng.standard_normal((r1 - r0, r1 - 128 * first[I]))
+            A = np.tril(A); A = A + A.T
+        else:
+            G = rng.standard_normal((n, min(n, 96)))
+            A = G @ G.T
+        A[np.diag_indices(n)] = np.abs(A).sum(axis=1) + 1.0
+        b = rng.standard_normal(n)
+        rc, x = gpu_bsfm.dense_chol_solve(A, b, backend=2 if env else 0)
+        rc2, x2 = gpu_bsfm.dense_chol_solve(A, b, backend=2 if env else 0)
+        assert rc == 0 and rc2 == 0 and x.tobytes() == x2.tobytes(), (c, n, env)
+        assert np.abs(A @ x - b).max() <= 1e-12 * np.abs(A).max() * max(np.abs(x).max(), 1e-300), (c, n, env)
+
+
+def test_info_is_the_first_failing_minor_even_when_diagonal_tiles_run_concurrently(gpu_bsfm):
+    """Block-diagonal S (a legal envelope: tile columns with nothing below their diagonal tile): the POTRFs of independent diagonal
+    tiles run at the same time on different chain workgroups, so the failure that happens first in TIME need not be the first in the
+    MATRIX.  dpotrf reports the first failing leading minor (sba_lapack.c:374-485 passes it on): the smaller index wins."""
+    n, blk = 1536, 384
+    rng = np.random.default_rng(9)
+    i, j = np.indices((n, n))
+    A = rng.standard_normal((n, n)); A[(i // blk) != (j // blk)] = 0.0
+    A = np.tril(A); A = A + A.T
+    A[np.arange(n), np.arange(n)] = np.abs(A).sum(axis=1) + 1.0
+    b = rng.standard_normal(n)
+    for planted in ((1300, 70), (70, 1300), (900, 500, 1400), (1535, 385)):
+        Ab = A.copy()
+        for q in planted:
+            Ab[q, q] = -1.0
+        for rep in range(3):
+            assert gpu_bsfm.dense_chol_solve(Ab, b, backend=2)[0] == min(planted) + 1, (planted, rep)
+
+
+@pytest.mark.parametrize("hook,value", [("BSFM_FLOW_TEST_STALL", "9"), ("BSFM_FLOW_TEST_STALL_BWD", "3")], ids=["forward-task-never-signals", "backward-column-never-signals"])
+def test_starved_dataflow_launch_falls_back_to_the_stream_schedule(gpu_bsfm, monkeypatch, capfd, hook, value):
+    """The tile-dataflow launch (chol_flow.hip.h) waits on counters other workgroups of the same launch signal; on a GPU shared with
+    another job those workgroups may not be resident in time.  The test hooks make ONE task never signal -- a bulk task of the
+    factorisation, or one column of the backward substitution -- with the spin limit cut from 0.4 s to 20 ms: the waiters give up, the
+    launch ends with the time-out word set, and the library repeats the solve on the stream-ordered schedule of rounds 1-3 (ordinary
+    launches, nothing to wait for but stream order) with a warning instead of failing.  The answer is LAPACK's; a
+    planted negative pivot still comes back as dpotrf's info."""
+    import scipy.linalg as sl
+    monkeypatch.setenv(hook, value); monkeypatch.setenv("BSFM_FLOW_SPIN_MS", "20")
+    A, b = spd(1500, 77)
+    rc, x = gpu_bsfm.dense_chol_solve(A, b)
+    err = capfd.readouterr().err
+    assert rc == 0 and "timed out" in err and "stream-ordered" in err, err[-500:]
+    ref = sl.cho_solve(sl.cho_factor(A, lower=True), b)
+    assert np.abs(x - ref).max() <= 1e-11 * np.abs(ref).max()
+    A[700, 700] = -1.0
+    assert gpu_bsfm.dense_chol_solve(A, b)[0] == 701
+    monkeypatch.delenv(hook)
+    capfd.readouterr()
+    A, b = spd(1500, 78)
+    rc, x = gpu_bsfm.dense_chol_solve(A, b)
+    assert rc == 0 and "timed out" not in capfd.readouterr().err          # and without the hook nothing times out
+
+
+def test_starved_dataflow_launch_inside_the_lm_loop(gpu_bsfm, monkeypatch, capfd):
+    """The same inside bsfm_lm_iterate (what run_sfm runs): the attempt whose solve timed out is repeated from the point inversion on
+    with the stream-ordered schedule -- no LM counter has moved -- and the problem stays on that schedule.  Same iterations, stop code,
+    linear-system count and (to rounding: another summation order inside the tiles) the same parameters as an undisturbed run."""
+    B = gpu_bsfm
+    m, n = 72, 6000
+    s = B.synth_ba(m, n, 8, banded=True)
+
+    def run():
+        pb = B.Problem(n, m, s["rowptr"], s["colidx"], s["proj"], s["cams"], s["pts"], options=B.default_options(jacobian=B.JAC_ANALYTIC, verbose=0, itmax=6))
+        rc, info = pb.solve()
+        p, _, _ = pb.download()
+        fb = pb.phase_ms("flow_fallbacks")
+        pb.close()
+        return rc, np.array(info), p, fb
+
+    ref = run()
+    assert ref[3] == 0
+    monkeypatch.setenv("BSFM_FLOW_TEST_STALL", "5"); monkeypatch.setenv("BSFM_FLOW_SPIN_MS", "20")
+    capfd.readouterr()
+    got = run()
+    err = capfd.readouterr().err
+    assert got[3] == 1 and "falling back to the stream-ordered schedule" in err, err[-400:]
+    assert got[0] == ref[0] and list(got[1][5:10]) == list(ref[1][5:10])
+    assert abs(got[1][1] - ref[1][1]) <= 1e-10 * ref[1][1]
+    assert np.abs(got[2] - ref[2]).max() <= 1e-9 * np.abs(ref[2]).max()
 
 
 @pytest.mark.parametrize("n,half_band,seed", [(700, 90, 1), (2500, 300, 2), (1500, 64, 3), (900, 1000, 4), (2000, 1, 5), (1536, 40, 6), (1300, 200, 7)])
