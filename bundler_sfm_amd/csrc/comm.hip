@@ -350,14 +350,39 @@ bsfm_comm_t* bsfm_comm_create_from_env(void)
             I->shm_path = shm_name();
             fd = open(I->shm_path.c_str(), O_RDWR | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
             if (fd < 0 || ftruncate(fd, (off_t)I->map_bytes) != 0) { fprintf(stderr, "[bsfm] comm: cannot create %s\n", I->shm_path.c_str()); if (fd >= 0) (void)close(fd); bsfm_comm_destroy(c); return nullptr; }
-        } else {
-            if (bsfm::idfile_wait(path, world, rank, tmo, g_process_start_ns, 120.0, nonce) != 0) { bsfm_comm_destroy(c); return nullptr; }
-            I->shm_path = shm_name();
-            fd = open(I->shm_path.c_str(), O_RDWR | O_NOFOLLOW);
-            if (fd < 0) { fprintf(stderr, "[bsfm] comm: rank %d cannot open %s\n", rank, I->shm_path.c_str()); bsfm_comm_destroy(c); return nullptr; }
         }
-        void* mp = mmap(nullptr, I->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        (void)close(fd);
+        void* mp = MAP_FAILED;
+        if (rank == 0) {
+            mp = mmap(nullptr, I->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            (void)close(fd);
+        } else {
+            // The id file may still be the record of a CRASHED job on the same address and port (inside the 120 s grace window, before this
+            // job's rank 0 has replaced it): its nonce names a control block that no longer exists, or one of another world size.  That is
+            // not an error but "not yet": keep polling the id file until the time-out.
+            const auto t_first = std::chrono::steady_clock::now();
+            for (;;) {
+                const double left = tmo - std::chrono::duration<double>(std::chrono::steady_clock::now() - t_first).count();
+                if (left <= 0.0 || bsfm::idfile_wait(path, world, rank, left, g_process_start_ns, 120.0, nonce) != 0) {
+                    fprintf(stderr, "[bsfm] comm: rank %d found no live ipc control block within %.0f s (id file %s)\n", rank, tmo, path.c_str());
+                    bsfm_comm_destroy(c); return nullptr;
+                }
+                I->shm_path = shm_name();
+                fd = open(I->shm_path.c_str(), O_RDWR | O_NOFOLLOW);
+                if (fd >= 0) {
+                    struct stat stb;
+                    if (fstat(fd, &stb) == 0 && (size_t)stb.st_size >= I->map_bytes) {
+                        mp = mmap(nullptr, I->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+                        if (mp != MAP_FAILED) {
+                            IpcShared* sh = (IpcShared*)mp;
+                            if (sh->magic == bsfm::IDFILE_MAGIC && sh->world == world) { (void)close(fd); break; }
+                            (void)munmap(mp, I->map_bytes); mp = MAP_FAILED;        // another job's block
+                        }
+                    }
+                    (void)close(fd);
+                }
+                std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            }
+        }
         if (mp == MAP_FAILED) { fprintf(stderr, "[bsfm] comm: mmap of %s failed\n", I->shm_path.c_str()); bsfm_comm_destroy(c); return nullptr; }
         I->sh = (IpcShared*)mp;
         if (rank == 0) {

@@ -83,13 +83,66 @@ __device__ __forceinline__ double wave_max(double v)
     return v;
 }
 
+__device__ __forceinline__ double block_max4(double s, double* sm)      // result valid in thread 0
+{
+    { double t;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { t = __shfl_down(s, o, 64); s = t > s ? t : s; } }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    double q = sm[0];
+    for (int i = 1; i < 4; ++i) q = sm[i] > q ? sm[i] : q;
+    return q;
+}
+__device__ __forceinline__ double block_sum4(double s, double* sm)
+{
+    s = wave_sum(s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// "The last workgroup finishes the job" (round 5): the second-stage reductions -- one-block kernels of a few microseconds that only
+// existed to wait for every workgroup of the kernel before them -- run inside that kernel, in the workgroup that arrives last.  An
+// iteration of a Bundler-sized problem (14 - 50 cameras, src/BundleFast.cpp:263-438 calls run_sfm hundreds of times at that size) is
+// nothing but launch latencies: ~25 launches of 3.5 - 16 us.  Same partitions, same order of the sums, executed by one workgroup: the
+// values are bit-identical to the two-launch form (which remains for ticket == nullptr).
+// Visibility without fences (as in chol_flow.hip.h): the partial results are written with agent-scope (sc1) stores, every storing
+// thread drains them (s_waitcnt vmcnt(0)), the workgroup synchronises, ONE thread takes a ticket with an agent-scope atomic; the
+// workgroup that draws the last ticket reads the partials with agent-scope loads and puts the ticket back to zero for the next launch.
+__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool last_block_arrives(unsigned* ticket, unsigned total)
+{
+    __shared__ int s_last_block;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last_block = (t == total - 1u) ? 1 : 0;
+        if (t == total - 1u) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return s_last_block != 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // per-camera derived table: one thread per camera (m <= a few thousand; trig happens only here)
+__device__ __forceinline__ void cam_table_row(const ModelCfg& cfg, int j, const double* __restrict__ pa, const double* __restrict__ Rinit,
+                            const double* __restrict__ finit, const double* __restrict__ known, int with_fd, double* __restrict__ camtab);
 __global__ void k_cam_table(ModelCfg cfg, int m, const double* __restrict__ pa, const double* __restrict__ Rinit,
                             const double* __restrict__ finit, const double* __restrict__ known, int with_fd, double* __restrict__ camtab)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
+    cam_table_row(cfg, j, pa, Rinit, finit, known, with_fd, camtab);
+}
+__device__ __forceinline__ void cam_table_row(const ModelCfg& cfg, int j, const double* __restrict__ pa, const double* __restrict__ Rinit,
+                            const double* __restrict__ finit, const double* __restrict__ known, int with_fd, double* __restrict__ camtab)
+{
     const double* a = pa + (size_t)j * cfg.cnp;
     const double* R0 = Rinit + (size_t)j * 9;
     double* ct = camtab + (size_t)j * CT_STRIDE;
@@ -135,7 +188,8 @@ __global__ __launch_bounds__(RES_BLOCK) void k_residual(ModelCfg cfg, int nvis,
         const double* __restrict__ xc, const int* __restrict__ cam_cam, const double* __restrict__ ptc,
         const double* __restrict__ camtab,
         double* __restrict__ e_out, const double* __restrict__ e_prev, double eps5,
-        double* __restrict__ part_cost, double* __restrict__ part_pct)
+        double* __restrict__ part_cost, double* __restrict__ part_pct,
+        unsigned* __restrict__ ticket /* null: k_reduce_sum_max follows */, double* __restrict__ out_sum, double* __restrict__ out_max)
 {
     __shared__ double sm[2 * (RES_BLOCK / 64)];
     const int k = blockIdx.x * RES_BLOCK + threadIdx.x;
@@ -166,8 +220,18 @@ __global__ __launch_bounds__(RES_BLOCK) void k_residual(ModelCfg cfg, int nvis,
     if (threadIdx.x == 0) {
         double s = 0.0, q = 0.0;
         for (int i = 0; i < RES_BLOCK / 64; ++i) { s += sm[i]; q = sm[RES_BLOCK / 64 + i] > q ? sm[RES_BLOCK / 64 + i] : q; }
-        part_cost[blockIdx.x] = s;
-        if (part_pct) part_pct[blockIdx.x] = q;
+        st_agent(part_cost + blockIdx.x, s);
+        if (part_pct) st_agent(part_pct + blockIdx.x, q);
+    }
+    if (!ticket || !last_block_arrives(ticket, gridDim.x)) return;
+    {   // k_reduce_sum_max, by the workgroup that arrived last (same partition, same order)
+        __shared__ double sm2[4];
+        const int count = (int)gridDim.x;
+        double s = 0.0, m = 0.0;
+#pragma unroll 8
+        for (int t = threadIdx.x; t < count; t += 256) { s += ld_agent(part_cost + t); if (part_pct) { const double v = ld_agent(part_pct + t); m = v > m ? v : m; } }
+        const double rs = block_sum4(s, sm2), rm = block_max4(m, sm2);
+        if (threadIdx.x == 0) { *out_sum = rs; if (part_pct) *out_max = rm; }
     }
 }
 
@@ -300,7 +364,8 @@ __device__ __forceinline__ void cam_slice(const int* __restrict__ camptr, int j,
 }
 
 template <int CNP>
-__global__ __launch_bounds__(256) void k_cam_blocks(DevProblem P, const double* __restrict__ e, double* __restrict__ part)
+__global__ __launch_bounds__(256) void k_cam_blocks(DevProblem P, const double* __restrict__ e, double* __restrict__ part,
+                                                    unsigned* __restrict__ cam_ticket /* per camera; null: k_cam_blocks_fin follows */)
 {
     constexpr int NU = CNP * (CNP + 1) / 2;
     constexpr int NV = NU + CNP;
@@ -332,7 +397,26 @@ __global__ __launch_bounds__(256) void k_cam_blocks(DevProblem P, const double* 
     for (int q = 0; q < NV; ++q) { const double v = wave_sum(acc[q]); if (lane == 0) sm[w][q] = v; }
     __syncthreads();
     if (threadIdx.x < NV)
-        part[(size_t)blockIdx.x * NV + threadIdx.x] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+        st_agent(part + (size_t)blockIdx.x * NV + threadIdx.x, (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]));
+    if (!cam_ticket || !last_block_arrives(cam_ticket + j, CAM_SPLIT)) return;
+    {   // k_cam_blocks_fin for camera j: the CAM_SPLIT slice rows in slice order (the same sums, the same order)
+        const double* pj = part + (size_t)j * CAM_SPLIT * NV;
+        if (threadIdx.x < CNP * CNP) {
+            const int r = threadIdx.x / CNP, c = threadIdx.x % CNP;
+            const int rr = r < c ? r : c, cc = r < c ? c : r;
+            const int u = rr * CNP - rr * (rr - 1) / 2 + (cc - rr);
+            double v = 0.0;
+#pragma unroll
+            for (int sl = 0; sl < CAM_SPLIT; ++sl) v += ld_agent(pj + sl * NV + u);
+            P.U[(size_t)j * CNP * CNP + threadIdx.x] = v;
+        } else if (threadIdx.x < CNP * CNP + CNP) {
+            const int u = NU + (threadIdx.x - CNP * CNP);
+            double v = 0.0;
+#pragma unroll
+            for (int sl = 0; sl < CAM_SPLIT; ++sl) v += ld_agent(pj + sl * NV + u);
+            P.ea[(size_t)j * CNP + (threadIdx.x - CNP * CNP)] = v;
+        }
+    }
 }
 
 template <int CNP>
@@ -551,13 +635,42 @@ __global__ __launch_bounds__(256) void k_unpermute_step(int count, int cnp, cons
     if (t < count) dpa[t] = x[(size_t)spos[t / cnp] * cnp + t % cnp];
 }
 
+// sum of the three block-partial rows of k_backsub + the camera part of the step (k_step_sums' job; see there)
+__device__ __forceinline__ void step_sums_body(int count, int fixed, double mu, const double* __restrict__ pa,
+        const double* __restrict__ dpa, const double* __restrict__ ea, double* __restrict__ pdpa, double* __restrict__ out3,
+        const double* __restrict__ part, int nbp, double* __restrict__ pt3, bool agent_loads)
+{
+    __shared__ double sm[4];
+    double s_dp = 0, s_p = 0, s_dl = 0;
+    for (int t = threadIdx.x; t < count; t += 256) {
+        const double d = (t < fixed) ? 0.0 : dpa[t], p = pa[t];
+        pdpa[t] = p + d;
+        s_dp += d * d; s_p += p * p; s_dl += d * (mu * d + ea[t]);
+    }
+    const double r0 = block_sum4(s_dp, sm), r1 = block_sum4(s_p, sm), r2 = block_sum4(s_dl, sm);
+    double q[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double s = 0.0;
+#pragma unroll 8
+        for (int t = threadIdx.x; t < nbp; t += 256) s += agent_loads ? ld_agent(part + (size_t)c * nbp + t) : part[(size_t)c * nbp + t];
+        q[c] = block_sum4(s, sm);
+    }
+    if (threadIdx.x == 0) { out3[0] = r0; out3[1] = r1; out3[2] = r2; pt3[0] = q[0]; pt3[1] = q[1]; pt3[2] = q[2]; }
+}
+struct StepFinalArgs {       // k_step_sums' and k_cam_table's arguments, for the workgroup of k_backsub that arrives last
+    int count, fixed; const double* pa; double* pdpa; double* out3; double* pt3;
+    const double* known; int with_fd; double* camtab_trial;
+};
+
 // ---------------------------------------------------------------------------------------------------
 // db_i = V*_i^-1 (eb_i - sum_j W_ij^T da_j), W_ij^T da_j = B_ij^T (A_ij da_j); thread per point.
 // Also writes pdp_b = p_b + db and block partials of sum db^2, sum p_b^2 and sum db (mu db + eb).
 template <int CNP>
 __global__ __launch_bounds__(256) void k_backsub(DevProblem P, double mu, const double* __restrict__ dpa,
         const double* __restrict__ pb, double* __restrict__ dpb, double* __restrict__ pdpb,
-        double* __restrict__ part /* [3][gridDim.x] */, double* __restrict__ ptc_out /* camera-major mirror of pdpb, or null */)
+        double* __restrict__ part /* [3][gridDim.x] */, double* __restrict__ ptc_out /* camera-major mirror of pdpb, or null */,
+        unsigned* __restrict__ ticket /* null: k_step_sums and k_cam_table follow */, StepFinalArgs fa)
 {
     __shared__ double sm[3][4];
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -603,8 +716,15 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem P, double mu, const 
     if ((threadIdx.x & 63) == 0) { sm[0][w] = s_dp; sm[1][w] = s_p; sm[2][w] = s_dl; }
     __syncthreads();
     if (threadIdx.x < 3)
-        part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
-            (sm[threadIdx.x][0] + sm[threadIdx.x][1]) + (sm[threadIdx.x][2] + sm[threadIdx.x][3]);
+        st_agent(part + (size_t)threadIdx.x * gridDim.x + blockIdx.x,
+                 (sm[threadIdx.x][0] + sm[threadIdx.x][1]) + (sm[threadIdx.x][2] + sm[threadIdx.x][3]));
+    if (!ticket || !last_block_arrives(ticket, gridDim.x)) return;
+    // k_step_sums (camera part of the step, sums of the point partials) and the camera table of the trial point, by the workgroup that
+    // arrived last: pdp_a is written and read inside this workgroup (a barrier in between)
+    step_sums_body(fa.count, fa.fixed, mu, fa.pa, dpa, P.ea, fa.pdpa, fa.out3, part, (int)gridDim.x, fa.pt3, true);
+    __syncthreads();
+    for (int j = threadIdx.x; j < P.m; j += 256)
+        cam_table_row(P.cfg, j, fa.pdpa, P.Rinit, P.finit, fa.known, fa.with_fd, fa.camtab_trial);
 }
 
 // camera part of the step: pdp_a = p_a + dp_a and sum dpa^2, sum pa^2, sum dpa (mu dpa + ea) (single block).
@@ -841,29 +961,19 @@ __global__ __launch_bounds__(64) void k_cam_solve(DevProblem P, double mu, doubl
 //   k_iter_partials (256 blocks): max |eb|, max diag V, sum p_b^2 over the block's slice -> part[0..255], [256..511], [512..767]
 //   k_iter_final    (1 block)  : reduces those, and computes max |ea|, max diag U, sum p_a^2, the constraint cost and
 //                                (multi-GPU) its point part.
-__device__ __forceinline__ double block_max4(double s, double* sm)      // result valid in thread 0
-{
-    { double t;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { t = __shfl_down(s, o, 64); s = t > s ? t : s; } }
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
-    __syncthreads();
-    double q = sm[0];
-    for (int i = 1; i < 4; ++i) q = sm[i] > q ? sm[i] : q;
-    return q;
-}
-__device__ __forceinline__ double block_sum4(double s, double* sm)
-{
-    s = wave_sum(s);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
-    __syncthreads();
-    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
-}
+struct IterFinalArgs {       // what k_iter_final is given (so that k_iter_partials can do its job in the workgroup that arrives last)
+    const double* pa; int have_points, point_part_slot;
+    int s_eabinf_a, s_eabinf_b, s_maxdiag_u, s_maxdiag_v, s_pl2_a, s_pl2_b, s_ccost;
+    double* scal;
+};
+__device__ __forceinline__ void iter_final_body(const DevProblem& P, const double* __restrict__ pa, const double* __restrict__ pb,
+        const double* __restrict__ part, int have_points, int point_part_slot,
+        int s_eabinf_a, int s_eabinf_b, int s_maxdiag_u, int s_maxdiag_v, int s_pl2_a, int s_pl2_b, int s_ccost,
+        double* __restrict__ scal, bool agent_loads);
 
 __global__ __launch_bounds__(256) void k_iter_partials(const double* __restrict__ eb, const double* __restrict__ V,
-        const double* __restrict__ pb, int n, double* __restrict__ part)
+        const double* __restrict__ pb, int n, double* __restrict__ part, unsigned* __restrict__ ticket /* null: k_iter_final follows */,
+        DevProblem P, IterFinalArgs fa)
 {
     __shared__ double sm[4];
     const size_t cnt3 = (size_t)3 * n;
@@ -879,7 +989,10 @@ __global__ __launch_bounds__(256) void k_iter_partials(const double* __restrict_
         vd = b > vd ? b : vd;
     }
     const double ra = block_max4(a, sm), rv = block_max4(vd, sm), rs = block_sum4(ss, sm);
-    if (threadIdx.x == 0) { part[blockIdx.x] = ra; part[256 + blockIdx.x] = rv; part[512 + blockIdx.x] = rs; }
+    if (threadIdx.x == 0) { st_agent(part + blockIdx.x, ra); st_agent(part + 256 + blockIdx.x, rv); st_agent(part + 512 + blockIdx.x, rs); }
+    if (!ticket || !last_block_arrives(ticket, gridDim.x)) return;
+    iter_final_body(P, fa.pa, pb, part, fa.have_points, fa.point_part_slot, fa.s_eabinf_a, fa.s_eabinf_b, fa.s_maxdiag_u, fa.s_maxdiag_v,
+                    fa.s_pl2_a, fa.s_pl2_b, fa.s_ccost, fa.scal, true);
 }
 
 __global__ __launch_bounds__(256) void k_iter_final(DevProblem P, const double* __restrict__ pa, const double* __restrict__ pb,
@@ -887,12 +1000,20 @@ __global__ __launch_bounds__(256) void k_iter_final(DevProblem P, const double* 
         int s_eabinf_a, int s_eabinf_b, int s_maxdiag_u, int s_maxdiag_v, int s_pl2_a, int s_pl2_b, int s_ccost,
         double* __restrict__ scal)
 {
+    iter_final_body(P, pa, pb, part, have_points, point_part_slot, s_eabinf_a, s_eabinf_b, s_maxdiag_u, s_maxdiag_v, s_pl2_a, s_pl2_b, s_ccost, scal, false);
+}
+__device__ __forceinline__ void iter_final_body(const DevProblem& P, const double* __restrict__ pa, const double* __restrict__ pb,
+        const double* __restrict__ part, int have_points, int point_part_slot,
+        int s_eabinf_a, int s_eabinf_b, int s_maxdiag_u, int s_maxdiag_v, int s_pl2_a, int s_pl2_b, int s_ccost,
+        double* __restrict__ scal, bool agent_loads)
+{
     __shared__ double sm[4];
     const int cnp = P.cfg.cnp, t = threadIdx.x;
     if (have_points) {
-        double a = part[t];        a = a > 0.0 ? a : 0.0;                   // k_reduce_max starts from 0
-        double v = part[256 + t];  v = v > 0.0 ? v : 0.0;
-        const double ra = block_max4(a, sm), rv = block_max4(v, sm), rs = block_sum4(part[512 + t], sm);
+        double a = agent_loads ? ld_agent(part + t) : part[t];                   a = a > 0.0 ? a : 0.0;                   // k_reduce_max starts from 0
+        double v = agent_loads ? ld_agent(part + 256 + t) : part[256 + t];       v = v > 0.0 ? v : 0.0;
+        const double p512 = agent_loads ? ld_agent(part + 512 + t) : part[512 + t];
+        const double ra = block_max4(a, sm), rv = block_max4(v, sm), rs = block_sum4(p512, sm);
         if (t == 0) { scal[s_eabinf_b] = ra; scal[s_maxdiag_v] = rv; scal[s_pl2_b] = rs; }
     }
     double ea = 0.0, ud = -DBL_MAX, ps = 0.0;
@@ -931,23 +1052,7 @@ __global__ __launch_bounds__(256) void k_step_sums(int count, int fixed, double 
         const double* __restrict__ dpa, const double* __restrict__ ea, double* __restrict__ pdpa, double* __restrict__ out3,
         const double* __restrict__ part, int nbp, double* __restrict__ pt3)
 {
-    __shared__ double sm[4];
-    double s_dp = 0, s_p = 0, s_dl = 0;
-    for (int t = threadIdx.x; t < count; t += 256) {
-        const double d = (t < fixed) ? 0.0 : dpa[t], p = pa[t];
-        pdpa[t] = p + d;
-        s_dp += d * d; s_p += p * p; s_dl += d * (mu * d + ea[t]);
-    }
-    const double r0 = block_sum4(s_dp, sm), r1 = block_sum4(s_p, sm), r2 = block_sum4(s_dl, sm);
-    double q[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        double s = 0.0;
-#pragma unroll 8
-        for (int t = threadIdx.x; t < nbp; t += 256) s += part[(size_t)c * nbp + t];
-        q[c] = block_sum4(s, sm);
-    }
-    if (threadIdx.x == 0) { out3[0] = r0; out3[1] = r1; out3[2] = r2; pt3[0] = q[0]; pt3[1] = q[1]; pt3[2] = q[2]; }
+    step_sums_body(count, fixed, mu, pa, dpa, ea, pdpa, out3, part, nbp, pt3, false);
 }
 
 // cost sum and Snavely pct-change max of the residual pass in one launch

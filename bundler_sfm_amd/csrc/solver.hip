@@ -231,6 +231,7 @@ struct bsfm_problem {
     double *d_scal = nullptr;
     double *d_mixed = nullptr;          // staging of allreduce_mixed: a few sums + world slots per maximum
     int *d_flags = nullptr;             // [0] singular V, [1] potrf info
+    unsigned* d_tickets = nullptr;      // "last workgroup finishes the job" tickets (kernels.hip.h): [0] residual, [1] iteration scalars, [2] back-substitution, [8 ..) one per camera
     // schur structure
     int ntriples = 0, ntasks = 0, nblk = 0;
     int2* d_triples = nullptr; SchurTask* d_tasks = nullptr; int* d_tri_pt = nullptr;
@@ -282,7 +283,7 @@ void free_all(bsfm_problem* pb)
     void* ptrs[] = { pb->d_x, pb->d_xc, pb->d_Rinit, pb->d_finit, pb->d_known, pb->d_obs_cam, pb->d_obs_pt, pb->d_rowptr, pb->d_camptr,
                      pb->d_camobs, pb->d_campos, pb->d_cam_pt, pb->d_cam_cam, pb->d_Ac, pb->d_Bc, pb->d_Cc, pb->d_ccon, pb->d_pcon, pb->d_cval, pb->d_cw, pb->d_pval, pb->d_p, pb->d_pdp,
                      pb->d_dp, pb->d_camtab, pb->d_camtab_trial, pb->d_e, pb->d_hx, pb->d_ptc[0], pb->d_ptc[1], pb->d_U,
-                     pb->d_V, pb->d_Vinv, pb->d_eb, pb->d_S, pb->d_E, pb->d_partials, pb->d_epart, pb->d_campart, pb->d_red, pb->d_scal, pb->d_mixed,
+                     pb->d_V, pb->d_Vinv, pb->d_eb, pb->d_S, pb->d_E, pb->d_partials, pb->d_epart, pb->d_campart, pb->d_red, pb->d_scal, pb->d_mixed, pb->d_tickets,
                      pb->d_triples, pb->d_tri_pt, pb->d_tasks, pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0,
                      pb->d_row_wgs, pb->d_row_pieces, pb->d_blk_row0, pb->d_blk_range, pb->d_row_tri, pb->d_tasks_launch != pb->d_tasks ? (void*)pb->d_tasks_launch : nullptr,
                      pb->d_gidx, pb->d_gblk_j, pb->d_gblk_k, pb->d_G, pb->d_spos, pb->d_xperm };
@@ -413,14 +414,15 @@ void launch_residual(bsfm_problem* pb, const double* camtab, const double* p_poi
     if (pb->P.nvis > 0 && pb->d_known)
         hipLaunchKernelGGL(k_residual<true>, dim3(nb), dim3(RES_BLOCK), 0, pb->stream, pb->P.cfg, pb->P.nvis, pb->d_xc,
                            pb->d_cam_cam, ptc, camtab, e_out, e_prev, pb->opt.opts[5], pc,
-                           e_prev ? pp : nullptr);
+                           e_prev ? pp : nullptr, pb->d_tickets + 0, pb->d_scal + cost_slot, pb->d_scal + SC_PCT);
     if (pb->P.nvis > 0 && !pb->d_known)
         hipLaunchKernelGGL(k_residual<false>, dim3(nb), dim3(RES_BLOCK), 0, pb->stream, pb->P.cfg, pb->P.nvis, pb->d_xc,
                            pb->d_cam_cam, ptc, camtab, e_out, e_prev, pb->opt.opts[5], pc,
-                           e_prev ? pp : nullptr);
-    const int cnt = pb->P.nvis > 0 ? nb : 0;
-    hipLaunchKernelGGL(k_reduce_sum_max, dim3(1), dim3(256), 0, pb->stream, pc, e_prev ? pp : (const double*)nullptr, cnt,
-                       pb->d_scal + cost_slot, pb->d_scal + SC_PCT);
+                           e_prev ? pp : nullptr, pb->d_tickets + 0, pb->d_scal + cost_slot, pb->d_scal + SC_PCT);
+    // (the sum over the workgroups' partial costs -- k_reduce_sum_max -- is done by the workgroup of k_residual that arrives last)
+    if (pb->P.nvis <= 0)
+        hipLaunchKernelGGL(k_reduce_sum_max, dim3(1), dim3(256), 0, pb->stream, pc, e_prev ? pp : (const double*)nullptr, 0,
+                           pb->d_scal + cost_slot, pb->d_scal + SC_PCT);
 }
 
 int read_scalars(bsfm_problem* pb)
@@ -522,8 +524,8 @@ int compute_normal_blocks(bsfm_problem* pb)
     }
     ph_end(pb, PH_JAC);
     ph_begin(pb, PH_CAMBLK);
-    DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_cam_blocks<C>), dim3(P.m * CAM_SPLIT), dim3(256), 0, pb->stream, P, pb->d_e, pb->d_campart));
-    DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_cam_blocks_fin<C>), dim3(P.m), dim3(128), 0, pb->stream, P, pb->d_campart));
+    // (k_cam_blocks_fin's sums over the CAM_SPLIT slices of a camera are done by the slice workgroup that arrives last)
+    DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_cam_blocks<C>), dim3(P.m * CAM_SPLIT), dim3(256), 0, pb->stream, P, pb->d_e, pb->d_campart, pb->d_tickets + 8));
     ph_end(pb, PH_CAMBLK);
     if (pb->world > 1) {   // U and ea are sums over ALL points: exchange step 1, 90*m doubles
         if (allreduce_dev(pb, pb->d_U, (size_t)P.m * cnp * cnp + (size_t)P.m * cnp, 0)) return BSFM_ERROR;   // ea follows U
@@ -874,6 +876,8 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     pb->red_blocks = std::max(grid_for(nvis, RES_BLOCK), std::max(grid_for(n, 256), 1024));
     DM(pb->d_red, 4 * (size_t)pb->red_blocks); DM(pb->d_scal, SC_COUNT + 16 + 2); DM(pb->d_mixed, 8 + 4 * (size_t)std::max(1, d->world_size));
     pb->d_flags = reinterpret_cast<int*>(pb->d_scal + SC_COUNT + 16);      // 4 ints behind the scalars: both travel in one copy
+    DM(pb->d_tickets, 8 + (size_t)m);
+    if (hipMemsetAsync(pb->d_tickets, 0, (8 + (size_t)m) * sizeof(unsigned), pb->stream) != hipSuccess) return fail("tickets");
 #undef DM
     if (nvis > 0) hipLaunchKernelGGL(k_permute16, dim3(grid_for(nvis, 256)), dim3(256), 0, pb->stream, nvis, pb->d_camobs, pb->d_x, pb->d_xc);   // measurements in camera-major order
     if (hipHostMalloc((void**)&pb->h_scal, (SC_COUNT + 16 + 2) * sizeof(double)) != hipSuccess) return fail("pinned");
@@ -1399,10 +1403,12 @@ static int lm_iterate_impl(bsfm_problem_t* pb, int iters)
         if (compute_normal_blocks(pb)) return BSFM_ERROR;
         ++pb->njev;
         // ||J^T e||_inf, ||p||^2, max diagonal (sba_levmar.c:1085-1128)
-        hipLaunchKernelGGL(k_iter_partials, dim3(256), dim3(256), 0, pb->stream, pb->d_eb, pb->d_V, d_pb, P.n, pb->d_red);
-        hipLaunchKernelGGL(k_iter_final, dim3(1), dim3(256), 0, pb->stream, P, d_pa, d_pb, pb->d_red, 1,
-                           pb->world > 1 ? SC_COUNT + 8 : -1, (int)SC_EABINF_A, (int)SC_EABINF_B, (int)SC_MAXDIAG_U, (int)SC_MAXDIAG_V,
-                           (int)SC_PL2_A, (int)SC_PL2_B, (int)SC_CCOST, pb->d_scal);
+        {   // (k_iter_final's job is done by the workgroup of k_iter_partials that arrives last)
+            IterFinalArgs fa; fa.pa = d_pa; fa.have_points = 1; fa.point_part_slot = pb->world > 1 ? SC_COUNT + 8 : -1;
+            fa.s_eabinf_a = SC_EABINF_A; fa.s_eabinf_b = SC_EABINF_B; fa.s_maxdiag_u = SC_MAXDIAG_U; fa.s_maxdiag_v = SC_MAXDIAG_V;
+            fa.s_pl2_a = SC_PL2_A; fa.s_pl2_b = SC_PL2_B; fa.s_ccost = SC_CCOST; fa.scal = pb->d_scal;
+            hipLaunchKernelGGL(k_iter_partials, dim3(256), dim3(256), 0, pb->stream, pb->d_eb, pb->d_V, d_pb, P.n, pb->d_red, pb->d_tickets + 1, P, fa);
+        }
         // The gradient norm / parameter norm / largest diagonal of this iteration (sba_levmar.c:1085-1130).  They cost a round trip to the
         // host, and on a 14-camera problem a round trip is a tenth of the iteration -- so from the second iteration on (mu is known
         // then) the first damping attempt is launched BEFORE they are read and they come back with the attempt's own scalars.  If the
@@ -1458,15 +1464,21 @@ static int lm_iterate_impl(bsfm_problem_t* pb, int iters)
             if (P.mcon > 0) (void)hipMemsetAsync(d_dpa, 0, (size_t)P.mcon * cnp * sizeof(double), pb->stream);
             ph_begin(pb, PH_BACKSUB);
             if (P.n > 0) {
+                // back-substitution; its last workgroup also does the camera part of the step with the sums (k_step_sums) and the camera
+                // table of the trial point (k_cam_table): three launches in one
                 const int ms = trial_mirror_slot(pb);            // the trial points also go to the camera-major mirror the residual kernel streams
-                DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_backsub<C>), dim3(nbp), dim3(256), 0, pb->stream, P, mu, d_dpa, d_pb, d_dpb, d_pdpb, pb->d_red, pb->d_ptc[ms]));
+                StepFinalArgs fa; fa.count = P.m * cnp; fa.fixed = P.mcon * cnp; fa.pa = d_pa; fa.pdpa = d_pdpa; fa.out3 = pb->d_scal + SC_CAM3;
+                fa.pt3 = pb->d_scal + SC_PT_DP; fa.known = pb->d_known; fa.with_fd = pb->opt.jacobian == BSFM_JAC_FD ? 1 : 0; fa.camtab_trial = pb->d_camtab_trial;
+                DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_backsub<C>), dim3(nbp), dim3(256), 0, pb->stream, P, mu, d_dpa, d_pb, d_dpb, d_pdpb, pb->d_red, pb->d_ptc[ms],
+                                                      pb->d_tickets + 2, fa));
                 pb->ptc_tag[ms] = pb->d_pdp;
+            } else {
+                hipLaunchKernelGGL(k_step_sums, dim3(1), dim3(256), 0, pb->stream, P.m * cnp, P.mcon * cnp, mu, d_pa, d_dpa, pb->d_ea, d_pdpa,
+                                   pb->d_scal + SC_CAM3, pb->d_red, 0, pb->d_scal + SC_PT_DP);
+                launch_cam_table(pb, pb->d_pdp, pb->d_camtab_trial);
             }
-            hipLaunchKernelGGL(k_step_sums, dim3(1), dim3(256), 0, pb->stream, P.m * cnp, P.mcon * cnp, mu, d_pa, d_dpa, pb->d_ea, d_pdpa,
-                               pb->d_scal + SC_CAM3, pb->d_red, P.n > 0 ? nbp : 0, pb->d_scal + SC_PT_DP);
             ph_end(pb, PH_BACKSUB);
             ph_begin(pb, PH_RESID);
-            launch_cam_table(pb, pb->d_pdp, pb->d_camtab_trial);
             launch_residual(pb, pb->d_camtab_trial, pb->d_pdp, pb->d_hx, pb->d_e, SC_COST_TRIAL);
             ph_end(pb, PH_RESID);
             if (read_scalars(pb)) return BSFM_ERROR;
