@@ -44,10 +44,13 @@ struct FlowArgs {
     double* E;             // right-hand side (working copy, ld)
     double* y;             // y = L^-1 E
     const FlowTask* tasks;        // bulk queue
-    const FlowTask* chain_tasks;  // chain queue
+    const FlowTask* chain_tasks;  // chain queue (without the POTRFs when n_potrf > 0)
+    const FlowTask* potrf_tasks;  // round 5: the POTRFs as a queue of their own, served by ONE workgroup (the first to claim a chain CU) -- the ~16 KB of
+                                  // POTRF code stay in that CU's instruction cache: the first block factorisation of a tile took 4.5 us cold, 1.6 warm
+    unsigned n_potrf;
     unsigned n_bulk, n_chain;
     unsigned n_chain_wgs;  // workgroups that serve the chain queue, each alone on its CU (0: one queue order is not split -- n_chain must be 0 then)
-    unsigned* sync;        // [0] bulk ticket, [1] time-out word, [2] chain ticket, [3] chain claims, [4 .. 4 + nflags) per-tile counters,
+    unsigned* sync;        // [0] bulk ticket, [1] time-out word, [2] chain ticket, [3] chain claims, [4] POTRF ticket, [8 .. 8 + nflags) per-tile counters,
                            // then FLOW_CU_KEYS arrivals per CU and FLOW_CU_KEYS verdicts per CU
     unsigned nflags;
     int* info;
@@ -164,6 +167,28 @@ __device__ __forceinline__ void flow_gemm_nt(const double* __restrict__ A, int l
 // branches on values the compiler takes for lane-divergent are linearised lane by lane -- around barriers that is not a
 // performance matter but a correctness one (see the note at k_chol_flow).
 #define BSFM_UNIFORM_INT(x) x = __builtin_amdgcn_readfirstlane(x)
+// The launch arguments, read where they are: in the KERNEL-ARGUMENT SEGMENT, through scalar loads (round 5).  Handing `const FlowArgs&` to
+// the role functions made the kernel copy the struct to scratch (nine scratch stores at entry) and every role read it back through
+// flat loads -- ~20 memory round trips at the start of every task, on the chain of the factorisation.  FlowArgs is the kernel's first
+// (only) argument, so it sits at offset 0 of the segment; values loaded from the constant address space are uniform by construction.
+static_assert(sizeof(FlowArgs) % 8 == 0, "FlowArgs is copied word by word out of the kernel-argument segment");
+typedef const unsigned long long __attribute__((address_space(4))) * FlowKWords;      // the kernel-argument segment, as the kernel hands it to its roles
+__device__ __forceinline__ FlowArgs flow_kernel_args(FlowKWords p)
+{
+    union U { FlowArgs a; unsigned long long w[sizeof(FlowArgs) / 8]; __device__ U() {} } u;
+#pragma unroll
+    for (unsigned q = 0; q < sizeof(FlowArgs) / 8; ++q) u.w[q] = p[q];
+    return u.a;
+}
+__device__ __forceinline__ FlowArgs flow_uniform_args(const FlowArgs& a);
+// How a role gets the launch arguments: the latency build (V = 2) straight out of the kernel-argument segment; the throughput build
+// (V = 4, 128 VGPRs) keeps the by-reference copy of round 4 -- there the scalar copies cost registers the tile product needs (measured:
+// n = 9 000 6.56 -> 6.65 ms with the segment reads, 3 712 on the same build 1.68 -> 1.60).
+template <int V> __device__ __forceinline__ FlowArgs flow_role_args(FlowKWords ka, const FlowArgs* a_in)
+{
+    if (V == 2) return flow_kernel_args(ka);
+    return flow_uniform_args(*a_in);
+}
 __device__ __forceinline__ FlowArgs flow_uniform_args(const FlowArgs& a)
 {
     FlowArgs u = a;
@@ -176,10 +201,10 @@ __device__ __forceinline__ FlowArgs flow_uniform_args(const FlowArgs& a)
     return u;
 }
 
-template <int MR>
-__device__ BSFM_FLOW_ROLE void flow_upd(const FlowArgs& a_in, int i, int j, int p0, int np, int r0, double* lds)
+template <int MR, int V>
+__device__ __forceinline__ void flow_upd_impl(FlowKWords ka, const FlowArgs* a_in, int i, int j, int p0, int np, int r0, double* lds)
 {
-    const FlowArgs a = flow_uniform_args(a_in); BSFM_UNIFORM_INT(i); BSFM_UNIFORM_INT(j); BSFM_UNIFORM_INT(p0); BSFM_UNIFORM_INT(np); BSFM_UNIFORM_INT(r0);
+    const FlowArgs a = flow_role_args<V>(ka, a_in); BSFM_UNIFORM_INT(i); BSFM_UNIFORM_INT(j); BSFM_UNIFORM_INT(p0); BSFM_UNIFORM_INT(np); BSFM_UNIFORM_INT(r0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = (wave >> 1) * (MR / 4), wc = (wave & 1) * 64;
     double* Sij = a.S + ((size_t)i * POTRF_NB + r0) * a.ld + (size_t)j * POTRF_NB;
@@ -210,9 +235,10 @@ __device__ BSFM_FLOW_ROLE void flow_upd(const FlowArgs& a_in, int i, int j, int 
 }
 
 // ---- TRSM64: rows [r0, r0 + 64) of P_ik = S_ik W_k^T -> compact panel tile.
-__device__ BSFM_FLOW_ROLE void flow_trsm64(const FlowArgs& a_in, int i, int k, int r0, double* lds)
+template <int V>
+__device__ __forceinline__ void flow_trsm64_impl(FlowKWords ka, const FlowArgs* a_in, int i, int k, int r0, double* lds)
 {
-    const FlowArgs a = flow_uniform_args(a_in); BSFM_UNIFORM_INT(i); BSFM_UNIFORM_INT(k); BSFM_UNIFORM_INT(r0);
+    const FlowArgs a = flow_role_args<V>(ka, a_in); BSFM_UNIFORM_INT(i); BSFM_UNIFORM_INT(k); BSFM_UNIFORM_INT(r0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = (wave >> 1) * 16, wc = (wave & 1) * 64;
     double acc[4][4];
@@ -235,10 +261,10 @@ __device__ BSFM_FLOW_ROLE void flow_trsm64(const FlowArgs& a_in, int i, int k, i
 // 16 x 16 block each on two accumulator chains -- bounded by one global-load round trip):
 //   TRSM32, part = 4 br + bc:  block (br, bc) of P_ik = S_ik W_k^T, K = 32 (bc + 1) (W is lower triangular)
 //   UPD32,  part -> (br, bc), bc <= br:  block of S_jj -= sum_p P_jp P_jp^T
-template <bool IS_UPD>
-__device__ BSFM_FLOW_ROLE void flow_tile32(const FlowArgs& a_in, int i, int k, int p0, int np, int part, double* lds)
+template <bool IS_UPD, int V>
+__device__ __forceinline__ void flow_tile32_impl(FlowKWords ka, const FlowArgs* a_in, int i, int k, int p0, int np, int part, double* lds)
 {
-    const FlowArgs a = flow_uniform_args(a_in); BSFM_UNIFORM_INT(i); BSFM_UNIFORM_INT(k); BSFM_UNIFORM_INT(p0); BSFM_UNIFORM_INT(np); BSFM_UNIFORM_INT(part);
+    const FlowArgs a = flow_role_args<V>(ka, a_in); BSFM_UNIFORM_INT(i); BSFM_UNIFORM_INT(k); BSFM_UNIFORM_INT(p0); BSFM_UNIFORM_INT(np); BSFM_UNIFORM_INT(part);
     int br, bc;
     if (!IS_UPD) { br = part >> 2; bc = part & 3; }
     else { br = part < 1 ? 0 : part < 3 ? 1 : part < 6 ? 2 : 3; bc = part - br * (br + 1) / 2; }
@@ -390,7 +416,7 @@ template <> struct FlowA1Out<16> { static __device__ __forceinline__ void run(do
 
 // A1 as a function of its own (its 64 live doubles + the calling wave's tile blocks do not fit 128 VGPRs in one body): reads the block
 // from LDS (one lane per row), leaves inv(L_ss) there; returns the index of the first non-positive pivot or -1.
-__device__ __attribute__((noinline)) int flow_factor16(double* blk, int lane_in)
+__device__ __forceinline__ int flow_factor16_body(double* blk, int lane_in)
 {
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
@@ -406,6 +432,10 @@ __device__ __attribute__((noinline)) int flow_factor16(double* blk, int lane_in)
     FlowA1Out<0>::run(blk, x, mysq, r, lane < 16);
     return bad;
 }
+// V = 4 (128 VGPRs): a function of its own (see above).  V = 2 (the 256-VGPR latency variant, round 5): inlined -- its 64 live doubles fit
+// beside the caller's tile blocks, and the call cost a save / restore of the callee-saved registers through scratch on the critical path.
+template <int V> __device__ __attribute__((noinline)) int flow_factor16(double* blk, int lane_in) { return flow_factor16_body(blk, lane_in); }
+template <> __device__ __forceinline__ int flow_factor16<2>(double* blk, int lane_in) { return flow_factor16_body(blk, lane_in); }
 
 // ---- POTRF: the diagonal tile, factor and inverse, in the footprint of a bulk workgroup.
 // The lower triangle of the tile is 36 blocks of 16 x 16.  Every block has ONE owner wave that holds it in registers in the
@@ -427,9 +457,10 @@ __device__ __attribute__((noinline)) int flow_factor16(double* blk, int lane_in)
 __device__ const unsigned long long kFlowPotrfSlots[8] = {      // 5 slots per wave, 8 bits each: I << 4 | J, 0xff = empty; sorted by (J, I)
     0xff65537200ull, 0xff75631110ull, 0xff44732120ull, 0xff54223130ull, 0x7764324140ull, 0x6674425150ull, 0x7633526160ull, 0x5543627170ull };
 
-__device__ BSFM_FLOW_ROLE void flow_potrf(const FlowArgs& a_in, int k, double* lds)
+template <int V>
+__device__ __forceinline__ void flow_potrf_impl(FlowKWords ka, const FlowArgs* a_in, int k, double* lds)
 {
-    const FlowArgs a = flow_uniform_args(a_in); BSFM_UNIFORM_INT(k);
+    const FlowArgs a = flow_role_args<V>(ka, a_in); BSFM_UNIFORM_INT(k);
     double* Lb = lds + FLOW_LB; double* Di = lds + FLOW_DI;
     const int tid = threadIdx.x, lane0 = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -563,7 +594,8 @@ __device__ BSFM_FLOW_ROLE void flow_potrf(const FlowArgs& a_in, int k, double* l
 #pragma unroll
             for (int q = 0; q < 4; ++q) blk[swz16(4 * q + lr, lc)] = cur[q];
             BSFM_LDS_FENCE();
-            const int bad = flow_factor16(blk, lane);
+            const int bad = flow_factor16<V>(blk, lane);
+            if (s < 0) BSFM_FLOW_MARK(3);
             if (lane == 0 && bad >= 0 && base + 16 * sn + bad < n_total) {
                 // dpotrf's info is the FIRST failing leading minor.  With an envelope whose diagonal tiles are independent (block-diagonal S)
                 // POTRFs of different columns run concurrently, so "first in time" is not "first in the matrix": keep the minimum
@@ -655,11 +687,30 @@ __device__ BSFM_FLOW_ROLE void flow_potrf(const FlowArgs& a_in, int k, double* l
 #undef BSFM_LDS_FENCE
 }
 
+// Role entry points.  Throughput build (V = 4, 128 VGPRs): functions of their own -- inlined into one body they share a register
+// allocation and spill (508 bytes of scratch per lane against 24 - 236 on their own; BSFM_FLOW_INLINE_ROLES is the bring-up switch of
+// scripts/r4/flow_dbg.hip).  Latency build (V = 2, 256 VGPRs): inlined -- there is room, and a call costs a save / restore of the
+// callee-saved registers through scratch at both ends of every task of the chain.
+template <int V> struct FlowTag {};
+template <int MR> __device__ BSFM_FLOW_ROLE void flow_upd(FlowTag<4>, FlowKWords ka, const FlowArgs* a_in, int i, int j, int p0, int np, int r0, double* lds) { flow_upd_impl<MR, 4>(ka, a_in, i, j, p0, np, r0, lds); }
+template <int MR> __device__ __forceinline__ void flow_upd(FlowTag<2>, FlowKWords ka, const FlowArgs* a_in, int i, int j, int p0, int np, int r0, double* lds) { flow_upd_impl<MR, 2>(ka, a_in, i, j, p0, np, r0, lds); }
+__device__ BSFM_FLOW_ROLE void flow_trsm64(FlowTag<4>, FlowKWords ka, const FlowArgs* a_in, int i, int k, int r0, double* lds) { flow_trsm64_impl<4>(ka, a_in, i, k, r0, lds); }
+__device__ __forceinline__ void flow_trsm64(FlowTag<2>, FlowKWords ka, const FlowArgs* a_in, int i, int k, int r0, double* lds) { flow_trsm64_impl<2>(ka, a_in, i, k, r0, lds); }
+template <bool IS_UPD> __device__ BSFM_FLOW_ROLE void flow_tile32(FlowTag<4>, FlowKWords ka, const FlowArgs* a_in, int i, int k, int p0, int np, int part, double* lds) { flow_tile32_impl<IS_UPD, 4>(ka, a_in, i, k, p0, np, part, lds); }
+template <bool IS_UPD> __device__ __forceinline__ void flow_tile32(FlowTag<2>, FlowKWords ka, const FlowArgs* a_in, int i, int k, int p0, int np, int part, double* lds) { flow_tile32_impl<IS_UPD, 2>(ka, a_in, i, k, p0, np, part, lds); }
+__device__ BSFM_FLOW_ROLE void flow_potrf(FlowTag<4>, FlowKWords ka, const FlowArgs* a_in, int k, double* lds) { flow_potrf_impl<4>(ka, a_in, k, lds); }
+__device__ __forceinline__ void flow_potrf(FlowTag<2>, FlowKWords ka, const FlowArgs* a_in, int k, double* lds) { flow_potrf_impl<2>(ka, a_in, k, lds); }
+
 constexpr long long FLOW_SPIN_LIMIT_TICKS = 40LL * 1000 * 1000;      // 0.4 s of the 100 MHz wall clock: far beyond any solve this library accepts (BSFM_FLOW_SPIN_MS overrides it)
 
-#ifndef BSFM_FLOW_WPS
-#define BSFM_FLOW_WPS 4          // waves per SIMD the kernel is compiled for: 4 = two 512-thread workgroups per CU (128 VGPRs)
-#endif
+// Two builds of the one kernel (round 5): WPS = waves per SIMD it is compiled for.
+//   4  two 512-thread workgroups per CU, 128 VGPRs: the THROUGHPUT build -- what a bulk-bound factorisation (many tile products per column)
+//      needs; its roles are functions of their own, and at 128 VGPRs each call saves / restores ~46 callee-saved registers through scratch.
+//   2  one workgroup per CU, 256 VGPRs: the LATENCY build -- no scratch anywhere, the 16 x 16 block factorisation inlined.  A POTRF takes
+//      36.6 instead of 40.8 us and a bulk tile product 25 instead of 34 us (nobody shares the CU), at half the resident workgroups: faster up to
+//      ~45 tile columns (n = 450: 0.27 -> 0.23 ms, 1 800: 0.90 -> 0.76, 3 712: 1.68 -> 1.45, 5 400: 2.80 -> 2.72; 9 000: 6.5 -> 6.9), i.e. for
+//      every problem of an incremental reconstruction (src/BundleFast.cpp:263-438: 14 - 400 cameras).  flow_solve picks by tile count
+//      (BSFM_FLOW_LATENCY_TILES, default 45).
 // NOTE on control flow.  Ticket, waits and signal are single-thread jobs between workgroup barriers.  Written as `if (tid == 0) { ...
 // loops, exits ... }` they are NOT sound: a lane-divergent region with loops inside gives the compiler no obligation to reconverge
 // wave 0 before the next barrier -- on the first bring-up lanes 1..63 of wave 0 ran on (through the barrier and the whole POTRF role,
@@ -676,15 +727,21 @@ constexpr long long FLOW_SPIN_LIMIT_TICKS = 40LL * 1000 * 1000;      // 0.4 s of
 // (Measured and dropped, round 4: drawing the NEXT ticket in the shadow of the store drain -- neutral; polling a task's three counters
 // together instead of one after the other -- 1.3 % slower, both together 3.5 % slower.  The 4.8 us a ready task spends between ticket and
 // work are not what limits the launch.)
-__global__ __launch_bounds__(512, BSFM_FLOW_WPS) void k_chol_flow(FlowArgs a)
+template <int WPS>
+__global__ __launch_bounds__(512, WPS) void k_chol_flow(FlowArgs a_param)
 {
+    constexpr int V = WPS;
+    const FlowKWords ka = (FlowKWords)__builtin_amdgcn_kernarg_segment_ptr();
+    const FlowArgs a_seg = flow_kernel_args(ka);        // scalar loads from the kernel-argument segment: no stack copy (see flow_kernel_args)
+    const FlowArgs& a = V == 2 ? a_seg : a_param;
+    const FlowArgs* const a_in = V == 2 ? nullptr : &a_param;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ unsigned s_ticket;
     __shared__ int s_abort;
     __shared__ int s_role;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned* const flags = a.sync + 4;
+    unsigned* const flags = a.sync + 8;
     // ---- role: 0 = bulk queue, 1 = chain queue, 2 = leave (second workgroup on a chain CU)
     if (wave == 0) {
         int role = 0;
@@ -704,6 +761,7 @@ __global__ __launch_bounds__(512, BSFM_FLOW_WPS) void k_chol_flow(FlowArgs a)
                 if (lane == 0) r = atomicAdd(a.sync + 3, 1u);
                 r = (unsigned)__builtin_amdgcn_readfirstlane((int)r);
                 role = r < n_cw ? 1 : 0;
+                if (r == 0u && a.n_potrf > 0u) role = 3;          // the first chain workgroup serves the POTRF queue alone
                 if (lane == 0) __hip_atomic_store(cu_state, role ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else if (slot == 1u) {
                 // the first workgroup on this CU decides within a microsecond; an unanswered wait just means "bulk"
@@ -720,10 +778,10 @@ __global__ __launch_bounds__(512, BSFM_FLOW_WPS) void k_chol_flow(FlowArgs a)
     __syncthreads();
     const int role = __builtin_amdgcn_readfirstlane(s_role);
     if (role == 2) return;
-    const FlowTask* const queue = role == 1 ? a.chain_tasks : a.tasks;
-    const unsigned t_end = (unsigned)__builtin_amdgcn_readfirstlane((int)(role == 1 ? a.n_chain : a.n_bulk));
-    unsigned* const ticket = a.sync + (role == 1 ? 2 : 0);
-    const size_t trace_base = role == 1 ? (size_t)a.n_bulk : 0;
+    const FlowTask* const queue = role == 3 ? a.potrf_tasks : role == 1 ? a.chain_tasks : a.tasks;
+    const unsigned t_end = (unsigned)__builtin_amdgcn_readfirstlane((int)(role == 3 ? a.n_potrf : role == 1 ? a.n_chain : a.n_bulk));
+    unsigned* const ticket = a.sync + (role == 3 ? 4 : role == 1 ? 2 : 0);
+    const size_t trace_base = role == 3 ? (size_t)a.n_bulk + a.n_chain : role == 1 ? (size_t)a.n_bulk : 0;
     for (;;) {
         long long st0 = 0;
         if (wave == 0) {
@@ -769,12 +827,12 @@ __global__ __launch_bounds__(512, BSFM_FLOW_WPS) void k_chol_flow(FlowArgs a)
         __syncthreads();
         if (__builtin_amdgcn_readfirstlane(s_abort)) return;
         switch (type) {
-        case FT_POTRF:  flow_potrf(a, tj, lds); break;
-        case FT_TRSM32: flow_tile32<false>(a, ti, tj, 0, 0, part, lds); break;
-        case FT_TRSM64: flow_trsm64(a, ti, tj, 64 * part, lds); break;
-        case FT_UPD32:  flow_tile32<true>(a, ti, tj, p0, np, part, lds); break;
-        case FT_UPD64:  flow_upd<64>(a, ti, tj, p0, np, 64 * part, lds); break;
-        case FT_UPD128: flow_upd<128>(a, ti, tj, p0, np, 0, lds); break;
+        case FT_POTRF:  flow_potrf(FlowTag<V>(), ka, a_in, tj, lds); break;
+        case FT_TRSM32: flow_tile32<false>(FlowTag<V>(), ka, a_in, ti, tj, 0, 0, part, lds); break;
+        case FT_TRSM64: flow_trsm64(FlowTag<V>(), ka, a_in, ti, tj, 64 * part, lds); break;
+        case FT_UPD32:  flow_tile32<true>(FlowTag<V>(), ka, a_in, ti, tj, p0, np, part, lds); break;
+        case FT_UPD64:  flow_upd<64>(FlowTag<V>(), ka, a_in, ti, tj, p0, np, 64 * part, lds); break;
+        case FT_UPD128: flow_upd<128>(FlowTag<V>(), ka, a_in, ti, tj, p0, np, 0, lds); break;
         case FT_FTRSM:  flow_ftrsm(a, tj, lds); break;
         case FT_FUPD:   flow_fupd(a, tj, p0, np); break;
         default: break;
@@ -878,12 +936,13 @@ struct FlowWorkspace {
     int nblk = 0;                          // tiles the buffers were sized for
     std::vector<int> env_key;              // envelope the schedule was built for
     FlowSchedule sched;                    // tasks in the simulated order (both queues)
-    std::vector<FlowTask> bulk, chain;     // the two queues, as uploaded
+    std::vector<FlowTask> bulk, chain, potrf;     // the queues, as uploaded (potrf: the chain's POTRFs when they have a workgroup of their own)
     FlowTask* d_tasks = nullptr;           // bulk queue, then chain queue
     unsigned* d_sync = nullptr;            // tickets, time-out, claims, per-tile counters, per-CU words
     size_t sync_words = 0;
     double* pc = nullptr;                  // compact panel tiles
     long long* d_trace = nullptr;
+    bool latency_build = false;                        // this system runs on k_chol_flow<2> (see there)
     long long spin_limit = FLOW_SPIN_LIMIT_TICKS;      // BSFM_FLOW_SPIN_MS
     int stall_ticket = -1, stall_bwd_col = -1;         // test hooks: BSFM_FLOW_TEST_STALL (bulk ticket that never signals), BSFM_FLOW_TEST_STALL_BWD (column)
     int wgs = 512;                         // workgroups launched (BSFM_FLOW_WGS)
@@ -980,14 +1039,24 @@ inline int flow_prepare(FlowWorkspace& f, int nblk, const std::vector<int>& env_
     f.chain_wgs = (f.sched.upd_tiles + f.sched.trsm_tiles) < 400.0 * nblk ? 26 : 16;
     if (const char* e = getenv("BSFM_FLOW_CHAIN_WGS")) f.chain_wgs = std::max(0, atoi(e));
     f.chain_wgs = std::min(f.chain_wgs, f.wgs / 4);
+    {
+        int lat_tiles = 45;
+        if (const char* e = getenv("BSFM_FLOW_LATENCY_TILES")) lat_tiles = atoi(e);
+        f.latency_build = nblk <= lat_tiles;
+    }
     f.nblk = nblk; f.env_key = key;
     f.bulk.clear(); f.chain.clear();
-    for (const FlowTask& t : f.sched.tasks) (f.chain_wgs > 0 && t.pad == 1 ? f.chain : f.bulk).push_back(t);
+    bool own_potrf_wg = f.chain_wgs >= 2;
+    if (const char* e = getenv("BSFM_FLOW_POTRF_WG")) own_potrf_wg = own_potrf_wg && atoi(e) != 0;
+    f.potrf.clear();
+    for (const FlowTask& t : f.sched.tasks)
+        (f.chain_wgs > 0 && t.pad == 1 ? (own_potrf_wg && t.type == FT_POTRF ? f.potrf : f.chain) : f.bulk).push_back(t);
     const size_t nt = f.sched.tasks.size();
     if (bsfm::dev_alloc((void**)&f.d_tasks, nt * sizeof(FlowTask)) != hipSuccess) return -1;
     if (!f.bulk.empty() && hipMemcpy(f.d_tasks, f.bulk.data(), f.bulk.size() * sizeof(FlowTask), hipMemcpyHostToDevice) != hipSuccess) return -1;
     if (!f.chain.empty() && hipMemcpy(f.d_tasks + f.bulk.size(), f.chain.data(), f.chain.size() * sizeof(FlowTask), hipMemcpyHostToDevice) != hipSuccess) return -1;
-    f.sync_words = 4 + (size_t)f.sched.nflags + 2 * (size_t)FLOW_CU_KEYS;
+    if (!f.potrf.empty() && hipMemcpy(f.d_tasks + f.bulk.size() + f.chain.size(), f.potrf.data(), f.potrf.size() * sizeof(FlowTask), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    f.sync_words = 8 + (size_t)f.sched.nflags + 2 * (size_t)FLOW_CU_KEYS;
     if (bsfm::dev_alloc((void**)&f.d_sync, f.sync_words * sizeof(unsigned)) != hipSuccess) return -1;
     if (!f.pc) {
         const size_t ntile = std::max<size_t>(1, (size_t)nblk * (size_t)(nblk - 1) / 2);
@@ -1000,7 +1069,9 @@ inline int flow_prepare(FlowWorkspace& f, int nblk, const std::vector<int>& env_
     }
     f.flops = (f.sched.upd_tiles + f.sched.trsm_tiles) * 2.0 * POTRF_NB * POTRF_NB * POTRF_NB;
     if (!f.k0) { (void)hipEventCreate(&f.k0); (void)hipEventCreate(&f.k1); }
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_flow), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_flow<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(FLOW_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_flow<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(FLOW_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
     return 0;
 }
@@ -1019,7 +1090,7 @@ inline void flow_dump_trace(FlowWorkspace& f, hipStream_t st)
     for (size_t q = 0; q < nt; ++q) t0 = std::min(t0, h[4 * q]);
     fprintf(fp, "# ticket type i j p0 np part  t_ticket t_ready t_done (us since the first ticket)  xcc wg queue\n");
     for (size_t q = 0; q < nt; ++q) {
-        const FlowTask& t = q < f.bulk.size() ? f.bulk[q] : f.chain[q - f.bulk.size()];
+        const FlowTask& t = q < f.bulk.size() ? f.bulk[q] : q < f.bulk.size() + f.chain.size() ? f.chain[q - f.bulk.size()] : f.potrf[q - f.bulk.size() - f.chain.size()];
         fprintf(fp, "%zu %d %d %d %d %d %d %.2f %.2f %.2f %lld %lld %lld\n", q, t.type, t.i, t.j, t.p0, t.np, t.part,
                 (h[4 * q] - t0) * 0.01, (h[4 * q + 1] - t0) * 0.01, (h[4 * q + 2] - t0) * 0.01, h[4 * q + 3] & 15, (h[4 * q + 3] >> 8) & 0xffffff, h[4 * q + 3] >> 32);
     }
@@ -1028,7 +1099,7 @@ inline void flow_dump_trace(FlowWorkspace& f, hipStream_t st)
         fprintf(fp, "# POTRF phases per column (us since entry): loaded | per block column: inverse diagonal block visible, block column visible, updates issued | loop done, end\n");
         for (int k = 0; k < f.nblk; ++k) {
             const long long* q = ph.data() + 40 * (size_t)k;
-            fprintf(fp, "#P %d: %.2f |", k, (q[2] - q[1]) * 0.01);
+            fprintf(fp, "#P %d: %.2f (first block factored %.2f) |", k, (q[2] - q[1]) * 0.01, (q[3] - q[1]) * 0.01);
             for (int s2 = 0; s2 < 8; ++s2) fprintf(fp, " %.2f %.2f %.2f |", (q[5 + 4 * s2] - q[1]) * 0.01, (q[6 + 4 * s2] - q[1]) * 0.01, s2 < 7 ? (q[7 + 4 * s2] - q[1]) * 0.01 : 0.0);
             fprintf(fp, " %.2f %.2f\n", (q[36] - q[1]) * 0.01, (q[37] - q[1]) * 0.01);
         }
@@ -1047,6 +1118,7 @@ inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, in
     FlowArgs a;
     a.S = S; a.ld = ld; a.n_total = n; a.T = nblk; a.Pc = f.pc; a.Linv = w.linv; a.E = w.etmp; a.y = w.y;
     a.tasks = f.d_tasks; a.chain_tasks = f.d_tasks + f.bulk.size(); a.n_bulk = (unsigned)f.bulk.size(); a.n_chain = (unsigned)f.chain.size();
+    a.potrf_tasks = f.d_tasks + f.bulk.size() + f.chain.size(); a.n_potrf = (unsigned)f.potrf.size();
     a.n_chain_wgs = (unsigned)f.chain_wgs; a.sync = f.d_sync; a.nflags = (unsigned)f.sched.nflags; a.info = d_info;
     a.trace = f.trace ? f.d_trace : nullptr; a.ptrace_ofs = (unsigned)(4 * nt);
     a.spin_limit = f.spin_limit; a.stall_ticket = f.stall_ticket;
@@ -1057,8 +1129,13 @@ inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, in
         (void)hipEventRecord(f.k0, st);
     }
     // every workgroup of the grid is resident at once (two per CU); small systems do not need them all
-    const unsigned grid = (unsigned)std::min<size_t>((size_t)f.wgs, nt + 2 * (size_t)f.chain_wgs);
-    hipLaunchKernelGGL(k_chol_flow, dim3(grid), dim3(512), lds_bytes, st, a);
+    if (f.latency_build) {      // one workgroup per CU: nothing shares a chain workgroup's CU anyway, so no CU claims are needed -- but they are harmless
+        const unsigned grid = (unsigned)std::min<size_t>((size_t)f.wgs / 2, nt + (size_t)f.chain_wgs);
+        hipLaunchKernelGGL(k_chol_flow<2>, dim3(grid), dim3(512), lds_bytes, st, a);
+    } else {
+        const unsigned grid = (unsigned)std::min<size_t>((size_t)f.wgs, nt + 2 * (size_t)f.chain_wgs);
+        hipLaunchKernelGGL(k_chol_flow<4>, dim3(grid), dim3(512), lds_bytes, st, a);
+    }
     if (timed) { (void)hipEventRecord(f.k1, st); f.kern_pending = true; }
     // backward substitution
     const bool env = (int)w.env_rows.size() >= nblk && w.d_last != nullptr;

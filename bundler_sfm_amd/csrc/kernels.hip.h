@@ -115,15 +115,36 @@ __device__ __forceinline__ double block_sum4(double s, double* sm)
 // workgroup that draws the last ticket reads the partials with agent-scope loads and puts the ticket back to zero for the next launch.
 __device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ bool last_block_arrives(unsigned* ticket, unsigned total)
+// Two levels for big grids: atomics on ONE address are served one at a time (measured on the headline's k_residual, 9 000 workgroups:
+// one ticket word made the kernel 261 us instead of 111 -- about 17 ns per ticket, more than the workgroups take to arrive), so
+// workgroups draw from the word of their group of 64 (TICKET_STRIDE words apart: a 128-byte line each, different channels) and only
+// the last of a group goes on to the top-level word.
+constexpr int TICKET_GROUP = 64, TICKET_STRIDE = 32;
+__host__ __device__ constexpr size_t ticket_group_words(size_t grid) { return ((grid + TICKET_GROUP - 1) / TICKET_GROUP) * TICKET_STRIDE; }
+__device__ __forceinline__ bool last_block_arrives(unsigned* ticket, unsigned total, unsigned* groups = nullptr)
 {
     __shared__ int s_last_block;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last_block = (t == total - 1u) ? 1 : 0;
-        if (t == total - 1u) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool last = false;
+        if (!groups || total <= (unsigned)TICKET_GROUP) {
+            const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = t == total - 1u;
+            if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const unsigned g = blockIdx.x / (unsigned)TICKET_GROUP, ng = (total + TICKET_GROUP - 1u) / (unsigned)TICKET_GROUP;
+            const unsigned in_group = min((unsigned)TICKET_GROUP, total - g * (unsigned)TICKET_GROUP);
+            unsigned* gw = groups + (size_t)g * TICKET_STRIDE;
+            const unsigned t = __hip_atomic_fetch_add(gw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == in_group - 1u) {
+                __hip_atomic_store(gw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned t2 = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = t2 == ng - 1u;
+                if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        s_last_block = last ? 1 : 0;
     }
     __syncthreads();
     return s_last_block != 0;
@@ -189,7 +210,8 @@ __global__ __launch_bounds__(RES_BLOCK) void k_residual(ModelCfg cfg, int nvis,
         const double* __restrict__ camtab,
         double* __restrict__ e_out, const double* __restrict__ e_prev, double eps5,
         double* __restrict__ part_cost, double* __restrict__ part_pct,
-        unsigned* __restrict__ ticket /* null: k_reduce_sum_max follows */, double* __restrict__ out_sum, double* __restrict__ out_max)
+        unsigned* __restrict__ ticket /* null: k_reduce_sum_max follows */, unsigned* __restrict__ ticket_groups,
+        double* __restrict__ out_sum, double* __restrict__ out_max)
 {
     __shared__ double sm[2 * (RES_BLOCK / 64)];
     const int k = blockIdx.x * RES_BLOCK + threadIdx.x;
@@ -223,7 +245,7 @@ __global__ __launch_bounds__(RES_BLOCK) void k_residual(ModelCfg cfg, int nvis,
         st_agent(part_cost + blockIdx.x, s);
         if (part_pct) st_agent(part_pct + blockIdx.x, q);
     }
-    if (!ticket || !last_block_arrives(ticket, gridDim.x)) return;
+    if (!ticket || !last_block_arrives(ticket, gridDim.x, ticket_groups)) return;
     {   // k_reduce_sum_max, by the workgroup that arrived last (same partition, same order)
         __shared__ double sm2[4];
         const int count = (int)gridDim.x;
@@ -661,6 +683,7 @@ __device__ __forceinline__ void step_sums_body(int count, int fixed, double mu, 
 struct StepFinalArgs {       // k_step_sums' and k_cam_table's arguments, for the workgroup of k_backsub that arrives last
     int count, fixed; const double* pa; double* pdpa; double* out3; double* pt3;
     const double* known; int with_fd; double* camtab_trial;
+    unsigned* ticket_groups;      // last_block_arrives' group words for this grid (null: one level)
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -718,7 +741,7 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem P, double mu, const 
     if (threadIdx.x < 3)
         st_agent(part + (size_t)threadIdx.x * gridDim.x + blockIdx.x,
                  (sm[threadIdx.x][0] + sm[threadIdx.x][1]) + (sm[threadIdx.x][2] + sm[threadIdx.x][3]));
-    if (!ticket || !last_block_arrives(ticket, gridDim.x)) return;
+    if (!ticket || !last_block_arrives(ticket, gridDim.x, fa.ticket_groups)) return;
     // k_step_sums (camera part of the step, sums of the point partials) and the camera table of the trial point, by the workgroup that
     // arrived last: pdp_a is written and read inside this workgroup (a barrier in between)
     step_sums_body(fa.count, fa.fixed, mu, fa.pa, dpa, P.ea, fa.pdpa, fa.out3, part, (int)gridDim.x, fa.pt3, true);

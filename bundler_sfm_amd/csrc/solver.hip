@@ -231,6 +231,7 @@ struct bsfm_problem {
     double *d_scal = nullptr;
     double *d_mixed = nullptr;          // staging of allreduce_mixed: a few sums + world slots per maximum
     int *d_flags = nullptr;             // [0] singular V, [1] potrf info
+    size_t tick_res = 0, tick_back = 0; // word offsets of the group tickets in d_tickets
     unsigned* d_tickets = nullptr;      // "last workgroup finishes the job" tickets (kernels.hip.h): [0] residual, [1] iteration scalars, [2] back-substitution, [8 ..) one per camera
     // schur structure
     int ntriples = 0, ntasks = 0, nblk = 0;
@@ -414,11 +415,11 @@ void launch_residual(bsfm_problem* pb, const double* camtab, const double* p_poi
     if (pb->P.nvis > 0 && pb->d_known)
         hipLaunchKernelGGL(k_residual<true>, dim3(nb), dim3(RES_BLOCK), 0, pb->stream, pb->P.cfg, pb->P.nvis, pb->d_xc,
                            pb->d_cam_cam, ptc, camtab, e_out, e_prev, pb->opt.opts[5], pc,
-                           e_prev ? pp : nullptr, pb->d_tickets + 0, pb->d_scal + cost_slot, pb->d_scal + SC_PCT);
+                           e_prev ? pp : nullptr, pb->d_tickets + 0, pb->d_tickets + pb->tick_res, pb->d_scal + cost_slot, pb->d_scal + SC_PCT);
     if (pb->P.nvis > 0 && !pb->d_known)
         hipLaunchKernelGGL(k_residual<false>, dim3(nb), dim3(RES_BLOCK), 0, pb->stream, pb->P.cfg, pb->P.nvis, pb->d_xc,
                            pb->d_cam_cam, ptc, camtab, e_out, e_prev, pb->opt.opts[5], pc,
-                           e_prev ? pp : nullptr, pb->d_tickets + 0, pb->d_scal + cost_slot, pb->d_scal + SC_PCT);
+                           e_prev ? pp : nullptr, pb->d_tickets + 0, pb->d_tickets + pb->tick_res, pb->d_scal + cost_slot, pb->d_scal + SC_PCT);
     // (the sum over the workgroups' partial costs -- k_reduce_sum_max -- is done by the workgroup of k_residual that arrives last)
     if (pb->P.nvis <= 0)
         hipLaunchKernelGGL(k_reduce_sum_max, dim3(1), dim3(256), 0, pb->stream, pc, e_prev ? pp : (const double*)nullptr, 0,
@@ -876,8 +877,13 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     pb->red_blocks = std::max(grid_for(nvis, RES_BLOCK), std::max(grid_for(n, 256), 1024));
     DM(pb->d_red, 4 * (size_t)pb->red_blocks); DM(pb->d_scal, SC_COUNT + 16 + 2); DM(pb->d_mixed, 8 + 4 * (size_t)std::max(1, d->world_size));
     pb->d_flags = reinterpret_cast<int*>(pb->d_scal + SC_COUNT + 16);      // 4 ints behind the scalars: both travel in one copy
-    DM(pb->d_tickets, 8 + (size_t)m);
-    if (hipMemsetAsync(pb->d_tickets, 0, (8 + (size_t)m) * sizeof(unsigned), pb->stream) != hipSuccess) return fail("tickets");
+    {   // [0 .. 8) top-level words, [8 .. 8 + m) the cameras', then the group words of k_residual's and k_backsub's grids (kernels.hip.h)
+        pb->tick_res = (8 + (size_t)m + 31) / 32 * 32;
+        pb->tick_back = pb->tick_res + ticket_group_words((size_t)grid_for(nvis, RES_BLOCK));
+        const size_t words = pb->tick_back + ticket_group_words((size_t)grid_for(n, 256));
+        DM(pb->d_tickets, words);
+        if (hipMemsetAsync(pb->d_tickets, 0, words * sizeof(unsigned), pb->stream) != hipSuccess) return fail("tickets");
+    }
 #undef DM
     if (nvis > 0) hipLaunchKernelGGL(k_permute16, dim3(grid_for(nvis, 256)), dim3(256), 0, pb->stream, nvis, pb->d_camobs, pb->d_x, pb->d_xc);   // measurements in camera-major order
     if (hipHostMalloc((void**)&pb->h_scal, (SC_COUNT + 16 + 2) * sizeof(double)) != hipSuccess) return fail("pinned");
@@ -1469,6 +1475,7 @@ static int lm_iterate_impl(bsfm_problem_t* pb, int iters)
                 const int ms = trial_mirror_slot(pb);            // the trial points also go to the camera-major mirror the residual kernel streams
                 StepFinalArgs fa; fa.count = P.m * cnp; fa.fixed = P.mcon * cnp; fa.pa = d_pa; fa.pdpa = d_pdpa; fa.out3 = pb->d_scal + SC_CAM3;
                 fa.pt3 = pb->d_scal + SC_PT_DP; fa.known = pb->d_known; fa.with_fd = pb->opt.jacobian == BSFM_JAC_FD ? 1 : 0; fa.camtab_trial = pb->d_camtab_trial;
+                fa.ticket_groups = pb->d_tickets + pb->tick_back;
                 DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_backsub<C>), dim3(nbp), dim3(256), 0, pb->stream, P, mu, d_dpa, d_pb, d_dpb, d_pdpb, pb->d_red, pb->d_ptc[ms],
                                                       pb->d_tickets + 2, fa));
                 pb->ptc_tag[ms] = pb->d_pdp;

@@ -20,7 +20,8 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 RULES = {   # kernel-name substring -> (object, max VGPRs, max VGPR spills, max scratch bytes per lane)
     "k_match_bound": ("match_l2.o", 256, 0, 0),
     "k_match_l2": ("match_l2.o", 256, 0, 0),
-    "k_chol_flow": ("solver.o", 128, 64, 1024),
+    "k_chol_flowILi4": ("solver.o", 128, 64, 1024),     # throughput build: two workgroups per CU; scratch = callee-save area of its role functions only
+    "k_chol_flowILi2": ("solver.o", 256, 0, 0),         # latency build (one workgroup per CU): nothing in scratch at all
 }
 
 
