@@ -367,12 +367,20 @@ __device__ __forceinline__ void flow_fupd(const FlowArgs& a, int j, int p0, int 
 // v_mov_b32_dpp per value, no SGPRs.  (The v_readlane form of rounds 1-3 needs an SGPR pair per value plus wait states before its
 // use; with the inverse carried along -- two FMAs per broadcast -- the compiler parked all 136 pairs in a VGPR through v_writelane:
 // 1 774 instructions per block; rows and inverse columns in separate lane halves: 1 059; this form: ~700.)
-template <int C> __device__ __forceinline__ double flow_bcast16(double v)
-{
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + C, 0xf, 0xf, true);       // every lane is written: no "old" value to keep
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + C, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
+// ONE v_mov_b64_dpp per value (round 5; gfx90a+: the 64-bit DPP move exists for exactly this control, row_newbcast; bound_ctrl: every
+// lane is written, there is no "old" value to keep).  Full specialisations: in a dependent expression the type-generic builtin is typed int.
+template <int C> __device__ __forceinline__ double flow_bcast16(double v);
+#define BSFM_FLOW_BCAST16(C)                                                                                            \
+    template <> __device__ __forceinline__ double flow_bcast16<C>(double v)                                             \
+    {                                                                                                                   \
+        const long long x = __builtin_bit_cast(long long, v);                                                           \
+        const long long y = __builtin_amdgcn_update_dpp(x, x, 0x150 + C, 0xf, 0xf, true);                               \
+        return __builtin_bit_cast(double, y);                                                                           \
+    }
+BSFM_FLOW_BCAST16(0) BSFM_FLOW_BCAST16(1) BSFM_FLOW_BCAST16(2) BSFM_FLOW_BCAST16(3) BSFM_FLOW_BCAST16(4) BSFM_FLOW_BCAST16(5)
+BSFM_FLOW_BCAST16(6) BSFM_FLOW_BCAST16(7) BSFM_FLOW_BCAST16(8) BSFM_FLOW_BCAST16(9) BSFM_FLOW_BCAST16(10) BSFM_FLOW_BCAST16(11)
+BSFM_FLOW_BCAST16(12) BSFM_FLOW_BCAST16(13) BSFM_FLOW_BCAST16(14) BSFM_FLOW_BCAST16(15)
+#undef BSFM_FLOW_BCAST16
 template <int J, int C> struct FlowA1Upd {
     static __device__ __forceinline__ void run(double (&d)[16], double (&x)[16], double lrj, double xj)
     {
@@ -594,7 +602,9 @@ __device__ __forceinline__ void flow_potrf_impl(FlowKWords ka, const FlowArgs* a
 #pragma unroll
             for (int q = 0; q < 4; ++q) blk[swz16(4 * q + lr, lc)] = cur[q];
             BSFM_LDS_FENCE();
+            __builtin_amdgcn_s_setprio(3);                      // the one wave the whole factorisation waits for: first pick of its SIMD's issue slots
             const int bad = flow_factor16<V>(blk, lane);
+            __builtin_amdgcn_s_setprio(0);
             if (s < 0) BSFM_FLOW_MARK(3);
             if (lane == 0 && bad >= 0 && base + 16 * sn + bad < n_total) {
                 // dpotrf's info is the FIRST failing leading minor.  With an envelope whose diagonal tiles are independent (block-diagonal S)
