@@ -687,12 +687,53 @@ struct StepFinalArgs {       // k_step_sums' and k_cam_table's arguments, for th
 };
 
 // ---------------------------------------------------------------------------------------------------
+// First pass of the back-substitution on big problems (round 5): w_k = W_k^T da_j = B_k^T (A_k da_j) for every observation, one thread
+// per CAMERA-major position.  The thread-per-point kernel below gathers the 144 + 48 bytes of (A, B) of each of its observations from
+// the camera-major streams -- whole 128-byte lines for pieces of them: 1.9 x the bytes (1 974 MB against 1 046 at config 3, 0.50 ms).
+// Here the two streams are read as they lie (the 256 records of a workgroup are contiguous: A through LDS with 16 consecutive bytes per
+// lane, the way k_jacobian wrote them), da_j is one broadcast per camera, and 32 bytes per observation go out for the gather of the
+// second pass.  Same operations in the same order as the one-pass form: bit-identical.  (Four lanes per point in the second pass -- more
+// gathers in flight -- measured slower, 270 against 232 us: that pass is bound by the number of scattered requests, not by their latency.)
+template <int CNP>
+__global__ __launch_bounds__(256) void k_backsub_obs(int nvis, int mcon, const int* __restrict__ cam_cam, const double* __restrict__ Ac,
+        const double* __restrict__ Bc, const double* __restrict__ dpa, double* __restrict__ wobs)
+{
+    constexpr int LA = CNP + 1 - (CNP & 1);                  // LDS row stride in 16-byte chunks (odd: conflict-free)
+    __shared__ double2 stage[256 * LA];
+    const int t0 = blockIdx.x * 256;
+    const int nrec = min(256, nvis - t0);
+    const double2* src = reinterpret_cast<const double2*>(Ac + (size_t)t0 * 2 * CNP);
+    for (int c = threadIdx.x; c < nrec * CNP; c += 256) {
+        const int rec = c / CNP, part = c - rec * CNP;
+        stage[rec * LA + part] = src[c];
+    }
+    __syncthreads();
+    const int t = t0 + threadIdx.x;
+    if (t >= nvis) return;
+    const int j = cam_cam[t];
+    double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+    if (j >= mcon) {
+        double B[6];
+        load_pairs<3>(Bc + (size_t)t * 8, B);
+        const double* da = dpa + (size_t)j * CNP;
+        const double2* mine = stage + threadIdx.x * LA;
+        double q0 = 0, q1 = 0;
+#pragma unroll
+        for (int c = 0; c < CNP; ++c) { const double2 a = mine[c]; q0 += a.x * da[c]; q1 += a.y * da[c]; }
+        w0 = B[0] * q0 + B[3] * q1; w1 = B[1] * q0 + B[4] * q1; w2 = B[2] * q0 + B[5] * q1;
+    }
+    reinterpret_cast<double2*>(wobs)[2 * (size_t)t] = make_double2(w0, w1);
+    reinterpret_cast<double2*>(wobs)[2 * (size_t)t + 1] = make_double2(w2, 0.0);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // db_i = V*_i^-1 (eb_i - sum_j W_ij^T da_j), W_ij^T da_j = B_ij^T (A_ij da_j); thread per point.
 // Also writes pdp_b = p_b + db and block partials of sum db^2, sum p_b^2 and sum db (mu db + eb).
 template <int CNP>
 __global__ __launch_bounds__(256) void k_backsub(DevProblem P, double mu, const double* __restrict__ dpa,
         const double* __restrict__ pb, double* __restrict__ dpb, double* __restrict__ pdpb,
         double* __restrict__ part /* [3][gridDim.x] */, double* __restrict__ ptc_out /* camera-major mirror of pdpb, or null */,
+        const double* __restrict__ wobs /* k_backsub_obs' products (camera-major), or null: computed here */,
         unsigned* __restrict__ ticket /* null: k_step_sums and k_cam_table follow */, StepFinalArgs fa)
 {
     __shared__ double sm[3][4];
@@ -702,6 +743,13 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem P, double mu, const 
         const double* g = P.eb + (size_t)i * 3;
         double w0 = 0, w1 = 0, w2 = 0;
         const int k1 = P.rowptr[i + 1];
+        if (wobs) {
+            for (int k = P.rowptr[i]; k < k1; ++k) {
+                const double2* wk = reinterpret_cast<const double2*>(wobs) + 2 * (size_t)P.campos[k];
+                const double2 a = wk[0], b = wk[1];
+                w0 += a.x; w1 += a.y; w2 += b.x;             // (a fixed camera's product is +0.0: the sum is what the skip below leaves)
+            }
+        } else
         for (int k = P.rowptr[i]; k < k1; ++k) {
             const int j = P.obs_cam[k];
             if (j < P.mcon) continue;

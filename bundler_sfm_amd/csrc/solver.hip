@@ -231,6 +231,7 @@ struct bsfm_problem {
     double *d_scal = nullptr;
     double *d_mixed = nullptr;          // staging of allreduce_mixed: a few sums + world slots per maximum
     int *d_flags = nullptr;             // [0] singular V, [1] potrf info
+    bool backsub_two_pass = false;      // k_backsub_obs + gather (nvis >= 200 000, or BSFM_BACKSUB_TWO_PASS=0|1)
     size_t tick_res = 0, tick_back = 0; // word offsets of the group tickets in d_tickets
     unsigned* d_tickets = nullptr;      // "last workgroup finishes the job" tickets (kernels.hip.h): [0] residual, [1] iteration scalars, [2] back-substitution, [8 ..) one per camera
     // schur structure
@@ -948,6 +949,8 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     // Phase timing (16 event records per solve attempt + their read-back) is on for problems where it is noise (>= 100 000
     // observations: bench.py's phases_ms) and off for the small problems of incremental reconstruction, where those host calls
     // were a tenth of an iteration; BSFM_PHASE_TIMING=1 / 0 forces it.
+    pb->backsub_two_pass = nvis >= 200000;
+    if (const char* e = getenv("BSFM_BACKSUB_TWO_PASS")) pb->backsub_two_pass = atoi(e) != 0;
     pb->ev_ok = nvis >= 100000;
     if (const char* e = getenv("BSFM_PHASE_TIMING")) pb->ev_ok = atoi(e) != 0;
     // measured (profiles/r03_small_problem_latency_speculate.txt): 10 % of an iteration at 14 cameras, nothing from 50 cameras on
@@ -1476,8 +1479,16 @@ static int lm_iterate_impl(bsfm_problem_t* pb, int iters)
                 StepFinalArgs fa; fa.count = P.m * cnp; fa.fixed = P.mcon * cnp; fa.pa = d_pa; fa.pdpa = d_pdpa; fa.out3 = pb->d_scal + SC_CAM3;
                 fa.pt3 = pb->d_scal + SC_PT_DP; fa.known = pb->d_known; fa.with_fd = pb->opt.jacobian == BSFM_JAC_FD ? 1 : 0; fa.camtab_trial = pb->d_camtab_trial;
                 fa.ticket_groups = pb->d_tickets + pb->tick_back;
+                // big problems: the per-observation products W^T da in a streaming pass of their own (k_backsub_obs); they go where the Schur
+                // phase kept its per-observation records (d_Cc: dead once S is assembled)
+                const double* wobs = nullptr;
+                if (pb->backsub_two_pass && pb->d_Cc) {
+                    DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_backsub_obs<C>), dim3(grid_for((size_t)P.nvis, 256)), dim3(256), 0, pb->stream, P.nvis, P.mcon,
+                                                          (const int*)pb->d_cam_cam, (const double*)pb->d_Ac, (const double*)pb->d_Bc, (const double*)d_dpa, pb->d_Cc));
+                    wobs = pb->d_Cc;
+                }
                 DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_backsub<C>), dim3(nbp), dim3(256), 0, pb->stream, P, mu, d_dpa, d_pb, d_dpb, d_pdpb, pb->d_red, pb->d_ptc[ms],
-                                                      pb->d_tickets + 2, fa));
+                                                      wobs, pb->d_tickets + 2, fa));
                 pb->ptc_tag[ms] = pb->d_pdp;
             } else {
                 hipLaunchKernelGGL(k_step_sums, dim3(1), dim3(256), 0, pb->stream, P.m * cnp, P.mcon * cnp, mu, d_pa, d_dpa, pb->d_ea, d_pdpa,
