@@ -90,8 +90,8 @@ __device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_
 __device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ---- LDS budget (doubles).  The POTRF role needs 28 + 8 blocks of 16 x 16; the GEMM roles 2 x 128 x 18.
-constexpr int FLOW_LB = 0, FLOW_DI = 28 * 256;
-constexpr int FLOW_LDS_DOUBLES = 36 * 256;                  // 73 728 bytes: two workgroups per CU (160 KB)
+constexpr int FLOW_LB = 0, FLOW_DI = 28 * 256, FLOW_WSYNC = 36 * 256;
+constexpr int FLOW_LDS_DOUBLES = 36 * 256 + 2;              // 73 744 bytes: two workgroups per CU (160 KB); the last two: POTRF's worker barrier word
 static_assert(FLOW_LDS_DOUBLES >= 2 * 128 * GEMM_LDS_STRIDE, "GEMM staging must fit");
 static_assert(FLOW_LDS_DOUBLES >= T32_LDS_DOUBLES, "32 x 32 block staging must fit");
 
@@ -446,24 +446,32 @@ template <int V> __device__ __attribute__((noinline)) int flow_factor16(double* 
 template <> __device__ __forceinline__ int flow_factor16<2>(double* blk, int lane_in) { return flow_factor16_body(blk, lane_in); }
 
 // ---- POTRF: the diagonal tile, factor and inverse, in the footprint of a bulk workgroup.
-// The lower triangle of the tile is 36 blocks of 16 x 16.  Every block has ONE owner wave that holds it in registers in the
-// accumulator layout of v_mfma_f64_16x16x4 (register q of lane l = row 4 q + (l >> 4), column l & 15), so the trailing updates
-// accumulate straight into it; the operands of every product come from LDS, where the FINISHED blocks of L (28 below the diagonal)
-// and the inverses of the 8 diagonal blocks live (swizzled, 72 KB).  owner(I, J) = (I - J + J (J + 1) / 2) mod 8: the blocks of one
-// column have eight different owners (its panel solves run in parallel), every wave owns 4 or 5 blocks (40 VGPRs), and the owner
-// of the next diagonal block has at most 2 other live blocks.  Per block column s:
-//   A1  the owner of (s, s) turns it into one-lane-per-row form (through LDS) and factors it -- v_readlane broadcasts, 1 / pivot by
+// The lower triangle of the tile is 36 blocks of 16 x 16.  The 28 blocks BELOW the diagonal have one owner wave each that holds them in
+// registers in the accumulator layout of v_mfma_f64_16x16x4 (register q of lane l = row 4 q + (l >> 4), column l & 15), so the
+// trailing updates accumulate straight into them; the operands of every product come from LDS, where the FINISHED blocks of L and the
+// inverses of the 8 diagonal blocks live (swizzled, 72 KB).
+// Round 5: the 8 DIAGONAL blocks are FACTORED by one wave, the FACTOR wave (wave 3), which does nothing else, and its SIMD partner
+// (wave 7) never issues a matrix instruction while a block is being factored.  The block factorisation A1 is a chain of ~620 dependent VALU instructions, 1.7 us alone on a SIMD -- and FP64
+// matrix instructions of ANOTHER wave on the same SIMD do not overlap with it, they add (scripts/r5/ubench_coexec.hip): with the
+// diagonal blocks spread over all eight waves, as in round 4, the partner's 20 - 36 trailing-update products landed inside A1, 3.0 us per
+// step, eight steps per tile column on the critical path of the whole solve.  The six WORKER waves (0, 1, 2, 4, 5, 6: SIMDs 0 - 2) own the
+// off-diagonal blocks, round robin down the columns: the blocks of a column have different owners (the seventh block of column 0 is wave
+// 7's: its one product falls into A2, when the factor wave is idle), every worker owns 4 or 5 (40 VGPRs).  The diagonal blocks wait in
+// LDS, each in the slot its inverse will take, and are updated there.  Per block column s:
+//   A1  the factor wave turns block (s, s) into one-lane-per-row form (through LDS) and factors it -- DPP row broadcasts, 1 / pivot by
 //       v_rcp_f64 + two Newton steps, no square root inside the loop -- and carries the inverse along in the same loop: lane c
 //       builds column c of inv(R) (R = the unscaled factor, L = R diag(1 / sqrt(pivot))) from the very broadcasts the
 //       elimination uses, one more FMA per broadcast; inv(L_ss) = diag(sqrt(pivot)) inv(R) goes to LDS;
-//   A2  the owner of (I, s): X = B inv(L_ss)^T as ONE 16 x 16 x 16 matrix product (all 64 lanes; the round-4 bring-up version
-//       solved it by substitution on 16 lanes: 3.4 us per step against 0.4), finished block of L -> LDS;
-//   A3  block (I, J) -= L_Is L_Js^T for every live block, the next diagonal block first: its owner goes straight on to A1 of the
-//       next column while the others are still updating.
-// Then the inverse of the whole factor by block forward substitution, wave J = block column J: X_IJ = -inv(L_II) sum_K L_IK X_KJ;
+//   A2  the owner of (I, s): X = B inv(L_ss)^T as ONE 16 x 16 x 16 matrix product, finished block of L -> LDS (the factor wave fetches
+//       block (s + 1, s + 1) meanwhile);
+//   A3  workers: block (I, J) -= L_Is L_Js^T for every live block, ONE of the diagonal blocks s + 2 .. 7 each (read - modify - write in
+//       LDS: all of it in the shadow of A1), then their block of row s of the inverse (below).  The factor wave: block (s + 1, s + 1)
+//       -= L_(s+1)s L_(s+1)s^T -- the one update of it that is still missing -- and straight on to A1.
+// Then the inverse of the whole factor by block forward substitution: X_IJ = -inv(L_II) sum_K L_IK X_KJ;
 // the accumulator layout of X_KJ IS the B-operand layout of the next product, so X never leaves the registers.
+constexpr int FLOW_FACTOR_WAVE = 3, FLOW_IDLE_WAVE = 7;
 __device__ const unsigned long long kFlowPotrfSlots[8] = {      // 5 slots per wave, 8 bits each: I << 4 | J, 0xff = empty; sorted by (J, I)
-    0xff65537200ull, 0xff75631110ull, 0xff44732120ull, 0xff54223130ull, 0x7764324140ull, 0x6674425150ull, 0x7633526160ull, 0x5543627170ull };
+    0xff74437110ull, 0x6553322120ull, 0x7563423130ull, 0xffffffffffull, 0x7673524140ull, 0xff54625150ull, 0xff64726160ull, 0xffffffff70ull };
 
 template <int V>
 __device__ __forceinline__ void flow_potrf_impl(FlowKWords ka, const FlowArgs* a_in, int k, double* lds)
@@ -475,12 +483,17 @@ __device__ __forceinline__ void flow_potrf_impl(FlowKWords ka, const FlowArgs* a
     const int base = k * POTRF_NB, n_total = a.n_total;
     const double* G = a.S + (size_t)base * a.ld + base;
     const int lr0 = lane0 >> 4, lc0 = lane0 & 15;
-#define BSFM_FLOW_MARK(code) do { if (a.trace && lane0 == 0 && w == 0) a.trace[a.ptrace_ofs + 40 * (size_t)k + (code)] = wall_clock64(); } while (0)
+#define BSFM_FLOW_MARK(code) do { if (a.trace && lane0 == 0 && w == FLOW_FACTOR_WAVE) a.trace[a.ptrace_ofs + 40 * (size_t)k + (code)] = wall_clock64(); } while (0)
 #define BSFM_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
     BSFM_FLOW_MARK(1);
+    const bool factor_wave = w == FLOW_FACTOR_WAVE;
+    const int wi = w < 3 ? w : (w == 3 || w == 7) ? -1 : w - 1;      // 0 .. 5: worker, -1: factor wave / wave 7 (wave-uniform: w is an SGPR)
+    typedef __attribute__((address_space(3))) volatile int FlowLdsWord;
+    FlowLdsWord* wsync = (FlowLdsWord*)(lds + FLOW_WSYNC);
+    if (w == 0 && lane0 == 0) *wsync = 0;                  // (the first use is behind the first barrier)
     int sI[5], sJ[5];
     {
-        const unsigned long long packed = kFlowPotrfSlots[w];
+        const unsigned long long packed = factor_wave ? 0xffffffffffull : kFlowPotrfSlots[w];
 #pragma unroll
         for (int m = 0; m < 5; ++m) {
             const int b = __builtin_amdgcn_readfirstlane((int)((packed >> (8 * m)) & 0xffull));
@@ -496,8 +509,13 @@ __device__ __forceinline__ void flow_potrf_impl(FlowKWords ka, const FlowArgs* a
         for (int m = 0; m < 5; ++m) {
             const int I = sI[m] < 0 ? 0 : sI[m], J = sJ[m] < 0 ? 0 : sJ[m];
             const double* bp = G + (size_t)(16 * I + lr) * a.ld + 16 * J + lc;
+            if (!factor_wave) {                              // (the factor wave has no slots: straight to its diagonal block)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) t[m][q] = ld_sc1(bp + (size_t)(4 * q) * a.ld);
+                for (int q = 0; q < 4; ++q) t[m][q] = ld_sc1(bp + (size_t)(4 * q) * a.ld);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) t[m][q] = 0.0;
+            }
         }
 #pragma unroll
         for (int m = 0; m < 5; ++m) {
@@ -511,10 +529,38 @@ __device__ __forceinline__ void flow_potrf_impl(FlowKWords ka, const FlowArgs* a
             }
         }
     }
+    double cur[4] = { 0.0, 0.0, 0.0, 0.0 };                // the factor wave's block (s + 1, s + 1) between its last update and A1
+    {
+        // the diagonal blocks, one per wave: block 0 by the factor wave, into registers (A1 is about to take it); blocks 1 .. 6 by the workers and
+        // block 7 by wave 7, into LDS, each in the slot of its inverse (nobody reads them before the first barrier)
+        const int lr = lr0, lc = lc0;
+        const int I = factor_wave ? 0 : wi >= 0 ? wi + 1 : 7;
+        double dg[4];
+        const double* bp = G + (size_t)(16 * I + lr) * a.ld + 16 * I + lc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dg[q] = ld_sc1(bp + (size_t)(4 * q) * a.ld);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 16 * I + 4 * q + lr, c = 16 * I + lc;
+            const bool inside = base + r < n_total && base + c < n_total;
+            const double pad = (r == c) ? 1.0 : 0.0;
+            const double v = inside ? (c <= r ? dg[q] : 0.0) : pad;
+            cur[q] = v;
+            if (!factor_wave) Di[I * 256 + swz16(4 * q + lr, lc)] = v;
+        }
+    }
+    // the blocks of column 0 are final as loaded: into their LDS slots, where A2 (and, for block (1, 0), the factor wave) takes them from
+    {
+        const int lr = lr0, lc = lc0;
+#pragma unroll
+        for (int m = 0; m < 5; ++m)
+            if (sJ[m] == 0) {
+                double* dst = Lb + (sI[m] * (sI[m] - 1) / 2) * 256;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[swz16(4 * q + lr, lc)] = t[m][q];
+            }
+    }
     BSFM_FLOW_MARK(2);
-    // cur: the block a phase works on, picked out of the wave's slots with scalar tests (one instantiation of A1 / A2 instead of five)
-    double cur[4];
-    bool have = false;
     // The INVERSE of the tile, X = inv(L), is built row by row IN THE SHADOW of the block factorisations: row s of X needs row s of L
     // (final after step s - 1), the rows above it and inv(L_ss) -- all there once A1(s) is done -- and while one wave factors block
     // (s + 1, s + 1) the others have nothing else to do.  X_sJ = -inv(L_ss) sum_{K = J}^{s-1} L_sK X_KJ, one block per wave; the
@@ -524,7 +570,11 @@ __device__ __forceinline__ void flow_potrf_impl(FlowKWords ka, const FlowArgs* a
     double xr[4] = { 0.0, 0.0, 0.0, 0.0 };            // this wave's block of the previous row of X, written out after the next barrier
     int xJ = -1;                                      // ... its column (-1: none)
     double* Wk = a.Linv + (size_t)k * FLOW_TL;
-    // ---- A1 of block column 0 (its owner: wave 0, slot 0), then per column: barrier, A2, barrier, A3 (+ A1 of the next column)
+    // ---- The factor wave runs a chain of its own: A1(s), barrier, then -- without waiting for anybody -- block (s + 1, s) = B inv(L_ss)^T, the
+    // last update of block (s + 1, s + 1), A1(s + 1), barrier ...  The other seven waves: barrier, A2 of column s, a barrier OF THEIR OWN
+    // (an LDS word; the factor wave is busy), A3 of column s, barrier.  Everything the factor wave reads behind barrier(s) was finished
+    // by the workers in A3(s - 1): the blocks of column s (they put them into their LDS slots at the end of that phase) and the diagonal
+    // blocks with the updates of the columns before s.
 #pragma unroll 1
     for (int s = -1; s < 8; ++s) {
         // opaque copies of the lane coordinates: the swizzled LDS addresses below are loop-invariant, and the compiler would otherwise
@@ -532,80 +582,95 @@ __device__ __forceinline__ void flow_potrf_impl(FlowKWords ka, const FlowArgs* a
         int lr = lr0, lc = lc0, lane = lane0;
         asm volatile("" : "+v"(lr), "+v"(lc), "+v"(lane));
         if (s >= 0) {
-            __syncthreads();                                   // inv(L_ss) is in LDS; every wave is done with row s - 1 of L
+            __syncthreads();                                   // inv(L_ss) is in LDS; the workers are done with A3(s - 1)
             BSFM_FLOW_MARK(4 + 4 * s + 1);
-            if (xJ >= 0) {
-                // row s - 1 of X: into the slot of L_(s-1)J and out to W
-                double* slot = Lb + ((s - 1) * (s - 2) / 2 + xJ) * 256;
+            if (factor_wave) {
+                if (s < 7) {
+                    // block (s + 1, s) of L, the one the next diagonal block waits for (its owner leaves it to this wave) ...
+                    double* dst = Lb + ((s + 1) * s / 2 + s) * 256;
+                    const double* Dd = Di + s * 256;
+                    const double* Dj = Di + (s + 1) * 256;
+                    double av[4], bv[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    slot[swz16(4 * q + lr, lc)] = xr[q];
-                    st_sc1(Wk + (size_t)(16 * (s - 1) + 4 * q + lr) * POTRF_NB + 16 * xJ + lc, xr[q]);
+                    for (int q = 0; q < 4; ++q) { av[q] = dst[swz16(lc, 4 * q + lr)]; bv[q] = Dd[swz16(lc, 4 * q + lr)]; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cur[q] = Dj[swz16(4 * q + lr, lc)];
+                    // (computed TRANSPOSED, X^T = inv(L_ss) B^T -- the same operands the other way round: the accumulator layout of X^T is the
+                    //  operand layout of X, so the update below takes it straight from the registers instead of through LDS; two
+                    //  accumulator chains: half the dependent latency)
+                    v4d x0 = { 0.0, 0.0, 0.0, 0.0 }, x1 = { 0.0, 0.0, 0.0, 0.0 };
+                    x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[0], av[0], x0, 0, 0, 0);
+                    x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[1], av[1], x1, 0, 0, 0);
+                    x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[2], av[2], x0, 0, 0, 0);
+                    x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[3], av[3], x1, 0, 0, 0);
+                    // ... and the update of block (s + 1, s + 1) by it
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) av[q] = x0[q] + x1[q];                 // X[lc][4 q + lr]
+                    v4d c0 = { cur[0], cur[1], cur[2], cur[3] }, c1 = { 0.0, 0.0, 0.0, 0.0 };
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[0], av[0], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[1], av[1], c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[2], av[2], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[3], av[3], c1, 0, 0, 0);
+                    // block (s + 1, s) for the workers (off this wave's chain), and this wave's share of their barrier
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dst[swz16(lc, 4 * q + lr)] = av[q];
+                    if (lane == 0) __hip_atomic_fetch_add((int*)(lds + FLOW_WSYNC), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cur[q] = c0[q] + c1[q];
                 }
-                xJ = -1;
-            }
-            // ---- A2
-            int Isel = -1;
+            } else {
+                if (xJ >= 0) {
+                    // row s - 1 of X: into the slot of L_(s-1)J and out to W
+                    double* slot = Lb + ((s - 1) * (s - 2) / 2 + xJ) * 256;
 #pragma unroll
-            for (int m = 0; m < 5; ++m)
-                if (sJ[m] == s && sI[m] > s) {
-                    Isel = sI[m];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) cur[q] = t[m][q];
+                    for (int q = 0; q < 4; ++q) {
+                        slot[swz16(4 * q + lr, lc)] = xr[q];
+                        st_sc1(Wk + (size_t)(16 * (s - 1) + 4 * q + lr) * POTRF_NB + 16 * xJ + lc, xr[q]);
+                    }
+                    xJ = -1;
                 }
-            if (Isel >= 0) {
-                double* dst = Lb + (Isel * (Isel - 1) / 2 + s) * 256;
-                const double* Dd = Di + s * 256;
+                // ---- A2: the wave's blocks of column s (already in their LDS slots) except (s + 1, s), which is the factor wave's
 #pragma unroll
-                for (int q = 0; q < 4; ++q) dst[swz16(4 * q + lr, lc)] = cur[q];
-                BSFM_LDS_FENCE();
-                double av[4], bv[4];
+                for (int m = 0; m < 5; ++m)
+                    if (sJ[m] == s && sI[m] != s + 1) {
+                        const int Isel = sI[m];
+                        double* dst = Lb + (Isel * (Isel - 1) / 2 + s) * 256;
+                        const double* Dd = Di + s * 256;
+                        double av[4], bv[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { av[q] = dst[swz16(lc, 4 * q + lr)]; bv[q] = Dd[swz16(lc, 4 * q + lr)]; }
-                v4d x = { 0.0, 0.0, 0.0, 0.0 };
+                        for (int q = 0; q < 4; ++q) { av[q] = dst[swz16(lc, 4 * q + lr)]; bv[q] = Dd[swz16(lc, 4 * q + lr)]; }
+                        v4d x0 = { 0.0, 0.0, 0.0, 0.0 }, x1 = { 0.0, 0.0, 0.0, 0.0 };     // two accumulator chains (as the factor wave's: the same bits for the same block)
+                        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], x0, 0, 0, 0);
+                        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], x1, 0, 0, 0);
+                        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], x0, 0, 0, 0);
+                        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], x1, 0, 0, 0);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], x, 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) dst[swz16(4 * q + lr, lc)] = x[q];
+                        for (int q = 0; q < 4; ++q) dst[swz16(4 * q + lr, lc)] = x0[q] + x1[q];
+                    }
             }
-            __syncthreads();                                   // block column s of L and row s - 1 of X are in LDS
-            BSFM_FLOW_MARK(4 + 4 * s + 2);
-            if (s == 7) break;
-            // ---- A3, the next diagonal block first
-            have = false;
-#pragma unroll
-            for (int m = 0; m < 5; ++m)
-                if (sI[m] == s + 1 && sJ[m] == s + 1) {
-                    have = true;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) cur[q] = t[m][q];
+            if (s == 7) { __syncthreads(); BSFM_FLOW_MARK(4 + 4 * s + 2); break; }      // row 6 of X is in LDS
+            if (!factor_wave) {
+                // the seven waves' own barrier: block column s of L (the factor wave adds its one for block (s + 1, s) and goes on without
+                // waiting) and row s - 1 of X are in LDS.
+                // One lane adds, the wave polls: LDS executes the DS instructions of a CU in order, so whoever reads the full count reads
+                // behind every write that preceded the adds.
+                if (lane == 0) __hip_atomic_fetch_add((int*)(lds + FLOW_WSYNC), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                unsigned spins = 0;
+                while (__builtin_amdgcn_readfirstlane(*wsync) < 8 * (s + 1)) {
+                    if (++spins > (1u << 24)) { atomicExch(a.sync + 1, 1u); break; }
                 }
-            if (have) {
-                const double* Ap = Lb + ((s + 1) * s / 2 + s) * 256;
-                double av[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) av[q] = Ap[swz16(lc, 4 * q + lr)];
-                v4d c = { cur[0], cur[1], cur[2], cur[3] };
-#pragma unroll
-                for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[q], av[q], c, 0, 0, 0);
-                cur[0] = c[0]; cur[1] = c[1]; cur[2] = c[2]; cur[3] = c[3];
             }
-        } else {
-            have = (w == 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cur[q] = t[0][q];
         }
         const int sn = s + 1;                                  // the block column whose diagonal block is factored now
-        if (have) {
+        if (factor_wave) {
             // ---- A1: factor + inverse of block (sn, sn)
             double* blk = Di + sn * 256;
+            BSFM_FLOW_MARK(4 + 4 * sn);
 #pragma unroll
             for (int q = 0; q < 4; ++q) blk[swz16(4 * q + lr, lc)] = cur[q];
             BSFM_LDS_FENCE();
-            __builtin_amdgcn_s_setprio(3);                      // the one wave the whole factorisation waits for: first pick of its SIMD's issue slots
             const int bad = flow_factor16<V>(blk, lane);
-            __builtin_amdgcn_s_setprio(0);
-            if (s < 0) BSFM_FLOW_MARK(3);
+            BSFM_FLOW_MARK(s < 0 ? 3 : 4 + 4 * s + 3);
             if (lane == 0 && bad >= 0 && base + 16 * sn + bad < n_total) {
                 // dpotrf's info is the FIRST failing leading minor.  With an envelope whose diagonal tiles are independent (block-diagonal S)
                 // POTRFs of different columns run concurrently, so "first in time" is not "first in the matrix": keep the minimum
@@ -619,31 +684,55 @@ __device__ __forceinline__ void flow_potrf_impl(FlowKWords ka, const FlowArgs* a
                 }
             }
         }
-        if (s >= 0) {
-            // ---- A3, the other live blocks
+        if (s >= 0 && wi >= 0) {
+            // ---- A3 (workers), every live block; the blocks of column s + 1 are final with it and go to their LDS slots
 #pragma unroll
             for (int m = 0; m < 5; ++m)
-                if (sJ[m] > s && !(sI[m] == s + 1 && sJ[m] == s + 1)) {
+                if (sJ[m] > s) {
                     const int I = sI[m], J = sJ[m];
                     const double* Ap = Lb + (I * (I - 1) / 2 + s) * 256;
-                    const double* Bp = I == J ? Ap : Lb + (J * (J - 1) / 2 + s) * 256;
+                    const double* Bp = Lb + (J * (J - 1) / 2 + s) * 256;
                     double av[4], bv[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { av[q] = -Ap[swz16(lc, 4 * q + lr)]; bv[q] = Bp[swz16(lc, 4 * q + lr)]; }
-                    v4d c = { t[m][0], t[m][1], t[m][2], t[m][3] };
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], c, 0, 0, 0);
+                    v4d c0 = { t[m][0], t[m][1], t[m][2], t[m][3] }, c1 = { 0.0, 0.0, 0.0, 0.0 };      // two chains: half the dependent latency
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], c1, 0, 0, 0);
+                    const v4d c = c0 + c1;
                     t[m][0] = c[0]; t[m][1] = c[1]; t[m][2] = c[2]; t[m][3] = c[3];
+                    if (J == s + 1) {
+                        double* dst = Lb + (I * (I - 1) / 2 + J) * 256;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) dst[swz16(4 * q + lr, lc)] = c[q];
+                    }
                 }
-            BSFM_FLOW_MARK(4 + 4 * s + 3);
-            // ---- row s of X (s >= 1): block (s, J) by the J-th wave that is not factoring
-            if (s >= 1 && !have) {
-                const int own = ((s + 1) * (s + 2) / 2) & 7;          // the wave that owns block (s + 1, s + 1)
-                const int J = w < own ? w : w - 1;
+            // ... and ONE pending diagonal block: (J, J) -= L_Js L_Js^T for J = s + 2 + worker index (in LDS; block s + 1 is the factor wave's)
+            {
+                const int J = s + 2 + wi;
+                if (J < 8) {
+                    const double* Ap = Lb + (J * (J - 1) / 2 + s) * 256;
+                    double* Dj = Di + J * 256;
+                    double av[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) av[q] = Ap[swz16(lc, 4 * q + lr)];
+                    v4d c0 = { Dj[swz16(lr, lc)], Dj[swz16(4 + lr, lc)], Dj[swz16(8 + lr, lc)], Dj[swz16(12 + lr, lc)] }, c1 = { 0.0, 0.0, 0.0, 0.0 };
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[0], av[0], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[1], av[1], c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[2], av[2], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[3], av[3], c1, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Dj[swz16(4 * q + lr, lc)] = c0[q] + c1[q];
+                }
+            }
+            // ---- row s of X (1 <= s <= 6 here: at most six blocks): block (s, J) by worker J
+            if (s >= 1) {
+                const int J = wi;
                 if (J < s) {
                     // (rolled on purpose: unrolled over K with scalar tests and two accumulator chains the role spills and a tile takes 46-52 us
                     //  instead of 39-41)
-                    v4d acc = { 0.0, 0.0, 0.0, 0.0 };
+                    v4d acc0 = { 0.0, 0.0, 0.0, 0.0 }, acc1 = { 0.0, 0.0, 0.0, 0.0 };      // two chains: this row is up to 24 dependent products otherwise
 #pragma unroll 1
                     for (int K = J; K < s; ++K) {
                         const double* Ap = Lb + (s * (s - 1) / 2 + K) * 256;                                   // L_sK
@@ -651,14 +740,19 @@ __device__ __forceinline__ void flow_potrf_impl(FlowKWords ka, const FlowArgs* a
                         double av[4], bv[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) { av[q] = Ap[swz16(lc, 4 * q + lr)]; bv[q] = Bp[swz16(4 * q + lr, lc)]; }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc1, 0, 0, 0);
                     }
+                    const v4d acc = acc0 + acc1;
                     const double* Ds = Di + s * 256;
-                    v4d res = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) res = __builtin_amdgcn_mfma_f64_16x16x4f64(Ds[swz16(lc, 4 * q + lr)], acc[q], res, 0, 0, 0);
-                    xr[0] = -res[0]; xr[1] = -res[1]; xr[2] = -res[2]; xr[3] = -res[3];
+                    v4d res0 = { 0.0, 0.0, 0.0, 0.0 }, res1 = { 0.0, 0.0, 0.0, 0.0 };
+                    res0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ds[swz16(lc, lr)], acc[0], res0, 0, 0, 0);
+                    res1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ds[swz16(lc, 4 + lr)], acc[1], res1, 0, 0, 0);
+                    res0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ds[swz16(lc, 8 + lr)], acc[2], res0, 0, 0, 0);
+                    res1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ds[swz16(lc, 12 + lr)], acc[3], res1, 0, 0, 0);
+                    xr[0] = -(res0[0] + res1[0]); xr[1] = -(res0[1] + res1[1]); xr[2] = -(res0[2] + res1[2]); xr[3] = -(res0[3] + res1[3]);
                     xJ = J;
                 }
             }
@@ -1106,12 +1200,12 @@ inline void flow_dump_trace(FlowWorkspace& f, hipStream_t st)
     }
     std::vector<long long> ph(40 * (size_t)f.nblk);
     if (hipMemcpy(ph.data(), f.d_trace + 4 * nt, ph.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
-        fprintf(fp, "# POTRF phases per column (us since entry): loaded | per block column: inverse diagonal block visible, block column visible, updates issued | loop done, end\n");
+        fprintf(fp, "# POTRF phases per column (us since entry, stamped by the factor wave): loaded | per block column: [A1 of this column began] inverse diagonal block visible (the barrier), A1 of the next column done (last column: the closing barrier) | loop done, end\n");
         for (int k = 0; k < f.nblk; ++k) {
             const long long* q = ph.data() + 40 * (size_t)k;
             fprintf(fp, "#P %d: %.2f (first block factored %.2f) |", k, (q[2] - q[1]) * 0.01, (q[3] - q[1]) * 0.01);
-            for (int s2 = 0; s2 < 8; ++s2) fprintf(fp, " %.2f %.2f %.2f |", (q[5 + 4 * s2] - q[1]) * 0.01, (q[6 + 4 * s2] - q[1]) * 0.01, s2 < 7 ? (q[7 + 4 * s2] - q[1]) * 0.01 : 0.0);
-            fprintf(fp, " %.2f %.2f\n", (q[36] - q[1]) * 0.01, (q[37] - q[1]) * 0.01);
+            for (int s2 = 0; s2 < 8; ++s2) fprintf(fp, " [%.2f] %.2f %.2f |", (q[4 + 4 * s2] - q[1]) * 0.01, (q[5 + 4 * s2] - q[1]) * 0.01, s2 < 7 ? (q[7 + 4 * s2] - q[1]) * 0.01 : (q[6 + 4 * s2] - q[1]) * 0.01);
+            fprintf(fp, " %.2f %.2f \n", (q[36] - q[1]) * 0.01, (q[37] - q[1]) * 0.01);
         }
     }
     fclose(fp);

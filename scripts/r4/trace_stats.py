@@ -27,4 +27,4 @@ b = queue == 0
 nb = len(np.unique(wg[b]))
 print('  ' + ' '.join(f'{(np.clip(td[b], a, c) - np.clip(tr[b], a, c)).sum() / (nb * (c - a)):.2f}/{(np.clip(tr[b], a, c) - np.clip(tt[b], a, c)).sum() / (nb * (c - a)):.2f}' for a, c in zip(edges[:-1], edges[1:])))
 for l in open(path):
-    if l.startswith('#P') and l.split()[1] in ('5:', '40:', '65:'): print(l.strip())
+    if l.startswith('#P') and l.split()[1] in ('1:', '5:', '40:', '65:'): print(l.strip())
