@@ -1253,6 +1253,59 @@ inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, in
     return 0;
 }
 
+// A system of ONE tile (n <= 128: the first pairs and triples of an incremental reconstruction, src/BundleFast.cpp:263-438): the tile
+// factorisation of the dataflow kernel and both substitutions in one workgroup, one launch.  x = inv(L)^T (inv(L) E); the inverse factor
+// was written by this workgroup with write-through stores and is read back past the L1 (agent-scope loads).
+__global__ __launch_bounds__(512, 2) void k_flow_solve_one(FlowArgs a_param, const double* __restrict__ E, double* __restrict__ x)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const FlowKWords ka = (FlowKWords)__builtin_amdgcn_kernarg_segment_ptr();
+    if (threadIdx.x == 64 * FLOW_FACTOR_WAVE) *a_param.info = 0;          // (the lane that reports a failing pivot)
+    flow_potrf(FlowTag<2>(), ka, &a_param, 0, lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    double* vec = lds; double* red = lds + POTRF_NB; double* yv = lds + 5 * POTRF_NB;         // the blocks in LDS are no longer needed
+    const int n_total = a_param.n_total;
+    const double* Linv = a_param.Linv;
+    const int r = threadIdx.x & 127, h = threadIdx.x >> 7;                                      // 4 quarter-sums per row
+    if (threadIdx.x < POTRF_NB) vec[threadIdx.x] = threadIdx.x < n_total ? E[threadIdx.x] : 0.0;
+    __syncthreads();
+    {
+        const double* Li = Linv + (size_t)r * POTRF_NB + 32 * h;
+        double s = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < 32; ++c) s += ld_sc1(Li + c) * vec[32 * h + c];
+        red[h * POTRF_NB + r] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < POTRF_NB) yv[r] = (red[r] + red[POTRF_NB + r]) + (red[2 * POTRF_NB + r] + red[3 * POTRF_NB + r]);
+    __syncthreads();
+    {
+        double s = 0.0;                                                                          // x[r] = sum_q inv(L)[q][r] y[q]
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) s += ld_sc1(Linv + (size_t)(32 * h + q) * POTRF_NB + r) * yv[32 * h + q];
+        red[h * POTRF_NB + r] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < POTRF_NB && threadIdx.x < n_total) x[r] = (red[r] + red[POTRF_NB + r]) + (red[2 * POTRF_NB + r] + red[3 * POTRF_NB + r]);
+}
+inline int flow_solve_one(PotrfWorkspace& w, double* S, int ld, int n, const double* E, double* x_out, int* d_info, hipStream_t st)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_flow_solve_one), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(FLOW_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+        attr_set = true;
+    }
+    FlowArgs a;
+    memset(&a, 0, sizeof a);
+    a.S = S; a.ld = ld; a.n_total = n; a.T = 1; a.Linv = w.linv; a.info = d_info;
+    a.sync = reinterpret_cast<unsigned*>(w.bflags);      // (only word [1], the time-out word, can be touched: the workers' bounded wait)
+    a.spin_limit = FLOW_SPIN_LIMIT_TICKS; a.stall_ticket = -1;
+    hipLaunchKernelGGL(k_flow_solve_one, dim3(1), dim3(512), FLOW_LDS_DOUBLES * sizeof(double), st, a, E, x_out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 inline int flow_solve_dispatch(PotrfWorkspace& w, double* S, int ld, int n, const double* E, double* x_out, int* d_info, hipStream_t st)
 {
     if (!w.flow) w.flow = new FlowWorkspace();

@@ -97,6 +97,7 @@ struct FlowWorkspace;          // chol_flow.hip.h: the tile-dataflow factorisati
 struct PotrfWorkspace;
 inline int flow_solve_dispatch(PotrfWorkspace& w, double* S, int ld, int n, const double* E, double* x_out, int* d_info, hipStream_t st);
 inline void flow_release(PotrfWorkspace& w);
+inline int flow_solve_one(PotrfWorkspace& w, double* S, int ld, int n, const double* E, double* x_out, int* d_info, hipStream_t st);
 
 struct PotrfWorkspace {
     FlowWorkspace* flow = nullptr;
@@ -1172,7 +1173,12 @@ inline int potrf_solve(PotrfWorkspace& w, double* S, int ld, int n, const double
         return -1;
     }
     w.sy_used = 0;
-    if (nblk == 1) {         // one tile: everything in one launch
+    if (nblk == 1 && w.use_flow) {      // one tile: everything in one launch, the tile factorisation of the dataflow kernel (27 us; the round-2 one below: 42)
+        const int rc = flow_solve_one(w, S, ld, n, E, x_out, d_info, st);
+        if (w.ev1 && w.timing) (void)hipEventRecord(w.ev1, st);
+        return rc;
+    }
+    if (nblk == 1) {         // (BSFM_CHOL=streams: the A/B reference)
         hipLaunchKernelGGL(k_potrf_solve_one, dim3(1), dim3(512), DG_LDS_DOUBLES * sizeof(double), st, S, ld, n, w.linv, d_info, E, x_out);
         if (w.ev1 && w.timing) (void)hipEventRecord(w.ev1, st);
         return 0;

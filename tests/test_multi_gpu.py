@@ -180,7 +180,7 @@ def test_rccl_communicator_from_env_world_size_one(tmp_path):
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_PORT="29876", BSFM_COMM_FORCE_RCCL="1",
                BSFM_COMM_ID_FILE=str(tmp_path / "nccl.id"), HSA_ENABLE_IPC_MODE_LEGACY="0")
     code = f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {HERE!r}); import test_multi_gpu as t; t._rccl_world1({str(out)!r})"
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=170)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0, r.stderr[-2000:]
     res = json.load(open(out))
     assert res["ok"] and res["transport"] == "rccl"
@@ -255,7 +255,7 @@ def test_two_processes_one_gpu_through_the_native_ipc_transport(tmp_path):
                    BSFM_COMM_TIMEOUT_S="60", HSA_ENABLE_IPC_MODE_LEGACY="0")
         code = f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {HERE!r}); import test_multi_gpu as t; t._ipc_worker({out!r})"
         procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    errs = [p.communicate(timeout=170) for p in procs]
+    errs = [p.communicate(timeout=420) for p in procs]
     assert all(p.returncode == 0 for p in procs), [e[1][-1500:] for e in errs]
     m = sc["m"]
     res = [json.load(open(out + f".{k}.json")) for k in (0, 1)]
@@ -279,7 +279,7 @@ def test_ipc_transport_times_out_when_a_rank_is_missing(tmp_path):
                BSFM_COMM_TRANSPORT="ipc", BSFM_COMM_ID_FILE=str(tmp_path / "job.id"), BSFM_COMM_TIMEOUT_S="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     code = (f"import sys; sys.path.insert(0, {ROOT!r}); import bundler_sfm_amd as B; import ctypes as C; "
             "B.lib.bsfm_comm_create_from_env.restype = C.c_void_p; c = B.lib.bsfm_comm_create_from_env(); print('COMM', bool(c))")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=420)
     assert r.returncode == 0 and "COMM False" in r.stdout
     assert "only 1 of 2 ranks reached the ipc group" in r.stderr
 
