@@ -473,8 +473,12 @@ constexpr int FLOW_FACTOR_WAVE = 3, FLOW_IDLE_WAVE = 7;
 __device__ const unsigned long long kFlowPotrfSlots[8] = {      // 5 slots per wave, 8 bits each: I << 4 | J, 0xff = empty; sorted by (J, I)
     0xff74437110ull, 0x6553322120ull, 0x7563423130ull, 0xffffffffffull, 0x7673524140ull, 0xff54625150ull, 0xff64726160ull, 0xffffffff70ull };
 
-template <int V>
-__device__ __forceinline__ void flow_potrf_impl(FlowKWords ka, const FlowArgs* a_in, int k, double* lds)
+// IS_F: the instantiation the factor wave runs / the one the other seven waves run.  Two functions, not one with a wave test inside: in the
+// 128-VGPR build a role is a function of its own, and in ONE function the workers' blocks (40 VGPRs, live across the whole loop) and the
+// 64 registers of A1 do not fit together -- A1 had to be a call, with a save / restore of ~46 registers through scratch around each of the
+// eight block factorisations (POTRF 36 us in that build against 27 in the 256-VGPR one).
+template <int V, bool IS_F>
+__device__ __forceinline__ void flow_potrf_part(FlowKWords ka, const FlowArgs* a_in, int k, double* lds)
 {
     const FlowArgs a = flow_role_args<V>(ka, a_in); BSFM_UNIFORM_INT(k);
     double* Lb = lds + FLOW_LB; double* Di = lds + FLOW_DI;
@@ -486,8 +490,8 @@ __device__ __forceinline__ void flow_potrf_impl(FlowKWords ka, const FlowArgs* a
 #define BSFM_FLOW_MARK(code) do { if (a.trace && lane0 == 0 && w == FLOW_FACTOR_WAVE) a.trace[a.ptrace_ofs + 40 * (size_t)k + (code)] = wall_clock64(); } while (0)
 #define BSFM_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
     BSFM_FLOW_MARK(1);
-    const bool factor_wave = w == FLOW_FACTOR_WAVE;
-    const int wi = w < 3 ? w : (w == 3 || w == 7) ? -1 : w - 1;      // 0 .. 5: worker, -1: factor wave / wave 7 (wave-uniform: w is an SGPR)
+    constexpr bool factor_wave = IS_F;
+    const int wi = IS_F ? -1 : w < 3 ? w : (w == 3 || w == 7) ? -1 : w - 1;      // 0 .. 5: worker, -1: factor wave / wave 7 (wave-uniform: w is an SGPR)
     typedef __attribute__((address_space(3))) volatile int FlowLdsWord;
     FlowLdsWord* wsync = (FlowLdsWord*)(lds + FLOW_WSYNC);
     if (w == 0 && lane0 == 0) *wsync = 0;                  // (the first use is behind the first barrier)
@@ -669,7 +673,7 @@ __device__ __forceinline__ void flow_potrf_impl(FlowKWords ka, const FlowArgs* a
 #pragma unroll
             for (int q = 0; q < 4; ++q) blk[swz16(4 * q + lr, lc)] = cur[q];
             BSFM_LDS_FENCE();
-            const int bad = flow_factor16<V>(blk, lane);
+            const int bad = flow_factor16_body(blk, lane);
             BSFM_FLOW_MARK(s < 0 ? 3 : 4 + 4 * s + 3);
             if (lane == 0 && bad >= 0 && base + 16 * sn + bad < n_total) {
                 // dpotrf's info is the FIRST failing leading minor.  With an envelope whose diagonal tiles are independent (block-diagonal S)
@@ -802,19 +806,26 @@ __device__ BSFM_FLOW_ROLE void flow_trsm64(FlowTag<4>, FlowKWords ka, const Flow
 __device__ __forceinline__ void flow_trsm64(FlowTag<2>, FlowKWords ka, const FlowArgs* a_in, int i, int k, int r0, double* lds) { flow_trsm64_impl<2>(ka, a_in, i, k, r0, lds); }
 template <bool IS_UPD> __device__ BSFM_FLOW_ROLE void flow_tile32(FlowTag<4>, FlowKWords ka, const FlowArgs* a_in, int i, int k, int p0, int np, int part, double* lds) { flow_tile32_impl<IS_UPD, 4>(ka, a_in, i, k, p0, np, part, lds); }
 template <bool IS_UPD> __device__ __forceinline__ void flow_tile32(FlowTag<2>, FlowKWords ka, const FlowArgs* a_in, int i, int k, int p0, int np, int part, double* lds) { flow_tile32_impl<IS_UPD, 2>(ka, a_in, i, k, p0, np, part, lds); }
-__device__ BSFM_FLOW_ROLE void flow_potrf(FlowTag<4>, FlowKWords ka, const FlowArgs* a_in, int k, double* lds) { flow_potrf_impl<4>(ka, a_in, k, lds); }
-__device__ __forceinline__ void flow_potrf(FlowTag<2>, FlowKWords ka, const FlowArgs* a_in, int k, double* lds) { flow_potrf_impl<2>(ka, a_in, k, lds); }
+__device__ BSFM_FLOW_ROLE void flow_potrf_factor(FlowTag<4>, FlowKWords ka, const FlowArgs* a_in, int k, double* lds) { flow_potrf_part<4, true>(ka, a_in, k, lds); }
+__device__ BSFM_FLOW_ROLE void flow_potrf_workers(FlowTag<4>, FlowKWords ka, const FlowArgs* a_in, int k, double* lds) { flow_potrf_part<4, false>(ka, a_in, k, lds); }
+__device__ __forceinline__ void flow_potrf_factor(FlowTag<2>, FlowKWords ka, const FlowArgs* a_in, int k, double* lds) { flow_potrf_part<2, true>(ka, a_in, k, lds); }
+__device__ __forceinline__ void flow_potrf_workers(FlowTag<2>, FlowKWords ka, const FlowArgs* a_in, int k, double* lds) { flow_potrf_part<2, false>(ka, a_in, k, lds); }
+template <int V> __device__ __forceinline__ void flow_potrf(FlowTag<V> tag, FlowKWords ka, const FlowArgs* a_in, int k, double* lds)
+{
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == FLOW_FACTOR_WAVE) flow_potrf_factor(tag, ka, a_in, k, lds);
+    else flow_potrf_workers(tag, ka, a_in, k, lds);
+}
 
 constexpr long long FLOW_SPIN_LIMIT_TICKS = 40LL * 1000 * 1000;      // 0.4 s of the 100 MHz wall clock: far beyond any solve this library accepts (BSFM_FLOW_SPIN_MS overrides it)
 
 // Two builds of the one kernel (round 5): WPS = waves per SIMD it is compiled for.
 //   4  two 512-thread workgroups per CU, 128 VGPRs: the THROUGHPUT build -- what a bulk-bound factorisation (many tile products per column)
 //      needs; its roles are functions of their own, and at 128 VGPRs each call saves / restores ~46 callee-saved registers through scratch.
-//   2  one workgroup per CU, 256 VGPRs: the LATENCY build -- no scratch anywhere, the 16 x 16 block factorisation inlined.  A POTRF takes
-//      36.6 instead of 40.8 us and a bulk tile product 25 instead of 34 us (nobody shares the CU), at half the resident workgroups: faster up to
-//      ~45 tile columns (n = 450: 0.27 -> 0.23 ms, 1 800: 0.90 -> 0.76, 3 712: 1.68 -> 1.45, 5 400: 2.80 -> 2.72; 9 000: 6.5 -> 6.9), i.e. for
-//      every problem of an incremental reconstruction (src/BundleFast.cpp:263-438: 14 - 400 cameras).  flow_solve picks by tile count
-//      (BSFM_FLOW_LATENCY_TILES, default 45).
+//   2  one workgroup per CU, 256 VGPRs: the LATENCY build -- no scratch anywhere, every role inlined.  A POTRF takes 27 instead of 29.5 us and
+//      a bulk tile product 25 instead of 34 us (nobody shares the CU), at half the resident workgroups: faster up to ~38 tile columns (end of
+//      round 5, n = 3 712: 1.33 -> 1.22 ms; 5 400: 2.37 against 2.41 -- there the throughput build wins), i.e. for every problem of an
+//      incremental reconstruction (src/BundleFast.cpp:263-438: 14 - 400 cameras).  flow_solve picks by tile count
+//      (BSFM_FLOW_LATENCY_TILES, default 38).
 // NOTE on control flow.  Ticket, waits and signal are single-thread jobs between workgroup barriers.  Written as `if (tid == 0) { ...
 // loops, exits ... }` they are NOT sound: a lane-divergent region with loops inside gives the compiler no obligation to reconverge
 // wave 0 before the next barrier -- on the first bring-up lanes 1..63 of wave 0 ran on (through the barrier and the whole POTRF role,
@@ -1073,8 +1084,12 @@ inline FlowParams flow_params_from_env()
     if (const char* e = getenv("BSFM_FLOW_SLOTS")) p.slots = std::max(32, atoi(e));
     if (const char* e = getenv("BSFM_FLOW_URGENT")) p.urgent_cols = std::max(0, atoi(e));
     if (const char* e = getenv("BSFM_FLOW_LAZY")) p.lazy_cols = std::max(0, atoi(e));
+    if (const char* e = getenv("BSFM_FLOW_LOOKAHEAD")) p.lookahead = std::max(0, atoi(e));
     if (const char* e = getenv("BSFM_FLOW_ADAPT")) p.adaptive_halves = std::max(0, atoi(e));
     if (const char* e = getenv("BSFM_FLOW_TPOTRF")) p.t_potrf = atof(e);
+    if (const char* e = getenv("BSFM_FLOW_THAND")) p.t_hand = atof(e);
+    if (const char* e = getenv("BSFM_FLOW_TCHAIN")) { double a0 = 0, a1 = 0, a2 = 0, a3 = 0; if (sscanf(e, "%lf,%lf,%lf,%lf", &a0, &a1, &a2, &a3) == 4) { p.t_trsm32 = a0; p.t_trsm64 = a1; p.t_upd32 = a2; p.t_upd32_per = a3; } }
+    if (const char* e = getenv("BSFM_FLOW_TUPD64")) { double a0 = 0, a1 = 0; if (sscanf(e, "%lf,%lf", &a0, &a1) == 2) { p.t_upd64_0 = a0; p.t_upd64_per = a1; } }
     if (const char* e = getenv("BSFM_FLOW_TUPD128")) { double a0 = 0, a1 = 0; if (sscanf(e, "%lf,%lf", &a0, &a1) == 2) { p.t_upd128_0 = a0; p.t_upd128_per = a1; } }
     return p;
 }
@@ -1092,7 +1107,7 @@ inline int flow_cached_schedule(int nblk, const std::vector<int>& key, const Flo
 {
     const std::vector<double> pv = { (double)p.slots, (double)p.np_max, (double)p.np_max_rhs, p.t_potrf, p.t_trsm32, p.t_trsm64, p.t_upd32, p.t_upd32_per,
                                      p.t_upd64_0, p.t_upd64_per, p.t_upd128_0, p.t_upd128_per, p.t_ftrsm, p.t_fupd_0, p.t_fupd_per, p.t_hand,
-                                     (double)p.urgent_cols, (double)p.lazy_cols, (double)p.adaptive_halves };
+                                     (double)p.urgent_cols, (double)p.lazy_cols, (double)p.adaptive_halves, (double)p.lookahead };
     {
         std::lock_guard<std::mutex> lock(flow_sched_cache_mutex());
         auto& c = flow_sched_cache();
@@ -1144,7 +1159,7 @@ inline int flow_prepare(FlowWorkspace& f, int nblk, const std::vector<int>& env_
     if (const char* e = getenv("BSFM_FLOW_CHAIN_WGS")) f.chain_wgs = std::max(0, atoi(e));
     f.chain_wgs = std::min(f.chain_wgs, f.wgs / 4);
     {
-        int lat_tiles = 45;
+        int lat_tiles = 38;
         if (const char* e = getenv("BSFM_FLOW_LATENCY_TILES")) lat_tiles = atoi(e);
         f.latency_build = nblk <= lat_tiles;
     }

@@ -72,6 +72,11 @@ struct FlowParams {
     int adaptive_halves = 128; // > 0: the column the chain needs next is served in 64-row halves only while the bulk has no backlog (fewer than this many
                               // ready tasks beyond the free slots): a half runs at 50 TFLOP/s-equivalent against 53-73 for a whole tile, and latency only
                               // matters when the chain is the bound.  6.47 -> 6.40 ms at 71 tile columns; 0 = always halves
+    int lookahead = 0;        // > 0: the LOOKAHEAD TRIANGLE (round 5) -- tiles (i, j) with front < j <= i <= front + lookahead are kept current: every panel is
+                              // applied to them as soon as it exists, in 64-row halves, whatever the backlog of the bulk.  Those are the tiles the next
+                              // `lookahead` columns of the chain read (row i of the factor up to column i); kept current, the chain runs ahead of the
+                              // bulk sweeps instead of in step with them (scripts/r5/critical_path.py: at 71 tile columns POTRF(38) waited 145 us for
+                              // the last two visits of tile (38, 37), whole-tile visits of four panels that had been queued behind the bulk)
     int lazy_cols = 0;        // > 0: a bulk tile further than this many columns ahead of the chain is only visited once TWO panels are ready
                               // for it (or its last one): a one-panel visit moves 393 KB for 4.2 Mflop and is HBM-bound
 };
@@ -155,11 +160,12 @@ inline int flow_build_schedule(int T, const std::vector<int>& last_in, const Flo
         }
         return n;
     };
+    auto in_triangle = [&](int i, int j) -> bool { return prm.lookahead > 0 && i < T && i <= front + prm.lookahead; };      // (j <= i always)
     auto classify_upd = [&](int i, int j) -> int {
         const bool urgent_col = j <= front + prm.urgent_cols;
         if (i == T) return urgent_col ? 2 : 3;
         if (i == j && urgent_col) return 1;
-        if (urgent_col) return 2;
+        if (urgent_col || in_triangle(i, j)) return 2;
         return 3;
     };
     auto consider = [&](int i, int j) {                 // push whatever the tile can do now
@@ -228,7 +234,7 @@ inline int flow_build_schedule(int T, const std::vector<int>& last_in, const Flo
                 const int cls = classify_upd(i, j);
                 if (i == T) { type = FT_FUPD; parts = 1; dur = prm.t_fupd_0 + prm.t_fupd_per * n; }
                 else if (cls == 1) { n = std::min(n, 3); type = FT_UPD32; parts = 10; dur = prm.t_upd32 + prm.t_upd32_per * (n - 1); }
-                else if (cls == 2 && !(prm.adaptive_halves && (long long)ready.size() > (long long)free_slots + prm.adaptive_halves)) {
+                else if (cls == 2 && (in_triangle(i, j) || !(prm.adaptive_halves && (long long)ready.size() > (long long)free_slots + prm.adaptive_halves))) {
                     n = std::min(n, 2); type = FT_UPD64; parts = 2; dur = prm.t_upd64_0 + prm.t_upd64_per * n;
                 }
                 else { type = FT_UPD128; parts = 1; dur = prm.t_upd128_0 + prm.t_upd128_per * n; }
@@ -284,6 +290,9 @@ inline int flow_build_schedule(int T, const std::vector<int>& last_in, const Flo
                     for (int r = j + 1; r < R; ++r) consider(r, j);                      // TRSMs of column j
                     for (int c2 = j + 1; c2 <= std::min(T - 1, front + std::max(prm.urgent_cols, prm.lazy_cols)); ++c2)     // urgency may have changed
                         for (int r = c2; r < R; ++r) consider(r, c2);
+                    if (prm.lookahead > 0)                                                  // the row that has just entered the triangle
+                        for (int r = std::max(j + 1, front + 1); r <= std::min(T - 1, front + prm.lookahead); ++r)
+                            for (int c2 = std::max(j + 1, front + prm.urgent_cols + 1); c2 <= r; ++c2) consider(r, c2);
                 } else {
                     // P_ij ready: row operand of tiles (i, c), j < c <= i; column operand of tiles (r, i), r >= i
                     for (int c2 = j + 1; c2 <= std::min(i, T - 1); ++c2) consider(i, c2);
