@@ -650,7 +650,39 @@ extern "C" int bsfm_merge_match_files(int count, const char* const* paths, const
 
 // ---- resident key set: descriptors + per-key statistics stay in HBM across calls (the measurement boundary of bench.py:
 // "inputs already resident in HBM when the timed region starts"; bsfm_key_match_full* = create + run + destroy)
+// One slot of the search pipeline (two per key set): the pairs of one database image, their nearest neighbours, and the pinned buffers the
+// accepted matches arrive in.  Kept with the key set (round 5): allocating 2 x 20 MB of pinned memory, the streams and the events inside
+// every pass was ~20 ms of a 290 ms pass at config 5.
+struct MatchSlot {
+    PairDesc* h_pairs = nullptr; PairDesc* d_pairs = nullptr; int* d_nn = nullptr; int* d_cnt = nullptr;
+    int* h_cnt = nullptr; int2* h_m = nullptr;           // pinned: accepted matches per pair / the pairs' (query, neighbour) lists back to back
+    hipEvent_t done = nullptr, k0 = nullptr, k1 = nullptr; int image = -1; size_t npairs = 0; std::vector<int> js; bool busy = false;
+    double dist = 0.0;
+};
 struct bsfm_match_set {
+    MatchSlot slots[2];
+    hipStream_t sts[2] = { nullptr, nullptr };    // one stream per slot: the tail of a launch (its last workgroups) overlaps the head of the next
+    hipEvent_t base_ev = nullptr;                 // time zero of a pass on the device clock
+    bool pipeline_ready = false;
+    void release_pipeline()
+    {
+        for (MatchSlot& s : slots) {
+            if (s.h_pairs) (void)hipHostFree(s.h_pairs);
+            if (s.h_cnt) (void)hipHostFree(s.h_cnt);
+            if (s.h_m) (void)hipHostFree(s.h_m);
+            if (s.d_cnt) (void)hipFree(s.d_cnt);
+            if (s.d_pairs) (void)hipFree(s.d_pairs);
+            if (s.d_nn) (void)hipFree(s.d_nn);
+            if (s.done) (void)hipEventDestroy(s.done);
+            if (s.k0) (void)hipEventDestroy(s.k0);
+            if (s.k1) (void)hipEventDestroy(s.k1);
+            s = MatchSlot();
+        }
+        for (hipStream_t& q : sts) { if (q) (void)hipStreamDestroy(q); q = nullptr; }
+        if (base_ev) (void)hipEventDestroy(base_ev);
+        base_ev = nullptr; pipeline_ready = false;
+    }
+    ~bsfm_match_set() { release_pipeline(); }
     int num_images = 0;
     std::vector<int> num_keys;
     std::vector<size_t> off;
@@ -724,46 +756,35 @@ static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_rad
     if (tot == 0) { if (f) fclose(f); return 0; }
     // Two-slot pipeline on one stream: while the GPU scans database image k, the host turns the accepted matches of image k-1
     // (compacted on the device, written by k_pair_write straight into the slot's pinned buffers) into text (own integer formatter).
-    struct Slot {
-        PairDesc* h_pairs = nullptr; PairDesc* d_pairs = nullptr; int* d_nn = nullptr; int* d_cnt = nullptr;
-        int* h_cnt = nullptr; int2* h_m = nullptr;           // pinned: accepted matches per pair / the pairs' (query, neighbour) lists back to back
-        hipEvent_t done = nullptr, k0 = nullptr, k1 = nullptr; int image = -1; size_t npairs = 0; std::vector<int> js; bool busy = false;
-        double dist = 0.0;
-    } slots[2];
-    hipEvent_t base_ev = nullptr;   // time zero of the pass on the device clock
+    typedef MatchSlot Slot;
+    Slot (&slots)[2] = ms->slots;
+    hipStream_t (&sts)[2] = ms->sts;
+    hipEvent_t& base_ev = ms->base_ev;
     double cover_end = 0.0;         // end of the union of scan intervals so far (ms after base_ev)
     double accept_rate = 0.0;       // accepted matches per query in the last drained launch (auto mode's signal)
-    hipStream_t sts[2] = { nullptr, nullptr };    // one stream per slot: the tail of a launch (its last workgroups) overlaps the head of the next
     // BSFM_MATCH_STREAMS=1: everything on one stream (launches strictly one after the other: what a profiler's per-launch durations need)
     static const bool one_stream = [] { const char* e = getenv("BSFM_MATCH_STREAMS"); return e && atoi(e) == 1; }();
-    auto release = [&] {
+    auto release = [&] {};          // (the pipeline's buffers stay with the key set: bsfm_match_set::release_pipeline)
+    bool ok = true;
+    if (!ms->pipeline_ready) {
+        ok = hipStreamCreateWithFlags(&sts[0], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&sts[1], hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreate(&base_ev) == hipSuccess;
         for (Slot& s : slots) {
-            if (s.h_pairs) (void)hipHostFree(s.h_pairs);
-            if (s.h_cnt) (void)hipHostFree(s.h_cnt);
-            if (s.h_m) (void)hipHostFree(s.h_m);
-            if (s.d_cnt) (void)hipFree(s.d_cnt);
-            if (s.d_pairs) (void)hipFree(s.d_pairs);
-            if (s.d_nn) (void)hipFree(s.d_nn);
-            if (s.done) (void)hipEventDestroy(s.done);
-            if (s.k0) (void)hipEventDestroy(s.k0);
-            if (s.k1) (void)hipEventDestroy(s.k1);
+            ok = ok && hipHostMalloc((void**)&s.h_pairs, (size_t)num_images * sizeof(PairDesc)) == hipSuccess;
+            ok = ok && hipHostMalloc((void**)&s.h_cnt, (size_t)num_images * sizeof(int)) == hipSuccess;
+            ok = ok && hipHostMalloc((void**)&s.h_m, tot * sizeof(int2)) == hipSuccess;
+            ok = ok && hipMalloc((void**)&s.d_cnt, (size_t)num_images * sizeof(int)) == hipSuccess;
+            ok = ok && hipMalloc((void**)&s.d_pairs, (size_t)num_images * sizeof(PairDesc)) == hipSuccess;
+            ok = ok && hipMalloc((void**)&s.d_nn, tot * sizeof(int)) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreate(&s.k0) == hipSuccess && hipEventCreate(&s.k1) == hipSuccess;
         }
-        for (hipStream_t q : sts) if (q) (void)hipStreamDestroy(q);
-        if (base_ev) (void)hipEventDestroy(base_ev);
-    };
-    bool ok = hipStreamCreateWithFlags(&sts[0], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&sts[1], hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipEventCreate(&base_ev) == hipSuccess && hipEventRecord(base_ev, sts[0]) == hipSuccess;
-    for (Slot& s : slots) {
-        ok = ok && hipHostMalloc((void**)&s.h_pairs, (size_t)num_images * sizeof(PairDesc)) == hipSuccess;
-        ok = ok && hipHostMalloc((void**)&s.h_cnt, (size_t)num_images * sizeof(int)) == hipSuccess;
-        ok = ok && hipHostMalloc((void**)&s.h_m, tot * sizeof(int2)) == hipSuccess;
-        ok = ok && hipMalloc((void**)&s.d_cnt, (size_t)num_images * sizeof(int)) == hipSuccess;
-        ok = ok && hipMalloc((void**)&s.d_pairs, (size_t)num_images * sizeof(PairDesc)) == hipSuccess;
-        ok = ok && hipMalloc((void**)&s.d_nn, tot * sizeof(int)) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
-        ok = ok && hipEventCreate(&s.k0) == hipSuccess && hipEventCreate(&s.k1) == hipSuccess;
+        if (!ok) { fprintf(stderr, "[bsfm] matcher: allocation failed\n"); ms->release_pipeline(); if (f) fclose(f); return BSFM_ERROR; }
+        ms->pipeline_ready = true;
     }
-    if (!ok) { fprintf(stderr, "[bsfm] matcher: allocation failed\n"); release(); if (f) fclose(f); return BSFM_ERROR; }
+    for (Slot& s : slots) { s.busy = false; s.image = -1; s.npairs = 0; s.dist = 0.0; }
+    ok = hipEventRecord(base_ev, sts[0]) == hipSuccess;
+    if (!ok) { fprintf(stderr, "[bsfm] matcher: HIP error\n"); if (f) fclose(f); return BSFM_ERROR; }
     int total_pairs_written = 0;
     std::vector<char> text;
     auto put_int = [&](int v, char sep) {
