@@ -1061,7 +1061,7 @@ struct FlowWorkspace {
     long long spin_limit = FLOW_SPIN_LIMIT_TICKS;      // BSFM_FLOW_SPIN_MS
     int stall_ticket = -1, stall_bwd_col = -1;         // test hooks: BSFM_FLOW_TEST_STALL (bulk ticket that never signals), BSFM_FLOW_TEST_STALL_BWD (column)
     int wgs = 512;                         // workgroups launched (BSFM_FLOW_WGS)
-    int chain_wgs = 16;                    // of them: serve the chain queue, alone on their CU (16 or 26, see flow_prepare; BSFM_FLOW_CHAIN_WGS; 0 = one queue)
+    int chain_wgs = 17;                    // of them: serve the chain queue, alone on their CU (17 or 27, see flow_prepare; BSFM_FLOW_CHAIN_WGS; 0 = one queue)
     bool trace = false;                    // BSFM_FLOW_TRACE=1: per-task stamps, dumped to BSFM_FLOW_TRACE_FILE after every solve
     double flops = 0.0;                    // flops of one factorisation as scheduled (UPD + TRSM tile products, 2 * 128^3 each)
     hipEvent_t k0 = nullptr, k1 = nullptr; // around the k_chol_flow launch: the roofline kernel's duration
@@ -1155,7 +1155,9 @@ inline int flow_prepare(FlowWorkspace& f, int nblk, const std::vector<int>& env_
     // Chain workgroups: 16 serve the sixteen blocks of the first panel tile at once, but the one that has just finished POTRF joins late;
     // a chain-bound factorisation (few tile products per column: up to ~45 dense tile columns, any envelope) gains 1-3 % from 26, a
     // bulk-bound one loses 2 % (every chain workgroup takes a CU away from the bulk): n = 3 600: 1.62 -> 1.58 ms, n = 9 000: 6.40 -> 6.55.
-    f.chain_wgs = (f.sched.upd_tiles + f.sched.trsm_tiles) < 400.0 * nblk ? 26 : 16;
+    // (+ 1: since round 5 one of them serves the POTRF queue alone, and the sixteen parts of a TRSM32 want sixteen others -- with fifteen they
+    //  took two rounds: n = 1 800 0.66 -> 0.61 ms)
+    f.chain_wgs = ((f.sched.upd_tiles + f.sched.trsm_tiles) < 400.0 * nblk ? 26 : 16) + 1;
     if (const char* e = getenv("BSFM_FLOW_CHAIN_WGS")) f.chain_wgs = std::max(0, atoi(e));
     f.chain_wgs = std::min(f.chain_wgs, f.wgs / 4);
     {
