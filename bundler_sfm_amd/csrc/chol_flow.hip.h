@@ -921,13 +921,23 @@ __global__ __launch_bounds__(512, WPS) void k_chol_flow(FlowArgs a_param)
             // every lane of wave 0 polls the same word: one request, a scalar verdict
             const long long t_begin = wall_clock64();
             int ab = 0;
-            for (int q = 0; q < nwait && !ab; ++q) {
-                const unsigned idx = (unsigned)__builtin_amdgcn_readfirstlane((int)tp->w[q].idx);
-                const unsigned thr = (unsigned)__builtin_amdgcn_readfirstlane((int)tp->w[q].thr);
+            {
+                // up to three counters, polled TOGETHER (round 5): one after the other cost a load round trip each -- past the XCD's L2, ~1 us --
+                // even when all of them had long been satisfied, at the start of every task of the chain
+                unsigned idx[3], thr[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int qq = q < nwait ? q : 0;
+                    idx[q] = (unsigned)__builtin_amdgcn_readfirstlane((int)tp->w[qq].idx);
+                    thr[q] = q < nwait ? (unsigned)__builtin_amdgcn_readfirstlane((int)tp->w[qq].thr) : 0u;
+                }
                 unsigned spins = 0;
-                for (;;) {
-                    const unsigned seen = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    if (seen >= thr) break;
+                while (nwait > 0) {
+                    const unsigned s0 = __hip_atomic_load(flags + idx[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned s1 = __hip_atomic_load(flags + idx[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned s2 = __hip_atomic_load(flags + idx[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int ready = __builtin_amdgcn_readfirstlane((int)(s0 >= thr[0] && s1 >= thr[1] && s2 >= thr[2]));
+                    if (ready) break;
                     __builtin_amdgcn_s_sleep(1);
                     if ((++spins & 63u) == 0u) {
                         const unsigned tmo = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
