@@ -544,11 +544,23 @@ template <int CNP>
 __global__ __launch_bounds__(128) void k_schur_assemble(int nblk, const int* __restrict__ blk_j, const int* __restrict__ blk_k,
         const int2* __restrict__ blk_range, const double* __restrict__ partials, const double* __restrict__ epart,
         const double* __restrict__ U, double mu, int mcon, double* __restrict__ S, int ld, double* __restrict__ E,
-        const int* __restrict__ spos)
+        const int* __restrict__ spos, int m_fill = 0, const int* __restrict__ camptr = nullptr)
 {
     // spos (envelope solver): position of free camera c = j - mcon in the reordered system; nullptr = natural order
     const int b = blockIdx.x;
-    if (b >= nblk) return;
+    if (b >= nblk) {
+        // blocks nblk .. : k_schur_diag_fill's job (round 5: one launch fewer per attempt) -- the diagonal block of a camera that has no
+        // (j, j) block in the triple list (no observations)
+        const int j = mcon + (b - nblk);
+        if (j >= m_fill || threadIdx.x >= CNP * CNP) return;
+        if (camptr[j + 1] > camptr[j]) return;
+        const int row = threadIdx.x / CNP, col = threadIdx.x % CNP;
+        double v = U[(size_t)j * CNP * CNP + threadIdx.x];
+        if (row == col) v += mu;
+        const size_t pj = spos ? spos[j - mcon] : j - mcon;
+        S[(pj * CNP + row) * ld + pj * CNP + col] = v;
+        return;
+    }
     const int j = blk_j[b], k = blk_k[b];
     const int pj = spos ? spos[j - mcon] : j - mcon, pk = spos ? spos[k - mcon] : k - mcon;
     const int2 sl = blk_range[b];               // the block's slots: tasks of k_schur_tasks or pieces of k_schur_rows (index_build.hip)
@@ -626,8 +638,16 @@ __global__ void k_schur_diag_fill(int m, int mcon, const int* __restrict__ campt
 // S is rebuilt for every solve attempt (the factorisation overwrites it and fills in its zero blocks).  Only the lower
 // triangle of 128x128 tiles is read by the factorisation, so only that half is cleared: one workgroup per tile,
 // 16-byte stores.  (The strictly upper tiles keep whatever the mirror writes of the assembly put there.)
-__global__ __launch_bounds__(256) void k_zero_lower_tiles(double* __restrict__ S, int ld)
+__global__ __launch_bounds__(256) void k_zero_lower_tiles(double* __restrict__ S, int ld, int ntl = 0x7fffffff, int count = 0, int off = 0, int add_ea = 0,
+        const double* __restrict__ ea = nullptr, double* __restrict__ E = nullptr, const int* __restrict__ spos = nullptr, int cnp = 0)
 {
+    if ((int)blockIdx.x >= ntl) {      // blocks ntl .. : k_rhs_init's job (round 5: one launch fewer per attempt)
+        const int t = ((int)blockIdx.x - ntl) * 256 + threadIdx.x;
+        if (t >= count) return;
+        const int dst = spos ? spos[t / cnp] * cnp + t % cnp : t;
+        E[dst] = add_ea ? ea[off + t] : 0.0;
+        return;
+    }
     int a = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
     while ((a + 1) * (a + 2) / 2 <= (int)blockIdx.x) ++a;
     while (a * (a + 1) / 2 > (int)blockIdx.x) --a;

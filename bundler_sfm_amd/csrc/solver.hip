@@ -692,11 +692,18 @@ int compute_schur(bsfm_problem* pb, double mu)
     // envelope solver: S, E are assembled in the reordered camera numbering (exports always use the natural one)
     const int* spos = (pb->envelope && !pb->export_full_s) ? pb->d_spos : nullptr;
     if (pb->export_full_s) (void)hipMemsetAsync(pb->d_S, 0, (size_t)pb->ld * pb->ld * sizeof(double), pb->stream);
-    else if (!pb->comps.active) {   // (the group-by-group solve never writes S: blocks that are structurally empty stay zero)
-        const int nt = pb->ld / POTRF_NB; hipLaunchKernelGGL(k_zero_lower_tiles, dim3(nt * (nt + 1) / 2), dim3(256), 0, pb->stream, pb->d_S, pb->ld); }
-    if (packed) (void)hipMemsetAsync(pb->d_G, 0, ((size_t)pb->ngblk * cnp * cnp + (size_t)pb->ld) * sizeof(double), pb->stream);
+    bool rhs_done = false, diag_done = false;
     double* Edst = packed ? pb->d_G + (size_t)pb->ngblk * cnp * cnp : pb->d_E;     // packed: E rides behind the blocks
-    if (mm > 0)
+    if (!pb->export_full_s && !pb->comps.active) {   // (the group-by-group solve never writes S: blocks that are structurally empty stay zero)
+        const int nt = pb->ld / POTRF_NB, ntl = nt * (nt + 1) / 2;
+        if (!packed && mm > 0) {      // one launch: the lower tiles of S cleared, E = ea
+            hipLaunchKernelGGL(k_zero_lower_tiles, dim3(ntl + grid_for((size_t)mm * cnp, 256)), dim3(256), 0, pb->stream, pb->d_S, pb->ld, ntl,
+                               mm * cnp, P.mcon * cnp, lead, (const double*)pb->d_ea, Edst, spos, cnp);
+            rhs_done = true;
+        } else hipLaunchKernelGGL(k_zero_lower_tiles, dim3(ntl), dim3(256), 0, pb->stream, pb->d_S, pb->ld);
+    }
+    if (packed) (void)hipMemsetAsync(pb->d_G, 0, ((size_t)pb->ngblk * cnp * cnp + (size_t)pb->ld) * sizeof(double), pb->stream);
+    if (mm > 0 && !rhs_done)
         hipLaunchKernelGGL(k_rhs_init, dim3(grid_for((size_t)mm * cnp, 256)), dim3(256), 0, pb->stream, mm * cnp, P.mcon * cnp,
                            lead, pb->d_ea, Edst, packed ? (const int*)nullptr : spos, cnp);     // (packed: E travels in the natural numbering)
     if (pb->ntasks > 0) {
@@ -731,9 +738,11 @@ int compute_schur(bsfm_problem* pb, double mu)
                                                   pb->d_blk_j, pb->d_blk_k, pb->d_blk_range, pb->d_partials, pb->d_epart,
                                                   pb->d_gidx, pb->d_G, P.mcon, Edst));
         } else {
-            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_assemble<C>), dim3(pb->nblk), dim3(128), 0, pb->stream, pb->nblk,
+            // (+ mm blocks: the diagonal blocks of cameras without observations, k_schur_diag_fill's job)
+            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_assemble<C>), dim3(pb->nblk + std::max(mm, 0)), dim3(128), 0, pb->stream, pb->nblk,
                                                   pb->d_blk_j, pb->d_blk_k, pb->d_blk_range, pb->d_partials, pb->d_epart,
-                                                  pb->d_U, mu, P.mcon, pb->d_S, pb->ld, Edst, spos));
+                                                  pb->d_U, mu, P.mcon, pb->d_S, pb->ld, Edst, spos, P.m, (const int*)pb->d_camptr));
+            diag_done = true;
         }
     }
     if (packed) {
@@ -749,7 +758,7 @@ int compute_schur(bsfm_problem* pb, double mu)
         if (pb->ngblk > 0)
             DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_unpack<C>), dim3(pb->ngblk), dim3(128), 0, pb->stream, pb->ngblk,
                                                   pb->d_gblk_j, pb->d_gblk_k, pb->d_G, pb->d_U, mu, P.mcon, pb->d_S, pb->ld, spos));
-    } else if (mm > 0) {
+    } else if (mm > 0 && !diag_done) {
         DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_diag_fill<C>), dim3(mm), dim3(128), 0, pb->stream, P.m, P.mcon,
                                               pb->d_camptr, pb->d_U, mu, pb->d_S, pb->ld, spos));
     }

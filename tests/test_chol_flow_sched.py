@@ -274,3 +274,23 @@ def test_distributed_flow_model_replays_to_the_cholesky_factor(T, N):
         for i in range(j + 1, T):
             assert np.abs(P[(i, j)] - Lref[i * nb:(i + 1) * nb, j * nb:(j + 1) * nb]).max() <= 1e-9 * np.abs(Lref).max()
     assert makespan > 0
+
+
+@pytest.mark.parametrize("lookahead", [2, 5])
+@pytest.mark.parametrize("name,T,last", [CASES[3], CASES[4], CASES[7]], ids=[CASES[3][0], CASES[4][0], CASES[7][0]])
+def test_lookahead_triangle_schedule_replays(monkeypatch, name, T, last, lookahead):
+    """Round 5: FlowParams::lookahead (BSFM_FLOW_LOOKAHEAD) keeps the tiles of the next rows current in halves.  Off by default (no gain
+    measured at 71 tile columns), but it is a different task order: the same structural check and replay as the default."""
+    monkeypatch.setenv("BSFM_FLOW_LOOKAHEAD", str(lookahead))
+    tasks, sim = B.chol_flow_schedule(T, last, np_max=4)
+    monkeypatch.delenv("BSFM_FLOW_LOOKAHEAD")
+    base, _ = B.chol_flow_schedule(T, last, np_max=4)
+    lastc = closed(last) if last is not None else [T - 1] * T
+    nb = 8
+    A, b = spd_with_envelope(T, nb, lastc, seed=T * 17 + lookahead)
+    rp = Replay(T, nb, A, b)
+    for t in tasks:
+        assert rp.ready(t)
+        rp.run(t)
+    check_result(rp, A, b, lastc)
+    assert (tasks["type"] == UPD64).sum() >= (base["type"] == UPD64).sum()        # more of the updates go out in halves
