@@ -76,7 +76,7 @@ SYMBOLS = [
     "bsfm_problem_row_sizes", "bsfm_problem_export_rows", "bsfm_schur_row_plan",
     "bsfm_problem_cnp", "bsfm_problem_num_cameras", "bsfm_problem_num_points", "bsfm_problem_nvis", "bsfm_eval_residuals", "bsfm_problem_outlier_stats", "bsfm_problem_ray_angles", "bsfm_triangulate_batch", "bsfm_rand_seed", "bsfm_rand_next", "bsfm_fmatrix_ransac_batch",
     "bsfm_estimate_fmatrix_batch", "bsfm_compute_tracks",
-    "bsfm_eval_normal_equations", "bsfm_dense_chol_solve", "bsfm_dense_chol_solve_timed", "bsfm_chol_flow_schedule", "bsfm_match_keys_l2", "bsfm_key_match_full",
+    "bsfm_eval_normal_equations", "bsfm_dense_chol_solve", "bsfm_dense_chol_solve_timed", "bsfm_chol_flow_schedule", "bsfm_chol_dyn_plan", "bsfm_match_keys_l2", "bsfm_key_match_full",
     "bsfm_key_match_full_sharded", "bsfm_merge_match_files", "bsfm_match_set_create", "bsfm_match_set_run", "bsfm_match_set_run_table", "bsfm_free", "bsfm_match_set_stats", "bsfm_match_kernel", "bsfm_match_set_rescan_launches",
     "bsfm_match_set_destroy",
     "bsfm_device_count", "bsfm_version", "bsfm_device_synchronize", "bsfm_synth_ba", "bsfm_synth_keys",
@@ -162,6 +162,8 @@ def _load():
     lib.bsfm_comm_idfile_exchange.restype = C.c_int
     lib.bsfm_chol_flow_schedule.argtypes = [C.c_int, ip, C.c_int, C.c_int, vp, C.c_int, dp]
     lib.bsfm_chol_flow_schedule.restype = C.c_int
+    lib.bsfm_chol_dyn_plan.argtypes = [C.c_int, ip, vp, C.c_int, vp, C.c_int, C.POINTER(C.c_uint), C.c_int, ip]
+    lib.bsfm_chol_dyn_plan.restype = C.c_int
     ucp = C.POINTER(C.c_ubyte)
     lib.bsfm_match_keys_l2.argtypes = [C.c_int, ucp, C.c_int, ucp, C.c_double, ip, C.c_int]
     lib.bsfm_match_keys_l2.restype = C.c_int

@@ -1076,6 +1076,8 @@ struct FlowWorkspace {
     double flops = 0.0;                    // flops of one factorisation as scheduled (UPD + TRSM tile products, 2 * 128^3 each)
     hipEvent_t k0 = nullptr, k1 = nullptr; // around the k_chol_flow launch: the roofline kernel's duration
     double kern_ms = 0.0; long long kern_cnt = 0; bool kern_pending = false;
+    void* dyn = nullptr;                   // DynWorkspace (chol_dyn.hip.h): the dynamic bulk of round 6
+    int dynamic = -1;                      // 1 = dynamic bulk (BSFM_FLOW_SCHED=dynamic, opt-in), 0 = the static ticket order of rounds 4-6 (default)
 };
 
 inline void flow_free(FlowWorkspace& f)
@@ -1288,6 +1290,8 @@ __global__ __launch_bounds__(512, 2) void k_flow_solve_one(FlowArgs a_param, con
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const FlowKWords ka = (FlowKWords)__builtin_amdgcn_kernarg_segment_ptr();
     if (threadIdx.x == 64 * FLOW_FACTOR_WAVE) *a_param.info = 0;          // (the lane that reports a failing pivot)
+    if (threadIdx.x == 0) __hip_atomic_store(a_param.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // this launch's time-out word (set only by an expired
+                                                                                                                    // wait of the tile role, 2^24 polls away)
     flow_potrf(FlowTag<2>(), ka, &a_param, 0, lds);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1315,14 +1319,17 @@ __global__ __launch_bounds__(512, 2) void k_flow_solve_one(FlowArgs a_param, con
     }
     __syncthreads();
     if (threadIdx.x < POTRF_NB && threadIdx.x < n_total) x[r] = (red[r] + red[POTRF_NB + r]) + (red[2 * POTRF_NB + r] + red[3 * POTRF_NB + r]);
+    // an expired wait inside the tile role becomes the solve's info, as in the multi-tile launch
+    if (threadIdx.x == 0 && __hip_atomic_load(a_param.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) *a_param.info = POTRF_INFO_TIMEOUT;
 }
 inline int flow_solve_one(PotrfWorkspace& w, double* S, int ld, int n, const double* E, double* x_out, int* d_info, hipStream_t st)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute belongs to the (device, function) pair and this workspace to one device: set once per workspace (run_sfm's in-process
+    // multi-GPU path solves the replicated system on every device through this function -- ADVICE r5)
+    if (!w.solve_one_attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_flow_solve_one), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(FLOW_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
-        attr_set = true;
+        w.solve_one_attr = true;
     }
     FlowArgs a;
     memset(&a, 0, sizeof a);
@@ -1333,15 +1340,7 @@ inline int flow_solve_one(PotrfWorkspace& w, double* S, int ld, int n, const dou
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-inline int flow_solve_dispatch(PotrfWorkspace& w, double* S, int ld, int n, const double* E, double* x_out, int* d_info, hipStream_t st)
-{
-    if (!w.flow) w.flow = new FlowWorkspace();
-    return flow_solve(w, *w.flow, S, ld, n, E, x_out, d_info, st);
-}
-inline void flow_release(PotrfWorkspace& w)
-{
-    if (w.flow) { flow_free(*w.flow); delete w.flow; w.flow = nullptr; }
-}
+// flow_solve_dispatch / flow_release: chol_dyn.hip.h (round 6: this file's static order stays the default; BSFM_FLOW_SCHED=dynamic selects the dynamic bulk)
 
 inline void flow_collect_time(FlowWorkspace& f)
 {

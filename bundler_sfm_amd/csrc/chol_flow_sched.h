@@ -61,7 +61,7 @@ static_assert(sizeof(FlowTask) == 40, "FlowTask layout is shared with the device
 
 struct FlowParams {
     int slots = 512;          // resident workgroups assumed by the simulation (2 per CU x 256)
-    int np_max = 4;           // panels per bulk visit
+    int np_max = 8;           // panels per bulk visit (round 6: 8 with lazy_cols = 2, 6.33 -> 6.23 ms at 71 tile columns; 4 / 0 before)
     int np_max_rhs = 8;       // ... for the right-hand-side row
     // estimated durations, microseconds: medians of the per-task trace of the n = 9 000 solve on MI355X (profiles/r04_flow_task_durations.txt)
     double t_potrf = 42.0, t_trsm32 = 4.5, t_trsm64 = 17.0, t_upd32 = 5.0, t_upd32_per = 2.5;
@@ -77,7 +77,7 @@ struct FlowParams {
                               // `lookahead` columns of the chain read (row i of the factor up to column i); kept current, the chain runs ahead of the
                               // bulk sweeps instead of in step with them (scripts/r5/critical_path.py: at 71 tile columns POTRF(38) waited 145 us for
                               // the last two visits of tile (38, 37), whole-tile visits of four panels that had been queued behind the bulk)
-    int lazy_cols = 0;        // > 0: a bulk tile further than this many columns ahead of the chain is only visited once TWO panels are ready
+    int lazy_cols = 2;        // > 0: a bulk tile further than this many columns ahead of the chain is only visited once TWO panels are ready
                               // for it (or its last one): a one-panel visit moves 393 KB for 4.2 Mflop and is HBM-bound
 };
 

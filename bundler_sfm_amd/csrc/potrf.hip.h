@@ -101,6 +101,7 @@ inline int flow_solve_one(PotrfWorkspace& w, double* S, int ld, int n, const dou
 
 struct PotrfWorkspace {
     FlowWorkspace* flow = nullptr;
+    bool solve_one_attr = false;   // k_flow_solve_one's dynamic-LDS attribute has been set on this workspace's device
     int use_flow = 1;           // BSFM_CHOL=streams selects the three-stream schedule of rounds 1-3 below (kept as the A/B reference)
     int ld = 0, nblk = 0, backend = 0;
     double* panel = nullptr;   // 4 x (nblk-1) tiles of NB x NB: compact copies of the last panels (ring, k & 3)

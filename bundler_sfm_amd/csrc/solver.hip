@@ -29,7 +29,7 @@
 #include "kernels.hip.h"
 #include "schur.hip.h"
 #include "potrf.hip.h"
-#include "chol_flow.hip.h"
+#include "chol_dyn.hip.h"
 #include "compsolve.hip.h"
 
 using namespace bsfm;
@@ -1236,6 +1236,7 @@ double bsfm_lm_last_kernel_ms(const bsfm_problem_t* pb, const char* phase)
     if (!strcmp(phase, "flow_kernel")) return pb->potrf.flow && pb->potrf.flow->kern_cnt ? pb->potrf.flow->kern_ms / (double)pb->potrf.flow->kern_cnt : -1.0;
     if (!strcmp(phase, "flow_gflop")) return pb->potrf.flow && pb->potrf.flow->kern_cnt ? (pb->potrf.flow->flops + (double)pb->potrf.flow->nblk * POTRF_NB * POTRF_NB * POTRF_NB) * 1e-9 : -1.0;
     if (!strcmp(phase, "flow_tasks")) return pb->potrf.flow && pb->potrf.flow->kern_cnt ? (double)pb->potrf.flow->sched.tasks.size() : -1.0;
+    if (!strcmp(phase, "flow_dynamic")) return pb->potrf.flow ? (double)pb->potrf.flow->dynamic : -1.0;
     if (!strcmp(phase, "flow_sim_us")) return pb->potrf.flow && pb->potrf.flow->kern_cnt ? pb->potrf.flow->sched.sim_us : -1.0;
     // bsfm_problem_create: host wall time (total / upload of the visibility index / index construction / allocation) and the
     // device time of the index construction alone
@@ -1815,6 +1816,22 @@ int bsfm_chol_flow_schedule(int nblk, const int* last, int np_max, int slots, vo
     const int nt = (int)sc.tasks.size();
     if (tasks_out) memcpy(tasks_out, sc.tasks.data(), (size_t)std::min(nt, std::max(0, capacity)) * sizeof(FlowTask));
     return nt;
+}
+
+int bsfm_chol_dyn_plan(int nblk, const int* last, void* chain_out, int chain_cap, void* potrf_out, int potrf_cap, unsigned* init_out, int init_cap, int* meta)
+{
+    std::vector<int> lv;
+    if (last && nblk > 0) lv.assign(last, last + nblk);
+    DynPlan p;
+    if (dyn_build_plan(nblk, lv, p) != 0) return -1;
+    if (chain_out) memcpy(chain_out, p.chain.data(), (size_t)std::min<long long>((long long)p.chain.size(), std::max(0, chain_cap)) * sizeof(FlowTask));
+    if (potrf_out) memcpy(potrf_out, p.potrf.data(), (size_t)std::min<long long>((long long)p.potrf.size(), std::max(0, potrf_cap)) * sizeof(FlowTask));
+    if (init_out) memcpy(init_out, p.init.data(), (size_t)std::min<long long>((long long)p.init.size(), std::max(0, init_cap)) * sizeof(unsigned));
+    if (meta) {
+        meta[0] = (int)p.chain.size(); meta[1] = (int)p.potrf.size(); meta[2] = (int)p.nwords; meta[3] = (int)p.ofs_c32; meta[4] = (int)p.ofs_c10;
+        meta[5] = (int)p.ofs_wd; meta[6] = (int)p.ofs_rd; meta[7] = (int)p.ofs_tw;
+    }
+    return 0;
 }
 
 static int dense_chol_solve_impl(int n, const double* A, const double* b, double* x, int backend, int reps_in, double* ms_out, double* flow_ms_out, double* flow_gflop_out);

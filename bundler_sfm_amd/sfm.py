@@ -427,6 +427,25 @@ def chol_flow_schedule(nblk, last=None, np_max=0, slots=0):
     return tasks, sim.value
 
 
+def chol_dyn_plan(nblk, last=None):
+    """Host-side plan of the dynamic tile-dataflow Cholesky (csrc/chol_dyn_plan.h); host only.
+    Returns dict(chain, potrf, init, ofs_c32, ofs_c10, ofs_wd, ofs_rd, ofs_tw)."""
+    lastp = None
+    if last is not None:
+        last = np.ascontiguousarray(last, np.int32)
+        lastp = last.ctypes.data_as(C.POINTER(C.c_int))
+    meta = np.zeros(8, np.int32)
+    mp = meta.ctypes.data_as(C.POINTER(C.c_int))
+    if lib.bsfm_chol_dyn_plan(nblk, lastp, None, 0, None, 0, None, 0, mp) != 0:
+        raise RuntimeError("bsfm_chol_dyn_plan failed")
+    chain = np.zeros(int(meta[0]), FLOW_TASK_DTYPE); potrf = np.zeros(int(meta[1]), FLOW_TASK_DTYPE); init = np.zeros(int(meta[2]), np.uint32)
+    rc = lib.bsfm_chol_dyn_plan(nblk, lastp, chain.ctypes.data_as(C.c_void_p), len(chain), potrf.ctypes.data_as(C.c_void_p), len(potrf),
+                                init.ctypes.data_as(C.POINTER(C.c_uint)), len(init), mp)
+    assert rc == 0
+    return dict(chain=chain, potrf=potrf, init=init, ofs_c32=int(meta[3]), ofs_c10=int(meta[4]), ofs_wd=int(meta[5]), ofs_rd=int(meta[6]),
+                ofs_tw=int(meta[7]))
+
+
 def dense_chol_solve_timed(A, b, reps=3, backend=0):
     """dense_chol_solve `reps` times; returns (rc, x, ms per repetition, mean k_chol_flow launch ms, Gflop scheduled per launch)."""
     A = np.ascontiguousarray(A, np.float64)

@@ -347,6 +347,14 @@ int bsfm_dense_chol_solve_timed(int n, const double *A, const double *b, double 
  * nblk = the right-hand side.  np_max / slots <= 0 select the defaults.  Returns the number of tasks, or -1 when the builder
  * fails its own dependency check (every wait must be satisfiable by tasks that come EARLIER in the order). */
 int bsfm_chol_flow_schedule(int nblk, const int *last, int np_max, int slots, void *tasks_out, int capacity, double *sim_us);
+/* Test / diagnostic hook (no device needed): the host-side plan of the DYNAMIC tile-dataflow Cholesky (csrc/chol_dyn_plan.h, the
+ * round-6 default; replaces sba_Axb_Chol, lib/sba-1.5/sba_lapack.c:374-485).  chain_out / potrf_out receive the two static queues
+ * (40-byte records as above; a wait whose thr has bit 31 set compares the low 10 bits of the word), init_out the initial image of
+ * the launch's state words.  meta[8] = { chain tasks, POTRF tasks, words, offset of the TRSM32 counters, of the UPD32 counters, of
+ * the "inverse diagonal factor exists" counters, of the rowdone pairs, of the half-tile state words (column-major pairs, nblk + 1
+ * rows per column) }.  Buffers may be NULL / capacities 0 to query the sizes.  Returns 0, -1 on a size the format cannot hold. */
+int bsfm_chol_dyn_plan(int nblk, const int *last, void *chain_out, int chain_cap, void *potrf_out, int potrf_cap,
+                       unsigned *init_out, int init_cap, int *meta);
 
 /* ---- 3b. batched multi-view triangulation -------------------------------------------- */
 /* npoints independent points; point i owns views view_ptr[i] .. view_ptr[i+1]-1.  View v observes the normalised image

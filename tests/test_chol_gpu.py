@@ -295,3 +295,54 @@ def test_envelope_factorisation_of_a_banded_system(gpu_bsfm, n, half_band, seed)
     if n > 400:
         A[333, 333] = -1.0
         assert gpu_bsfm.dense_chol_solve(A, b, backend=2)[0] == 334
+
+
+# ---- the dynamic bulk (csrc/chol_dyn.hip.h, chol_dyn_plan.h; opt-in BSFM_FLOW_SCHED=dynamic): same roles, served from per-half-tile
+# state words (scan, claim by atomic OR, release by store) instead of the host-simulated ticket order.  Round 6 measured it slower than the
+# static order (profiles/r06_dynamic_bulk_*.txt), so it is not the default; it stays correct and tested.
+@pytest.mark.parametrize("n", [129, 300, 450, 1000, 1799, 2900])
+def test_dynamic_bulk_matches_numpy_and_is_independent_of_the_number_of_workgroups(gpu_bsfm, monkeypatch, n):
+    """Which workgroup applies which panels to a tile, and in how many passes, is decided at run time -- but every role applies the panels
+    of a tile in ascending order through the same accumulation chains, and which role applies which panel is fixed on the host: the bits
+    must not depend on the batching.  Same system with 512, 96 and 40 workgroups (different interleavings, different batch sizes)."""
+    monkeypatch.setenv("BSFM_FLOW_SCHED", "dynamic")
+    A, b = spd(n, 100 + n)
+    ref = np.linalg.solve(A, b)
+    first = None
+    for wgs in ("512", "96", "40"):
+        monkeypatch.setenv("BSFM_FLOW_WGS", wgs)
+        rc, x = gpu_bsfm.dense_chol_solve(A, b)
+        assert rc == 0
+        assert np.abs(x - ref).max() <= 1e-10 * np.abs(ref).max()
+        if first is None:
+            first = x.copy()
+        assert x.tobytes() == first.tobytes(), (n, wgs)
+
+
+def test_dynamic_bulk_envelopes_info_and_starved_launch(gpu_bsfm, monkeypatch, capfd):
+    import scipy.linalg as sl
+    monkeypatch.setenv("BSFM_FLOW_SCHED", "dynamic")
+    rng = np.random.default_rng(31)
+    for n, half_band, blk in ((2500, 300, 0), (1500, 64, 0), (1536, 40, 512), (1300, 200, 384)):
+        A = rng.standard_normal((n, n))
+        i, j = np.indices((n, n))
+        A[np.abs(i - j) > half_band] = 0.0
+        if blk:
+            A[(i // blk) != (j // blk)] = 0.0
+        A = np.tril(A); A = A + A.T
+        A[np.arange(n), np.arange(n)] = np.abs(A).sum(axis=1) + 1.0
+        b = rng.standard_normal(n)
+        rc, x = gpu_bsfm.dense_chol_solve(A, b, backend=2)
+        ref = sl.cho_solve(sl.cho_factor(A, lower=True), b)
+        assert rc == 0 and np.abs(x - ref).max() <= 1e-11 * np.abs(ref).max(), (n, half_band, blk)
+        A[333, 333] = -1.0
+        assert gpu_bsfm.dense_chol_solve(A, b, backend=2)[0] == 334
+    # a claim that is never released: the waiters give up, the solve is repeated on the stream-ordered schedule
+    monkeypatch.setenv("BSFM_FLOW_TEST_STALL", "9"); monkeypatch.setenv("BSFM_FLOW_SPIN_MS", "20")
+    A, b = spd(1500, 77)
+    capfd.readouterr()
+    rc, x = gpu_bsfm.dense_chol_solve(A, b)
+    err = capfd.readouterr().err
+    assert rc == 0 and "timed out" in err and "stream-ordered" in err, err[-500:]
+    ref = sl.cho_solve(sl.cho_factor(A, lower=True), b)
+    assert np.abs(x - ref).max() <= 1e-11 * np.abs(ref).max()
