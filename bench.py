@@ -42,6 +42,9 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet FP64 matrix (== vector) peak; 
 NB = 128                        # Cholesky tile (bundler_sfm_amd/csrc/potrf.hip.h)
 
 
+os.environ.setdefault("BSFM_PHASE_TIMING", "1")      # phases_ms and the roofline kernel's HIP-event time need the library's event records (off below 2 M observations by default)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +72,9 @@ def parse():
     ap.add_argument("--match-images", type=int, default=500)
     ap.add_argument("--match-keys", type=int, default=5000)
     ap.add_argument("--match-cpu-pairs", type=int, default=60, help="image pairs of the bounded CPU (reference ANN) sample")
+    ap.add_argument("--match-check-pairs", type=int, default=4,
+                    help="random image pairs of the written match file checked against the reference's exact MatchKeys(..., 0) (3-4 s of one host core "
+                         "each; profiles/r06_match_cfg5_file_sample_check.txt holds the 200-pair run of scripts/r6/match_file_sample_check.py)")
     ap.add_argument("--collective", choices=["native", "torch"], default="native")
     ap.add_argument("--window", choices=["run", "continue"], default="run",
                     help="run (default): the timed steps are iterations 1..K of run_sfm's own LM run from the initial parameters (its options and stop "
@@ -98,6 +104,32 @@ def syrk_flops_per_launch(sdim):
     nblk = (sdim + NB - 1) // NB
     tiles = [t * (t - 1) // 2 - 1 for t in range(nblk - 1, 2, -1)]
     return 2.0 * NB ** 3 * sum(tiles) / max(len(tiles), 1), len(tiles)
+
+
+def algorithmic_bytes(nvis, npts, cnp=9, sdim=0):
+    """ALGORITHMIC HBM bytes of the streaming kernels of one LM iteration with the layout of DESIGN.md section 3 -- what each kernel must move if
+    every byte is moved once and nothing is found in a cache.  THE one table: DESIGN.md section 4 quotes these formulas, hbm_kernels divides them by the
+    HIP-event times and compares them with the profiler's counters.  Per observation unless noted; a_b = 16 * cnp bytes of A_ij."""
+    a_b = 16.0 * cnp
+    t = {
+        # camera index 4, point from the camera-major mirror 32, residual 16 in; A record a_b, B || e record 64 out
+        "jacobian": {"kernels": ["k_jacobian"], "bytes": nvis * (4 + 32 + 16 + a_b + 64)},
+        # A record and residual streamed
+        "cam_blocks": {"kernels": ["k_cam_blocks"], "bytes": nvis * (a_b + 16)},
+        # one B || e record + its position per observation; row pointer, point, V (48) and eb (24) per point
+        "point_blocks": {"kernels": ["k_point_blocks"], "bytes": nvis * (64 + 4) + npts * (4 + 24 + 48 + 24)},
+        # two passes (>= 200 000 observations).  Pass 1 streams camera index, A and B records and writes the 32-byte product; pass 2 gathers it, scatters the trial
+        # point into the mirror (32), per point: row pointer, eb, V*^-1, p, dp, p + dp
+        "backsub": {"kernels": ["k_backsub_obs", "k_backsub"], "bytes": nvis * (4 + a_b + 64 + 32) + nvis * (4 + 32 + 32) + npts * (4 + 24 + 48 + 24 + 24 + 24),
+                    "one_pass_bound_bytes": nvis * (a_b + 48 + 8 + 32) + npts * (4 + 24 + 48 + 24 + 24 + 24)},
+        # camera index, mirror point, measurement, previous residual (stop rule 8), residual out
+        "residual": {"kernels": ["k_residual"], "bytes": nvis * (4 + 32 + 16 + 16 + 16)},
+        # observation -> point / position 8, B || e record in, C || r record out; V (48) and eb (24) per point (+ V*^-1 out 48: the fused inversion of round 6)
+        # (round 6: its appended workgroups also clear the lower 128 x 128 tiles of S, 128 KB each -- k_zero_lower_tiles' job)
+        "schur_prep": {"kernels": ["k_schur_prep"], "bytes": nvis * (8 + 64 + 64) + npts * (48 + 24 + 48)
+                                                             + (lambda t: t * (t + 1) // 2 * 131072.0)((int(sdim) + 127) // 128)},
+    }
+    return t
 
 
 def pmc_summary():
@@ -151,22 +183,54 @@ def pmc_mfma(kernel):
 
 def cpu_baseline_live_headline(m, n, deg):
     """--cpu-baseline live: the reference's sba_motstr_levmar at the headline size IN THIS RUN (one LM iteration, forward differences,
-    one host thread; ~80 s on the GPU box's EPYC)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_util as O
-    import bundler_sfm_amd as B
-    if not O.have_ref():
+    one host thread; ~80 s on the GPU box's EPYC), from the -DTIMINGS build so that the reference's own phase split comes with it."""
+    import importlib.util
+    lib_path = os.path.join(ROOT, "oracle", "_ref", "libsfmref_timings.so")
+    if not os.path.exists(lib_path):
         return {"error": "oracle/_ref not built"}
-    s = B.synth_ba(m, n, deg)
-    vm = B.dense_vmask(n, m, s["rowptr"], s["colidx"])
-    t0 = time.perf_counter()
-    r = O.ref_sba(n, m, vm, s["proj"], s["cams"], s["pts"], itmax=1, jac_mode=0)
-    wall = time.perf_counter() - t0
-    its = max(int(r["info"][5]), 1)
-    return {"value": round(its / r["secs"], 6), "unit": "LM iterations/s", "cores": 1, "kind": "reference", "cached": False,
-            "sample": f"LIVE in this run: reference sba_motstr_levmar (FD Jacobian, vendored CLAPACK, gcc -O3, 1 thread) at {m} cams / {n} pts / "
-                      f"{int(s['rowptr'][-1])} obs, itmax=1: {r['secs']:.1f} s per iteration ({wall:.1f} s wall incl. setup)",
-            "ms_per_iteration": round(1e3 * r["secs"] / its, 1), "final_cost": r["info"][1], "host_cpus": os.cpu_count()}
+    spec = importlib.util.spec_from_file_location("cpu_baseline_cfg3", os.path.join(ROOT, "scripts", "cpu_baseline_cfg3.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    assert deg == 10
+    r = mod.run(m, n, 1)
+    its = max(r["iterations"], 1)
+    out = {"value": round(its / r["sba_s"], 6), "unit": "LM iterations/s", "cores": 1, "kind": "reference", "cached": False,
+           "sample": f"LIVE in this run: reference sba_motstr_levmar (FD Jacobian, -DTIMINGS, vendored CLAPACK, gcc -O3, 1 thread) at {m} cams / {n} pts / "
+                     f"{r['config']['observations']} obs, itmax=1: {r['sba_s']:.1f} s per iteration ({r['wall_s']:.1f} s wall incl. setup)",
+           "ms_per_iteration": round(1e3 * r["sba_s"] / its, 1), "final_cost": r["final_cost"], "host_cpus": os.cpu_count(), "host_cpu": r["host_cpu"],
+           "phases_s_mean": r["phases_s_mean"],
+           "phases_note": "the reference's own -DTIMINGS prints of this run (lib/sba-1.5/sba_levmar.c:49-53)"}
+    out["optimised_blas"] = optimised_blas_leg(m * 9, r["phases_s_mean"])
+    return out
+
+
+def optimised_blas_leg(order, ref_phases):
+    """SURVEY 8(d) "optimised-LAPACK variant": the reference links the vendored f2c CLAPACK (unblocked reference BLAS), so part of its iteration is
+    an artefact of that BLAS.  dpotrf of a dense SPD matrix of the reduced system's order with the host's optimised BLAS (scipy's), one thread
+    and all threads, next to the time the reference's own linear-system phase took in this run."""
+    try:
+        import scipy.linalg.lapack as la
+        rng = np.random.default_rng(1)
+        G = rng.standard_normal((order, 256))
+        A = G @ G.T
+        A[np.diag_indices(order)] += order
+        out = {"what": f"scipy.linalg.lapack.dpotrf (lower) of a dense SPD matrix of order {order}", "order": order}
+        try:
+            from threadpoolctl import threadpool_info, threadpool_limits
+            info = [i for i in threadpool_info() if i.get("user_api") == "blas"]
+            out["blas"] = [{k: i.get(k) for k in ("internal_api", "version", "num_threads", "threading_layer")} for i in info]
+            with threadpool_limits(limits=1, user_api="blas"):
+                t0 = time.perf_counter(); c, rc1 = la.dpotrf(A, lower=1, overwrite_a=0); out["one_thread_s"] = round(time.perf_counter() - t0, 2)
+        except ImportError:
+            rc1 = 0
+        t0 = time.perf_counter(); c, rc = la.dpotrf(A, lower=1, overwrite_a=0); out["all_threads_s"] = round(time.perf_counter() - t0, 2)
+        out["info"] = int(rc) | int(rc1)
+        if ref_phases:
+            solve = [v for k, v in ref_phases.items() if "linear" in k.lower() or "solv" in k.lower()]
+            if solve:
+                out["reference_linear_system_phase_s"] = round(sum(solve), 2)
+        return out
+    except Exception as exc:
+        return {"error": repr(exc)}
 
 
 def cpu_baseline(sample):
@@ -225,6 +289,57 @@ def synth_key_set(B, images, nkeys):
     return keys
 
 
+def check_match_file_sample(path, keys, npairs, seed, workers=1):
+    """The match file of the bench leg against the reference: `npairs` random image pairs (j < i) of the SAME key set through the reference's
+    exact search -- MatchKeys(keys_j, tree(keys_i), 0.6, max_pts_visit = 0), src/keys2a.cpp:347-372 compiled into oracle/_ref -- and the
+    blocks the library wrote for them: same matches in the same order, and no block where the reference finds fewer than 16
+    (src/KeyMatchFull.cpp:131-142).  Checker only (oracle/_ref), outside every timed region."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_util as O
+    if not os.path.exists(O.REF_KM_PATH):
+        return {"error": "oracle/_ref/libkeymatchref.so not built"}
+    images = len(keys)
+    rng = np.random.default_rng(seed)
+    want = set()
+    while len(want) < min(npairs, images * (images - 1) // 2):
+        i = int(rng.integers(1, images)); j = int(rng.integers(0, i))
+        want.add((j, i))
+    t0 = time.perf_counter()
+    tok = np.fromfile(path, dtype=np.int64, sep=" ")            # the whole file, every block walked
+    blocks, q, nblocks = {}, 0, 0
+    while q < len(tok):
+        a, b, n = int(tok[q]), int(tok[q + 1]), int(tok[q + 2]); q += 3
+        if (a, b) in want:
+            blocks[(a, b)] = tok[q:q + 2 * n].reshape(n, 2).astype(np.int32)
+        q += 2 * n; nblocks += 1
+    t_parse = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    if workers > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(workers) as pool:
+            refs = pool.starmap(_ref_exact_pair, [(keys[j], keys[i]) for (j, i) in sorted(want)])
+    else:
+        refs = [_ref_exact_pair(keys[j], keys[i]) for (j, i) in sorted(want)]
+    bad, with_block = [], 0
+    for (j, i), ref in zip(sorted(want), refs):
+        got = blocks.get((j, i))
+        if len(ref) >= 16:
+            with_block += 1
+            if got is None or got.shape != ref.shape or not np.array_equal(got, ref):
+                bad.append([j, i])
+        elif got is not None:
+            bad.append([j, i])
+    return {"pairs_checked": len(want), "pairs_with_a_block": with_block, "mismatching_pairs": bad, "identical": not bad,
+            "blocks_in_file": nblocks, "parse_s": round(t_parse, 1), "reference_s": round(time.perf_counter() - t0, 1), "workers": workers,
+            "reference": "MatchKeys(.., ratio 0.6, max_pts_visit 0) of oracle/_ref (src/keys2a.cpp:347-372): exact 2-NN"}
+
+
+def _ref_exact_pair(kj, ki):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_util as O
+    return O.ref_match(kj, ki, 0.6, 0)[0]
+
+
 def matcher_leg(args, passes=1):
     """BASELINE.json configs[4]: KeyMatchFull, `images` x `nkeys` SIFT-like keys, all pairs (j < i), 128-D uchar L2 2-NN + ratio
     test, text output as the reference writes it.  A step = one pass over all pairs with the descriptors resident in HBM.
@@ -261,6 +376,12 @@ def matcher_leg(args, passes=1):
     n_rescan = int(B.lib.bsfm_match_set_rescan_launches(ms))
     B.lib.bsfm_match_set_destroy(ms)
     size = os.path.getsize(out_path)
+    file_check = None
+    if getattr(args, "match_check_pairs", 0) > 0:
+        try:
+            file_check = check_match_file_sample(out_path.decode(), keys, args.match_check_pairs, seed=20260930)
+        except Exception as exc:      # the checker must never take the number down with it
+            file_check = {"error": repr(exc)}
     os.unlink(out_path)
     ops = dist.value * 256.0
     ach = ops / (kms.value * 1e-3) / 1e12 if kms.value > 0 else None
@@ -270,6 +391,7 @@ def matcher_leg(args, passes=1):
                                   "exact 2-NN, matches.init.txt written", "images": images, "keys_per_image": nkeys,
                       "image_pairs": pairs_total, "pair_blocks_written": blocks, "output_bytes": size,
                       "key_generation_s": round(t_gen, 2), "upload_and_stats_s": round(t_up, 3)},
+           "file_sample_check": file_check,
            "roofline": None if ach is None else {
                "bound": "mfma", "kernel": "k_match_bound" if 2 * n_rescan >= nl.value else "k_match_l2",
                "launches_by_kernel": {"k_match_bound": n_rescan, "k_match_l2": int(nl.value) - n_rescan},
@@ -519,25 +641,28 @@ def main():
         rp = r["rp"]
         nv_loc, np_loc = float(r["k1"] - r["k0"]), float(r["hi"] - r["lo"])
         deg2 = float(np.sum(np.diff(rp).astype(np.float64) * (np.diff(rp) + 1) / 2))        # co-visibility triples
-        # algorithmic bytes per observation with the round-3 layout: Ac 16 cnp B, Bc 64 B (B || e), Cc 64 B, e 16 B, xc 16 B
-        a_b = 16.0 * cnp
-        alg = {"jacobian": nv_loc * (8 + 24 + 16 + a_b + 64),                 # index pair, point, e in; Ac, Bc out
-               "cam_blocks": nv_loc * (a_b + 16),                             # Ac, e streamed
-               "point_blocks": nv_loc * (64 + 4) + np_loc * 72,               # one Bc record per observation, V / eb out
-               "backsub": nv_loc * (a_b + 48 + 8) + np_loc * 120,             # Ac + B gathered, index pair
-               "residual": nv_loc * (16 + 8 + 24 + 16)}                       # xc, index pair, point in; e out
+        # ONE algorithmic byte count per kernel (algorithmic_bytes above = DESIGN.md section 4); a phase made of two kernels is compared with the SUM of
+        # their counters (round 5 compared the two-pass back-substitution's one-pass figure with one of its two kernels: VERDICT r5 weak #2)
+        alg = algorithmic_bytes(nv_loc, np_loc, cnp, sdim)
         hbm = {}
-        kern_of = {"jacobian": "k_jacobian", "cam_blocks": "k_cam_blocks", "point_blocks": "k_point_blocks", "backsub": "k_backsub", "residual": "k_residual"}
-        for ph, nbytes in alg.items():
+        for ph, ent in alg.items():
             ms = phases.get(ph, 0.0)
             if ms and ms > 0:
+                nbytes = ent["bytes"]
                 gbs = nbytes / (ms * 1e-3) / 1e9
-                hbm[ph] = {"alg_GB": round(nbytes / 1e9, 3), "ms": ms, "GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / 8000.0, 3)}
-                ctr = pmc_traffic(kern_of[ph]) if world == 1 else None       # the committed counters are of the single-GPU command
-                if ctr:
+                hbm[ph] = {"kernels": ent["kernels"], "alg_GB": round(nbytes / 1e9, 3), "ms": ms, "GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / 8000.0, 3)}
+                # the committed counters are of the single-GPU command at the headline size: other sizes get no counter columns
+                ctrs = [pmc_traffic(k) for k in ent["kernels"]] if (world == 1 and m == 1000 and n == 500000) else []
+                if ctrs and all(c for c in ctrs):
+                    ctr = float(sum(ctrs))
                     hbm[ph]["counter_GB"] = round(ctr / 1e9, 3); hbm[ph]["counter_over_algorithmic"] = round(ctr / nbytes, 3)
-        hbm["note"] = ("algorithmic bytes per phase (DESIGN.md section 4) over its HIP-event time; counter_GB = 2 x FETCH_SIZE + WRITE_SIZE per launch "
-                       "from " + (pmc_summary()[1] and "profiles/" + pmc_summary()[1] or "no committed PMC summary"))
+                    if "one_pass_bound_bytes" in ent:
+                        hbm[ph]["one_pass_bound_GB"] = round(ent["one_pass_bound_bytes"] / 1e9, 3)
+                        hbm[ph]["counter_over_one_pass_bound"] = round(ctr / ent["one_pass_bound_bytes"], 3)
+        hbm["note"] = ("algorithmic bytes per phase (bench.py:algorithmic_bytes = DESIGN.md section 4: every byte once, nothing cached) over the phase's HIP-event time; "
+                       "counter_GB = 2 x FETCH_SIZE + WRITE_SIZE per launch, summed over the phase's kernels, from "
+                       + (pmc_summary()[1] and "profiles/" + pmc_summary()[1] or "no committed PMC summary")
+                       + "; a ratio a few per cent BELOW 1 is the 32 MB of L2 holding part of what the previous kernel wrote (FETCH_SIZE counts what leaves L2)")
         schur_flop = deg2 * 486.0                       # 486 flop per co-visibility pair with the symmetry used
         schur = {"ms": phases["schur"], "prep_ms": phases["schur_prep"], "rows_kernel_ms": phases["schur_rows"], "tasks_kernel_ms": phases["schur_tasks"],
                  "row_kernel": {"workgroups": int(pb.phase_ms("row_wgs")), "pieces": int(pb.phase_ms("row_pieces")), "dense_blocks": int(pb.phase_ms("row_blocks")),

@@ -46,6 +46,7 @@ struct DeviceIndex {
     int n_row_wgs = 0, n_row_pieces = 0, n_row_slots = 0, row_L = 0, n_row_blocks = 0;
     long long row_triples = 0;
     std::vector<int> h_blk_j, h_blk_k;      // host copies of the block list (component analysis / multi-GPU union)
+    bool empty_rows = false;      // some point has no observation (k_schur_prep's fused point inversion needs every point to have one)
     double build_ms = 0.0;        // device time of the whole construction (HIP events)
 };
 

@@ -36,13 +36,15 @@ namespace {
 inline int grid_for(size_t count, int block) { return (int)std::max<size_t>(1, (count + block - 1) / block); }
 inline int bits_for(unsigned long long maxval) { int b = 1; while (b < 64 && (maxval >> b)) ++b; return b; }
 
-// flag bit 0: rowptr not monotone / out of range; bit 1: colidx out of range; bit 2: colidx not strictly ascending in a row
+// flag bit 0: rowptr not monotone / out of range; bit 1: colidx out of range; bit 2: colidx not strictly ascending in a row;
+// bit 3 (not an error): a row is empty
 __global__ void k_validate_rows(int n, int m, int nvis, const int* __restrict__ rowptr, const int* __restrict__ colidx, int* __restrict__ flag)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int r0 = rowptr[i], r1 = rowptr[i + 1];
     if (r0 < 0 || r1 < r0 || r1 > nvis) { atomicOr(flag, 1); return; }
+    if (r1 == r0) atomicOr(flag, 8);
     int prev = -1;
     for (int k = r0; k < r1; ++k) {
         const int c = colidx[k];
@@ -684,6 +686,8 @@ int build_index_device(int n, int m, int mcon, int nvis, const int* d_rowptr, co
     int hflag = 0;
     IX_OK(hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, st));
     IX_OK(hipStreamSynchronize(st));
+    ix.empty_rows = (hflag & 8) != 0 || n == 0;
+    hflag &= 7;
     if (hflag) {
         fprintf(stderr, "[bsfm] bad visibility index:%s%s%s\n", (hflag & 1) ? " rowptr not monotone" : "",
                 (hflag & 2) ? " colidx out of range" : "", (hflag & 4) ? " colidx not strictly ascending in a row" : "");

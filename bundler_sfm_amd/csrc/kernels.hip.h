@@ -151,51 +151,55 @@ __device__ __forceinline__ bool last_block_arrives(unsigned* ticket, unsigned to
 }
 
 // ---------------------------------------------------------------------------------------------------
-// per-camera derived table: one thread per camera (m <= a few thousand; trig happens only here)
-__device__ __forceinline__ void cam_table_row(const ModelCfg& cfg, int j, const double* __restrict__ pa, const double* __restrict__ Rinit,
-                            const double* __restrict__ finit, const double* __restrict__ known, int with_fd, double* __restrict__ camtab);
-__global__ void k_cam_table(ModelCfg cfg, int m, const double* __restrict__ pa, const double* __restrict__ Rinit,
-                            const double* __restrict__ finit, const double* __restrict__ known, int with_fd, double* __restrict__ camtab)
-{
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    cam_table_row(cfg, j, pa, Rinit, finit, known, with_fd, camtab);
-}
-__device__ __forceinline__ void cam_table_row(const ModelCfg& cfg, int j, const double* __restrict__ pa, const double* __restrict__ Rinit,
+// per-camera derived table (trig happens only here).  A row is FOUR independent parts -- the rotation with its derivative factor and
+// the scalars; the three perturbed rotations of the forward differences -- and a thread computes one part (round 6: one thread per camera
+// spent ~20 us on its four Rodrigues formulas one after the other, on the critical path of every solve attempt of a small problem:
+// k_backsub's finishing workgroup builds the trial point's table).  Same functions on the same inputs: the values do not change.
+constexpr int CT_PARTS = 4;
+__device__ __forceinline__ void cam_table_part(const ModelCfg& cfg, int j, int part, const double* __restrict__ pa, const double* __restrict__ Rinit,
                             const double* __restrict__ finit, const double* __restrict__ known, int with_fd, double* __restrict__ camtab)
 {
     const double* a = pa + (size_t)j * cfg.cnp;
     const double* R0 = Rinit + (size_t)j * 9;
     double* ct = camtab + (size_t)j * CT_STRIDE;
-    double R[9], Q[9], Ri[9];
+    double Ri[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) Ri[k] = R0[k];
-    rot_update(Ri, a[3], a[4], a[5], R);
-    rot_deriv_factor(Ri, R, a[3], a[4], a[5], Q);
+    if (part == 0) {
+        double R[9], Q[9];
+        rot_update(Ri, a[3], a[4], a[5], R);
+        rot_deriv_factor(Ri, R, a[3], a[4], a[5], Q);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { ct[CT_R + k] = R[k]; ct[CT_Q + k] = Q[k]; }
-    for (int k = 0; k < 9; ++k) ct[CT_A + k] = (k < cfg.cnp) ? a[k] : 0.0;
-    int col = 6;
-    double f = finit[j];
-    if (cfg.est_focal) { f = a[6] / cfg.f_scale; col = 7; }
-    ct[CT_F] = f;
-    ct[CT_K1] = cfg.undistort ? a[col] / cfg.k_scale : 0.0;
-    ct[CT_K2] = cfg.undistort ? a[col + 1] / cfg.k_scale : 0.0;
-    ct[30] = finit[j]; ct[31] = 0.0;
-    for (int k = 0; k < CT_EXT; ++k) ct[CT_KN + k] = known ? known[(size_t)j * CT_EXT + k] : 0.0;   // extended-model block (model.hip.h)
-    if (with_fd) {
-        for (int k = 0; k < 9; ++k) {
-            double d = 0.0;
-            if (k < cfg.cnp) { d = 1E-04 * a[k]; d = fabs(d); if (d < 1E-06) d = 1E-06; }
-            ct[CT_D + k] = d;
-        }
-        for (int k = 0; k < 3; ++k) {
-            const double d = ct[CT_D + 3 + k];
-            double Rp[9];
-            rot_update(Ri, k == 0 ? a[3] + d : a[3], k == 1 ? a[4] + d : a[4], k == 2 ? a[5] + d : a[5], Rp);
-            for (int q = 0; q < 9; ++q) ct[CT_RP + 9 * k + q] = Rp[q];
-        }
+        for (int k = 0; k < 9; ++k) { ct[CT_R + k] = R[k]; ct[CT_Q + k] = Q[k]; }
+        for (int k = 0; k < 9; ++k) ct[CT_A + k] = (k < cfg.cnp) ? a[k] : 0.0;
+        int col = 6;
+        double f = finit[j];
+        if (cfg.est_focal) { f = a[6] / cfg.f_scale; col = 7; }
+        ct[CT_F] = f;
+        ct[CT_K1] = cfg.undistort ? a[col] / cfg.k_scale : 0.0;
+        ct[CT_K2] = cfg.undistort ? a[col + 1] / cfg.k_scale : 0.0;
+        ct[30] = finit[j]; ct[31] = 0.0;
+        for (int k = 0; k < CT_EXT; ++k) ct[CT_KN + k] = known ? known[(size_t)j * CT_EXT + k] : 0.0;   // extended-model block (model.hip.h)
+        if (with_fd)
+            for (int k = 0; k < 9; ++k) {
+                double d = 0.0;
+                if (k < cfg.cnp) { d = 1E-04 * a[k]; d = fabs(d); if (d < 1E-06) d = 1E-06; }
+                ct[CT_D + k] = d;
+            }
+    } else if (with_fd) {
+        const int k = part - 1;
+        double d = 1E-04 * a[3 + k]; d = fabs(d); if (d < 1E-06) d = 1E-06;       // (= ct[CT_D + 3 + k]: cnp >= 6 always)
+        double Rp[9];
+        rot_update(Ri, k == 0 ? a[3] + d : a[3], k == 1 ? a[4] + d : a[4], k == 2 ? a[5] + d : a[5], Rp);
+        for (int q = 0; q < 9; ++q) ct[CT_RP + 9 * k + q] = Rp[q];
     }
+}
+__global__ void k_cam_table(ModelCfg cfg, int m, const double* __restrict__ pa, const double* __restrict__ Rinit,
+                            const double* __restrict__ finit, const double* __restrict__ known, int with_fd, double* __restrict__ camtab)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m * CT_PARTS) return;
+    cam_table_part(cfg, t / CT_PARTS, t % CT_PARTS, pa, Rinit, finit, known, with_fd, camtab);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -343,33 +347,67 @@ __device__ __forceinline__ void load_pairs(const double* __restrict__ p, double*
 
 // ---------------------------------------------------------------------------------------------------
 // V_i (packed upper: 00 01 02 11 12 22), eb_i: one thread per point walks its CRS row.
+// Round 6: with part != nullptr the kernel also does k_iter_partials' and k_iter_final's job (sba_levmar.c:1085-1128: max |eb|, the largest
+// diagonal entry of V, sum p_b^2 while the values are in registers; the workgroup that arrives last reduces them, adds the camera side and
+// the constraint cost) and clears the flags of the iteration's first solve attempt: two stream operations fewer per iteration.
+struct IterFinalArgs {       // what the finishing workgroup needs
+    const double* pa; int have_points, point_part_slot;
+    int s_eabinf_a, s_eabinf_b, s_maxdiag_u, s_maxdiag_v, s_pl2_a, s_pl2_b, s_ccost;
+    double* scal;
+};
+__device__ __forceinline__ void iter_final_body(const DevProblem& P, const double* __restrict__ pa, const double* __restrict__ pb,
+        const double* __restrict__ part, int nparts, int have_points, int point_part_slot,
+        int s_eabinf_a, int s_eabinf_b, int s_maxdiag_u, int s_maxdiag_v, int s_pl2_a, int s_pl2_b, int s_ccost,
+        double* __restrict__ scal, bool agent_loads);
+
 template <int CNP>
-__global__ __launch_bounds__(256) void k_point_blocks(DevProblem P, const double* __restrict__ pb)
+__global__ __launch_bounds__(256) void k_point_blocks(DevProblem P, const double* __restrict__ pb,
+        double* __restrict__ part = nullptr /* [3][gridDim.x] */, unsigned* __restrict__ ticket = nullptr, unsigned* __restrict__ ticket_groups = nullptr,
+        IterFinalArgs fa = IterFinalArgs(), int* __restrict__ flags_to_clear = nullptr)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P.n) return;
-    double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, g0 = 0, g1 = 0, g2 = 0;
-    const int k1 = P.rowptr[i + 1];
-    for (int k = P.rowptr[i]; k < k1; ++k) {
-        double R[8];                                                   // B (2 x 3) || e: one 64-byte sector
-        load_pairs<4>(P.Bc + (size_t)P.campos[k] * 8, R);
-        const double b0 = R[0], b1 = R[1], b2 = R[2], b3 = R[3], b4 = R[4], b5 = R[5];
-        const double e0 = R[6], e1 = R[7];
-        v00 += b0 * b0 + b3 * b3; v01 += b0 * b1 + b3 * b4; v02 += b0 * b2 + b3 * b5;
-        v11 += b1 * b1 + b4 * b4; v12 += b1 * b2 + b4 * b5; v22 += b2 * b2 + b5 * b5;
-        g0 += b0 * e0 + b3 * e1; g1 += b1 * e0 + b4 * e1; g2 += b2 * e0 + b5 * e1;
+    double it_a = 0.0, it_v = -DBL_MAX, it_s = 0.0;
+    if (i < P.n) {
+        double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, g0 = 0, g1 = 0, g2 = 0;
+        const int k1 = P.rowptr[i + 1];
+        for (int k = P.rowptr[i]; k < k1; ++k) {
+            double R[8];                                                   // B (2 x 3) || e: one 64-byte sector
+            load_pairs<4>(P.Bc + (size_t)P.campos[k] * 8, R);
+            const double b0 = R[0], b1 = R[1], b2 = R[2], b3 = R[3], b4 = R[4], b5 = R[5];
+            const double e0 = R[6], e1 = R[7];
+            v00 += b0 * b0 + b3 * b3; v01 += b0 * b1 + b3 * b4; v02 += b0 * b2 + b3 * b5;
+            v11 += b1 * b1 + b4 * b4; v12 += b1 * b2 + b4 * b5; v22 += b2 * b2 + b5 * b5;
+            g0 += b0 * e0 + b3 * e1; g1 += b1 * e0 + b4 * e1; g2 += b2 * e0 + b5 * e1;
+        }
+        if (P.pcon && P.pcon[i]) {   // sba_levmar.c:1017-1028 (weights scale with the job-wide nvis)
+            const double w = P.nvis_global * P.pweight;
+            v00 += w; v11 += w; v22 += w;
+            g0 += w * (P.pval[3 * i] - pb[3 * i]);
+            g1 += w * (P.pval[3 * i + 1] - pb[3 * i + 1]);
+            g2 += w * (P.pval[3 * i + 2] - pb[3 * i + 2]);
+        }
+        double* V = P.V + (size_t)i * 6;
+        V[0] = v00; V[1] = v01; V[2] = v02; V[3] = v11; V[4] = v12; V[5] = v22;
+        double* g = P.eb + (size_t)i * 3;
+        g[0] = g0; g[1] = g1; g[2] = g2;
+        if (part) {
+            const double a0 = fabs(g0), a1 = fabs(g1), a2 = fabs(g2);
+            it_a = a0 > a1 ? a0 : a1; it_a = it_a > a2 ? it_a : a2;
+            it_v = v00 > v11 ? v00 : v11; it_v = it_v > v22 ? it_v : v22;
+            const double p0 = pb[3 * (size_t)i], p1 = pb[3 * (size_t)i + 1], p2 = pb[3 * (size_t)i + 2];
+            it_s = p0 * p0 + p1 * p1 + p2 * p2;
+        }
     }
-    if (P.pcon && P.pcon[i]) {   // sba_levmar.c:1017-1028 (weights scale with the job-wide nvis)
-        const double w = P.nvis_global * P.pweight;
-        v00 += w; v11 += w; v22 += w;
-        g0 += w * (P.pval[3 * i] - pb[3 * i]);
-        g1 += w * (P.pval[3 * i + 1] - pb[3 * i + 1]);
-        g2 += w * (P.pval[3 * i + 2] - pb[3 * i + 2]);
+    if (!part) return;
+    __shared__ double sm[4];
+    const double ra = block_max4(it_a, sm), rv = block_max4(it_v, sm), rs = block_sum4(it_s, sm);
+    if (threadIdx.x == 0) {
+        st_agent(part + blockIdx.x, ra); st_agent(part + (size_t)gridDim.x + blockIdx.x, rv); st_agent(part + 2 * (size_t)gridDim.x + blockIdx.x, rs);
     }
-    double* V = P.V + (size_t)i * 6;
-    V[0] = v00; V[1] = v01; V[2] = v02; V[3] = v11; V[4] = v12; V[5] = v22;
-    double* g = P.eb + (size_t)i * 3;
-    g[0] = g0; g[1] = g1; g[2] = g2;
+    if (!last_block_arrives(ticket, gridDim.x, ticket_groups)) return;
+    iter_final_body(P, fa.pa, pb, part, (int)gridDim.x, fa.have_points, fa.point_part_slot, fa.s_eabinf_a, fa.s_eabinf_b, fa.s_maxdiag_u, fa.s_maxdiag_v,
+                    fa.s_pl2_a, fa.s_pl2_b, fa.s_ccost, fa.scal, true);
+    if (flags_to_clear && threadIdx.x < 4) flags_to_clear[threadIdx.x] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -387,7 +425,8 @@ __device__ __forceinline__ void cam_slice(const int* __restrict__ camptr, int j,
 
 template <int CNP>
 __global__ __launch_bounds__(256) void k_cam_blocks(DevProblem P, const double* __restrict__ e, double* __restrict__ part,
-                                                    unsigned* __restrict__ cam_ticket /* per camera; null: k_cam_blocks_fin follows */)
+                                                    unsigned* __restrict__ cam_ticket /* per camera; null: k_cam_blocks_fin follows */,
+                                                    const double* __restrict__ pa_con = nullptr /* != null: k_cam_constraints' terms are added here (single GPU) */)
 {
     constexpr int NU = CNP * (CNP + 1) / 2;
     constexpr int NV = NU + CNP;
@@ -430,13 +469,16 @@ __global__ __launch_bounds__(256) void k_cam_blocks(DevProblem P, const double* 
             double v = 0.0;
 #pragma unroll
             for (int sl = 0; sl < CAM_SPLIT; ++sl) v += ld_agent(pj + sl * NV + u);
+            if (pa_con && r == c && j >= P.mcon && P.ccon[(size_t)j * CNP + r]) v += P.cw[(size_t)j * CNP + r];      // sba_levmar.c:953-962 (k_cam_constraints)
             P.U[(size_t)j * CNP * CNP + threadIdx.x] = v;
         } else if (threadIdx.x < CNP * CNP + CNP) {
             const int u = NU + (threadIdx.x - CNP * CNP);
             double v = 0.0;
 #pragma unroll
             for (int sl = 0; sl < CAM_SPLIT; ++sl) v += ld_agent(pj + sl * NV + u);
-            P.ea[(size_t)j * CNP + (threadIdx.x - CNP * CNP)] = v;
+            const size_t t = (size_t)j * CNP + (threadIdx.x - CNP * CNP);
+            if (pa_con && j >= P.mcon && P.ccon[t]) { const double diff = P.cval[t] - pa_con[t]; v += P.cw[t] * diff; }
+            P.ea[t] = v;
         }
     }
 }
@@ -482,20 +524,58 @@ __global__ void k_cam_constraints(DevProblem P, const double* __restrict__ pa)
 // ---------------------------------------------------------------------------------------------------
 // (V_i + mu I)^-1, closed form for the symmetric 3x3 (the reference goes through dsytrf/dsytri);
 // a non-finite or zero determinant raises the "singular" flag => more damping (sba_levmar.c:1156-1161).
+// (one function for both users -- the stand-alone kernel and k_schur_prep's fused form -- so that the same source expressions, hence the
+//  same contractions, produce V*^-1: the two forms are bit-identical)
+__device__ __forceinline__ bool sym3_invert(const double* __restrict__ v, double mu, double (&o)[6])
+{
+    const double a = v[0] + mu, b = v[1], c = v[2], d = v[3] + mu, e = v[4], f = v[5] + mu;
+    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+    const double det = a * c00 + b * c01 + c * c02;
+    const double id = 1.0 / det;
+    o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
+    o[3] = (a * f - c * c) * id; o[4] = (b * c - a * e) * id; o[5] = (a * d - b * b) * id;
+    return !(fabs(det) > 0.0) || !isfinite(id);
+}
 __global__ __launch_bounds__(256) void k_point_invert(int n, double mu, const double* __restrict__ V,
                                                       double* __restrict__ Vinv, int* __restrict__ flag)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const double* v = V + (size_t)i * 6;
-    const double a = v[0] + mu, b = v[1], c = v[2], d = v[3] + mu, e = v[4], f = v[5] + mu;
-    const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
-    const double det = a * c00 + b * c01 + c * c02;
-    const double id = 1.0 / det;
+    double inv[6];
+    const bool singular = sym3_invert(V + (size_t)i * 6, mu, inv);
     double* o = Vinv + (size_t)i * 6;
-    o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
-    o[3] = (a * f - c * c) * id; o[4] = (b * c - a * e) * id; o[5] = (a * d - b * b) * id;
-    if (!(fabs(det) > 0.0) || !isfinite(id)) atomicOr(flag, 1);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) o[q] = inv[q];
+    if (singular) atomicOr(flag, 1);
+}
+
+// S is rebuilt for every solve attempt (the factorisation overwrites it and fills in its zero blocks).  Only the lower
+// triangle of 128x128 tiles is read by the factorisation, so only that half is cleared: one workgroup per tile,
+// 16-byte stores.  (The strictly upper tiles keep whatever the mirror writes of the assembly put there.)  Virtual blocks ntl .. do
+// k_rhs_init's job.  Round 6: the body is a function so that k_schur_prep can run it in workgroups appended to its own grid (one launch
+// fewer per solve attempt; k_zero_lower_tiles below is the stand-alone form).
+struct ZeroTilesArgs {
+    double* S; int ld, ntl, count, off, add_ea; const double* ea; double* E; const int* spos; int cnp;
+    int first_block;      // k_schur_prep: its workgroups from this index on run zero_tiles_body (0 = none appended)
+};
+__device__ __forceinline__ void zero_tiles_body(const ZeroTilesArgs& z, int vb)
+{
+    if (vb >= z.ntl) {      // blocks ntl .. : k_rhs_init's job (round 5: one launch fewer per attempt)
+        const int t = (vb - z.ntl) * 256 + threadIdx.x;
+        if (t >= z.count) return;
+        const int dst = z.spos ? z.spos[t / z.cnp] * z.cnp + t % z.cnp : t;
+        z.E[dst] = z.add_ea ? z.ea[z.off + t] : 0.0;
+        return;
+    }
+    int a = (int)((sqrt(8.0 * vb + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= vb) ++a;
+    while (a * (a + 1) / 2 > vb) --a;
+    const int b = vb - a * (a + 1) / 2;          // tile (a, b), b <= a
+    double* T = z.S + ((size_t)a * 128) * z.ld + (size_t)b * 128;
+    for (int idx = threadIdx.x; idx < 128 * 64; idx += 256) {
+        const int r = idx >> 6, c2 = (idx & 63) * 2;
+        *reinterpret_cast<double2*>(T + (size_t)r * z.ld + c2) = make_double2(0.0, 0.0);
+    }
 }
 
 // Per solve attempt (V*^-1 depends on mu): C_ij = B_ij V*_i^-1 (2 x 3) and r_ij = C_ij eb_i for every observation, camera-major,
@@ -506,9 +586,16 @@ __global__ __launch_bounds__(256) void k_point_invert(int n, double mu, const do
 // next point (streamed; in camera-major order every camera sweeps the whole 36 MB of point data past L2: 0.28 ms), the B || e record
 // is ONE 64-byte sector fetched by the quad (lane q loads chunk q, the six B values go round by DPP), and lane q stores chunk q of the
 // C || r record: one whole 64-byte sector per quad, gathered and scattered through campos[].
+// Round 6: with V != nullptr the kernel ALSO does k_point_invert's job (one launch fewer per solve attempt, and at 14 cameras a launch is
+// 3 % of the iteration): every quad inverts V*_i itself from the six numbers it would otherwise have loaded as V*^-1, and the quad of a
+// point's FIRST observation stores the inverse (k_backsub reads it) and raises the "singular" flag.  Needs every point to have an
+// observation (the index build reports empty rows; then the stand-alone kernel runs).
 __global__ __launch_bounds__(256) void k_schur_prep(int nvis, const int* __restrict__ obs_pt, const int* __restrict__ campos,
-        const double* __restrict__ Bc, const double* __restrict__ Vinv, const double* __restrict__ eb, double* __restrict__ Cc)
+        const double* __restrict__ Bc, const double* __restrict__ Vinv, const double* __restrict__ eb, double* __restrict__ Cc,
+        const double* __restrict__ V = nullptr, double mu = 0.0, const int* __restrict__ rowptr = nullptr, double* __restrict__ Vinv_out = nullptr,
+        int* __restrict__ flag = nullptr, ZeroTilesArgs z = ZeroTilesArgs())
 {
+    if (z.first_block > 0 && (int)blockIdx.x >= z.first_block) { zero_tiles_body(z, (int)blockIdx.x - z.first_block); return; }      // (appended workgroups: k_zero_lower_tiles' job)
     const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t k = min(g >> 2, (size_t)nvis - 1);               // surplus quads of the last workgroup repeat the last observation
     const int q = (int)(g & 3);
@@ -516,7 +603,17 @@ __global__ __launch_bounds__(256) void k_schur_prep(int nvis, const int* __restr
     const int i = obs_pt[k];
     const double2 mine = reinterpret_cast<const double2*>(Bc)[t * 4 + q];
     double vi[6];
-    load_pairs<3>(Vinv + (size_t)i * 6, vi);
+    if (V) {
+        double vv[6];
+        load_pairs<3>(V + (size_t)i * 6, vv);
+        const bool singular = sym3_invert(vv, mu, vi);
+        if (q == 0 && (g >> 2) < (size_t)nvis && (int)k == rowptr[i]) {
+            double* o = Vinv_out + (size_t)i * 6;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) o[c] = vi[c];
+            if (singular) atomicOr(flag, 1);
+        }
+    } else load_pairs<3>(Vinv + (size_t)i * 6, vi);
     const double b0 = quad_bcast_d<0>(mine.x), b1 = quad_bcast_d<0>(mine.y), b2 = quad_bcast_d<1>(mine.x);
     const double b3 = quad_bcast_d<1>(mine.y), b4 = quad_bcast_d<2>(mine.x), b5 = quad_bcast_d<2>(mine.y);
     const double i00 = vi[0], i01 = vi[1], i02 = vi[2], i11 = vi[3], i12 = vi[4], i22 = vi[5];
@@ -635,28 +732,11 @@ __global__ void k_schur_diag_fill(int m, int mcon, const int* __restrict__ campt
     S[(pj * CNP + row) * ld + pj * CNP + col] = v;
 }
 
-// S is rebuilt for every solve attempt (the factorisation overwrites it and fills in its zero blocks).  Only the lower
-// triangle of 128x128 tiles is read by the factorisation, so only that half is cleared: one workgroup per tile,
-// 16-byte stores.  (The strictly upper tiles keep whatever the mirror writes of the assembly put there.)
 __global__ __launch_bounds__(256) void k_zero_lower_tiles(double* __restrict__ S, int ld, int ntl = 0x7fffffff, int count = 0, int off = 0, int add_ea = 0,
         const double* __restrict__ ea = nullptr, double* __restrict__ E = nullptr, const int* __restrict__ spos = nullptr, int cnp = 0)
 {
-    if ((int)blockIdx.x >= ntl) {      // blocks ntl .. : k_rhs_init's job (round 5: one launch fewer per attempt)
-        const int t = ((int)blockIdx.x - ntl) * 256 + threadIdx.x;
-        if (t >= count) return;
-        const int dst = spos ? spos[t / cnp] * cnp + t % cnp : t;
-        E[dst] = add_ea ? ea[off + t] : 0.0;
-        return;
-    }
-    int a = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
-    while ((a + 1) * (a + 2) / 2 <= (int)blockIdx.x) ++a;
-    while (a * (a + 1) / 2 > (int)blockIdx.x) --a;
-    const int b = blockIdx.x - a * (a + 1) / 2;          // tile (a, b), b <= a
-    double* T = S + ((size_t)a * 128) * ld + (size_t)b * 128;
-    for (int idx = threadIdx.x; idx < 128 * 64; idx += 256) {
-        const int r = idx >> 6, c2 = (idx & 63) * 2;
-        *reinterpret_cast<double2*>(T + (size_t)r * ld + c2) = make_double2(0.0, 0.0);
-    }
+    ZeroTilesArgs z; z.S = S; z.ld = ld; z.ntl = ntl; z.count = count; z.off = off; z.add_ea = add_ea; z.ea = ea; z.E = E; z.spos = spos; z.cnp = cnp; z.first_block = 0;
+    zero_tiles_body(z, (int)blockIdx.x);
 }
 
 // Reduced right-hand side: E_j starts as ea_j (on the rank that contributes U/ea to a multi-GPU sum, else 0); the tasks of
@@ -742,6 +822,9 @@ __global__ __launch_bounds__(256) void k_backsub_obs(int nvis, int mcon, const i
         for (int c = 0; c < CNP; ++c) { const double2 a = mine[c]; q0 += a.x * da[c]; q1 += a.y * da[c]; }
         w0 = B[0] * q0 + B[3] * q1; w1 = B[1] * q0 + B[4] * q1; w2 = B[2] * q0 + B[5] * q1;
     }
+    // (Round 6, measured and dropped: writing the product to the observation's POINT-major slot so that the second pass streams its row instead of
+    //  gathering 32 bytes out of a 128-byte line.  The scattered 32-byte stores of this pass cost more than the gathers of the next: back-substitution
+    //  0.50 -> 0.63 ms at config 3.)
     reinterpret_cast<double2*>(wobs)[2 * (size_t)t] = make_double2(w0, w1);
     reinterpret_cast<double2*>(wobs)[2 * (size_t)t + 1] = make_double2(w2, 0.0);
 }
@@ -814,8 +897,8 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem P, double mu, const 
     // arrived last: pdp_a is written and read inside this workgroup (a barrier in between)
     step_sums_body(fa.count, fa.fixed, mu, fa.pa, dpa, P.ea, fa.pdpa, fa.out3, part, (int)gridDim.x, fa.pt3, true);
     __syncthreads();
-    for (int j = threadIdx.x; j < P.m; j += 256)
-        cam_table_row(P.cfg, j, fa.pdpa, P.Rinit, P.finit, fa.known, fa.with_fd, fa.camtab_trial);
+    for (int t = threadIdx.x; t < P.m * CT_PARTS; t += 256)
+        cam_table_part(P.cfg, t / CT_PARTS, t % CT_PARTS, fa.pdpa, P.Rinit, P.finit, fa.known, fa.with_fd, fa.camtab_trial);
 }
 
 // camera part of the step: pdp_a = p_a + dp_a and sum dpa^2, sum pa^2, sum dpa (mu dpa + ea) (single block).
@@ -1046,65 +1129,31 @@ __global__ __launch_bounds__(64) void k_cam_solve(DevProblem P, double mu, doubl
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Per-iteration scalars in TWO launches instead of eleven (every launch is ~5 us of an iteration that, for the small
-// problems an incremental reconstruction mostly solves, is nothing but launch latency).  Same partitions and the same
-// reduction order as the individual kernels above, so the values are bit-identical.
-//   k_iter_partials (256 blocks): max |eb|, max diag V, sum p_b^2 over the block's slice -> part[0..255], [256..511], [512..767]
-//   k_iter_final    (1 block)  : reduces those, and computes max |ea|, max diag U, sum p_a^2, the constraint cost and
-//                                (multi-GPU) its point part.
-struct IterFinalArgs {       // what k_iter_final is given (so that k_iter_partials can do its job in the workgroup that arrives last)
-    const double* pa; int have_points, point_part_slot;
-    int s_eabinf_a, s_eabinf_b, s_maxdiag_u, s_maxdiag_v, s_pl2_a, s_pl2_b, s_ccost;
-    double* scal;
-};
-__device__ __forceinline__ void iter_final_body(const DevProblem& P, const double* __restrict__ pa, const double* __restrict__ pb,
-        const double* __restrict__ part, int have_points, int point_part_slot,
-        int s_eabinf_a, int s_eabinf_b, int s_maxdiag_u, int s_maxdiag_v, int s_pl2_a, int s_pl2_b, int s_ccost,
-        double* __restrict__ scal, bool agent_loads);
-
-__global__ __launch_bounds__(256) void k_iter_partials(const double* __restrict__ eb, const double* __restrict__ V,
-        const double* __restrict__ pb, int n, double* __restrict__ part, unsigned* __restrict__ ticket /* null: k_iter_final follows */,
-        DevProblem P, IterFinalArgs fa)
-{
-    __shared__ double sm[4];
-    const size_t cnt3 = (size_t)3 * n;
-    double a = 0.0, ss = 0.0, vd = -DBL_MAX;
-    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < cnt3; t += (size_t)gridDim.x * 256) {
-        const double x = fabs(eb[t]); a = x > a ? x : a;
-        const double y = pb[t]; ss += y * y;
-    }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const double* v = V + (size_t)i * 6;
-        const double q = v[0] > v[3] ? v[0] : v[3];
-        const double b = q > v[5] ? q : v[5];
-        vd = b > vd ? b : vd;
-    }
-    const double ra = block_max4(a, sm), rv = block_max4(vd, sm), rs = block_sum4(ss, sm);
-    if (threadIdx.x == 0) { st_agent(part + blockIdx.x, ra); st_agent(part + 256 + blockIdx.x, rv); st_agent(part + 512 + blockIdx.x, rs); }
-    if (!ticket || !last_block_arrives(ticket, gridDim.x)) return;
-    iter_final_body(P, fa.pa, pb, part, fa.have_points, fa.point_part_slot, fa.s_eabinf_a, fa.s_eabinf_b, fa.s_maxdiag_u, fa.s_maxdiag_v,
-                    fa.s_pl2_a, fa.s_pl2_b, fa.s_ccost, fa.scal, true);
-}
-
+// Per-iteration scalars (sba_levmar.c:1085-1128).  The point side's block partials come from k_point_blocks (round 6: it was a kernel of
+// its own, k_iter_partials); k_iter_final is the stand-alone finisher of the camera-only problem (have_points = 0).
 __global__ __launch_bounds__(256) void k_iter_final(DevProblem P, const double* __restrict__ pa, const double* __restrict__ pb,
         const double* __restrict__ part, int have_points, int point_part_slot,
         int s_eabinf_a, int s_eabinf_b, int s_maxdiag_u, int s_maxdiag_v, int s_pl2_a, int s_pl2_b, int s_ccost,
         double* __restrict__ scal)
 {
-    iter_final_body(P, pa, pb, part, have_points, point_part_slot, s_eabinf_a, s_eabinf_b, s_maxdiag_u, s_maxdiag_v, s_pl2_a, s_pl2_b, s_ccost, scal, false);
+    iter_final_body(P, pa, pb, part, 0, have_points, point_part_slot, s_eabinf_a, s_eabinf_b, s_maxdiag_u, s_maxdiag_v, s_pl2_a, s_pl2_b, s_ccost, scal, false);
 }
 __device__ __forceinline__ void iter_final_body(const DevProblem& P, const double* __restrict__ pa, const double* __restrict__ pb,
-        const double* __restrict__ part, int have_points, int point_part_slot,
+        const double* __restrict__ part, int nparts, int have_points, int point_part_slot,
         int s_eabinf_a, int s_eabinf_b, int s_maxdiag_u, int s_maxdiag_v, int s_pl2_a, int s_pl2_b, int s_ccost,
         double* __restrict__ scal, bool agent_loads)
 {
     __shared__ double sm[4];
     const int cnp = P.cfg.cnp, t = threadIdx.x;
-    if (have_points) {
-        double a = agent_loads ? ld_agent(part + t) : part[t];                   a = a > 0.0 ? a : 0.0;                   // k_reduce_max starts from 0
-        double v = agent_loads ? ld_agent(part + 256 + t) : part[256 + t];       v = v > 0.0 ? v : 0.0;
-        const double p512 = agent_loads ? ld_agent(part + 512 + t) : part[512 + t];
-        const double ra = block_max4(a, sm), rv = block_max4(v, sm), rs = block_sum4(p512, sm);
+    if (have_points) {      // part = [3][nparts]: the block partials of k_point_blocks, reduced in a fixed order
+        double a = 0.0, v = 0.0, s = 0.0;                                         // (maxima of non-negative quantities: a 0-based maximum is exact)
+        for (int q = t; q < nparts; q += 256) {
+            const double pa_ = agent_loads ? ld_agent(part + q) : part[q];
+            const double pv_ = agent_loads ? ld_agent(part + (size_t)nparts + q) : part[(size_t)nparts + q];
+            a = pa_ > a ? pa_ : a; v = pv_ > v ? pv_ : v;
+            s += agent_loads ? ld_agent(part + 2 * (size_t)nparts + q) : part[2 * (size_t)nparts + q];
+        }
+        const double ra = block_max4(a, sm), rv = block_max4(v, sm), rs = block_sum4(s, sm);
         if (t == 0) { scal[s_eabinf_b] = ra; scal[s_maxdiag_v] = rv; scal[s_pl2_b] = rs; }
     }
     double ea = 0.0, ud = -DBL_MAX, ps = 0.0;

@@ -871,7 +871,12 @@ static int match_set_run_impl(bsfm_match_set_t* ms, double ratio, int window_rad
     }
     ok = ok && drain(slots[turn & 1]) && drain(slots[(turn + 1) & 1]);
     release();
-    if (!ok) { fprintf(stderr, "[bsfm] matcher: HIP error in the pair pipeline\n"); if (f) fclose(f); return BSFM_ERROR; }
+    if (!ok) {
+        // a failed pass may leave kernels of a busy slot in flight that still write its pinned buffers: nothing of the pipeline -- which now lives
+        // with the match set and is reused by the next run -- may be touched again before both streams are idle
+        for (int q = 0; q < 2; ++q) { (void)hipStreamSynchronize(sts[q]); slots[q].busy = false; }
+        fprintf(stderr, "[bsfm] matcher: HIP error in the pair pipeline\n"); if (f) fclose(f); return BSFM_ERROR;
+    }
     if (f) fclose(f);
     return total_pairs_written;
 }

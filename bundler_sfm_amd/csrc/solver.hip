@@ -233,6 +233,7 @@ struct bsfm_problem {
     int *d_flags = nullptr;             // [0] singular V, [1] potrf info
     bool backsub_two_pass = false;      // k_backsub_obs + gather (nvis >= 200 000, or BSFM_BACKSUB_TWO_PASS=0|1)
     size_t tick_res = 0, tick_back = 0; // word offsets of the group tickets in d_tickets
+    size_t tick_words = 0;
     unsigned* d_tickets = nullptr;      // "last workgroup finishes the job" tickets (kernels.hip.h): [0] residual, [1] iteration scalars, [2] back-substitution, [8 ..) one per camera
     // schur structure
     int ntriples = 0, ntasks = 0, nblk = 0;
@@ -258,6 +259,8 @@ struct bsfm_problem {
     bsfm_problem_desc_t desc0{};                  // scalar fields of the description the problem was created from
     hipStream_t stream = nullptr; bool own_stream = false;
     int flow_fallbacks = 0;             // solves repeated on the stream-ordered Cholesky schedule after a hand-off time-out of the dataflow launch
+    bool empty_rows = false;           // some point has no observation (index build)
+    bool fuse_invert = false;          // V*^-1 is computed inside k_schur_prep (every point has an observation; BSFM_FUSE_INVERT=0|1)
     bool speculate = false;            // launch the first damping attempt of an iteration before its gradient test is read (small problems; BSFM_SPECULATE=0|1)
     bsfm_allreduce_fn allreduce = nullptr; void* allreduce_ctx = nullptr;
     bsfm_comm_t* comm = nullptr;        // library-side collective (comm.hip: RCCL over xGMI); takes precedence over the hook
@@ -316,6 +319,8 @@ int adopt_index(bsfm_problem* pb, DeviceIndex& ix)
     pb->n_row_blocks = ix.n_row_blocks; pb->row_triples = ix.row_triples;
     pb->h_blk_j.swap(ix.h_blk_j); pb->h_blk_k.swap(ix.h_blk_k);
     pb->index_build_ms = ix.build_ms;
+    pb->empty_rows = ix.empty_rows;
+    pb->fuse_invert = pb->fuse_invert && !pb->empty_rows;
     ix = DeviceIndex();                                  // ownership moved: free_all releases the arrays
     if (pb->mot) return 0;
     if (pb->world == 1 && setup_components(pb, pb->h_blk_j, pb->h_blk_k)) return BSFM_ERROR;   // world > 1: after the block-union exchange
@@ -384,7 +389,7 @@ inline int grid_for(size_t count, int block) { return (int)std::max<size_t>(1, (
 
 void launch_cam_table(bsfm_problem* pb, const double* p, double* camtab)
 {
-    hipLaunchKernelGGL(k_cam_table, dim3(grid_for(pb->P.m, 64)), dim3(64), 0, pb->stream, pb->P.cfg, pb->P.m, p,
+    hipLaunchKernelGGL(k_cam_table, dim3(grid_for((size_t)pb->P.m * CT_PARTS, 64)), dim3(64), 0, pb->stream, pb->P.cfg, pb->P.m, p,
                        pb->d_Rinit, pb->d_finit, pb->d_known, pb->opt.jacobian == BSFM_JAC_FD ? 1 : 0, camtab);
 }
 
@@ -504,8 +509,11 @@ void collect_phase_times(bsfm_problem* pb)
 }
 
 // J, U/ea, V/eb at the current p
-int compute_normal_blocks(bsfm_problem* pb)
+// with_iter_scalars: the point-block kernel also leaves the iteration's scalars (sba_levmar.c:1085-1128) in d_scal and clears the flags of the
+// first solve attempt (round 6: was k_iter_partials + a memset); *did_scalars says whether it did (no points: the caller runs k_iter_final)
+int compute_normal_blocks(bsfm_problem* pb, bool with_iter_scalars = false, bool* did_scalars = nullptr)
 {
+    if (did_scalars) *did_scalars = false;
     const int cnp = pb->cnp;
     DevProblem& P = pb->P;
     const double* pbpts = pb->d_p + (size_t)P.m * cnp;
@@ -527,15 +535,27 @@ int compute_normal_blocks(bsfm_problem* pb)
     ph_end(pb, PH_JAC);
     ph_begin(pb, PH_CAMBLK);
     // (k_cam_blocks_fin's sums over the CAM_SPLIT slices of a camera are done by the slice workgroup that arrives last)
-    DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_cam_blocks<C>), dim3(P.m * CAM_SPLIT), dim3(256), 0, pb->stream, P, pb->d_e, pb->d_campart, pb->d_tickets + 8));
+    // single GPU: the camera constraints (sba_levmar.c:953-962) are added by the workgroup that finishes a camera's sums -- one launch fewer, and
+    // Bundler always constrains (focal length, distortion: src/Bundle.cpp:942-974); several ranks: after the reduction of U and ea, below
+    const double* pa_con = (P.ccon && pb->world == 1) ? (const double*)pb->d_p : nullptr;
+    DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_cam_blocks<C>), dim3(P.m * CAM_SPLIT), dim3(256), 0, pb->stream, P, pb->d_e, pb->d_campart, pb->d_tickets + 8, pa_con));
     ph_end(pb, PH_CAMBLK);
     if (pb->world > 1) {   // U and ea are sums over ALL points: exchange step 1, 90*m doubles
         if (allreduce_dev(pb, pb->d_U, (size_t)P.m * cnp * cnp + (size_t)P.m * cnp, 0)) return BSFM_ERROR;   // ea follows U
     }
-    if (P.ccon)
+    if (P.ccon && !pa_con)
         hipLaunchKernelGGL(k_cam_constraints, dim3(grid_for((size_t)P.m * cnp, 256)), dim3(256), 0, pb->stream, P, pb->d_p);
     ph_begin(pb, PH_PTBLK);
-    if (P.n > 0 && !pb->mot) DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_point_blocks<C>), dim3(grid_for(P.n, 256)), dim3(256), 0, pb->stream, P, pbpts));
+    if (P.n > 0 && !pb->mot) {
+        if (with_iter_scalars) {
+            IterFinalArgs fa; fa.pa = pb->d_p; fa.have_points = 1; fa.point_part_slot = pb->world > 1 ? SC_COUNT + 8 : -1;
+            fa.s_eabinf_a = SC_EABINF_A; fa.s_eabinf_b = SC_EABINF_B; fa.s_maxdiag_u = SC_MAXDIAG_U; fa.s_maxdiag_v = SC_MAXDIAG_V;
+            fa.s_pl2_a = SC_PL2_A; fa.s_pl2_b = SC_PL2_B; fa.s_ccost = SC_CCOST; fa.scal = pb->d_scal;
+            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_point_blocks<C>), dim3(grid_for(P.n, 256)), dim3(256), 0, pb->stream, P, pbpts, pb->d_red, pb->d_tickets + 1,
+                                                  pb->d_tickets + pb->tick_back, fa, pb->d_flags));
+            if (did_scalars) *did_scalars = true;
+        } else DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_point_blocks<C>), dim3(grid_for(P.n, 256)), dim3(256), 0, pb->stream, P, pbpts));
+    }
     ph_end(pb, PH_PTBLK);
     return 0;
 }
@@ -694,6 +714,14 @@ int compute_schur(bsfm_problem* pb, double mu)
     if (pb->export_full_s) (void)hipMemsetAsync(pb->d_S, 0, (size_t)pb->ld * pb->ld * sizeof(double), pb->stream);
     bool rhs_done = false, diag_done = false;
     double* Edst = packed ? pb->d_G + (size_t)pb->ngblk * cnp * cnp : pb->d_E;     // packed: E rides behind the blocks
+    ZeroTilesArgs zt; memset(&zt, 0, sizeof zt);      // != 0 first_block: k_schur_prep clears the tiles / initialises E in workgroups appended to its grid
+    const int nprep = grid_for(4 * (size_t)P.nvis, 256);
+    if (!pb->export_full_s && !pb->comps.active && !packed && mm > 0 && pb->ntasks > 0) {
+        const int nt = pb->ld / POTRF_NB, ntl = nt * (nt + 1) / 2;
+        zt.S = pb->d_S; zt.ld = pb->ld; zt.ntl = ntl; zt.count = mm * cnp; zt.off = P.mcon * cnp; zt.add_ea = lead; zt.ea = pb->d_ea; zt.E = Edst; zt.spos = spos; zt.cnp = cnp;
+        zt.first_block = nprep;
+        rhs_done = true;
+    } else
     if (!pb->export_full_s && !pb->comps.active) {   // (the group-by-group solve never writes S: blocks that are structurally empty stay zero)
         const int nt = pb->ld / POTRF_NB, ntl = nt * (nt + 1) / 2;
         if (!packed && mm > 0) {      // one launch: the lower tiles of S cleared, E = ea
@@ -709,7 +737,13 @@ int compute_schur(bsfm_problem* pb, double mu)
     if (pb->ntasks > 0) {
         // C_ij = B_ij V*_i^-1 || C_ij eb_i for this attempt's mu, then the task kernel (schur.hip.h)
         ph_begin(pb, PH_SCHUR_PREP);
-        hipLaunchKernelGGL(k_schur_prep, dim3(grid_for(4 * (size_t)P.nvis, 256)), dim3(256), 0, pb->stream, P.nvis, pb->d_obs_pt, pb->d_campos, pb->d_Bc, pb->d_Vinv, pb->d_eb, pb->d_Cc);
+        const int nzero = zt.first_block > 0 ? zt.ntl + grid_for((size_t)zt.count, 256) : 0;
+        if (pb->fuse_invert)
+            hipLaunchKernelGGL(k_schur_prep, dim3(nprep + nzero), dim3(256), 0, pb->stream, P.nvis, pb->d_obs_pt, pb->d_campos, pb->d_Bc, pb->d_Vinv, pb->d_eb, pb->d_Cc,
+                               (const double*)pb->d_V, mu, (const int*)pb->d_rowptr, pb->d_Vinv, pb->d_flags, zt);
+        else
+            hipLaunchKernelGGL(k_schur_prep, dim3(nprep + nzero), dim3(256), 0, pb->stream, P.nvis, pb->d_obs_pt, pb->d_campos, pb->d_Bc, pb->d_Vinv, pb->d_eb, pb->d_Cc,
+                               (const double*)nullptr, 0.0, (const int*)nullptr, (double*)nullptr, (int*)nullptr, zt);
         ph_end(pb, PH_SCHUR_PREP);
         static const int wps = [] { const char* e = getenv("BSFM_SCHUR_WPS"); const int v = e ? atoi(e) : 3; return v < 2 ? 2 : (v > 4 ? 4 : v); }();
         ph_begin(pb, PH_SCHUR_ROWS);
@@ -892,6 +926,7 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
         pb->tick_back = pb->tick_res + ticket_group_words((size_t)grid_for(nvis, RES_BLOCK));
         const size_t words = pb->tick_back + ticket_group_words((size_t)grid_for(n, 256));
         DM(pb->d_tickets, words);
+        pb->tick_words = words;
         if (hipMemsetAsync(pb->d_tickets, 0, words * sizeof(unsigned), pb->stream) != hipSuccess) return fail("tickets");
     }
 #undef DM
@@ -960,10 +995,12 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     // were a tenth of an iteration; BSFM_PHASE_TIMING=1 / 0 forces it.
     pb->backsub_two_pass = nvis >= 200000;
     if (const char* e = getenv("BSFM_BACKSUB_TWO_PASS")) pb->backsub_two_pass = atoi(e) != 0;
-    pb->ev_ok = nvis >= 100000;
+    pb->ev_ok = nvis >= 2000000;      // (round 6: was 100 000 -- exactly the 50-camera problem of the latency table, whose iteration the event records made a third longer)
     if (const char* e = getenv("BSFM_PHASE_TIMING")) pb->ev_ok = atoi(e) != 0;
-    // measured (profiles/r03_small_problem_latency_speculate.txt): 10 % of an iteration at 14 cameras, nothing from 50 cameras on
-    pb->speculate = pb->nvis_global <= 30000;
+    // measured (profiles/r03_small_problem_latency_speculate.txt, profiles/r06_small_problem_latency.txt): 10 % of an iteration at 14 cameras
+    pb->speculate = pb->nvis_global <= 1200000;      // (round 6: 3 - 5 % at 50 / 100 cameras once the event records were gone, 1 % at 400; was <= 30 000)
+    pb->fuse_invert = !pb->empty_rows;
+    if (const char* e = getenv("BSFM_FUSE_INVERT")) pb->fuse_invert = atoi(e) != 0 && !pb->empty_rows;
     if (const char* e = getenv("BSFM_SPECULATE")) pb->speculate = atoi(e) != 0;
     pb->potrf.timing = pb->ev_ok ? 1 : 0;
     for (int i = 0; pb->ev_ok && i < PH_COUNT; ++i) {
@@ -1251,6 +1288,11 @@ double bsfm_lm_last_kernel_ms(const bsfm_problem_t* pb, const char* phase)
 int bsfm_lm_begin(bsfm_problem_t* pb)
 {
     const long long nobs = 2 * pb->nvis_global;
+    // The "last workgroup finishes" tickets (kernels.hip.h) go back to zero by themselves at the end of every launch.  A run that ended in an error may
+    // have left one half-drawn -- the next launch would then never see a "last" workgroup and keep stale sums -- so after an error they are cleared
+    // here (not unconditionally: on a 14-camera problem every stream operation is 3 % of an iteration).
+    if (pb->error && pb->d_tickets && pb->tick_words)
+        (void)hipMemsetAsync(pb->d_tickets, 0, pb->tick_words * sizeof(unsigned), pb->stream);
     pb->itno = 0; pb->stop = 0; pb->nu = 2; pb->nfev = 0; pb->njev = 0; pb->nlss = 0; pb->error = 0;
     pb->mu = 0.0; pb->eab_inf = 0.0; pb->dp_L2 = DBL_MAX; pb->p_L2 = 0.0; pb->maxdiag = DBL_MIN;
     for (int i = 0; i < PH_COUNT; ++i) { pb->ph_ms[i] = 0.0; pb->ph_cnt[i] = 0; }
@@ -1419,15 +1461,14 @@ static int lm_iterate_impl(bsfm_problem_t* pb, int iters)
     int done = 0;
 
     for (; pb->itno < itmax && !pb->stop && done < iters; ++pb->itno, ++done) {
-        if (compute_normal_blocks(pb)) return BSFM_ERROR;
+        // J, U / ea, V / eb -- and, in the last workgroup of the point-block kernel, ||J^T e||_inf, ||p||^2, the largest diagonal entry
+        // (sba_levmar.c:1085-1128) and the cleared flags of the first solve attempt
+        bool flags_cleared = false;
+        if (compute_normal_blocks(pb, true, &flags_cleared)) return BSFM_ERROR;
         ++pb->njev;
-        // ||J^T e||_inf, ||p||^2, max diagonal (sba_levmar.c:1085-1128)
-        {   // (k_iter_final's job is done by the workgroup of k_iter_partials that arrives last)
-            IterFinalArgs fa; fa.pa = d_pa; fa.have_points = 1; fa.point_part_slot = pb->world > 1 ? SC_COUNT + 8 : -1;
-            fa.s_eabinf_a = SC_EABINF_A; fa.s_eabinf_b = SC_EABINF_B; fa.s_maxdiag_u = SC_MAXDIAG_U; fa.s_maxdiag_v = SC_MAXDIAG_V;
-            fa.s_pl2_a = SC_PL2_A; fa.s_pl2_b = SC_PL2_B; fa.s_ccost = SC_CCOST; fa.scal = pb->d_scal;
-            hipLaunchKernelGGL(k_iter_partials, dim3(256), dim3(256), 0, pb->stream, pb->d_eb, pb->d_V, d_pb, P.n, pb->d_red, pb->d_tickets + 1, P, fa);
-        }
+        if (!flags_cleared)      // a problem without points: the camera side alone (the point entries of d_scal stay at their initial zeros)
+            hipLaunchKernelGGL(k_iter_final, dim3(1), dim3(256), 0, pb->stream, P, (const double*)d_pa, (const double*)d_pb, (const double*)pb->d_red, 0, -1,
+                               SC_EABINF_A, SC_EABINF_B, SC_MAXDIAG_U, SC_MAXDIAG_V, SC_PL2_A, SC_PL2_B, SC_CCOST, pb->d_scal);
         // The gradient norm / parameter norm / largest diagonal of this iteration (sba_levmar.c:1085-1130).  They cost a round trip to the
         // host, and on a 14-camera problem a round trip is a tenth of the iteration -- so from the second iteration on (mu is known
         // then) the first damping attempt is launched BEFORE they are read and they come back with the attempt's own scalars.  If the
@@ -1463,9 +1504,12 @@ static int lm_iterate_impl(bsfm_problem_t* pb, int iters)
 
         while (1) {   // determine increment using adaptive damping (sba_levmar.c:1131)
             const double mu = pb->mu;
-            (void)hipMemsetAsync(pb->d_flags, 0, 4 * sizeof(int), pb->stream);
+            if (!flags_cleared) (void)hipMemsetAsync(pb->d_flags, 0, 4 * sizeof(int), pb->stream);      // (a repeated attempt, or no point-block kernel before it)
+            flags_cleared = false;
             ph_begin(pb, PH_INVERT);
-            if (P.n > 0) hipLaunchKernelGGL(k_point_invert, dim3(nbp), dim3(256), 0, pb->stream, P.n, mu, pb->d_V, pb->d_Vinv, pb->d_flags);
+            // V*^-1: inside k_schur_prep when that kernel runs and every point has an observation (round 6), else here
+            if (P.n > 0 && !(pb->fuse_invert && pb->ntasks > 0))
+                hipLaunchKernelGGL(k_point_invert, dim3(nbp), dim3(256), 0, pb->stream, P.n, mu, pb->d_V, pb->d_Vinv, pb->d_flags);
             ph_end(pb, PH_INVERT);
             ph_begin(pb, PH_SCHUR);
             if (compute_schur(pb, mu)) return BSFM_ERROR;

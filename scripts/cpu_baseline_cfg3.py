@@ -32,16 +32,13 @@ def cpu_model():
     return "unknown"
 
 
-def main():
-    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "cpu_baseline_cfg3.json")
-    itmax = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-    m = int(sys.argv[3]) if len(sys.argv) > 4 else 1000
-    n = int(sys.argv[4]) if len(sys.argv) > 4 else 500000
+def run(m=1000, n=500000, itmax=3):
+    """The reference's sba_motstr_levmar (-DTIMINGS build) on the seeded scene; returns the record (phases from its own prints)."""
     import oracle_util as O
     import bundler_sfm_amd as B            # host-only helpers: seeded scene generator, dense vmask
     lib_path = os.path.join(ROOT, "oracle", "_ref", "libsfmref_timings.so")
     if not os.path.exists(lib_path):
-        sys.exit(lib_path + " missing (make -C oracle ref, build container)")
+        raise RuntimeError(lib_path + " missing (make -C oracle ref, build container)")
     lib = C.CDLL(lib_path)
     s = B.synth_ba(m, n, 10)
     vm = B.dense_vmask(n, m, s["rowptr"], s["colidx"])
@@ -62,7 +59,6 @@ def main():
         rc = fn(n, m, 0, vm.ctypes.data_as(C.c_char_p), O._d(s["proj"]), 1, 1, 1, cams, O._d(pts), 0, 0, None, 0.0, 1e-12, itmax, 0, 0,
                 O._d(info), O._d(p), None, None, None, None, C.byref(secs))
     finally:
-        lib.fflush_stdout() if hasattr(lib, "fflush_stdout") else None
         C.CDLL(None).fflush(None)
         os.dup2(saved, 1); os.close(saved)
     wall = time.time() - t0
@@ -72,7 +68,7 @@ def main():
     for name, val in re.findall(r"\[sba_motstr_levmar_x\] (.+?) took ([0-9.]+)s", text):
         phases.setdefault(name, []).append(float(val))
     its = max(int(info[5]), 1)
-    out = {
+    return {
         "what": "reference sba_motstr_levmar (lib/sba-1.5, -DTIMINGS, vendored CLAPACK, gcc -O3), FD Jacobian, 1 thread",
         "config": {"cameras": m, "points": n, "observations": int(s["rowptr"][-1]), "itmax": itmax},
         "host_cpu": cpu_model(), "host_cpus": os.cpu_count(), "cores_used": 1,
@@ -83,6 +79,17 @@ def main():
         "phases_s_per_call": {k: [round(v, 3) for v in vals] for k, vals in phases.items()},
         "phases_s_mean": {k: round(sum(vals) / len(vals), 3) for k, vals in phases.items()},
     }
+
+
+def main():
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "cpu_baseline_cfg3.json")
+    itmax = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    m = int(sys.argv[3]) if len(sys.argv) > 4 else 1000
+    n = int(sys.argv[4]) if len(sys.argv) > 4 else 500000
+    try:
+        out = run(m, n, itmax)
+    except RuntimeError as exc:
+        sys.exit(str(exc))
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
     json.dump(out, open(out_path, "w"), indent=1)
     print(json.dumps(out))

@@ -1,7 +1,11 @@
 """Phase split of one LM iteration at the sizes incremental Bundler spends its time at (tens to hundreds of cameras)."""
+import os
+os.environ.setdefault("BSFM_PHASE_TIMING", "1")      # (phase events are off below 2 M observations since round 6)
 import os, sys, time, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import os
+os.environ.setdefault("BSFM_PHASE_TIMING", "1")      # (phase events are off below 2 M observations since round 6)
 import bundler_sfm_amd as B
 for m, n in ((14, 3000), (50, 10000), (100, 20000), (200, 50000), (400, 100000)):
     s = B.synth_ba(m, n, 10 if m >= 50 else 7, banded=(m >= 100))

@@ -131,7 +131,11 @@ def known_intrinsics():
     out["cam_K_known"] = np.array([list(cams[j].K_known) for j in range(c["m"])])
     out["cam_k_known"] = np.array([list(cams[j].k_known) for j in range(c["m"])])
     out["rowptr"] = s["rowptr"]; out["colidx"] = s["colidx"]; out["proj"] = s["proj"]; out["pts"] = s["pts"]
-    for it in (1, 3, 150):
+    # 10 and 15: FIXED iteration indices inside the reference's 38-iteration run (round 6): the converged run stops on its relative-step test on a
+    # plateau, where one iteration more or less is rounding.  This scene's trajectory separates from ANY other arithmetic after ~12 iterations --
+    # the dataflow solve and the round-2 LAPACK-style kernel alike (profiles/r06_known_intrinsics_trajectory.txt: 1e-11 at 10, 4e-8 at 15, 2e-4 at
+    # 25) -- so the tight pin sits at 10 and a looser one at 15
+    for it in (1, 3, 10, 15, 150):
         r = O.ref_sba(c["n"], c["m"], vm, s["proj"], cams, s["pts"], itmax=it, jac_mode=0)
         out[f"fd_it{it}_p"] = r["p"]; out[f"fd_it{it}_info"] = r["info"]
     np.savez_compressed(os.path.join(HERE, "known_golden.npz"), **out)
