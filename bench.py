@@ -599,7 +599,7 @@ def main():
         flops_launch, nlaunch = syrk_flops_per_launch(sdim)
         syrk_ms = pb.phase_ms("syrk")
         phases = {ph: round(pb.phase_ms(ph), 4) for ph in
-                  ("jacobian", "cam_blocks", "point_blocks", "point_invert", "schur", "schur_prep", "schur_rows", "schur_tasks",
+                  ("jacobian", "cam_blocks", "point_blocks", "point_invert", "schur", "schur_prep", "schur_tasks",
                    "solve", "backsub", "residual")}
         roof = None
         flow_ms = pb.phase_ms("flow_kernel")
@@ -664,11 +664,8 @@ def main():
                        + (pmc_summary()[1] and "profiles/" + pmc_summary()[1] or "no committed PMC summary")
                        + "; a ratio a few per cent BELOW 1 is the 32 MB of L2 holding part of what the previous kernel wrote (FETCH_SIZE counts what leaves L2)")
         schur_flop = deg2 * 486.0                       # 486 flop per co-visibility pair with the symmetry used
-        schur = {"ms": phases["schur"], "prep_ms": phases["schur_prep"], "rows_kernel_ms": phases["schur_rows"], "tasks_kernel_ms": phases["schur_tasks"],
-                 "row_kernel": {"workgroups": int(pb.phase_ms("row_wgs")), "pieces": int(pb.phase_ms("row_pieces")), "dense_blocks": int(pb.phase_ms("row_blocks")),
-                                "triples": int(pb.phase_ms("row_triples")), "segment_records": int(pb.phase_ms("row_L"))},
-                 "kernels_frac_of_fp64_peak": (round(schur_flop / ((phases["schur_rows"] + phases["schur_tasks"]) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)
-                                               if phases["schur_rows"] + phases["schur_tasks"] > 0 else None),
+        schur = {"ms": phases["schur"], "prep_ms": phases["schur_prep"], "tasks_kernel_ms": phases["schur_tasks"],
+                 "kernels_frac_of_fp64_peak": (round(schur_flop / (phases["schur_tasks"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if phases["schur_tasks"] > 0 else None),
                  "triples": deg2, "useful_flop": schur_flop,
                  "TFLOPs": round(schur_flop / (phases["schur"] * 1e-3) / 1e12, 2) if phases["schur"] > 0 else None,
                  "frac_of_fp64_peak": round(schur_flop / (phases["schur"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4) if phases["schur"] > 0 else None,
@@ -685,6 +682,8 @@ def main():
                        "cameras": m, "points": n, "observations": nvis_global, "jacobian": args.jacobian,
                        "reduced_solver": args.reduced_solver, "collective": collective, "rccl_ranks_seen": ranks_seen,
                        "solve_attempts_per_step": round(r["att"] / max(done, 1), 3), "restarts_after_convergence": r["restarts"],
+                       # > 0: the ranks factored the reduced camera system TOGETHER (BSFM_DIST_CHOL=1 on a transport that maps peer buffers), 0: every rank all of it
+                       "distributed_cholesky_ranks": int(pb.phase_ms("flow_dist")),
                        "timed_window": ("iterations 1..K of run_sfm's own LM run from the initial parameters (its options and stop rules, "
                                         "sfm.c:705-714; restarted from the initial parameters when it stops: 20 iterations / 21 linear systems on "
                                         "this scene, the run tests/golden/cfg3_fd_conv_golden.npz pins to the reference)") if args.window == "run"

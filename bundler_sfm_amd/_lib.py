@@ -73,10 +73,9 @@ SYMBOLS = [
     "bsfm_problem_set_allreduce", "bsfm_problem_set_stream", "bsfm_problem_reset_params", "bsfm_problem_append", "bsfm_problem_remove_points", "bsfm_lm_begin",
     "bsfm_lm_iterate", "bsfm_lm_finish", "bsfm_lm_solve_attempts", "bsfm_lm_last_kernel_ms",
     "bsfm_problem_download", "bsfm_problem_export_index", "bsfm_problem_schur_sizes", "bsfm_problem_export_schur", "bsfm_crs_from_vmask", "bsfm_crs_from_vmask_device", "bsfm_run_sfm_last_ms", "bsfm_schur_chunk", "bsfm_device_cache_trim",
-    "bsfm_problem_row_sizes", "bsfm_problem_export_rows", "bsfm_schur_row_plan",
     "bsfm_problem_cnp", "bsfm_problem_num_cameras", "bsfm_problem_num_points", "bsfm_problem_nvis", "bsfm_eval_residuals", "bsfm_problem_outlier_stats", "bsfm_problem_ray_angles", "bsfm_triangulate_batch", "bsfm_rand_seed", "bsfm_rand_next", "bsfm_fmatrix_ransac_batch",
     "bsfm_estimate_fmatrix_batch", "bsfm_compute_tracks",
-    "bsfm_eval_normal_equations", "bsfm_dense_chol_solve", "bsfm_dense_chol_solve_timed", "bsfm_chol_flow_schedule", "bsfm_chol_dyn_plan", "bsfm_match_keys_l2", "bsfm_key_match_full",
+    "bsfm_eval_normal_equations", "bsfm_dense_chol_solve", "bsfm_dense_chol_solve_timed", "bsfm_chol_flow_schedule", "bsfm_chol_dyn_plan", "bsfm_comm_share", "bsfm_comm_unshare", "bsfm_dense_chol_solve_dist", "bsfm_match_keys_l2", "bsfm_key_match_full",
     "bsfm_key_match_full_sharded", "bsfm_merge_match_files", "bsfm_match_set_create", "bsfm_match_set_run", "bsfm_match_set_run_table", "bsfm_free", "bsfm_match_set_stats", "bsfm_match_kernel", "bsfm_match_set_rescan_launches",
     "bsfm_match_set_destroy",
     "bsfm_device_count", "bsfm_version", "bsfm_device_synchronize", "bsfm_synth_ba", "bsfm_synth_keys",
@@ -158,6 +157,12 @@ def _load():
     lib.bsfm_eval_normal_equations.restype = C.c_int
     lib.bsfm_dense_chol_solve.argtypes = [C.c_int, dp, dp, dp, C.c_int]
     lib.bsfm_dense_chol_solve.restype = C.c_int
+    lib.bsfm_dense_chol_solve_dist.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int]
+    lib.bsfm_dense_chol_solve_dist.restype = C.c_int
+    lib.bsfm_comm_share.argtypes = [vp, vp, C.POINTER(vp)]
+    lib.bsfm_comm_share.restype = C.c_int
+    lib.bsfm_comm_unshare.argtypes = [vp, C.POINTER(vp)]
+    lib.bsfm_comm_unshare.restype = C.c_int
     lib.bsfm_comm_idfile_exchange.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_ubyte)]
     lib.bsfm_comm_idfile_exchange.restype = C.c_int
     lib.bsfm_chol_flow_schedule.argtypes = [C.c_int, ip, C.c_int, C.c_int, vp, C.c_int, dp]
@@ -223,13 +228,6 @@ def _load():
     lib.bsfm_problem_schur_sizes.restype = C.c_int
     lib.bsfm_problem_export_schur.argtypes = [vp, ip, ip, ip, ip, ip, ip]
     lib.bsfm_problem_export_schur.restype = C.c_int
-    lib.bsfm_problem_row_sizes.argtypes = [vp, ip, ip, ip, ip, ip]
-    lib.bsfm_problem_row_sizes.restype = C.c_int
-    lib.bsfm_problem_export_rows.argtypes = [vp, ip, ip, ip, ip, ip, ip]
-    lib.bsfm_problem_export_rows.restype = C.c_int
-    lib.bsfm_schur_row_plan.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, ip, ip, ip, ip, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, ip, ip,
-                                        ip, C.c_int, ip, ip, C.c_int, ip]
-    lib.bsfm_schur_row_plan.restype = C.c_int
     lib.bsfm_dense_chol_solve_timed.argtypes = [C.c_int, dp, dp, dp, C.c_int, C.c_int, dp, dp, dp]
     lib.bsfm_dense_chol_solve_timed.restype = C.c_int
     lib.bsfm_crs_from_vmask.argtypes = [C.c_int, C.c_int, C.c_char_p, ip, ip]

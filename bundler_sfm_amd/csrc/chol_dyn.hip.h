@@ -600,6 +600,10 @@ inline int flow_solve_dispatch(PotrfWorkspace& w, double* S, int ld, int n, cons
 {
     if (!w.flow) w.flow = new FlowWorkspace();
     FlowWorkspace& f = *w.flow;
+    if (w.dist_comm) {      // the ranks of a communicator factor the replicated system together (chol_flow.hip.h: FlowDist)
+        if (!f.dist) { f.dist = new FlowDist(); f.dist->comm = w.dist_comm; }
+        return flow_solve_dist(w, f, *f.dist, S, ld, n, E, x_out, d_info, st);
+    }
     if (f.dynamic < 0) {
         // Round 6, measured (profiles/r06_dynamic_bulk_*.txt): the dynamic bulk is correct and bit-identical to itself for any number of
         // workgroups, but at 71 tile columns it takes 8.9 - 13 ms against 6.2 ms for the static order -- every row's TRSM -> UPD chain pays

@@ -35,6 +35,14 @@
 #include <memory>
 #include <mutex>
 
+extern "C" {      // comm.hip (declared again in include/bsfm.h with the typedef'd name)
+int bsfm_comm_share(struct bsfm_comm* c, void* mine, void** peers);
+int bsfm_comm_unshare(struct bsfm_comm* c, void** peers);
+int bsfm_comm_rank(const struct bsfm_comm* c);
+int bsfm_comm_world(const struct bsfm_comm* c);
+int bsfm_comm_barrier(struct bsfm_comm* c);
+}
+
 namespace bsfm {
 
 struct FlowArgs {
@@ -58,7 +66,22 @@ struct FlowArgs {
     unsigned ptrace_ofs;
     long long spin_limit;  // wall-clock ticks (100 MHz) a task may wait for its dependencies before the launch gives up
     int stall_ticket;      // TEST HOOK (BSFM_FLOW_TEST_STALL=k): the bulk task with ticket k never signals -- what a starved launch looks like; -1 = none
+    unsigned genbase;      // DISTRIBUTED factorisation (round 6): the value the per-tile counters start from in this solve (generation << 16): a rank that
+                           // polls a peer's counter never mistakes the count of the PREVIOUS solve for this one's; 0 on one rank
+    const struct FlowPeers* peers;      // ... the ranks' buffers (device memory); nullptr = one rank owns every tile column
 };
+// Distributed factorisation: tile column j -- its diagonal tile, its panel tiles, W_j, y_j, the counters of its tiles -- belongs to rank j mod n.  A rank
+// runs the tasks of its own columns (the same static order, filtered), WRITES only its own buffers, and READS the panel tiles / y / counters of a column
+// from the buffers of that column's owner: peer-mapped windows (hipIpc on a shared device, xGMI peer access between the devices of a node).
+constexpr int FLOW_MAX_RANKS = 16;
+struct FlowPeers {
+    int n, rank;
+    double* Pc[FLOW_MAX_RANKS]; double* Linv[FLOW_MAX_RANKS]; double* y[FLOW_MAX_RANKS]; double* x[FLOW_MAX_RANKS];
+    unsigned* flags[FLOW_MAX_RANKS]; int* bflags[FLOW_MAX_RANKS];
+};
+constexpr unsigned FLOW_OWNER_SHIFT = 24;      // FlowWait.idx of a distributed task list: owner rank << 24 | counter index
+__device__ __forceinline__ const double* flow_pc(const FlowArgs& a, int p) { return a.peers ? a.peers->Pc[p % a.peers->n] : a.Pc; }
+__device__ __forceinline__ const double* flow_yv(const FlowArgs& a, int p) { return a.peers ? a.peers->y[p % a.peers->n] : a.y; }
 constexpr unsigned FLOW_CU_KEYS = 4096;      // XCC (4 bits) | SE (3) | SH (1) | CU (4)
 
 // The heavy roles are separate functions: inlined into one kernel body they share a register allocation and spill (508 bytes of
@@ -198,6 +221,7 @@ __device__ __forceinline__ FlowArgs flow_uniform_args(const FlowArgs& a)
     u.info = (int*)up(a.info); u.trace = (long long*)up(a.trace); u.ptrace_ofs = (unsigned)__builtin_amdgcn_readfirstlane((int)a.ptrace_ofs);
     u.ld = __builtin_amdgcn_readfirstlane(a.ld); u.n_total = __builtin_amdgcn_readfirstlane(a.n_total); u.T = __builtin_amdgcn_readfirstlane(a.T);
     u.stall_ticket = __builtin_amdgcn_readfirstlane(a.stall_ticket);
+    u.genbase = (unsigned)__builtin_amdgcn_readfirstlane((int)a.genbase); u.peers = (const FlowPeers*)up(a.peers);
     return u;
 }
 
@@ -220,8 +244,11 @@ __device__ __forceinline__ void flow_upd_impl(FlowKWords ka, const FlowArgs* a_i
     }
 #pragma unroll 1
     for (int p = p0; p < p0 + np; ++p)
-        flow_gemm_nt<MR, true, false>(a.Pc + flow_tri(i, p) * FLOW_TL + (size_t)r0 * POTRF_NB, POTRF_NB,
-                                      a.Pc + flow_tri(j, p) * FLOW_TL, POTRF_NB, POTRF_NB, lds, acc);
+    {
+        const double* Pp = flow_pc(a, p);       // (distributed: panel p's tiles live with the owner of column p)
+        flow_gemm_nt<MR, true, false>(Pp + flow_tri(i, p) * FLOW_TL + (size_t)r0 * POTRF_NB, POTRF_NB,
+                                      Pp + flow_tri(j, p) * FLOW_TL, POTRF_NB, POTRF_NB, lds, acc);
+    }
     int tid2 = threadIdx.x;
     asm volatile("" : "+v"(tid2));          // recompute the store address (keeping the load addresses alive costs registers)
     const int wave2 = tid2 >> 6, lane2 = tid2 & 63;
@@ -297,7 +324,7 @@ __device__ __forceinline__ void flow_tile32_impl(FlowKWords ka, const FlowArgs* 
                 for (int q = 0; q < 8; ++q) if (16 * q < K0) { const double2 t = *reinterpret_cast<const double2*>(B_ + 16 * q + c2); pv[q][0] = t.x; pv[q][1] = t.y; }
             }
         } else {
-            const double* base_ = a.Pc + flow_tri(i, p0 + sg) * FLOW_TL;
+            const double* base_ = flow_pc(a, p0 + sg) + flow_tri(i, p0 + sg) * FLOW_TL;
             const double* src = base_ + (size_t)(32 * (half ? bc : br) + row) * POTRF_NB;
 #pragma unroll
             for (int q = 0; q < 8; ++q) { const double2 t = *reinterpret_cast<const double2*>(src + 16 * q + c2); pv[q][0] = t.x; pv[q][1] = t.y; }
@@ -350,8 +377,8 @@ __device__ __forceinline__ void flow_fupd(const FlowArgs& a, int j, int p0, int 
     if (part == 0) e = ld_sc1(a.E + (size_t)j * POTRF_NB + row);
 #pragma unroll 1
     for (int p = p0; p < p0 + np; ++p) {
-        const double* Pr = a.Pc + flow_tri(j, p) * FLOW_TL + (size_t)row * POTRF_NB + 32 * part;
-        const double* yp = a.y + (size_t)p * POTRF_NB + 32 * part;
+        const double* Pr = flow_pc(a, p) + flow_tri(j, p) * FLOW_TL + (size_t)row * POTRF_NB + 32 * part;
+        const double* yp = flow_yv(a, p) + (size_t)p * POTRF_NB + 32 * part;
         double s = 0.0;
 #pragma unroll 8
         for (int c = 0; c < 32; ++c) s += Pr[c] * yp[c];
@@ -924,19 +951,31 @@ __global__ __launch_bounds__(512, WPS) void k_chol_flow(FlowArgs a_param)
             {
                 // up to three counters, polled TOGETHER (round 5): one after the other cost a load round trip each -- past the XCD's L2, ~1 us --
                 // even when all of them had long been satisfied, at the start of every task of the chain
-                unsigned idx[3], thr[3];
+                unsigned thr[3];
+                const unsigned* fp[3];
+                const unsigned gb = (unsigned)__builtin_amdgcn_readfirstlane((int)a.genbase);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const int qq = q < nwait ? q : 0;
-                    idx[q] = (unsigned)__builtin_amdgcn_readfirstlane((int)tp->w[qq].idx);
+                    const unsigned ix = (unsigned)__builtin_amdgcn_readfirstlane((int)tp->w[qq].idx);
                     thr[q] = q < nwait ? (unsigned)__builtin_amdgcn_readfirstlane((int)tp->w[qq].thr) : 0u;
+                    // (distributed: the counter lives with the owner of its tile column; the host put the owner's rank above bit 24)
+                    fp[q] = a.peers ? a.peers->flags[ix >> FLOW_OWNER_SHIFT] + (ix & ((1u << FLOW_OWNER_SHIFT) - 1u)) : flags + ix;
                 }
                 unsigned spins = 0;
                 while (nwait > 0) {
-                    const unsigned s0 = __hip_atomic_load(flags + idx[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned s1 = __hip_atomic_load(flags + idx[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned s2 = __hip_atomic_load(flags + idx[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const int ready = __builtin_amdgcn_readfirstlane((int)(s0 >= thr[0] && s1 >= thr[1] && s2 >= thr[2]));
+                    unsigned s0, s1, s2;
+                    if (a.peers) {      // a peer's counter may live on another device of the node: system scope
+                        s0 = __hip_atomic_load(fp[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        s1 = __hip_atomic_load(fp[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        s2 = __hip_atomic_load(fp[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    } else {
+                        s0 = __hip_atomic_load(fp[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s1 = __hip_atomic_load(fp[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s2 = __hip_atomic_load(fp[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    // counters count up from genbase (0 on one rank): a value of the previous solve's generation is below it (signed difference)
+                    const int ready = __builtin_amdgcn_readfirstlane((int)((int)(s0 - gb) >= (int)thr[0] && (int)(s1 - gb) >= (int)thr[1] && (int)(s2 - gb) >= (int)thr[2]));
                     if (ready) break;
                     __builtin_amdgcn_s_sleep(1);
                     if ((++spins & 63u) == 0u) {
@@ -981,13 +1020,31 @@ __global__ __launch_bounds__(512, WPS) void k_chol_flow(FlowArgs a_param)
 // Every workgroup of a launch must be resident (it waits for the tile columns to its right), so systems of more than POTRF_MAX_TILES
 // tile columns run it in WAVES of that many columns, rightmost first (`first` = columns already done): a later wave finds the flags
 // of the earlier ones set.
+// Distributed (peers != nullptr): column kk is done by its owner alone (Pc, Linv, y of a column are the owner's), which sends x_kk and the column's flag
+// to every rank; flagval = this solve's generation (the flags are never cleared between solves: a peer may write into them while this rank is still
+// on its way to the launch).
 __global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc, int nblk, int first, const double* __restrict__ Linv,
-        const double* __restrict__ y, double* x, int* flags, int* timeout, const int* __restrict__ last_row, long long spin_limit, int stall_col)
+        const double* __restrict__ y, double* x, int* flags, int* timeout, const int* __restrict__ last_row, long long spin_limit, int stall_col,
+        const FlowPeers* __restrict__ peers = nullptr, int flagval = 1)
 {
     __shared__ double yk[POTRF_NB];
     __shared__ double xi[POTRF_NB];
     __shared__ double red[POTRF_NB];
     const int kk = nblk - 1 - first - (int)blockIdx.x;
+    if (peers && kk % peers->n != peers->rank) {
+        // a peer's column: nothing to compute, but the launch must not end before x_kk has ARRIVED (k_flow_end copies the whole solution out)
+        if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            const long long t_begin = wall_clock64();
+            while (__hip_atomic_load(&flags[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != flagval) {
+                __builtin_amdgcn_s_sleep(8);
+                if ((++spins & 63u) == 0u && (wall_clock64() - t_begin > spin_limit || __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    atomicExch(timeout, 1); break;
+                }
+            }
+        }
+        return;
+    }
     const int c = threadIdx.x & 127, h = threadIdx.x >> 7;
     double lreg[64], tcur[64];
     {
@@ -1007,7 +1064,7 @@ __global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc,
         if (threadIdx.x == 0) {
             unsigned spins = 0;
             const long long t_begin = wall_clock64();
-            while (__hip_atomic_load(&flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1) {
+            while (__hip_atomic_load(&flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != flagval) {
                 __builtin_amdgcn_s_sleep(2);
                 if ((++spins & 63u) == 0u && (wall_clock64() - t_begin > spin_limit || __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                     atomicExch(timeout, 1); break;              // a bounded wait: the solve reports POTRF_INFO_TIMEOUT instead of hanging
@@ -1031,20 +1088,33 @@ __global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc,
     for (int r = 0; r < 64; ++r) sacc += lreg[r] * yk[64 * h + r];
     if (h == 1) red[c] = sacc;
     __syncthreads();
-    if (h == 0) __hip_atomic_store(&x[(size_t)kk * POTRF_NB + c], sacc + red[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (h == 0) {
+        const double v = sacc + red[c];
+        __hip_atomic_store(&x[(size_t)kk * POTRF_NB + c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (peers)
+            for (int r = 0; r < peers->n; ++r)
+                if (r != peers->rank) __hip_atomic_store(peers->x[r] + (size_t)kk * POTRF_NB + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0 && kk != stall_col) __hip_atomic_store(&flags[kk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (stall_col: test hook, -1 = none)
+    if (threadIdx.x == 0 && kk != stall_col) {      // (stall_col: test hook, -1 = none)
+        __hip_atomic_store(&flags[kk], flagval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (peers)
+            for (int r = 0; r < peers->n; ++r)
+                if (r != peers->rank) __hip_atomic_store(peers->bflags[r] + kk, flagval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // The small jobs around the two kernels, one launch each instead of three memsets and two copies (at 50 cameras a solve is 0.2 ms and
 // every stream operation costs 5-8 us of it).  Begin: counters / tickets / per-CU words and the backward flags to zero, the right-hand
 // side into its padded working copy.  End: a time-out of either kernel becomes the solve's info, the solution leaves the padded vector.
 __global__ __launch_bounds__(256) void k_flow_begin(unsigned* __restrict__ sync, unsigned sync_words, int* __restrict__ bflags, int nbflags,
-                                                    double* __restrict__ etmp, const double* __restrict__ E, int n, int ld)
+                                                    double* __restrict__ etmp, const double* __restrict__ E, int n, int ld,
+                                                    unsigned genbase = 0u, unsigned nflags = 0u /* distributed: the per-tile counters start at genbase;
+                                                                                                   the backward flags keep their generations (nbflags = the time-out word only) */)
 {
     const unsigned stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
-    for (unsigned q = t0; q < sync_words; q += stride) sync[q] = 0u;
+    for (unsigned q = t0; q < sync_words; q += stride) sync[q] = (q >= 8u && q < 8u + nflags) ? genbase : 0u;
     for (unsigned q = t0; q < (unsigned)nbflags; q += stride) bflags[q] = 0;
     for (unsigned q = t0; q < (unsigned)ld; q += stride) etmp[q] = q < (unsigned)n ? E[q] : 0.0;
 }
@@ -1076,12 +1146,41 @@ struct FlowWorkspace {
     double flops = 0.0;                    // flops of one factorisation as scheduled (UPD + TRSM tile products, 2 * 128^3 each)
     hipEvent_t k0 = nullptr, k1 = nullptr; // around the k_chol_flow launch: the roofline kernel's duration
     double kern_ms = 0.0; long long kern_cnt = 0; bool kern_pending = false;
+    struct FlowDist* dist = nullptr;       // distributed factorisation over a communicator's ranks (round 6, opt-in)
     void* dyn = nullptr;                   // DynWorkspace (chol_dyn.hip.h): the dynamic bulk of round 6
     int dynamic = -1;                      // 1 = dynamic bulk (BSFM_FLOW_SCHED=dynamic, opt-in), 0 = the static ticket order of rounds 4-6 (default)
 };
 
+// ---- distributed factorisation (round 6; VERDICT r5 "missing #1": the replicated Cholesky caps the multi-GPU curve at 1.2 x).  Tile column j belongs to
+// rank j mod n.  Every rank builds the SAME static order and keeps the tasks of its own columns (a subsequence: the earliest unfinished task of the whole
+// order is at the head of its owner's queue with all of its dependencies done, so the no-deadlock argument of chol_flow_sched.h carries over); waits name the
+// counter's owner; panel tiles, W, y, the solution and the counters are read through peer-mapped pointers (bsfm_comm_share).  Same tasks, same arithmetic:
+// the solution is bit-identical to the one-rank solve.  S and E are replicated (they come out of the all-reduce), each rank touches its own columns of them.
+struct FlowDist {
+    ::bsfm_comm* comm = nullptr;
+    int rank = 0, n = 1, nblk = 0, ld = 0;
+    std::vector<int> env_key;
+    double *pc = nullptr, *linv = nullptr, *y = nullptr, *xs = nullptr; unsigned* sync = nullptr; int* bflags = nullptr;
+    size_t sync_words = 0;
+    void* peer[6][FLOW_MAX_RANKS] = {};        // pc, linv, y, xs, sync, bflags as every rank sees them
+    FlowPeers* d_peers = nullptr;
+    FlowTask* d_tasks = nullptr; size_t n_bulk = 0, n_chain = 0, n_potrf = 0;
+    unsigned gen = 0;
+    bool shared = false;
+};
+inline void flow_dist_free(FlowDist& d)
+{
+    // COLLECTIVE like the allocation: a peer may still be writing the last pieces of the solution into this rank's buffers when this rank is done
+    if (d.shared && d.comm) { (void)hipDeviceSynchronize(); (void)bsfm_comm_barrier(d.comm); }
+    if (d.shared && d.comm) for (int q = 0; q < 6; ++q) (void)bsfm_comm_unshare(d.comm, d.peer[q]);
+    if (d.pc) (void)hipFree(d.pc); if (d.linv) (void)hipFree(d.linv); if (d.y) (void)hipFree(d.y); if (d.xs) (void)hipFree(d.xs);
+    if (d.sync) (void)hipFree(d.sync); if (d.bflags) (void)hipFree(d.bflags); if (d.d_peers) (void)hipFree(d.d_peers); if (d.d_tasks) (void)hipFree(d.d_tasks);
+    d = FlowDist();
+}
+
 inline void flow_free(FlowWorkspace& f)
 {
+    if (f.dist) { flow_dist_free(*f.dist); delete f.dist; f.dist = nullptr; }
     bsfm::dev_free(f.d_tasks, true); bsfm::dev_free(f.d_sync, true); bsfm::dev_free(f.pc, true);
     if (f.d_trace) (void)hipFree(f.d_trace);
     if (f.k0) (void)hipEventDestroy(f.k0);
@@ -1249,6 +1348,7 @@ inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, in
     hipLaunchKernelGGL(k_flow_begin, dim3((unsigned)std::min<size_t>(64, (std::max<size_t>(f.sync_words, (size_t)ld) + 255) / 256)), dim3(256), 0, st,
                        f.d_sync, (unsigned)f.sync_words, w.bflags, w.nblk + 1, w.etmp, E, n, ld);
     FlowArgs a;
+    memset(&a, 0, sizeof a);      // (genbase = 0, peers = nullptr: one rank)
     a.S = S; a.ld = ld; a.n_total = n; a.T = nblk; a.Pc = f.pc; a.Linv = w.linv; a.E = w.etmp; a.y = w.y;
     a.tasks = f.d_tasks; a.chain_tasks = f.d_tasks + f.bulk.size(); a.n_bulk = (unsigned)f.bulk.size(); a.n_chain = (unsigned)f.chain.size();
     a.potrf_tasks = f.d_tasks + f.bulk.size() + f.chain.size(); a.n_potrf = (unsigned)f.potrf.size();
@@ -1279,6 +1379,102 @@ inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, in
     hipLaunchKernelGGL(k_flow_end, dim3((unsigned)std::min(64, (n + 255) / 256)), dim3(256), 0, st, (const unsigned*)f.d_sync, (const int*)(w.bflags + w.nblk),
                        d_info, (const double*)w.xs, x_out, n);
     if (f.trace) flow_dump_trace(f, st);
+    return 0;
+}
+
+// (Re)builds this rank's part of the distributed launch.  COLLECTIVE when the shape changes (the buffers are shared again): every rank of the
+// communicator calls it with the same system, as the LM loop does.
+inline int flow_prepare_dist(FlowWorkspace& f, FlowDist& d, int nblk, int ld, const std::vector<int>& env_rows)
+{
+    std::vector<int> key;
+    if ((int)env_rows.size() >= nblk) { key.resize((size_t)nblk); for (int k = 0; k < nblk; ++k) key[k] = k + env_rows[k]; }
+    if (d.d_tasks && d.nblk == nblk && d.ld == ld && d.env_key == key) return 0;
+    ::bsfm_comm* comm = d.comm;
+    { FlowDist fresh; fresh.comm = comm; fresh.gen = d.gen; flow_dist_free(d); d = fresh; }
+    d.rank = bsfm_comm_rank(comm); d.n = bsfm_comm_world(comm);
+    if (d.n < 2 || d.n > FLOW_MAX_RANKS) return -1;
+    if (const char* e = getenv("BSFM_FLOW_WGS")) f.wgs = std::max(2, atoi(e));
+    f.spin_limit = FLOW_SPIN_LIMIT_TICKS; f.stall_ticket = -1; f.stall_bwd_col = -1;
+    if (const char* e = getenv("BSFM_FLOW_SPIN_MS")) f.spin_limit = std::max(1LL, (long long)atoll(e)) * 100000LL;
+    if (const char* e = getenv("BSFM_FLOW_TEST_STALL")) f.stall_ticket = atoi(e);
+    if (const char* e = getenv("BSFM_FLOW_TEST_STALL_RANK")) { if (atoi(e) != d.rank) f.stall_ticket = -1; }      // (the hook on one rank only)
+    if (flow_cached_schedule(nblk, key, flow_params_from_env(), f.sched) != 0) return -1;
+    f.chain_wgs = ((f.sched.upd_tiles + f.sched.trsm_tiles) < 400.0 * nblk ? 26 : 16) + 1;
+    if (const char* e = getenv("BSFM_FLOW_CHAIN_WGS")) f.chain_wgs = std::max(0, atoi(e));
+    f.chain_wgs = std::max(2, std::min(f.chain_wgs, f.wgs / 4));
+    { int lat_tiles = 38; if (const char* e = getenv("BSFM_FLOW_LATENCY_TILES")) lat_tiles = atoi(e); f.latency_build = nblk <= lat_tiles; }
+    f.nblk = nblk; f.env_key = key; d.nblk = nblk; d.ld = ld; d.env_key = key;
+    const int T = nblk, n = d.n;
+    auto owner_of_flag = [&](uint32_t idx) { return (int)(idx % (uint32_t)T) % n; };      // counter of tile (i, j) = i * T + j: the owner of column j
+    std::vector<FlowTask> bulk, chain, potrf;
+    for (const FlowTask& t0 : f.sched.tasks) {
+        if ((int)t0.j % n != d.rank) continue;
+        FlowTask t = t0;
+        for (int q = 0; q < t.nwait; ++q) t.w[q].idx |= (uint32_t)owner_of_flag(t.w[q].idx) << FLOW_OWNER_SHIFT;
+        (t.pad == 1 ? (t.type == FT_POTRF ? potrf : chain) : bulk).push_back(t);
+    }
+    d.n_bulk = bulk.size(); d.n_chain = chain.size(); d.n_potrf = potrf.size();
+    const size_t nt = bulk.size() + chain.size() + potrf.size();
+    if (hipMalloc((void**)&d.d_tasks, std::max<size_t>(1, nt) * sizeof(FlowTask)) != hipSuccess) return -1;
+    if (!bulk.empty() && hipMemcpy(d.d_tasks, bulk.data(), bulk.size() * sizeof(FlowTask), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (!chain.empty() && hipMemcpy(d.d_tasks + bulk.size(), chain.data(), chain.size() * sizeof(FlowTask), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (!potrf.empty() && hipMemcpy(d.d_tasks + bulk.size() + chain.size(), potrf.data(), potrf.size() * sizeof(FlowTask), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    // the shared buffers: plain hipMalloc allocations (hipIpc exports whole allocations), full size on every rank, valid for the rank's own columns
+    const size_t ntile = std::max<size_t>(1, (size_t)nblk * (size_t)(nblk - 1) / 2);
+    d.sync_words = 8 + (size_t)f.sched.nflags + 2 * (size_t)FLOW_CU_KEYS;
+    if (hipMalloc((void**)&d.pc, ntile * FLOW_TL * sizeof(double)) != hipSuccess) return -1;
+    if (hipMalloc((void**)&d.linv, (size_t)nblk * FLOW_TL * sizeof(double)) != hipSuccess || hipMemset(d.linv, 0, (size_t)nblk * FLOW_TL * sizeof(double)) != hipSuccess) return -1;
+    if (hipMalloc((void**)&d.y, (size_t)ld * sizeof(double)) != hipSuccess || hipMalloc((void**)&d.xs, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
+    if (hipMalloc((void**)&d.sync, d.sync_words * sizeof(unsigned)) != hipSuccess || hipMemset(d.sync, 0, d.sync_words * sizeof(unsigned)) != hipSuccess) return -1;
+    if (hipMalloc((void**)&d.bflags, (size_t)(nblk + 1) * sizeof(int)) != hipSuccess || hipMemset(d.bflags, 0, (size_t)(nblk + 1) * sizeof(int)) != hipSuccess) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    void* mine[6] = { d.pc, d.linv, d.y, d.xs, d.sync, d.bflags };
+    for (int q = 0; q < 6; ++q)
+        if (bsfm_comm_share(comm, mine[q], d.peer[q]) != 0) { fprintf(stderr, "[bsfm] distributed Cholesky: rank %d could not map its peers' buffers\n", d.rank); return -1; }
+    d.shared = true;
+    FlowPeers hp; memset(&hp, 0, sizeof hp);
+    hp.n = n; hp.rank = d.rank;
+    for (int r = 0; r < n; ++r) {
+        hp.Pc[r] = (double*)d.peer[0][r]; hp.Linv[r] = (double*)d.peer[1][r]; hp.y[r] = (double*)d.peer[2][r]; hp.x[r] = (double*)d.peer[3][r];
+        hp.flags[r] = (unsigned*)d.peer[4][r] + 8; hp.bflags[r] = (int*)d.peer[5][r];
+    }
+    if (hipMalloc((void**)&d.d_peers, sizeof(FlowPeers)) != hipSuccess || hipMemcpy(d.d_peers, &hp, sizeof hp, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    f.flops = (f.sched.upd_tiles + f.sched.trsm_tiles) * 2.0 * POTRF_NB * POTRF_NB * POTRF_NB / n;
+    if (!f.k0) { (void)hipEventCreate(&f.k0); (void)hipEventCreate(&f.k1); }
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_flow<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FLOW_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_flow<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FLOW_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    return 0;
+}
+
+// Solves S x = E with the ranks of d.comm: every rank calls it with the same (replicated) S and E and ends with the same x.  info: this rank's columns only
+// (0, dpotrf's k, POTRF_INFO_TIMEOUT): the caller combines the ranks' words (the smallest positive k; a time-out anywhere is a time-out).
+inline int flow_solve_dist(PotrfWorkspace& w, FlowWorkspace& f, FlowDist& d, double* S, int ld, int n, const double* E, double* x_out, int* d_info, hipStream_t st)
+{
+    const int nblk = (n + POTRF_NB - 1) / POTRF_NB;
+    if (flow_prepare_dist(f, d, nblk, ld, w.env_rows) != 0) return -1;
+    d.gen = (d.gen % 0x7ffeu) + 1u;                           // 1 .. 0x7fff: never 0 (the backward flags' "nothing yet")
+    const unsigned genbase = d.gen << 16;
+    hipLaunchKernelGGL(k_flow_begin, dim3((unsigned)std::min<size_t>(64, (std::max<size_t>(d.sync_words, (size_t)ld) + 255) / 256)), dim3(256), 0, st,
+                       d.sync, (unsigned)d.sync_words, d.bflags + nblk, 1, w.etmp, E, n, ld, genbase, (unsigned)f.sched.nflags);
+    FlowArgs a;
+    memset(&a, 0, sizeof a);
+    a.S = S; a.ld = ld; a.n_total = n; a.T = nblk; a.Pc = d.pc; a.Linv = d.linv; a.E = w.etmp; a.y = d.y;
+    a.tasks = d.d_tasks; a.chain_tasks = d.d_tasks + d.n_bulk; a.n_bulk = (unsigned)d.n_bulk; a.n_chain = (unsigned)d.n_chain;
+    a.potrf_tasks = d.d_tasks + d.n_bulk + d.n_chain; a.n_potrf = (unsigned)d.n_potrf;
+    a.n_chain_wgs = (unsigned)f.chain_wgs; a.sync = d.sync; a.nflags = (unsigned)f.sched.nflags; a.info = d_info;
+    a.trace = nullptr; a.ptrace_ofs = 0; a.spin_limit = f.spin_limit; a.stall_ticket = f.stall_ticket;
+    a.genbase = genbase; a.peers = d.d_peers;
+    const size_t lds_bytes = FLOW_LDS_DOUBLES * sizeof(double);
+    const size_t nt = d.n_bulk + d.n_chain + d.n_potrf;
+    if (f.latency_build) hipLaunchKernelGGL(k_chol_flow<2>, dim3((unsigned)std::min<size_t>((size_t)f.wgs / 2, nt + (size_t)f.chain_wgs)), dim3(512), lds_bytes, st, a);
+    else hipLaunchKernelGGL(k_chol_flow<4>, dim3((unsigned)std::min<size_t>((size_t)f.wgs, nt + 2 * (size_t)f.chain_wgs)), dim3(512), lds_bytes, st, a);
+    const bool env = (int)w.env_rows.size() >= nblk && w.d_last != nullptr;
+    for (int first = 0; first < nblk; first += POTRF_MAX_TILES)
+        hipLaunchKernelGGL(k_bwd_flow, dim3(std::min(POTRF_MAX_TILES, nblk - first)), dim3(256), 0, st, (const double*)d.pc, nblk, first,
+                           (const double*)d.linv, (const double*)d.y, d.xs, d.bflags, d.bflags + nblk, (const int*)(env ? w.d_last : nullptr),
+                           f.spin_limit, f.stall_bwd_col, (const FlowPeers*)d.d_peers, (int)d.gen);
+    hipLaunchKernelGGL(k_flow_end, dim3((unsigned)std::min(64, (n + 255) / 256)), dim3(256), 0, st, (const unsigned*)d.sync, (const int*)(d.bflags + nblk),
+                       d_info, (const double*)d.xs, x_out, n);
     return 0;
 }
 

@@ -81,6 +81,7 @@ struct Loopback {
     std::condition_variable cv;
     int arrived = 0; long generation = 0;
     std::vector<double*> bufs;          // this round's buffers, by rank
+    std::vector<void*> shared;          // bsfm_comm_share: this round's allocations, by rank
     std::vector<double*> scratch;       // per-rank result buffers
     std::vector<size_t> scratch_cap;
     int refs = 0;
@@ -122,6 +123,7 @@ struct IpcShared {
     std::atomic<int> arrived; std::atomic<long> generation; std::atomic<int> broken; std::atomic<int> published;
     unsigned long long capacity;                   // doubles per exchange buffer
     hipIpcMemHandle_t handles[IPC_MAX_WORLD];
+    hipIpcMemHandle_t board[IPC_MAX_WORLD];        // bsfm_comm_share: the handle of the allocation every rank is currently publishing
 };
 struct IpcPeer {
     IpcShared* sh = nullptr; size_t map_bytes = 0; std::string shm_path;
@@ -253,6 +255,47 @@ int bsfm_comm_allreduce_host(bsfm_comm_t* c, double* vals, int count, int op)
     if (bsfm_comm_allreduce(c, c->d_small, (size_t)count, op, nullptr) != 0) return BSFM_ERROR;
     if (hipStreamSynchronize(nullptr) != hipSuccess) return BSFM_ERROR;
     if (hipMemcpy(vals, c->d_small, (size_t)count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return BSFM_ERROR;
+    return 0;
+}
+
+// Collective: every rank passes one device allocation of its own (the BASE pointer of a hipMalloc) and receives, in peers[0 .. world), pointers
+// through which it can address every rank's allocation -- its own pointer at peers[rank].  ipc transport: hipIpc handles through the control block
+// (same device: shared memory; other devices of the node: peer access over xGMI); loopback transport (ranks = threads of one process): the pointers
+// themselves.  RCCL transport: not available (BSFM_ERROR) -- the distributed factorisation (chol_flow.hip.h) is offered on the other two.
+// bsfm_comm_unshare closes what share opened (every rank, before it frees its own allocation).
+int bsfm_comm_share(bsfm_comm_t* c, void* mine, void** peers)
+{
+    if (!c || !peers || !mine) return BSFM_ERROR;
+    if (c->world <= 1) { peers[0] = mine; return 0; }
+    const double tmo = comm_timeout_s();
+    if (c->ipc) {
+        IpcPeer* I = c->ipc;
+        if (hipIpcGetMemHandle(&I->sh->board[c->rank], mine) != hipSuccess) { fprintf(stderr, "[bsfm] comm: rank %d cannot export an allocation\n", c->rank); I->sh->broken.store(1); return BSFM_ERROR; }
+        if (!I->barrier(c->world, tmo)) return BSFM_ERROR;                     // every handle is on the board
+        int bad = 0;
+        for (int r = 0; r < c->world; ++r) {
+            if (r == c->rank) { peers[r] = mine; continue; }
+            if (hipIpcOpenMemHandle(&peers[r], I->sh->board[r], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { peers[r] = nullptr; bad = 1; }
+        }
+        if (bad) I->sh->broken.store(1);
+        if (!I->barrier(c->world, tmo) || bad) return BSFM_ERROR;              // every rank has opened every handle: the board may be reused
+        return 0;
+    }
+    if (c->loop) {
+        Loopback* L = c->loop;
+        { std::lock_guard<std::mutex> lk(L->mu); if ((int)L->shared.size() < c->world) L->shared.assign((size_t)c->world, nullptr); L->shared[c->rank] = mine; }
+        if (!L->barrier(tmo)) return BSFM_ERROR;
+        { std::lock_guard<std::mutex> lk(L->mu); for (int r = 0; r < c->world; ++r) peers[r] = L->shared[r]; }
+        if (!L->barrier(tmo)) return BSFM_ERROR;
+        return 0;
+    }
+    return BSFM_ERROR;
+}
+int bsfm_comm_unshare(bsfm_comm_t* c, void** peers)
+{
+    if (!c || !peers) return BSFM_ERROR;
+    if (c->ipc)
+        for (int r = 0; r < c->world; ++r) if (r != c->rank && peers[r]) { (void)hipIpcCloseMemHandle(peers[r]); peers[r] = nullptr; }
     return 0;
 }
 

@@ -2,7 +2,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <vector>
-#include "schur_rows.h"       // RowWG, RowPiece: plan of the row-wise Schur kernel (round 5)
 
 namespace bsfm {
 
@@ -32,19 +31,8 @@ struct DeviceIndex {
     SchurTask* tasks = nullptr;   // nslots, launch order
     int* blk_j = nullptr; int* blk_k = nullptr; int* blk_task0 = nullptr;     // nblk, nblk, nblk + 1
     int ntriples = 0, ntasks = 0, nblk = 0, nslots = 0;
-    // Round 5: the DENSE blocks (schur_rows.h) are accumulated by the row kernel k_schur_rows; the task kernel keeps the sparse ones.
-    // Both write partial sums into ONE slot space: task t -> slot t (as before), row piece -> slot ntasks + r; blk_range[b] = the
-    // slots k_schur_assemble adds for block b, in that order.  `tasks` stays the full launch list of rounds 3-4 (exported, pinned by
-    // tests/test_index.py); tasks_launch is what the task kernel is given: the same array when no block is dense, a copy with the
-    // dense blocks' tasks turned into padding (out = -1) when some are, nullptr when all are.
-    RowWG* row_wgs = nullptr; RowPiece* row_pieces = nullptr; int* blk_row0 = nullptr;      // blk_row0: nblk + 1 (row slots per block, without the offset)
-    int2* row_tri = nullptr;            // the row kernel's own triple array: (slab row of the j side | ROW_DEAD on padding, record of the k side),
-                                        // workgroup after workgroup, every piece padded to whole passes; row_ntri entries
-    long long row_ntri = 0; int row_tri_max = 0;
-    int2* blk_range = nullptr;          // nblk
-    SchurTask* tasks_launch = nullptr;  // see above (owned unless == tasks)
-    int n_row_wgs = 0, n_row_pieces = 0, n_row_slots = 0, row_L = 0, n_row_blocks = 0;
-    long long row_triples = 0;
+    int2* blk_range = nullptr;          // nblk: the slots (= tasks, in task order) k_schur_assemble adds for block b
+    SchurTask* tasks_launch = nullptr;  // what the task kernel is given (== tasks; a separate name since round 5's row kernel, removed in round 6)
     std::vector<int> h_blk_j, h_blk_k;      // host copies of the block list (component analysis / multi-GPU union)
     bool empty_rows = false;      // some point has no observation (k_schur_prep's fused point inversion needs every point to have one)
     double build_ms = 0.0;        // device time of the whole construction (HIP events)
@@ -57,9 +45,6 @@ struct DeviceIndex {
 enum { SCHUR_ORDER_CLUSTERED = 0, SCHUR_ORDER_BLOCK = 1, SCHUR_ORDER_POINT = 2 };
 int build_index_device(int n, int m, int mcon, int nvis, const int* d_rowptr, const int* d_colidx, bool want_schur,
                        int order_mode, DeviceIndex& out, hipStream_t st);
-// Row-kernel switches (BSFM_SCHUR_ROWS = 0 | 1 | auto, BSFM_SCHUR_ROW_L, BSFM_SCHUR_ROW_MIN, BSFM_SCHUR_ROW_WGMIN, BSFM_SCHUR_ROW_TRIMAX):
-// false = rows off for a problem of nvis observations, else prm holds the plan's parameters.
-bool schur_row_config(int nvis, RowPlanParams& prm);
 void free_index_device(DeviceIndex& ix);
 
 // Growing a resident problem: merges `nadd` new observations (point, camera, x, y -- device arrays, any order) into

@@ -186,58 +186,12 @@ __global__ void k_launch_order(int ntasks, int nwg, const SchurTask* __restrict_
     launch[slot] = tk;
 }
 
-// ---- row-wise Schur kernel (round 5; schur_rows.h has the plan, schur.hip.h the kernel) --------------------------------------------
-// stage B: one thread per candidate visit (dense block b, segment s of camera j): the triples of b whose j-side record is in s
-__global__ void k_row_visits(int nvisits, int nblk, int L, const int* __restrict__ visbase, const int* __restrict__ blk_start,
-                             const int* __restrict__ blk_j, const int* __restrict__ camptr, const int2* __restrict__ triples,
-                             int* __restrict__ vis_lo, int* __restrict__ vis_cnt)
-{
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= nvisits) return;
-    int lo = 0, hi = nblk;                           // block of visit v: last b with visbase[b] <= v (sparse blocks have empty ranges)
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (visbase[mid + 1] <= v) lo = mid + 1; else hi = mid; }
-    const int b = lo, s = v - visbase[b];
-    const int r0 = camptr[blk_j[b]] + s * L;
-    int first = 0, cnt = 0;
-    row_visit_range(blk_start[b], blk_start[b + 1], r0, r0 + L, [&](int t) { return triples[t].x; }, first, cnt);
-    vis_lo[v] = first; vis_cnt[v] = cnt;
-}
-
-// the row kernel's own triple array: one 64-thread block per piece copies its slice, j side as slab row, padded to whole passes
-__global__ __launch_bounds__(64) void k_row_fill(int nfill, const RowFill* __restrict__ fills, const int2* __restrict__ triples, int2* __restrict__ rtri)
-{
-    if ((int)blockIdx.x >= nfill) return;
-    const RowFill f = fills[blockIdx.x];
-    const int padded = (f.count + ROW_PASS - 1) / ROW_PASS * ROW_PASS;
-    for (int t = threadIdx.x; t < padded; t += 64) {
-        int2 e = triples[f.src + min(t, f.count - 1)];
-        e.x = (e.x - f.rec0) | (t < f.count ? 0 : ROW_DEAD);
-        rtri[(size_t)f.dst + t] = e;
-    }
-}
-
-// slots k_schur_assemble / k_schur_pack add for block b: the row pieces of a dense block, the tasks of a sparse one
-__global__ void k_blk_ranges(int nblk, int ntasks, const int* __restrict__ blk_task0, const int* __restrict__ blk_row0, int2* __restrict__ range)
+// slots k_schur_assemble / k_schur_pack add for block b: its tasks', in task order
+__global__ void k_blk_ranges(int nblk, const int* __restrict__ blk_task0, int2* __restrict__ range)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblk) return;
-    if (blk_row0 && blk_row0[b + 1] > blk_row0[b]) range[b] = make_int2(ntasks + blk_row0[b], ntasks + blk_row0[b + 1]);
-    else range[b] = make_int2(blk_task0[b], blk_task0[b + 1]);
-}
-
-// launch list of the task kernel when some blocks went to the row kernel: their tasks become padding
-__global__ void k_mask_tasks(int nslots, int nblk, const SchurTask* __restrict__ tasks, const int* __restrict__ blk_task0,
-                             const int* __restrict__ blk_row0, SchurTask* __restrict__ out)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nslots) return;
-    SchurTask tk = tasks[t];
-    if (tk.out >= 0) {
-        int lo = 0, hi = nblk;                       // block of slot tk.out: last b with blk_task0[b] <= out (every block has >= 1 task)
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (blk_task0[mid + 1] <= tk.out) lo = mid + 1; else hi = mid; }
-        if (blk_row0[lo + 1] > blk_row0[lo]) { tk.start = 0; tk.count = 0; tk.diag = 0; tk.out = -1; }
-    }
-    out[t] = tk;
+    range[b] = make_int2(blk_task0[b], blk_task0[b + 1]);
 }
 
 // Temporaries of one build come from the device's stream-ordered memory pool (hipMallocAsync): the pool keeps what it is given
@@ -439,55 +393,11 @@ int build_schur(int n, int m, int mcon, int nvis, const int* d_rowptr, const int
         hipLaunchKernelGGL(k_launch_order, dim3(grid_for((size_t)ix.nslots, 256)), dim3(256), 0, st, ntasks, nwg, tasks, ord, ix.tasks);
     }
     IX_OK(hipStreamSynchronize(st));
-    // ---- round 5: plan of the row kernel for the dense blocks (schur_rows.h), slot ranges per block, launch list of the task kernel
+    // slot ranges per block; the task kernel is given the whole launch list (round 5's row kernel for dense blocks -- measured slower on both
+    // scenes, profiles/r05_schur_kernels.txt -- was removed in round 6)
     ix.tasks_launch = ix.tasks;
-    RowPlanParams prm;
-    if (schur_row_config(nvis, prm) && nblk > 0) {
-        const int L = prm.L;
-        std::vector<int> h_counts((size_t)nblk), h_camptr((size_t)m + 1);
-        IX_OK(hipMemcpyAsync(h_counts.data(), counts, (size_t)nblk * sizeof(int), hipMemcpyDeviceToHost, st));
-        IX_OK(hipMemcpyAsync(h_camptr.data(), ix.camptr, ((size_t)m + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
-        IX_OK(hipStreamSynchronize(st));
-        RowPlanA pa;
-        row_plan_stage_a(m, mcon, ix.h_blk_j, h_counts, h_camptr, prm, pa);
-        if (pa.nvisits > 0) {
-            int *d_visbase = nullptr, *d_lo = nullptr, *d_cnt = nullptr;
-            IX_OK(tmp.alloc(&d_visbase, (size_t)nblk + 1)); IX_OK(tmp.alloc(&d_lo, (size_t)pa.nvisits)); IX_OK(tmp.alloc(&d_cnt, (size_t)pa.nvisits));
-            IX_OK(hipMemcpyAsync(d_visbase, pa.visbase.data(), ((size_t)nblk + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_row_visits, dim3(grid_for((size_t)pa.nvisits, 256)), dim3(256), 0, st, pa.nvisits, nblk, L, d_visbase, blk_start,
-                               ix.blk_j, ix.camptr, ix.triples, d_lo, d_cnt);
-            std::vector<int> h_lo((size_t)pa.nvisits), h_cnt((size_t)pa.nvisits);
-            IX_OK(hipMemcpyAsync(h_lo.data(), d_lo, (size_t)pa.nvisits * sizeof(int), hipMemcpyDeviceToHost, st));
-            IX_OK(hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)pa.nvisits * sizeof(int), hipMemcpyDeviceToHost, st));
-            IX_OK(hipStreamSynchronize(st));
-            if (rank.empty()) bfs_rank(mm, mcon, ix.h_blk_j, ix.h_blk_k, rank);
-            RowPlan plan;
-            if (row_plan_stage_c(m, mcon, ix.h_blk_j, ix.h_blk_k, h_camptr, prm, pa, h_lo, h_cnt, rank, ntasks, plan) == 0 && !plan.wgs.empty()) {
-                ix.n_row_wgs = (int)plan.wgs.size(); ix.n_row_pieces = (int)plan.pieces.size(); ix.n_row_slots = plan.nslots;
-                ix.row_L = L; ix.n_row_blocks = pa.ndense; ix.row_triples = plan.triples; ix.row_ntri = plan.ntri; ix.row_tri_max = row_tri_max(prm);
-                IX_OK(keep(&ix.row_wgs, plan.wgs.size())); IX_OK(keep(&ix.row_pieces, plan.pieces.size())); IX_OK(keep(&ix.blk_row0, (size_t)nblk + 1));
-                IX_OK(keep(&ix.row_tri, (size_t)plan.ntri));
-                RowFill* d_fills = nullptr;
-                IX_OK(tmp.alloc(&d_fills, plan.fills.size()));
-                IX_OK(hipMemcpyAsync(ix.row_wgs, plan.wgs.data(), plan.wgs.size() * sizeof(RowWG), hipMemcpyHostToDevice, st));
-                IX_OK(hipMemcpyAsync(ix.row_pieces, plan.pieces.data(), plan.pieces.size() * sizeof(RowPiece), hipMemcpyHostToDevice, st));
-                IX_OK(hipMemcpyAsync(ix.blk_row0, plan.blk_row0.data(), ((size_t)nblk + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-                IX_OK(hipMemcpyAsync(d_fills, plan.fills.data(), plan.fills.size() * sizeof(RowFill), hipMemcpyHostToDevice, st));
-                hipLaunchKernelGGL(k_row_fill, dim3((unsigned)plan.fills.size()), dim3(64), 0, st, (int)plan.fills.size(), d_fills, ix.triples, ix.row_tri);
-                if (plan.triples == total) ix.tasks_launch = nullptr;            // every block is dense: the task kernel has nothing to do
-                else {
-                    SchurTask* masked = nullptr;
-                    IX_OK(keep(&masked, (size_t)ix.nslots));
-                    ix.tasks_launch = masked;
-                    hipLaunchKernelGGL(k_mask_tasks, dim3(grid_for((size_t)ix.nslots, 256)), dim3(256), 0, st, ix.nslots, nblk, ix.tasks, ix.blk_task0,
-                                       ix.blk_row0, masked);
-                }
-                IX_OK(hipStreamSynchronize(st));          // the plan's host vectors were sources of asynchronous copies
-            }
-        }
-    }
     IX_OK(keep(&ix.blk_range, (size_t)nblk));
-    hipLaunchKernelGGL(k_blk_ranges, dim3(grid_for((size_t)nblk, 256)), dim3(256), 0, st, nblk, ntasks, ix.blk_task0, ix.blk_row0, ix.blk_range);
+    hipLaunchKernelGGL(k_blk_ranges, dim3(grid_for((size_t)nblk, 256)), dim3(256), 0, st, nblk, ix.blk_task0, ix.blk_range);
     IX_OK(hipStreamSynchronize(st));          // temporaries are freed when `tmp` goes out of scope
     return 0;
 }
@@ -662,8 +572,7 @@ int gather_kept_device(int n, const int* d_remap, int width_bytes, const void* s
 void free_index_device(DeviceIndex& ix)
 {
     void* ptrs[] = { ix.obs_pt, ix.camptr, ix.camobs, ix.campos, ix.cam_pt, ix.cam_cam, ix.triples, ix.tri_pt, ix.tasks,
-                     ix.blk_j, ix.blk_k, ix.blk_task0, ix.row_wgs, ix.row_pieces, ix.blk_row0, ix.blk_range, ix.row_tri,
-                     ix.tasks_launch != ix.tasks ? (void*)ix.tasks_launch : nullptr };
+                     ix.blk_j, ix.blk_k, ix.blk_task0, ix.blk_range };
     (void)hipDeviceSynchronize();
     for (void* p : ptrs) bsfm::dev_free(p, true);
     ix = DeviceIndex();
@@ -736,28 +645,6 @@ int build_index_device(int n, int m, int mcon, int nvis, const int* d_rowptr, co
         if (e0 && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ix.build_ms = ms;
     } else IX_OK(hipStreamSynchronize(st));
     return 0;
-}
-
-bool schur_row_config(int nvis, RowPlanParams& prm)
-{
-    // read at every problem_create (not cached: the tests switch the row kernel on and off inside one process)
-    const char* e = getenv("BSFM_SCHUR_ROWS");
-    const char* const e0 = e;
-    const int mode = !e ? 2 : (!strcmp(e, "0") ? 0 : (!strcmp(e, "1") ? 1 : 2));
-    prm = RowPlanParams();
-    if ((e = getenv("BSFM_SCHUR_ROW_L"))) prm.L = atoi(e);
-    prm.L = std::min(ROW_LMAX, (std::max(16, std::min(ROW_LMAX, prm.L)) + 15) / 16 * 16);
-    if ((e = getenv("BSFM_SCHUR_ROW_MIN"))) prm.dense_min = std::max(1, atoi(e));
-    if ((e = getenv("BSFM_SCHUR_ROW_WGMIN"))) prm.wg_min = std::max(1, atoi(e));
-    if ((e = getenv("BSFM_SCHUR_ROW_TRIMAX"))) prm.tri_max = std::max(ROW_LMAX, std::min(4096, atoi(e))) / ROW_PASS * ROW_PASS;
-    // OFF unless asked for (BSFM_SCHUR_ROWS=1, or =auto: on once the Jacobian records no longer fit one XCD's L2).  Measured in round 5
-    // at 1 000 cameras / 5 M observations (profiles/r05_schur_kernels.txt): 0.95-1.05 ms for the row kernel against 0.85 ms for the
-    // task kernel -- the gathers it saves were never the bound (served from L1 AND without matrix instructions the pass loop still
-    // takes 0.63 ms: both kernels sit on a chain of LDS round trips and on VALU work that FP64 matrix instructions do not overlap
-    // with on gfx950), and its segment fill adds 0.2 ms.  Kept as a tested alternative, not as the default.
-    if (mode == 0 || !e0) return false;
-    if (mode == 2 && (size_t)nvis * 272u <= (size_t)(4u << 20)) return false;
-    return true;
 }
 
 int schur_chunk()

@@ -660,7 +660,7 @@ __global__ __launch_bounds__(128) void k_schur_assemble(int nblk, const int* __r
     }
     const int j = blk_j[b], k = blk_k[b];
     const int pj = spos ? spos[j - mcon] : j - mcon, pk = spos ? spos[k - mcon] : k - mcon;
-    const int2 sl = blk_range[b];               // the block's slots: tasks of k_schur_tasks or pieces of k_schur_rows (index_build.hip)
+    const int2 sl = blk_range[b];               // the block's slots: its tasks of k_schur_tasks, in task order (index_build.hip)
     if (j == k && threadIdx.x >= CNP * CNP && threadIdx.x < CNP * CNP + CNP) {   // e_j -= this block's tasks (E was set to ea by k_rhs_init)
         const int q = threadIdx.x - CNP * CNP;
         double se = 0.0;

@@ -40,6 +40,8 @@
 #include <mutex>
 #include "devcache.h"
 
+struct bsfm_comm;      // include/bsfm.h: one rank's communicator (comm.hip)
+
 namespace bsfm {
 
 // Process-wide pool of plain non-blocking streams.  An incremental reconstruction calls run_sfm hundreds of times on small
@@ -101,6 +103,7 @@ inline int flow_solve_one(PotrfWorkspace& w, double* S, int ld, int n, const dou
 
 struct PotrfWorkspace {
     FlowWorkspace* flow = nullptr;
+    ::bsfm_comm* dist_comm = nullptr;      // != nullptr: systems of two or more tiles are factored by this communicator's ranks together (chol_flow.hip.h: FlowDist)
     bool solve_one_attr = false;   // k_flow_solve_one's dynamic-LDS attribute has been set on this workspace's device
     int use_flow = 1;           // BSFM_CHOL=streams selects the three-stream schedule of rounds 1-3 below (kept as the A/B reference)
     int ld = 0, nblk = 0, backend = 0;

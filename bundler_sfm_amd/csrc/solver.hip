@@ -57,9 +57,9 @@ namespace {
 constexpr double SBA_EPSILON_SQ = 1E-12 * 1E-12;   // lib/sba-1.5/sba_levmar.c:35-36
 constexpr double SBA_ONE_THIRD = 0.3333333334;     // lib/sba-1.5/sba_levmar.c:38
 
-enum Phase { PH_JAC = 0, PH_CAMBLK, PH_PTBLK, PH_INVERT, PH_SCHUR, PH_SOLVE, PH_BACKSUB, PH_RESID, PH_SCHUR_PREP, PH_SCHUR_ROWS, PH_SCHUR_TASKS, PH_COUNT };
+enum Phase { PH_JAC = 0, PH_CAMBLK, PH_PTBLK, PH_INVERT, PH_SCHUR, PH_SOLVE, PH_BACKSUB, PH_RESID, PH_SCHUR_PREP, PH_SCHUR_TASKS, PH_COUNT };
 const char* kPhaseNames[PH_COUNT] = { "jacobian", "cam_blocks", "point_blocks", "point_invert", "schur",
-                                      "solve", "backsub", "residual", "schur_prep", "schur_rows", "schur_tasks" };
+                                      "solve", "backsub", "residual", "schur_prep", "schur_tasks" };
 
 // scalar block layout (device doubles)
 enum Scal { SC_COST = 0, SC_COST_TRIAL, SC_PCT, SC_CAM3 /*3*/, SC_PT_DP = 6, SC_PT_P, SC_PT_DL,
@@ -240,12 +240,9 @@ struct bsfm_problem {
     int2* d_triples = nullptr; SchurTask* d_tasks = nullptr; int* d_tri_pt = nullptr;
     int nslots = 0;                     // entries of d_tasks (launch order, padded to whole workgroups)
     int *d_blk_j = nullptr, *d_blk_k = nullptr, *d_blk_task0 = nullptr;
-    // round 5: dense blocks go through the row kernel (schur_rows.h / k_schur_rows); d_tasks_launch is the task kernel's list
-    // (== d_tasks when no block is dense, a masked copy when some are, nullptr when all are); d_blk_range = slots per block
-    RowWG* d_row_wgs = nullptr; RowPiece* d_row_pieces = nullptr; int* d_blk_row0 = nullptr; int2* d_blk_range = nullptr;
-    int2* d_row_tri = nullptr; long long row_ntri = 0; int row_tri_max = 0;
+    // d_blk_range = partial-sum slots per block (its tasks', in task order); d_tasks_launch = the task kernel's launch list (== d_tasks)
+    int2* d_blk_range = nullptr;
     SchurTask* d_tasks_launch = nullptr;
-    int n_row_wgs = 0, n_row_pieces = 0, n_row_slots = 0, row_L = 0, n_row_blocks = 0; long long row_triples = 0;
     // multi-GPU exchange of the reduced camera system: the UNION over ranks of the non-empty blocks S_jk (j <= k),
     // one cnp x cnp sum per block, is what crosses xGMI -- not the dense (9m)^2 matrix
     std::vector<int> h_blk_j, h_blk_k;
@@ -290,7 +287,7 @@ void free_all(bsfm_problem* pb)
                      pb->d_dp, pb->d_camtab, pb->d_camtab_trial, pb->d_e, pb->d_hx, pb->d_ptc[0], pb->d_ptc[1], pb->d_U,
                      pb->d_V, pb->d_Vinv, pb->d_eb, pb->d_S, pb->d_E, pb->d_partials, pb->d_epart, pb->d_campart, pb->d_red, pb->d_scal, pb->d_mixed, pb->d_tickets,
                      pb->d_triples, pb->d_tri_pt, pb->d_tasks, pb->d_blk_j, pb->d_blk_k, pb->d_blk_task0,
-                     pb->d_row_wgs, pb->d_row_pieces, pb->d_blk_row0, pb->d_blk_range, pb->d_row_tri, pb->d_tasks_launch != pb->d_tasks ? (void*)pb->d_tasks_launch : nullptr,
+                     pb->d_blk_range,
                      pb->d_gidx, pb->d_gblk_j, pb->d_gblk_k, pb->d_G, pb->d_spos, pb->d_xperm };
     for (void* p : ptrs) bsfm::dev_free(p, true);          // bsfm_problem_destroy has synchronised the device
     if (pb->h_scal) (void)hipHostFree(pb->h_scal);
@@ -312,11 +309,8 @@ int adopt_index(bsfm_problem* pb, DeviceIndex& ix)
     pb->d_triples = ix.triples; pb->d_tri_pt = ix.tri_pt; pb->d_tasks = ix.tasks;
     pb->d_blk_j = ix.blk_j; pb->d_blk_k = ix.blk_k; pb->d_blk_task0 = ix.blk_task0;
     pb->ntriples = ix.ntriples; pb->ntasks = ix.ntasks; pb->nblk = ix.nblk; pb->nslots = ix.nslots;
-    pb->d_row_wgs = ix.row_wgs; pb->d_row_pieces = ix.row_pieces; pb->d_blk_row0 = ix.blk_row0; pb->d_blk_range = ix.blk_range;
+    pb->d_blk_range = ix.blk_range;
     pb->d_tasks_launch = ix.tasks_launch;
-    pb->d_row_tri = ix.row_tri; pb->row_ntri = ix.row_ntri; pb->row_tri_max = ix.row_tri_max;
-    pb->n_row_wgs = ix.n_row_wgs; pb->n_row_pieces = ix.n_row_pieces; pb->n_row_slots = ix.n_row_slots; pb->row_L = ix.row_L;
-    pb->n_row_blocks = ix.n_row_blocks; pb->row_triples = ix.row_triples;
     pb->h_blk_j.swap(ix.h_blk_j); pb->h_blk_k.swap(ix.h_blk_k);
     pb->index_build_ms = ix.build_ms;
     pb->empty_rows = ix.empty_rows;
@@ -324,11 +318,8 @@ int adopt_index(bsfm_problem* pb, DeviceIndex& ix)
     ix = DeviceIndex();                                  // ownership moved: free_all releases the arrays
     if (pb->mot) return 0;
     if (pb->world == 1 && setup_components(pb, pb->h_blk_j, pb->h_blk_k)) return BSFM_ERROR;   // world > 1: after the block-union exchange
-    HIP_OK(dmalloc(&pb->d_partials, ((size_t)pb->ntasks + pb->n_row_slots) * pb->cnp * pb->cnp));      // task slots, then row-piece slots
-    HIP_OK(dmalloc(&pb->d_epart, ((size_t)pb->ntasks + pb->n_row_slots) * pb->cnp));
-    if (pb->opt.verbose >= 2 && pb->n_row_wgs > 0)
-        printf("[bsfm] Schur complement: %d of %d blocks (%lld of %d triples) through the row kernel: %d workgroups, %d pieces, segments of %d records\n",
-               pb->n_row_blocks, pb->nblk, pb->row_triples, pb->ntriples, pb->n_row_wgs, pb->n_row_pieces, pb->row_L);
+    HIP_OK(dmalloc(&pb->d_partials, (size_t)pb->ntasks * pb->cnp * pb->cnp));      // one slot per task
+    HIP_OK(dmalloc(&pb->d_epart, (size_t)pb->ntasks * pb->cnp));
     return 0;
 }
 
@@ -746,16 +737,8 @@ int compute_schur(bsfm_problem* pb, double mu)
                                (const double*)nullptr, 0.0, (const int*)nullptr, (double*)nullptr, (int*)nullptr, zt);
         ph_end(pb, PH_SCHUR_PREP);
         static const int wps = [] { const char* e = getenv("BSFM_SCHUR_WPS"); const int v = e ? atoi(e) : 3; return v < 2 ? 2 : (v > 4 ? 4 : v); }();
-        ph_begin(pb, PH_SCHUR_ROWS);
-        if (pb->n_row_wgs > 0) {      // dense blocks: the j side from an LDS slab, one workgroup per (camera, segment of its records)
-            const int slab_chunks = pb->row_L * (cnp + 4);                      // then the workgroup's triple entries (8 bytes each)
-            const size_t dyn = (size_t)slab_chunks * 16 + (size_t)pb->row_tri_max * sizeof(int2);
-            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_schur_rows<C>), dim3(pb->n_row_wgs), dim3(256), dyn, pb->stream, P, pb->d_row_wgs,
-                                                  pb->d_row_pieces, pb->d_row_tri, pb->d_partials, pb->d_epart, slab_chunks));
-        }
-        ph_end(pb, PH_SCHUR_ROWS);
         ph_begin(pb, PH_SCHUR_TASKS);
-        if (pb->d_tasks_launch) {     // sparse blocks (all blocks when the row kernel is off): one wave per task, both sides gathered
+        if (pb->d_tasks_launch) {     // one wave per task, both sides gathered
             const SchurTask* tl = pb->d_tasks_launch;
             const dim3 sg((pb->nslots + 3) / 4);
             // block sums on v_mfma_f64_4x4x4_4b (round 5: 0.847 against 0.875 ms at the headline size, three workgroups per CU);
@@ -998,7 +981,7 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     pb->ev_ok = nvis >= 2000000;      // (round 6: was 100 000 -- exactly the 50-camera problem of the latency table, whose iteration the event records made a third longer)
     if (const char* e = getenv("BSFM_PHASE_TIMING")) pb->ev_ok = atoi(e) != 0;
     // measured (profiles/r03_small_problem_latency_speculate.txt, profiles/r06_small_problem_latency.txt): 10 % of an iteration at 14 cameras
-    pb->speculate = pb->nvis_global <= 1200000;      // (round 6: 3 - 5 % at 50 / 100 cameras once the event records were gone, 1 % at 400; was <= 30 000)
+    pb->speculate = true;      // (round 6: every size -- 3 - 5 % at 50 / 100 cameras once the event records were gone, 1 % at 400; one host round trip per iteration at 1 000; was <= 30 000 observations)
     pb->fuse_invert = !pb->empty_rows;
     if (const char* e = getenv("BSFM_FUSE_INVERT")) pb->fuse_invert = atoi(e) != 0 && !pb->empty_rows;
     if (const char* e = getenv("BSFM_SPECULATE")) pb->speculate = atoi(e) != 0;
@@ -1022,7 +1005,15 @@ void bsfm_problem_destroy(bsfm_problem_t* pb)
 }
 
 void bsfm_problem_set_allreduce(bsfm_problem_t* pb, bsfm_allreduce_fn fn, void* ctx) { pb->allreduce = fn; pb->allreduce_ctx = ctx; }
-void bsfm_problem_set_comm(bsfm_problem_t* pb, bsfm_comm_t* comm) { pb->comm = comm; }
+void bsfm_problem_set_comm(bsfm_problem_t* pb, bsfm_comm_t* comm)
+{
+    pb->comm = comm;
+    // BSFM_DIST_CHOL=1: the ranks factor the (replicated) reduced camera system TOGETHER instead of each factoring all of it (chol_flow.hip.h: FlowDist).
+    // Opt-in: it needs a transport that can map the peers' buffers ("ipc", "loopback"), and it has only run between processes sharing one device.
+    pb->potrf.dist_comm = nullptr;
+    if (const char* e = getenv("BSFM_DIST_CHOL"))
+        if (atoi(e) != 0 && comm && bsfm_comm_world(comm) > 1 && strcmp(bsfm_comm_transport(comm), "rccl") != 0) pb->potrf.dist_comm = comm;
+}
 
 void bsfm_problem_set_stream(bsfm_problem_t* pb, void* s)
 {
@@ -1184,67 +1175,6 @@ int bsfm_problem_export_schur(bsfm_problem_t* pb, int* triples, int* tri_pt, int
     return ok ? 0 : BSFM_ERROR;
 }
 
-// round 5: the plan of the row kernel as the problem holds it (tests/test_index.py compares it with the host restatement)
-int bsfm_problem_row_sizes(const bsfm_problem_t* pb, int* nwg, int* npieces, int* nslots, int* L, int* ntri)
-{
-    if (nwg) *nwg = pb->n_row_wgs;
-    if (npieces) *npieces = pb->n_row_pieces;
-    if (nslots) *nslots = pb->n_row_slots;
-    if (L) *L = pb->row_L;
-    if (ntri) *ntri = (int)pb->row_ntri;
-    return 0;
-}
-
-// wgs: 16 ints per workgroup (RowWG); pieces: 4 ints (RowPiece); row_tri: 2 ints per entry of the kernel's own triple array; blk_row0: nblk + 1 (zeros when the row kernel is off); blk_range: 2 ints
-// per block; tasks_launch: 4 ints per task slot (what k_schur_tasks is given; out = -1 everywhere when it is not launched at all)
-int bsfm_problem_export_rows(bsfm_problem_t* pb, int* wgs, int* pieces, int* blk_row0, int* blk_range, int* tasks_launch, int* row_tri)
-{
-    if (pb->mot) return BSFM_ERROR;
-    HIP_OK(hipStreamSynchronize(pb->stream));
-    auto down = [](void* dst, const void* src, size_t bytes) { return !dst || bytes == 0 || !src || hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess; };
-    if (blk_row0 && !pb->d_blk_row0) memset(blk_row0, 0, ((size_t)pb->nblk + 1) * sizeof(int));
-    if (tasks_launch && !pb->d_tasks_launch) for (int t = 0; t < pb->nslots; ++t) { tasks_launch[4 * t] = 0; tasks_launch[4 * t + 1] = 0; tasks_launch[4 * t + 2] = 0; tasks_launch[4 * t + 3] = -1; }
-    const bool ok = down(wgs, pb->d_row_wgs, (size_t)pb->n_row_wgs * sizeof(RowWG)) && down(pieces, pb->d_row_pieces, (size_t)pb->n_row_pieces * sizeof(RowPiece)) &&
-                    down(blk_row0, pb->d_blk_row0, ((size_t)pb->nblk + 1) * sizeof(int)) && down(blk_range, pb->d_blk_range, (size_t)pb->nblk * sizeof(int2)) &&
-                    down(tasks_launch, pb->d_tasks_launch, (size_t)pb->nslots * sizeof(SchurTask)) &&
-                    down(row_tri, pb->d_row_tri, (size_t)pb->row_ntri * sizeof(int2));
-    return ok ? 0 : BSFM_ERROR;
-}
-
-// Host only (no device needed): the plan of the row kernel (schur_rows.h) for a block list -- stage B replayed with the same search
-// routine the device kernel uses.  tri_x: j-side record of every triple, block after block (blk_start: nblk + 1); rank: breadth-first
-// numbers of the free cameras or null.  Call with null outputs for the sizes; returns 0 or -1 (capacity too small).
-int bsfm_schur_row_plan(int m, int mcon, int nblk, const int* blk_j, const int* blk_k, const int* blk_start, const int* tri_x, const int* camptr,
-                        const int* rank, int L, int dense_min, int wg_min, int tri_max, int slot_base, int* nwg, int* npieces, int* nslots, int* ntri,
-                        int* wgs_out, int cap_wgs, int* pieces_out, int* fills_out, int cap_pieces, int* blk_row0_out)
-{
-    if (m <= 0 || nblk < 0 || L < 16 || L > ROW_LMAX || (L & 15)) return -1;
-    RowPlanParams prm; prm.L = L; prm.dense_min = std::max(1, dense_min); prm.wg_min = wg_min; prm.tri_max = tri_max;
-    std::vector<int> bj(blk_j, blk_j + nblk), bk(blk_k, blk_k + nblk), cp(camptr, camptr + m + 1), counts((size_t)nblk);
-    for (int b = 0; b < nblk; ++b) counts[b] = blk_start[b + 1] - blk_start[b];
-    RowPlanA pa;
-    row_plan_stage_a(m, mcon, bj, counts, cp, prm, pa);
-    std::vector<int> lo((size_t)pa.nvisits), cnt((size_t)pa.nvisits);
-    for (int b = 0; b < nblk; ++b)
-        for (int v = pa.visbase[b]; v < pa.visbase[b + 1]; ++v) {
-            const int r0 = cp[bj[b]] + (v - pa.visbase[b]) * L;
-            row_visit_range(blk_start[b], blk_start[b + 1], r0, r0 + L, [&](int t) { return tri_x[t]; }, lo[v], cnt[v]);
-        }
-    std::vector<int> rk;
-    if (rank) rk.assign(rank, rank + (m - mcon));
-    RowPlan plan;
-    if (row_plan_stage_c(m, mcon, bj, bk, cp, prm, pa, lo, cnt, rk, slot_base, plan) != 0) return -1;
-    if (nwg) *nwg = (int)plan.wgs.size();
-    if (npieces) *npieces = (int)plan.pieces.size();
-    if (nslots) *nslots = plan.nslots;
-    if (ntri) *ntri = (int)plan.ntri;
-    if (wgs_out) { if ((int)plan.wgs.size() > cap_wgs) return -1; memcpy(wgs_out, plan.wgs.data(), plan.wgs.size() * sizeof(RowWG)); }
-    if (pieces_out) { if ((int)plan.pieces.size() > cap_pieces) return -1; memcpy(pieces_out, plan.pieces.data(), plan.pieces.size() * sizeof(RowPiece)); }
-    if (fills_out) { if ((int)plan.fills.size() > cap_pieces) return -1; memcpy(fills_out, plan.fills.data(), plan.fills.size() * sizeof(RowFill)); }
-    if (blk_row0_out) memcpy(blk_row0_out, plan.blk_row0.data(), ((size_t)nblk + 1) * sizeof(int));
-    return 0;
-}
-
 int bsfm_schur_chunk(void) { return schur_chunk(); }
 int bsfm_problem_cnp(const bsfm_problem_t* pb) { return pb->cnp; }
 int bsfm_problem_num_cameras(const bsfm_problem_t* pb) { return pb->P.m; }
@@ -1256,13 +1186,7 @@ double bsfm_lm_last_kernel_ms(const bsfm_problem_t* pb, const char* phase)
 {
     for (int i = 0; i < PH_COUNT; ++i)
         if (!strcmp(phase, kPhaseNames[i])) return pb->ph_cnt[i] ? pb->ph_ms[i] / pb->ph_cnt[i] : -1.0;
-    // row kernel of the Schur complement (schur_rows.h): workgroups, pieces, dense blocks, triples it covers, segment length
     if (!strcmp(phase, "flow_fallbacks")) return (double)pb->flow_fallbacks;
-    if (!strcmp(phase, "row_wgs")) return (double)pb->n_row_wgs;
-    if (!strcmp(phase, "row_pieces")) return (double)pb->n_row_pieces;
-    if (!strcmp(phase, "row_blocks")) return (double)pb->n_row_blocks;
-    if (!strcmp(phase, "row_triples")) return (double)pb->row_triples;
-    if (!strcmp(phase, "row_L")) return (double)pb->row_L;
     if (!strcmp(phase, "groups")) return pb->comps.active ? (double)pb->comps.ncomp : 0.0;   // group-by-group reduced solve in use?
     if (!strcmp(phase, "potrf")) return pb->potrf.cnt ? pb->potrf.ms / pb->potrf.cnt : -1.0;
     if (!strcmp(phase, "syrk")) return pb->potrf.syrk_cnt ? pb->potrf.syrk_ms / (double)pb->potrf.syrk_cnt : -1.0;
@@ -1273,6 +1197,7 @@ double bsfm_lm_last_kernel_ms(const bsfm_problem_t* pb, const char* phase)
     if (!strcmp(phase, "flow_kernel")) return pb->potrf.flow && pb->potrf.flow->kern_cnt ? pb->potrf.flow->kern_ms / (double)pb->potrf.flow->kern_cnt : -1.0;
     if (!strcmp(phase, "flow_gflop")) return pb->potrf.flow && pb->potrf.flow->kern_cnt ? (pb->potrf.flow->flops + (double)pb->potrf.flow->nblk * POTRF_NB * POTRF_NB * POTRF_NB) * 1e-9 : -1.0;
     if (!strcmp(phase, "flow_tasks")) return pb->potrf.flow && pb->potrf.flow->kern_cnt ? (double)pb->potrf.flow->sched.tasks.size() : -1.0;
+    if (!strcmp(phase, "flow_dist")) return pb->potrf.flow && pb->potrf.flow->dist ? (double)pb->potrf.flow->dist->n : 0.0;      // ranks that factored the last system together (0: replicated)
     if (!strcmp(phase, "flow_dynamic")) return pb->potrf.flow ? (double)pb->potrf.flow->dynamic : -1.0;
     if (!strcmp(phase, "flow_sim_us")) return pb->potrf.flow && pb->potrf.flow->kern_cnt ? pb->potrf.flow->sched.sim_us : -1.0;
     // bsfm_problem_create: host wall time (total / upload of the visibility index / index construction / allocation) and the
@@ -1568,10 +1493,12 @@ static int lm_iterate_impl(bsfm_problem_t* pb, int iters)
             if (pb->world > 1) {
                 // a hand-off time-out inside one rank's solve rides the exchange: every rank learns of it and they leave TOGETHER
                 // (a rank that left alone would strand its peers inside the next collective)
-                double mx3[3] = { flagsd[0], maxs[0], potrf_info < 0 ? 1.0 : 0.0 };
-                if (allreduce_mixed(pb, sums, 3, mx3, 3)) return BSFM_ERROR;
+                // (distributed factorisation: every rank holds dpotrf's word for its own tile columns; the system's is the smallest positive one)
+                double mx3[4] = { flagsd[0], maxs[0], potrf_info < 0 ? 1.0 : 0.0, potrf_info > 0 ? 1e9 - (double)potrf_info : 0.0 };
+                if (allreduce_mixed(pb, sums, 3, mx3, 4)) return BSFM_ERROR;
                 flagsd[0] = mx3[0]; maxs[0] = mx3[1];
                 if (mx3[2] != 0.0 && potrf_info >= 0) potrf_info = POTRF_INFO_TIMEOUT;
+                if (potrf_info >= 0 && pb->potrf.dist_comm) potrf_info = mx3[3] > 0.0 ? (int)(1e9 - mx3[3] + 0.5) : 0;
             }
             const bool singularV = flagsd[0] != 0.0;
             if (potrf_info < 0) {         // POTRF_INFO_TIMEOUT: a hand-off inside the persistent Cholesky kernels never arrived
@@ -1878,11 +1805,21 @@ int bsfm_chol_dyn_plan(int nblk, const int* last, void* chain_out, int chain_cap
     return 0;
 }
 
-static int dense_chol_solve_impl(int n, const double* A, const double* b, double* x, int backend, int reps_in, double* ms_out, double* flow_ms_out, double* flow_gflop_out);
+static int dense_chol_solve_impl(int n, const double* A, const double* b, double* x, int backend, int reps_in, double* ms_out, double* flow_ms_out, double* flow_gflop_out,
+                                 bsfm_comm_t* comm = nullptr);
 
 int bsfm_dense_chol_solve(int n, const double* A, const double* b, double* x, int backend)
 {
     return dense_chol_solve_impl(n, A, b, x, backend, 0, nullptr, nullptr, nullptr);
+}
+
+// The same solve by the ranks of a communicator TOGETHER (test entry of the distributed factorisation, chol_flow.hip.h: FlowDist): every rank calls it
+// with the same A and b and receives the same x -- bit-identical to bsfm_dense_chol_solve's -- and the same return value (0, dpotrf's k, BSFM_ERROR).
+// COLLECTIVE.  Transports: "ipc", "loopback".  backend 0 = dense task list, 2 = tile envelope of A.
+int bsfm_dense_chol_solve_dist(bsfm_comm_t* comm, int n, const double* A, const double* b, double* x, int backend)
+{
+    if (!comm || bsfm_comm_world(comm) < 2) return dense_chol_solve_impl(n, A, b, x, backend, 0, nullptr, nullptr, nullptr);
+    return dense_chol_solve_impl(n, A, b, x, backend, 0, nullptr, nullptr, nullptr, comm);
 }
 
 // The same solve `reps` times with the device time of every repetition (ms_out[reps]: factorisation + both substitutions, HIP events
@@ -1894,7 +1831,17 @@ int bsfm_dense_chol_solve_timed(int n, const double* A, const double* b, double*
     return dense_chol_solve_impl(n, A, b, x, backend, std::max(1, reps), ms_out, flow_ms_out, flow_gflop_out);
 }
 
-static int dense_chol_solve_impl(int n, const double* A, const double* b, double* x, int backend, int reps_in, double* ms_out, double* flow_ms_out, double* flow_gflop_out)
+// ranks' dpotrf words -> the system's: a time-out anywhere is a time-out; else the smallest positive k; collective
+static int combine_potrf_info(bsfm_comm_t* comm, int info)
+{
+    double v[2] = { info > 0 ? 1e9 - (double)info : 0.0, info < 0 ? 1.0 : 0.0 };
+    if (bsfm_comm_allreduce_host(comm, v, 2, 1) != 0) return POTRF_INFO_TIMEOUT;
+    if (v[1] != 0.0) return POTRF_INFO_TIMEOUT;
+    return v[0] > 0.0 ? (int)(1e9 - v[0] + 0.5) : 0;
+}
+
+static int dense_chol_solve_impl(int n, const double* A, const double* b, double* x, int backend, int reps_in, double* ms_out, double* flow_ms_out, double* flow_gflop_out,
+                                 bsfm_comm_t* comm)
 {
     if (bsfm_device_count() <= 0) { fprintf(stderr, "[bsfm] FATAL: no usable HIP device\n"); return BSFM_ERROR; }
     if (n <= 0) return BSFM_ERROR;
@@ -1903,6 +1850,7 @@ static int dense_chol_solve_impl(int n, const double* A, const double* b, double
     if (envelope) backend = 0;
     PotrfWorkspace ws;
     if (potrf_init(ws, ld, backend)) return BSFM_ERROR;
+    if (comm && n > POTRF_NB && backend == 0) ws.dist_comm = comm;
     double *dS = nullptr, *dE = nullptr, *dx = nullptr; int* dinfo = nullptr;
     int rc = BSFM_ERROR, info = 0;
     hipStream_t st = nullptr;
@@ -1950,6 +1898,11 @@ static int dense_chol_solve_impl(int n, const double* A, const double* b, double
         }
         if (failed) break;
         if (hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) break;
+        if (ws.dist_comm) {      // every rank holds the verdict of its own tile columns: combine (and fall back TOGETHER on a time-out)
+            info = combine_potrf_info(ws.dist_comm, info);
+            if (hipMemcpy(dinfo, &info, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) break;
+            if (info == POTRF_INFO_TIMEOUT) ws.dist_comm = nullptr;      // the repetition below is every rank's own (replicated) solve
+        }
         if (info == POTRF_INFO_TIMEOUT && ws.use_flow && backend == 0 && ld / POTRF_NB <= POTRF_MAX_TILES) {
             // starved dataflow launch: the same system once more on the stream-ordered schedule (see bsfm_lm_iterate)
             fprintf(stderr, "[bsfm] WARNING: the tile-dataflow Cholesky launch timed out waiting for its own workgroups; repeating the solve on the "

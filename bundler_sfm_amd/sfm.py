@@ -366,45 +366,6 @@ class Problem:
         return out
 
 
-    def export_rows(self):
-        """Plan of the row-wise Schur kernel as resident on the device (csrc/schur_rows.h): workgroups (launch order), pieces, slots,
-        the kernel's own triple array."""
-        sz = [C.c_int() for _ in range(5)]
-        lib.bsfm_problem_row_sizes(self.h, *[C.byref(v) for v in sz])
-        nwg, npc, nslots, L, ntri = [v.value for v in sz]
-        s4 = [C.c_int() for _ in range(4)]
-        lib.bsfm_problem_schur_sizes(self.h, *[C.byref(v) for v in s4])
-        nb, ntask_slots = s4[1].value, s4[3].value
-        out = dict(wgs=np.zeros((nwg, 16), np.int32), pieces=np.zeros((npc, 4), np.int32), blk_row0=np.zeros(nb + 1, np.int32),
-                   blk_range=np.zeros((nb, 2), np.int32), tasks_launch=np.zeros((ntask_slots, 4), np.int32), row_tri=np.zeros((ntri, 2), np.int32))
-        rc = lib.bsfm_problem_export_rows(self.h, *[_ip(out[k]) for k in ("wgs", "pieces", "blk_row0", "blk_range", "tasks_launch", "row_tri")])
-        if rc != 0:
-            raise RuntimeError("bsfm_problem_export_rows failed")
-        out["nslots"] = nslots; out["L"] = L
-        return out
-
-
-ROW_DEAD = 1 << 16
-
-
-def schur_row_plan(m, mcon, blk_j, blk_k, blk_start, tri_x, camptr, rank=None, L=96, dense_min=24, wg_min=0, tri_max=0, slot_base=0):
-    """Host-side plan of the row-wise Schur kernel (csrc/schur_rows.h) for a block list; no device needed."""
-    a = lambda v: np.ascontiguousarray(v, np.int32)
-    blk_j, blk_k, blk_start, tri_x, camptr = a(blk_j), a(blk_k), a(blk_start), a(tri_x), a(camptr)
-    rk = a(rank) if rank is not None else None
-    nblk = len(blk_j)
-    sz = [C.c_int() for _ in range(4)]
-    args = [m, mcon, nblk, _ip(blk_j), _ip(blk_k), _ip(blk_start), _ip(tri_x), _ip(camptr), _ip(rk) if rk is not None else None, L, dense_min,
-            wg_min, tri_max, slot_base]
-    if lib.bsfm_schur_row_plan(*args, *[C.byref(v) for v in sz], None, 0, None, None, 0, None) != 0:
-        raise RuntimeError("bsfm_schur_row_plan failed")
-    nwg, npc, nslots, ntri = [v.value for v in sz]
-    out = dict(wgs=np.zeros((nwg, 16), np.int32), pieces=np.zeros((npc, 4), np.int32), fills=np.zeros((npc, 4), np.int32),
-               blk_row0=np.zeros(nblk + 1, np.int32), nslots=nslots, ntri=ntri)
-    if lib.bsfm_schur_row_plan(*args, *[C.byref(v) for v in sz], _ip(out["wgs"]), nwg, _ip(out["pieces"]), _ip(out["fills"]), npc, _ip(out["blk_row0"])) != 0:
-        raise RuntimeError("bsfm_schur_row_plan failed")
-    return out
-
 
 FLOW_TASK_DTYPE = np.dtype([("type", "u1"), ("np", "u1"), ("part", "u1"), ("nwait", "u1"), ("i", "<u2"), ("j", "<u2"), ("p0", "<u2"),
                             ("pad", "<u2"), ("sig", "<u4"), ("w", "<u4", (3, 2))])
@@ -454,6 +415,15 @@ def dense_chol_solve_timed(A, b, reps=3, backend=0):
     ms = np.zeros(max(1, reps)); fm = C.c_double(-1.0); gf = C.c_double(-1.0)
     rc = lib.bsfm_dense_chol_solve_timed(A.shape[0], _dp(A), _dp(b), _dp(x), backend, reps, _dp(ms), C.byref(fm), C.byref(gf))
     return rc, x, ms, fm.value, gf.value
+
+
+def dense_chol_solve_dist(comm, A, b, backend=0):
+    """bsfm_dense_chol_solve_dist: the ranks of `comm` (a bsfm_comm_t* as c_void_p) factor A together; collective."""
+    A = np.ascontiguousarray(A, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    x = np.zeros_like(b)
+    rc = lib.bsfm_dense_chol_solve_dist(comm, A.shape[0], _dp(A), _dp(b), _dp(x), backend)
+    return rc, x
 
 
 def dense_chol_solve(A, b, backend=0):

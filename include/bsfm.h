@@ -205,6 +205,12 @@ const char *bsfm_comm_transport(const bsfm_comm_t *c);      /* "rccl", "loopback
 int bsfm_comm_allreduce(bsfm_comm_t *c, void *device_buf, size_t count, int op, void *stream);
 int bsfm_comm_allreduce_host(bsfm_comm_t *c, double *vals, int count, int op);     /* count <= 256, synchronous */
 int bsfm_comm_barrier(bsfm_comm_t *c);
+/* Collective: every rank passes one device allocation of its own (the BASE pointer of a hipMalloc) and receives pointers through which it can
+ * address every rank's allocation (its own at peers[rank]).  "ipc" transport (hipIpc handles: processes sharing a device, or the devices of a
+ * node over xGMI peer access) and "loopback" (threads of one process); BSFM_ERROR on "rccl".  What the distributed reduced-camera
+ * factorisation (replaces the replicated sba_Axb_Chol, lib/sba-1.5/sba_levmar.c:1368) maps its panel tiles and counters with. */
+int bsfm_comm_share(bsfm_comm_t *c, void *mine, void **peers);
+int bsfm_comm_unshare(bsfm_comm_t *c, void **peers);
 /* Test hook (no device, no RCCL): the id hand-over of bsfm_comm_create_from_env on its own (csrc/idfile.h).  rank 0 publishes
  * id[128] at `path`; any other rank waits up to timeout_s for a record that was written by THIS user with mode 0600, is no symbolic
  * link, carries this world size and is not older than the calling process by more than grace_s (120 in production), and receives it
@@ -265,25 +271,6 @@ int bsfm_schur_chunk(void);
  * e.g. before another library needs the memory. */
 void bsfm_device_cache_trim(void);
 int bsfm_problem_export_schur(bsfm_problem_t *pb, int *triples, int *tri_pt, int *blk_j, int *blk_k, int *blk_task0, int *tasks);
-/* Round 5 -- the row-wise Schur kernel (csrc/schur_rows.h; reference loop lib/sba-1.5/sba_levmar.c:1195-1302).  Blocks (j,k) with
- * enough co-visibility triples per segment of camera j's records ("dense") are accumulated by workgroups that own (camera j, a
- * segment of <= L consecutive camera-major records): the j side of every triple is streamed once into LDS, only the k side is
- * gathered.  The plan as the problem holds it: wgs (16 ints each: rec0, nrec, first entry of the row triple array, passes, first
- * piece, pieces, first pass of wave 0..3, first piece of wave 0..3, 2 x pad; launch order), pieces (4 ints each: passes, diag, slot,
- * pad), blk_row0 (nblk + 1: row slots per block before the offset ntasks), blk_range (2 ints per block: the slots k_schur_assemble
- * adds, in that order), tasks_launch (4 ints per task slot: what the task kernel of the sparse blocks is given), row_tri (2 ints per
- * entry: slab row of the j side -- bit 16 set on padding --, camera-major record of the k side).  Any pointer may be NULL. */
-int bsfm_problem_row_sizes(const bsfm_problem_t *pb, int *nwg, int *npieces, int *nslots, int *L, int *ntri);
-int bsfm_problem_export_rows(bsfm_problem_t *pb, int *wgs, int *pieces, int *blk_row0, int *blk_range, int *tasks_launch, int *row_tri);
-/* The same plan computed on the HOST from a block list (no device needed; tests): tri_x = j-side record of every triple, block after
- * block (blk_start: nblk + 1), camptr (m + 1), rank = breadth-first numbers of the free cameras or NULL; wg_min / tri_max: 0 = the
- * defaults (2.5 L triples per segment to take a camera's row at all, 12 L padded triples per workgroup).  fills_out: 4 ints per piece
- * (first triple, count, first entry of the row triple array, rec0).  Call with NULL outputs for the sizes.  Returns 0, or -1 (bad
- * arguments / capacity too small). */
-int bsfm_schur_row_plan(int m, int mcon, int nblk, const int *blk_j, const int *blk_k, const int *blk_start, const int *tri_x,
-                        const int *camptr, const int *rank, int L, int dense_min, int wg_min, int tri_max, int slot_base, int *nwg,
-                        int *npieces, int *nslots, int *ntri, int *wgs_out, int cap_wgs, int *pieces_out, int *fills_out, int cap_pieces,
-                        int *blk_row0_out);
 /* dense vmask -> CRS exactly as run_sfm does it (host only); returns nvis, rowptr / colidx may be NULL. */
 int bsfm_crs_from_vmask(int n, int m, const char *vmask, int *rowptr, int *colidx);
 /* The same CRS built ON THE DEVICE (what run_sfm does for masks of at least 1 MB, BSFM_VMASK_DEVICE_MIN: upload, count / scan /
@@ -347,6 +334,13 @@ int bsfm_dense_chol_solve_timed(int n, const double *A, const double *b, double 
  * nblk = the right-hand side.  np_max / slots <= 0 select the defaults.  Returns the number of tasks, or -1 when the builder
  * fails its own dependency check (every wait must be satisfiable by tasks that come EARLIER in the order). */
 int bsfm_chol_flow_schedule(int nblk, const int *last, int np_max, int slots, void *tasks_out, int capacity, double *sim_us);
+/* bsfm_dense_chol_solve by the ranks of a communicator TOGETHER: the distributed tile-dataflow factorisation (tile column j belongs to rank
+ * j mod world; panel tiles, inverse diagonal factors, y, x and the hand-off counters through peer-mapped windows, bsfm_comm_share) that replaces the
+ * REPLICATED sba_Axb_Chol of the multi-GPU path (lib/sba-1.5/sba_levmar.c:1368; SURVEY 8(e) "what does not shard").  COLLECTIVE: every rank
+ * passes the same A and b and receives the same x -- bit-identical to bsfm_dense_chol_solve's -- and the same return value.  Transports "ipc" and
+ * "loopback"; a hand-off time-out on any rank makes every rank repeat the solve on its own (stream-ordered schedule).  Inside run_sfm / bsfm_lm_*:
+ * BSFM_DIST_CHOL=1 with such a communicator. */
+int bsfm_dense_chol_solve_dist(bsfm_comm_t *comm, int n, const double *A, const double *b, double *x, int backend);
 /* Test / diagnostic hook (no device needed): the host-side plan of the DYNAMIC tile-dataflow Cholesky (csrc/chol_dyn_plan.h, the
  * round-6 default; replaces sba_Axb_Chol, lib/sba-1.5/sba_lapack.c:374-485).  chain_out / potrf_out receive the two static queues
  * (40-byte records as above; a wait whose thr has bit 31 set compares the low 10 bits of the word), init_out the initial image of

@@ -229,6 +229,7 @@ def _ipc_worker(out):
         pb.lm_iterate(ITERS)
         rc, info = pb.lm_finish()
         p = pb.download(want_cams=False)[0]
+        res["dist_ranks"] = int(pb.phase_ms("flow_dist"))
         pb.close()
         np.save(out + f".p{rank}.npy", p)
         res["info"] = [float(x) for x in info]
@@ -237,7 +238,8 @@ def _ipc_worker(out):
     json.dump(res, open(out + f".{rank}.json", "w"))
 
 
-def test_two_processes_one_gpu_through_the_native_ipc_transport(tmp_path):
+@pytest.mark.parametrize("dist_chol", [0, 1], ids=["replicated-cholesky", "distributed-cholesky"])
+def test_two_processes_one_gpu_through_the_native_ipc_transport(tmp_path, dist_chol):
     """bsfm_comm_create_from_env with WORLD_SIZE = 2 between two PROCESSES that share cuda:0 -- the id-file
     hand-over (csrc/idfile.h), the control block in shared memory, the exchange buffers opened through hipIpc, chunked all-reduces in
     rank order and the whole multi-rank LM control flow of solver.hip, without torch.distributed in the loop.  (RCCL refuses two
@@ -253,7 +255,9 @@ def test_two_processes_one_gpu_through_the_native_ipc_transport(tmp_path):
     for rank in (1, 0):                     # the waiting rank starts first
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
                    BSFM_COMM_TRANSPORT="ipc", BSFM_COMM_IPC_MB="1", BSFM_COMM_ID_FILE=str(tmp_path / "job.id"),
-                   BSFM_COMM_TIMEOUT_S="60", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   BSFM_COMM_TIMEOUT_S="60", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   # dist_chol: the two ranks factor the (two-tile) reduced camera system TOGETHER inside the LM loop -- same bits as replicated
+                   BSFM_DIST_CHOL=str(dist_chol), BSFM_FLOW_WGS="256")
         code = f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {HERE!r}); import test_multi_gpu as t; t._ipc_worker({out!r})"
         procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     errs = [p.communicate(timeout=420) for p in procs]
@@ -271,6 +275,13 @@ def test_two_processes_one_gpu_through_the_native_ipc_transport(tmp_path):
         assert np.abs(ps[k][9 * m:] - p1[9 * m + 3 * r["lo"]:9 * m + 3 * r["hi"]]).max() <= 1e-8
     assert np.array_equal(ps[0][:9 * m], ps[1][:9 * m])               # bitwise identical replicas
     assert not os.path.exists(str(tmp_path / "job.id"))                # rank 0 removed the id file on destroy
+    assert [r["dist_ranks"] for r in res] == [2 * dist_chol] * 2
+    # the distributed factorisation is the same arithmetic: the run must not differ from the replicated one by a single bit
+    keep = os.path.join(os.path.dirname(str(tmp_path)), "ipc_two_ranks_cameras.npy")
+    if dist_chol == 0:
+        np.save(keep, ps[0][:9 * m])
+    elif os.path.exists(keep):
+        assert np.array_equal(np.load(keep), ps[0][:9 * m])
 
 
 def test_ipc_transport_times_out_when_a_rank_is_missing(tmp_path):
@@ -303,7 +314,8 @@ def test_bench_runs_as_two_ranks_on_one_gpu(tmp_path):
     procs = []
     for rank in (1, 0):
         env = dict(env1, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
-                   BSFM_COMM_TRANSPORT="ipc", BSFM_COMM_ID_FILE=str(tmp_path / "bench.id"), BSFM_COMM_TIMEOUT_S="60")
+                   BSFM_COMM_TRANSPORT="ipc", BSFM_COMM_ID_FILE=str(tmp_path / "bench.id"), BSFM_COMM_TIMEOUT_S="60",
+                   BSFM_DIST_CHOL="1", BSFM_FLOW_WGS="256")      # the two ranks factor the reduced camera system together (round 6)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=280) for p in procs]
@@ -313,6 +325,7 @@ def test_bench_runs_as_two_ranks_on_one_gpu(tmp_path):
     assert len(lines) == 1                                             # ONE JSON line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["rccl_ranks_seen"] == 2 and "ipc" in d["config"]["collective"]
+    assert d["config"]["distributed_cholesky_ranks"] == 2
     assert d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "strong" and d["cpu_baseline"] is None
     close = lambda a, b: abs(a - b) <= 1e-9 * abs(b)
     assert close(d["cost_after_3_iterations"], ref["cost_after_3_iterations"])
@@ -355,3 +368,95 @@ def test_bench_line_has_the_contract_fields(tmp_path):
     assert two.returncode == 0, two.stderr[-1500:]
     d2 = json.loads([ln for ln in two.stdout.strip().splitlines() if ln.startswith("{")][0])
     assert d2["continued_past_convergence"] is None and "rounds 1-3" in d2["config"]["timed_window"]
+
+
+# ---- the DISTRIBUTED reduced-camera factorisation (chol_flow.hip.h: FlowDist; VERDICT r5 "missing #1") between processes sharing cuda:0 ------------
+DIST_SIZES = (1100, 3700, 9000)          # 9, 29 and 71 tile columns
+
+
+def _dist_system(n, seed):
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((n, 64))
+    A = G @ G.T
+    A[np.diag_indices(n)] += np.exp(rng.uniform(np.log(0.5), np.log(50.0), n)) * 64.0
+    d = 1.0 + np.arange(n) / n
+    return A * d[:, None] * d[None, :], rng.standard_normal(n)
+
+
+def _dist_worker(out):
+    import ctypes as C
+    import json
+    import bundler_sfm_amd.sfm as S
+    import bundler_sfm_amd as B
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    B.lib.bsfm_comm_create_from_env.restype = C.c_void_p
+    c = C.c_void_p(B.lib.bsfm_comm_create_from_env())
+    res = dict(ok=bool(c), rank=rank, rc=[], info=None, stalled=None)
+    if c:
+        for n in DIST_SIZES:
+            A, b = _dist_system(n, n)
+            rc, x = S.dense_chol_solve_dist(c, A, b)
+            res["rc"].append(int(rc))
+            np.save(out + f".x{n}.{rank}.npy", x)
+        # dpotrf's info = the first failing leading minor, whichever rank owns its tile column (and a second failure in another rank's column)
+        A, b = _dist_system(1100, 7)
+        A[700, 700] = -1.0; A[300, 300] = -1.0
+        res["info"] = int(S.dense_chol_solve_dist(c, A, b)[0])
+        # band envelope
+        A, b = _dist_system(1500, 8)
+        i, j = np.indices(A.shape); A[np.abs(i - j) > 300] = 0.0
+        A[np.diag_indices(1500)] = np.abs(A).sum(axis=1) + 1.0
+        rc, x = S.dense_chol_solve_dist(c, A, b, backend=2)
+        res["rc_env"] = int(rc); np.save(out + f".xenv.{rank}.npy", x)
+        # a task of rank 1 never signals: every rank's waits expire, every rank repeats the solve on its own
+        os.environ["BSFM_FLOW_TEST_STALL"] = "5"; os.environ["BSFM_FLOW_TEST_STALL_RANK"] = "1"; os.environ["BSFM_FLOW_SPIN_MS"] = "30"
+        A, b = _dist_system(1100, 9)
+        rc, x = S.dense_chol_solve_dist(c, A, b)
+        res["stalled"] = int(rc); np.save(out + f".xstall.{rank}.npy", x)
+        B.lib.bsfm_comm_destroy(c)
+    json.dump(res, open(out + f".{rank}.json", "w"))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_distributed_cholesky_is_bit_identical_to_the_one_rank_solve(tmp_path, world):
+    """The replicated factorisation of the multi-GPU path (every rank factoring the whole reduced camera system, sba_levmar.c:1368) split by tile
+    columns over the ranks -- here 2 and 4 PROCESSES sharing cuda:0 through hipIpc (the transport a node's GPUs would use over xGMI peer access):
+    panel tiles, inverse diagonal factors, y, the solution and the hand-off counters are read through peer-mapped windows.  Same static order, same
+    arithmetic: every rank's solution equals bsfm_dense_chol_solve's to the last bit at 9, 29 and 71 tile columns and on a band envelope; dpotrf's
+    info is the first failing minor whichever rank owns it; a starved rank makes EVERY rank fall back to its own stream-ordered solve."""
+    import json
+    import subprocess
+    import scipy.linalg as sl
+    import bundler_sfm_amd.sfm as S
+    out = str(tmp_path / "dist")
+    port = str(_free_port())
+    procs = []
+    for rank in reversed(range(world)):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   BSFM_COMM_TRANSPORT="ipc", BSFM_COMM_IPC_MB="1", BSFM_COMM_ID_FILE=str(tmp_path / "job.id"), BSFM_COMM_TIMEOUT_S="120",
+                   BSFM_FLOW_WGS=str(512 // world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        code = f"import sys; sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {HERE!r}); import test_multi_gpu as t; t._dist_worker({out!r})"
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    errs = [p.communicate(timeout=800) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [e[1][-2500:] for e in errs]
+    res = [json.load(open(out + f".{k}.json")) for k in range(world)]
+    for n_i, n in enumerate(DIST_SIZES):
+        A, b = _dist_system(n, n)
+        rc1, x1 = S.dense_chol_solve(A, b)
+        assert rc1 == 0
+        for k in range(world):
+            assert res[k]["ok"] and res[k]["rc"][n_i] == 0
+            assert np.load(out + f".x{n}.{k}.npy").tobytes() == x1.tobytes(), (n, k)
+    for k in range(world):
+        assert res[k]["info"] == 301                      # the smaller of the two planted minors (rows 300 and 700)
+        assert res[k]["stalled"] == 0
+    A, b = _dist_system(1500, 8)
+    i, j = np.indices(A.shape); A[np.abs(i - j) > 300] = 0.0
+    A[np.diag_indices(1500)] = np.abs(A).sum(axis=1) + 1.0
+    rc1, x1 = S.dense_chol_solve(A, b, backend=2)
+    A9, b9 = _dist_system(1100, 9)
+    ref9 = sl.cho_solve(sl.cho_factor(A9, lower=True), b9)
+    for k in range(world):
+        assert res[k]["rc_env"] == 0 and np.load(out + f".xenv.{k}.npy").tobytes() == x1.tobytes()
+        assert np.abs(np.load(out + f".xstall.{k}.npy") - ref9).max() <= 1e-11 * np.abs(ref9).max()
+    assert any("timed out" in e[1] for e in errs)        # the fallback announced itself
