@@ -887,7 +887,11 @@ __global__ __launch_bounds__(512, WPS) void k_chol_flow(FlowArgs a_param)
     // ---- role: 0 = bulk queue, 1 = chain queue, 2 = leave (second workgroup on a chain CU)
     if (wave == 0) {
         int role = 0;
-        const unsigned n_cw = (unsigned)__builtin_amdgcn_readfirstlane((int)a.n_chain_wgs);
+        // (bit 31 of n_chain_wgs, BSFM_FLOW_CHAIN_SHARED=1: only the POTRF workgroup keeps its CU to itself; the other chain workgroups share theirs with a
+        //  bulk workgroup -- 16 more bulk slots against slower 4 - 5 us chain tasks; an experiment of round 6)
+        const unsigned n_cw_raw = (unsigned)__builtin_amdgcn_readfirstlane((int)a.n_chain_wgs);
+        const unsigned n_cw = n_cw_raw & 0x7fffffffu;
+        const bool chain_shares = (n_cw_raw >> 31) != 0u;
         if (n_cw > 0u) {
             unsigned hw = 0, xcc = 0;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -904,7 +908,7 @@ __global__ __launch_bounds__(512, WPS) void k_chol_flow(FlowArgs a_param)
                 r = (unsigned)__builtin_amdgcn_readfirstlane((int)r);
                 role = r < n_cw ? 1 : 0;
                 if (r == 0u && a.n_potrf > 0u) role = 3;          // the first chain workgroup serves the POTRF queue alone
-                if (lane == 0) __hip_atomic_store(cu_state, role ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(cu_state, (role == 3 || (role == 1 && !chain_shares)) ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else if (slot == 1u) {
                 // the first workgroup on this CU decides within a microsecond; an unanswered wait just means "bulk"
                 unsigned st = 0;
@@ -1141,6 +1145,7 @@ struct FlowWorkspace {
     long long spin_limit = FLOW_SPIN_LIMIT_TICKS;      // BSFM_FLOW_SPIN_MS
     int stall_ticket = -1, stall_bwd_col = -1;         // test hooks: BSFM_FLOW_TEST_STALL (bulk ticket that never signals), BSFM_FLOW_TEST_STALL_BWD (column)
     int wgs = 512;                         // workgroups launched (BSFM_FLOW_WGS)
+    bool chain_shared = false;             // the chain workgroups other than POTRF's share their CUs with bulk workgroups (bulk-bound systems, see flow_prepare)
     int chain_wgs = 17;                    // of them: serve the chain queue, alone on their CU (17 or 27, see flow_prepare; BSFM_FLOW_CHAIN_WGS; 0 = one queue)
     bool trace = false;                    // BSFM_FLOW_TRACE=1: per-task stamps, dumped to BSFM_FLOW_TRACE_FILE after every solve
     double flops = 0.0;                    // flops of one factorisation as scheduled (UPD + TRSM tile products, 2 * 128^3 each)
@@ -1271,6 +1276,11 @@ inline int flow_prepare(FlowWorkspace& f, int nblk, const std::vector<int>& env_
     f.chain_wgs = ((f.sched.upd_tiles + f.sched.trsm_tiles) < 400.0 * nblk ? 26 : 16) + 1;
     if (const char* e = getenv("BSFM_FLOW_CHAIN_WGS")) f.chain_wgs = std::max(0, atoi(e));
     f.chain_wgs = std::min(f.chain_wgs, f.wgs / 4);
+    // Round 6: on a BULK-bound factorisation (>= 600 tile products per tile column: from ~60 columns) only the POTRF workgroup keeps a CU to itself; the
+    // other chain workgroups share theirs with a bulk workgroup -- 16 bulk slots more.  n = 9 000: 6.15 -> 6.01 ms; chain-bound sizes lose (n = 5 400,
+    // 43 columns: 2.33 -> 2.39 ms), hence the threshold.  BSFM_FLOW_CHAIN_SHARED=0|1 forces it.  (profiles/r06_chain_shared_cus.txt)
+    f.chain_shared = (f.sched.upd_tiles + f.sched.trsm_tiles) >= 600.0 * nblk;
+    if (const char* e = getenv("BSFM_FLOW_CHAIN_SHARED")) f.chain_shared = atoi(e) != 0;
     {
         int lat_tiles = 38;
         if (const char* e = getenv("BSFM_FLOW_LATENCY_TILES")) lat_tiles = atoi(e);
@@ -1353,6 +1363,7 @@ inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, in
     a.tasks = f.d_tasks; a.chain_tasks = f.d_tasks + f.bulk.size(); a.n_bulk = (unsigned)f.bulk.size(); a.n_chain = (unsigned)f.chain.size();
     a.potrf_tasks = f.d_tasks + f.bulk.size() + f.chain.size(); a.n_potrf = (unsigned)f.potrf.size();
     a.n_chain_wgs = (unsigned)f.chain_wgs; a.sync = f.d_sync; a.nflags = (unsigned)f.sched.nflags; a.info = d_info;
+    if (f.chain_shared) a.n_chain_wgs |= 0x80000000u;
     a.trace = f.trace ? f.d_trace : nullptr; a.ptrace_ofs = (unsigned)(4 * nt);
     a.spin_limit = f.spin_limit; a.stall_ticket = f.stall_ticket;
     const size_t lds_bytes = FLOW_LDS_DOUBLES * sizeof(double);

@@ -199,7 +199,7 @@ __global__ void k_cam_table(ModelCfg cfg, int m, const double* __restrict__ pa, 
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= m * CT_PARTS) return;
-    cam_table_part(cfg, t / CT_PARTS, t % CT_PARTS, pa, Rinit, finit, known, with_fd, camtab);
+    cam_table_part(cfg, t % m, t / m, pa, Rinit, finit, known, with_fd, camtab);      // (neighbouring lanes = neighbouring cameras, the SAME part: no divergence)
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -897,8 +897,11 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem P, double mu, const 
     // arrived last: pdp_a is written and read inside this workgroup (a barrier in between)
     step_sums_body(fa.count, fa.fixed, mu, fa.pa, dpa, P.ea, fa.pdpa, fa.out3, part, (int)gridDim.x, fa.pt3, true);
     __syncthreads();
-    for (int t = threadIdx.x; t < P.m * CT_PARTS; t += 256)
-        cam_table_part(P.cfg, t / CT_PARTS, t % CT_PARTS, fa.pdpa, P.Rinit, P.finit, fa.known, fa.with_fd, fa.camtab_trial);
+    // (one workgroup for the whole table is only right for the small problems this fusion was made for: from 256 cameras on the host launches
+    //  k_cam_table behind this kernel -- at 1 000 cameras this loop was 60 - 80 us of ONE workgroup with the rest of the device idle)
+    if (fa.camtab_trial)
+        for (int t = threadIdx.x; t < P.m * CT_PARTS; t += 256)
+            cam_table_part(P.cfg, t % P.m, t / P.m, fa.pdpa, P.Rinit, P.finit, fa.known, fa.with_fd, fa.camtab_trial);
 }
 
 // camera part of the step: pdp_a = p_a + dp_a and sum dpa^2, sum pa^2, sum dpa (mu dpa + ea) (single block).

@@ -1456,7 +1456,8 @@ static int lm_iterate_impl(bsfm_problem_t* pb, int iters)
                 // table of the trial point (k_cam_table): three launches in one
                 const int ms = trial_mirror_slot(pb);            // the trial points also go to the camera-major mirror the residual kernel streams
                 StepFinalArgs fa; fa.count = P.m * cnp; fa.fixed = P.mcon * cnp; fa.pa = d_pa; fa.pdpa = d_pdpa; fa.out3 = pb->d_scal + SC_CAM3;
-                fa.pt3 = pb->d_scal + SC_PT_DP; fa.known = pb->d_known; fa.with_fd = pb->opt.jacobian == BSFM_JAC_FD ? 1 : 0; fa.camtab_trial = pb->d_camtab_trial;
+                const bool table_in_backsub = P.m < 256;      // (see k_backsub: the finishing workgroup builds the trial point's camera table only on small problems)
+                fa.pt3 = pb->d_scal + SC_PT_DP; fa.known = pb->d_known; fa.with_fd = pb->opt.jacobian == BSFM_JAC_FD ? 1 : 0; fa.camtab_trial = table_in_backsub ? pb->d_camtab_trial : nullptr;
                 fa.ticket_groups = pb->d_tickets + pb->tick_back;
                 // big problems: the per-observation products W^T da in a streaming pass of their own (k_backsub_obs); they go where the Schur
                 // phase kept its per-observation records (d_Cc: dead once S is assembled)
@@ -1468,6 +1469,7 @@ static int lm_iterate_impl(bsfm_problem_t* pb, int iters)
                 }
                 DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_backsub<C>), dim3(nbp), dim3(256), 0, pb->stream, P, mu, d_dpa, d_pb, d_dpb, d_pdpb, pb->d_red, pb->d_ptc[ms],
                                                       wobs, pb->d_tickets + 2, fa));
+                if (!table_in_backsub) launch_cam_table(pb, pb->d_pdp, pb->d_camtab_trial);
                 pb->ptc_tag[ms] = pb->d_pdp;
             } else {
                 hipLaunchKernelGGL(k_step_sums, dim3(1), dim3(256), 0, pb->stream, P.m * cnp, P.mcon * cnp, mu, d_pa, d_dpa, pb->d_ea, d_pdpa,
