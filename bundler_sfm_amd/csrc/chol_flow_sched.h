@@ -77,6 +77,13 @@ struct FlowParams {
                               // `lookahead` columns of the chain read (row i of the factor up to column i); kept current, the chain runs ahead of the
                               // bulk sweeps instead of in step with them (scripts/r5/critical_path.py: at 71 tile columns POTRF(38) waited 145 us for
                               // the last two visits of tile (38, 37), whole-tile visits of four panels that had been queued behind the bulk)
+    double laxity = 2.0;      // > 0 (round 6; default 2.0, 0 = the column order of rounds 4-5): LEAST LAXITY instead of "lowest column first" for the bulk.  A tile is a SEQUENTIAL job -- one workgroup at a time,
+                              // ~30 us per panel -- so a tile that is B panels behind must be started B * 30 us before the chain reaches its column, not when
+                              // every lower column has run dry: the traced launch had tile (50, 49) 27 panels behind with the front at column 36, and POTRF(50)
+                              // then waited 160 us for five serial 8-panel visits of it (profiles/r06_chain_critical_path.txt).  The bulk's priority key becomes
+                              // column - laxity * (panels the tile is behind): laxity = columns of head start per panel of backlog
+    int band_rows = 0;        // > 0 (round 6): tiles within this many tile rows of the diagonal -- (j, j), (j + 1, j), ... : what the chain itself reads when it reaches column
+                              // j -- are kept current in EVERY column (priority class of the urgent column, ordered by column), not only next to the front
     int lazy_cols = 2;        // > 0: a bulk tile further than this many columns ahead of the chain is only visited once TWO panels are ready
                               // for it (or its last one): a one-panel visit moves 393 KB for 4.2 Mflop and is HBM-bound
 };
@@ -140,9 +147,10 @@ inline int flow_build_schedule(int T, const std::vector<int>& last_in, const Flo
     std::vector<char> potrf_done((size_t)T, 0);
 
     // ready queue: (class, column, row) ascending; entries are re-validated when popped
-    struct Cand { int cls, col, row, kind; };   // kind 0: POTRF / TRSM (finalise), 1: UPD
+    struct Cand { int cls, col, row, kind; double key; };   // kind 0: POTRF / TRSM (finalise), 1: UPD; key: the column, or the column less the laxity bonus
     auto ccmp = [](const Cand& x, const Cand& y) {
         if (x.cls != y.cls) return x.cls > y.cls;
+        if (x.key != y.key) return x.key > y.key;
         if (x.col != y.col) return x.col > y.col;
         return x.row > y.row;
     };
@@ -160,12 +168,27 @@ inline int flow_build_schedule(int T, const std::vector<int>& last_in, const Flo
         }
         return n;
     };
+    // panels the tile could apply right now without the per-visit cap (its backlog), for the laxity key
+    auto backlog = [&](int i, int j, int v) -> int {
+        int n = 0;
+        while (v + n < j) {
+            const int p = v + n;
+            const Tile& a = tl(i, p); const Tile& b = tl(j, p);
+            if (a.p_ready >= 0.0 && a.p_ready <= now && b.p_ready >= 0.0 && b.p_ready <= now) ++n; else break;
+        }
+        return n;
+    };
+    auto upd_key = [&](int cls, int i, int j, int v) -> double {
+        if (prm.laxity <= 0.0 || cls != 3 || i == T) return (double)j;
+        return (double)j - prm.laxity * (double)backlog(i, j, v);
+    };
     auto in_triangle = [&](int i, int j) -> bool { return prm.lookahead > 0 && i < T && i <= front + prm.lookahead; };      // (j <= i always)
     auto classify_upd = [&](int i, int j) -> int {
         const bool urgent_col = j <= front + prm.urgent_cols;
         if (i == T) return urgent_col ? 2 : 3;
         if (i == j && urgent_col) return 1;
         if (urgent_col || in_triangle(i, j)) return 2;
+        if (prm.band_rows > 0 && i - j <= prm.band_rows) return 2;
         return 3;
     };
     auto consider = [&](int i, int j) {                 // push whatever the tile can do now
@@ -176,13 +199,13 @@ inline int flow_build_schedule(int T, const std::vector<int>& last_in, const Flo
         if (t.ver < j) {
             const int nr = panels_ready(i, j, t.ver);
             const int need = (prm.lazy_cols > 0 && i != T && j > front + prm.lazy_cols) ? std::min(2, j - t.ver) : 1;
-            if (nr >= need) ready.push({ classify_upd(i, j), j, i, 1 });
+            if (nr >= need) { const int cls_ = classify_upd(i, j); ready.push({ cls_, j, i, 1, upd_key(cls_, i, j, t.ver) }); }
         } else {
             // final: POTRF (diagonal) or TRSM
-            if (i == j) ready.push({ 0, j, i, 0 });
+            if (i == j) ready.push({ 0, j, i, 0, (double)j });
             else {
                 const Tile& d = tl(j, j);
-                if (d.p_ready >= 0.0 && d.p_ready <= now) ready.push({ i == j + 1 ? 1 : 2, j, i, 0 });
+                if (d.p_ready >= 0.0 && d.p_ready <= now) ready.push({ i == j + 1 ? 1 : 2, j, i, 0, (double)j });
             }
         }
     };
@@ -221,7 +244,7 @@ inline int flow_build_schedule(int T, const std::vector<int>& last_in, const Flo
                 ok = t.ver >= j;
                 if (ok && i != j) { const Tile& d = tl(j, j); ok = d.p_ready >= 0.0 && d.p_ready <= now; }
             }
-            if (ok && c.kind == 1 && classify_upd(i, j) != c.cls) { ready.pop(); ready.push({ classify_upd(i, j), j, i, 1 }); continue; }
+            if (ok && c.kind == 1 && classify_upd(i, j) != c.cls) { ready.pop(); const int cls_ = classify_upd(i, j); ready.push({ cls_, j, i, 1, upd_key(cls_, i, j, t.ver) }); continue; }
             if (!ok) { ready.pop(); continue; }
             // parts and duration
             uint8_t type; int parts; double dur;
