@@ -1202,6 +1202,7 @@ inline FlowParams flow_params_from_env()
     if (const char* e = getenv("BSFM_FLOW_LAZY")) p.lazy_cols = std::max(0, atoi(e));
     if (const char* e = getenv("BSFM_FLOW_LAXITY")) p.laxity = std::max(0.0, atof(e));
     if (const char* e = getenv("BSFM_FLOW_BAND")) p.band_rows = std::max(0, atoi(e));
+    if (const char* e = getenv("BSFM_FLOW_NPHALF")) p.np_max_half = std::max(1, std::min(8, atoi(e)));
     if (const char* e = getenv("BSFM_FLOW_LOOKAHEAD")) p.lookahead = std::max(0, atoi(e));
     if (const char* e = getenv("BSFM_FLOW_ADAPT")) p.adaptive_halves = std::max(0, atoi(e));
     if (const char* e = getenv("BSFM_FLOW_TPOTRF")) p.t_potrf = atof(e);
@@ -1225,7 +1226,7 @@ inline int flow_cached_schedule(int nblk, const std::vector<int>& key, const Flo
 {
     const std::vector<double> pv = { (double)p.slots, (double)p.np_max, (double)p.np_max_rhs, p.t_potrf, p.t_trsm32, p.t_trsm64, p.t_upd32, p.t_upd32_per,
                                      p.t_upd64_0, p.t_upd64_per, p.t_upd128_0, p.t_upd128_per, p.t_ftrsm, p.t_fupd_0, p.t_fupd_per, p.t_hand,
-                                     (double)p.urgent_cols, (double)p.lazy_cols, (double)p.adaptive_halves, (double)p.lookahead, p.laxity, (double)p.band_rows };
+                                     (double)p.urgent_cols, (double)p.lazy_cols, (double)p.adaptive_halves, (double)p.lookahead, p.laxity, (double)p.band_rows, (double)p.np_max_half };
     {
         std::lock_guard<std::mutex> lock(flow_sched_cache_mutex());
         auto& c = flow_sched_cache();

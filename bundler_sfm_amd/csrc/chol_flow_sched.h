@@ -63,6 +63,7 @@ struct FlowParams {
     int slots = 512;          // resident workgroups assumed by the simulation (2 per CU x 256)
     int np_max = 8;           // panels per bulk visit (round 6: 8 with lazy_cols = 2, 6.33 -> 6.23 ms at 71 tile columns; 4 / 0 before)
     int np_max_rhs = 8;       // ... for the right-hand-side row
+    int np_max_half = 2;      // ... for the 64-row halves of the urgent column (a tile that reaches the urgent column with a backlog catches up in halves)
     // estimated durations, microseconds: medians of the per-task trace of the n = 9 000 solve on MI355X (profiles/r04_flow_task_durations.txt)
     double t_potrf = 42.0, t_trsm32 = 4.5, t_trsm64 = 17.0, t_upd32 = 5.0, t_upd32_per = 2.5;
     double t_upd64_0 = 7.0, t_upd64_per = 12.5, t_upd128_0 = 12.0, t_upd128_per = 27.0;
@@ -258,7 +259,7 @@ inline int flow_build_schedule(int T, const std::vector<int>& last_in, const Flo
                 if (i == T) { type = FT_FUPD; parts = 1; dur = prm.t_fupd_0 + prm.t_fupd_per * n; }
                 else if (cls == 1) { n = std::min(n, 3); type = FT_UPD32; parts = 10; dur = prm.t_upd32 + prm.t_upd32_per * (n - 1); }
                 else if (cls == 2 && (in_triangle(i, j) || !(prm.adaptive_halves && (long long)ready.size() > (long long)free_slots + prm.adaptive_halves))) {
-                    n = std::min(n, 2); type = FT_UPD64; parts = 2; dur = prm.t_upd64_0 + prm.t_upd64_per * n;
+                    n = std::min(n, prm.np_max_half); type = FT_UPD64; parts = 2; dur = prm.t_upd64_0 + prm.t_upd64_per * n;
                 }
                 else { type = FT_UPD128; parts = 1; dur = prm.t_upd128_0 + prm.t_upd128_per * n; }
             }
