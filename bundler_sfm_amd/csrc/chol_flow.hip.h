@@ -1020,6 +1020,7 @@ __global__ __launch_bounds__(512, WPS) void k_chol_flow(FlowArgs a_param)
     }
 }
 
+constexpr unsigned long long FLOW_X_PENDING = 0xfff85eeddeadbeefull;      // "x_k has not arrived": a quiet NaN with a payload no instruction generates
 // Backward substitution x = L^-T y, one persistent launch (k_bwd_persistent of potrf.hip.h reading the compact panel tiles).
 // Every workgroup of a launch must be resident (it waits for the tile columns to its right), so systems of more than POTRF_MAX_TILES
 // tile columns run it in WAVES of that many columns, rightmost first (`first` = columns already done): a later wave finds the flags
@@ -1029,10 +1030,10 @@ __global__ __launch_bounds__(512, WPS) void k_chol_flow(FlowArgs a_param)
 // on its way to the launch).
 __global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc, int nblk, int first, const double* __restrict__ Linv,
         const double* __restrict__ y, double* x, int* flags, int* timeout, const int* __restrict__ last_row, long long spin_limit, int stall_col,
-        const FlowPeers* __restrict__ peers = nullptr, int flagval = 1)
+        const FlowPeers* __restrict__ peers = nullptr, int flagval = 1, int x_is_flag = 0)
 {
     __shared__ double yk[POTRF_NB];
-    __shared__ double xi[POTRF_NB];
+    __shared__ double xi[2][POTRF_NB];      // double-buffered: one barrier per step
     __shared__ double red[POTRF_NB];
     const int kk = nblk - 1 - first - (int)blockIdx.x;
     if (peers && kk % peers->n != peers->rank) {
@@ -1050,48 +1051,118 @@ __global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc,
         return;
     }
     const int c = threadIdx.x & 127, h = threadIdx.x >> 7;
-    double lreg[64], tcur[64];
-    {
-        const double* Li = Linv + (size_t)kk * FLOW_TL + (size_t)(64 * h) * POTRF_NB + c;
-#pragma unroll
-        for (int r = 0; r < 64; ++r) lreg[r] = Li[(size_t)r * POTRF_NB];
-    }
+    double ta[64], tb[64];
     if (threadIdx.x < POTRF_NB) yk[threadIdx.x] = y[(size_t)kk * POTRF_NB + threadIdx.x];
     __syncthreads();
     const int itop = last_row ? last_row[kk] : nblk - 1;
-    for (int i = itop; i > kk; --i) {
-        {
-            const double* Lc = Pc + flow_tri(i, kk) * FLOW_TL + (size_t)(64 * h) * POTRF_NB + c;
-#pragma unroll
-            for (int r = 0; r < 64; ++r) tcur[r] = Lc[(size_t)r * POTRF_NB];
-        }
-        if (threadIdx.x == 0) {
-            unsigned spins = 0;
-            const long long t_begin = wall_clock64();
-            while (__hip_atomic_load(&flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != flagval) {
-                __builtin_amdgcn_s_sleep(2);
-                if ((++spins & 63u) == 0u && (wall_clock64() - t_begin > spin_limit || __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                    atomicExch(timeout, 1); break;              // a bounded wait: the solve reports POTRF_INFO_TIMEOUT instead of hanging
-                }
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < POTRF_NB)
-            xi[threadIdx.x] = __hip_atomic_load(&x[(size_t)i * POTRF_NB + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        double sacc = 0.0;
-#pragma unroll
-        for (int r = 0; r < 64; ++r) sacc += tcur[r] * xi[64 * h + r];
-        if (h == 1) red[c] = sacc;
-        __syncthreads();
-        if (h == 0) yk[c] -= sacc + red[c];
-        __syncthreads();
+    const int nstep = itop - kk;
+    // The column's operands are a SEQUENCE of 128 x 128 tiles: P(itop, kk), ..., P(kk + 1, kk), and last the inverse W_kk (instead of 128 registers
+    // held from the start).  Two register buffers: tile j + 1 is requested in step j, with the first poll of that step in front of it (vector loads
+    // return in order: a poll issued behind a 128 KB tile request is answered when the tile has landed).  The prefetch is unconditional -- tile
+    // j + 1 always exists, W closes the sequence -- so the compiler can count the loads in flight.
+    // What sets the period of this chain of nblk hand-offs (round 6, found by changing everything else first -- flag protocol, three polls in flight,
+    // four accumulator chains, one barrier per step: 2.4 - 2.8 us per column every time) is the time ONE workgroup needs to pull a 128 KB tile:
+    // every column has one tile in flight per step, so it cannot take a step in less.  Going below needs two tiles in flight per column (three
+    // buffers = 384 VGPRs) AND polls that do not queue behind them (a polling wave of its own): not built.
+#define BSFM_BWD_LOAD(T_, J_)                                                                                       \
+    {                                                                                                               \
+        const double* Lc_ = ((J_) < nstep ? Pc + flow_tri(itop - (J_), kk) * FLOW_TL : Linv + (size_t)kk * FLOW_TL) + (size_t)(64 * h) * POTRF_NB + c; \
+        _Pragma("unroll") for (int r = 0; r < 64; ++r) T_[r] = Lc_[(size_t)r * POTRF_NB];                           \
     }
-    double sacc = 0.0;
+#define BSFM_BWD_STEP(CUR_, NXT_, J_)                                                                             \
+    {                                                                                                               \
+        const int i_ = itop - (J_);                                                                                 \
+        if (x_is_flag) {                                                                                            \
+            /* the solution values ARE the flag: k_flow_begin filled x with FLOW_X_PENDING, a NaN pattern no arithmetic produces; each of the  \
+               128 lanes polls its own entry.  Against flag + value this takes the producer's drain of its stores, the flag store and the       \
+               consumer's dependent load of x_i off a chain of nblk serial hand-offs. */                                                      \
+            const unsigned long long* px_ = reinterpret_cast<const unsigned long long*>(x) + (size_t)i_ * POTRF_NB + (threadIdx.x & (POTRF_NB - 1)); \
+            unsigned long long bits_ = __hip_atomic_load(px_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          \
+            BSFM_BWD_LOAD(NXT_, (J_) + 1)                                                                           \
+            if (threadIdx.x < POTRF_NB) {                                                                           \
+                if (bits_ == FLOW_X_PENDING) {                                                                      \
+                    /* THREE polls in flight, a new one every ~100 ns: a poll is a round trip to memory (the other XCDs' L2s are not      \
+                       coherent with this one), and with one at a time the value is seen half a round trip late on average */           \
+                    unsigned spins_ = 0;                                                                            \
+                    long long t_begin_ = 0;                     /* (the clock is a scalar memory read: not on the way in) */ \
+                    unsigned long long b0_ = __hip_atomic_load(px_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    \
+                    __builtin_amdgcn_s_sleep(3);                                                                    \
+                    unsigned long long b1_ = __hip_atomic_load(px_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    \
+                    __builtin_amdgcn_s_sleep(3);                                                                    \
+                    for (;;) {                                                                                      \
+                        const unsigned long long b2_ = __hip_atomic_load(px_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                        bits_ = b0_; b0_ = b1_; b1_ = b2_;                                                          \
+                        if (bits_ != FLOW_X_PENDING) break;                                                         \
+                        __builtin_amdgcn_s_sleep(3);                                                                \
+                        if ((++spins_ & 255u) == 0u) {                                                              \
+                            const long long now_ = wall_clock64();                                                  \
+                            if (t_begin_ == 0) t_begin_ = now_;                                                     \
+                            if (now_ - t_begin_ > spin_limit || __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { atomicExch(timeout, 1); break; } \
+                        }                                                                                           \
+                    }                                                                                               \
+                }                                                                                                   \
+                xi[(J_) & 1][threadIdx.x] = __builtin_bit_cast(double, bits_);                                      \
+            }                                                                                                       \
+            __syncthreads();                                                                                        \
+        } else {                                                                                                    \
+            const int seen_ = __hip_atomic_load(&flags[i_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == flagval; \
+            BSFM_BWD_LOAD(NXT_, (J_) + 1)                                                                           \
+            if (threadIdx.x == 0 && !seen_) {                                                                       \
+                unsigned spins_ = 0;                                                                                \
+                const long long t_begin_ = wall_clock64();                                                          \
+                while (__hip_atomic_load(&flags[i_], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != flagval) {      \
+                    __builtin_amdgcn_s_sleep(2);                                                                    \
+                    if ((++spins_ & 63u) == 0u && (wall_clock64() - t_begin_ > spin_limit || __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { \
+                        atomicExch(timeout, 1); break;              /* a bounded wait: the solve reports POTRF_INFO_TIMEOUT instead of hanging */ \
+                    }                                                                                               \
+                }                                                                                                   \
+            }                                                                                                       \
+            __syncthreads();                                                                                        \
+            if (threadIdx.x < POTRF_NB)                                                                             \
+                xi[(J_) & 1][threadIdx.x] = __hip_atomic_load(&x[(size_t)i_ * POTRF_NB + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+            __syncthreads();                                                                                        \
+        }                                                                                                           \
+        /* this thread's share of sum_i P_i,kk^T x_i stays in its registers until the column is finished (four chains: a single one is 64   \
+           dependent FMAs, 0.25 us of every hand-off); xi is double-buffered, so a step costs ONE barrier */                              \
+        const double* xv_ = xi[(J_) & 1] + 64 * h;                                                                  \
+        _Pragma("unroll") for (int r = 0; r < 64; r += 4) {                                                         \
+            part0 = fma(CUR_[r], xv_[r], part0); part1 = fma(CUR_[r + 1], xv_[r + 1], part1);                       \
+            part2 = fma(CUR_[r + 2], xv_[r + 2], part2); part3 = fma(CUR_[r + 3], xv_[r + 3], part3);               \
+        }                                                                                                           \
+    }
+    double part0 = 0.0, part1 = 0.0, part2 = 0.0, part3 = 0.0;
+    BSFM_BWD_LOAD(ta, 0)
+    for (int j = 0; j < nstep; j += 2) {
+        BSFM_BWD_STEP(ta, tb, j)
+        if (j + 1 < nstep) BSFM_BWD_STEP(tb, ta, j + 1)
+    }
+#undef BSFM_BWD_STEP
+#undef BSFM_BWD_LOAD
+    // y_kk - the two halves' sums, then x_kk = W_kk^T of it
+    const double part = (part0 + part1) + (part2 + part3);
+    if (h == 1) red[c] = part;
+    __syncthreads();
+    if (h == 0) yk[c] -= part + red[c];
+    __syncthreads();
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    {
+        const double* yv = yk + 64 * h;
+        if (nstep & 1) {
 #pragma unroll
-    for (int r = 0; r < 64; ++r) sacc += lreg[r] * yk[64 * h + r];
+            for (int r = 0; r < 64; r += 4) { s0 = fma(tb[r], yv[r], s0); s1 = fma(tb[r + 1], yv[r + 1], s1); s2 = fma(tb[r + 2], yv[r + 2], s2); s3 = fma(tb[r + 3], yv[r + 3], s3); }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 64; r += 4) { s0 = fma(ta[r], yv[r], s0); s1 = fma(ta[r + 1], yv[r + 1], s1); s2 = fma(ta[r + 2], yv[r + 2], s2); s3 = fma(ta[r + 3], yv[r + 3], s3); }
+        }
+    }
+    const double sacc = (s0 + s1) + (s2 + s3);
+    __syncthreads();                                     // (red is read above by the other half)
     if (h == 1) red[c] = sacc;
     __syncthreads();
+    if (x_is_flag) {      // (stall_col: test hook, a column that never arrives)
+        if (h == 0 && kk != stall_col) __hip_atomic_store(&x[(size_t)kk * POTRF_NB + c], sacc + red[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     if (h == 0) {
         const double v = sacc + red[c];
         __hip_atomic_store(&x[(size_t)kk * POTRF_NB + c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1115,9 +1186,11 @@ __global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc,
 __global__ __launch_bounds__(256) void k_flow_begin(unsigned* __restrict__ sync, unsigned sync_words, int* __restrict__ bflags, int nbflags,
                                                     double* __restrict__ etmp, const double* __restrict__ E, int n, int ld,
                                                     unsigned genbase = 0u, unsigned nflags = 0u /* distributed: the per-tile counters start at genbase;
-                                                                                                   the backward flags keep their generations (nbflags = the time-out word only) */)
+                                                                                                   the backward flags keep their generations (nbflags = the time-out word only) */,
+                                                    unsigned long long* __restrict__ x_pending = nullptr /* one rank: the solution vector, filled with FLOW_X_PENDING */)
 {
     const unsigned stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x_pending) for (unsigned q = t0; q < (unsigned)ld; q += stride) x_pending[q] = FLOW_X_PENDING;
     for (unsigned q = t0; q < sync_words; q += stride) sync[q] = (q >= 8u && q < 8u + nflags) ? genbase : 0u;
     for (unsigned q = t0; q < (unsigned)nbflags; q += stride) bflags[q] = 0;
     for (unsigned q = t0; q < (unsigned)ld; q += stride) etmp[q] = q < (unsigned)n ? E[q] : 0.0;
@@ -1359,7 +1432,7 @@ inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, in
     if (flow_prepare(f, nblk, w.env_rows) != 0) return -1;
     const size_t nt = f.sched.tasks.size();
     hipLaunchKernelGGL(k_flow_begin, dim3((unsigned)std::min<size_t>(64, (std::max<size_t>(f.sync_words, (size_t)ld) + 255) / 256)), dim3(256), 0, st,
-                       f.d_sync, (unsigned)f.sync_words, w.bflags, w.nblk + 1, w.etmp, E, n, ld);
+                       f.d_sync, (unsigned)f.sync_words, w.bflags, w.nblk + 1, w.etmp, E, n, ld, 0u, 0u, reinterpret_cast<unsigned long long*>(w.xs));
     FlowArgs a;
     memset(&a, 0, sizeof a);      // (genbase = 0, peers = nullptr: one rank)
     a.S = S; a.ld = ld; a.n_total = n; a.T = nblk; a.Pc = f.pc; a.Linv = w.linv; a.E = w.etmp; a.y = w.y;
@@ -1389,7 +1462,7 @@ inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, in
     for (int first = 0; first < nblk; first += POTRF_MAX_TILES)
         hipLaunchKernelGGL(k_bwd_flow, dim3(std::min(POTRF_MAX_TILES, nblk - first)), dim3(256), 0, st, (const double*)f.pc, nblk, first,
                            (const double*)w.linv, (const double*)w.y, w.xs, w.bflags, w.bflags + w.nblk, (const int*)(env ? w.d_last : nullptr),
-                           f.spin_limit, f.stall_bwd_col);
+                           f.spin_limit, f.stall_bwd_col, (const FlowPeers*)nullptr, 1, 1);
     hipLaunchKernelGGL(k_flow_end, dim3((unsigned)std::min(64, (n + 255) / 256)), dim3(256), 0, st, (const unsigned*)f.d_sync, (const int*)(w.bflags + w.nblk),
                        d_info, (const double*)w.xs, x_out, n);
     if (f.trace) flow_dump_trace(f, st);
