@@ -370,14 +370,26 @@ __global__ __launch_bounds__(256) void k_point_blocks(DevProblem P, const double
     if (i < P.n) {
         double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, g0 = 0, g1 = 0, g2 = 0;
         const int k1 = P.rowptr[i + 1];
-        for (int k = P.rowptr[i]; k < k1; ++k) {
-            double R[8];                                                   // B (2 x 3) || e: one 64-byte sector
-            load_pairs<4>(P.Bc + (size_t)P.campos[k] * 8, R);
-            const double b0 = R[0], b1 = R[1], b2 = R[2], b3 = R[3], b4 = R[4], b5 = R[5];
-            const double e0 = R[6], e1 = R[7];
-            v00 += b0 * b0 + b3 * b3; v01 += b0 * b1 + b3 * b4; v02 += b0 * b2 + b3 * b5;
-            v11 += b1 * b1 + b4 * b4; v12 += b1 * b2 + b4 * b5; v22 += b2 * b2 + b5 * b5;
-            g0 += b0 * e0 + b3 * e1; g1 += b1 * e0 + b4 * e1; g2 += b2 * e0 + b5 * e1;
+        // four observations at a time (round 6): positions first, then the four records, then the sums in the row's order -- one record per trip
+        // is a chain of 2 d_i dependent loads, which is what a 14-camera problem (6 workgroups) waits for.  Past the row's end the last position is
+        // read again and its terms are dropped: the loads stay unconditional (the compiler can count them), the sums bit-identical.
+        for (int k = P.rowptr[i]; k < k1; k += 4) {
+            int pos[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pos[u] = P.campos[min(k + u, k1 - 1)];
+            double R[4][8];                                                // B (2 x 3) || e: one 64-byte sector each
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load_pairs<4>(P.Bc + (size_t)pos[u] * 8, R[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (k + u < k1) {
+                    const double b0 = R[u][0], b1 = R[u][1], b2 = R[u][2], b3 = R[u][3], b4 = R[u][4], b5 = R[u][5];
+                    const double e0 = R[u][6], e1 = R[u][7];
+                    v00 += b0 * b0 + b3 * b3; v01 += b0 * b1 + b3 * b4; v02 += b0 * b2 + b3 * b5;
+                    v11 += b1 * b1 + b4 * b4; v12 += b1 * b2 + b4 * b5; v22 += b2 * b2 + b5 * b5;
+                    g0 += b0 * e0 + b3 * e1; g1 += b1 * e0 + b4 * e1; g2 += b2 * e0 + b5 * e1;
+                }
+            }
         }
         if (P.pcon && P.pcon[i]) {   // sba_levmar.c:1017-1028 (weights scale with the job-wide nvis)
             const double w = P.nvis_global * P.pweight;
@@ -832,7 +844,7 @@ __global__ __launch_bounds__(256) void k_backsub_obs(int nvis, int mcon, const i
 // ---------------------------------------------------------------------------------------------------
 // db_i = V*_i^-1 (eb_i - sum_j W_ij^T da_j), W_ij^T da_j = B_ij^T (A_ij da_j); thread per point.
 // Also writes pdp_b = p_b + db and block partials of sum db^2, sum p_b^2 and sum db (mu db + eb).
-template <int CNP>
+template <int CNP, bool TWO_PASS /* the per-observation products come from k_backsub_obs (wobs); false: computed here */>
 __global__ __launch_bounds__(256) void k_backsub(DevProblem P, double mu, const double* __restrict__ dpa,
         const double* __restrict__ pb, double* __restrict__ dpb, double* __restrict__ pdpb,
         double* __restrict__ part /* [3][gridDim.x] */, double* __restrict__ ptc_out /* camera-major mirror of pdpb, or null */,
@@ -846,25 +858,36 @@ __global__ __launch_bounds__(256) void k_backsub(DevProblem P, double mu, const 
         const double* g = P.eb + (size_t)i * 3;
         double w0 = 0, w1 = 0, w2 = 0;
         const int k1 = P.rowptr[i + 1];
-        if (wobs) {
+        if (TWO_PASS) {
             for (int k = P.rowptr[i]; k < k1; ++k) {
                 const double2* wk = reinterpret_cast<const double2*>(wobs) + 2 * (size_t)P.campos[k];
                 const double2 a = wk[0], b = wk[1];
                 w0 += a.x; w1 += a.y; w2 += b.x;             // (a fixed camera's product is +0.0: the sum is what the skip below leaves)
             }
         } else
-        for (int k = P.rowptr[i]; k < k1; ++k) {
-            const int j = P.obs_cam[k];
-            if (j < P.mcon) continue;
-            const int t = P.campos[k];
-            double A[2 * CNP], B[6];
-            load_pairs<CNP>(P.Ac + (size_t)t * 2 * CNP, A);
-            load_pairs<3>(P.Bc + (size_t)t * 8, B);
-            const double* da = dpa + (size_t)j * CNP;
-            double q0 = 0, q1 = 0;
+        // the one-pass form of the small problems, TWO observations at a time (round 6; see k_point_blocks): camera and position of both, then both
+        // records and both camera steps, then the products in the row's order
+        for (int k = P.rowptr[i]; k < k1; k += 2) {
+            int jj[2], tt[2];
 #pragma unroll
-            for (int c = 0; c < CNP; ++c) { q0 += A[2 * c] * da[c]; q1 += A[2 * c + 1] * da[c]; }
-            w0 += B[0] * q0 + B[3] * q1; w1 += B[1] * q0 + B[4] * q1; w2 += B[2] * q0 + B[5] * q1;
+            for (int u = 0; u < 2; ++u) { const int kc = min(k + u, k1 - 1); jj[u] = P.obs_cam[kc]; tt[u] = P.campos[kc]; }
+            double A[2][2 * CNP], B[2][6], da[2][CNP];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                load_pairs<CNP>(P.Ac + (size_t)tt[u] * 2 * CNP, A[u]);
+                load_pairs<3>(P.Bc + (size_t)tt[u] * 8, B[u]);
+#pragma unroll
+                for (int c = 0; c < CNP; ++c) da[u][c] = dpa[(size_t)jj[u] * CNP + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (k + u < k1 && jj[u] >= P.mcon) {
+                    double q0 = 0, q1 = 0;
+#pragma unroll
+                    for (int c = 0; c < CNP; ++c) { q0 += A[u][2 * c] * da[u][c]; q1 += A[u][2 * c + 1] * da[u][c]; }
+                    w0 += B[u][0] * q0 + B[u][3] * q1; w1 += B[u][1] * q0 + B[u][4] * q1; w2 += B[u][2] * q0 + B[u][5] * q1;
+                }
+            }
         }
         const double r0 = g[0] - w0, r1 = g[1] - w1, r2 = g[2] - w2;
         const double* vi = P.Vinv + (size_t)i * 6;

@@ -1467,8 +1467,13 @@ static int lm_iterate_impl(bsfm_problem_t* pb, int iters)
                                                           (const int*)pb->d_cam_cam, (const double*)pb->d_Ac, (const double*)pb->d_Bc, (const double*)d_dpa, pb->d_Cc));
                     wobs = pb->d_Cc;
                 }
-                DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_backsub<C>), dim3(nbp), dim3(256), 0, pb->stream, P, mu, d_dpa, d_pb, d_dpb, d_pdpb, pb->d_red, pb->d_ptc[ms],
-                                                      wobs, pb->d_tickets + 2, fa));
+                if (wobs) {
+                    DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_backsub<C, true>), dim3(nbp), dim3(256), 0, pb->stream, P, mu, d_dpa, d_pb, d_dpb, d_pdpb, pb->d_red, pb->d_ptc[ms],
+                                                          wobs, pb->d_tickets + 2, fa));
+                } else {
+                    DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_backsub<C, false>), dim3(nbp), dim3(256), 0, pb->stream, P, mu, d_dpa, d_pb, d_dpb, d_pdpb, pb->d_red, pb->d_ptc[ms],
+                                                          wobs, pb->d_tickets + 2, fa));
+                }
                 if (!table_in_backsub) launch_cam_table(pb, pb->d_pdp, pb->d_camtab_trial);
                 pb->ptc_tag[ms] = pb->d_pdp;
             } else {
