@@ -354,35 +354,49 @@ struct IterFinalArgs {       // what the finishing workgroup needs
     const double* pa; int have_points, point_part_slot;
     int s_eabinf_a, s_eabinf_b, s_maxdiag_u, s_maxdiag_v, s_pl2_a, s_pl2_b, s_ccost;
     double* scal;
+    int point_blocks;      // workgroups of k_point_blocks that do points; ONE MORE behind them does the camera side of the scalars (0: the grid is points only)
 };
 __device__ __forceinline__ void iter_final_body(const DevProblem& P, const double* __restrict__ pa, const double* __restrict__ pb,
         const double* __restrict__ part, int nparts, int have_points, int point_part_slot,
         int s_eabinf_a, int s_eabinf_b, int s_maxdiag_u, int s_maxdiag_v, int s_pl2_a, int s_pl2_b, int s_ccost,
-        double* __restrict__ scal, bool agent_loads);
+        double* __restrict__ scal, bool agent_loads, int which = 3 /* bit 0: the point side's partials, bit 1: the camera side and the constraint cost */);
 
-template <int CNP>
+// LPP lanes per point (round 6): 1 = a thread walks its point's row, four observations per trip (positions first, then the four records; past the
+// row's end the last position is read again and its terms dropped, so the loads stay unconditional); 4 = the small problems, where the kernel is
+// nothing but the latency of that chain of dependent gathers (see k_backsub): lane q takes observations q, q + 4, q + 8 -- one trip for up to twelve --
+// and the quad adds its partial sums in a fixed order.  With part != nullptr the camera side of the iteration's scalars is done by one more workgroup
+// behind the points' (beside them, not after them: it needs U and ea of the kernel before, nothing of this one).
+constexpr int PB_TRIP = 3;
+template <int CNP, int LPP>
 __global__ __launch_bounds__(256) void k_point_blocks(DevProblem P, const double* __restrict__ pb,
-        double* __restrict__ part = nullptr /* [3][gridDim.x] */, unsigned* __restrict__ ticket = nullptr, unsigned* __restrict__ ticket_groups = nullptr,
+        double* __restrict__ part = nullptr /* [3][point blocks] */, unsigned* __restrict__ ticket = nullptr, unsigned* __restrict__ ticket_groups = nullptr,
         IterFinalArgs fa = IterFinalArgs(), int* __restrict__ flags_to_clear = nullptr)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int nbp = part ? fa.point_blocks : (int)gridDim.x;
+    if ((int)blockIdx.x >= nbp) {
+        iter_final_body(P, fa.pa, pb, part, nbp, fa.have_points, fa.point_part_slot, fa.s_eabinf_a, fa.s_eabinf_b, fa.s_maxdiag_u, fa.s_maxdiag_v,
+                        fa.s_pl2_a, fa.s_pl2_b, fa.s_ccost, fa.scal, true, 2);
+        return;
+    }
+    const int gi = blockIdx.x * 256 + threadIdx.x;
+    const int ireal = gi / LPP, q = gi % LPP;
+    const bool active = ireal < P.n && q == 0;
+    const int i = ireal < P.n ? ireal : P.n - 1;             // (quads past the end compute along: the quad sums need every lane)
     double it_a = 0.0, it_v = -DBL_MAX, it_s = 0.0;
-    if (i < P.n) {
+    {
         double v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, g0 = 0, g1 = 0, g2 = 0;
-        const int k1 = P.rowptr[i + 1];
-        // four observations at a time (round 6): positions first, then the four records, then the sums in the row's order -- one record per trip
-        // is a chain of 2 d_i dependent loads, which is what a 14-camera problem (6 workgroups) waits for.  Past the row's end the last position is
-        // read again and its terms are dropped: the loads stay unconditional (the compiler can count them), the sums bit-identical.
-        for (int k = P.rowptr[i]; k < k1; k += 4) {
-            int pos[4];
+        const int k0 = P.rowptr[i], k1 = P.rowptr[i + 1];
+        constexpr int TRIP = LPP == 1 ? 4 : PB_TRIP;
+        for (int kb = k0; kb < k1; kb += LPP * TRIP) {
+            int pos[TRIP];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) pos[u] = P.campos[min(k + u, k1 - 1)];
-            double R[4][8];                                                // B (2 x 3) || e: one 64-byte sector each
+            for (int u = 0; u < TRIP; ++u) pos[u] = P.campos[min(kb + LPP * u + q, k1 - 1)];
+            double R[TRIP][8];                                             // B (2 x 3) || e: one 64-byte sector each
 #pragma unroll
-            for (int u = 0; u < 4; ++u) load_pairs<4>(P.Bc + (size_t)pos[u] * 8, R[u]);
+            for (int u = 0; u < TRIP; ++u) load_pairs<4>(P.Bc + (size_t)pos[u] * 8, R[u]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (k + u < k1) {
+            for (int u = 0; u < TRIP; ++u) {
+                if (kb + LPP * u + q < k1) {
                     const double b0 = R[u][0], b1 = R[u][1], b2 = R[u][2], b3 = R[u][3], b4 = R[u][4], b5 = R[u][5];
                     const double e0 = R[u][6], e1 = R[u][7];
                     v00 += b0 * b0 + b3 * b3; v01 += b0 * b1 + b3 * b4; v02 += b0 * b2 + b3 * b5;
@@ -391,34 +405,41 @@ __global__ __launch_bounds__(256) void k_point_blocks(DevProblem P, const double
                 }
             }
         }
-        if (P.pcon && P.pcon[i]) {   // sba_levmar.c:1017-1028 (weights scale with the job-wide nvis)
-            const double w = P.nvis_global * P.pweight;
-            v00 += w; v11 += w; v22 += w;
-            g0 += w * (P.pval[3 * i] - pb[3 * i]);
-            g1 += w * (P.pval[3 * i + 1] - pb[3 * i + 1]);
-            g2 += w * (P.pval[3 * i + 2] - pb[3 * i + 2]);
+        if (LPP == 4) {
+#define BSFM_QSUM(x) x = (quad_bcast_d<0>(x) + quad_bcast_d<1>(x)) + (quad_bcast_d<2>(x) + quad_bcast_d<3>(x))
+            BSFM_QSUM(v00); BSFM_QSUM(v01); BSFM_QSUM(v02); BSFM_QSUM(v11); BSFM_QSUM(v12); BSFM_QSUM(v22); BSFM_QSUM(g0); BSFM_QSUM(g1); BSFM_QSUM(g2);
+#undef BSFM_QSUM
         }
-        double* V = P.V + (size_t)i * 6;
-        V[0] = v00; V[1] = v01; V[2] = v02; V[3] = v11; V[4] = v12; V[5] = v22;
-        double* g = P.eb + (size_t)i * 3;
-        g[0] = g0; g[1] = g1; g[2] = g2;
-        if (part) {
-            const double a0 = fabs(g0), a1 = fabs(g1), a2 = fabs(g2);
-            it_a = a0 > a1 ? a0 : a1; it_a = it_a > a2 ? it_a : a2;
-            it_v = v00 > v11 ? v00 : v11; it_v = it_v > v22 ? it_v : v22;
-            const double p0 = pb[3 * (size_t)i], p1 = pb[3 * (size_t)i + 1], p2 = pb[3 * (size_t)i + 2];
-            it_s = p0 * p0 + p1 * p1 + p2 * p2;
+        if (active) {
+            if (P.pcon && P.pcon[i]) {   // sba_levmar.c:1017-1028 (weights scale with the job-wide nvis)
+                const double w = P.nvis_global * P.pweight;
+                v00 += w; v11 += w; v22 += w;
+                g0 += w * (P.pval[3 * i] - pb[3 * i]);
+                g1 += w * (P.pval[3 * i + 1] - pb[3 * i + 1]);
+                g2 += w * (P.pval[3 * i + 2] - pb[3 * i + 2]);
+            }
+            double* V = P.V + (size_t)i * 6;
+            V[0] = v00; V[1] = v01; V[2] = v02; V[3] = v11; V[4] = v12; V[5] = v22;
+            double* g = P.eb + (size_t)i * 3;
+            g[0] = g0; g[1] = g1; g[2] = g2;
+            if (part) {
+                const double a0 = fabs(g0), a1 = fabs(g1), a2 = fabs(g2);
+                it_a = a0 > a1 ? a0 : a1; it_a = it_a > a2 ? it_a : a2;
+                it_v = v00 > v11 ? v00 : v11; it_v = it_v > v22 ? it_v : v22;
+                const double p0 = pb[3 * (size_t)i], p1 = pb[3 * (size_t)i + 1], p2 = pb[3 * (size_t)i + 2];
+                it_s = p0 * p0 + p1 * p1 + p2 * p2;
+            }
         }
     }
     if (!part) return;
     __shared__ double sm[4];
     const double ra = block_max4(it_a, sm), rv = block_max4(it_v, sm), rs = block_sum4(it_s, sm);
     if (threadIdx.x == 0) {
-        st_agent(part + blockIdx.x, ra); st_agent(part + (size_t)gridDim.x + blockIdx.x, rv); st_agent(part + 2 * (size_t)gridDim.x + blockIdx.x, rs);
+        st_agent(part + blockIdx.x, ra); st_agent(part + (size_t)nbp + blockIdx.x, rv); st_agent(part + 2 * (size_t)nbp + blockIdx.x, rs);
     }
-    if (!last_block_arrives(ticket, gridDim.x, ticket_groups)) return;
-    iter_final_body(P, fa.pa, pb, part, (int)gridDim.x, fa.have_points, fa.point_part_slot, fa.s_eabinf_a, fa.s_eabinf_b, fa.s_maxdiag_u, fa.s_maxdiag_v,
-                    fa.s_pl2_a, fa.s_pl2_b, fa.s_ccost, fa.scal, true);
+    if (!last_block_arrives(ticket, (unsigned)nbp, ticket_groups)) return;
+    iter_final_body(P, fa.pa, pb, part, nbp, fa.have_points, fa.point_part_slot, fa.s_eabinf_a, fa.s_eabinf_b, fa.s_maxdiag_u, fa.s_maxdiag_v,
+                    fa.s_pl2_a, fa.s_pl2_b, fa.s_ccost, fa.scal, true, 1);
     if (flags_to_clear && threadIdx.x < 4) flags_to_clear[threadIdx.x] = 0;
 }
 
@@ -774,28 +795,42 @@ __device__ __forceinline__ void step_sums_body(int count, int fixed, double mu, 
         const double* __restrict__ dpa, const double* __restrict__ ea, double* __restrict__ pdpa, double* __restrict__ out3,
         const double* __restrict__ part, int nbp, double* __restrict__ pt3, bool agent_loads)
 {
-    __shared__ double sm[4];
+    __shared__ double sm[6][4];
     double s_dp = 0, s_p = 0, s_dl = 0;
     for (int t = threadIdx.x; t < count; t += 256) {
         const double d = (t < fixed) ? 0.0 : dpa[t], p = pa[t];
         pdpa[t] = p + d;
         s_dp += d * d; s_p += p * p; s_dl += d * (mu * d + ea[t]);
     }
-    const double r0 = block_sum4(s_dp, sm), r1 = block_sum4(s_p, sm), r2 = block_sum4(s_dl, sm);
-    double q[3];
+    double v[6] = { s_dp, s_p, s_dl, 0.0, 0.0, 0.0 };
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        double s = 0.0;
+        double a = 0.0;
 #pragma unroll 8
-        for (int t = threadIdx.x; t < nbp; t += 256) s += agent_loads ? ld_agent(part + (size_t)c * nbp + t) : part[(size_t)c * nbp + t];
-        q[c] = block_sum4(s, sm);
+        for (int t = threadIdx.x; t < nbp; t += 256) a += agent_loads ? ld_agent(part + (size_t)c * nbp + t) : part[(size_t)c * nbp + t];
+        v[3 + c] = a;
     }
+    // six block sums through ONE exchange (round 6: six block_sum4 were twelve barriers on the way to every trial point of a small problem); the
+    // order inside each sum is block_sum4's: lanes of a wave, then (w0 + w1) + (w2 + w3)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v[c] = wave_sum(v[c]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) sm[c][threadIdx.x >> 6] = v[c];
+    }
+    __syncthreads();
+    const double r0 = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]), r1 = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]), r2 = (sm[2][0] + sm[2][1]) + (sm[2][2] + sm[2][3]);
+    double q[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) q[c] = (sm[3 + c][0] + sm[3 + c][1]) + (sm[3 + c][2] + sm[3 + c][3]);
     if (threadIdx.x == 0) { out3[0] = r0; out3[1] = r1; out3[2] = r2; pt3[0] = q[0]; pt3[1] = q[1]; pt3[2] = q[2]; }
 }
 struct StepFinalArgs {       // k_step_sums' and k_cam_table's arguments, for the workgroup of k_backsub that arrives last
     int count, fixed; const double* pa; double* pdpa; double* out3; double* pt3;
     const double* known; int with_fd; double* camtab_trial;
     unsigned* ticket_groups;      // last_block_arrives' group words for this grid (null: one level)
+    int point_blocks;             // workgroups of k_backsub that do points; one more behind them builds the trial point's camera table (camtab_trial != null)
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -844,87 +879,118 @@ __global__ __launch_bounds__(256) void k_backsub_obs(int nvis, int mcon, const i
 // ---------------------------------------------------------------------------------------------------
 // db_i = V*_i^-1 (eb_i - sum_j W_ij^T da_j), W_ij^T da_j = B_ij^T (A_ij da_j); thread per point.
 // Also writes pdp_b = p_b + db and block partials of sum db^2, sum p_b^2 and sum db (mu db + eb).
+// Round 6, the small problems (one-pass form, below 200 000 observations) are latency: a 14-camera problem is 6 workgroups whose threads each walked
+// a chain of 2 d_i dependent gathers, every one a miss of the XCD's L2 (the records were written on other XCDs): 12.7 us of a 26 us kernel, and the
+// last workgroup then spent 6.3 us on the trial point's camera table (profiles/r06_small_problem_latency.txt).  Now FOUR lanes share a point -- lane q
+// takes observations q, q + 4, q + 8 of the row, three per trip: positions, then records, one trip for up to 12 observations; the quad adds its four
+// partial products in a fixed order -- and the camera table is built by ONE MORE workgroup at the end of the grid, beside the gathers instead of behind
+// them (it needs p_a + dp_a only, which it forms itself).
+constexpr int BS_LANES = 4, BS_TRIP = 3;
+constexpr int BS_TABLE_MAX = 256 * 9;      // camera parameters the table workgroup stages in LDS (the host builds the table here below 256 cameras)
 template <int CNP, bool TWO_PASS /* the per-observation products come from k_backsub_obs (wobs); false: computed here */>
 __global__ __launch_bounds__(256) void k_backsub(DevProblem P, double mu, const double* __restrict__ dpa,
         const double* __restrict__ pb, double* __restrict__ dpb, double* __restrict__ pdpb,
-        double* __restrict__ part /* [3][gridDim.x] */, double* __restrict__ ptc_out /* camera-major mirror of pdpb, or null */,
+        double* __restrict__ part /* [3][fa.point_blocks] */, double* __restrict__ ptc_out /* camera-major mirror of pdpb, or null */,
         const double* __restrict__ wobs /* k_backsub_obs' products (camera-major), or null: computed here */,
         unsigned* __restrict__ ticket /* null: k_step_sums and k_cam_table follow */, StepFinalArgs fa)
 {
     __shared__ double sm[3][4];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int nbp = fa.point_blocks;
+    if ((int)blockIdx.x >= nbp) {
+        // ---- the table workgroup: trial camera parameters into LDS, then the four parts of every camera's row
+        __shared__ double s_pd[BS_TABLE_MAX];
+        for (int t = threadIdx.x; t < fa.count; t += 256) s_pd[t] = fa.pa[t] + ((t < fa.fixed) ? 0.0 : dpa[t]);      // = pdp_a as step_sums_body forms it
+        __syncthreads();
+        for (int t = threadIdx.x; t < P.m * CT_PARTS; t += 256)
+            cam_table_part(P.cfg, t % P.m, t / P.m, s_pd, P.Rinit, P.finit, fa.known, fa.with_fd, fa.camtab_trial);
+        return;
+    }
+    constexpr int LPP = TWO_PASS ? 1 : BS_LANES;
+    const int gi = blockIdx.x * 256 + threadIdx.x;
+    const int ireal = gi / LPP, q = gi % LPP;
+    const bool active = ireal < P.n && q == 0;               // the lane that owns the point's results
+    const int i = ireal < P.n ? ireal : P.n - 1;             // (the other lanes of a quad, and quads past the end, compute along: the quad sums need every lane)
     double s_dp = 0.0, s_p = 0.0, s_dl = 0.0;
-    if (i < P.n) {
+    {
         const double* g = P.eb + (size_t)i * 3;
         double w0 = 0, w1 = 0, w2 = 0;
-        const int k1 = P.rowptr[i + 1];
+        const int k0 = P.rowptr[i], k1 = P.rowptr[i + 1];
+        // (everything that does not depend on the sum below is requested in front of it: the loop is a chain of dependent gathers)
+        const double g0 = g[0], g1 = g[1], g2 = g[2];
+        const double* vi = P.Vinv + (size_t)i * 6;
+        const double vi0 = vi[0], vi1 = vi[1], vi2 = vi[2], vi3 = vi[3], vi4 = vi[4], vi5 = vi[5];
+        const double p0 = pb[3 * (size_t)i], p1 = pb[3 * (size_t)i + 1], p2 = pb[3 * (size_t)i + 2];
         if (TWO_PASS) {
-            for (int k = P.rowptr[i]; k < k1; ++k) {
+            for (int k = k0; k < k1; ++k) {
                 const double2* wk = reinterpret_cast<const double2*>(wobs) + 2 * (size_t)P.campos[k];
                 const double2 a = wk[0], b = wk[1];
                 w0 += a.x; w1 += a.y; w2 += b.x;             // (a fixed camera's product is +0.0: the sum is what the skip below leaves)
             }
-        } else
-        // the one-pass form of the small problems, TWO observations at a time (round 6; see k_point_blocks): camera and position of both, then both
-        // records and both camera steps, then the products in the row's order
-        for (int k = P.rowptr[i]; k < k1; k += 2) {
-            int jj[2], tt[2];
+        } else {
+            for (int kb = k0; kb < k1; kb += BS_LANES * BS_TRIP) {
+                int jj[BS_TRIP], tt[BS_TRIP];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { const int kc = min(k + u, k1 - 1); jj[u] = P.obs_cam[kc]; tt[u] = P.campos[kc]; }
-            double A[2][2 * CNP], B[2][6], da[2][CNP];
+                for (int u = 0; u < BS_TRIP; ++u) { const int kc = min(kb + BS_LANES * u + q, k1 - 1); jj[u] = P.obs_cam[kc]; tt[u] = P.campos[kc]; }
+                double A[BS_TRIP][2 * CNP], B[BS_TRIP][6], da[BS_TRIP][CNP];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                load_pairs<CNP>(P.Ac + (size_t)tt[u] * 2 * CNP, A[u]);
-                load_pairs<3>(P.Bc + (size_t)tt[u] * 8, B[u]);
+                for (int u = 0; u < BS_TRIP; ++u) {
+                    load_pairs<CNP>(P.Ac + (size_t)tt[u] * 2 * CNP, A[u]);
+                    load_pairs<3>(P.Bc + (size_t)tt[u] * 8, B[u]);
 #pragma unroll
-                for (int c = 0; c < CNP; ++c) da[u][c] = dpa[(size_t)jj[u] * CNP + c];
+                    for (int c = 0; c < CNP; ++c) da[u][c] = dpa[(size_t)jj[u] * CNP + c];
+                }
+#pragma unroll
+                for (int u = 0; u < BS_TRIP; ++u) {
+                    if (kb + BS_LANES * u + q < k1 && jj[u] >= P.mcon) {
+                        double q0 = 0, q1 = 0;
+#pragma unroll
+                        for (int c = 0; c < CNP; ++c) { q0 += A[u][2 * c] * da[u][c]; q1 += A[u][2 * c + 1] * da[u][c]; }
+                        w0 += B[u][0] * q0 + B[u][3] * q1; w1 += B[u][1] * q0 + B[u][4] * q1; w2 += B[u][2] * q0 + B[u][5] * q1;
+                    }
+                }
             }
+            // the quad's four partial sums in a fixed order; every lane ends up with the point's sum
+            w0 = (quad_bcast_d<0>(w0) + quad_bcast_d<1>(w0)) + (quad_bcast_d<2>(w0) + quad_bcast_d<3>(w0));
+            w1 = (quad_bcast_d<0>(w1) + quad_bcast_d<1>(w1)) + (quad_bcast_d<2>(w1) + quad_bcast_d<3>(w1));
+            w2 = (quad_bcast_d<0>(w2) + quad_bcast_d<1>(w2)) + (quad_bcast_d<2>(w2) + quad_bcast_d<3>(w2));
+        }
+        const double r0 = g0 - w0, r1 = g1 - w1, r2 = g2 - w2;
+        const double d0 = vi0 * r0 + vi1 * r1 + vi2 * r2;
+        const double d1 = vi1 * r0 + vi3 * r1 + vi4 * r2;
+        const double d2 = vi2 * r0 + vi4 * r1 + vi5 * r2;
+        if (active) {
+            dpb[3 * (size_t)i] = d0; dpb[3 * (size_t)i + 1] = d1; dpb[3 * (size_t)i + 2] = d2;
+            pdpb[3 * (size_t)i] = p0 + d0; pdpb[3 * (size_t)i + 1] = p1 + d1; pdpb[3 * (size_t)i + 2] = p2 + d2;
+        }
+        if (ptc_out && ireal < P.n) {      // the trial point to the camera-major positions of its observations (32-byte records; campos[] is L1 / L2 warm)
+            const double2 v01 = make_double2(p0 + d0, p1 + d1), v2 = make_double2(p2 + d2, 0.0);
+            for (int k = k0 + 4 * q; k < k1; k += 4 * LPP) {      // four positions per trip and lane (past the end: the last one again -- the same record twice)
+                int pos[4];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (k + u < k1 && jj[u] >= P.mcon) {
-                    double q0 = 0, q1 = 0;
+                for (int u = 0; u < 4; ++u) pos[u] = P.campos[min(k + u, k1 - 1)];
 #pragma unroll
-                    for (int c = 0; c < CNP; ++c) { q0 += A[u][2 * c] * da[u][c]; q1 += A[u][2 * c + 1] * da[u][c]; }
-                    w0 += B[u][0] * q0 + B[u][3] * q1; w1 += B[u][1] * q0 + B[u][4] * q1; w2 += B[u][2] * q0 + B[u][5] * q1;
+                for (int u = 0; u < 4; ++u) {
+                    double2* dst = reinterpret_cast<double2*>(ptc_out) + 2 * (size_t)pos[u];
+                    dst[0] = v01; dst[1] = v2;
                 }
             }
         }
-        const double r0 = g[0] - w0, r1 = g[1] - w1, r2 = g[2] - w2;
-        const double* vi = P.Vinv + (size_t)i * 6;
-        const double d0 = vi[0] * r0 + vi[1] * r1 + vi[2] * r2;
-        const double d1 = vi[1] * r0 + vi[3] * r1 + vi[4] * r2;
-        const double d2 = vi[2] * r0 + vi[4] * r1 + vi[5] * r2;
-        dpb[3 * (size_t)i] = d0; dpb[3 * (size_t)i + 1] = d1; dpb[3 * (size_t)i + 2] = d2;
-        const double p0 = pb[3 * (size_t)i], p1 = pb[3 * (size_t)i + 1], p2 = pb[3 * (size_t)i + 2];
-        pdpb[3 * (size_t)i] = p0 + d0; pdpb[3 * (size_t)i + 1] = p1 + d1; pdpb[3 * (size_t)i + 2] = p2 + d2;
-        if (ptc_out) {      // the trial point to the camera-major positions of its observations (32-byte records; campos[] is L1 / L2 warm)
-            const double2 v01 = make_double2(p0 + d0, p1 + d1), v2 = make_double2(p2 + d2, 0.0);
-            for (int k = P.rowptr[i]; k < k1; ++k) {
-                double2* dst = reinterpret_cast<double2*>(ptc_out) + 2 * (size_t)P.campos[k];
-                dst[0] = v01; dst[1] = v2;
-            }
+        if (active) {
+            s_dp = d0 * d0 + d1 * d1 + d2 * d2;
+            s_p = p0 * p0 + p1 * p1 + p2 * p2;
+            s_dl = d0 * (mu * d0 + g0) + d1 * (mu * d1 + g1) + d2 * (mu * d2 + g2);
         }
-        s_dp = d0 * d0 + d1 * d1 + d2 * d2;
-        s_p = p0 * p0 + p1 * p1 + p2 * p2;
-        s_dl = d0 * (mu * d0 + g[0]) + d1 * (mu * d1 + g[1]) + d2 * (mu * d2 + g[2]);
     }
     s_dp = wave_sum(s_dp); s_p = wave_sum(s_p); s_dl = wave_sum(s_dl);
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { sm[0][w] = s_dp; sm[1][w] = s_p; sm[2][w] = s_dl; }
     __syncthreads();
     if (threadIdx.x < 3)
-        st_agent(part + (size_t)threadIdx.x * gridDim.x + blockIdx.x,
+        st_agent(part + (size_t)threadIdx.x * nbp + blockIdx.x,
                  (sm[threadIdx.x][0] + sm[threadIdx.x][1]) + (sm[threadIdx.x][2] + sm[threadIdx.x][3]));
-    if (!ticket || !last_block_arrives(ticket, gridDim.x, fa.ticket_groups)) return;
-    // k_step_sums (camera part of the step, sums of the point partials) and the camera table of the trial point, by the workgroup that
-    // arrived last: pdp_a is written and read inside this workgroup (a barrier in between)
-    step_sums_body(fa.count, fa.fixed, mu, fa.pa, dpa, P.ea, fa.pdpa, fa.out3, part, (int)gridDim.x, fa.pt3, true);
-    __syncthreads();
-    // (one workgroup for the whole table is only right for the small problems this fusion was made for: from 256 cameras on the host launches
-    //  k_cam_table behind this kernel -- at 1 000 cameras this loop was 60 - 80 us of ONE workgroup with the rest of the device idle)
-    if (fa.camtab_trial)
-        for (int t = threadIdx.x; t < P.m * CT_PARTS; t += 256)
-            cam_table_part(P.cfg, t % P.m, t / P.m, fa.pdpa, P.Rinit, P.finit, fa.known, fa.with_fd, fa.camtab_trial);
+    if (!ticket || !last_block_arrives(ticket, (unsigned)nbp, fa.ticket_groups)) return;
+    // k_step_sums (camera part of the step, sums of the point partials), by the point workgroup that arrived last
+    step_sums_body(fa.count, fa.fixed, mu, fa.pa, dpa, P.ea, fa.pdpa, fa.out3, part, nbp, fa.pt3, true);
 }
 
 // camera part of the step: pdp_a = p_a + dp_a and sum dpa^2, sum pa^2, sum dpa (mu dpa + ea) (single block).
@@ -1167,11 +1233,11 @@ __global__ __launch_bounds__(256) void k_iter_final(DevProblem P, const double* 
 __device__ __forceinline__ void iter_final_body(const DevProblem& P, const double* __restrict__ pa, const double* __restrict__ pb,
         const double* __restrict__ part, int nparts, int have_points, int point_part_slot,
         int s_eabinf_a, int s_eabinf_b, int s_maxdiag_u, int s_maxdiag_v, int s_pl2_a, int s_pl2_b, int s_ccost,
-        double* __restrict__ scal, bool agent_loads)
+        double* __restrict__ scal, bool agent_loads, int which)
 {
     __shared__ double sm[4];
     const int cnp = P.cfg.cnp, t = threadIdx.x;
-    if (have_points) {      // part = [3][nparts]: the block partials of k_point_blocks, reduced in a fixed order
+    if (have_points && (which & 1)) {      // part = [3][nparts]: the block partials of k_point_blocks, reduced in a fixed order
         double a = 0.0, v = 0.0, s = 0.0;                                         // (maxima of non-negative quantities: a 0-based maximum is exact)
         for (int q = t; q < nparts; q += 256) {
             const double pa_ = agent_loads ? ld_agent(part + q) : part[q];
@@ -1182,6 +1248,7 @@ __device__ __forceinline__ void iter_final_body(const DevProblem& P, const doubl
         const double ra = block_max4(a, sm), rv = block_max4(v, sm), rs = block_sum4(s, sm);
         if (t == 0) { scal[s_eabinf_b] = ra; scal[s_maxdiag_v] = rv; scal[s_pl2_b] = rs; }
     }
+    if (!(which & 2)) return;
     double ea = 0.0, ud = -DBL_MAX, ps = 0.0;
 #pragma unroll 4
     for (int q = t; q < P.m * cnp; q += 256) {

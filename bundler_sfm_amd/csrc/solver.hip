@@ -542,10 +542,18 @@ int compute_normal_blocks(bsfm_problem* pb, bool with_iter_scalars = false, bool
             IterFinalArgs fa; fa.pa = pb->d_p; fa.have_points = 1; fa.point_part_slot = pb->world > 1 ? SC_COUNT + 8 : -1;
             fa.s_eabinf_a = SC_EABINF_A; fa.s_eabinf_b = SC_EABINF_B; fa.s_maxdiag_u = SC_MAXDIAG_U; fa.s_maxdiag_v = SC_MAXDIAG_V;
             fa.s_pl2_a = SC_PL2_A; fa.s_pl2_b = SC_PL2_B; fa.s_ccost = SC_CCOST; fa.scal = pb->d_scal;
-            DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_point_blocks<C>), dim3(grid_for(P.n, 256)), dim3(256), 0, pb->stream, P, pbpts, pb->d_red, pb->d_tickets + 1,
-                                                  pb->d_tickets + pb->tick_back, fa, pb->d_flags));
+            // (small problems: four lanes per point; the camera side of the scalars is one more workgroup behind the points')
+            if (pb->backsub_two_pass) {
+                fa.point_blocks = grid_for(P.n, 256);
+                DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_point_blocks<C, 1>), dim3(fa.point_blocks + 1), dim3(256), 0, pb->stream, P, pbpts, pb->d_red, pb->d_tickets + 1,
+                                                      pb->d_tickets + pb->tick_back, fa, pb->d_flags));
+            } else {
+                fa.point_blocks = grid_for((size_t)BS_LANES * (size_t)P.n, 256);
+                DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_point_blocks<C, 4>), dim3(fa.point_blocks + 1), dim3(256), 0, pb->stream, P, pbpts, pb->d_red, pb->d_tickets + 1,
+                                                      pb->d_tickets + pb->tick_back, fa, pb->d_flags));
+            }
             if (did_scalars) *did_scalars = true;
-        } else DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_point_blocks<C>), dim3(grid_for(P.n, 256)), dim3(256), 0, pb->stream, P, pbpts));
+        } else DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_point_blocks<C, 1>), dim3(grid_for(P.n, 256)), dim3(256), 0, pb->stream, P, pbpts));
     }
     ph_end(pb, PH_PTBLK);
     return 0;
@@ -901,13 +909,13 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     DM(pb->d_Ac, (size_t)nvis * 2 * cnp); DM(pb->d_Bc, (size_t)nvis * 8); if (!pb->mot) { DM(pb->d_Cc, (size_t)nvis * 8); } DM(pb->d_xc, 2 * (size_t)nvis); DM(pb->d_campart, (size_t)m * CAM_SPLIT * (cnp * (cnp + 1) / 2 + cnp)); DM(pb->d_U, (size_t)m * cnp * cnp + (size_t)m * cnp); pb->d_ea = pb->d_U + (size_t)m * cnp * cnp;   /* one buffer: one exchange */
     DM(pb->d_V, 6 * (size_t)n); DM(pb->d_Vinv, 6 * (size_t)n); DM(pb->d_eb, 3 * (size_t)n);
     DM(pb->d_S, (size_t)pb->ld * pb->ld); DM(pb->d_E, pb->ld);
-    pb->red_blocks = std::max(grid_for(nvis, RES_BLOCK), std::max(grid_for(n, 256), 1024));
+    pb->red_blocks = std::max(grid_for(nvis, RES_BLOCK), std::max(grid_for((size_t)BS_LANES * (size_t)n, 256), 1024));
     DM(pb->d_red, 4 * (size_t)pb->red_blocks); DM(pb->d_scal, SC_COUNT + 16 + 2); DM(pb->d_mixed, 8 + 4 * (size_t)std::max(1, d->world_size));
     pb->d_flags = reinterpret_cast<int*>(pb->d_scal + SC_COUNT + 16);      // 4 ints behind the scalars: both travel in one copy
     {   // [0 .. 8) top-level words, [8 .. 8 + m) the cameras', then the group words of k_residual's and k_backsub's grids (kernels.hip.h)
         pb->tick_res = (8 + (size_t)m + 31) / 32 * 32;
         pb->tick_back = pb->tick_res + ticket_group_words((size_t)grid_for(nvis, RES_BLOCK));
-        const size_t words = pb->tick_back + ticket_group_words((size_t)grid_for(n, 256));
+        const size_t words = pb->tick_back + ticket_group_words((size_t)grid_for((size_t)BS_LANES * (size_t)n, 256));      // (k_backsub's one-pass form: four lanes per point)
         DM(pb->d_tickets, words);
         pb->tick_words = words;
         if (hipMemsetAsync(pb->d_tickets, 0, words * sizeof(unsigned), pb->stream) != hipSuccess) return fail("tickets");
@@ -1467,11 +1475,14 @@ static int lm_iterate_impl(bsfm_problem_t* pb, int iters)
                                                           (const int*)pb->d_cam_cam, (const double*)pb->d_Ac, (const double*)pb->d_Bc, (const double*)d_dpa, pb->d_Cc));
                     wobs = pb->d_Cc;
                 }
+                // (one-pass form: four lanes per point; the trial point's camera table, where this kernel builds it, is one more workgroup behind the points')
+                fa.point_blocks = wobs ? nbp : grid_for((size_t)BS_LANES * (size_t)P.n, 256);
+                const unsigned bs_grid = (unsigned)fa.point_blocks + (table_in_backsub ? 1u : 0u);
                 if (wobs) {
-                    DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_backsub<C, true>), dim3(nbp), dim3(256), 0, pb->stream, P, mu, d_dpa, d_pb, d_dpb, d_pdpb, pb->d_red, pb->d_ptc[ms],
+                    DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_backsub<C, true>), dim3(bs_grid), dim3(256), 0, pb->stream, P, mu, d_dpa, d_pb, d_dpb, d_pdpb, pb->d_red, pb->d_ptc[ms],
                                                           wobs, pb->d_tickets + 2, fa));
                 } else {
-                    DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_backsub<C, false>), dim3(nbp), dim3(256), 0, pb->stream, P, mu, d_dpa, d_pb, d_dpb, d_pdpb, pb->d_red, pb->d_ptc[ms],
+                    DISPATCH_CNP(cnp, hipLaunchKernelGGL((k_backsub<C, false>), dim3(bs_grid), dim3(256), 0, pb->stream, P, mu, d_dpa, d_pb, d_dpb, d_pdpb, pb->d_red, pb->d_ptc[ms],
                                                           wobs, pb->d_tickets + 2, fa));
                 }
                 if (!table_in_backsub) launch_cam_table(pb, pb->d_pdp, pb->d_camtab_trial);
