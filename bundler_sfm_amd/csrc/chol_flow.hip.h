@@ -504,7 +504,9 @@ __device__ const unsigned long long kFlowPotrfSlots[8] = {      // 5 slots per w
 // 128-VGPR build a role is a function of its own, and in ONE function the workers' blocks (40 VGPRs, live across the whole loop) and the
 // 64 registers of A1 do not fit together -- A1 had to be a call, with a save / restore of ~46 registers through scratch around each of the
 // eight block factorisations (POTRF 36 us in that build against 27 in the 256-VGPR one).
-template <int V, bool IS_F>
+// KEEP (the one-tile solve): the last row of the inverse also goes to LDS, into the slots of row 7 of L, so that the whole of inv(L) can be read there
+// afterwards (one more workgroup barrier: not in the multi-tile launch, where this function is the chain).
+template <int V, bool IS_F, bool KEEP = false>
 __device__ __forceinline__ void flow_potrf_part(FlowKWords ka, const FlowArgs* a_in, int k, double* lds)
 {
     const FlowArgs a = flow_role_args<V>(ka, a_in); BSFM_UNIFORM_INT(k);
@@ -793,6 +795,7 @@ __device__ __forceinline__ void flow_potrf_part(FlowKWords ka, const FlowArgs* a
     // ---- the last row of X (block (7, J) by wave J) and the diagonal blocks X_II = inv(L_II) (wave I); row 6 was written out above
     {
         const int lr = lr0, lc = lc0;
+        v4d res = { 0.0, 0.0, 0.0, 0.0 };
         if (w < 7) {
             const int J = w;
             v4d acc = { 0.0, 0.0, 0.0, 0.0 };
@@ -807,11 +810,18 @@ __device__ __forceinline__ void flow_potrf_part(FlowKWords ka, const FlowArgs* a
                 for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
             }
             const double* Ds = Di + 7 * 256;
-            v4d res = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
             for (int q = 0; q < 4; ++q) res = __builtin_amdgcn_mfma_f64_16x16x4f64(Ds[swz16(lc, 4 * q + lr)], acc[q], res, 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) st_sc1(Wk + (size_t)(112 + 4 * q + lr) * POTRF_NB + 16 * J + lc, -res[q]);
+        }
+        if (KEEP) {
+            __syncthreads();                               // every wave has read the blocks of row 7 of L it needed
+            if (w < 7) {
+                double* slot = Lb + (21 + w) * 256;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) slot[swz16(4 * q + lr, lc)] = -res[q];
+            }
         }
         const double* Dw = Di + w * 256;
 #pragma unroll
@@ -1568,36 +1578,42 @@ inline int flow_solve_dist(PotrfWorkspace& w, FlowWorkspace& f, FlowDist& d, dou
 // A system of ONE tile (n <= 128: the first pairs and triples of an incremental reconstruction, src/BundleFast.cpp:263-438): the tile
 // factorisation of the dataflow kernel and both substitutions in one workgroup, one launch.  x = inv(L)^T (inv(L) E); the inverse factor
 // was written by this workgroup with write-through stores and is read back past the L1 (agent-scope loads).
-__global__ __launch_bounds__(512, 2) void k_flow_solve_one(FlowArgs a_param, const double* __restrict__ E, double* __restrict__ x)
+// entry (row, col), col <= row, of the inverse factor the tile role leaves in LDS (KEEP form: all eight block rows)
+__device__ __forceinline__ double flow_xinv_lds(const double* lds, int row, int col)
+{
+    const int I = row >> 4, J = col >> 4;
+    const double* blk = I == J ? lds + FLOW_DI + I * 256 : lds + FLOW_LB + (I * (I - 1) / 2 + J) * 256;
+    return blk[swz16(row & 15, col & 15)];
+}
+__global__ __launch_bounds__(512, 1) void k_flow_solve_one(FlowArgs a_param, const double* __restrict__ E, double* __restrict__ x)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double vec[POTRF_NB], red[4 * POTRF_NB], yv[POTRF_NB];
     const FlowKWords ka = (FlowKWords)__builtin_amdgcn_kernarg_segment_ptr();
     if (threadIdx.x == 64 * FLOW_FACTOR_WAVE) *a_param.info = 0;          // (the lane that reports a failing pivot)
     if (threadIdx.x == 0) __hip_atomic_store(a_param.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // this launch's time-out word (set only by an expired
                                                                                                                     // wait of the tile role, 2^24 polls away)
-    flow_potrf(FlowTag<2>(), ka, &a_param, 0, lds);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    double* vec = lds; double* red = lds + POTRF_NB; double* yv = lds + 5 * POTRF_NB;         // the blocks in LDS are no longer needed
     const int n_total = a_param.n_total;
-    const double* Linv = a_param.Linv;
-    const int r = threadIdx.x & 127, h = threadIdx.x >> 7;                                      // 4 quarter-sums per row
-    if (threadIdx.x < POTRF_NB) vec[threadIdx.x] = threadIdx.x < n_total ? E[threadIdx.x] : 0.0;
+    if (threadIdx.x < POTRF_NB) vec[threadIdx.x] = threadIdx.x < n_total ? E[threadIdx.x] : 0.0;      // (requested in front of the factorisation)
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == FLOW_FACTOR_WAVE) flow_potrf_part<2, true, true>(ka, &a_param, 0, lds);
+    else flow_potrf_part<2, false, true>(ka, &a_param, 0, lds);
     __syncthreads();
+    // Both substitutions straight from LDS (round 6): the tile role leaves the whole inverse there.  Reading it back from memory cost the drain of the
+    // role's write-through stores and two rounds of agent-scope loads, ~7 of the kernel's 37 us.
+    const int r = threadIdx.x & 127, h = threadIdx.x >> 7;                                      // 4 quarter-sums per row
     {
-        const double* Li = Linv + (size_t)r * POTRF_NB + 32 * h;
-        double s = 0.0;
+        double s = 0.0;                                                                          // y[r] = sum_{c <= r} inv(L)[r][c] E[c]
 #pragma unroll 8
-        for (int c = 0; c < 32; ++c) s += ld_sc1(Li + c) * vec[32 * h + c];
+        for (int c = 32 * h; c < 32 * h + 32; ++c) s += c <= r ? flow_xinv_lds(lds, r, c) * vec[c] : 0.0;
         red[h * POTRF_NB + r] = s;
     }
     __syncthreads();
     if (threadIdx.x < POTRF_NB) yv[r] = (red[r] + red[POTRF_NB + r]) + (red[2 * POTRF_NB + r] + red[3 * POTRF_NB + r]);
     __syncthreads();
     {
-        double s = 0.0;                                                                          // x[r] = sum_q inv(L)[q][r] y[q]
+        double s = 0.0;                                                                          // x[r] = sum_{q >= r} inv(L)[q][r] y[q]
 #pragma unroll 8
-        for (int q = 0; q < 32; ++q) s += ld_sc1(Linv + (size_t)(32 * h + q) * POTRF_NB + r) * yv[32 * h + q];
+        for (int q = 32 * h; q < 32 * h + 32; ++q) s += q >= r ? flow_xinv_lds(lds, q, r) * yv[q] : 0.0;
         red[h * POTRF_NB + r] = s;
     }
     __syncthreads();
