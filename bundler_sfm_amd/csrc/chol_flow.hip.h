@@ -1040,7 +1040,10 @@ constexpr unsigned long long FLOW_X_PENDING = 0xfff85eeddeadbeefull;      // "x_
 // on its way to the launch).
 __global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc, int nblk, int first, const double* __restrict__ Linv,
         const double* __restrict__ y, double* x, int* flags, int* timeout, const int* __restrict__ last_row, long long spin_limit, int stall_col,
-        const FlowPeers* __restrict__ peers = nullptr, int flagval = 1, int x_is_flag = 0)
+        const FlowPeers* __restrict__ peers = nullptr, int flagval = 1, int x_is_flag = 0,
+        double* __restrict__ x_out = nullptr, int n_out = 0, const unsigned* __restrict__ fwd_timeout = nullptr, int* __restrict__ info = nullptr
+        /* x_out != null (one rank, round 6): every column writes its part of the solution where the caller wants it and an expired wait of either
+           kernel becomes the solve's info here -- k_flow_end's job, one launch fewer per solve */)
 {
     __shared__ double yk[POTRF_NB];
     __shared__ double xi[2][POTRF_NB];      // double-buffered: one barrier per step
@@ -1107,7 +1110,7 @@ __global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc,
                         if ((++spins_ & 255u) == 0u) {                                                              \
                             const long long now_ = wall_clock64();                                                  \
                             if (t_begin_ == 0) t_begin_ = now_;                                                     \
-                            if (now_ - t_begin_ > spin_limit || __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { atomicExch(timeout, 1); break; } \
+                            if (now_ - t_begin_ > spin_limit || __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { atomicExch(timeout, 1); if (info) atomicExch(info, POTRF_INFO_TIMEOUT); break; } \
                         }                                                                                           \
                     }                                                                                               \
                 }                                                                                                   \
@@ -1170,7 +1173,13 @@ __global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc,
     if (h == 1) red[c] = sacc;
     __syncthreads();
     if (x_is_flag) {      // (stall_col: test hook, a column that never arrives)
-        if (h == 0 && kk != stall_col) __hip_atomic_store(&x[(size_t)kk * POTRF_NB + c], sacc + red[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (h == 0 && kk != stall_col) {
+            const double v = sacc + red[c];
+            __hip_atomic_store(&x[(size_t)kk * POTRF_NB + c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (x_out && kk * POTRF_NB + c < n_out) x_out[(size_t)kk * POTRF_NB + c] = v;
+        }
+        // the factorisation kernel's time-out word (that launch is complete): any one workgroup reports it
+        if (info && kk == 0 && threadIdx.x == 0 && fwd_timeout && __hip_atomic_load(fwd_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) atomicExch(info, POTRF_INFO_TIMEOUT);
         return;
     }
     if (h == 0) {
@@ -1472,9 +1481,8 @@ inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, in
     for (int first = 0; first < nblk; first += POTRF_MAX_TILES)
         hipLaunchKernelGGL(k_bwd_flow, dim3(std::min(POTRF_MAX_TILES, nblk - first)), dim3(256), 0, st, (const double*)f.pc, nblk, first,
                            (const double*)w.linv, (const double*)w.y, w.xs, w.bflags, w.bflags + w.nblk, (const int*)(env ? w.d_last : nullptr),
-                           f.spin_limit, f.stall_bwd_col, (const FlowPeers*)nullptr, 1, 1);
-    hipLaunchKernelGGL(k_flow_end, dim3((unsigned)std::min(64, (n + 255) / 256)), dim3(256), 0, st, (const unsigned*)f.d_sync, (const int*)(w.bflags + w.nblk),
-                       d_info, (const double*)w.xs, x_out, n);
+                           f.spin_limit, f.stall_bwd_col, (const FlowPeers*)nullptr, 1, 1, x_out, n, (const unsigned*)(f.d_sync + 1), d_info);
+    // (k_flow_end's two jobs -- the solution out of the padded vector, a time-out into info -- are done by k_bwd_flow itself on this path)
     if (f.trace) flow_dump_trace(f, st);
     return 0;
 }
