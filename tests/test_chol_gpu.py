@@ -166,6 +166,27 @@ def test_info_word_of_a_normal_and_of_an_indefinite_solve(gpu_bsfm):
             assert gpu_bsfm.dense_chol_solve(A, b)[0] == 151
 
 
+def test_one_tile_solve_random_sizes(gpu_bsfm):
+    """The one-tile launch (n <= 128: factorisation and both substitutions in one workgroup, the substitutions reading the inverse factor from LDS --
+    round 6): random sizes against numpy, a failing pivot at the first / an inner / the last position, every system twice with the same bits.
+    scripts/r6/one_tile_stress.py is the long form."""
+    rng = np.random.default_rng(31)
+    for c in range(40):
+        n = int(rng.integers(1, 129))
+        G = rng.standard_normal((n, n + 3))
+        A = G @ G.T + (1e-3 + n * rng.random()) * np.eye(n)
+        b = rng.standard_normal(n)
+        rc, x = gpu_bsfm.dense_chol_solve(A, b)
+        rc2, x2 = gpu_bsfm.dense_chol_solve(A, b)
+        assert rc == 0 and rc2 == 0 and np.array_equal(x, x2), (c, n)
+        ref = np.linalg.solve(A, b)
+        assert np.abs(x - ref).max() <= 1e-13 * np.linalg.cond(A) * max(np.abs(ref).max(), 1e-300), (c, n)
+    for n, k in ((40, 17), (128, 128), (100, 1), (1, 1)):
+        A = np.eye(n) * 4.0
+        A[k - 1, k - 1] = -1.0
+        assert gpu_bsfm.dense_chol_solve(A, np.ones(n))[0] == k, (n, k)
+
+
 def test_flow_stress_bit_identity(gpu_bsfm):
     """Random sizes and random tile envelopes through the dataflow launch (the dynamic check of the hand-off invariant stated at flow_tri,
     chol_flow.hip.h: write-once lines have one writer, rewritten data is only touched with agent-scope accesses): every solution
