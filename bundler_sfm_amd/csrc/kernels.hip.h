@@ -879,7 +879,7 @@ __global__ __launch_bounds__(256) void k_backsub_obs(int nvis, int mcon, const i
 // ---------------------------------------------------------------------------------------------------
 // db_i = V*_i^-1 (eb_i - sum_j W_ij^T da_j), W_ij^T da_j = B_ij^T (A_ij da_j); thread per point.
 // Also writes pdp_b = p_b + db and block partials of sum db^2, sum p_b^2 and sum db (mu db + eb).
-// Round 6, the small problems (one-pass form, below 200 000 observations) are latency: a 14-camera problem is 6 workgroups whose threads each walked
+// Round 6, the small problems (one-pass form, below 400 000 observations) are latency: a 14-camera problem is 6 workgroups whose threads each walked
 // a chain of 2 d_i dependent gathers, every one a miss of the XCD's L2 (the records were written on other XCDs): 12.7 us of a 26 us kernel, and the
 // last workgroup then spent 6.3 us on the trial point's camera table (profiles/r06_small_problem_latency.txt).  Now FOUR lanes share a point -- lane q
 // takes observations q, q + 4, q + 8 of the row, three per trip: positions, then records, one trip for up to 12 observations; the quad adds its four

@@ -231,7 +231,7 @@ struct bsfm_problem {
     double *d_scal = nullptr;
     double *d_mixed = nullptr;          // staging of allreduce_mixed: a few sums + world slots per maximum
     int *d_flags = nullptr;             // [0] singular V, [1] potrf info
-    bool backsub_two_pass = false;      // k_backsub_obs + gather (nvis >= 200 000, or BSFM_BACKSUB_TWO_PASS=0|1)
+    bool backsub_two_pass = false;      // k_backsub_obs + gather (nvis >= 400 000, or BSFM_BACKSUB_TWO_PASS=0|1); below: four lanes per point in k_backsub and k_point_blocks
     size_t tick_res = 0, tick_back = 0; // word offsets of the group tickets in d_tickets
     size_t tick_words = 0;
     unsigned* d_tickets = nullptr;      // "last workgroup finishes the job" tickets (kernels.hip.h): [0] residual, [1] iteration scalars, [2] back-substitution, [8 ..) one per camera
@@ -984,7 +984,7 @@ bsfm_problem_t* bsfm_problem_create(const bsfm_problem_desc_t* d, const bsfm_opt
     // Phase timing (16 event records per solve attempt + their read-back) is on for problems where it is noise (>= 100 000
     // observations: bench.py's phases_ms) and off for the small problems of incremental reconstruction, where those host calls
     // were a tenth of an iteration; BSFM_PHASE_TIMING=1 / 0 forces it.
-    pb->backsub_two_pass = nvis >= 200000;
+    pb->backsub_two_pass = nvis >= 400000;      // (round 6: the one-pass form with four lanes per point wins up to ~400 000 observations: 24 against 29 us at 200 000, 48 / 44 at 500 000)
     if (const char* e = getenv("BSFM_BACKSUB_TWO_PASS")) pb->backsub_two_pass = atoi(e) != 0;
     pb->ev_ok = nvis >= 2000000;      // (round 6: was 100 000 -- exactly the 50-camera problem of the latency table, whose iteration the event records made a third longer)
     if (const char* e = getenv("BSFM_PHASE_TIMING")) pb->ev_ok = atoi(e) != 0;
