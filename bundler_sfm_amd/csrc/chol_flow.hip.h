@@ -1138,12 +1138,17 @@ __global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc,
         /* this thread's share of sum_i P_i,kk^T x_i stays in its registers until the column is finished (four chains: a single one is 64   \
            dependent FMAs, 0.25 us of every hand-off); xi is double-buffered, so a step costs ONE barrier */                              \
         const double* xv_ = xi[(J_) & 1] + 64 * h;                                                                  \
-        _Pragma("unroll") for (int r = 0; r < 64; r += 4) {                                                         \
-            part0 = fma(CUR_[r], xv_[r], part0); part1 = fma(CUR_[r + 1], xv_[r + 1], part1);                       \
-            part2 = fma(CUR_[r + 2], xv_[r + 2], part2); part3 = fma(CUR_[r + 3], xv_[r + 3], part3);               \
+        _Pragma("unroll") for (int r = 0; r < 32; r += 4) {                                                         \
+            pa[0] = fma(CUR_[r], xv_[r], pa[0]); pa[1] = fma(CUR_[r + 1], xv_[r + 1], pa[1]);                       \
+            pa[2] = fma(CUR_[r + 2], xv_[r + 2], pa[2]); pa[3] = fma(CUR_[r + 3], xv_[r + 3], pa[3]);               \
+            pb[0] = fma(CUR_[r + 32], xv_[r + 32], pb[0]); pb[1] = fma(CUR_[r + 33], xv_[r + 33], pb[1]);           \
+            pb[2] = fma(CUR_[r + 34], xv_[r + 34], pb[2]); pb[3] = fma(CUR_[r + 35], xv_[r + 35], pb[3]);           \
         }                                                                                                           \
     }
-    double part0 = 0.0, part1 = 0.0, part2 = 0.0, part3 = 0.0;
+    // THE ORDER OF THE SUMS (shared with k_bwd_scalar, so that every path gives the same bits): the 128 rows of a tile are four QUARTERS of 32; inside
+    // a quarter row r belongs to chain r mod 4; a chain runs over all steps in order; quarter = (c0 + c1) + (c2 + c3); column = (q0 + q1) + (q2 + q3).
+    // A thread of this kernel holds two quarters (pa: rows 64 h .. + 31, pb: the next 32).
+    double pa[4] = { 0.0, 0.0, 0.0, 0.0 }, pb[4] = { 0.0, 0.0, 0.0, 0.0 };
     BSFM_BWD_LOAD(ta, 0)
     for (int j = 0; j < nstep; j += 2) {
         BSFM_BWD_STEP(ta, tb, j)
@@ -1152,23 +1157,23 @@ __global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc,
 #undef BSFM_BWD_STEP
 #undef BSFM_BWD_LOAD
     // y_kk - the two halves' sums, then x_kk = W_kk^T of it
-    const double part = (part0 + part1) + (part2 + part3);
+    const double part = ((pa[0] + pa[1]) + (pa[2] + pa[3])) + ((pb[0] + pb[1]) + (pb[2] + pb[3]));
     if (h == 1) red[c] = part;
     __syncthreads();
     if (h == 0) yk[c] -= part + red[c];
     __syncthreads();
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    double sa[4] = { 0.0, 0.0, 0.0, 0.0 }, sb[4] = { 0.0, 0.0, 0.0, 0.0 };
     {
         const double* yv = yk + 64 * h;
-        if (nstep & 1) {
-#pragma unroll
-            for (int r = 0; r < 64; r += 4) { s0 = fma(tb[r], yv[r], s0); s1 = fma(tb[r + 1], yv[r + 1], s1); s2 = fma(tb[r + 2], yv[r + 2], s2); s3 = fma(tb[r + 3], yv[r + 3], s3); }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 64; r += 4) { s0 = fma(ta[r], yv[r], s0); s1 = fma(ta[r + 1], yv[r + 1], s1); s2 = fma(ta[r + 2], yv[r + 2], s2); s3 = fma(ta[r + 3], yv[r + 3], s3); }
+#define BSFM_BWD_FINAL(T_)                                                                                          \
+        _Pragma("unroll") for (int r = 0; r < 32; r += 4) {                                                         \
+            sa[0] = fma(T_[r], yv[r], sa[0]); sa[1] = fma(T_[r + 1], yv[r + 1], sa[1]); sa[2] = fma(T_[r + 2], yv[r + 2], sa[2]); sa[3] = fma(T_[r + 3], yv[r + 3], sa[3]); \
+            sb[0] = fma(T_[r + 32], yv[r + 32], sb[0]); sb[1] = fma(T_[r + 33], yv[r + 33], sb[1]); sb[2] = fma(T_[r + 34], yv[r + 34], sb[2]); sb[3] = fma(T_[r + 35], yv[r + 35], sb[3]); \
         }
+        if (nstep & 1) { BSFM_BWD_FINAL(tb) } else { BSFM_BWD_FINAL(ta) }
+#undef BSFM_BWD_FINAL
     }
-    const double sacc = (s0 + s1) + (s2 + s3);
+    const double sacc = ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sb[0] + sb[1]) + (sb[2] + sb[3]));
     __syncthreads();                                     // (red is read above by the other half)
     if (h == 1) red[c] = sacc;
     __syncthreads();
@@ -1197,6 +1202,115 @@ __global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc,
             for (int r = 0; r < peers->n; ++r)
                 if (r != peers->rank) __hip_atomic_store(peers->bflags[r] + kk, flagval, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// ---- k_bwd_scalar (round 6): the backward substitution of ONE rank with its polls on the SCALAR memory path.
+// What bounds k_bwd_flow is the order of a wave's vector loads: a poll queues behind the wave's own tile request and is answered when the 128 KB have
+// landed, 2.4 us later (profiles/r06_backward_substitution_chain.txt).  Scalar loads have a queue of their own (lgkmcnt), and a word another XCD
+// stores is seen through them 0.66 us later when the buffer is UNCACHED device memory (scripts/r6/ubench_scalar_poll.hip) -- so here
+//   * x lives in an uncached buffer; wave w (rows 32 w .. 32 w + 31 of every tile, columns 2 lane and 2 lane + 1) polls ITS 32 entries of x_i with four
+//     s_load_dwordx16 and takes them as the scalar operands of its 64 FMAs: no LDS staging, no barrier per step, the four waves run through the
+//     steps independently;
+//   * THREE tile buffers: tile j + 2 is requested in step j -- two tiles in flight per column, which is what a period below the 2.4 us of one tile
+//     needs -- and nothing ever waits behind them except their own use.
+// The order of the sums is k_bwd_flow's (quarters of 32 rows, four chains, fixed trees): the same bits on every path.
+typedef unsigned int bwd_u16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void k_bwd_scalar(const double* __restrict__ Pc, int nblk, int first, const double* __restrict__ Linv,
+        const double* __restrict__ y, double* x /* uncached, filled with FLOW_X_PENDING */, int* timeout, const int* __restrict__ last_row,
+        long long spin_limit, int stall_col, double* __restrict__ x_out, int n_out, const unsigned* __restrict__ fwd_timeout, int* __restrict__ info)
+{
+    __shared__ double yk[POTRF_NB];
+    __shared__ double red[4][POTRF_NB];
+    const int kk = nblk - 1 - first - (int)blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    double ta[64], tb[64], tc[64];                       // [2 r + v]: row 32 w + r, column 2 lane + v -- ONE 16-byte load per row: a wave may have 64 vector
+                                                         // loads in flight (vmcnt is six bits), and two tiles in flight are what this kernel is for
+    if (threadIdx.x < POTRF_NB) yk[threadIdx.x] = y[(size_t)kk * POTRF_NB + threadIdx.x];
+    const int itop = last_row ? last_row[kk] : nblk - 1;
+    const int nstep = itop - kk;
+    // tile j of the column's sequence: P(itop - j, kk) for j < nstep, then W_kk (and W_kk again for the requests past the end: the loads stay unconditional)
+#define BSFM_BWS_LOAD(T_, J_)                                                                                       \
+    {                                                                                                               \
+        const int j_ = (J_) < nstep ? (J_) : nstep;                                                                 \
+        const double* Lc_ = (j_ < nstep ? Pc + flow_tri(itop - j_, kk) * FLOW_TL : Linv + (size_t)kk * FLOW_TL) + (size_t)(32 * w) * POTRF_NB + 2 * lane; \
+        _Pragma("unroll") for (int r = 0; r < 32; ++r) { const double2 t_ = *reinterpret_cast<const double2*>(Lc_ + (size_t)r * POTRF_NB); T_[2 * r] = t_.x; T_[2 * r + 1] = t_.y; } \
+    }
+    double pa[4] = { 0.0, 0.0, 0.0, 0.0 }, pb[4] = { 0.0, 0.0, 0.0, 0.0 };
+#define BSFM_BWS_FMA8(CUR_, V_, R0_)                                                                                \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                             \
+            const double xq_ = __hiloint2double((int)V_[2 * q + 1], (int)V_[2 * q]);                                \
+            pa[q & 3] = fma(CUR_[2 * ((R0_) + q)], xq_, pa[q & 3]); pb[q & 3] = fma(CUR_[2 * ((R0_) + q) + 1], xq_, pb[q & 3]); \
+        }
+#define BSFM_BWS_STEP(CUR_, PRE_, J_)                                                                               \
+    {                                                                                                               \
+        BSFM_BWS_LOAD(PRE_, (J_) + 2)                                                                               \
+        const double* xp_ = x + (size_t)(itop - (J_)) * POTRF_NB + 32 * w;                                          \
+        bwd_u16 v0_, v1_, v2_, v3_;                                                                                 \
+        unsigned spins_ = 0;                                                                                        \
+        long long t_begin_ = 0;                                                                                     \
+        for (;;) {                                                                                                  \
+            asm volatile("s_load_dwordx16 %0, %4, 0x0 glc\n\ts_load_dwordx16 %1, %4, 0x40 glc\n\ts_load_dwordx16 %2, %4, 0x80 glc\n\t"   \
+                         "s_load_dwordx16 %3, %4, 0xc0 glc\n\ts_waitcnt lgkmcnt(0)"                                  \
+                         : "=&s"(v0_), "=&s"(v1_), "=&s"(v2_), "=&s"(v3_) : "s"(xp_) : "memory");                   \
+            bool pend_ = false;                                                                                     \
+            _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                         \
+                pend_ |= (((unsigned long long)v0_[2 * q + 1] << 32) | v0_[2 * q]) == FLOW_X_PENDING;               \
+                pend_ |= (((unsigned long long)v1_[2 * q + 1] << 32) | v1_[2 * q]) == FLOW_X_PENDING;               \
+                pend_ |= (((unsigned long long)v2_[2 * q + 1] << 32) | v2_[2 * q]) == FLOW_X_PENDING;               \
+                pend_ |= (((unsigned long long)v3_[2 * q + 1] << 32) | v3_[2 * q]) == FLOW_X_PENDING;               \
+            }                                                                                                       \
+            if (!pend_) break;                                                                                      \
+            __builtin_amdgcn_s_sleep(1);                                                                            \
+            if ((++spins_ & 255u) == 0u) {                                                                          \
+                const long long now_ = wall_clock64();                                                              \
+                if (t_begin_ == 0) t_begin_ = now_;                                                                 \
+                if (now_ - t_begin_ > spin_limit || __hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { \
+                    if (lane == 0) { atomicExch(timeout, 1); atomicExch(info, POTRF_INFO_TIMEOUT); }                \
+                    break;                                                                                          \
+                }                                                                                                   \
+            }                                                                                                       \
+        }                                                                                                           \
+        /* entry q of load u is x[32 w + 8 u + q]: row 8 u + q of the quarter, chain (row mod 4); rows in ascending order, as in k_bwd_flow */ \
+        BSFM_BWS_FMA8(CUR_, v0_, 0) BSFM_BWS_FMA8(CUR_, v1_, 8) BSFM_BWS_FMA8(CUR_, v2_, 16) BSFM_BWS_FMA8(CUR_, v3_, 24)                       \
+    }
+    BSFM_BWS_LOAD(ta, 0)
+    BSFM_BWS_LOAD(tb, 1)
+    for (int j = 0; j < nstep; j += 3) {
+        BSFM_BWS_STEP(ta, tc, j)
+        if (j + 1 < nstep) BSFM_BWS_STEP(tb, ta, j + 1)
+        if (j + 2 < nstep) BSFM_BWS_STEP(tc, tb, j + 2)
+    }
+#undef BSFM_BWS_STEP
+#undef BSFM_BWS_FMA8
+#undef BSFM_BWS_LOAD
+    // ---- y_kk - the four quarters' sums, then x_kk = W_kk^T of it (W_kk is tile nstep of the sequence: in buffer nstep mod 3)
+    red[w][2 * lane] = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+    red[w][2 * lane + 1] = (pb[0] + pb[1]) + (pb[2] + pb[3]);
+    __syncthreads();
+    if (threadIdx.x < POTRF_NB) yk[threadIdx.x] -= (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    __syncthreads();
+    double sa[4] = { 0.0, 0.0, 0.0, 0.0 }, sb[4] = { 0.0, 0.0, 0.0, 0.0 };
+    {
+        const double* yv = yk + 32 * w;
+#define BSFM_BWS_FINAL(T_)                                                                                          \
+        _Pragma("unroll") for (int r = 0; r < 32; ++r) { sa[r & 3] = fma(T_[2 * r], yv[r], sa[r & 3]); sb[r & 3] = fma(T_[2 * r + 1], yv[r], sb[r & 3]); }
+        const int fin = nstep % 3;
+        if (fin == 0) { BSFM_BWS_FINAL(ta) } else if (fin == 1) { BSFM_BWS_FINAL(tb) } else { BSFM_BWS_FINAL(tc) }
+#undef BSFM_BWS_FINAL
+    }
+    __syncthreads();                                     // (red was read above)
+    red[w][2 * lane] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+    red[w][2 * lane + 1] = (sb[0] + sb[1]) + (sb[2] + sb[3]);
+    __syncthreads();
+    if (threadIdx.x < POTRF_NB && kk != stall_col) {     // (stall_col: test hook, a column that never arrives)
+        const int c = threadIdx.x;
+        const double v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        __hip_atomic_store(&x[(size_t)kk * POTRF_NB + c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (kk * POTRF_NB + c < n_out) x_out[(size_t)kk * POTRF_NB + c] = v;
+    }
+    // the factorisation kernel's time-out word (that launch is complete): the workgroup of column 0 reports it
+    if (kk == 0 && threadIdx.x == 0 && __hip_atomic_load(fwd_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) atomicExch(info, POTRF_INFO_TIMEOUT);
 }
 
 // The small jobs around the two kernels, one launch each instead of three memsets and two copies (at 50 cameras a solve is 0.2 ms and
@@ -1236,6 +1350,7 @@ struct FlowWorkspace {
     bool latency_build = false;                        // this system runs on k_chol_flow<2> (see there)
     long long spin_limit = FLOW_SPIN_LIMIT_TICKS;      // BSFM_FLOW_SPIN_MS
     int stall_ticket = -1, stall_bwd_col = -1;         // test hooks: BSFM_FLOW_TEST_STALL (bulk ticket that never signals), BSFM_FLOW_TEST_STALL_BWD (column)
+    bool bwd_scalar = true;                // BSFM_BWD_SCALAR=0|1: backward substitution with its polls on the scalar memory path (k_bwd_scalar; one rank)
     int wgs = 512;                         // workgroups launched (BSFM_FLOW_WGS)
     bool chain_shared = false;             // the chain workgroups other than POTRF's share their CUs with bulk workgroups (bulk-bound systems, see flow_prepare)
     int chain_wgs = 17;                    // of them: serve the chain queue, alone on their CU (17 or 27, see flow_prepare; BSFM_FLOW_CHAIN_WGS; 0 = one queue)
@@ -1362,6 +1477,7 @@ inline int flow_prepare(FlowWorkspace& f, int nblk, const std::vector<int>& env_
     if (const char* e = getenv("BSFM_FLOW_SPIN_MS")) f.spin_limit = std::max(1LL, (long long)atoll(e)) * 100000LL;
     if (const char* e = getenv("BSFM_FLOW_TEST_STALL")) f.stall_ticket = atoi(e);
     if (const char* e = getenv("BSFM_FLOW_TEST_STALL_BWD")) f.stall_bwd_col = atoi(e);
+    if (const char* e = getenv("BSFM_BWD_SCALAR")) f.bwd_scalar = atoi(e) != 0;
     if (flow_cached_schedule(nblk, key, flow_params_from_env(), f.sched) != 0) return -1;
     // Chain workgroups: 16 serve the sixteen blocks of the first panel tile at once, but the one that has just finished POTRF joins late;
     // a chain-bound factorisation (few tile products per column: up to ~45 dense tile columns, any envelope) gains 1-3 % from 26, a
@@ -1450,8 +1566,11 @@ inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, in
     const int nblk = (n + POTRF_NB - 1) / POTRF_NB;
     if (flow_prepare(f, nblk, w.env_rows) != 0) return -1;
     const size_t nt = f.sched.tasks.size();
+    // the solution vector of the backward substitution: the uncached buffer and the scalar-poll kernel where that buffer exists (BSFM_BWD_SCALAR=0: the
+    // vector-poll kernel on the ordinary buffer)
+    double* const xvec = (w.xu && f.bwd_scalar) ? w.xu : w.xs;
     hipLaunchKernelGGL(k_flow_begin, dim3((unsigned)std::min<size_t>(64, (std::max<size_t>(f.sync_words, (size_t)ld) + 255) / 256)), dim3(256), 0, st,
-                       f.d_sync, (unsigned)f.sync_words, w.bflags, w.nblk + 1, w.etmp, E, n, ld, 0u, 0u, reinterpret_cast<unsigned long long*>(w.xs));
+                       f.d_sync, (unsigned)f.sync_words, w.bflags, w.nblk + 1, w.etmp, E, n, ld, 0u, 0u, reinterpret_cast<unsigned long long*>(xvec));
     FlowArgs a;
     memset(&a, 0, sizeof a);      // (genbase = 0, peers = nullptr: one rank)
     a.S = S; a.ld = ld; a.n_total = n; a.T = nblk; a.Pc = f.pc; a.Linv = w.linv; a.E = w.etmp; a.y = w.y;
@@ -1478,10 +1597,16 @@ inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, in
     if (timed) { (void)hipEventRecord(f.k1, st); f.kern_pending = true; }
     // backward substitution
     const bool env = (int)w.env_rows.size() >= nblk && w.d_last != nullptr;
-    for (int first = 0; first < nblk; first += POTRF_MAX_TILES)
-        hipLaunchKernelGGL(k_bwd_flow, dim3(std::min(POTRF_MAX_TILES, nblk - first)), dim3(256), 0, st, (const double*)f.pc, nblk, first,
-                           (const double*)w.linv, (const double*)w.y, w.xs, w.bflags, w.bflags + w.nblk, (const int*)(env ? w.d_last : nullptr),
-                           f.spin_limit, f.stall_bwd_col, (const FlowPeers*)nullptr, 1, 1, x_out, n, (const unsigned*)(f.d_sync + 1), d_info);
+    for (int first = 0; first < nblk; first += POTRF_MAX_TILES) {
+        if (xvec == w.xu)
+            hipLaunchKernelGGL(k_bwd_scalar, dim3(std::min(POTRF_MAX_TILES, nblk - first)), dim3(256), 0, st, (const double*)f.pc, nblk, first,
+                               (const double*)w.linv, (const double*)w.y, w.xu, w.bflags + w.nblk, (const int*)(env ? w.d_last : nullptr),
+                               f.spin_limit, f.stall_bwd_col, x_out, n, (const unsigned*)(f.d_sync + 1), d_info);
+        else
+            hipLaunchKernelGGL(k_bwd_flow, dim3(std::min(POTRF_MAX_TILES, nblk - first)), dim3(256), 0, st, (const double*)f.pc, nblk, first,
+                               (const double*)w.linv, (const double*)w.y, w.xs, w.bflags, w.bflags + w.nblk, (const int*)(env ? w.d_last : nullptr),
+                               f.spin_limit, f.stall_bwd_col, (const FlowPeers*)nullptr, 1, 1, x_out, n, (const unsigned*)(f.d_sync + 1), d_info);
+    }
     // (k_flow_end's two jobs -- the solution out of the padded vector, a time-out into info -- are done by k_bwd_flow itself on this path)
     if (f.trace) flow_dump_trace(f, st);
     return 0;

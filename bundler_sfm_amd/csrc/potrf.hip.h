@@ -121,6 +121,7 @@ struct PotrfWorkspace {
     double* linv = nullptr;    // nblk tiles: inverse of each diagonal factor tile
     double* y = nullptr;       // ld
     double* xs = nullptr;      // ld
+    double* xu = nullptr;      // ld, UNCACHED device memory (hipExtMallocWithFlags): the solution vector k_bwd_scalar polls through the scalar path; null if the allocation is refused
     double* etmp = nullptr;    // ld (rhs working copy)
     int* bflags = nullptr;     // nblk + 1: hand-off flags of the persistent backward substitution (+ timeout word)
     // rocSOLVER cross-check backend
@@ -1067,6 +1068,7 @@ inline void potrf_free(PotrfWorkspace& w)
     bsfm::dev_free(w.linv, true);
     bsfm::dev_free(w.y, true);
     bsfm::dev_free(w.xs, true);
+    if (w.xu) { (void)hipFree(w.xu); w.xu = nullptr; }
     bsfm::dev_free(w.etmp, true);
     bsfm::dev_free(w.bflags, true);
     bsfm::dev_free(w.d_last, true);
@@ -1122,6 +1124,8 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
     if (const char* e = getenv("BSFM_CHOL")) w.use_flow = strcmp(e, "streams") != 0;
     if (bsfm::dev_alloc((void**)&w.y, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
     if (bsfm::dev_alloc((void**)&w.xs, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
+    if (w.xu) { (void)hipFree(w.xu); w.xu = nullptr; }
+    if (hipExtMallocWithFlags((void**)&w.xu, (size_t)ld * sizeof(double), hipDeviceMallocUncached) != hipSuccess) { w.xu = nullptr; (void)hipGetLastError(); }
     if (bsfm::dev_alloc((void**)&w.etmp, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
     if (bsfm::dev_alloc((void**)&w.bflags, (size_t)(w.nblk + 1) * sizeof(int)) != hipSuccess) return -1;
     if (const char* e = getenv("BSFM_SYRK_EVENTS")) w.syrk_events = std::max(0, atoi(e));
