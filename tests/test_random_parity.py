@@ -12,16 +12,16 @@ import oracle_util as O
 pytestmark = pytest.mark.gpu
 
 
-def _case(B, seed):
+def _case(B, seed, kmax_cap=8):
     rng = np.random.default_rng(1000 + seed)
-    m = int(rng.integers(3, 36))
+    m = int(rng.integers(3, 36)) if kmax_cap <= 8 else int(rng.integers(16, 36))
     n = int(rng.integers(10 * m, 14 * m))
     est, und = int(rng.integers(0, 2)), int(rng.integers(0, 2))
     cnp = 6 + est + 2 * und
     mcon = int(rng.integers(0, min(3, m - 1)))
     base = B.synth_ba(max(m, 2), n, 2)
     cams = base["cams"]
-    kmax = min(m, 8)
+    kmax = min(m, kmax_cap)
     rows = [np.sort(rng.choice(m, int(rng.integers(2, kmax + 1)), replace=False)) for _ in range(n)]
     if seed % 3 == 0 and m > 6:                       # two camera groups that share no point (group-by-group solver)
         half = m // 2
@@ -76,3 +76,26 @@ def test_random_problem_matches_oracle(gpu_bsfm, seed):
     assert np.abs(p - q["p"]).max() <= 1e-6 * np.abs(q["p"]).max(), tag
     if c["auto"] and seed % 3 == 0 and c["m"] > 6:
         assert groups >= 2, tag
+
+
+@pytest.mark.parametrize("seed", [100, 101, 103, 104, 106, 107, 109, 110])      # (seeds divisible by 3 build two small camera groups: short rows)
+def test_long_rows_match_oracle(gpu_bsfm, seed):
+    """Points with up to 30 observations: the small-problem kernels of round 6 give a point to FOUR lanes, three observations per lane and trip
+    (kernels.hip.h: k_point_blocks<CNP, 4>, the one-pass k_backsub) -- rows beyond twelve observations take more than one trip, rows of two leave lanes
+    idle; the case generator above stops at eight."""
+    B = gpu_bsfm
+    c = _case(B, seed, kmax_cap=30)
+    vm = B.dense_vmask(c["n"], c["m"], c["rowptr"], c["colidx"])
+    assert np.diff(c["rowptr"]).max() > 12
+    q = O.port_run_sfm(c["n"], c["m"], vm, c["proj"], c["cams"], c["pts"], itmax=3, jac_mode=c["jac"], ncons=c["mcon"],
+                       est_focal=c["est"], undistort=c["und"])
+    opt = B.default_options(jacobian=B.JAC_ANALYTIC if c["jac"] else B.JAC_FD, verbose=0, itmax=3, reduced_solver=B.SOLVER_DENSE)
+    pb = B.Problem(c["n"], c["m"], c["rowptr"], c["colidx"], c["proj"], c["cams"], c["pts"], mcon=c["mcon"],
+                   est_focal_length=c["est"], undistort=c["und"], options=opt)
+    rc, info = pb.solve()
+    p = pb.download(want_cams=False)[0]
+    pb.close()
+    tag = {k: c[k] for k in ("m", "n", "cnp", "mcon", "jac")}
+    assert list(info[5:10]) == list(q["info"][5:10]), (tag, info, q["info"])
+    assert abs(info[0] - q["info"][0]) <= 1e-10 * q["info"][0] and abs(info[1] - q["info"][1]) <= 1e-8 * q["info"][1], tag
+    assert np.abs(p - q["p"]).max() <= 1e-6 * np.abs(q["p"]).max(), tag
