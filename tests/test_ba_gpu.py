@@ -176,6 +176,25 @@ def test_config2_single_iteration_vs_oracle(gpu_bsfm):
         pb.close()
 
 
+def test_two_pass_backsub_below_256_cameras_vs_oracle(gpu_bsfm):
+    """120 cameras / 45 000 points / 450 000 observations, one LM iteration against the oracle: the size class where the back-substitution is two
+    passes (from 400 000 observations) AND the trial point's camera table is built by the workgroup appended to k_backsub (below 256 cameras) --
+    a combination neither the 50-camera case above nor the 1 000-camera fixtures reach."""
+    B = gpu_bsfm
+    m, n = 120, 45000
+    s = B.synth_ba(m, n, 10)
+    vm = B.dense_vmask(n, m, s["rowptr"], s["colidx"])
+    q = O.port_run_sfm(n, m, vm, s["proj"], s["cams"], s["pts"], itmax=1, jac_mode=1)
+    pb = B.Problem(n, m, s["rowptr"], s["colidx"], s["proj"], s["cams"], s["pts"], options=B.default_options(jacobian=1, verbose=0, itmax=1))
+    rc, info = pb.solve()
+    p, _, _ = pb.download()
+    pb.close()
+    assert info[5] == 1 and info[9] == q["info"][9]
+    assert abs(info[0] - q["info"][0]) <= 1e-12 * q["info"][0]
+    assert abs(info[1] - q["info"][1]) <= 1e-9 * q["info"][1]
+    assert np.abs(p - q["p"]).max() <= 1e-7 * np.abs(q["p"]).max()
+
+
 def test_large_problem_properties(gpu_bsfm):
     """Size-independent properties at a size the CPU oracle cannot follow (200 cams / 50k pts / 500k obs):
     cost decreases monotonically over accepted steps, S is symmetric with U on its diagonal blocks when no point is
