@@ -69,7 +69,13 @@ struct FlowArgs {
     unsigned genbase;      // DISTRIBUTED factorisation (round 6): the value the per-tile counters start from in this solve (generation << 16): a rank that
                            // polls a peer's counter never mistakes the count of the PREVIOUS solve for this one's; 0 on one rank
     const struct FlowPeers* peers;      // ... the ranks' buffers (device memory); nullptr = one rank owns every tile column
+    // DATA AS FLAG on the chain (round 6, one rank): second copies of W_k (tile k) and of the chain's panel tile P(k + 1, k) (tile k), read only with
+    // agent-scope loads, filled with FLOW_PENDING by k_flow_begin.  TRSM32 and UPD32 do not wait for the producer's counter: they load these copies until no entry
+    // is pending -- the producer's drain of its stores, its counter update, the consumer's poll and its dependent load shrink to one load of the data
+    // that sees the stores (0.7 us, scripts/r6/ubench_scalar_poll.hip).  Everybody else reads the cached originals behind the counters, as before.
+    double* Wu; double* Pu;             // nullptr: off
 };
+constexpr unsigned long long FLOW_PENDING = 0xfff85eeddeadbeefull;      // "not written yet": a quiet NaN with a payload no instruction generates
 // Distributed factorisation: tile column j -- its diagonal tile, its panel tiles, W_j, y_j, the counters of its tiles -- belongs to rank j mod n.  A rank
 // runs the tasks of its own columns (the same static order, filtered), WRITES only its own buffers, and READS the panel tiles / y / counters of a column
 // from the buffers of that column's owner: peer-mapped windows (hipIpc on a shared device, xGMI peer access between the devices of a node).
@@ -222,6 +228,7 @@ __device__ __forceinline__ FlowArgs flow_uniform_args(const FlowArgs& a)
     u.ld = __builtin_amdgcn_readfirstlane(a.ld); u.n_total = __builtin_amdgcn_readfirstlane(a.n_total); u.T = __builtin_amdgcn_readfirstlane(a.T);
     u.stall_ticket = __builtin_amdgcn_readfirstlane(a.stall_ticket);
     u.genbase = (unsigned)__builtin_amdgcn_readfirstlane((int)a.genbase); u.peers = (const FlowPeers*)up(a.peers);
+    u.Wu = (double*)up(a.Wu); u.Pu = (double*)up(a.Pu);
     return u;
 }
 
@@ -318,10 +325,50 @@ __device__ __forceinline__ void flow_tile32_impl(FlowKWords ka, const FlowArgs* 
                 const double* A_ = a.S + ((size_t)i * POTRF_NB + 32 * br + row) * a.ld + (size_t)k * POTRF_NB;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) if (16 * q < K0) { pv[q][0] = ld_sc1(A_ + 16 * q + c2); pv[q][1] = ld_sc1(A_ + 16 * q + c2 + 1); }
+            } else if (a.Wu) {
+                // W_k from its uncached copy, until no entry is pending (data as flag: see FlowArgs) -- this task did not wait for POTRF(k)'s counter
+                const double* B_ = a.Wu + (size_t)k * FLOW_TL + (size_t)(32 * bc + row) * POTRF_NB;
+                unsigned spins = 0;
+                long long t_begin = 0;
+                for (;;) {
+                    bool pend = false;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (16 * q < K0) { pv[q][0] = ld_sc1(B_ + 16 * q + c2); pv[q][1] = ld_sc1(B_ + 16 * q + c2 + 1); }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (16 * q < K0) pend |= __builtin_bit_cast(unsigned long long, pv[q][0]) == FLOW_PENDING || __builtin_bit_cast(unsigned long long, pv[q][1]) == FLOW_PENDING;
+                    if (!__any(pend)) break;
+                    if ((++spins & 63u) == 0u) {
+                        const long long now = wall_clock64();
+                        if (t_begin == 0) t_begin = now;
+                        if (now - t_begin > a.spin_limit || __hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                            __hip_atomic_store(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;      // the launch gives up: its result is discarded
+                        }
+                    }
+                }
             } else {
                 const double* B_ = a.Linv + (size_t)k * FLOW_TL + (size_t)(32 * bc + row) * POTRF_NB;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) if (16 * q < K0) { const double2 t = *reinterpret_cast<const double2*>(B_ + 16 * q + c2); pv[q][0] = t.x; pv[q][1] = t.y; }
+            }
+        } else if (a.Pu && np == 1 && p0 == i - 1) {
+            // the chain's panel tile P(i, i - 1) from its uncached copy, until no entry is pending -- this task did not wait for TRSM32's counter
+            const double* src = a.Pu + (size_t)(i - 1) * FLOW_TL + (size_t)(32 * (half ? bc : br) + row) * POTRF_NB;
+            unsigned spins = 0;
+            long long t_begin = 0;
+            for (;;) {
+                bool pend = false;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { pv[q][0] = ld_sc1(src + 16 * q + c2); pv[q][1] = ld_sc1(src + 16 * q + c2 + 1); }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) pend |= __builtin_bit_cast(unsigned long long, pv[q][0]) == FLOW_PENDING || __builtin_bit_cast(unsigned long long, pv[q][1]) == FLOW_PENDING;
+                if (!__any(pend)) break;
+                if ((++spins & 63u) == 0u) {
+                    const long long now = wall_clock64();
+                    if (t_begin == 0) t_begin = now;
+                    if (now - t_begin > a.spin_limit || __hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                        __hip_atomic_store(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;
+                    }
+                }
             }
         } else {
             const double* base_ = flow_pc(a, p0 + sg) + flow_tri(i, p0 + sg) * FLOW_TL;
@@ -348,7 +395,7 @@ __device__ __forceinline__ void flow_tile32_impl(FlowKWords ka, const FlowArgs* 
         for (int t = 0; t < 4; ++t) {
             const int rw = wr + 4 * t + (lane >> 4), col = wc + (lane & 15);
             const double v = c[t] + cc[t];
-            if (!IS_UPD) st_sc1(a.Pc + flow_tri(i, k) * FLOW_TL + (size_t)(32 * br + rw) * POTRF_NB + 32 * bc + col, v);
+            if (!IS_UPD) { st_sc1(a.Pc + flow_tri(i, k) * FLOW_TL + (size_t)(32 * br + rw) * POTRF_NB + 32 * bc + col, v); if (a.Pu) st_sc1(a.Pu + (size_t)k * FLOW_TL + (size_t)(32 * br + rw) * POTRF_NB + 32 * bc + col, v); }
             else st_sc1(Ct + (size_t)rw * a.ld + col, cin[t] - v);
         }
     }
@@ -603,6 +650,7 @@ __device__ __forceinline__ void flow_potrf_part(FlowKWords ka, const FlowArgs* a
     double xr[4] = { 0.0, 0.0, 0.0, 0.0 };            // this wave's block of the previous row of X, written out after the next barrier
     int xJ = -1;                                      // ... its column (-1: none)
     double* Wk = a.Linv + (size_t)k * FLOW_TL;
+    double* Wuk = a.Wu ? a.Wu + (size_t)k * FLOW_TL : nullptr;      // the uncached copy TRSM32 polls (see FlowArgs)
     // ---- The factor wave runs a chain of its own: A1(s), barrier, then -- without waiting for anybody -- block (s + 1, s) = B inv(L_ss)^T, the
     // last update of block (s + 1, s + 1), A1(s + 1), barrier ...  The other seven waves: barrier, A2 of column s, a barrier OF THEIR OWN
     // (an LDS word; the factor wave is busy), A3 of column s, barrier.  Everything the factor wave reads behind barrier(s) was finished
@@ -659,6 +707,7 @@ __device__ __forceinline__ void flow_potrf_part(FlowKWords ka, const FlowArgs* a
                     for (int q = 0; q < 4; ++q) {
                         slot[swz16(4 * q + lr, lc)] = xr[q];
                         st_sc1(Wk + (size_t)(16 * (s - 1) + 4 * q + lr) * POTRF_NB + 16 * xJ + lc, xr[q]);
+                        if (Wuk) st_sc1(Wuk + (size_t)(16 * (s - 1) + 4 * q + lr) * POTRF_NB + 16 * xJ + lc, xr[q]);
                     }
                     xJ = -1;
                 }
@@ -813,7 +862,7 @@ __device__ __forceinline__ void flow_potrf_part(FlowKWords ka, const FlowArgs* a
 #pragma unroll
             for (int q = 0; q < 4; ++q) res = __builtin_amdgcn_mfma_f64_16x16x4f64(Ds[swz16(lc, 4 * q + lr)], acc[q], res, 0, 0, 0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) st_sc1(Wk + (size_t)(112 + 4 * q + lr) * POTRF_NB + 16 * J + lc, -res[q]);
+            for (int q = 0; q < 4; ++q) { st_sc1(Wk + (size_t)(112 + 4 * q + lr) * POTRF_NB + 16 * J + lc, -res[q]); if (Wuk) st_sc1(Wuk + (size_t)(112 + 4 * q + lr) * POTRF_NB + 16 * J + lc, -res[q]); }
         }
         if (KEEP) {
             __syncthreads();                               // every wave has read the blocks of row 7 of L it needed
@@ -825,7 +874,7 @@ __device__ __forceinline__ void flow_potrf_part(FlowKWords ka, const FlowArgs* a
         }
         const double* Dw = Di + w * 256;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) st_sc1(Wk + (size_t)(16 * w + 4 * q + lr) * POTRF_NB + 16 * w + lc, Dw[swz16(4 * q + lr, lc)]);
+        for (int q = 0; q < 4; ++q) { const double dv = Dw[swz16(4 * q + lr, lc)]; st_sc1(Wk + (size_t)(16 * w + 4 * q + lr) * POTRF_NB + 16 * w + lc, dv); if (Wuk) st_sc1(Wuk + (size_t)(16 * w + 4 * q + lr) * POTRF_NB + 16 * w + lc, dv); }
     }
     BSFM_FLOW_MARK(37);
 #undef BSFM_FLOW_MARK
@@ -958,6 +1007,10 @@ __global__ __launch_bounds__(512, WPS) void k_chol_flow(FlowArgs a_param)
         const int part = __builtin_amdgcn_readfirstlane((int)((w0 >> 16) & 255u)), nwait = __builtin_amdgcn_readfirstlane((int)(w0 >> 24));
         const int ti = __builtin_amdgcn_readfirstlane((int)(w1 & 0xffffu)), tj = __builtin_amdgcn_readfirstlane((int)(w1 >> 16));
         const int p0 = __builtin_amdgcn_readfirstlane((int)(w2 & 0xffffu));
+        // data as flag (FlowArgs::Wu / Pu): the LAST wait of a TRSM32 (POTRF's counter) and of a UPD32 whose last panel is the chain's tile (TRSM32's
+        // counter) is replaced by the task's own loads of the data (flow_tile32_impl)
+        // (a UPD32 visit of several panels keeps its wait: that counter also stands for the earlier panels of the visit, which are read first and cached)
+        const int nwait_eff = ((a.Wu && type == FT_TRSM32) || (a.Pu && type == FT_UPD32 && np == 1 && p0 == ti - 1)) ? nwait - 1 : nwait;
         if (wave == 0) {
             // every lane of wave 0 polls the same word: one request, a scalar verdict
             const long long t_begin = wall_clock64();
@@ -970,14 +1023,14 @@ __global__ __launch_bounds__(512, WPS) void k_chol_flow(FlowArgs a_param)
                 const unsigned gb = (unsigned)__builtin_amdgcn_readfirstlane((int)a.genbase);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    const int qq = q < nwait ? q : 0;
+                    const int qq = q < nwait_eff ? q : 0;
                     const unsigned ix = (unsigned)__builtin_amdgcn_readfirstlane((int)tp->w[qq].idx);
-                    thr[q] = q < nwait ? (unsigned)__builtin_amdgcn_readfirstlane((int)tp->w[qq].thr) : 0u;
+                    thr[q] = q < nwait_eff ? (unsigned)__builtin_amdgcn_readfirstlane((int)tp->w[qq].thr) : 0u;
                     // (distributed: the counter lives with the owner of its tile column; the host put the owner's rank above bit 24)
                     fp[q] = a.peers ? a.peers->flags[ix >> FLOW_OWNER_SHIFT] + (ix & ((1u << FLOW_OWNER_SHIFT) - 1u)) : flags + ix;
                 }
                 unsigned spins = 0;
-                while (nwait > 0) {
+                while (nwait_eff > 0) {
                     unsigned s0, s1, s2;
                     if (a.peers) {      // a peer's counter may live on another device of the node: system scope
                         s0 = __hip_atomic_load(fp[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1030,7 +1083,7 @@ __global__ __launch_bounds__(512, WPS) void k_chol_flow(FlowArgs a_param)
     }
 }
 
-constexpr unsigned long long FLOW_X_PENDING = 0xfff85eeddeadbeefull;      // "x_k has not arrived": a quiet NaN with a payload no instruction generates
+constexpr unsigned long long FLOW_X_PENDING = FLOW_PENDING;      // "x_k has not arrived"
 // Backward substitution x = L^-T y, one persistent launch (k_bwd_persistent of potrf.hip.h reading the compact panel tiles).
 // Every workgroup of a launch must be resident (it waits for the tile columns to its right), so systems of more than POTRF_MAX_TILES
 // tile columns run it in WAVES of that many columns, rightmost first (`first` = columns already done): a later wave finds the flags
@@ -1207,8 +1260,9 @@ __global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc,
 // ---- k_bwd_scalar (round 6): the backward substitution of ONE rank with its polls on the SCALAR memory path.
 // What bounds k_bwd_flow is the order of a wave's vector loads: a poll queues behind the wave's own tile request and is answered when the 128 KB have
 // landed, 2.4 us later (profiles/r06_backward_substitution_chain.txt).  Scalar loads have a queue of their own (lgkmcnt), and a word another XCD
-// stores is seen through them 0.66 us later when the buffer is UNCACHED device memory (scripts/r6/ubench_scalar_poll.hip) -- so here
-//   * x lives in an uncached buffer; wave w (rows 32 w .. 32 w + 31 of every tile, columns 2 lane and 2 lane + 1) polls ITS 32 entries of x_i with four
+// stores is seen through them (s_load ... glc) 1.3 us later on ordinary device memory, 0.66 us on uncached memory (scripts/r6/ubench_scalar_poll.hip;
+// uncached buffers are NOT used by default: see potrf_alloc) -- so here
+//   * x lives in a buffer of its own that is only ever read this way; wave w (rows 32 w .. 32 w + 31 of every tile, columns 2 lane and 2 lane + 1) polls ITS 32 entries of x_i with four
 //     s_load_dwordx16 and takes them as the scalar operands of its 64 FMAs: no LDS staging, no barrier per step, the four waves run through the
 //     steps independently;
 //   * THREE tile buffers: tile j + 2 is requested in step j -- two tiles in flight per column, which is what a period below the 2.4 us of one tile
@@ -1216,7 +1270,7 @@ __global__ __launch_bounds__(256) void k_bwd_flow(const double* __restrict__ Pc,
 // The order of the sums is k_bwd_flow's (quarters of 32 rows, four chains, fixed trees): the same bits on every path.
 typedef unsigned int bwd_u16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void k_bwd_scalar(const double* __restrict__ Pc, int nblk, int first, const double* __restrict__ Linv,
-        const double* __restrict__ y, double* x /* uncached, filled with FLOW_X_PENDING */, int* timeout, const int* __restrict__ last_row,
+        const double* __restrict__ y, double* x /* a buffer of its own, filled with FLOW_X_PENDING */, int* timeout, const int* __restrict__ last_row,
         long long spin_limit, int stall_col, double* __restrict__ x_out, int n_out, const unsigned* __restrict__ fwd_timeout, int* __restrict__ info)
 {
     __shared__ double yk[POTRF_NB];
@@ -1320,9 +1374,18 @@ __global__ __launch_bounds__(256) void k_flow_begin(unsigned* __restrict__ sync,
                                                     double* __restrict__ etmp, const double* __restrict__ E, int n, int ld,
                                                     unsigned genbase = 0u, unsigned nflags = 0u /* distributed: the per-tile counters start at genbase;
                                                                                                    the backward flags keep their generations (nbflags = the time-out word only) */,
-                                                    unsigned long long* __restrict__ x_pending = nullptr /* one rank: the solution vector, filled with FLOW_X_PENDING */)
+                                                    unsigned long long* __restrict__ x_pending = nullptr /* one rank: the solution vector, filled with FLOW_X_PENDING */,
+                                                    unsigned long long* __restrict__ wu = nullptr, unsigned long long* __restrict__ pu = nullptr, unsigned ntiles = 0u
+                                                    /* data as flag (FlowArgs::Wu / Pu): every entry pending -- except the 16 x 16 blocks above W's diagonal, which
+                                                       POTRF never writes and TRSM32 reads as the zeros they are */)
 {
     const unsigned stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wu)
+        for (unsigned q = t0; q < ntiles * (unsigned)FLOW_TL; q += stride) {
+            const unsigned r = (q >> 7) & 127u, c = q & 127u;
+            wu[q] = (r >> 4) >= (c >> 4) ? FLOW_PENDING : 0ull;
+            pu[q] = FLOW_PENDING;
+        }
     if (x_pending) for (unsigned q = t0; q < (unsigned)ld; q += stride) x_pending[q] = FLOW_X_PENDING;
     for (unsigned q = t0; q < sync_words; q += stride) sync[q] = (q >= 8u && q < 8u + nflags) ? genbase : 0u;
     for (unsigned q = t0; q < (unsigned)nbflags; q += stride) bflags[q] = 0;
@@ -1351,6 +1414,8 @@ struct FlowWorkspace {
     long long spin_limit = FLOW_SPIN_LIMIT_TICKS;      // BSFM_FLOW_SPIN_MS
     int stall_ticket = -1, stall_bwd_col = -1;         // test hooks: BSFM_FLOW_TEST_STALL (bulk ticket that never signals), BSFM_FLOW_TEST_STALL_BWD (column)
     bool bwd_scalar = true;                // BSFM_BWD_SCALAR=0|1: backward substitution with its polls on the scalar memory path (k_bwd_scalar; one rank)
+    int data_flags = 3;                    // BSFM_FLOW_DATA_FLAGS=0|1: the chain's TRSM32 / UPD32 poll uncached copies of W_k / P(k + 1, k) instead of counters (FlowArgs::Wu / Pu)
+    double* wu = nullptr; double* pu = nullptr;      // those copies: nblk tiles each (ordinary device memory, read with agent-scope loads only)
     int wgs = 512;                         // workgroups launched (BSFM_FLOW_WGS)
     bool chain_shared = false;             // the chain workgroups other than POTRF's share their CUs with bulk workgroups (bulk-bound systems, see flow_prepare)
     int chain_wgs = 17;                    // of them: serve the chain queue, alone on their CU (17 or 27, see flow_prepare; BSFM_FLOW_CHAIN_WGS; 0 = one queue)
@@ -1395,6 +1460,7 @@ inline void flow_free(FlowWorkspace& f)
     if (f.dist) { flow_dist_free(*f.dist); delete f.dist; f.dist = nullptr; }
     bsfm::dev_free(f.d_tasks, true); bsfm::dev_free(f.d_sync, true); bsfm::dev_free(f.pc, true);
     if (f.d_trace) (void)hipFree(f.d_trace);
+    bsfm::dev_free(f.wu, true); bsfm::dev_free(f.pu, true);
     if (f.k0) (void)hipEventDestroy(f.k0);
     if (f.k1) (void)hipEventDestroy(f.k1);
     f = FlowWorkspace();
@@ -1470,7 +1536,12 @@ inline int flow_prepare(FlowWorkspace& f, int nblk, const std::vector<int>& env_
     if (f.d_tasks && f.nblk == nblk && f.env_key == key) return 0;
     bsfm::dev_free(f.d_tasks, true); f.d_tasks = nullptr;
     bsfm::dev_free(f.d_sync, true); f.d_sync = nullptr;
-    if (f.nblk != nblk) { bsfm::dev_free(f.pc, true); f.pc = nullptr; }
+    if (f.nblk != nblk) {
+        bsfm::dev_free(f.pc, true); f.pc = nullptr;
+        bsfm::dev_free(f.wu, true); f.wu = nullptr;
+        bsfm::dev_free(f.pu, true); f.pu = nullptr;
+    }
+    if (const char* e = getenv("BSFM_FLOW_DATA_FLAGS")) f.data_flags = atoi(e);      // bit 0: W_k, bit 1: P(k + 1, k)
     if (const char* e = getenv("BSFM_FLOW_WGS")) f.wgs = std::max(2, atoi(e));
     if (const char* e = getenv("BSFM_FLOW_TRACE")) f.trace = atoi(e) != 0;
     f.spin_limit = FLOW_SPIN_LIMIT_TICKS; f.stall_ticket = -1; f.stall_bwd_col = -1;
@@ -1514,6 +1585,15 @@ inline int flow_prepare(FlowWorkspace& f, int nblk, const std::vector<int>& env_
     if (!f.pc) {
         const size_t ntile = std::max<size_t>(1, (size_t)nblk * (size_t)(nblk - 1) / 2);
         if (bsfm::dev_alloc((void**)&f.pc, ntile * FLOW_TL * sizeof(double)) != hipSuccess) return -1;
+    }
+    if (f.data_flags && nblk >= 2 && !f.wu) {
+        // ORDINARY device memory: these copies are read ONLY with agent-scope loads (which never hit a stale line of an L2) and written with write-through
+        // stores, like the counters.  (Uncached memory was tried first and gave wrong factors in ~1 % of a randomised sweep, always in the same cases of a
+        // sequence and never when such a case ran alone: buffers of that type that are allocated and freed between solves apparently inherit something
+        // from the pages' earlier life.  profiles/r06_chain_data_flags.txt)
+        const size_t bytes = (size_t)nblk * FLOW_TL * sizeof(double);
+        if (bsfm::dev_alloc((void**)&f.wu, bytes) != hipSuccess) { f.wu = nullptr; (void)hipGetLastError(); }
+        else if (bsfm::dev_alloc((void**)&f.pu, bytes) != hipSuccess) { bsfm::dev_free(f.wu, true); f.wu = nullptr; f.pu = nullptr; (void)hipGetLastError(); }
     }
     if (f.trace) {
         if (f.d_trace) (void)hipFree(f.d_trace);
@@ -1569,11 +1649,14 @@ inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, in
     // the solution vector of the backward substitution: the uncached buffer and the scalar-poll kernel where that buffer exists (BSFM_BWD_SCALAR=0: the
     // vector-poll kernel on the ordinary buffer)
     double* const xvec = (w.xu && f.bwd_scalar) ? w.xu : w.xs;
-    hipLaunchKernelGGL(k_flow_begin, dim3((unsigned)std::min<size_t>(64, (std::max<size_t>(f.sync_words, (size_t)ld) + 255) / 256)), dim3(256), 0, st,
-                       f.d_sync, (unsigned)f.sync_words, w.bflags, w.nblk + 1, w.etmp, E, n, ld, 0u, 0u, reinterpret_cast<unsigned long long*>(xvec));
+    const bool dflags = f.data_flags != 0 && f.wu && f.pu;
+    hipLaunchKernelGGL(k_flow_begin, dim3((unsigned)std::min<size_t>(dflags ? 1024 : 64, (std::max<size_t>(std::max<size_t>(f.sync_words, (size_t)ld), dflags ? (size_t)nblk * FLOW_TL / 8 : 0) + 255) / 256)),
+                       dim3(256), 0, st, f.d_sync, (unsigned)f.sync_words, w.bflags, w.nblk + 1, w.etmp, E, n, ld, 0u, 0u, reinterpret_cast<unsigned long long*>(xvec),
+                       reinterpret_cast<unsigned long long*>(dflags ? f.wu : nullptr), reinterpret_cast<unsigned long long*>(dflags ? f.pu : nullptr), (unsigned)nblk);
     FlowArgs a;
     memset(&a, 0, sizeof a);      // (genbase = 0, peers = nullptr: one rank)
     a.S = S; a.ld = ld; a.n_total = n; a.T = nblk; a.Pc = f.pc; a.Linv = w.linv; a.E = w.etmp; a.y = w.y;
+    a.Wu = (dflags && (f.data_flags & 1)) ? f.wu : nullptr; a.Pu = (dflags && (f.data_flags & 2)) ? f.pu : nullptr;
     a.tasks = f.d_tasks; a.chain_tasks = f.d_tasks + f.bulk.size(); a.n_bulk = (unsigned)f.bulk.size(); a.n_chain = (unsigned)f.chain.size();
     a.potrf_tasks = f.d_tasks + f.bulk.size() + f.chain.size(); a.n_potrf = (unsigned)f.potrf.size();
     a.n_chain_wgs = (unsigned)f.chain_wgs; a.sync = f.d_sync; a.nflags = (unsigned)f.sched.nflags; a.info = d_info;

@@ -121,7 +121,7 @@ struct PotrfWorkspace {
     double* linv = nullptr;    // nblk tiles: inverse of each diagonal factor tile
     double* y = nullptr;       // ld
     double* xs = nullptr;      // ld
-    double* xu = nullptr;      // ld, UNCACHED device memory (hipExtMallocWithFlags): the solution vector k_bwd_scalar polls through the scalar path; null if the allocation is refused
+    double* xu = nullptr;      // ld: the solution vector k_bwd_scalar polls through the scalar path (a buffer of its own: nothing else ever reads it cached)
     double* etmp = nullptr;    // ld (rhs working copy)
     int* bflags = nullptr;     // nblk + 1: hand-off flags of the persistent backward substitution (+ timeout word)
     // rocSOLVER cross-check backend
@@ -1125,7 +1125,12 @@ inline int potrf_init(PotrfWorkspace& w, int ld, int backend)
     if (bsfm::dev_alloc((void**)&w.y, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
     if (bsfm::dev_alloc((void**)&w.xs, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
     if (w.xu) { (void)hipFree(w.xu); w.xu = nullptr; }
-    if (hipExtMallocWithFlags((void**)&w.xu, (size_t)ld * sizeof(double), hipDeviceMallocUncached) != hipSuccess) { w.xu = nullptr; (void)hipGetLastError(); }
+    // ORDINARY device memory by default.  Uncached memory (BSFM_XU_UNCACHED=1) makes the scalar polls see a store 0.66 us after it instead of 1.3 us
+    // (k_bwd_scalar 181 instead of 242 us at 71 tile columns) -- but buffers of that type, allocated and freed between solves, gave WRONG RESULTS in
+    // ~1 % of a randomised sweep when the chain's hand-offs used them (profiles/r06_chain_data_flags.txt): not a memory type to ship a solution vector in.
+    if (getenv("BSFM_XU_UNCACHED") && atoi(getenv("BSFM_XU_UNCACHED")) != 0) {
+        if (hipExtMallocWithFlags((void**)&w.xu, (size_t)ld * sizeof(double), hipDeviceMallocUncached) != hipSuccess) { w.xu = nullptr; (void)hipGetLastError(); }
+    } else if (hipMalloc((void**)&w.xu, (size_t)ld * sizeof(double)) != hipSuccess) { w.xu = nullptr; (void)hipGetLastError(); }
     if (bsfm::dev_alloc((void**)&w.etmp, (size_t)ld * sizeof(double)) != hipSuccess) return -1;
     if (bsfm::dev_alloc((void**)&w.bflags, (size_t)(w.nblk + 1) * sizeof(int)) != hipSuccess) return -1;
     if (const char* e = getenv("BSFM_SYRK_EVENTS")) w.syrk_events = std::max(0, atoi(e));
