@@ -74,6 +74,7 @@ struct FlowArgs {
     // is pending -- the producer's drain of its stores, its counter update, the consumer's poll and its dependent load shrink to one load of the data
     // that sees the stores (0.7 us, scripts/r6/ubench_scalar_poll.hip).  Everybody else reads the cached originals behind the counters, as before.
     double* Wu; double* Pu;             // nullptr: off
+    double* Du;                         // ... and of the diagonal tile after its LAST update where that is a one-panel UPD32 (tile k): POTRF(k) polls it (latency build)
 };
 constexpr unsigned long long FLOW_PENDING = 0xfff85eeddeadbeefull;      // "not written yet": a quiet NaN with a payload no instruction generates
 // Distributed factorisation: tile column j -- its diagonal tile, its panel tiles, W_j, y_j, the counters of its tiles -- belongs to rank j mod n.  A rank
@@ -228,7 +229,7 @@ __device__ __forceinline__ FlowArgs flow_uniform_args(const FlowArgs& a)
     u.ld = __builtin_amdgcn_readfirstlane(a.ld); u.n_total = __builtin_amdgcn_readfirstlane(a.n_total); u.T = __builtin_amdgcn_readfirstlane(a.T);
     u.stall_ticket = __builtin_amdgcn_readfirstlane(a.stall_ticket);
     u.genbase = (unsigned)__builtin_amdgcn_readfirstlane((int)a.genbase); u.peers = (const FlowPeers*)up(a.peers);
-    u.Wu = (double*)up(a.Wu); u.Pu = (double*)up(a.Pu);
+    u.Wu = (double*)up(a.Wu); u.Pu = (double*)up(a.Pu); u.Du = (double*)up(a.Du);
     return u;
 }
 
@@ -396,7 +397,7 @@ __device__ __forceinline__ void flow_tile32_impl(FlowKWords ka, const FlowArgs* 
             const int rw = wr + 4 * t + (lane >> 4), col = wc + (lane & 15);
             const double v = c[t] + cc[t];
             if (!IS_UPD) { st_sc1(a.Pc + flow_tri(i, k) * FLOW_TL + (size_t)(32 * br + rw) * POTRF_NB + 32 * bc + col, v); if (a.Pu) st_sc1(a.Pu + (size_t)k * FLOW_TL + (size_t)(32 * br + rw) * POTRF_NB + 32 * bc + col, v); }
-            else st_sc1(Ct + (size_t)rw * a.ld + col, cin[t] - v);
+            else { st_sc1(Ct + (size_t)rw * a.ld + col, cin[t] - v); if (a.Du && np == 1 && p0 == i - 1) st_sc1(a.Du + (size_t)i * FLOW_TL + (size_t)(32 * br + rw) * POTRF_NB + 32 * bc + col, cin[t] - v); }
         }
     }
 }
@@ -554,14 +555,18 @@ __device__ const unsigned long long kFlowPotrfSlots[8] = {      // 5 slots per w
 // KEEP (the one-tile solve): the last row of the inverse also goes to LDS, into the slots of row 7 of L, so that the whole of inv(L) can be read there
 // afterwards (one more workgroup barrier: not in the multi-tile launch, where this function is the chain).
 template <int V, bool IS_F, bool KEEP = false>
-__device__ __forceinline__ void flow_potrf_part(FlowKWords ka, const FlowArgs* a_in, int k, double* lds)
+__device__ __forceinline__ void flow_potrf_part(FlowKWords ka, const FlowArgs* a_in, int k, double* lds, int poll_in = 0)
 {
     const FlowArgs a = flow_role_args<V>(ka, a_in); BSFM_UNIFORM_INT(k);
+    // poll: the tile comes from its copy in a.Du (row stride 128), loaded until no entry is pending -- the task did not wait for the counter of the ten
+    // UPD32 parts that wrote it (data as flag, see FlowArgs)
+    const bool poll = a.Du != nullptr && __builtin_amdgcn_readfirstlane(poll_in) != 0;
     double* Lb = lds + FLOW_LB; double* Di = lds + FLOW_DI;
     const int tid = threadIdx.x, lane0 = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int base = k * POTRF_NB, n_total = a.n_total;
-    const double* G = a.S + (size_t)base * a.ld + base;
+    const double* G = poll ? a.Du + (size_t)k * FLOW_TL : a.S + (size_t)base * a.ld + base;
+    const int gld = poll ? POTRF_NB : a.ld;
     const int lr0 = lane0 >> 4, lc0 = lane0 & 15;
 #define BSFM_FLOW_MARK(code) do { if (a.trace && lane0 == 0 && w == FLOW_FACTOR_WAVE) a.trace[a.ptrace_ofs + 40 * (size_t)k + (code)] = wall_clock64(); } while (0)
 #define BSFM_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -581,20 +586,47 @@ __device__ __forceinline__ void flow_potrf_part(FlowKWords ka, const FlowArgs* a
         }
     }
     double t[5][4];
+    double dg[4];                                          // this wave's diagonal block (see below)
     {
         // The whole tile lies inside the padded allocation of S, so every lane loads unconditionally (20 loads in flight, no divergent
         // control flow) and the triangle / padding rules are applied with selects: lower triangle of S, identity beyond n_total.
         const int lr = lr0, lc = lc0;
+        const int Id = factor_wave ? 0 : wi >= 0 ? wi + 1 : 7;
+        unsigned spins = 0;
+        long long t_begin = 0;
+        for (;;) {
 #pragma unroll
-        for (int m = 0; m < 5; ++m) {
-            const int I = sI[m] < 0 ? 0 : sI[m], J = sJ[m] < 0 ? 0 : sJ[m];
-            const double* bp = G + (size_t)(16 * I + lr) * a.ld + 16 * J + lc;
-            if (!factor_wave) {                              // (the factor wave has no slots: straight to its diagonal block)
+            for (int m = 0; m < 5; ++m) {
+                const int I = sI[m] < 0 ? 0 : sI[m], J = sJ[m] < 0 ? 0 : sJ[m];
+                const double* bp = G + (size_t)(16 * I + lr) * gld + 16 * J + lc;
+                if (!factor_wave) {                              // (the factor wave has no slots: straight to its diagonal block)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) t[m][q] = ld_sc1(bp + (size_t)(4 * q) * a.ld);
-            } else {
+                    for (int q = 0; q < 4; ++q) t[m][q] = ld_sc1(bp + (size_t)(4 * q) * gld);
+                } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) t[m][q] = 0.0;
+                    for (int q = 0; q < 4; ++q) t[m][q] = 0.0;
+                }
+            }
+            {
+                const double* bp = G + (size_t)(16 * Id + lr) * gld + 16 * Id + lc;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dg[q] = ld_sc1(bp + (size_t)(4 * q) * gld);
+            }
+            if (!poll) break;
+            bool pend = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                pend |= __builtin_bit_cast(unsigned long long, dg[q]) == FLOW_PENDING;
+#pragma unroll
+                for (int m = 0; m < 5; ++m) pend |= __builtin_bit_cast(unsigned long long, t[m][q]) == FLOW_PENDING;
+            }
+            if (!__any(pend)) break;
+            if ((++spins & 63u) == 0u) {
+                const long long now = wall_clock64();
+                if (t_begin == 0) t_begin = now;
+                if (now - t_begin > a.spin_limit || __hip_atomic_load(a.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    __hip_atomic_store(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break;      // the launch gives up: its result is discarded
+                }
             }
         }
 #pragma unroll
@@ -614,11 +646,7 @@ __device__ __forceinline__ void flow_potrf_part(FlowKWords ka, const FlowArgs* a
         // the diagonal blocks, one per wave: block 0 by the factor wave, into registers (A1 is about to take it); blocks 1 .. 6 by the workers and
         // block 7 by wave 7, into LDS, each in the slot of its inverse (nobody reads them before the first barrier)
         const int lr = lr0, lc = lc0;
-        const int I = factor_wave ? 0 : wi >= 0 ? wi + 1 : 7;
-        double dg[4];
-        const double* bp = G + (size_t)(16 * I + lr) * a.ld + 16 * I + lc;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dg[q] = ld_sc1(bp + (size_t)(4 * q) * a.ld);
+        const int I = factor_wave ? 0 : wi >= 0 ? wi + 1 : 7;      // (dg was loaded with the slots above)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = 16 * I + 4 * q + lr, c = 16 * I + lc;
@@ -892,14 +920,14 @@ __device__ BSFM_FLOW_ROLE void flow_trsm64(FlowTag<4>, FlowKWords ka, const Flow
 __device__ __forceinline__ void flow_trsm64(FlowTag<2>, FlowKWords ka, const FlowArgs* a_in, int i, int k, int r0, double* lds) { flow_trsm64_impl<2>(ka, a_in, i, k, r0, lds); }
 template <bool IS_UPD> __device__ BSFM_FLOW_ROLE void flow_tile32(FlowTag<4>, FlowKWords ka, const FlowArgs* a_in, int i, int k, int p0, int np, int part, double* lds) { flow_tile32_impl<IS_UPD, 4>(ka, a_in, i, k, p0, np, part, lds); }
 template <bool IS_UPD> __device__ __forceinline__ void flow_tile32(FlowTag<2>, FlowKWords ka, const FlowArgs* a_in, int i, int k, int p0, int np, int part, double* lds) { flow_tile32_impl<IS_UPD, 2>(ka, a_in, i, k, p0, np, part, lds); }
-__device__ BSFM_FLOW_ROLE void flow_potrf_factor(FlowTag<4>, FlowKWords ka, const FlowArgs* a_in, int k, double* lds) { flow_potrf_part<4, true>(ka, a_in, k, lds); }
-__device__ BSFM_FLOW_ROLE void flow_potrf_workers(FlowTag<4>, FlowKWords ka, const FlowArgs* a_in, int k, double* lds) { flow_potrf_part<4, false>(ka, a_in, k, lds); }
-__device__ __forceinline__ void flow_potrf_factor(FlowTag<2>, FlowKWords ka, const FlowArgs* a_in, int k, double* lds) { flow_potrf_part<2, true>(ka, a_in, k, lds); }
-__device__ __forceinline__ void flow_potrf_workers(FlowTag<2>, FlowKWords ka, const FlowArgs* a_in, int k, double* lds) { flow_potrf_part<2, false>(ka, a_in, k, lds); }
-template <int V> __device__ __forceinline__ void flow_potrf(FlowTag<V> tag, FlowKWords ka, const FlowArgs* a_in, int k, double* lds)
+__device__ BSFM_FLOW_ROLE void flow_potrf_factor(FlowTag<4>, FlowKWords ka, const FlowArgs* a_in, int k, double* lds, int poll) { flow_potrf_part<4, true>(ka, a_in, k, lds, poll); }
+__device__ BSFM_FLOW_ROLE void flow_potrf_workers(FlowTag<4>, FlowKWords ka, const FlowArgs* a_in, int k, double* lds, int poll) { flow_potrf_part<4, false>(ka, a_in, k, lds, poll); }
+__device__ __forceinline__ void flow_potrf_factor(FlowTag<2>, FlowKWords ka, const FlowArgs* a_in, int k, double* lds, int poll) { flow_potrf_part<2, true>(ka, a_in, k, lds, poll); }
+__device__ __forceinline__ void flow_potrf_workers(FlowTag<2>, FlowKWords ka, const FlowArgs* a_in, int k, double* lds, int poll) { flow_potrf_part<2, false>(ka, a_in, k, lds, poll); }
+template <int V> __device__ __forceinline__ void flow_potrf(FlowTag<V> tag, FlowKWords ka, const FlowArgs* a_in, int k, double* lds, int poll = 0)
 {
-    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == FLOW_FACTOR_WAVE) flow_potrf_factor(tag, ka, a_in, k, lds);
-    else flow_potrf_workers(tag, ka, a_in, k, lds);
+    if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == FLOW_FACTOR_WAVE) flow_potrf_factor(tag, ka, a_in, k, lds, poll);
+    else flow_potrf_workers(tag, ka, a_in, k, lds, poll);
 }
 
 constexpr long long FLOW_SPIN_LIMIT_TICKS = 40LL * 1000 * 1000;      // 0.4 s of the 100 MHz wall clock: far beyond any solve this library accepts (BSFM_FLOW_SPIN_MS overrides it)
@@ -1010,7 +1038,8 @@ __global__ __launch_bounds__(512, WPS) void k_chol_flow(FlowArgs a_param)
         // data as flag (FlowArgs::Wu / Pu): the LAST wait of a TRSM32 (POTRF's counter) and of a UPD32 whose last panel is the chain's tile (TRSM32's
         // counter) is replaced by the task's own loads of the data (flow_tile32_impl)
         // (a UPD32 visit of several panels keeps its wait: that counter also stands for the earlier panels of the visit, which are read first and cached)
-        const int nwait_eff = ((a.Wu && type == FT_TRSM32) || (a.Pu && type == FT_UPD32 && np == 1 && p0 == ti - 1)) ? nwait - 1 : nwait;
+        const int nwait_eff = ((a.Wu && type == FT_TRSM32) || (a.Pu && type == FT_UPD32 && np == 1 && p0 == ti - 1)) ? nwait - 1
+                            : (a.Du && type == FT_POTRF && np == 1) ? 0 : nwait;      // (a POTRF marked np = 1 by the host: its tile's last update was a one-panel UPD32)
         if (wave == 0) {
             // every lane of wave 0 polls the same word: one request, a scalar verdict
             const long long t_begin = wall_clock64();
@@ -1058,7 +1087,7 @@ __global__ __launch_bounds__(512, WPS) void k_chol_flow(FlowArgs a_param)
         __syncthreads();
         if (__builtin_amdgcn_readfirstlane(s_abort)) return;
         switch (type) {
-        case FT_POTRF:  flow_potrf(FlowTag<V>(), ka, a_in, tj, lds); break;
+        case FT_POTRF:  flow_potrf(FlowTag<V>(), ka, a_in, tj, lds, V == 2 ? np : 0); break;      // (the polled tile copy exists in the latency build only)
         case FT_TRSM32: flow_tile32<false>(FlowTag<V>(), ka, a_in, ti, tj, 0, 0, part, lds); break;
         case FT_TRSM64: flow_trsm64(FlowTag<V>(), ka, a_in, ti, tj, 64 * part, lds); break;
         case FT_UPD32:  flow_tile32<true>(FlowTag<V>(), ka, a_in, ti, tj, p0, np, part, lds); break;
@@ -1375,7 +1404,8 @@ __global__ __launch_bounds__(256) void k_flow_begin(unsigned* __restrict__ sync,
                                                     unsigned genbase = 0u, unsigned nflags = 0u /* distributed: the per-tile counters start at genbase;
                                                                                                    the backward flags keep their generations (nbflags = the time-out word only) */,
                                                     unsigned long long* __restrict__ x_pending = nullptr /* one rank: the solution vector, filled with FLOW_X_PENDING */,
-                                                    unsigned long long* __restrict__ wu = nullptr, unsigned long long* __restrict__ pu = nullptr, unsigned ntiles = 0u
+                                                    unsigned long long* __restrict__ wu = nullptr, unsigned long long* __restrict__ pu = nullptr, unsigned ntiles = 0u,
+                                                    unsigned long long* __restrict__ du = nullptr
                                                     /* data as flag (FlowArgs::Wu / Pu): every entry pending -- except the 16 x 16 blocks above W's diagonal, which
                                                        POTRF never writes and TRSM32 reads as the zeros they are */)
 {
@@ -1385,6 +1415,7 @@ __global__ __launch_bounds__(256) void k_flow_begin(unsigned* __restrict__ sync,
             const unsigned r = (q >> 7) & 127u, c = q & 127u;
             wu[q] = (r >> 4) >= (c >> 4) ? FLOW_PENDING : 0ull;
             pu[q] = FLOW_PENDING;
+            if (du) du[q] = FLOW_PENDING;
         }
     if (x_pending) for (unsigned q = t0; q < (unsigned)ld; q += stride) x_pending[q] = FLOW_X_PENDING;
     for (unsigned q = t0; q < sync_words; q += stride) sync[q] = (q >= 8u && q < 8u + nflags) ? genbase : 0u;
@@ -1414,8 +1445,8 @@ struct FlowWorkspace {
     long long spin_limit = FLOW_SPIN_LIMIT_TICKS;      // BSFM_FLOW_SPIN_MS
     int stall_ticket = -1, stall_bwd_col = -1;         // test hooks: BSFM_FLOW_TEST_STALL (bulk ticket that never signals), BSFM_FLOW_TEST_STALL_BWD (column)
     bool bwd_scalar = true;                // BSFM_BWD_SCALAR=0|1: backward substitution with its polls on the scalar memory path (k_bwd_scalar; one rank)
-    int data_flags = 3;                    // BSFM_FLOW_DATA_FLAGS=0|1: the chain's TRSM32 / UPD32 poll uncached copies of W_k / P(k + 1, k) instead of counters (FlowArgs::Wu / Pu)
-    double* wu = nullptr; double* pu = nullptr;      // those copies: nblk tiles each (ordinary device memory, read with agent-scope loads only)
+    int data_flags = 7;                    // BSFM_FLOW_DATA_FLAGS=0|1: the chain's TRSM32 / UPD32 poll uncached copies of W_k / P(k + 1, k) instead of counters (FlowArgs::Wu / Pu)
+    double* wu = nullptr; double* pu = nullptr; double* du = nullptr;      // those copies: nblk tiles each (ordinary device memory, read with agent-scope loads only)
     int wgs = 512;                         // workgroups launched (BSFM_FLOW_WGS)
     bool chain_shared = false;             // the chain workgroups other than POTRF's share their CUs with bulk workgroups (bulk-bound systems, see flow_prepare)
     int chain_wgs = 17;                    // of them: serve the chain queue, alone on their CU (17 or 27, see flow_prepare; BSFM_FLOW_CHAIN_WGS; 0 = one queue)
@@ -1460,7 +1491,7 @@ inline void flow_free(FlowWorkspace& f)
     if (f.dist) { flow_dist_free(*f.dist); delete f.dist; f.dist = nullptr; }
     bsfm::dev_free(f.d_tasks, true); bsfm::dev_free(f.d_sync, true); bsfm::dev_free(f.pc, true);
     if (f.d_trace) (void)hipFree(f.d_trace);
-    bsfm::dev_free(f.wu, true); bsfm::dev_free(f.pu, true);
+    bsfm::dev_free(f.wu, true); bsfm::dev_free(f.pu, true); bsfm::dev_free(f.du, true);
     if (f.k0) (void)hipEventDestroy(f.k0);
     if (f.k1) (void)hipEventDestroy(f.k1);
     f = FlowWorkspace();
@@ -1540,8 +1571,9 @@ inline int flow_prepare(FlowWorkspace& f, int nblk, const std::vector<int>& env_
         bsfm::dev_free(f.pc, true); f.pc = nullptr;
         bsfm::dev_free(f.wu, true); f.wu = nullptr;
         bsfm::dev_free(f.pu, true); f.pu = nullptr;
+        bsfm::dev_free(f.du, true); f.du = nullptr;
     }
-    if (const char* e = getenv("BSFM_FLOW_DATA_FLAGS")) f.data_flags = atoi(e);      // bit 0: W_k, bit 1: P(k + 1, k)
+    if (const char* e = getenv("BSFM_FLOW_DATA_FLAGS")) f.data_flags = atoi(e);      // bit 0: W_k, bit 1: P(k + 1, k), bit 2: the diagonal tile
     if (const char* e = getenv("BSFM_FLOW_WGS")) f.wgs = std::max(2, atoi(e));
     if (const char* e = getenv("BSFM_FLOW_TRACE")) f.trace = atoi(e) != 0;
     f.spin_limit = FLOW_SPIN_LIMIT_TICKS; f.stall_ticket = -1; f.stall_bwd_col = -1;
@@ -1594,6 +1626,7 @@ inline int flow_prepare(FlowWorkspace& f, int nblk, const std::vector<int>& env_
         const size_t bytes = (size_t)nblk * FLOW_TL * sizeof(double);
         if (bsfm::dev_alloc((void**)&f.wu, bytes) != hipSuccess) { f.wu = nullptr; (void)hipGetLastError(); }
         else if (bsfm::dev_alloc((void**)&f.pu, bytes) != hipSuccess) { bsfm::dev_free(f.wu, true); f.wu = nullptr; f.pu = nullptr; (void)hipGetLastError(); }
+        else if (bsfm::dev_alloc((void**)&f.du, bytes) != hipSuccess) { f.du = nullptr; (void)hipGetLastError(); }
     }
     if (f.trace) {
         if (f.d_trace) (void)hipFree(f.d_trace);
@@ -1652,11 +1685,13 @@ inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, in
     const bool dflags = f.data_flags != 0 && f.wu && f.pu;
     hipLaunchKernelGGL(k_flow_begin, dim3((unsigned)std::min<size_t>(dflags ? 1024 : 64, (std::max<size_t>(std::max<size_t>(f.sync_words, (size_t)ld), dflags ? (size_t)nblk * FLOW_TL / 8 : 0) + 255) / 256)),
                        dim3(256), 0, st, f.d_sync, (unsigned)f.sync_words, w.bflags, w.nblk + 1, w.etmp, E, n, ld, 0u, 0u, reinterpret_cast<unsigned long long*>(xvec),
-                       reinterpret_cast<unsigned long long*>(dflags ? f.wu : nullptr), reinterpret_cast<unsigned long long*>(dflags ? f.pu : nullptr), (unsigned)nblk);
+                       reinterpret_cast<unsigned long long*>(dflags ? f.wu : nullptr), reinterpret_cast<unsigned long long*>(dflags ? f.pu : nullptr), (unsigned)nblk,
+                       reinterpret_cast<unsigned long long*>(dflags && f.latency_build && (f.data_flags & 4) ? f.du : nullptr));
     FlowArgs a;
     memset(&a, 0, sizeof a);      // (genbase = 0, peers = nullptr: one rank)
     a.S = S; a.ld = ld; a.n_total = n; a.T = nblk; a.Pc = f.pc; a.Linv = w.linv; a.E = w.etmp; a.y = w.y;
     a.Wu = (dflags && (f.data_flags & 1)) ? f.wu : nullptr; a.Pu = (dflags && (f.data_flags & 2)) ? f.pu : nullptr;
+    a.Du = (dflags && f.latency_build && (f.data_flags & 4)) ? f.du : nullptr;      // (latency build only: the 128-VGPR POTRF role has no registers to spare)
     a.tasks = f.d_tasks; a.chain_tasks = f.d_tasks + f.bulk.size(); a.n_bulk = (unsigned)f.bulk.size(); a.n_chain = (unsigned)f.chain.size();
     a.potrf_tasks = f.d_tasks + f.bulk.size() + f.chain.size(); a.n_potrf = (unsigned)f.potrf.size();
     a.n_chain_wgs = (unsigned)f.chain_wgs; a.sync = f.d_sync; a.nflags = (unsigned)f.sched.nflags; a.info = d_info;

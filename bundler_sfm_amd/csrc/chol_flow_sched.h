@@ -124,6 +124,7 @@ inline int flow_build_schedule(int T, const std::vector<int>& last_in, const Flo
         int ver = 0;          // next panel to apply
         uint32_t cum = 0;     // signals issued so far on this tile's counter
         bool busy = false, fin = false, started_final = false;
+        bool last_u32 = false; // the last visit was a one-panel UPD32 with panel j - 1 (diagonal tiles)
         double t_ready = 0.0; // time the last modification becomes visible
         double p_ready = -1.0;   // time P (or W for diagonal tiles) becomes visible; < 0: not yet
         uint32_t p_thr = 0;      // counter value that means "P / W ready"
@@ -272,7 +273,9 @@ inline int flow_build_schedule(int T, const std::vector<int>& last_in, const Flo
             if (c.kind == 0) {
                 if (i != j) { const Tile& d = tl(j, j); w[nw++] = { flow_flag(T, j, j), d.p_thr }; }
                 if (i == j) out.stage_start[(size_t)j] = (int)out.tasks.size();
-                for (int part = 0; part < parts; ++part) emit(type, i, j, 0, 0, part, me, w, nw);
+                // (np of a POTRF task: 1 = the tile's last update was a one-panel UPD32 with the chain's panel -- the kernel may take the tile from that update's
+                //  second copy instead of waiting for its counter; chol_flow.hip.h, FlowArgs::Du)
+                for (int part = 0; part < parts; ++part) emit(type, i, j, 0, (type == FT_POTRF && t.last_u32) ? 1 : 0, part, me, w, nw);
                 t.started_final = true; t.busy = true;
                 t.p_thr = t.cum + (uint32_t)parts;
                 t.cum += (uint32_t)parts;
@@ -284,6 +287,7 @@ inline int flow_build_schedule(int T, const std::vector<int>& last_in, const Flo
                 { const Tile& a = tl(i, pl); w[nw++] = { flow_flag(T, i, pl), a.p_thr }; }
                 if (i != j) { const Tile& b = tl(j, pl); w[nw++] = { flow_flag(T, j, pl), b.p_thr }; }
                 for (int part = 0; part < parts; ++part) emit(type, i, j, t.ver, n, part, me, w, nw);
+                t.last_u32 = type == FT_UPD32 && n == 1 && pl == j - 1;
                 t.busy = true;
                 t.cum += (uint32_t)parts;
                 t.ver += n;

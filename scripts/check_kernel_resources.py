@@ -20,7 +20,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 RULES = {   # kernel-name substring -> (object, max VGPRs, max VGPR spills, max scratch bytes per lane)
     "k_match_bound": ("match_l2.o", 256, 0, 0),
     "k_match_l2": ("match_l2.o", 256, 0, 0),
-    "k_chol_flowILi4": ("solver.o", 128, 48, 320),      # throughput build: two workgroups per CU; its scratch is the kernel body's own state around the role
+    "k_chol_flowILi4": ("solver.o", 128, 48, 336),      # throughput build: two workgroups per CU; its scratch is the kernel body's own state around the role
                                                         # calls (44 VGPRs, 288 bytes at the end of round 5) -- the roles themselves, the POTRF factor
                                                         # wave's included, use none (scripts/role_resources.py, profiles/r05_flow_role_resources.txt)
     "k_chol_flowILi2": ("solver.o", 256, 0, 0),         # latency build (one workgroup per CU): nothing in scratch at all
