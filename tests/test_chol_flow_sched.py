@@ -294,3 +294,22 @@ def test_lookahead_triangle_schedule_replays(monkeypatch, name, T, last, lookahe
         rp.run(t)
     check_result(rp, A, b, lastc)
     assert (tasks["type"] == UPD64).sum() >= (base["type"] == UPD64).sum()        # more of the updates go out in halves
+
+
+@pytest.mark.parametrize("T,last", [(9, None), (24, None), (12, [3, 6, 6, 7, 7, 8, 8, 9, 9, 10, 11, 11])])
+def test_potrf_tasks_marked_for_the_polled_tile_copy(T, last):
+    """np of a POTRF task (round 6, chol_flow.hip.h FlowArgs::Du): 1 exactly when the LAST visit of its diagonal tile was a one-panel UPD32 with the chain's
+    panel j - 1 -- only then do that visit's ten parts write the whole final tile to the copy the POTRF polls instead of waiting for their counter."""
+    tasks, _ = B.chol_flow_schedule(T, last)
+    last_visit = {}
+    seen = 0
+    for t in tasks:
+        ty, i, j = int(t["type"]), int(t["i"]), int(t["j"])
+        if ty in (UPD32, UPD64, UPD128) and i == j and int(t["part"]) == 0:
+            last_visit[j] = (ty, int(t["p0"]), int(t["np"]))
+        if ty == POTRF:
+            lv = last_visit.get(j)
+            want = 1 if (lv is not None and lv[0] == UPD32 and lv[2] == 1 and lv[1] == j - 1) else 0
+            assert int(t["np"]) == want, (j, lv, int(t["np"]))
+            seen += want
+    assert seen >= T - 2          # all but the first column (and at most one straggler) take the fast path
