@@ -74,7 +74,7 @@ struct FlowArgs {
     // is pending -- the producer's drain of its stores, its counter update, the consumer's poll and its dependent load shrink to one load of the data
     // that sees the stores (0.7 us, scripts/r6/ubench_scalar_poll.hip).  Everybody else reads the cached originals behind the counters, as before.
     double* Wu; double* Pu;             // nullptr: off
-    double* Du;                         // ... and of the diagonal tile after its LAST update where that is a one-panel UPD32 (tile k): POTRF(k) polls it (latency build)
+    double* Du;                         // ... and of the diagonal tile after its LAST update where that is a one-panel UPD32 (tile k): POTRF(k) polls it
 };
 constexpr unsigned long long FLOW_PENDING = 0xfff85eeddeadbeefull;      // "not written yet": a quiet NaN with a payload no instruction generates
 // Distributed factorisation: tile column j -- its diagonal tile, its panel tiles, W_j, y_j, the counters of its tiles -- belongs to rank j mod n.  A rank
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(512, WPS) void k_chol_flow(FlowArgs a_param)
         __syncthreads();
         if (__builtin_amdgcn_readfirstlane(s_abort)) return;
         switch (type) {
-        case FT_POTRF:  flow_potrf(FlowTag<V>(), ka, a_in, tj, lds, V == 2 ? np : 0); break;      // (the polled tile copy exists in the latency build only)
+        case FT_POTRF:  flow_potrf(FlowTag<V>(), ka, a_in, tj, lds, np); break;
         case FT_TRSM32: flow_tile32<false>(FlowTag<V>(), ka, a_in, ti, tj, 0, 0, part, lds); break;
         case FT_TRSM64: flow_trsm64(FlowTag<V>(), ka, a_in, ti, tj, 64 * part, lds); break;
         case FT_UPD32:  flow_tile32<true>(FlowTag<V>(), ka, a_in, ti, tj, p0, np, part, lds); break;
@@ -1686,12 +1686,12 @@ inline int flow_solve(PotrfWorkspace& w, FlowWorkspace& f, double* S, int ld, in
     hipLaunchKernelGGL(k_flow_begin, dim3((unsigned)std::min<size_t>(dflags ? 1024 : 64, (std::max<size_t>(std::max<size_t>(f.sync_words, (size_t)ld), dflags ? (size_t)nblk * FLOW_TL / 8 : 0) + 255) / 256)),
                        dim3(256), 0, st, f.d_sync, (unsigned)f.sync_words, w.bflags, w.nblk + 1, w.etmp, E, n, ld, 0u, 0u, reinterpret_cast<unsigned long long*>(xvec),
                        reinterpret_cast<unsigned long long*>(dflags ? f.wu : nullptr), reinterpret_cast<unsigned long long*>(dflags ? f.pu : nullptr), (unsigned)nblk,
-                       reinterpret_cast<unsigned long long*>(dflags && f.latency_build && (f.data_flags & 4) ? f.du : nullptr));
+                       reinterpret_cast<unsigned long long*>(dflags && f.du && (f.data_flags & 4) ? f.du : nullptr));
     FlowArgs a;
     memset(&a, 0, sizeof a);      // (genbase = 0, peers = nullptr: one rank)
     a.S = S; a.ld = ld; a.n_total = n; a.T = nblk; a.Pc = f.pc; a.Linv = w.linv; a.E = w.etmp; a.y = w.y;
     a.Wu = (dflags && (f.data_flags & 1)) ? f.wu : nullptr; a.Pu = (dflags && (f.data_flags & 2)) ? f.pu : nullptr;
-    a.Du = (dflags && f.latency_build && (f.data_flags & 4)) ? f.du : nullptr;      // (latency build only: the 128-VGPR POTRF role has no registers to spare)
+    a.Du = (dflags && f.du && (f.data_flags & 4)) ? f.du : nullptr;
     a.tasks = f.d_tasks; a.chain_tasks = f.d_tasks + f.bulk.size(); a.n_bulk = (unsigned)f.bulk.size(); a.n_chain = (unsigned)f.chain.size();
     a.potrf_tasks = f.d_tasks + f.bulk.size() + f.chain.size(); a.n_potrf = (unsigned)f.potrf.size();
     a.n_chain_wgs = (unsigned)f.chain_wgs; a.sync = f.d_sync; a.nflags = (unsigned)f.sched.nflags; a.info = d_info;
