@@ -338,6 +338,9 @@ __device__ __forceinline__ void flow_tile32_impl(FlowKWords ka, const FlowArgs* 
 #pragma unroll
                     for (int q = 0; q < 8; ++q) if (16 * q < K0) pend |= __builtin_bit_cast(unsigned long long, pv[q][0]) == FLOW_PENDING || __builtin_bit_cast(unsigned long long, pv[q][1]) == FLOW_PENDING;
                     if (!__any(pend)) break;
+            if (V == 4) __builtin_amdgcn_s_sleep(12);
+                if (V == 4) __builtin_amdgcn_s_sleep(12);
+                    if (V == 4) __builtin_amdgcn_s_sleep(12);      // (throughput build: the CU is shared with a bulk workgroup, and sixteen workgroups re-loading 32 KB each without a pause are 0.5 TB/s)
                     if ((++spins & 63u) == 0u) {
                         const long long now = wall_clock64();
                         if (t_begin == 0) t_begin = now;
@@ -363,6 +366,8 @@ __device__ __forceinline__ void flow_tile32_impl(FlowKWords ka, const FlowArgs* 
 #pragma unroll
                 for (int q = 0; q < 8; ++q) pend |= __builtin_bit_cast(unsigned long long, pv[q][0]) == FLOW_PENDING || __builtin_bit_cast(unsigned long long, pv[q][1]) == FLOW_PENDING;
                 if (!__any(pend)) break;
+            if (V == 4) __builtin_amdgcn_s_sleep(12);
+                if (V == 4) __builtin_amdgcn_s_sleep(12);
                 if ((++spins & 63u) == 0u) {
                     const long long now = wall_clock64();
                     if (t_begin == 0) t_begin = now;
@@ -621,6 +626,7 @@ __device__ __forceinline__ void flow_potrf_part(FlowKWords ka, const FlowArgs* a
                 for (int m = 0; m < 5; ++m) pend |= __builtin_bit_cast(unsigned long long, t[m][q]) == FLOW_PENDING;
             }
             if (!__any(pend)) break;
+            if (V == 4) __builtin_amdgcn_s_sleep(12);
             if ((++spins & 63u) == 0u) {
                 const long long now = wall_clock64();
                 if (t_begin == 0) t_begin = now;
