@@ -1602,7 +1602,7 @@ inline int flow_prepare(FlowWorkspace& f, int nblk, const std::vector<int>& env_
     f.chain_shared = (f.sched.upd_tiles + f.sched.trsm_tiles) >= 600.0 * nblk;
     if (const char* e = getenv("BSFM_FLOW_CHAIN_SHARED")) f.chain_shared = atoi(e) != 0;
     {
-        int lat_tiles = 38;
+        int lat_tiles = 48;      // (round 6: 38 -> 48 once the chain handed its data over by data: n = 5 400 (43 columns) 2.27 -> 2.24 ms, 6 000 (47) 2.69 -> 2.67, 7 000 (55) 3.46 against 3.58)
         if (const char* e = getenv("BSFM_FLOW_LATENCY_TILES")) lat_tiles = atoi(e);
         f.latency_build = nblk <= lat_tiles;
     }
